@@ -1,0 +1,314 @@
+#include "binfile.h"
+#include <string.h>
+#include <stdexcept>
+#include "bitio.h"
+
+namespace fs {
+
+namespace {
+
+struct FileHeader { uint64_t footerOffset, recordsCount, blockCount, footerSize; uint8_t usesHeaderStream; uint8_t reserved[7]; };
+static_assert(sizeof(FileHeader) == 40, "BinFileHeader::HeaderSize");
+
+FILE* openOrThrow(const std::string& name)
+{
+    FILE* f = fopen(name.c_str(), "rb");
+    if (!f) throw std::runtime_error("Cannot open file: " + name);
+    return f;
+}
+uint64_t fileSize(FILE* f) { fseeko(f, 0, SEEK_END); uint64_t n = (uint64_t)ftello(f); fseeko(f, 0, SEEK_SET); return n; }
+
+uint32_t bitLength(uint64_t x) { for (uint32_t i = 0; i < 32; ++i) if (x < (1ull << i)) return i; return 64; }
+const uint32_t kBitsPerClass[4] = {4, 8, 16, 30};
+const uint8_t kIdxToQua8[8] = {0, 6, 15, 22, 27, 33, 37, 40};
+
+struct Settings {
+    bool hasConstLen = false, hasReadGroups = false, usesHeaders = false;
+    uint32_t minLen = (uint32_t)-1, maxLen = 0, suffixLen = 0, bitsPerLen = 0, signatureId = 0;
+    char signature[32];
+};
+
+void generateMinimizer(const MinimizerParametersRaw& mp, uint32_t id, char* buf)
+{
+    const uint32_t total = 1u << (2 * mp.signatureLen);
+    if (id == total) { for (int i = 0; i < mp.signatureLen; ++i) buf[i] = 'N'; return; }
+    for (int i = mp.signatureLen - 1; i >= 0; --i) { buf[i] = mp.dnaSymbolOrder[id & 3]; id >>= 2; }
+}
+
+struct Unpacker {
+    const BinModuleConfigRaw& cfg;
+    Batch& b;
+    BitReader meta, dna, qua, head;
+    bool pe;
+    Settings pairSettings;
+
+    Unpacker(const BinModuleConfigRaw& c, Batch& batch, const std::vector<uint8_t>& m, uint64_t ms, const std::vector<uint8_t>& d, uint64_t ds,
+             const std::vector<uint8_t>& q, uint64_t qs, const std::vector<uint8_t>& h, uint64_t hs)
+        : cfg(c), b(batch), meta(m.data(), ms), dna(d.data(), ds), qua(q.data(), qs), head(h.data(), hs), pe(c.archiveType.readType == READ_PE)
+    {
+        pairSettings.minLen = pairSettings.maxLen = 1; pairSettings.hasConstLen = true; pairSettings.usesHeaders = false;
+    }
+
+    void readDna(uint8_t* seq, uint32_t seqLen, uint32_t minimPos, uint32_t suffixLen)
+    {
+        const bool plain = meta.getBit() != 0;
+        const char* idxToDna = cfg.minimizer.dnaSymbolOrder;
+        if (plain) {
+            for (uint32_t i = 0; i < minimPos; ++i) seq[i] = (uint8_t)idxToDna[dna.get2Bits()];
+            for (uint32_t i = minimPos + suffixLen; i < seqLen; ++i) seq[i] = (uint8_t)idxToDna[dna.get2Bits()];
+        } else {
+            for (uint32_t i = 0; i < minimPos; ++i) seq[i] = (uint8_t)idxToDna[dna.getBits(3) & 7];
+            for (uint32_t i = minimPos + suffixLen; i < seqLen; ++i) seq[i] = (uint8_t)idxToDna[dna.getBits(3) & 7];
+        }
+    }
+    void readQuality(uint8_t* q, uint32_t n)
+    {
+        const uint32_t off = cfg.archiveType.qualityOffset;
+        switch (cfg.quaParams.method) {
+        case MET_BINARY: for (uint32_t i = 0; i < n; ++i) q[i] = (uint8_t)(off + (qua.getBit() ? 40 : 6)); break;
+        case MET_8BIN: for (uint32_t i = 0; i < n; ++i) q[i] = (uint8_t)(off + kIdxToQua8[qua.getBits(3)]); break;
+        default: for (uint32_t i = 0; i < n; ++i) q[i] = (uint8_t)(qua.getBits(6) + off); break;
+        }
+    }
+    void readHeader(Rec& r)
+    {
+        r.headLen = (uint8_t)head.getBits(8);
+        r.headOff = (uint32_t)b.head.size();
+        b.head.resize(b.head.size() + r.headLen);
+        uint8_t* h = b.head.data() + r.headOff;
+        if (r.headLen) h[0] = '@';
+        for (uint32_t i = 1; i < r.headLen; ++i) h[i] = (uint8_t)head.getBits(7);
+    }
+    // IFastqPacker::ReadNextRecord on the bytes [seq, seq+len): returns false when the dna stream is exhausted
+    bool readNextRecord(const Settings& s, Rec& r, uint32_t seqOff, uint32_t len, bool isMate2)
+    {
+        if (dna.position() >= dna.size()) return false;
+        uint32_t minimPos = 0;
+        if (s.suffixLen != 0) {
+            const bool rev = meta.getBit() != 0;
+            if (rev) r.flags |= FLAG_REVERSE; else r.flags &= ~FLAG_REVERSE;
+            r.minimPos = (uint16_t)meta.getBits(8);
+            minimPos = r.minimPos;
+        } else if (!isMate2) { r.flags &= ~FLAG_REVERSE; r.minimPos = 0; }
+        readDna(b.seq.data() + seqOff, len, minimPos, s.suffixLen);
+        readQuality(b.qua.data() + seqOff, len);
+        if (s.usesHeaders) readHeader(r);
+        return true;
+    }
+    uint32_t allocSeq(uint32_t n)
+    {
+        const uint64_t off = b.seq.size();
+        if (off + n > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB of bases");
+        b.seq.resize(off + n); b.qua.resize(off + n);
+        return (uint32_t)off;
+    }
+    void readRecordData(const Settings& s, Rec& r)
+    {
+        r.flags = 0; r.minimPos = 0; r.headLen = 0; r.headOff = (uint32_t)b.head.size();
+        if (s.hasConstLen) { r.seqLen = (uint16_t)s.minLen; r.auxLen = pe ? r.seqLen : 0; }
+        else {
+            r.seqLen = (uint16_t)(meta.getBits(s.bitsPerLen) + s.minLen);
+            r.auxLen = pe ? (uint16_t)(meta.getBits(s.bitsPerLen) + s.minLen) : 0;
+        }
+        if (pe && s.suffixLen) { if (meta.getBit()) r.flags |= FLAG_SWAPPED; }
+        r.seqOff = allocSeq((uint32_t)r.seqLen + r.auxLen);
+        readNextRecord(s, r, r.seqOff, r.seqLen, false);
+        if (s.suffixLen > 0) memcpy(b.seq.data() + r.seqOff + r.minimPos, s.signature, cfg.minimizer.signatureLen);
+        if (pe) readNextRecord(pairSettings, r, r.seqOff + r.seqLen, r.auxLen, true);
+    }
+    void readExactMatch(const Settings& s, const Rec& mainRec, Rec& r)
+    {
+        r.flags = 0; r.headLen = 0; r.headOff = (uint32_t)b.head.size();
+        if (meta.getBit()) r.flags |= FLAG_REVERSE;
+        if (pe && meta.getBit()) r.flags |= FLAG_SWAPPED;
+        r.seqLen = mainRec.seqLen; r.auxLen = pe ? mainRec.auxLen : 0;
+        r.seqOff = allocSeq((uint32_t)r.seqLen + r.auxLen);
+        memcpy(b.seq.data() + r.seqOff, b.seq.data() + mainRec.seqOff, mainRec.seqLen);
+        r.minimPos = mainRec.minimPos;
+        readQuality(b.qua.data() + r.seqOff, r.seqLen);
+        if (cfg.archiveType.readsHaveHeaders) readHeader(r);
+        if (pe) readNextRecord(pairSettings, r, r.seqOff + r.seqLen, r.auxLen, true);
+    }
+    // IFastqNodesPacker::ReadNextNode -- node slot `nodeIdx` must already exist
+    void readNextNode(uint32_t nodeIdx, const Settings& s, uint32_t& recIdx)
+    {
+        const uint32_t mainRec = recIdx++;
+        readRecordData(s, b.recs[mainRec]);
+        b.nodes[nodeIdx].rec = mainRec;
+        if (!s.hasReadGroups) return;
+        const bool hasEm = meta.getBit() != 0;
+        const bool hasTrees = meta.getBit() != 0;
+        if (hasEm) {
+            const uint32_t groupSize = meta.getBits(kBitsPerClass[meta.get2Bits()]);
+            b.nodes[nodeIdx].emBegin = (uint32_t)b.emRecs.size();
+            b.nodes[nodeIdx].emCount = groupSize;
+            b.emRecs.resize(b.emRecs.size() + groupSize);
+            for (uint32_t i = 0; i < groupSize; ++i) {
+                const uint32_t em = recIdx++;
+                readExactMatch(s, b.recs[mainRec], b.recs[em]);
+                b.emRecs[b.nodes[nodeIdx].emBegin + i] = em;
+            }
+        }
+        if (hasTrees) {
+            const uint32_t tCount = meta.getBits(kBitsPerClass[meta.get2Bits()]);
+            const uint32_t treeBegin = (uint32_t)b.trees.size();
+            b.nodes[nodeIdx].treeBegin = treeBegin; b.nodes[nodeIdx].treeCount = tCount;
+            b.trees.resize(b.trees.size() + tCount);
+            for (uint32_t t = 0; t < tCount; ++t) {
+                TreeIn tr;
+                tr.signatureId = meta.getBits(cfg.minimizer.signatureLen * 2);
+                tr.mainSignaturePos = (int32_t)meta.getBits(8);
+                const uint32_t groupSize = meta.getBits(kBitsPerClass[meta.get2Bits()]);
+                tr.nodeBegin = (uint32_t)b.nodes.size(); tr.nodeCount = groupSize;
+                b.nodes.resize(b.nodes.size() + groupSize, NodeIn{0, 0, 0, 0, 0});
+                b.trees[treeBegin + t] = tr;
+                Settings cs = s;
+                cs.signatureId = tr.signatureId; cs.suffixLen = cfg.minimizer.signatureLen;
+                generateMinimizer(cfg.minimizer, cs.signatureId, cs.signature);
+                for (uint32_t i = 0; i < groupSize; ++i) readNextNode(tr.nodeBegin + i, cs, recIdx);
+            }
+        }
+    }
+};
+
+}  // namespace
+
+BinFile::~BinFile() { close(); }
+
+void BinFile::close()
+{
+    for (FILE** f : {&meta_, &dna_, &qua_, &headf_}) if (*f) { fclose(*f); *f = nullptr; }
+}
+
+void BinFile::readAt(FILE* f, uint64_t off, void* dst, uint64_t n, const char* what)
+{
+    if (n == 0) return;
+    if (fseeko(f, (off_t)off, SEEK_SET) != 0 || fread(dst, 1, n, f) != n) throw std::runtime_error(std::string("Cannot read ") + what);
+}
+
+void BinFile::open(const std::string& prefix, uint32_t minBinSize)
+{
+    close();
+    meta_ = openOrThrow(prefix + ".bmeta");
+    const uint64_t metaSize = fileSize(meta_);
+    if (metaSize == 0) throw std::runtime_error("Empty file.");
+    dna_ = openOrThrow(prefix + ".bdna");
+    qua_ = openOrThrow(prefix + ".bqua");
+    FileHeader fh; memset(&fh, 0, sizeof fh);
+    readAt(meta_, 0, &fh, sizeof fh, "bin header");
+    if (fh.blockCount == 0 || fh.footerOffset + fh.footerSize > metaSize) throw std::runtime_error("Corrupted archive header");
+    usesHeaderStream_ = fh.usesHeaderStream != 0;
+    if (usesHeaderStream_) headf_ = openOrThrow(prefix + ".bhead");
+    std::vector<uint8_t> footer(fh.footerSize);
+    readAt(meta_, fh.footerOffset, footer.data(), fh.footerSize, "bin footer");
+    readFooter(footer);
+    // BinFileExtractor::StartDecompress: split signatures (N bin excluded) by record count
+    std_.clear(); small_.clear();
+    const uint32_t nSig = nSignature();
+    for (const auto& kv : bins_) {
+        if (kv.first == nSig) continue;
+        if (kv.second.totalRecordsCount >= minBinSize) std_.push_back(kv.first); else small_.push_back(kv.first);
+    }
+}
+
+void BinFile::readFooter(const std::vector<uint8_t>& buf)
+{
+    BitReader r(buf.data(), buf.size());
+    r.getBytes(&cfg_, sizeof cfg_);
+    const uint32_t total = (1u << (2 * cfg_.minimizer.signatureLen)) + 1;
+    std::vector<bool> bitmap(total);
+    for (uint32_t i = 0; i < total; ++i) bitmap[i] = r.getBit() != 0;
+    r.flushWord();
+    bins_.clear();
+    for (uint32_t i = 0; i < total; ++i) {
+        if (!bitmap[i]) continue;
+        BinInfo& bi = bins_[i];
+        bi.totalMetaSize = r.get8Bytes(); bi.totalDnaSize = r.get8Bytes(); bi.totalQuaSize = r.get8Bytes();
+        bi.totalRawDnaSize = r.get8Bytes(); bi.totalRecordsCount = r.get8Bytes();
+        if (usesHeaderStream_) { bi.totalHeadSize = r.get8Bytes(); bi.totalRawHeadSize = r.get8Bytes(); }
+        const uint64_t n = r.get8Bytes();
+        bi.blocks.resize(n);
+        r.getBytes(bi.blocks.data(), n * sizeof(BlockMetaDataRaw));
+    }
+    qvzBytes_.clear();
+    if (cfg_.quaParams.method == MET_QVZ)
+        throw std::runtime_error("QVZ (--lossy) archives are not supported by this build yet");
+    head_ = HeaderStats();
+    if (usesHeaderStream_) {
+        const uint32_t fields = r.getByte();
+        head_.fields.resize(fields);
+        for (HeaderField& f : head_.fields) {
+            f.isNumeric = r.getByte() != 0;
+            f.isConst = r.getByte() != 0;
+            f.separator = (char)r.getByte();
+            if (f.isNumeric) {
+                f.minValue = r.get8Bytes();
+                if (!f.isConst) f.maxValue = r.get8Bytes();
+            } else {
+                uint32_t possible = 1;
+                if (!f.isConst) possible = r.get2Bytes();
+                std::set<std::string> vals;
+                for (uint32_t i = 0; i < possible; ++i) {
+                    const uint32_t ss = r.getByte();
+                    std::string s(ss, '\0');
+                    r.getBytes(&s[0], ss);
+                    vals.insert(s);
+                }
+                f.possibleValues.assign(vals.begin(), vals.end());
+            }
+        }
+        if (cfg_.archiveType.readType == READ_PE) head_.pairedEndFieldIdx = r.getByte();
+    }
+}
+
+void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin)
+{
+    const auto it = bins_.find(signature);
+    if (it == bins_.end()) throw std::runtime_error("signature not present in bin file");
+    const BinInfo& bi = it->second;
+    // BinFileReader::ReadBlock: gather the signature's slices from the four streams
+    bMeta_.resize(bi.totalMetaSize); bDna_.resize(bi.totalDnaSize); bQua_.resize(bi.totalQuaSize);
+    bHead_.resize(usesHeaderStream_ ? bi.totalHeadSize : 0);
+    uint64_t mo = 0, dO = 0, qo = 0, ho = 0, rawDna = 0, records = 0;
+    for (const BlockMetaDataRaw& blk : bi.blocks) {
+        readAt(meta_, blk.metaFileOffset, bMeta_.data() + mo, blk.metaSize, ".bmeta"); mo += blk.metaSize;
+        readAt(dna_, blk.dnaFileOffset, bDna_.data() + dO, blk.dnaSize, ".bdna"); dO += blk.dnaSize;
+        readAt(qua_, blk.quaFileOffset, bQua_.data() + qo, blk.quaSize, ".bqua"); qo += blk.quaSize;
+        if (usesHeaderStream_) { readAt(headf_, blk.headFileOffset, bHead_.data() + ho, blk.headSize, ".bhead"); ho += blk.headSize; }
+        rawDna += blk.rawDnaSize; records += blk.recordsCount;
+    }
+    if (asNewBin || batch.bins.empty()) {
+        BinIn nb{}; nb.signature = signature; nb.recBegin = (uint32_t)batch.recs.size(); nb.topBegin = (uint32_t)batch.topNodes.size();
+        batch.bins.push_back(nb);
+    }
+    BinIn& bin = batch.bins.back();
+    bin.rawDnaSize += rawDna;
+    uint32_t recIdx = (uint32_t)batch.recs.size();
+    batch.recs.resize(batch.recs.size() + records, Rec{});
+    batch.seq.reserve(batch.seq.size() + rawDna); batch.qua.reserve(batch.qua.size() + rawDna);
+
+    Unpacker u(cfg_, batch, bMeta_, mo, bDna_, dO, bQua_, qo, bHead_, ho);
+    Settings s;
+    s.signatureId = signature;
+    if (signature != nSignature()) { s.suffixLen = cfg_.minimizer.signatureLen; generateMinimizer(cfg_.minimizer, signature, s.signature); }
+    s.usesHeaders = cfg_.archiveType.readsHaveHeaders != 0;
+    for (const BlockMetaDataRaw& blk : bi.blocks) {
+        s.minLen = u.meta.getBits(8); s.maxLen = u.meta.getBits(8);
+        s.hasReadGroups = u.meta.getBit() != 0;
+        s.hasConstLen = (s.minLen == s.maxLen);
+        if (!s.hasConstLen) s.bitsPerLen = bitLength(s.maxLen - s.minLen);
+        const uint32_t end = recIdx + (uint32_t)blk.recordsCount;
+        while (recIdx < end) {
+            const uint32_t nodeIdx = (uint32_t)batch.nodes.size();
+            batch.nodes.push_back(NodeIn{0, 0, 0, 0, 0});
+            batch.topNodes.push_back(nodeIdx);
+            u.readNextNode(nodeIdx, s, recIdx);
+        }
+        u.meta.flushWord(); u.dna.flushWord(); u.qua.flushWord(); u.head.flushWord();
+    }
+    bin.minLen = s.minLen; bin.maxLen = s.maxLen;     // the reference keeps the last slice's values (NodesPacker.cpp:560-563)
+    bin.recCount = (uint32_t)batch.recs.size() - bin.recBegin;
+    bin.topCount = (uint32_t)batch.topNodes.size() - bin.topBegin;
+}
+
+}  // namespace fs

@@ -1,0 +1,51 @@
+// Reader for the bin/rebin -> pack hand-off files and the record/graph unpacker (drop-in boundary,
+// SURVEY §8b "Input").  Restates, with flat SoA output:
+//   BinFileReader::StartDecompress/ReadFileFooter/ReadBlock   fastore_bin/BinFile.cpp:470-813
+//   BinFileExtractor (std / small / N split)                   fastore_pack/BinFileExtractor.cpp:21-103
+//   IFastqNodesPacker::UnpackFromBin / ReadNextNode            fastore_rebin/NodesPacker.cpp:416-679
+//   FastqNodesPackerSE/PE::ReadRecordData / ReadExactMatch     fastore_rebin/NodesPacker.cpp:705-979
+//   IFastqPacker::ReadNextRecord / ReadDna / ReadQuality / ReadHeader   fastore_bin/FastqPacker.cpp:62-411
+#pragma once
+#include <stdio.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "format.h"
+
+namespace fs {
+
+class BinFile {
+public:
+    ~BinFile();
+    void open(const std::string& prefix, uint32_t minBinSize);
+    void close();
+
+    const BinModuleConfigRaw& config() const { return cfg_; }
+    const HeaderStats& headData() const { return head_; }
+    const std::vector<uint8_t>& qvzFooterBytes() const { return qvzBytes_; }
+    const std::map<uint32_t, BinInfo>& bins() const { return bins_; }
+    const std::vector<uint32_t>& stdSignatures() const { return std_; }
+    const std::vector<uint32_t>& smallSignatures() const { return small_; }
+    bool hasNBin() const { return bins_.count(nSignature()) != 0; }
+    uint32_t nSignature() const { return 1u << (2 * cfg_.minimizer.signatureLen); }
+    bool usesHeaders() const { return usesHeaderStream_; }
+
+    // Unpack one signature into `batch`.  asNewBin: start a new BinIn; otherwise append the
+    // records/nodes to the last bin of the batch (block-0 merge of small bins and the N bin).
+    void unpack(uint32_t signature, Batch& batch, bool asNewBin);
+
+private:
+    void readFooter(const std::vector<uint8_t>& buf);
+    void readAt(FILE* f, uint64_t off, void* dst, uint64_t n, const char* what);
+
+    FILE *meta_ = nullptr, *dna_ = nullptr, *qua_ = nullptr, *headf_ = nullptr;
+    BinModuleConfigRaw cfg_{};
+    bool usesHeaderStream_ = false;
+    std::map<uint32_t, BinInfo> bins_;
+    HeaderStats head_;
+    std::vector<uint8_t> qvzBytes_;
+    std::vector<uint32_t> std_, small_;
+    std::vector<uint8_t> bMeta_, bDna_, bQua_, bHead_;   // scratch for one signature
+};
+
+}  // namespace fs

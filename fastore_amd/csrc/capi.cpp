@@ -1,0 +1,177 @@
+// extern "C" boundary (include/fastore_amd.h).  No exceptions cross it.
+#include <string.h>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include "../../include/fastore_amd.h"
+#include "packer.h"
+
+struct fsgpu_ctx { fs::Context c; };
+
+static thread_local std::string g_createError;
+
+#define FS_GUARD(ctx, ...)                                                               \
+    try { __VA_ARGS__; return FSGPU_OK; }                                                       \
+    catch (const std::exception& e) { (ctx)->c.err = e.what();                          \
+        return strncmp(e.what(), "device:", 7) == 0 ? FSGPU_ERR_DEVICE : (strncmp(e.what(), "Cannot", 6) == 0 ? FSGPU_ERR_IO : FSGPU_ERR_INTERNAL); } \
+    catch (...) { (ctx)->c.err = "unknown error"; return FSGPU_ERR_INTERNAL; }
+
+extern "C" {
+
+void fsgpu_config_defaults(fsgpu_config* cfg)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    fs::PackParams p;
+    cfg->min_bin_size = p.minBinSize; cfg->shift_cost = p.shiftCost; cfg->mismatch_cost = p.mismatchCost;
+    cfg->max_lz_window = p.maxLzWindowSize; cfg->max_pair_lz_window = 4096;    // MAX_LZ_PE (fastore_bin/Globals.h:62)
+    cfg->max_new_variants_per_read = p.maxNewVariantsPerRead; cfg->max_hamming_distance = p.maxHammingDistance;
+    cfg->min_consensus_size = p.minConsensusSize; cfg->world_size = 1;
+}
+
+int fsgpu_device_count(void) { return fsengine::device_count(); }
+const char* fsgpu_create_error(void) { return g_createError.c_str(); }
+
+fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
+{
+    if (!cfg) { g_createError = "null config"; return nullptr; }
+    fsgpu_ctx* ctx = new fsgpu_ctx();
+    fs::Context& c = ctx->c;
+    c.cfg = *cfg;
+    c.par.minBinSize = cfg->min_bin_size; c.par.encodeThreshold = cfg->encode_threshold; c.par.pairEncodeThreshold = cfg->pair_encode_threshold;
+    c.par.shiftCost = cfg->shift_cost; c.par.mismatchCost = cfg->mismatch_cost;
+    c.par.maxLzWindowSize = cfg->max_lz_window; c.par.maxPairLzWindowSize = cfg->max_pair_lz_window;
+    c.par.extraReduceHardReads = cfg->extra_reduce_hard_reads != 0; c.par.extraReduceExpensiveLzMatches = cfg->extra_reduce_expensive_lz != 0;
+    c.par.maxRecordShiftDifference = cfg->max_record_shift_diff; c.par.maxNewVariantsPerRead = cfg->max_new_variants_per_read;
+    c.par.maxHammingDistance = cfg->max_hamming_distance; c.par.minConsensusSize = cfg->min_consensus_size;
+    c.hostThreads = cfg->host_threads ? cfg->host_threads : std::max(1u, std::thread::hardware_concurrency());
+    if (c.par.mismatchCost <= 0 || c.par.maxLzWindowSize == 0 || c.par.maxPairLzWindowSize == 0) { g_createError = "invalid matcher parameters"; delete ctx; return nullptr; }
+    if (fsengine::device_count() <= 0) {
+        g_createError = "no HIP device available: the fastore_pack hot path has no CPU fallback";
+        delete ctx; return nullptr;
+    }
+    char err[256] = {0};
+    if (fsengine::device_create(&c.dev, cfg->device_id, cfg->max_waves, err, sizeof err) != 0) { g_createError = err; delete ctx; return nullptr; }
+    return ctx;
+}
+
+void fsgpu_destroy(fsgpu_ctx* ctx) { if (!ctx) return; fsengine::device_destroy(ctx->c.dev); delete ctx; }
+const char* fsgpu_last_error(const fsgpu_ctx* ctx) { return ctx ? ctx->c.err.c_str() : "null context"; }
+const char* fsgpu_device_name(const fsgpu_ctx* ctx) { return (ctx && ctx->c.dev) ? ctx->c.dev->name : ""; }
+
+int fsgpu_set_archive_params(fsgpu_ctx* ctx, const void* cfgRaw, size_t cfgBytes, const uint8_t* fields, size_t fieldBytes)
+{
+    if (!ctx || !cfgRaw || cfgBytes != sizeof(fs::BinModuleConfigRaw)) return FSGPU_ERR_ARG;
+    FS_GUARD(ctx, {
+        memcpy(&ctx->c.binCfg, cfgRaw, cfgBytes);
+        fs::parseHeaderFields(fields, fieldBytes, ctx->c.binCfg.archiveType.readType == fs::READ_PE, ctx->c.head);
+        if (ctx->c.binCfg.archiveType.readsHaveHeaders && ctx->c.head.fields.empty()) throw std::runtime_error("archive has read ids but no field table was given");
+        ctx->c.haveArchive = true;
+    });
+}
+
+int fsgpu_compress_bins(fsgpu_ctx* ctx, const fsgpu_bin_batch* in, fsgpu_block_batch* out)
+{
+    if (!ctx || !in || !out) return FSGPU_ERR_ARG;
+    if (!ctx->c.haveArchive) { ctx->c.err = "fsgpu_set_archive_params() has not been called"; return FSGPU_ERR_ARG; }
+    FS_GUARD(ctx, {
+        fs::Batch b;
+        b.seq.assign(in->bases, in->bases + in->n_bases); b.qua.assign(in->quals, in->quals + in->n_bases);
+        if (in->n_heads) b.head.assign(in->heads, in->heads + in->n_heads);
+        b.recs.resize(in->n_records);
+        for (size_t i = 0; i < in->n_records; ++i) {
+            const fsgpu_record& r = in->records[i];
+            if ((uint64_t)r.seq_off + r.seq_len + r.aux_len > in->n_bases || (uint64_t)r.head_off + r.head_len > in->n_heads) throw std::runtime_error("record outside the batch buffers");
+            b.recs[i] = fs::Rec{r.seq_off, r.head_off, r.seq_len, r.aux_len, r.minim_pos, r.head_len, r.flags};
+        }
+        b.nodes.resize(in->n_nodes);
+        for (size_t i = 0; i < in->n_nodes; ++i) {
+            const fsgpu_node& n = in->nodes[i];
+            if (n.rec >= in->n_records || (uint64_t)n.em_begin + n.em_count > in->n_em_records || (uint64_t)n.tree_begin + n.tree_count > in->n_trees) throw std::runtime_error("node references outside the batch");
+            b.nodes[i] = fs::NodeIn{n.rec, n.em_begin, n.em_count, n.tree_begin, n.tree_count};
+        }
+        b.topNodes.assign(in->top_nodes, in->top_nodes + in->n_top_nodes);
+        for (uint32_t t : b.topNodes) if (t >= in->n_nodes) throw std::runtime_error("top node outside the batch");
+        b.emRecs.assign(in->em_records, in->em_records + in->n_em_records);
+        for (uint32_t e : b.emRecs) if (e >= in->n_records) throw std::runtime_error("exact-match record outside the batch");
+        b.trees.resize(in->n_trees);
+        for (size_t i = 0; i < in->n_trees; ++i) {
+            const fsgpu_tree& t = in->trees[i];
+            if ((uint64_t)t.node_begin + t.node_count > in->n_nodes) throw std::runtime_error("tree nodes outside the batch");
+            b.trees[i] = fs::TreeIn{t.signature, t.main_signature_pos, t.node_begin, t.node_count};
+        }
+        b.bins.resize(in->n_bins);
+        for (size_t i = 0; i < in->n_bins; ++i) {
+            const fsgpu_bin& x = in->bins[i];
+            if ((uint64_t)x.rec_begin + x.rec_count > in->n_records || (uint64_t)x.top_begin + x.top_count > in->n_top_nodes || x.top_count == 0) throw std::runtime_error("bin ranges outside the batch");
+            fs::BinIn bi{}; bi.signature = x.signature; bi.minLen = x.min_len; bi.maxLen = x.max_len; bi.rawDnaSize = x.raw_dna_size;
+            bi.recBegin = x.rec_begin; bi.recCount = x.rec_count; bi.topBegin = x.top_begin; bi.topCount = x.top_count;
+            b.bins[i] = bi;
+        }
+        ctx->c.compressBatch(b);
+        out->data = ctx->c.blocks.data(); out->sizes = ctx->c.blockSizes.data(); out->n_blocks = ctx->c.blockSizes.size();
+    });
+}
+
+static int encodeStreams(fsgpu_ctx* ctx, size_t n, const uint32_t* kinds, const uint8_t* const* in, const size_t* inLen,
+                         uint8_t* const* out, const size_t* outCap, size_t* outLen)
+{
+    using namespace fsdev;
+    FS_GUARD(ctx, {
+        std::vector<StreamItem> items(n); uint64_t inBytes = 0;
+        for (size_t i = 0; i < n; ++i) {
+            StreamItem it; memset(&it, 0, sizeof it);
+            const bool rc = kinds[i] != KIND_PPMD;
+            const uint64_t bytes = rc ? inLen[i] * 2 : inLen[i];
+            if (bytes > 0xF0000000ull) throw std::runtime_error("stream larger than 4 GiB");
+            it.kind = kinds[i]; it.in_len = (uint32_t)inLen[i]; it.in_off = inBytes; it.bin = 0;
+            it.out_cap = rc ? 2 * it.in_len + 32 : (uint32_t)(bytes + bytes / 8 + 64);
+            items[i] = it; inBytes += (bytes + 15) & ~15ull;
+        }
+        std::vector<uint8_t> input(inBytes + 16);
+        for (size_t i = 0; i < n; ++i) { const uint64_t bytes = items[i].kind != KIND_PPMD ? 2ull * items[i].in_len : items[i].in_len; if (bytes) memcpy(input.data() + items[i].in_off, in[i], bytes); }
+        // one pseudo-bin per stream so that the assemble step hands every stream back separately
+        std::vector<fsdev::BlockPlan> plans; std::vector<uint8_t> blocks; std::vector<uint64_t> sizes;
+        std::vector<uint8_t> raw; std::vector<uint32_t> rawSizes;
+        if (fsengine::encode_streams_raw(ctx->c.dev, input.data(), inBytes, items, raw, rawSizes, &ctx->c.timing) != 0) throw std::runtime_error(std::string("device: ") + ctx->c.dev->err);
+        for (size_t i = 0; i < n; ++i) {
+            outLen[i] = rawSizes[i];
+            const size_t c = std::min<size_t>(rawSizes[i], outCap[i]);
+            if (c) memcpy(out[i], raw.data() + items[i].out_off, c);
+        }
+    });
+}
+
+int fsgpu_ppmd_encode(fsgpu_ctx* ctx, size_t n, const uint8_t* const* in, const size_t* inLen, uint8_t* const* out, const size_t* outCap, size_t* outLen)
+{
+    if (!ctx || (n && (!in || !inLen || !out || !outCap || !outLen))) return FSGPU_ERR_ARG;
+    std::vector<uint32_t> kinds(n, fsdev::KIND_PPMD);
+    return encodeStreams(ctx, n, kinds.data(), in, inLen, out, outCap, outLen);
+}
+
+int fsgpu_rc_encode(fsgpu_ctx* ctx, size_t n, const uint32_t* model, const uint8_t* const* pairs, const size_t* nPairs, uint8_t* const* out,
+                    const size_t* outCap, size_t* outLen)
+{
+    if (!ctx || (n && (!model || !pairs || !nPairs || !out || !outCap || !outLen))) return FSGPU_ERR_ARG;
+    std::vector<uint32_t> kinds(n);
+    for (size_t i = 0; i < n; ++i) { if (model[i] > 5) return FSGPU_ERR_ARG; kinds[i] = fsdev::KIND_RC_BASE + model[i]; }
+    return encodeStreams(ctx, n, kinds.data(), pairs, nPairs, out, outCap, outLen);
+}
+
+int fsgpu_pack_file(fsgpu_ctx* ctx, const char* inPrefix, const char* outPrefix, int verbose)
+{
+    if (!ctx || !inPrefix || !outPrefix) return FSGPU_ERR_ARG;
+    FS_GUARD(ctx, ctx->c.packFile(inPrefix, outPrefix, verbose != 0));
+}
+
+int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out)
+{
+    if (!ctx || !out) return FSGPU_ERR_ARG;
+    *out = ctx->c.stats;
+    out->encode_kernel_ms = ctx->c.timing.encode_ms; out->assemble_kernel_ms = ctx->c.timing.assemble_ms;
+    out->kernel_launches = ctx->c.timing.launches; out->stream_items = ctx->c.timing.items; out->ppmd_symbols = ctx->c.timing.ppmd_symbols;
+    out->rc_symbols = ctx->c.timing.rc_symbols; out->ppmd_restarts = ctx->c.timing.restarts; out->h2d_bytes = ctx->c.timing.h2d_bytes; out->d2h_bytes = ctx->c.timing.d2h_bytes;
+    return FSGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// Host-visible interface of the HIP batch engine (engine.hip).  No HIP types leak out.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <vector>
+#include "device_types.h"
+
+namespace fsengine {
+
+struct BatchTiming {
+    double encode_ms = 0, assemble_ms = 0;      // HIP-event time of the two kernels (summed over launches)
+    uint64_t launches = 0, items = 0, ppmd_symbols = 0, rc_symbols = 0, restarts = 0;
+    uint64_t h2d_bytes = 0, d2h_bytes = 0;
+};
+
+struct Device {
+    int deviceId, cus;
+    char name[64];
+    char err[256];
+    void* stream;
+    void* ev[4];
+    uint8_t* arenas; uint32_t* queueHead; uint32_t nWaves;
+    uint8_t* dIn; size_t capIn;
+    uint8_t* dScratch; size_t capScratch;
+    void* dItems; size_t capItems;
+    uint32_t* dOrder; size_t capOrder;
+    uint32_t* dSizes; size_t capSizes;
+    uint32_t* dRestarts; size_t capRestarts;
+    void* dPlans; size_t capPlans;
+    uint8_t* dBlocks; size_t capBlocks;
+};
+
+int device_count();
+int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size_t errLen);
+void device_destroy(Device* dev);
+int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,
+                       std::vector<uint8_t>& raw, std::vector<uint32_t>& sizes, BatchTiming* timing);
+int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,
+                 std::vector<fsdev::BlockPlan>& plans, std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes,
+                 BatchTiming* timing);
+
+}  // namespace fsengine

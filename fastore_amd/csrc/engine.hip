@@ -1,0 +1,279 @@
+// HIP side of the fastore_pack hot path: entropy-coding kernels + the batch engine.
+//
+// Kernels (gfx950, wave64, one 64-thread workgroup = one wavefront = one stream at a time):
+//   fs_encode_streams   work-queue kernel.  Every wave owns a private HBM arena (PPMd heap or
+//                       range-coder frequency table) and pulls stream items -- one entropy-coded
+//                       stream of one bin -- from a device counter until the queue is empty.
+//                       Items are queued longest-first by the host.  No inter-wave hand-off: the
+//                       only shared word is the queue head (returning atomicAdd).
+//   fs_assemble_blocks  one workgroup per bin: exclusive scan of the stream sizes, block header
+//                       (reference layout, big-endian), then a coalesced copy of the streams into
+//                       the compact output buffer.
+// Reference path replaced: LzCompressorSE::CompressBuffers + StoreHeader
+//   (/root/reference/fastore/fastore_pack/FastqCompressor.cpp:1055-1126, 684-699, 1199-1210) and
+//   the TEncoder<...>/PpmdEncoder calls behind them.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "device_types.h"
+#include "engine.h"
+#include "ppmd_core.h"
+#include "rc_core.h"
+
+using namespace fsdev;
+
+namespace {
+
+constexpr uint64_t kArenaStride = (32ull << 20) + (64ull << 10);   // 32 MiB table / 16 MiB heap + guard
+
+__global__ __launch_bounds__(64) void fs_encode_streams(const StreamItem* __restrict__ items, const uint32_t* __restrict__ order,
+                                                        uint32_t nItems, const uint8_t* in, uint8_t* out, uint32_t* outSizes,
+                                                        uint32_t* restarts, uint8_t* arenas, uint32_t* queueHead)
+{
+    __shared__ fsppmd::Shared sh;
+    uint8_t* arena = arenas + (uint64_t)blockIdx.x * kArenaStride;
+    for (;;) {
+        uint32_t q = 0;
+        if (threadIdx.x == 0) q = atomicAdd(queueHead, 1u);
+        q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+        if (q >= nItems) break;                       // every wave reaches this exit: the queue is finite
+        const uint32_t it = order[q];
+        const StreamItem item = items[it];
+        const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.kind);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.in_len);
+        const uint32_t cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.out_cap);
+        const uint8_t* src = in + item.in_off;
+        uint8_t* dst = out + item.out_off;
+        uint32_t size = 0, rs = 0;
+        if (kind == KIND_PPMD) {
+            if (n > 0) size = fsppmd::encode_member(arena, &sh, src, n, dst, cap, &rs);
+        } else {
+            size = fsrc::encode_model(kind - KIND_RC_BASE, arena, src, n, dst, cap);
+        }
+        if (threadIdx.x == 0) { outSizes[it] = size; restarts[it] = rs; }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void put_be(uint8_t* p, uint64_t v, int nbytes)
+{ for (int i = 0; i < nbytes; ++i) p[i] = (uint8_t)(v >> (8 * (nbytes - 1 - i))); }
+
+__global__ __launch_bounds__(256) void fs_assemble_blocks(const BlockPlan* __restrict__ plans, const StreamItem* __restrict__ items,
+                                                          const uint32_t* __restrict__ sizes, const uint8_t* __restrict__ scratch,
+                                                          uint8_t* blocks)
+{
+    const BlockPlan& pl = plans[blockIdx.x];
+    const uint32_t N = pl.n_streams;
+    __shared__ uint64_t dstOff[MAX_STREAMS];
+    __shared__ uint64_t payloadEnd;
+    uint8_t* blk = blocks + pl.block_off;
+    const uint64_t headerSize = 42ull + 16ull * N;
+    if (threadIdx.x == 0) {
+        uint64_t pos = headerSize;
+        for (uint32_t k = 0; k < N; ++k) { const uint32_t s = pl.copy_order[k]; dstOff[s] = pos; pos += sizes[pl.first_item + s]; }
+        payloadEnd = pos;
+        // StoreRawHeader + work sizes + comp sizes (FastqCompressor.cpp:56-69, 684-699)
+        uint8_t* h = blk;
+        put_be(h, pl.signature, 4); h += 4;
+        put_be(h, pl.records, 8); h += 8;
+        *h++ = pl.min_len; *h++ = pl.max_len;
+        put_be(h, pl.raw_dna_size, 8); h += 8;
+        put_be(h, pos, 8); h += 8;                    // footerOffset
+        put_be(h, 1, 4); h += 4;                      // footerSize
+        if (pl.has_headers) { put_be(h, pl.raw_id_size, 8); h += 8; }
+        for (uint32_t s = 0; s < N; ++s) { put_be(h, pl.work_size[s] == ~0ull ? (uint64_t)sizes[pl.first_item + s] : pl.work_size[s], 8); h += 8; }  // range-coded streams: work size == coded size
+        for (uint32_t s = 0; s < N; ++s) { put_be(h, sizes[pl.first_item + s], 8); h += 8; }
+        while (h < blk + headerSize) *h++ = 0;        // the 8-byte hole of header-less archives: defined as zero here
+        blk[pos] = 0;                                 // footer: sampleValue
+    }
+    __syncthreads();
+    for (uint32_t s = 0; s < N; ++s) {
+        const uint32_t n = sizes[pl.first_item + s];
+        const uint8_t* src = scratch + items[pl.first_item + s].out_off;
+        uint8_t* dst = blk + dstOff[s];
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(dev->err, sizeof dev->err, "%s failed: %s", #x, hipGetErrorString(e_)); return -1; } } while (0)
+
+template <class T> int ensure(fsengine::Device* dev, T*& p, size_t& capBytes, size_t needBytes)
+{
+    if (needBytes <= capBytes && p) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; capBytes = 0;
+    size_t want = needBytes + needBytes / 4 + 4096;
+    HIP_TRY(hipMalloc((void**)&p, want));
+    capBytes = want;
+    return 0;
+}
+
+}  // namespace
+
+namespace fsengine {
+
+int device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size_t errLen)
+{
+    Device* dev = new Device();
+    memset(dev, 0, sizeof *dev);
+    *out = dev;
+    auto fail = [&](const char* what, hipError_t e) {
+        snprintf(err, errLen, "%s: %s", what, hipGetErrorString(e));
+        delete dev; *out = nullptr; return -1;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(deviceId)) != hipSuccess) return fail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, deviceId)) != hipSuccess) return fail("hipGetDeviceProperties", e);
+    dev->deviceId = deviceId;
+    dev->cus = prop.multiProcessorCount;
+    snprintf(dev->name, sizeof dev->name, "%s", prop.gcnArchName);
+    if ((e = hipStreamCreate((hipStream_t*)&dev->stream)) != hipSuccess) return fail("hipStreamCreate", e);
+    size_t freeB = 0, totalB = 0;
+    if ((e = hipMemGetInfo(&freeB, &totalB)) != hipSuccess) return fail("hipMemGetInfo", e);
+    // resident waves: 16 per CU when memory allows (one private arena each), never more than half of HBM
+    uint32_t waves = maxWaves ? maxWaves : (uint32_t)dev->cus * 16u;
+    const uint64_t budget = freeB / 2;
+    if ((uint64_t)waves * kArenaStride > budget) waves = (uint32_t)(budget / kArenaStride);
+    if (waves == 0) { snprintf(err, errLen, "not enough device memory for one coder arena"); delete dev; *out = nullptr; return -1; }
+    dev->nWaves = waves;
+    if ((e = hipMalloc((void**)&dev->arenas, (uint64_t)waves * kArenaStride)) != hipSuccess) return fail("hipMalloc(arenas)", e);
+    if ((e = hipMalloc((void**)&dev->queueHead, 64)) != hipSuccess) return fail("hipMalloc(queue)", e);
+    if ((e = hipEventCreate((hipEvent_t*)&dev->ev[0])) != hipSuccess) return fail("hipEventCreate", e);
+    for (int i = 1; i < 4; ++i) (void)hipEventCreate((hipEvent_t*)&dev->ev[i]);
+    return 0;
+}
+
+void device_destroy(Device* dev)
+{
+    if (!dev) return;
+    (void)hipSetDevice(dev->deviceId);
+    void* ptrs[] = {dev->arenas, dev->queueHead, dev->dIn, dev->dScratch, dev->dItems, dev->dOrder, dev->dSizes, dev->dRestarts, dev->dPlans, dev->dBlocks};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int i = 0; i < 4; ++i) if (dev->ev[i]) (void)hipEventDestroy((hipEvent_t)dev->ev[i]);
+    if (dev->stream) (void)hipStreamDestroy((hipStream_t)dev->stream);
+    delete dev;
+}
+
+// H2D + fs_encode_streams + D2H of the per-stream sizes.  Leaves the coded streams in dev->dScratch.
+static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items,
+                      std::vector<uint32_t>& sizes, uint64_t& scratchBytes, BatchTiming* timing)
+{
+    HIP_TRY(hipSetDevice(dev->deviceId));
+    hipStream_t st = (hipStream_t)dev->stream;
+    const uint32_t nItems = (uint32_t)items.size();
+    uint64_t scratch = 0;
+    for (auto& it : items) { it.out_off = scratch; scratch += ((uint64_t)it.out_cap + 15u) & ~15ull; }
+    scratchBytes = scratch;
+    // longest-first queue order (a PPMd symbol costs roughly 10x a range-coder symbol)
+    std::vector<uint32_t> order(nItems);
+    for (uint32_t i = 0; i < nItems; ++i) order[i] = i;
+    auto cost = [&](uint32_t i) -> uint64_t {
+        const StreamItem& s = items[i];
+        if (s.kind == KIND_PPMD) return (uint64_t)s.in_len * 10u + 2000u;
+        const uint64_t tbl = fsrc::model_table_bytes(s.kind - KIND_RC_BASE);
+        return (uint64_t)s.in_len * 2u + tbl / 512u + 100u;
+    };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
+
+    if (ensure(dev, dev->dIn, dev->capIn, inputBytes + 16)) return -1;
+    if (ensure(dev, dev->dScratch, dev->capScratch, scratch + 16)) return -1;
+    if (ensure(dev, dev->dItems, dev->capItems, sizeof(StreamItem) * nItems)) return -1;
+    if (ensure(dev, dev->dOrder, dev->capOrder, 4ull * nItems)) return -1;
+    if (ensure(dev, dev->dSizes, dev->capSizes, 4ull * nItems)) return -1;
+    if (ensure(dev, dev->dRestarts, dev->capRestarts, 4ull * nItems)) return -1;
+
+    HIP_TRY(hipMemcpyAsync(dev->dIn, input, inputBytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dev->dItems, items.data(), sizeof(StreamItem) * nItems, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dev->dOrder, order.data(), 4ull * nItems, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(dev->queueHead, 0, 64, st));
+    const uint32_t grid = std::min(nItems, dev->nWaves);
+    HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[0], st));
+    hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, (const StreamItem*)dev->dItems, (const uint32_t*)dev->dOrder,
+                       nItems, (const uint8_t*)dev->dIn, (uint8_t*)dev->dScratch, (uint32_t*)dev->dSizes, (uint32_t*)dev->dRestarts,
+                       (uint8_t*)dev->arenas, (uint32_t*)dev->queueHead);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));
+    sizes.resize(nItems);
+    std::vector<uint32_t> restarts(nItems);
+    HIP_TRY(hipMemcpyAsync(sizes.data(), dev->dSizes, 4ull * nItems, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(restarts.data(), dev->dRestarts, 4ull * nItems, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (timing) {
+        float a = 0;
+        (void)hipEventElapsedTime(&a, (hipEvent_t)dev->ev[0], (hipEvent_t)dev->ev[1]);
+        timing->encode_ms += a; timing->launches += 1; timing->items += nItems; timing->h2d_bytes += inputBytes;
+        for (uint32_t i = 0; i < nItems; ++i) { timing->restarts += restarts[i]; if (items[i].kind == KIND_PPMD) timing->ppmd_symbols += items[i].in_len; else timing->rc_symbols += items[i].in_len; }
+    }
+    return 0;
+}
+
+// Entropy-code independent streams and hand the raw coded bytes back (layout: items[i].out_off).
+int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items,
+                       std::vector<uint8_t>& raw, std::vector<uint32_t>& sizes, BatchTiming* timing)
+{
+    raw.clear(); sizes.clear();
+    if (items.empty()) return 0;
+    uint64_t scratch = 0;
+    if (run_encode(dev, input, inputBytes, items, sizes, scratch, timing)) return -1;
+    raw.resize(scratch);
+    HIP_TRY(hipMemcpy(raw.data(), dev->dScratch, scratch, hipMemcpyDeviceToHost));
+    if (timing) timing->d2h_bytes += scratch;
+    return 0;
+}
+
+// Entropy-code a batch of bins and assemble their blocks: `input` holds every stream's pre-entropy
+// bytes / (symbol, ctx) pairs.
+int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items,
+                 std::vector<BlockPlan>& plans, std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes,
+                 BatchTiming* timing)
+{
+    const uint32_t nItems = (uint32_t)items.size(), nBins = (uint32_t)plans.size();
+    blocks.clear(); blockSizes.assign(nBins, 0);
+    if (nItems == 0) return 0;
+    std::vector<uint32_t> sizes; uint64_t scratch = 0;
+    if (run_encode(dev, input, inputBytes, items, sizes, scratch, timing)) return -1;
+    hipStream_t st = (hipStream_t)dev->stream;
+    if (ensure(dev, dev->dPlans, dev->capPlans, sizeof(BlockPlan) * nBins)) return -1;
+    // a stream that filled its scratch slot was clipped: refuse rather than emit a corrupt block
+    for (uint32_t i = 0; i < nItems; ++i)
+        if (sizes[i] >= items[i].out_cap && items[i].in_len > 0) {
+            snprintf(dev->err, sizeof dev->err, "stream item %u overflowed its output slot (%u >= %u)", i, sizes[i], items[i].out_cap);
+            return -2;
+        }
+    uint64_t total = 0;
+    for (uint32_t b = 0; b < nBins; ++b) {
+        BlockPlan& pl = plans[b];
+        uint64_t sz = 42ull + 16ull * pl.n_streams + 1ull;
+        for (uint32_t s = 0; s < pl.n_streams; ++s) sz += sizes[pl.first_item + s];
+        pl.block_off = total; blockSizes[b] = sz; total += sz;
+    }
+    if (ensure(dev, dev->dBlocks, dev->capBlocks, total + 16)) return -1;
+    HIP_TRY(hipMemcpyAsync(dev->dPlans, plans.data(), sizeof(BlockPlan) * nBins, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[2], st));
+    hipLaunchKernelGGL(fs_assemble_blocks, dim3(nBins), dim3(256), 0, st, (const BlockPlan*)dev->dPlans, (const StreamItem*)dev->dItems,
+                       (const uint32_t*)dev->dSizes, (const uint8_t*)dev->dScratch, (uint8_t*)dev->dBlocks);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[3], st));
+    blocks.resize(total);
+    HIP_TRY(hipMemcpyAsync(blocks.data(), dev->dBlocks, total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (timing) {
+        float b = 0;
+        (void)hipEventElapsedTime(&b, (hipEvent_t)dev->ev[2], (hipEvent_t)dev->ev[3]);
+        timing->assemble_ms += b; timing->d2h_bytes += total;
+    }
+    return 0;
+}
+
+}  // namespace fsengine

@@ -1,0 +1,101 @@
+// On-disk structures of the bin/rebin -> pack hand-off (.bmeta/.bdna/.bqua/.bhead) and of the
+// archive (.cmeta/.cdata), plus the in-memory batch layout handed to the hot path.
+//
+// The reference serialises several structs raw (x86-64 SysV layout); the mirrors below have the
+// same field order and types so that sizeof/offsetof agree:
+//   BinModuleConfig     /root/reference/fastore/fastore_bin/Params.h:167-193  (BinFile.cpp:323,684)
+//   BlockMetaData       /root/reference/fastore/fastore_bin/BinFile.h:27-48   (11 x u64)
+//   ArchiveConfig       /root/reference/fastore/fastore_pack/ArchiveFile.h:29-34 (ArchiveFile.cpp:123)
+#pragma once
+#include <stdint.h>
+#include <set>
+#include <string>
+#include <vector>
+
+namespace fs {
+
+struct ArchiveTypeRaw { uint8_t readType, qualityOffset, readsHaveHeaders; };
+struct CategorizerParametersRaw { uint32_t minBlockBinSize; };
+struct MinimizerParametersRaw { uint8_t signatureLen, skipZoneLen, signatureMaskCutoffBits; char dnaSymbolOrder[5]; };
+struct MinimizerFilteringParametersRaw { uint8_t filterLowQualitySignatures, lowQualityThreshold; };
+struct QvOptionsRaw { uint8_t verbose, stats, uncompressed, distortion; const char* dist_file; const char* uncompressed_name; double D; };
+struct QualityCompressionParamsRaw { uint8_t method, binaryThreshold; QvOptionsRaw qvzOpts; };
+struct HeadersCompressionParamsRaw { uint8_t preserveComments; };
+struct BinModuleConfigRaw {
+    ArchiveTypeRaw archiveType;
+    CategorizerParametersRaw catParams;
+    MinimizerParametersRaw minimizer;
+    MinimizerFilteringParametersRaw minFilter;
+    QualityCompressionParamsRaw quaParams;
+    HeadersCompressionParamsRaw headParams;
+    uint64_t fastqBlockSize;
+    uint32_t binningLevel;
+    uint8_t binningType;
+};
+struct ArchiveConfigRaw { ArchiveTypeRaw archType; MinimizerParametersRaw minParams; QualityCompressionParamsRaw quaParams; };
+static_assert(sizeof(QualityCompressionParamsRaw) == 40, "layout");
+static_assert(sizeof(BinModuleConfigRaw) == 88, "layout");
+static_assert(sizeof(ArchiveConfigRaw) == 56, "layout");
+
+struct BlockMetaDataRaw {           // BinaryBinDescriptor + file offsets
+    uint64_t metaSize, dnaSize, quaSize, headSize, recordsCount, rawDnaSize, rawHeadSize;
+    uint64_t metaFileOffset, dnaFileOffset, quaFileOffset, headFileOffset;
+};
+static_assert(sizeof(BlockMetaDataRaw) == 88, "layout");
+
+enum QualityMethod { MET_NONE = 0, MET_BINARY = 1, MET_8BIN = 2, MET_QVZ = 3 };
+enum ReadType { READ_SE = 0, READ_PE = 1 };
+
+// read-id field statistics produced by fastore_bin (fastore_bin/Stats.h:40-71)
+struct HeaderField {
+    bool isConst = false, isNumeric = false;
+    char separator = 0;
+    uint64_t minValue = (uint64_t)-1, maxValue = 0;
+    std::vector<std::string> possibleValues;    // kept in std::set order (sorted, unique)
+};
+struct HeaderStats { std::vector<HeaderField> fields; uint32_t pairedEndFieldIdx = 0; };
+
+struct BinInfo {
+    std::vector<BlockMetaDataRaw> blocks;
+    uint64_t totalMetaSize = 0, totalDnaSize = 0, totalQuaSize = 0, totalHeadSize = 0;
+    uint64_t totalRawDnaSize = 0, totalRawHeadSize = 0, totalRecordsCount = 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Unpacked records of a batch of bins: structure-of-arrays, the layout that is copied to HBM.
+// Bases and qualities share offsets (seqOff); a PE record stores mate 1 then mate 2 contiguously.
+struct Rec {
+    uint32_t seqOff;      // into Batch::seq / Batch::qua
+    uint32_t headOff;     // into Batch::head
+    uint16_t seqLen, auxLen, minimPos;
+    uint8_t headLen, flags;   // flags: bit0 = read is reverse-complemented, bit1 = pair swapped
+};
+enum { FLAG_REVERSE = 1, FLAG_SWAPPED = 2 };
+
+struct NodeIn {           // a node of the stored match graph (fastore_rebin/NodesPacker.cpp:567-679)
+    uint32_t rec;
+    uint32_t emBegin, emCount;       // exact-match group: records emRecs[emBegin .. +emCount)
+    uint32_t treeBegin, treeCount;   // sub-tree groups: trees[treeBegin .. +treeCount)
+};
+struct TreeIn { uint32_t signatureId; int32_t mainSignaturePos; uint32_t nodeBegin, nodeCount; };
+
+struct BinIn {            // one bin = one future archive block
+    uint32_t signature;
+    uint32_t minLen, maxLen;
+    uint64_t rawDnaSize;
+    uint32_t recBegin, recCount;     // records of the bin in Batch::recs
+    uint32_t topBegin, topCount;     // top-level nodes: Batch::topNodes[topBegin .. +topCount) -> Batch::nodes
+};
+
+struct Batch {
+    std::vector<uint8_t> seq, qua, head;
+    std::vector<Rec> recs;
+    std::vector<NodeIn> nodes;
+    std::vector<uint32_t> topNodes;
+    std::vector<uint32_t> emRecs;
+    std::vector<TreeIn> trees;
+    std::vector<BinIn> bins;
+    void clear() { seq.clear(); qua.clear(); head.clear(); recs.clear(); nodes.clear(); topNodes.clear(); emRecs.clear(); trees.clear(); bins.clear(); }
+};
+
+}  // namespace fs

@@ -1,0 +1,930 @@
+#include "frontend.h"
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include "introsort.h"
+
+namespace fs {
+
+namespace {
+
+enum NodeType : uint8_t { TYPE_NONE = 0, TYPE_HARD, TYPE_LZ, TYPE_CONTIG_READ };
+enum ReadFlags { ReadIdentical = 0, ReadDifficult, ReadShiftOnly, ReadFullEncode, ReadFullExpensive, ReadTreeGroupStart,
+                 ReadContigGroupStart, ReadContigGroupNext, ReadGroupEnd };
+enum ReadMatchType { HardRead = 0, ExactMatch, LzMatch, ContigRead };
+enum ReadFlagsPE { ReadDifficultPE = 0, ReadIdenticalPE, ReadFullEncodePE, ReadFullExpensivePE, ReadShiftOnlyPE };
+const int32_t ShiftOffset = 128 + 1;
+
+// A record as the matcher sees it.  Real records map 1:1; sub-tree roots are *copies* of a
+// record with another signature position (FastqCompressor.cpp:1791-1798) and get their own id so
+// that "same FastqRecord object" tests (LZ history lookup) keep their meaning.
+struct VRec { uint32_t rec; uint16_t minimPos; };
+
+struct Contig {
+    std::vector<char> sequence;
+    std::vector<uint8_t> variant;
+    uint32_t rangeFirst = 0, rangeSecond = 0, variantsCount = 0, readLen = 0;
+    std::vector<int32_t> nodes;       // contig member nodes in encode order
+};
+
+struct Node {
+    int32_t vrec = -1;
+    uint8_t type = TYPE_NONE;
+    bool noMismatches = false, hasEm = false;
+    int16_t shift = 0, cost = 0;
+    int32_t lzVrec = -1, parent = -1, contig = -1;
+    std::vector<int32_t> children;
+    std::vector<int32_t> em;          // exact-match group: vrec ids
+    std::vector<uint32_t> trees;      // sub-tree group ids (Batch::trees)
+};
+
+struct BinaryRle {                   // rle/RleEncoder.h:21-79
+    std::vector<uint8_t>* w = nullptr; uint32_t cur = 0;
+    void start(std::vector<uint8_t>* o) { w = o; cur = 0; }
+    void put(bool s)
+    {
+        if (s) { cur++; if (cur == 255 - 2) { w->push_back((uint8_t)(cur + 2)); cur = 0; } }
+        else {
+            const bool mism = (cur > 0) && (cur < 255 - 2);
+            if (cur > 0) { w->push_back((uint8_t)(cur + 2)); cur = 0; }
+            if (!mism) w->push_back(0);
+        }
+    }
+    void end() { if (cur > 0) { w->push_back((uint8_t)(cur + 2)); cur = 0; } }
+};
+struct Rle0 {                        // rle/RleEncoder.h:140-212
+    std::vector<uint8_t>* w = nullptr; uint32_t prev = 0;
+    void start(std::vector<uint8_t>* o) { w = o; prev = 0; }
+    void put(uint32_t s)
+    {
+        if (s == 0) { if (prev == 0) prev = 1; else if (prev == 1) { w->push_back(0); prev = 0; } }
+        else {
+            if (prev == 1) { w->push_back(1); prev = 0; }
+            const uint32_t ss = s + 1;
+            if (ss < 253) w->push_back((uint8_t)ss);
+            else if (ss < (1u << 16) - 1) { w->push_back(0xFE); w->push_back((uint8_t)(ss >> 8)); w->push_back((uint8_t)ss); }
+            else { w->push_back(0xFF); w->push_back((uint8_t)(ss >> 24)); w->push_back((uint8_t)(ss >> 16)); w->push_back((uint8_t)(ss >> 8)); w->push_back((uint8_t)ss); }
+        }
+    }
+    void end() { if (prev == 1) w->push_back(1); }
+};
+
+uint32_t intLog(uint64_t x, uint64_t base)
+{
+    uint32_t r = 0;
+    if (base == 0) return 1;
+    if (base == 1) base++;
+    for (uint64_t t = base; t <= x; t *= base) ++r;
+    return r;
+}
+
+}  // namespace
+
+bool streamIsRangeCoded(uint32_t s, uint32_t qm)
+{
+    switch (s) {
+    case S_Rev: case S_MatchBinary: case S_LettersX: case S_CLetters: case S_IdToken: case S_IdValue:
+    case S_LettersXPE: case S_MatchBinaryPE: case S_FlagPE: return true;
+    case S_Quality: return qm != MET_NONE;
+    default: return false;
+    }
+}
+uint32_t streamModel(uint32_t s, uint32_t qm)
+{
+    // fsrc::Model ids: 0 s2o4, 1 s8o4, 2 a8o4, 3 a2o10, 4 a8o6, 5 a256o1
+    switch (s) {
+    case S_Rev: case S_MatchBinary: case S_MatchBinaryPE: return 0;
+    case S_LettersX: case S_CLetters: case S_LettersXPE: case S_FlagPE: return 2;
+    case S_IdToken: case S_IdValue: return 5;
+    case S_Quality: return qm == MET_BINARY ? 3 : 4;
+    default: return 0;
+    }
+}
+
+void compressReadId(const HeaderStats& head, const uint8_t* h, uint32_t headLen, std::vector<uint8_t>& tok, std::vector<uint8_t>& val)
+{
+    uint32_t fieldStart = 0, fi = 0;
+    const uint32_t nf = (uint32_t)head.fields.size();
+    for (uint32_t i = 0; i <= headLen; ++i) {
+        if (fi >= nf) break;                                   // more separators than fields: the reference would run off the table
+        const HeaderField& f = head.fields[fi];
+        if (i != headLen && (char)h[i] != f.separator) continue;
+        if (f.isConst) { fieldStart = i + 1; fi++; continue; }
+        const uint8_t* field = h + fieldStart;
+        const uint32_t fieldLen = i - fieldStart;
+        if (!f.isNumeric) {
+            const std::string s((const char*)field, fieldLen);
+            const auto it = std::find(f.possibleValues.begin(), f.possibleValues.end(), s);
+            const uint32_t id = (uint32_t)(it - f.possibleValues.begin());
+            tok.push_back((uint8_t)id); tok.push_back((uint8_t)fi);
+        } else {
+            uint64_t v = 0;                                     // is_num(): digits prefix
+            for (uint32_t k = 0; k < fieldLen; ++k) { if (field[k] < '0' || field[k] > '9') break; v = v * 10 + (field[k] - '0'); }
+            const int64_t diff = (int64_t)(v - f.minValue);
+            uint32_t ctxBase = fi << 2;
+            const int32_t valueRange = (int32_t)(f.maxValue - f.minValue);
+            int32_t plog = (int32_t)intLog((uint64_t)(int64_t)valueRange, 256);
+            while (plog >= 0) { val.push_back((uint8_t)((diff >> (8 * plog--)) & 0xFF)); val.push_back((uint8_t)ctxBase++); }
+        }
+        fieldStart = i + 1; fi++;
+    }
+}
+
+void compressReadQuality(const BinModuleConfigRaw& cfg, const uint8_t* seq, const uint8_t* qua, uint32_t len, bool reverse, std::vector<uint8_t>& out)
+{
+    static const uint8_t q8[64] = {0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5,
+                                   5, 5, 5, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7};
+    const uint32_t off = cfg.archiveType.qualityOffset;
+    switch (cfg.quaParams.method) {
+    case MET_NONE:
+        for (uint32_t i = 0; i < len; ++i) { const uint32_t ii = reverse ? len - 1 - i : i; out.push_back((uint8_t)(qua[ii] - off)); }
+        break;
+    case MET_BINARY:
+        for (uint32_t i = 0; i < len; ++i) {
+            const uint32_t ii = reverse ? len - 1 - i : i;
+            if (seq[ii] == 'N') continue;
+            const uint32_t q = (uint32_t)(qua[ii] - off) >= cfg.quaParams.binaryThreshold;
+            out.push_back((uint8_t)q); out.push_back((uint8_t)((i * 2) / len));
+        }
+        break;
+    case MET_8BIN:
+        for (uint32_t i = 0; i < len; ++i) {
+            const uint32_t ii = reverse ? len - 1 - i : i;
+            if (seq[ii] == 'N') continue;
+            out.push_back(q8[(qua[ii] - off) & 63]); out.push_back((uint8_t)((i * 8) / len));
+        }
+        break;
+    default: throw std::runtime_error("QVZ quality coding is not supported by this build yet");
+    }
+}
+
+// =================================================================================================
+struct BinEncoder::Impl {
+    const BinModuleConfigRaw cfg;
+    const HeaderStats& head;
+    const PackParams par;
+    const uint32_t sigLen;
+    const bool pe, hasHeaders;
+    int8_t dnaToIdx[128];
+
+    const Batch* B = nullptr;
+    BinStreams* out = nullptr;
+    uint32_t recBase = 0, curSig = 0;
+    std::vector<VRec> vrecs;
+    std::vector<Node> nodes;          // all nodes of the bin (top-level first, sub-tree nodes by Batch order)
+    std::deque<Contig> contigs;       // deque: references stay valid while nested sub-trees add contigs
+    uint32_t nodeBase = 0;            // Batch node index of nodes[0]
+
+    BinaryRle matchRle, consMatchRle, matchRlePE;
+    Rle0 lzRle0;
+
+    struct LzContext { std::vector<int32_t> history; };
+    std::vector<LzContext> lzStack;
+    struct ConsEnc { int32_t lastMinimPos = 0; const Contig* def = nullptr; };
+    std::vector<ConsEnc> consStack;
+
+    Impl(const BinModuleConfigRaw& c, const HeaderStats& h, const PackParams& p)
+        : cfg(c), head(h), par(p), sigLen(c.minimizer.signatureLen), pe(c.archiveType.readType == READ_PE),
+          hasHeaders(c.archiveType.readsHaveHeaders != 0)
+    {
+        memset(dnaToIdx, -1, sizeof dnaToIdx);
+        for (int i = 0; i < 5; ++i) dnaToIdx[(int)c.minimizer.dnaSymbolOrder[i]] = (int8_t)i;
+    }
+
+    // ---- record accessors ----
+    const Rec& R(int32_t v) const { return B->recs[vrecs[v].rec]; }
+    const uint8_t* seq(int32_t v) const { return B->seq.data() + R(v).seqOff; }
+    const uint8_t* qua(int32_t v) const { return B->qua.data() + R(v).seqOff; }
+    uint32_t seqLen(int32_t v) const { return R(v).seqLen; }
+    uint32_t minimPos(int32_t v) const { return vrecs[v].minimPos; }
+    bool isReverse(int32_t v) const { return (R(v).flags & FLAG_REVERSE) != 0; }
+
+    void putByte(uint32_t s, uint32_t b) { out->s[s].push_back((uint8_t)b); }
+    void putSym(uint32_t s, uint32_t sym, uint32_t ctx = 0) { out->s[s].push_back((uint8_t)sym); out->s[s].push_back((uint8_t)ctx); }
+    uint32_t d2i(uint8_t c) const { return (uint32_t)(uint8_t)dnaToIdx[c & 127]; }
+
+    // ------------------------------------------------------------------------------------------
+    // TFastqComparator / IFastqComparator::CompareReads  (fastore_bin/FastqRecord.h:226-257)
+    bool compareReads(int32_t a, int32_t b) const
+    {
+        const Rec &r1 = R(a), &r2 = R(b);
+        const uint32_t m1 = minimPos(a), m2 = minimPos(b);
+        const uint8_t *p1 = seq(a) + m1, *p2 = seq(b) + m2;
+        const uint32_t l1 = (uint32_t)r1.seqLen + r1.auxLen - m1, l2 = (uint32_t)r2.seqLen + r2.auxLen - m2;
+        const uint32_t len = l1 < l2 ? l1 : l2;
+        const int r = memcmp(p1, p2, len);               // strncmp on NUL-free bases
+        if (r == 0) {
+            if (m1 == m2) {
+                const uint8_t *s1 = seq(a), *s2 = seq(b);
+                for (int32_t i = (int32_t)m1; i >= 0; i--) { if (s1[i] < s2[i]) return true; if (s1[i] > s2[i]) return false; }
+                return false;
+            }
+            return m1 > m2;
+        }
+        return r < 0;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // ReadsClassifierSE::UpdateLzMatchResult (fastore_pack/ReadsClassifier.h:160-196)
+    struct MatchResult { int32_t cost = 255; bool noMismatches = false; int32_t prevId = 0, shift = 0; };
+    bool updateLzMatch(MatchResult& res, const uint8_t* s, uint32_t sLen, int32_t minPos, const uint8_t* lz, uint32_t lzLen, int32_t lzMinPos) const
+    {
+        const int32_t shift = lzMinPos - minPos;
+        const int32_t ashift = shift < 0 ? -shift : shift;
+        const int32_t insertCost = ashift * par.shiftCost;
+        if (insertCost > res.cost || (uint32_t)ashift > 127u) return false;
+        const int32_t recOff = shift < 0 ? -shift : 0, lzOff = shift > 0 ? shift : 0;
+        const uint8_t *s1 = s + recOff, *s2 = lz + lzOff;
+        const uint32_t a = sLen - recOff, b = lzLen - lzOff, minLen = a < b ? a : b;
+        int32_t cc = insertCost;
+        for (uint32_t i = 0; i < minLen && cc < res.cost; ++i) cc += (s1[i] != s2[i]) * par.mismatchCost;
+        if (cc < res.cost) { res.cost = cc; res.noMismatches = (cc - insertCost == 0); res.shift = shift; return true; }
+        return false;
+    }
+
+    struct WinEntry { const uint8_t* seq; int32_t node; uint16_t seqLen, minPos; };
+
+    // ReadsClassifierSE::ConstructMatchTree (fastore_pack/ReadsClassifier.cpp:95-442).
+    // order: node ids in processing order; auxRoot: node id of the sub-tree root copy or -1.
+    void constructMatchTree(const std::vector<int32_t>& order, std::vector<int32_t>& roots, int32_t auxRoot)
+    {
+        static uint8_t dummy[256]; static bool dummyInit = false;
+        if (!dummyInit) { memset(dummy, 'N', sizeof dummy); dummyInit = true; }
+        roots.clear();
+        const uint32_t W = par.maxLzWindowSize;
+        std::deque<WinEntry> win;                 // real entries, newest first
+        uint32_t numDummies = W; bool dupAtBack = false;
+        const bool usePrefix = par.extraReduceHardReads || par.extraReduceExpensiveLzMatches;
+        std::vector<int32_t> rp[25];              // the 25 std::set<MatchNode*, prefixFun> as sorted vectors
+
+        auto prefixLess = [&](int32_t x, int32_t y) {
+            const int32_t mx = (int32_t)minimPos(nodes[x].vrec), my = (int32_t)minimPos(nodes[y].vrec);
+            const int32_t maxRange = (mx < my ? mx : my) - 2;
+            const uint8_t *px = seq(nodes[x].vrec) + mx - 2, *py = seq(nodes[y].vrec) + my - 2;
+            for (int32_t i = 0; i < maxRange; i++) { if (*px < *py) return true; if (*px > *py) return false; px--; py--; }
+            return mx > my;
+        };
+        auto popBack = [&]() {
+            if (dupAtBack) dupAtBack = false;
+            else if (numDummies > 0) numDummies--;
+            else win.pop_back();
+        };
+        if (auxRoot >= 0) {
+            popBack();
+            const int32_t v = nodes[auxRoot].vrec;
+            win.push_front(WinEntry{seq(v), auxRoot, (uint16_t)seqLen(v), (uint16_t)minimPos(v)});
+            roots.push_back(auxRoot);
+        }
+        for (int32_t cur : order) {
+            Node& curNode = nodes[cur];
+            const int32_t v = curNode.vrec;
+            const uint8_t* rs = seq(v); const uint32_t rl = seqLen(v); const int32_t rm = (int32_t)minimPos(v);
+            popBack();
+            int32_t encodeThreshold = par.encodeThreshold == 0 ? (int32_t)(rl / 2) : par.encodeThreshold;
+            // FindBestLzMatch (ReadsClassifier.cpp:55-83)
+            MatchResult mr; mr.cost = encodeThreshold + 1;
+            bool stop = false;
+            for (uint32_t i = 0; i < win.size(); ++i) {
+                const WinEntry& lz = win[i];
+                if (!updateLzMatch(mr, rs, rl, rm, lz.seq, lz.seqLen, lz.minPos)) continue;
+                mr.prevId = (int32_t)i;
+                if (mr.cost == 0) { stop = true; break; }
+            }
+            if (!stop && numDummies > 0) {
+                // dummy entries (256 x 'N', minPos 0) can only win for reads that are >= 1/3 'N' or with a manual
+                // threshold; all dummies are identical, so the first one decides
+                if (updateLzMatch(mr, rs, rl, rm, dummy, 256, 0)) mr.prevId = (int32_t)win.size();
+            }
+            const bool bestIsReal = (uint32_t)mr.prevId < win.size();
+            const uint32_t bestLen = bestIsReal ? win[mr.prevId].seqLen : 256u;
+            bool identical = (mr.cost == 0 && bestLen == rl);
+            bool isHard = mr.cost > encodeThreshold;
+            if (identical) identical = bestIsReal && nodes[win[mr.prevId].node].type != TYPE_NONE;
+            const WinEntry newLz{rs, cur, (uint16_t)rl, (uint16_t)rm};
+            if (identical) {
+                curNode.type = TYPE_NONE; curNode.lzVrec = -1; curNode.parent = -1;
+                Node& parent = nodes[win[mr.prevId].node];
+                if (curNode.hasEm) {
+                    if (!parent.hasEm) { parent.hasEm = true; parent.em = std::move(curNode.em); }
+                    else parent.em.insert(parent.em.end(), curNode.em.begin(), curNode.em.end());
+                    curNode.em.clear(); curNode.hasEm = false;
+                }
+                if (!curNode.trees.empty()) {
+                    parent.trees.insert(parent.trees.end(), curNode.trees.begin(), curNode.trees.end());
+                    curNode.trees.clear();
+                }
+                parent.hasEm = true;
+                parent.em.push_back(v);
+                dupAtBack = true;                 // lzBuffer.push_back(newLz): recycled by the next read
+            } else {
+                int32_t parentNode = -1;
+                std::vector<int32_t>* rpb = nullptr;
+                if (usePrefix) {
+                    const uint32_t expensiveLzThreshold = (uint32_t)encodeThreshold / 2;
+                    const bool searchRev = isHard || (par.extraReduceExpensiveLzMatches && mr.cost > (int32_t)expensiveLzThreshold);
+                    if (!isHard) encodeThreshold = (int32_t)expensiveLzThreshold;
+                    if (rm >= 8) {
+                        int32_t bi = dnaToIdxAcgtn(rs[rm - 2]);
+                        bi = bi * 5 + dnaToIdxAcgtn(rs[rm - 1]);
+                        rpb = &rp[bi];
+                    }
+                    if (searchRev && rm >= 8) {
+                        MatchResult fwd, rev; int32_t fwdNode = -1, revNode = -1;
+                        fwd.cost = encodeThreshold + 1; rev.cost = encodeThreshold + 1;
+                        const size_t lb = std::lower_bound(rpb->begin(), rpb->end(), cur, prefixLess) - rpb->begin();
+                        const uint32_t maxCnt = W / 2 + 1;
+                        for (size_t p = lb, cnt = 0; p < rpb->size() && cnt < maxCnt; ++p, ++cnt) {
+                            const int32_t lv = nodes[(*rpb)[p]].vrec;
+                            if (!updateLzMatch(fwd, rs, rl, rm, seq(lv), seqLen(lv), (int32_t)minimPos(lv))) continue;
+                            fwdNode = (*rpb)[p];
+                        }
+                        for (size_t q = lb, cnt = 0; q > 0 && cnt < maxCnt; --q, ++cnt) {
+                            const int32_t lv = nodes[(*rpb)[q - 1]].vrec;
+                            if (!updateLzMatch(rev, rs, rl, rm, seq(lv), seqLen(lv), (int32_t)minimPos(lv))) continue;
+                            revNode = (*rpb)[q - 1];
+                        }
+                        const int32_t minCost = fwd.cost < rev.cost ? fwd.cost : rev.cost;
+                        if (minCost < encodeThreshold && minCost < mr.cost) {
+                            if (fwd.cost < rev.cost) { parentNode = fwdNode; mr = fwd; } else { parentNode = revNode; mr = rev; }
+                            isHard = false;
+                        }
+                    }
+                }
+                if (isHard) {
+                    curNode.type = TYPE_HARD; curNode.lzVrec = -1; curNode.parent = -1;
+                    roots.push_back(cur);
+                } else {
+                    if (parentNode < 0) parentNode = win[mr.prevId].node;
+                    curNode.type = TYPE_LZ; curNode.parent = parentNode; curNode.lzVrec = nodes[parentNode].vrec;
+                    curNode.shift = (int16_t)mr.shift; curNode.noMismatches = mr.noMismatches; curNode.cost = (int16_t)mr.cost;
+                    nodes[parentNode].children.push_back(cur);
+                }
+                win.push_front(newLz);
+                if (rpb) {                        // std::set::insert: skipped when an equivalent node is present
+                    const auto it = std::lower_bound(rpb->begin(), rpb->end(), cur, prefixLess);
+                    if (it == rpb->end() || prefixLess(cur, *it)) rpb->insert(it, cur);
+                }
+            }
+        }
+    }
+    static int32_t dnaToIdxAcgtn(uint8_t c) { switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; case 'N': return 4; } return -1; }
+
+    // ------------------------------------------------------------------------------------------
+    // ContigBuilder (fastore_pack/ContigBuilder.cpp:50-669, costs ContigBuilder.h:128-151)
+    struct WorkNode { int32_t match = -1; std::vector<uint16_t> newVariantPositions; };
+    struct BuildInfo {
+        Contig cons; int32_t mainNode = -1;
+        std::vector<WorkNode> nodes; std::vector<uint16_t> variantFreqPerPos, recordsPerPos;
+        std::vector<int32_t> removedNodes;
+        void reset(uint32_t L)
+        {
+            cons.sequence.assign(2 * L, '.'); cons.variant.assign(2 * L, 0); cons.readLen = L;
+            variantFreqPerPos.assign(2 * L, 0); recordsPerPos.assign(2 * L, 0);
+            mainNode = -1; nodes.clear(); removedNodes.clear();
+            cons.variantsCount = 0; cons.rangeFirst = L; cons.rangeSecond = L;
+        }
+    };
+    void addChildrenToQueue(std::deque<int32_t>& q, int32_t n)
+    {
+        const auto& ch = nodes[n].children;
+        if (ch.size() > 1) {
+            std::vector<int32_t> c2;
+            for (int32_t c : ch) { if (nodes[c].children.empty()) q.push_back(c); else c2.push_back(c); }
+            q.insert(q.end(), c2.begin(), c2.end());
+        } else q.push_back(ch.front());
+    }
+    float normalEncodeCost(const Node& n) const
+    {
+        float rleCost = 0.0f;
+        const int32_t as = n.shift < 0 ? -n.shift : n.shift;
+        if (as != n.cost) rleCost = 1.0f + n.cost / 1.5f;
+        return (1.0f + n.cost) + rleCost + 2.0f;
+    }
+    bool consCostExceeds(const BuildInfo& bi, const WorkNode& w, uint32_t ham, const Node& n) const
+    {
+        uint32_t newVarCost = 0;
+        for (uint16_t p : w.newVariantPositions) newVarCost += bi.recordsPerPos[p];
+        if (newVarCost > 0) ham -= 1;
+        // "(float)(...) + float(newVarCost) * 0.9" is evaluated in double and rounded to the float return type
+        const float c = (float)((double)(float)(1 + ham + par.beginCut + par.endCut) + (double)(float)newVarCost * 0.9);
+        return c > normalEncodeCost(n);
+    }
+    void updateRange(BuildInfo& bi, uint32_t m, uint32_t consBegin, uint32_t consEnd, uint32_t L, bool first)
+    {
+        const uint32_t f = (m <= par.beginCut) ? consBegin + m + sigLen : consBegin + par.beginCut;
+        const uint32_t s = (L - m - sigLen <= par.endCut) ? consBegin + m : consEnd - par.endCut;
+        if (first) { bi.cons.rangeFirst = f; bi.cons.rangeSecond = s; }
+        else { bi.cons.rangeFirst = std::min(bi.cons.rangeFirst, f); bi.cons.rangeSecond = std::max(bi.cons.rangeSecond, s); }
+    }
+    bool addRecord(BuildInfo& bi, int32_t n, bool fullMatchOnly)
+    {
+        const Node& node = nodes[n];
+        if (!node.trees.empty()) return false;                  // AvoidTreesInConsensus
+        const uint32_t L = bi.cons.readLen;
+        const int32_t v = node.vrec;
+        const uint8_t* s = seq(v); const uint32_t m = minimPos(v);
+        const uint32_t consBegin = L - m, consEnd = consBegin + L;
+        if (!bi.nodes.empty()) {
+            WorkNode w; uint32_t ham = 0;
+            for (uint32_t i = par.beginCut; i < L - par.endCut; ++i) {
+                const uint32_t p = consBegin + i;
+                if (bi.cons.sequence[p] != '.' && bi.cons.sequence[p] != (char)s[i]) { ham++; if (bi.variantFreqPerPos[p] == 0) w.newVariantPositions.push_back((uint16_t)p); }
+                else if (bi.cons.sequence[p] == '.' && s[i] == 'N') return false;
+            }
+            if (fullMatchOnly) { if (!w.newVariantPositions.empty()) return false; }
+            else {
+                const uint32_t maxShift = par.maxRecordShiftDifference == 0 ? L / 2 : par.maxRecordShiftDifference;
+                const int32_t lastM = (int32_t)minimPos(nodes[bi.nodes.back().match].vrec);
+                // the reference's macro is  ABS(x) ((x) >= 0 ? (x) : (-x))  -- applied to "last - cur" the negative
+                // branch expands to (-last - cur), i.e. never exceeds maxShift (fastore_bin/Globals.h:70, ContigBuilder.cpp:219)
+                int32_t d = lastM - (int32_t)m; if (d < 0) d = -lastM - (int32_t)m;
+#ifdef FS_DEBUG_DUMP
+                if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == curSig) { uint32_t nvc = 0; for (uint16_t p : w.newVariantPositions) nvc += bi.recordsPerPos[p];
+                  printf("D ham %u newvars %zu nvc %u d %d maxShift %u normal %f shift %d cost %d exceeds %d\n", ham, w.newVariantPositions.size(), nvc, d, maxShift, normalEncodeCost(node), node.shift, node.cost, (int)consCostExceeds(bi, w, ham, node)); }
+#endif
+                if (!(w.newVariantPositions.empty() || (ham <= par.maxHammingDistance && w.newVariantPositions.size() <= par.maxNewVariantsPerRead))
+                    || d > (int32_t)maxShift || consCostExceeds(bi, w, ham, node))
+                    return false;
+            }
+            bi.cons.variantsCount += (uint32_t)w.newVariantPositions.size();
+            for (uint32_t i = par.beginCut; i < L - par.endCut; ++i) {
+                const uint32_t p = consBegin + i;
+                if (bi.cons.sequence[p] == '.') bi.cons.sequence[p] = (char)s[i];
+                else if (bi.cons.sequence[p] != (char)s[i]) bi.variantFreqPerPos[p]++;
+                bi.recordsPerPos[p]++;
+            }
+            updateRange(bi, m, consBegin, consEnd, L, false);
+            w.match = n; bi.nodes.push_back(std::move(w));
+        } else {
+            if (memchr(s, 'N', L) != nullptr) return false;
+            for (uint32_t i = par.beginCut; i < L - par.endCut; ++i) bi.cons.sequence[consBegin + i] = (char)s[i];
+            updateRange(bi, m, consBegin, consEnd, L, true);
+            WorkNode w; w.match = n; bi.nodes.push_back(std::move(w));
+        }
+        return true;
+    }
+    void optimizeContig(BuildInfo& bi)
+    {
+        std::vector<uint32_t> idxToRemove;
+        for (uint32_t i = 0; i < bi.nodes.size(); ++i) {
+            const WorkNode& n = bi.nodes[i];
+            if (n.newVariantPositions.empty()) continue;
+            bool onlyOne = false;
+            for (uint16_t pos : n.newVariantPositions) if (bi.variantFreqPerPos[pos] == 1) onlyOne = true;
+            if (onlyOne) idxToRemove.push_back(i);
+        }
+        if (idxToRemove.empty()) return;
+        std::vector<WorkNode> old = std::move(bi.nodes);
+        const uint32_t L = bi.cons.readLen;
+        bi.reset(L);
+        uint32_t idx = 0;
+        for (uint32_t r : idxToRemove) {
+            if (r > idx) for (uint32_t k = idx; k < r; ++k) bi.nodes.push_back(old[k]);
+            bi.removedNodes.push_back(old[r].match);
+            idx = r + 1;
+        }
+        for (uint32_t k = idx; k < old.size(); ++k) bi.nodes.push_back(old[k]);
+        {
+            const int32_t v = nodes[bi.nodes[0].match].vrec; const uint8_t* s = seq(v); const uint32_t m = minimPos(v);
+            const uint32_t consBegin = L - m, consEnd = consBegin + L;
+            for (uint32_t i = par.beginCut; i < L - par.endCut; ++i) bi.cons.sequence[consBegin + i] = (char)s[i];
+            updateRange(bi, m, consBegin, consEnd, L, true);
+        }
+        for (size_t k = 1; k < bi.nodes.size(); ++k) {
+            WorkNode& w = bi.nodes[k];
+            const int32_t v = nodes[w.match].vrec; const uint8_t* s = seq(v); const uint32_t m = minimPos(v);
+            const uint32_t consBegin = L - m, consEnd = consBegin + L;
+            w.newVariantPositions.clear();
+            for (uint32_t i = par.beginCut; i < L - par.endCut; ++i) {
+                const uint32_t p = consBegin + i;
+                if (bi.cons.sequence[p] != '.' && bi.cons.sequence[p] != (char)s[i]) if (bi.variantFreqPerPos[p] == 0) w.newVariantPositions.push_back((uint16_t)p);
+            }
+            bi.cons.variantsCount += (uint32_t)w.newVariantPositions.size();
+            for (uint32_t i = par.beginCut; i < L - par.endCut; ++i) {
+                const uint32_t p = consBegin + i;
+                if (bi.cons.sequence[p] == '.') bi.cons.sequence[p] = (char)s[i];
+                else if (bi.cons.sequence[p] != (char)s[i]) bi.variantFreqPerPos[p]++;
+                bi.recordsPerPos[p]++;
+            }
+            updateRange(bi, m, consBegin, consEnd, L, false);
+        }
+    }
+    static void removeChild(std::vector<int32_t>& ch, int32_t c) { auto it = std::find(ch.begin(), ch.end(), c); if (it != ch.end()) ch.erase(it); }
+    void updateContigLinkage(BuildInfo& bi)
+    {
+        std::vector<int32_t> consNodes;
+        for (const auto& w : bi.nodes) consNodes.push_back(w.match);
+        std::sort(consNodes.begin(), consNodes.end());
+        auto inCons = [&](int32_t n) { return std::binary_search(consNodes.begin(), consNodes.end(), n); };
+        int32_t bestParent = -1; int32_t minCost = 255;
+        for (auto& w : bi.nodes) {
+            Node& n = nodes[w.match];
+            if (!inCons(n.parent)) {
+                const int32_t parent = n.parent;
+                removeChild(nodes[parent].children, w.match);
+                n.parent = -1;
+                if (std::find(bi.removedNodes.begin(), bi.removedNodes.end(), parent) == bi.removedNodes.end()
+                    && (bi.mainNode < 0 || minCost > n.cost)) {
+                    bestParent = parent; bi.mainNode = w.match; minCost = n.cost;
+                }
+            }
+        }
+        if (bi.mainNode < 0 || bestParent < 0) throw std::runtime_error("contig linkage: no external parent");
+        nodes[bi.mainNode].parent = bestParent;
+        nodes[bestParent].children.push_back(bi.mainNode);
+        for (size_t k = 0; k < bi.nodes.size(); ++k) if (bi.nodes[k].match == bi.mainNode) { bi.nodes.erase(bi.nodes.begin() + k); break; }
+        consNodes.erase(std::lower_bound(consNodes.begin(), consNodes.end(), bi.mainNode));
+        {
+            auto& ch = nodes[bi.mainNode].children;
+            for (size_t k = 0; k < ch.size();) { if (inCons(ch[k])) ch.erase(ch.begin() + k); else ++k; }
+        }
+        for (auto& w : bi.nodes) {
+            Node& n = nodes[w.match];
+            if (n.children.empty()) continue;                  // children == NULL (an emptied list is deleted by RemoveChild)
+            for (int32_t c : n.children) if (!inCons(c)) { nodes[c].parent = bi.mainNode; nodes[bi.mainNode].children.push_back(c); }
+            n.children.clear();
+        }
+    }
+    void postProcessContig(BuildInfo& bi)
+    {
+        const uint32_t L = bi.cons.readLen;
+        if (bi.cons.variantsCount != 0) {
+            auto agctn = [](uint8_t c) -> int { switch (c) { case 'A': return 0; case 'G': return 1; case 'C': return 2; case 'T': return 3; case 'N': return 4; } return 0; };
+            static const char idxToDna[] = "AGCTN";
+            std::map<uint32_t, std::vector<uint32_t>> posStats;
+            for (const auto& w : bi.nodes) {
+                const int32_t v = nodes[w.match].vrec; const uint8_t* s = seq(v);
+                const uint32_t consBegin = L - minimPos(v);
+                for (uint32_t i = par.beginCut; i < L - par.endCut; ++i) {
+                    const uint32_t p = consBegin + i;
+                    if (bi.variantFreqPerPos[p] > 0) { auto& st = posStats[p]; if (st.empty()) st.resize(5); st[agctn(s[i])] += 1; }
+                }
+            }
+            for (auto& st : posStats) {
+                char c = 'N'; uint32_t maxFreq = 0;
+                for (uint32_t i = 0; i < 5; ++i) if (st.second[i] > maxFreq) { maxFreq = st.second[i]; c = idxToDna[i]; }
+                bi.cons.sequence[st.first] = c;
+            }
+            for (uint32_t i = 0; i < bi.variantFreqPerPos.size(); ++i) {
+                bi.cons.variant[i] = bi.variantFreqPerPos[i] != 0;
+                bi.cons.variantsCount += bi.variantFreqPerPos[i] != 0;
+            }
+        }
+        for (char& c : bi.cons.sequence) if (c == '.') c = 'N';
+        // std::sort(nodes) by record minimPos -- unstable, libstdc++ order (ContigBuilder.cpp:521)
+        introsort(bi.nodes.data(), bi.nodes.size(), [&](const WorkNode& a, const WorkNode& b) {
+            return minimPos(nodes[a.match].vrec) < minimPos(nodes[b.match].vrec);
+        });
+    }
+    void storeContig(BuildInfo& bi)
+    {
+        const int32_t id = (int32_t)contigs.size();
+        contigs.push_back(Contig());
+        Contig& c = contigs.back();
+        c = std::move(bi.cons);
+        nodes[bi.mainNode].contig = id;
+        nodes[bi.mainNode].type = TYPE_LZ;
+        for (auto& w : bi.nodes) { nodes[w.match].type = TYPE_CONTIG_READ; c.nodes.push_back(w.match); }
+    }
+    void buildContigs(int32_t root)
+    {
+        const uint32_t L = seqLen(nodes[root].vrec);
+        std::deque<int32_t> nextQueue;
+        if (!nodes[root].children.empty()) addChildrenToQueue(nextQueue, root);
+        BuildInfo bi;
+        while (!nextQueue.empty()) {
+            int32_t node = nextQueue.front(); nextQueue.pop_front();
+            bi.reset(L);
+#ifdef FS_DEBUG_DUMP
+            if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == curSig) { const Rec& r = R(nodes[node].vrec); printf("T start %s\n", std::string((const char*)B->head.data() + r.headOff, r.headLen).c_str()); }
+#endif
+            if (!addRecord(bi, node, false)) { if (!nodes[node].children.empty()) addChildrenToQueue(nextQueue, node); continue; }
+            std::deque<int32_t> curQueue = std::move(nextQueue); nextQueue.clear();
+            if (!nodes[node].children.empty()) addChildrenToQueue(curQueue, node);
+            while (!curQueue.empty()) {
+                node = curQueue.front(); curQueue.pop_front();
+                { bool r1 = addRecord(bi, node, true);
+#ifdef FS_DEBUG_DUMP
+                if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == curSig) { const Rec& r = R(nodes[node].vrec); printf("A1 %s %d\n", std::string((const char*)B->head.data() + r.headOff, r.headLen).c_str(), (int)r1); }
+#endif
+                if (!r1) { nextQueue.push_back(node); continue; } }
+                if (false) {}
+                else if (!nodes[node].children.empty()) addChildrenToQueue(curQueue, node);
+            }
+            std::swap(curQueue, nextQueue);
+            while (!curQueue.empty()) {
+                node = curQueue.front(); curQueue.pop_front();
+                { bool r2 = addRecord(bi, node, false);
+#ifdef FS_DEBUG_DUMP
+                if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == curSig) { const Rec& r = R(nodes[node].vrec); printf("A2 %s %d\n", std::string((const char*)B->head.data() + r.headOff, r.headLen).c_str(), (int)r2); }
+#endif
+                if (!r2) { nextQueue.push_back(node); continue; } }
+                if (false) {}
+                else if (!nodes[node].children.empty()) addChildrenToQueue(curQueue, node);
+            }
+#ifdef FS_DEBUG_DUMP
+            if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == curSig) printf("T size %zu\n", bi.nodes.size());
+#endif
+            if (bi.nodes.size() < par.minConsensusSize) continue;
+            optimizeContig(bi);
+#ifdef FS_DEBUG_DUMP
+            if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == curSig) printf("T opt size %zu\n", bi.nodes.size());
+#endif
+            if (bi.nodes.size() < par.minConsensusSize) continue;
+            updateContigLinkage(bi);
+            postProcessContig(bi);
+            storeContig(bi);
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // record-level emitters (fastore_pack/FastqCompressor.cpp:1388-2119)
+    void compressId(int32_t v)
+    {
+        if (!hasHeaders) return;
+        const Rec& r = R(v);
+        compressReadId(head, B->head.data() + r.headOff, r.headLen, out->s[S_IdToken], out->s[S_IdValue]);
+        out->rawIdSize += r.headLen;
+    }
+    void compressQuality(int32_t v) { compressReadQuality(cfg, seq(v), qua(v), seqLen(v), isReverse(v), out->s[S_Quality]); }
+
+    void compressHardRead(int32_t v)
+    {
+        putSym(S_Rev, isReverse(v));
+        putByte(S_Flag, ReadDifficult);
+        const uint8_t* s = seq(v); const int32_t L = (int32_t)seqLen(v), m = (int32_t)minimPos(v);
+        for (int32_t i = 0; i < L; ++i) {
+            if (i < m || i >= m + (int32_t)sigLen) putByte(S_HardReads, s[i]);
+            else if (i == m) putByte(S_HardReads, '.');
+        }
+    }
+    void compressExactRead(int32_t v) { putSym(S_Rev, isReverse(v)); putByte(S_Flag, ReadIdentical); }
+
+    void compressNormalMatch(const Node& n, uint32_t lzId, bool expensive)
+    {
+        const int32_t v = n.vrec, lv = n.lzVrec;
+        putSym(S_Rev, isReverse(v));
+        putByte(S_Shift, (uint32_t)(ShiftOffset + n.shift));
+        lzRle0.put(lzId);
+        const int32_t flag = n.noMismatches ? ReadShiftOnly : (expensive ? ReadFullExpensive : ReadFullEncode);
+        putByte(S_Flag, (uint32_t)flag);
+        const uint8_t* bestSeq = seq(lv); uint32_t bestLen = seqLen(lv), bestPos = minimPos(lv);
+        const uint8_t* newSeq = seq(v); uint32_t newLen = seqLen(v);
+        if (n.shift >= 0) { bestSeq += n.shift; bestLen -= n.shift; bestPos -= n.shift; }
+        else {
+            for (int32_t i = 0; i < -n.shift; ++i) putSym(S_LettersX, d2i(newSeq[i]), d2i('N'));
+            newSeq += -n.shift; newLen -= -n.shift;
+        }
+        const uint32_t minLen = bestLen < newLen ? bestLen : newLen;
+        if (flag == ReadFullEncode) {
+            for (uint32_t i = 0; i < minLen; ++i) {
+                if (i == bestPos) { i += sigLen - 1; continue; }
+                if (bestSeq[i] == newSeq[i]) matchRle.put(true);
+                else { matchRle.put(false); putSym(S_LettersX, d2i(newSeq[i]), d2i(bestSeq[i])); }
+            }
+        } else if (flag == ReadFullExpensive) {
+            for (uint32_t i = 0; i < minLen; ++i) {
+                if (i == bestPos) { i += sigLen - 1; continue; }
+                putSym(S_MatchBinary, bestSeq[i] == newSeq[i]);
+                if (bestSeq[i] != newSeq[i]) putSym(S_LettersX, d2i(newSeq[i]), d2i(bestSeq[i]));
+            }
+        }
+        for (uint32_t i = minLen; i < newLen; ++i) putSym(S_LettersX, d2i(newSeq[i]), d2i('N'));
+    }
+    void compressContigRead(int32_t v, bool useTreeShift)
+    {
+        ConsEnc& ce = consStack.back();
+        const int32_t m = (int32_t)minimPos(v);
+        const int32_t dpos = m - ce.lastMinimPos; ce.lastMinimPos = m;
+        const uint32_t stream = useTreeShift ? S_TreeShift : S_CShift;
+        const uint32_t readLen = seqLen(v);
+        if (readLen * 2 >= 256) putByte(stream, (uint32_t)m); else putByte(stream, (uint32_t)(ShiftOffset + dpos));
+        putSym(S_Rev, isReverse(v));
+        const uint32_t consStart = readLen - m;
+        const uint8_t* s = seq(v); const Contig& def = *ce.def;
+        uint32_t it = 0;
+        while (it < par.beginCut) {
+            if (it == (uint32_t)m) { it += sigLen; continue; }
+            putSym(S_CLetters, d2i(s[it]), d2i((uint8_t)def.sequence[consStart + it])); it++;
+        }
+        while (it < readLen - par.endCut) {
+            if (it == (uint32_t)m) { it += sigLen; continue; }
+            if (def.variant[consStart + it]) putSym(S_CLetters, d2i(s[it]), d2i((uint8_t)def.sequence[consStart + it]));
+            it++;
+        }
+        while (it < readLen) { putSym(S_CLetters, d2i(s[it]), d2i((uint8_t)def.sequence[consStart + it])); it++; }
+    }
+    // LzCompressorSE::CompressRead / LzCompressorPE::CompressRead
+    void compressRead(int32_t v, ReadMatchType type, bool aux = false)
+    {
+        compressId(v);
+        switch (type) {
+        case HardRead: compressHardRead(v); break;
+        case ExactMatch: compressExactRead(v); break;
+        case ContigRead: compressContigRead(v, aux); break;
+        default: break;
+        }
+        compressQuality(v);
+        if (pe) compressPair(v, type);
+    }
+    // LzCompressorSE::CompressMatch / LzCompressorPE::CompressMatch
+    void compressMatch(int32_t n)
+    {
+        const Node& node = nodes[n];
+        auto& hist = lzStack.back().history;
+        uint32_t lzId = 0;
+        for (size_t k = hist.size(); k > 0; --k, ++lzId) if (hist[k - 1] == node.lzVrec) break;
+        if (lzId == hist.size()) throw std::runtime_error("LZ parent not found in history");
+        int32_t as = node.shift * par.shiftCost; if (as < 0) as = -as;
+        const uint32_t mism = (uint32_t)(node.cost - as) / (uint32_t)par.mismatchCost;
+        compressNormalMatch(node, lzId, mism > par.maxMismatchesLowCost);
+        hist.push_back(node.vrec);
+        compressId(node.vrec);
+        compressQuality(node.vrec);
+        if (pe) compressPair(node.vrec, LzMatch);
+    }
+    void compressExactChildren(int32_t n) { for (size_t k = 0; k < nodes[n].em.size(); ++k) compressRead(nodes[n].em[k], ExactMatch); }
+
+    void storeContigDefinition(const Contig& d, const uint8_t* mainSeq, uint32_t mainSigPos)
+    {
+        (void)mainSeq;
+        const uint32_t lzFirst = d.readLen - mainSigPos, lzSecond = lzFirst + d.readLen;
+        if (d.readLen < 128) {
+            const int32_t r1 = ShiftOffset - (int32_t)d.readLen / 2, r2 = ShiftOffset - (int32_t)d.readLen * 3 / 2;
+            putByte(S_TreeShift, (uint32_t)((int32_t)d.rangeFirst + r1));
+            putByte(S_TreeShift, (uint32_t)((int32_t)d.rangeSecond + r2));
+        } else {
+            putByte(S_TreeShift, d.rangeFirst);
+            const int32_t rangeDiff = (int32_t)d.rangeSecond - (int32_t)d.rangeFirst;
+            const int32_t rescale = (int32_t)sigLen + 2 + 2;      // Default::BeginCut + Default::EndCut
+            putByte(S_TreeShift, (uint32_t)(rangeDiff - (int32_t)d.readLen + rescale));
+        }
+        for (uint32_t i = d.rangeFirst; i < d.rangeSecond; ++i) {
+            if (i == d.readLen) { i += sigLen - 1; continue; }
+            consMatchRle.put(d.variant[i] == 0);
+            if (i < lzFirst + 2 || i >= lzSecond - 2 || d.variant[i] != 0) putSym(S_CLetters, d2i((uint8_t)d.sequence[i]), d2i('N'));
+        }
+    }
+    void compressContig(int32_t n)
+    {
+        const Contig& c = contigs[nodes[n].contig];
+        consStack.push_back(ConsEnc());
+        consStack.back().def = &c; consStack.back().lastMinimPos = (int32_t)minimPos(nodes[n].vrec);
+        putByte(S_Flag, ReadContigGroupStart);
+        storeContigDefinition(c, seq(nodes[n].vrec), minimPos(nodes[n].vrec));
+        bool first = true;
+        for (int32_t mn : c.nodes) {
+            if (!first) putByte(S_Flag, ReadContigGroupNext);
+            compressRead(nodes[mn].vrec, ContigRead, first);
+            first = false;
+            lzStack.back().history.push_back(nodes[mn].vrec);
+            if (nodes[mn].hasEm) compressExactChildren(mn);
+            if (!nodes[mn].trees.empty()) compressSubTree(mn);
+        }
+        putByte(S_Flag, ReadGroupEnd);
+        consStack.pop_back();
+    }
+    void compressNode(int32_t n)
+    {
+        if (nodes[n].type == TYPE_HARD) {
+            lzStack.back().history.clear();
+            compressRead(nodes[n].vrec, HardRead);
+            lzStack.back().history.push_back(nodes[n].vrec);
+            if (nodes[n].hasEm) compressExactChildren(n);
+            if (!nodes[n].trees.empty()) compressSubTree(n);
+        } else {
+            compressMatch(n);
+            if (nodes[n].hasEm) compressExactChildren(n);
+            if (!nodes[n].trees.empty()) compressSubTree(n);
+            if (nodes[n].contig >= 0) compressContig(n);
+        }
+    }
+    void encodeTree(int32_t root, bool skipRoot)
+    {
+        std::deque<int32_t> nq;
+        if (skipRoot) nq.insert(nq.end(), nodes[root].children.begin(), nodes[root].children.end());
+        else nq.push_back(root);
+        while (!nq.empty()) {
+            const int32_t n = nq.front(); nq.pop_front();
+            compressNode(n);
+            nq.insert(nq.end(), nodes[n].children.begin(), nodes[n].children.end());
+        }
+    }
+    void compressSubTree(int32_t n)
+    {
+        const int32_t rootV = nodes[n].vrec;
+        const std::vector<uint32_t> treeList = nodes[n].trees;      // copy: nodes may reallocate below
+        for (uint32_t t : treeList) {
+            const TreeIn& tree = B->trees[t];
+            consStack.push_back(ConsEnc());
+            consStack.back().lastMinimPos = tree.mainSignaturePos;
+            const uint32_t rl = seqLen(rootV);
+            if (rl * 2 >= 256) putByte(S_TreeShift, (uint32_t)tree.mainSignaturePos);
+            else putByte(S_TreeShift, (uint32_t)(ShiftOffset + (tree.mainSignaturePos - (int32_t)minimPos(rootV))));
+            putByte(S_Flag, ReadTreeGroupStart);
+            lzStack.push_back(LzContext());
+            // local copy of the root with the sub-tree's signature position
+            const int32_t localV = (int32_t)vrecs.size();
+            vrecs.push_back(VRec{vrecs[rootV].rec, (uint16_t)tree.mainSignaturePos});
+            const int32_t localRoot = (int32_t)nodes.size();
+            nodes.push_back(Node());
+            nodes[localRoot].vrec = localV; nodes[localRoot].type = TYPE_NONE;
+            lzStack.back().history.push_back(localV);
+            std::vector<int32_t> order(tree.nodeCount);
+            for (uint32_t k = 0; k < tree.nodeCount; ++k) order[k] = (int32_t)(tree.nodeBegin - nodeBase + k);
+            std::vector<int32_t> roots;
+            constructMatchTree(order, roots, localRoot);
+            const size_t contigMark = contigs.size();
+            bool isFirst = true;
+            for (int32_t root : roots) {
+                if (!nodes[root].children.empty()) buildContigs(root);
+                encodeTree(root, isFirst);
+                isFirst = false;
+            }
+            (void)contigMark;
+            putByte(S_Flag, ReadGroupEnd);
+            consStack.pop_back();
+            lzStack.pop_back();
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // PE mate coder -- filled in by frontend_pe.inc
+    void compressPair(int32_t v, ReadMatchType seType);
+    void resetPair();
+    struct PairState;
+    PairState* pairState = nullptr;
+
+    // ------------------------------------------------------------------------------------------
+    void initNodes(const BinIn& bin)
+    {
+        // node table: Batch nodes [nodeBase, nodeEnd) of this bin; bins own contiguous node ranges
+        nodeBase = B->topNodes[bin.topBegin];
+        uint32_t nodeEnd = nodeBase;
+        for (uint32_t k = 0; k < bin.topCount; ++k) nodeEnd = std::max(nodeEnd, B->topNodes[bin.topBegin + k] + 1);
+        // sub-tree nodes are allocated after their owner, so scan trees reachable from the range
+        for (uint32_t i = nodeBase; i < nodeEnd; ++i) {
+            const NodeIn& ni = B->nodes[i];
+            for (uint32_t t = 0; t < ni.treeCount; ++t) nodeEnd = std::max(nodeEnd, B->trees[ni.treeBegin + t].nodeBegin + B->trees[ni.treeBegin + t].nodeCount);
+        }
+        recBase = bin.recBegin;
+        vrecs.resize(bin.recCount);
+        for (uint32_t i = 0; i < bin.recCount; ++i) vrecs[i] = VRec{recBase + i, B->recs[recBase + i].minimPos};
+        nodes.clear(); nodes.resize(nodeEnd - nodeBase);
+        for (uint32_t i = nodeBase; i < nodeEnd; ++i) {
+            const NodeIn& ni = B->nodes[i]; Node& n = nodes[i - nodeBase];
+            n.vrec = (int32_t)(ni.rec - recBase);
+            if (ni.emCount) { n.hasEm = true; n.em.resize(ni.emCount); for (uint32_t k = 0; k < ni.emCount; ++k) n.em[k] = (int32_t)(B->emRecs[ni.emBegin + k] - recBase); }
+            if (ni.treeCount) { n.trees.resize(ni.treeCount); for (uint32_t k = 0; k < ni.treeCount; ++k) n.trees[k] = ni.treeBegin + k; }
+        }
+        contigs.clear();
+    }
+
+    void encodeLz(const Batch& batch, const BinIn& bin, BinStreams& o)
+    {
+        B = &batch; out = &o; curSig = bin.signature;
+        o.reset(pe ? S_PE_COUNT : S_SE_COUNT);
+        initNodes(bin);
+        lzStack.clear(); consStack.clear();
+        lzStack.push_back(LzContext());
+        matchRle.start(&o.s[S_Match]); consMatchRle.start(&o.s[S_CMatch]); lzRle0.start(&o.s[S_LzId]);
+        if (pe) { matchRlePE.start(&o.s[S_MatchRlePE]); resetPair(); }
+        // CompressRecords (FastqCompressor.cpp:1228-1276): sort the top-level nodes, match, then per root contigs + BFS
+        std::vector<int32_t> order(bin.topCount);
+        for (uint32_t k = 0; k < bin.topCount; ++k) order[k] = (int32_t)(B->topNodes[bin.topBegin + k] - nodeBase);
+        introsort(order.data(), order.size(), [&](int32_t a, int32_t b) { return compareReads(nodes[a].vrec, nodes[b].vrec); });
+        std::vector<int32_t> roots;
+        constructMatchTree(order, roots, -1);
+#ifdef FS_DEBUG_DUMP
+        if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == bin.signature) {
+            auto H = [&](int32_t n) { if (n < 0) return std::string("-"); const Rec& r = R(nodes[n].vrec); return std::string((const char*)B->head.data() + r.headOff, r.headLen); };
+            for (int32_t n : order) printf("N %s type %d parent %s shift %d cost %d nomism %d em %d trees %d\n", H(n).c_str(), nodes[n].type, H(nodes[n].parent).c_str(), nodes[n].shift, nodes[n].cost, (int)nodes[n].noMismatches, (int)nodes[n].em.size(), (int)nodes[n].trees.size());
+            for (int32_t root : roots) if (!nodes[root].children.empty()) buildContigs(root);
+            for (auto& c : contigs) { printf("C range %u %u vars %u members", c.rangeFirst, c.rangeSecond, c.variantsCount); for (int32_t mm : c.nodes) printf(" %s", H(mm).c_str()); printf("\n"); }
+            for (int32_t n : order) if (nodes[n].contig >= 0) printf("M %s\n", H(n).c_str());
+            for (int32_t n : order) { printf("K %s :", H(n).c_str()); for (int32_t c : nodes[n].children) printf(" %s", H(c).c_str()); printf("\n"); }
+            fflush(stdout); exit(0);
+        }
+#endif
+        for (int32_t root : roots) {
+            if (!nodes[root].children.empty()) buildContigs(root);
+            encodeTree(root, false);
+        }
+        matchRle.end(); consMatchRle.end(); lzRle0.end();
+        if (pe) matchRlePE.end();
+    }
+};
+
+}  // namespace fs
+
+#include "frontend_pe.inc"
+
+namespace fs {
+
+BinEncoder::BinEncoder(const BinModuleConfigRaw& cfg, const HeaderStats& head, const PackParams& par) : impl_(new Impl(cfg, head, par)) {}
+BinEncoder::~BinEncoder() { if (impl_) { impl_->resetPair(); } delete impl_; }
+void BinEncoder::encodeLz(const Batch& batch, const BinIn& bin, BinStreams& out) { impl_->encodeLz(batch, bin, out); }
+
+}  // namespace fs

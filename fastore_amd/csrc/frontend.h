@@ -1,0 +1,77 @@
+// Per-bin read-cluster modelling ("front end" of the hot path, SURVEY §8 a3-a6, a8, a10, a11,
+// a14): sorts the bin, builds the LZ match tree, the contigs, walks the trees in the
+// reference's order and emits the work streams that the device entropy-codes.
+//
+// Round-1 placement: this stage runs on host cores (one bin per task, independent bins) and feeds
+// the HIP kernels; DESIGN.md lists it as the next stage to move on-device.  Every function cites
+// the reference code whose decisions it reproduces bit-for-bit.
+#pragma once
+#include <stdint.h>
+#include <deque>
+#include <vector>
+#include "format.h"
+
+namespace fs {
+
+struct PackParams {                       // fastore_pack CLI knobs (fastore_pack/Params.h:18-147)
+    uint32_t minBinSize = 256;            // -f
+    int32_t encodeThreshold = 0;          // -e (0 = auto: seqLen / 2)
+    int32_t pairEncodeThreshold = 0;      // -E
+    int32_t shiftCost = 1;                // -s
+    int32_t mismatchCost = 2;             // -m
+    uint32_t maxLzWindowSize = 255;       // -w  (MAX_LZ_SE)
+    uint32_t maxPairLzWindowSize = 255;   // -W  (MAX_LZ_PE)
+    bool extraReduceHardReads = false;    // -r
+    bool extraReduceExpensiveLzMatches = false;   // -l
+    uint32_t beginCut = 2, endCut = 2;
+    uint32_t maxNewVariantsPerRead = 1;   // -n
+    uint32_t maxRecordShiftDifference = 0;   // -q
+    uint32_t maxHammingDistance = 8;      // -d
+    uint32_t minConsensusSize = 10;       // -c
+    uint32_t maxMismatchesLowCost = 4;
+};
+
+// stream indices: fastore_pack/CompressedBlockData.h:97-154
+enum Stream {
+    S_Flag = 0, S_LettersX, S_Rev, S_HardReads, S_LzId, S_Shift, S_Match, S_MatchBinary, S_TreeShift, S_CMatch, S_CShift, S_CLetters,
+    S_Quality, S_IdToken, S_IdValue, S_SE_COUNT,
+    S_FlagPE = S_SE_COUNT, S_LettersXPE, S_SwapPE, S_HardPE, S_LzIdPE, S_ShiftPE, S_MatchRlePE, S_MatchBinaryPE, S_PE_COUNT
+};
+
+struct BinStreams {
+    std::vector<uint8_t> s[S_PE_COUNT];   // P streams: raw bytes; R streams: (symbol, ctx0) byte pairs
+    uint64_t rawIdSize = 0;
+    uint32_t nStreams = S_SE_COUNT;
+    void reset(uint32_t n) { nStreams = n; rawIdSize = 0; for (auto& v : s) v.clear(); }
+};
+
+// which streams are range-coded in place (true) vs PPMd-compressed (false), and with which model
+// (ILzCompressorBase::SetupBufferMask, FastqCompressor.h:557-581; PE: FastqCompressor.cpp:4309-4319)
+bool streamIsRangeCoded(uint32_t stream, uint32_t qualityMethod);
+uint32_t streamModel(uint32_t stream, uint32_t qualityMethod);
+
+class BinEncoder {
+public:
+    BinEncoder(const BinModuleConfigRaw& cfg, const HeaderStats& head, const PackParams& par);
+    // standard bin: LzCompressorSE/PE::Compress up to (not including) CompressBuffers
+    void encodeLz(const Batch& batch, const BinIn& bin, BinStreams& out);
+
+private:
+    struct Impl;
+    Impl* impl_;
+public:
+    ~BinEncoder();
+    BinEncoder(const BinEncoder&) = delete;
+    BinEncoder& operator=(const BinEncoder&) = delete;
+};
+
+// read-id tokeniser shared with the raw (block 0) coder: IHeaderStoreBase::CompressReadId
+// (fastore_pack/FastqCompressor.cpp:504-583).  Appends (symbol, ctx) pairs.
+struct FieldSpec { uint8_t method; };     // 0 const, 1 token, 2 raw numeric
+void compressReadId(const HeaderStats& head, const uint8_t* h, uint32_t headLen, std::vector<uint8_t>& tokenPairs,
+                    std::vector<uint8_t>& valuePairs);
+// IQualityStoreBase::CompressReadQuality for MET_NONE / MET_BINARY / MET_8BIN (FastqCompressor.cpp:221-320)
+void compressReadQuality(const BinModuleConfigRaw& cfg, const uint8_t* seq, const uint8_t* qua, uint32_t len, bool reverse,
+                         std::vector<uint8_t>& out);
+
+}  // namespace fs

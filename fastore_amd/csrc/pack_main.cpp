@@ -1,0 +1,84 @@
+// fastore_pack -- command-line front of the MI355X-native pack path.
+// Keeps the reference's `fastore_pack e` surface (fastore_pack/main.cpp:26-41, 165-330): first
+// argument e|d, >= 3 arguments, -i<prefix> -o<prefix> -t<n> [-z] [-v] and the matcher/consensus
+// knobs; errors as "Error: <what>" on stderr with exit status 255.  `d` (decode) is outside this
+// build's scope: it is delegated to the reference binary when FASTORE_PACK_REF is set.
+// New flags: -g<device> (HIP device ordinal), -R<rank>/-N<world> (bin sharding).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <string>
+#include "../../include/fastore_amd.h"
+
+static void usage()
+{
+    fprintf(stderr, "\n\n\t\t--- FaStore (MI355X pack path) ---\n\n\n"
+                    "fastore_pack -- FASTQ reads compression tool\n\n"
+                    "usage:\tfastore_pack <e|d> [options] -i<input_file> -o<output_file>\n"
+                    "\t-i<file>\t: input file(s) prefix\t-o<file>\t: output files prefix\n"
+                    "\t-z\t\t: use paired-end mode\n"
+                    "\t-f<n> -e<n> -m<n> -s<n> -w<n> -r -l -E<n> -W<n> -c<n> -q<n> -n<n> -d<n>\t: as the reference\n"
+                    "\t-t<n>\t\t: host threads\n\t-g<n>\t\t: HIP device ordinal\n\t-v\t\t: verbose mode\n");
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 1 + 3 || (argv[1][0] != 'e' && argv[1][0] != 'd')) { usage(); return 255; }
+    if (argv[1][0] == 'd') {
+        const char* ref = getenv("FASTORE_PACK_REF");
+        if (!ref) { fprintf(stderr, "Error: decode mode is served by the reference fastore_pack; set FASTORE_PACK_REF to its path\n"); return 255; }
+        argv[0] = (char*)ref;
+        execv(ref, argv);
+        perror("Error: execv"); return 255;
+    }
+    fsgpu_config cfg; fsgpu_config_defaults(&cfg);
+    std::string in, out; int verbose = 0; int threads = 0; bool pe = false;
+    for (int i = 2; i < argc; ++i) {
+        const char* p = argv[i];
+        if (p[0] != '-') continue;
+        const size_t len = strlen(p);
+        int v = -1;
+        if (len > 2 && len < 10) v = atoi(p + 2);
+        switch (p[1]) {
+        case 'i': in = p + 2; break;
+        case 'o': out = p + 2; { size_t sp = out.find_first_of(" \n"); if (sp != std::string::npos) out = out.substr(0, sp); } break;
+        case 't': threads = v; break;
+        case 'v': verbose = 1; break;
+        case 'z': pe = true; break;
+        case 'f': cfg.min_bin_size = v; break;
+        case 'w': cfg.max_lz_window = v; break;
+        case 'W': cfg.max_pair_lz_window = v; break;
+        case 'e': cfg.encode_threshold = v; break;
+        case 'E': cfg.pair_encode_threshold = v; break;
+        case 's': cfg.shift_cost = v; break;
+        case 'm': cfg.mismatch_cost = v; break;
+        case 'r': cfg.extra_reduce_hard_reads = 1; break;
+        case 'l': cfg.extra_reduce_expensive_lz = 1; break;
+        case 'q': cfg.max_record_shift_diff = v; break;
+        case 'n': cfg.max_new_variants_per_read = v; break;
+        case 'd': cfg.max_hamming_distance = v; break;
+        case 'c': cfg.min_consensus_size = v; break;
+        case 'g': cfg.device_id = v; break;
+        case 'R': cfg.rank = v; break;
+        case 'N': cfg.world_size = v; break;
+        }
+    }
+    (void)pe;   // the read type is taken from the .bmeta config, as the reference effectively does for the data path
+    if (in.empty()) { fprintf(stderr, "Error: no input file specified\n"); return 255; }
+    if (out.empty()) { fprintf(stderr, "Error: no output file(s) specified\n"); return 255; }
+    if (threads < 0 || threads > 64) { fprintf(stderr, "Error: invalid number of threads specified\n"); return 255; }
+    cfg.host_threads = (uint32_t)threads;
+    fsgpu_ctx* ctx = fsgpu_create(&cfg);
+    if (!ctx) { fprintf(stderr, "Error: %s\n", fsgpu_create_error()); return 255; }
+    const int rc = fsgpu_pack_file(ctx, in.c_str(), out.c_str(), verbose);
+    if (rc != 0) { fprintf(stderr, "Error: %s\n", fsgpu_last_error(ctx)); fsgpu_destroy(ctx); return 255; }
+    if (verbose) {
+        fsgpu_stats st; fsgpu_get_stats(ctx, &st);
+        fprintf(stderr, "device %s: %llu bins, %llu records, encode kernel %.1f ms, assemble %.1f ms, front end %.1f ms, block0 %.1f ms, total %.1f ms\n",
+                fsgpu_device_name(ctx), (unsigned long long)st.bins, (unsigned long long)st.records, st.encode_kernel_ms, st.assemble_kernel_ms,
+                st.frontend_ms, st.block0_ms, st.total_ms);
+    }
+    fsgpu_destroy(ctx);
+    return 0;
+}

@@ -1,0 +1,307 @@
+#include "packer.h"
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <atomic>
+#include <memory>
+#include <chrono>
+#include <stdexcept>
+#include <thread>
+#include "bitio.h"
+#include "hostcoders.h"
+
+namespace fs {
+
+namespace {
+double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+template <class F> void parallelFor(uint32_t n, uint32_t threads, F f)
+{
+    if (threads <= 1 || n <= 1) { for (uint32_t i = 0; i < n; ++i) f(i, 0u); return; }
+    std::atomic<uint32_t> next(0);
+    std::vector<std::thread> pool;
+    std::vector<std::string> errors(threads);
+    const uint32_t t = std::min(threads, n);
+    for (uint32_t k = 0; k < t; ++k)
+        pool.emplace_back([&, k]() {
+            try { for (;;) { const uint32_t i = next.fetch_add(1); if (i >= n) break; f(i, k); } }
+            catch (const std::exception& e) { errors[k] = e.what(); next.store(n); }
+        });
+    for (auto& th : pool) th.join();
+    for (auto& e : errors) if (!e.empty()) throw std::runtime_error(e);
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+void parseHeaderFields(const uint8_t* p, size_t n, bool pairedEnd, HeaderStats& out)
+{
+    out = HeaderStats();
+    if (!p || n == 0) return;
+    BitReader r(p, n);
+    const uint32_t fields = r.getByte();
+    out.fields.resize(fields);
+    for (HeaderField& f : out.fields) {
+        f.isNumeric = r.getByte() != 0; f.isConst = r.getByte() != 0; f.separator = (char)r.getByte();
+        if (f.isNumeric) { f.minValue = r.get8Bytes(); if (!f.isConst) f.maxValue = r.get8Bytes(); }
+        else {
+            uint32_t possible = 1;
+            if (!f.isConst) possible = r.get2Bytes();
+            std::set<std::string> vals;
+            for (uint32_t i = 0; i < possible; ++i) { const uint32_t ss = r.getByte(); std::string s(ss, '\0'); r.getBytes(&s[0], ss); vals.insert(s); }
+            f.possibleValues.assign(vals.begin(), vals.end());
+        }
+    }
+    if (pairedEnd) out.pairedEndFieldIdx = r.getByte();
+}
+
+void serializeHeaderFields(const HeaderStats& head, bool pairedEnd, std::vector<uint8_t>& out)
+{
+    ByteWriter w;
+    w.put((uint32_t)head.fields.size());
+    for (const HeaderField& f : head.fields) {
+        w.put(f.isNumeric); w.put(f.isConst); w.put((uint8_t)f.separator);
+        if (f.isNumeric) { w.put8(f.minValue); if (!f.isConst) w.put8(f.maxValue); }
+        else {
+            if (!f.isConst) w.put2((uint32_t)f.possibleValues.size());
+            for (const std::string& s : f.possibleValues) { w.put((uint32_t)s.size()); w.putBytes(s.data(), s.size()); }
+        }
+    }
+    if (pairedEnd) w.put(head.pairedEndFieldIdx);
+    out = std::move(w.b);
+}
+
+// ------------------------------------------------------------------------------------------------
+ArchiveWriter::~ArchiveWriter() { if (meta_) fclose(meta_); if (data_) fclose(data_); }
+
+void ArchiveWriter::start(const std::string& prefix, const BinModuleConfigRaw& cfg)
+{
+    meta_ = fopen((prefix + ".cmeta").c_str(), "wb");
+    data_ = fopen((prefix + ".cdata").c_str(), "wb");
+    if (!meta_ || !data_) throw std::runtime_error("Cannot open file: " + prefix + ".cmeta/.cdata");
+    memset(&conf_, 0, sizeof conf_);                       // padding bytes are zero here (stack garbage in the reference)
+    conf_.archType = cfg.archiveType; conf_.minParams = cfg.minimizer;
+    conf_.quaParams.method = cfg.quaParams.method; conf_.quaParams.binaryThreshold = cfg.quaParams.binaryThreshold;
+    conf_.quaParams.qvzOpts.verbose = cfg.quaParams.qvzOpts.verbose; conf_.quaParams.qvzOpts.stats = cfg.quaParams.qvzOpts.stats;
+    conf_.quaParams.qvzOpts.uncompressed = cfg.quaParams.qvzOpts.uncompressed; conf_.quaParams.qvzOpts.distortion = cfg.quaParams.qvzOpts.distortion;
+    conf_.quaParams.qvzOpts.D = cfg.quaParams.qvzOpts.D;    // the two char* members are process-local garbage: left null
+    static const uint8_t zeros[24] = {0};
+    fwrite(zeros, 1, 24, meta_);
+}
+
+void ArchiveWriter::writeBlock(const uint8_t* data, uint64_t size, uint32_t signature)
+{
+    sizes_.push_back(size); sigs_.push_back(signature);
+    if (fwrite(data, 1, size, data_) != size) throw std::runtime_error("Cannot write .cdata");
+    dataBytes_ += size;
+}
+
+void ArchiveWriter::finish(const HeaderStats& head)
+{
+    const uint64_t footerOffset = 24;
+    const uint32_t count = (uint32_t)sizes_.size();
+    fwrite(&count, 4, 1, meta_);
+    fwrite(sizes_.data(), 8, sizes_.size(), meta_);
+    fwrite(sigs_.data(), 4, sigs_.size(), meta_);
+    fwrite(&conf_, sizeof conf_, 1, meta_);
+    if (conf_.archType.readsHaveHeaders) {
+        std::vector<uint8_t> blob;
+        serializeHeaderFields(head, conf_.archType.readType == READ_PE, blob);
+        fwrite(blob.data(), 1, blob.size(), meta_);
+    }
+    const uint64_t end = (uint64_t)ftello(meta_);
+    const uint64_t footerSize = end - footerOffset;
+    fseeko(meta_, 0, SEEK_SET);
+    fwrite(&footerOffset, 8, 1, meta_); fwrite(&footerSize, 8, 1, meta_);
+    fclose(meta_); meta_ = nullptr;
+    fclose(data_); data_ = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+void Context::compressBatch(const Batch& batch)
+{
+    using namespace fsdev;
+    const uint32_t nBins = (uint32_t)batch.bins.size();
+    blocks.clear(); blockSizes.clear();
+    if (nBins == 0) return;
+    const double t0 = nowMs();
+    std::vector<BinStreams> st(nBins);
+    {
+        std::vector<std::unique_ptr<BinEncoder>> encs(hostThreads);
+        parallelFor(nBins, hostThreads, [&](uint32_t b, uint32_t tid) {
+            if (!encs[tid]) encs[tid].reset(new BinEncoder(binCfg, head, par));
+            encs[tid]->encodeLz(batch, batch.bins[b], st[b]);
+        });
+    }
+    stats.frontend_ms += nowMs() - t0;
+    const uint32_t qm = binCfg.quaParams.method;
+    std::vector<StreamItem> items; std::vector<BlockPlan> plans(nBins);
+    uint64_t inBytes = 0;
+    for (uint32_t b = 0; b < nBins; ++b) {
+        const BinIn& bin = batch.bins[b]; BinStreams& bs = st[b];
+        BlockPlan& pl = plans[b]; memset(&pl, 0, sizeof pl);
+        pl.signature = bin.signature; pl.records = bin.recCount; pl.raw_dna_size = bin.rawDnaSize; pl.raw_id_size = bs.rawIdSize;
+        pl.min_len = (uint8_t)bin.minLen; pl.max_len = (uint8_t)bin.maxLen; pl.has_headers = binCfg.archiveType.readsHaveHeaders != 0;
+        pl.n_streams = bs.nStreams; pl.first_item = (uint32_t)items.size();
+        uint32_t k = 0;
+        for (uint32_t s = 0; s < bs.nStreams; ++s) if (streamIsRangeCoded(s, qm)) pl.copy_order[k++] = s;
+        for (uint32_t s = 0; s < bs.nStreams; ++s) if (!streamIsRangeCoded(s, qm)) pl.copy_order[k++] = s;
+        for (uint32_t s = 0; s < bs.nStreams; ++s) {
+            const bool rc = streamIsRangeCoded(s, qm);
+            const uint64_t bytes = bs.s[s].size();
+            if (bytes > 0xF0000000ull) throw std::runtime_error("stream larger than 4 GiB");
+            StreamItem it; memset(&it, 0, sizeof it);
+            it.bin = b; it.in_off = inBytes;
+            if (rc) { it.kind = KIND_RC_BASE + streamModel(s, qm); it.in_len = (uint32_t)(bytes / 2); it.out_cap = 2 * it.in_len + 32; pl.work_size[s] = ~0ull; }
+            else { it.kind = KIND_PPMD; it.in_len = (uint32_t)bytes; it.out_cap = (uint32_t)(bytes + bytes / 8 + 64); pl.work_size[s] = bytes; }
+            items.push_back(it);
+            inBytes += (bytes + 15) & ~15ull;
+        }
+        stats.records += bin.recCount;
+    }
+    std::vector<uint8_t> input(inBytes + 16);
+    parallelFor(nBins, hostThreads, [&](uint32_t b, uint32_t) {
+        const BlockPlan& pl = plans[b];
+        for (uint32_t s = 0; s < pl.n_streams; ++s) {
+            const auto& v = st[b].s[s];
+            if (!v.empty()) memcpy(input.data() + items[pl.first_item + s].in_off, v.data(), v.size());
+        }
+    });
+    st.clear(); st.shrink_to_fit();
+    if (fsengine::encode_batch(dev, input.data(), inBytes, items, plans, blocks, blockSizes, &timing) != 0)
+        throw std::runtime_error(std::string("device: ") + dev->err);
+    stats.bins += nBins;
+    for (uint32_t b = 0; b < nBins; ++b) {
+        const BinIn& bin = batch.bins[b];
+        uint64_t a = blockSizes[b];
+        for (uint32_t r = bin.recBegin; r < bin.recBegin + bin.recCount; ++r) { const Rec& rc = batch.recs[r]; a += 2ull * (rc.seqLen + rc.auxLen) + rc.headLen; }
+        stats.algorithmic_bytes += a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RawCompressorSE/PE::Compress (fastore_pack/FastqCompressor.cpp:3407-3600, 5426-5441) preceded by the
+// un-reverse-complement / un-swap pass of CompressorModule.cpp:136-149, 718-733.
+void Context::compressRawBlock(Batch& batch, std::vector<uint8_t>& out)
+{
+    const BinIn& bin = batch.bins.at(0);
+    const bool pe = binCfg.archiveType.readType == READ_PE;
+    const bool hasHeaders = binCfg.archiveType.readsHaveHeaders != 0;
+    const uint32_t qm = binCfg.quaParams.method;
+    auto comp = [](uint8_t c) -> uint8_t { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case 'N': return 'N'; } return 0xFF; };
+    for (uint32_t i = bin.recBegin; i < bin.recBegin + bin.recCount; ++i) {
+        Rec& r = batch.recs[i];
+        uint8_t* s = batch.seq.data() + r.seqOff; uint8_t* q = batch.qua.data() + r.seqOff;
+        const uint32_t len = (uint32_t)r.seqLen + r.auxLen;
+        if (r.flags & FLAG_REVERSE) {
+            for (uint32_t a = 0, b = len - 1; a < b; ++a, --b) { const uint8_t t = comp(s[a]); s[a] = comp(s[b]); s[b] = t; std::swap(q[a], q[b]); }
+            if (len & 1) s[len / 2] = comp(s[len / 2]);
+            r.flags &= ~FLAG_REVERSE;
+        }
+        if (pe && (r.flags & FLAG_SWAPPED)) {
+            for (uint32_t a = 0; a < r.seqLen; ++a) { std::swap(s[a], s[a + r.seqLen]); std::swap(q[a], q[a + r.seqLen]); }
+            r.flags &= ~FLAG_SWAPPED;
+        }
+        r.minimPos = 0;
+    }
+    std::vector<uint8_t> tok, val, dna, quaStream;
+    uint64_t rawId = 0;
+    for (uint32_t i = bin.recBegin; i < bin.recBegin + bin.recCount; ++i) {
+        const Rec& r = batch.recs[i];
+        const uint8_t* s = batch.seq.data() + r.seqOff; const uint8_t* q = batch.qua.data() + r.seqOff;
+        if (hasHeaders) { compressReadId(head, batch.head.data() + r.headOff, r.headLen, tok, val); rawId += r.headLen; }
+        dna.insert(dna.end(), s, s + r.seqLen + r.auxLen);
+        compressReadQuality(binCfg, s, q, r.seqLen, false, quaStream);
+        if (pe) compressReadQuality(binCfg, s + r.seqLen, q + r.seqLen, r.auxLen, false, quaStream);
+    }
+    std::vector<uint8_t> cTok, cVal, cDna, cQua;
+    std::thread tq([&]() { if (qm == MET_NONE) fshost::ppmdEncode(quaStream.data(), quaStream.size(), cQua); else fshost::rcEncode(streamModel(S_Quality, qm), quaStream.data(), quaStream.size() / 2, cQua); });
+    std::thread ti([&]() { if (hasHeaders) { fshost::rcEncode(5, tok.data(), tok.size() / 2, cTok); fshost::rcEncode(5, val.data(), val.size() / 2, cVal); } });
+    fshost::ppmdEncode(dna.data(), dna.size(), cDna);
+    tq.join(); ti.join();
+    ByteWriter w;
+    w.put4(bin.signature); w.put8(bin.recCount); w.put(bin.minLen); w.put(bin.maxLen);
+    w.put8(bin.rawDnaSize);
+    const uint64_t footerOff = 74 + cTok.size() + cVal.size() + cDna.size() + cQua.size();
+    w.put8(footerOff); w.put4(1);
+    if (hasHeaders) w.put8(rawId);
+    w.put8(cDna.size()); w.put8(cQua.size());
+    if (hasHeaders) { w.put8(cTok.size()); w.put8(cVal.size()); }
+    while (w.size() < 74) w.put(0);                         // RawBlockHeader::Size, zero-filled (FastqCompressor.cpp:3496)
+    w.putBytes(cTok.data(), cTok.size()); w.putBytes(cVal.data(), cVal.size());
+    w.putBytes(cDna.data(), cDna.size()); w.putBytes(cQua.data(), cQua.size());
+    w.put(0);                                               // footer
+    out = std::move(w.b);
+    stats.block0_records = bin.recCount; stats.block0_bytes = out.size();
+}
+
+// ------------------------------------------------------------------------------------------------
+void Context::packFile(const std::string& inPrefix, const std::string& outPrefix, bool verbose)
+{
+    const double tStart = nowMs();
+    BinFile bf;
+    bf.open(inPrefix, par.minBinSize);
+    binCfg = bf.config(); head = bf.headData(); haveArchive = true;
+    const uint32_t world = cfg.world_size ? cfg.world_size : 1, rank = cfg.rank;
+    ArchiveWriter aw;
+    aw.start(world > 1 ? outPrefix + ".part" + std::to_string(rank) : outPrefix, binCfg);
+
+    // block 0: merged small bins + N bin (rank 0 only); compressed on host cores while the GPU works
+    Batch b0; std::vector<uint8_t> block0; std::thread t0; std::string t0err; double t0ms = 0;
+    bool haveBlock0 = false;
+    if (rank == 0) {
+        uint64_t rawDna = 0;
+        for (uint32_t sig : bf.smallSignatures()) { bf.unpack(sig, b0, b0.bins.empty()); rawDna += bf.bins().at(sig).totalRawDnaSize; }
+        if (bf.hasNBin()) { bf.unpack(bf.nSignature(), b0, b0.bins.empty()); rawDna += bf.bins().at(bf.nSignature()).totalRawDnaSize; }
+        if (!b0.recs.empty()) {
+            haveBlock0 = true;
+            b0.bins[0].signature = bf.nSignature(); b0.bins[0].rawDnaSize = rawDna;
+            t0 = std::thread([&]() { const double a = nowMs(); try { compressRawBlock(b0, block0); } catch (const std::exception& e) { t0err = e.what(); } t0ms = nowMs() - a; });
+        }
+    }
+    const auto& stdSigs = bf.stdSignatures();
+    std::vector<uint32_t> mine;
+    for (uint32_t i = 0; i < stdSigs.size(); ++i) if (i % world == rank) mine.push_back(stdSigs[i]);
+    const uint64_t budget = cfg.batch_bases ? cfg.batch_bases : (512ull << 20);
+    struct Pending { std::vector<uint8_t> data; std::vector<uint64_t> sizes; std::vector<uint32_t> sigs; };
+    std::vector<Pending> pending;
+    bool block0Written = !haveBlock0;
+    auto flush = [&](bool wait) {
+        if (!block0Written) {
+            if (!wait) return;
+            t0.join(); if (!t0err.empty()) throw std::runtime_error(t0err);
+            stats.block0_ms = t0ms;
+            aw.writeBlock(block0.data(), block0.size(), bf.nSignature());
+            block0Written = true;
+        }
+        for (auto& p : pending) { uint64_t off = 0; for (size_t k = 0; k < p.sizes.size(); ++k) { aw.writeBlock(p.data.data() + off, p.sizes[k], p.sigs[k]); off += p.sizes[k]; } }
+        pending.clear();
+    };
+    Batch batch; size_t next = 0, done = 0;
+    while (next < mine.size()) {
+        batch.clear();
+        double tio = nowMs();
+        while (next < mine.size() && (batch.bins.empty() || batch.seq.size() + bf.bins().at(mine[next]).totalRawDnaSize <= budget)) {
+            bf.unpack(mine[next], batch, true); ++next;
+        }
+        stats.io_ms += nowMs() - tio;
+        compressBatch(batch);
+        Pending p; p.data = std::move(blocks); p.sizes = blockSizes;
+        for (const auto& b : batch.bins) p.sigs.push_back(b.signature);
+        pending.push_back(std::move(p));
+        done += batch.bins.size();
+        tio = nowMs();
+        flush(false);
+        stats.io_ms += nowMs() - tio;
+        if (verbose) { fprintf(stderr, "\rParts processed: %zu (%zu%%) ", done, mine.empty() ? 100 : done * 100 / mine.size()); fflush(stderr); }
+    }
+    flush(true);
+    aw.finish(head);
+    stats.cdata_bytes = aw.dataBytes();
+    stats.encode_kernel_ms = timing.encode_ms; stats.assemble_kernel_ms = timing.assemble_ms;
+    stats.kernel_launches = timing.launches; stats.stream_items = timing.items; stats.ppmd_symbols = timing.ppmd_symbols;
+    stats.rc_symbols = timing.rc_symbols; stats.ppmd_restarts = timing.restarts; stats.h2d_bytes = timing.h2d_bytes; stats.d2h_bytes = timing.d2h_bytes;
+    stats.total_ms = nowMs() - tStart;
+    if (verbose) fprintf(stderr, "\n");
+}
+
+}  // namespace fs

@@ -1,0 +1,55 @@
+// Host orchestration of the hot path: batches of bins -> front end (host threads) -> HIP engine ->
+// blocks; plus the merged small-bins/N block and the archive writer (drop-in boundary).
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/fastore_amd.h"
+#include "binfile.h"
+#include "engine.h"
+#include "format.h"
+#include "frontend.h"
+
+namespace fs {
+
+// .cmeta/.cdata writer: ArchiveFileWriter (fastore_pack/ArchiveFile.cpp:21-204)
+class ArchiveWriter {
+public:
+    ~ArchiveWriter();
+    void start(const std::string& prefix, const BinModuleConfigRaw& cfg);
+    void writeBlock(const uint8_t* data, uint64_t size, uint32_t signature);
+    void finish(const HeaderStats& head);
+    uint64_t dataBytes() const { return dataBytes_; }
+private:
+    FILE *meta_ = nullptr, *data_ = nullptr;
+    ArchiveConfigRaw conf_{};
+    std::vector<uint64_t> sizes_;
+    std::vector<uint32_t> sigs_;
+    uint64_t dataBytes_ = 0;
+};
+
+struct Context {
+    fsgpu_config cfg{};
+    PackParams par;
+    fsengine::Device* dev = nullptr;
+    BinModuleConfigRaw binCfg{};
+    HeaderStats head;
+    bool haveArchive = false;
+    std::string err;
+    std::vector<uint8_t> blocks;
+    std::vector<uint64_t> blockSizes;
+    fsgpu_stats stats{};
+    fsengine::BatchTiming timing;
+    uint32_t hostThreads = 1;
+
+    // standard bins of `batch` -> blocks/blockSizes (bin order)
+    void compressBatch(const Batch& batch);
+    // merged small bins + N bin (batch with ONE bin, records already in stored order): RawCompressorSE/PE
+    void compressRawBlock(Batch& batch, std::vector<uint8_t>& out);
+    void packFile(const std::string& inPrefix, const std::string& outPrefix, bool verbose);
+};
+
+void parseHeaderFields(const uint8_t* p, size_t n, bool pairedEnd, HeaderStats& out);
+void serializeHeaderFields(const HeaderStats& head, bool pairedEnd, std::vector<uint8_t>& out);
+
+}  // namespace fs

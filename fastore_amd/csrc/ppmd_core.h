@@ -1,0 +1,627 @@
+// PPMd var.J (PPMII) order-4 encoder, one stream per wavefront  (SURVEY §8 a12).
+//
+// Produces the exact member bytes of the reference path
+//   PpmdEncoder::EncodeNextMember -> ppmd_compress -> EncodeFile
+//   (/root/reference/fastore/ppmd/PPMd.cpp:119-154, Model.cpp:559-586; model Model.cpp:109-540;
+//    sub-allocator SubAlloc.hpp:65-199; carry-less range coder Coder.hpp:7-28)
+// with the parameters fastore_pack uses (order 4, 16 MiB sub-allocator, no cut-off:
+// fastore_pack/FastqCompressor.h:107-108, FastqCompressor.cpp:772-774).
+//
+// MI355X mapping: the model heap is a private 16 MiB arena in HBM addressed by 32-bit indices
+// (index = byte offset + 1, 0 = null -- the numeric values the reference keeps in its
+// iSuccessor/iStats/iSuffix fields, so "successor >= UnitsStart" style tests are plain integer
+// compares); the adaptive side tables (binary SEE, SEE2, symbol mask) live in LDS; the coder
+// registers stay in SGPR/VGPRs of the wave.  Control flow is wave-uniform (wave.h); table
+// initialisation, mask clears and unit copies are spread over the 64 lanes.
+#pragma once
+#include "wave.h"
+
+namespace fsppmd {
+
+enum { UNIT_SIZE = 12, N1 = 4, N2 = 4, N3 = 4, N4 = (128 + 3 - 1 * N1 - 2 * N2 - 3 * N3) / 4, N_INDEXES = N1 + N2 + N3 + N4 };
+enum { INT_BITS = 7, PERIOD_BITS = 7, TOT_BITS = INT_BITS + PERIOD_BITS, INTERVAL = 1 << INT_BITS,
+       BIN_SCALE = 1 << TOT_BITS, ROUND = 16, MAX_FREQ = 124 };
+enum : uint32_t { TOP = 1u << 24, BOT = 1u << 15 };
+enum : uint32_t { SA_SIZE = 16u << 20, MAX_ORDER = 4,
+                  // list heads BList[0..N_INDEXES] + one scratch head live behind the heap proper
+                  HEADS_OFF = SA_SIZE + 64u, ARENA_BYTES = HEADS_OFF + 12u * (N_INDEXES + 2) + 16u };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+  #define FS_TABLE __constant__ static const
+#else
+  #define FS_TABLE static const
+#endif
+// constants of PPMD_STARTUP (Model.cpp:88-108), tabulated
+FS_TABLE uint8_t kIndx2Units[N_INDEXES] = {1, 2, 3, 4, 6, 8, 10, 12, 15, 18, 21, 24, 28, 32, 36, 40, 44, 48, 52, 56,
+                                           60, 64, 68, 72, 76, 80, 84, 88, 92, 96, 100, 104, 108, 112, 116, 120, 124, 128};
+FS_TABLE uint8_t kUnits2Indx[128] = {
+    0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 8, 9, 9, 9, 10, 10, 10, 11, 11, 11, 12, 12, 12, 12, 13, 13, 13, 13,
+    14, 14, 14, 14, 15, 15, 15, 15, 16, 16, 16, 16, 17, 17, 17, 17, 18, 18, 18, 18, 19, 19, 19, 19, 20, 20, 20, 20,
+    21, 21, 21, 21, 22, 22, 22, 22, 23, 23, 23, 23, 24, 24, 24, 24, 25, 25, 25, 25, 26, 26, 26, 26, 27, 27, 27, 27,
+    28, 28, 28, 28, 29, 29, 29, 29, 30, 30, 30, 30, 31, 31, 31, 31, 32, 32, 32, 32, 33, 33, 33, 33, 34, 34, 34, 34,
+    35, 35, 35, 35, 36, 36, 36, 36, 37, 37, 37, 37};
+FS_TABLE uint8_t kExpEscape[16] = {51, 43, 18, 12, 11, 9, 8, 7, 6, 5, 4, 3, 3, 2, 2, 2};
+FS_TABLE int8_t kEscCoef[12] = {16, -10, 1, 51, 14, 89, 23, 35, 64, 26, -42, 43};
+
+FS_DEV uint32_t NS2BSIndx(uint32_t ns) { return ns == 0 ? 0u : (ns < 3 ? 2u : (ns < 29 ? 4u : 6u)); }
+// QTable[i] = i for i < 5; then runs of length 1,2,3,... of 5,6,7,...  (Model.cpp:103-107)
+FS_DEV uint32_t QTable(uint32_t i)
+{
+    if (i < 5) return i;
+    uint32_t j = i - 5, m = 5, step = 1;        // closed form of the run-length table
+    // j < 1 -> 5 ; j < 1+2 -> 6 ; j < 1+2+3 -> 7 ...   (i <= 259 => m <= 26)
+    while (j >= step) { j -= step; ++step; ++m; }
+    return m;
+}
+
+// side tables: LDS on the device (one instance per wave)
+struct Shared {
+    uint16_t BinSumm[25 * 64];
+    uint32_t SEE2[23 * 32];      // Summ | Shift << 16 | Count << 24
+    uint8_t CharMask[256];
+    uint8_t QT[260];             // QTable, tabulated once per wave
+};
+
+struct Coder {
+    uint8_t* hb;                 // heap base - 1  (so that index ix lives at hb + ix)
+    Shared* sh;
+    uint32_t pText, UnitsStart, LoUnit, HiUnit, GlueCount, GlueCount1;
+    uint32_t MaxContext, FoundState;
+    uint32_t NumMasked, PrevSuccess, EscCount;
+    int32_t BSumm, OrderFall, RunLength, InitRL;
+    uint32_t low, range, rLow, rHigh, rScale;
+    uint32_t dummySee;
+    uint8_t* out; uint32_t outCap, outPos;
+    uint32_t restarts;
+};
+
+#define HP(ix) (m.hb + (ix))
+// PPM_CONTEXT: NumStats@0 Flags@1 SummFreq@2 iStats@4 iSuffix@8 ; oneState = STATE at +2
+#define C_NS(c) fs_ld8(HP(c))
+#define C_NS_SET(c, v) fs_st8(HP(c), (v))
+#define C_FLAGS(c) fs_ld8(HP(c) + 1)
+#define C_FLAGS_SET(c, v) fs_st8(HP(c) + 1, (v))
+#define C_SF(c) fs_ld16(HP(c) + 2)
+#define C_SF_SET(c, v) fs_st16(HP(c) + 2, (v))
+#define C_STATS(c) fs_ld32(HP(c) + 4)
+#define C_STATS_SET(c, v) fs_st32(HP(c) + 4, (v))
+#define C_SUFF(c) fs_ld32(HP(c) + 8)
+#define C_SUFF_SET(c, v) fs_st32(HP(c) + 8, (v))
+#define C_ONE(c) ((c) + 2u)
+// STATE: Symbol@0 Freq@1 iSuccessor@2
+#define S_SYM(s) fs_ld8(HP(s))
+#define S_FREQ(s) fs_ld8(HP(s) + 1)
+#define S_SYMFREQ(s) fs_ld16(HP(s))
+#define S_FREQ_SET(s, v) fs_st8(HP(s) + 1, (v))
+#define S_SUCC(s) fs_ld32h(HP(s) + 2)
+#define S_SUCC_SET(s, v) fs_st32h(HP(s) + 2, (v))
+// BLK_NODE / MEM_BLK: Stamp@0 NextIndx@4 NU@8
+#define B_STAMP(b) fs_ld32(HP(b))
+#define B_STAMP_SET(b, v) fs_st32(HP(b), (v))
+#define B_NEXT(b) fs_ld32(HP(b) + 4)
+#define B_NEXT_SET(b, v) fs_st32(HP(b) + 4, (v))
+#define B_NU(b) fs_ld32(HP(b) + 8)
+#define B_NU_SET(b, v) fs_st32(HP(b) + 8, (v))
+#define BL(i) (1u + HEADS_OFF + 12u * (uint32_t)(i))
+
+FS_DEV void state_store(Coder& m, uint32_t s, uint32_t symfreq, uint32_t succ)
+{ fs_st16(HP(s), symfreq); fs_st32h(HP(s) + 2, succ); }
+FS_DEV void state_swap(Coder& m, uint32_t a, uint32_t b)
+{
+    uint32_t a0 = S_SYMFREQ(a), a1 = S_SUCC(a), b0 = S_SYMFREQ(b), b1 = S_SUCC(b);
+    state_store(m, a, b0, b1); state_store(m, b, a0, a1);
+}
+FS_DEV void state_cpy(Coder& m, uint32_t d, uint32_t s) { state_store(m, d, S_SYMFREQ(s), S_SUCC(s)); }
+
+// ---------------- sub-allocator ----------------
+FS_DEV uint32_t blk_remove(Coder& m, uint32_t n)
+{ uint32_t p = B_NEXT(n); B_NEXT_SET(n, B_NEXT(p)); B_STAMP_SET(n, B_STAMP(n) - 1u); return p; }
+FS_DEV void blk_insert(Coder& m, uint32_t n, uint32_t pv, uint32_t nu)
+{ B_NEXT_SET(pv, B_NEXT(n)); B_NEXT_SET(n, pv); B_STAMP_SET(pv, 0xFFFFFFFFu); B_NU_SET(pv, nu); B_STAMP_SET(n, B_STAMP(n) + 1u); }
+FS_DEV bool blk_avail(Coder& m, uint32_t n) { return B_NEXT(n) != 0u; }
+
+FS_DEV void SplitBlock(Coder& m, uint32_t pv, uint32_t oldI, uint32_t newI)
+{
+    uint32_t i, k, UDiff = (uint32_t)kIndx2Units[oldI] - kIndx2Units[newI];
+    uint32_t p = pv + 12u * kIndx2Units[newI];
+    if (kIndx2Units[i = kUnits2Indx[UDiff - 1]] != UDiff) {
+        k = kIndx2Units[--i]; blk_insert(m, BL(i), p, k);
+        p += 12u * k; UDiff -= k;
+    }
+    blk_insert(m, BL(kUnits2Indx[UDiff - 1]), p, UDiff);
+}
+
+FS_DEV void InitSubAllocator(Coder& m)
+{
+    // memset(BList, 0)  -- heads are 4-byte words behind the heap
+    for (uint32_t i = (uint32_t)FS_LANE(); i < 3u * (N_INDEXES + 2); i += FS_WAVE) *(uint32_t*)(HP(BL(0)) + 4u * i) = 0u;
+    FS_WAVE_SYNC();
+    m.pText = 1u; m.HiUnit = 1u + SA_SIZE;
+    const uint32_t Diff = 12u * (SA_SIZE / 8 / UNIT_SIZE * 7);
+    m.LoUnit = m.UnitsStart = m.HiUnit - Diff; m.GlueCount = m.GlueCount1 = 0;
+}
+
+FS_DEV_NOINLINE void GlueFreeBlocks(Coder& m)
+{
+    uint32_t i, k, sz, p, p0, p1;
+    const uint32_t s0 = BL(N_INDEXES + 1);
+    if (m.LoUnit != m.HiUnit) fs_st8(HP(m.LoUnit), 0);
+    p0 = s0; B_NEXT_SET(s0, 0); B_STAMP_SET(s0, 0); B_NU_SET(s0, 0);
+    for (i = 0; i <= N_INDEXES; i++)
+        while (blk_avail(m, BL(i))) {
+            p = blk_remove(m, BL(i));
+            if (!B_NU(p)) continue;
+            while (B_STAMP(p1 = p + 12u * B_NU(p)) == 0xFFFFFFFFu) { B_NU_SET(p, B_NU(p) + B_NU(p1)); B_NU_SET(p1, 0); }
+            B_NEXT_SET(p, B_NEXT(p0)); B_NEXT_SET(p0, p);
+            p0 = p;
+        }
+    while (blk_avail(m, s0)) {
+        p = blk_remove(m, s0); sz = B_NU(p);
+        if (!sz) continue;
+        for (; sz > 128; sz -= 128, p += 12u * 128) blk_insert(m, BL(N_INDEXES - 1), p, 128);
+        if (kIndx2Units[i = kUnits2Indx[sz - 1]] != sz) { k = sz - kIndx2Units[--i]; blk_insert(m, BL(k - 1), p + 12u * (sz - k), k); }
+        blk_insert(m, BL(i), p, kIndx2Units[i]);
+    }
+    m.GlueCount = 1u << (13 + m.GlueCount1++);
+}
+
+FS_DEV_NOINLINE uint32_t AllocUnitsRare(Coder& m, uint32_t indx)
+{
+    uint32_t i = indx;
+    do {
+        if (++i == N_INDEXES) {
+            if (!m.GlueCount--) {
+                GlueFreeBlocks(m);
+                if (blk_avail(m, BL(i = indx))) return blk_remove(m, BL(i));
+            } else {
+                i = 12u * kIndx2Units[indx];
+                return (m.UnitsStart - m.pText > i) ? (m.UnitsStart -= i) : 0u;
+            }
+        }
+    } while (!blk_avail(m, BL(i)));
+    uint32_t r = blk_remove(m, BL(i)); SplitBlock(m, r, i, indx);
+    return r;
+}
+
+FS_DEV uint32_t AllocUnits(Coder& m, uint32_t NU)
+{
+    uint32_t indx = kUnits2Indx[NU - 1];
+    if (blk_avail(m, BL(indx))) return blk_remove(m, BL(indx));
+    uint32_t r = m.LoUnit; m.LoUnit += 12u * kIndx2Units[indx];
+    if (m.LoUnit <= m.HiUnit) return r;
+    m.LoUnit -= 12u * kIndx2Units[indx]; return AllocUnitsRare(m, indx);
+}
+
+FS_DEV uint32_t AllocContext(Coder& m)
+{
+    if (m.HiUnit != m.LoUnit) return (m.HiUnit -= UNIT_SIZE);
+    return blk_avail(m, BL(0)) ? blk_remove(m, BL(0)) : AllocUnitsRare(m, 0);
+}
+
+FS_DEV uint32_t ExpandUnits(Coder& m, uint32_t oldPtr, uint32_t oldNU)
+{
+    uint32_t i0 = kUnits2Indx[oldNU - 1], i1 = kUnits2Indx[oldNU - 1 + 1];
+    if (i0 == i1) return oldPtr;
+    uint32_t ptr = AllocUnits(m, oldNU + 1);
+    if (ptr) { fs_wave_copy4(HP(ptr), HP(oldPtr), 12u * oldNU); blk_insert(m, BL(i0), oldPtr, oldNU); }
+    return ptr;
+}
+
+FS_DEV uint32_t ShrinkUnits(Coder& m, uint32_t oldPtr, uint32_t oldNU, uint32_t newNU)
+{
+    uint32_t i0 = kUnits2Indx[oldNU - 1], i1 = kUnits2Indx[newNU - 1];
+    if (i0 == i1) return oldPtr;
+    if (blk_avail(m, BL(i1))) {
+        uint32_t ptr = blk_remove(m, BL(i1)); fs_wave_copy4(HP(ptr), HP(oldPtr), 12u * newNU);
+        blk_insert(m, BL(i0), oldPtr, kIndx2Units[i0]);
+        return ptr;
+    }
+    SplitBlock(m, oldPtr, i0, i1); return oldPtr;
+}
+
+FS_DEV void FreeUnits(Coder& m, uint32_t ptr, uint32_t NU)
+{ uint32_t indx = kUnits2Indx[NU - 1]; blk_insert(m, BL(indx), ptr, kIndx2Units[indx]); }
+
+// ---------------- range coder ----------------
+FS_DEV void put_byte(Coder& m, uint32_t c) { if (m.outPos < m.outCap) m.out[m.outPos] = (uint8_t)c; m.outPos += (m.outPos < m.outCap); }
+FS_DEV void rc_normalize(Coder& m)
+{
+    while ((m.low ^ (m.low + m.range)) < TOP || (m.range < BOT && ((m.range = (0u - m.low) & (BOT - 1)), true))) {
+        put_byte(m, m.low >> 24);
+        m.range <<= 8; m.low <<= 8;
+    }
+}
+FS_DEV void rc_encode(Coder& m) { m.low += m.rLow * (m.range /= m.rScale); m.range *= m.rHigh - m.rLow; }
+
+// ---------------- model ----------------
+FS_DEV void clear_mask(Coder& m)
+{
+    for (uint32_t i = (uint32_t)FS_LANE(); i < 64u; i += FS_WAVE) ((uint32_t*)m.sh->CharMask)[i] = 0u;
+    FS_WAVE_SYNC();
+    m.EscCount = 1;
+}
+
+FS_DEV void StartModelRare(Coder& m)
+{
+    clear_mask(m);
+    m.OrderFall = MAX_ORDER;
+    InitSubAllocator(m);
+    m.RunLength = m.InitRL = -(int32_t)MAX_ORDER;
+    m.MaxContext = AllocContext(m);
+    C_NS_SET(m.MaxContext, 255); C_SF_SET(m.MaxContext, 257);
+    const uint32_t st = AllocUnits(m, 128);
+    C_STATS_SET(m.MaxContext, st);
+    m.PrevSuccess = 0; C_SUFF_SET(m.MaxContext, 0); C_FLAGS_SET(m.MaxContext, 0);
+    for (uint32_t i = (uint32_t)FS_LANE(); i < 256u; i += FS_WAVE) {       // {Symbol=i, Freq=1, iSuccessor=0}
+        uint16_t* q = (uint16_t*)(HP(st) + 6u * i);
+        q[0] = (uint16_t)(i | 0x100u); q[1] = 0; q[2] = 0;
+    }
+    // binary SEE contexts: BinSumm[i][k] = BIN_SCALE - 128*clamp(sum coef)/i2f[i],  i2f[i] = (#k: QTable[k] <= i) + 1
+    for (uint32_t e = (uint32_t)FS_LANE(); e < 25u * 64u; e += FS_WAVE) {
+        const uint32_t i = e >> 6, k = e & 63u;
+        int s = 0;
+        for (int b = 0; b < 6; ++b) s += kEscCoef[2 * b + ((k >> b) & 1u)];
+        s = 128 * (s < 32 ? 32 : (s > 256 - 32 ? 256 - 32 : s));
+        uint32_t kk = 0; while (m.sh->QT[kk] <= i) kk++;              // first k with QTable[k] > i
+        m.sh->BinSumm[e] = (uint16_t)(BIN_SCALE - s / (int)(kk + 1));
+    }
+    for (uint32_t e = (uint32_t)FS_LANE(); e < 23u * 32u; e += FS_WAVE) {
+        const uint32_t i = e >> 5;                                     // init(8*i+5): Summ = v << 3, Shift = 3, Count = 7
+        m.sh->SEE2[e] = ((8u * i + 5u) << (PERIOD_BITS - 4)) | ((uint32_t)(PERIOD_BITS - 4) << 16) | (7u << 24);
+    }
+    FS_WAVE_SYNC();
+}
+
+FS_DEV void RestoreModelRare(Coder& m) { m.pText = 1u; StartModelRare(m); m.EscCount = 0; m.restarts++; }
+
+FS_DEV uint32_t find_sym(Coder& m, uint32_t pc, uint32_t sym)      // state of `sym` in a multi-symbol context (must exist)
+{
+    uint32_t p = C_STATS(pc);
+    if (S_SYM(p) != sym) do { p += 6; } while (S_SYM(p) != sym);
+    return p;
+}
+
+FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pc)
+{
+    const uint32_t iUpBranch = S_SUCC(m.FoundState);
+    uint32_t ps[MAX_ORDER + 1]; uint32_t pps = 0;
+    uint32_t cf, s0, tmp;
+    uint32_t sym = S_SYM(m.FoundState);
+    bool toLoop = true;
+    if (!Skip) {
+        ps[pps++] = m.FoundState;
+        if (!C_SUFF(pc)) toLoop = false;
+    }
+    if (toLoop) {
+        bool first = (p != 0);
+        if (first) pc = C_SUFF(pc);
+        do {
+            if (!first) {
+                pc = C_SUFF(pc);
+                if (C_NS(pc)) {
+                    p = find_sym(m, pc, sym);
+                    tmp = (S_FREQ(p) < MAX_FREQ);
+                    S_FREQ_SET(p, S_FREQ(p) + tmp); C_SF_SET(pc, C_SF(pc) + tmp);
+                } else {
+                    p = C_ONE(pc);
+                    S_FREQ_SET(p, S_FREQ(p) + ((!C_NS(C_SUFF(pc))) & (S_FREQ(p) < 11)));
+                }
+            }
+            first = false;
+            if (S_SUCC(p) != iUpBranch) { pc = S_SUCC(p); break; }
+            ps[pps++] = p;
+        } while (C_SUFF(pc));
+    }
+    if (pps == 0) return pc;
+    uint32_t ctFlags = 0x10u * (sym >= 0x40);
+    sym = fs_ld8(HP(iUpBranch));
+    ctFlags |= 0x08u * (sym >= 0x40);
+    uint32_t ctFreq;
+    if (C_NS(pc)) {
+        p = find_sym(m, pc, sym);
+        s0 = C_SF(pc) - C_NS(pc) - (cf = S_FREQ(p) - 1u);
+        cf = 1 + ((2 * cf <= s0) ? (uint32_t)(12 * cf > s0) : ((cf + 2 * s0) / s0));
+        ctFreq = (cf < 7) ? cf : 7;
+    } else ctFreq = S_FREQ(C_ONE(pc));
+    const uint32_t w0 = (ctFlags << 8) | (sym << 16) | (ctFreq << 24);   // NumStats=0, Flags, oneState{Symbol,Freq}
+    do {
+        const uint32_t pc1 = AllocContext(m);
+        if (!pc1) return 0;
+        fs_st32(HP(pc1), w0); fs_st32(HP(pc1) + 4, iUpBranch + 1u); fs_st32(HP(pc1) + 8, pc);
+        S_SUCC_SET(ps[--pps], pc = pc1);
+    } while (pps != 0);
+    return pc;
+}
+
+FS_DEV uint32_t ReduceOrder(Coder& m, uint32_t p, uint32_t pc)
+{
+    uint32_t p1, tmp; const uint32_t pc1 = pc;
+    const uint32_t iUpBranch = m.pText; S_SUCC_SET(m.FoundState, iUpBranch);
+    const uint32_t sym = S_SYM(m.FoundState); m.OrderFall++;
+    bool first = (p != 0);
+    if (first) pc = C_SUFF(pc);
+    for (;;) {
+        if (!first) {
+            if (!C_SUFF(pc)) return pc;
+            pc = C_SUFF(pc);
+            if (C_NS(pc)) {
+                p = find_sym(m, pc, sym);
+                tmp = 2u * (S_FREQ(p) < MAX_FREQ - 3);
+                S_FREQ_SET(p, S_FREQ(p) + tmp); C_SF_SET(pc, C_SF(pc) + tmp);
+            } else { p = C_ONE(pc); S_FREQ_SET(p, S_FREQ(p) + (S_FREQ(p) < 11)); }
+        }
+        first = false;
+        if (S_SUCC(p)) break;
+        S_SUCC_SET(p, iUpBranch); m.OrderFall++;
+    }
+    if (S_SUCC(p) <= iUpBranch) {
+        p1 = m.FoundState; m.FoundState = p;
+        S_SUCC_SET(p, CreateSuccessors(m, false, 0, pc));
+        m.FoundState = p1;
+    }
+    if (m.OrderFall == 1 && pc1 == m.MaxContext) { S_SUCC_SET(m.FoundState, S_SUCC(p)); m.pText--; }
+    return S_SUCC(p);
+}
+
+FS_DEV_NOINLINE void rescale(Coder& m, uint32_t c)
+{
+    uint32_t f0, sf, EscFreq, a = (m.OrderFall != 0), i = C_NS(c);
+    uint32_t p1, p;
+    C_FLAGS_SET(c, C_FLAGS(c) & 0x14u);
+    const uint32_t stats = C_STATS(c);
+    for (p = m.FoundState; p != stats; p -= 6) state_swap(m, p, p - 6);
+    f0 = S_FREQ(p); sf = C_SF(c);
+    EscFreq = sf - f0;
+    uint32_t nf = (f0 + a) >> 1; S_FREQ_SET(p, nf);
+    uint32_t summ = nf, flags = C_FLAGS(c);
+    do {
+        p += 6; const uint32_t fr = S_FREQ(p); EscFreq -= fr;
+        nf = (fr + a) >> 1; S_FREQ_SET(p, nf); summ += nf;
+        if (nf) flags |= 0x08u * (S_SYM(p) >= 0x40);
+        if (nf > S_FREQ(p - 6)) {
+            const uint32_t t0 = S_SYMFREQ(p), t1 = S_SUCC(p);
+            p1 = p;
+            do { state_cpy(m, p1, p1 - 6); p1 -= 6; } while (nf > S_FREQ(p1 - 6));
+            state_store(m, p1, t0, t1);
+        }
+    } while (--i);
+    C_FLAGS_SET(c, flags);
+    if (S_FREQ(p) == 0) {
+        do { i++; p -= 6; } while (S_FREQ(p) == 0);
+        EscFreq += i; a = (C_NS(c) + 2u) >> 1;
+        const uint32_t ns = C_NS(c) - i; C_NS_SET(c, ns);
+        if (ns == 0) {
+            const uint32_t t0 = S_SYMFREQ(stats), t1 = S_SUCC(stats);
+            C_FLAGS_SET(c, C_FLAGS(c) & 0x18u);
+            uint32_t tf = (2u * (t0 >> 8) + EscFreq - 1) / EscFreq;
+            if (tf > MAX_FREQ / 3) tf = MAX_FREQ / 3;
+            FreeUnits(m, stats, a);
+            state_store(m, C_ONE(c), (t0 & 0xFFu) | (tf << 8), t1);
+            m.FoundState = C_ONE(c); return;
+        }
+        C_STATS_SET(c, ShrinkUnits(m, stats, a, (ns + 2u) >> 1));
+    }
+    summ += (EscFreq + 1) >> 1;
+    if (m.OrderFall || (C_FLAGS(c) & 0x04u) == 0) {
+        a = (sf -= EscFreq) - f0;
+        a = (f0 * summ - sf * S_FREQ(C_STATS(c)) + a - 1) / a;
+        a = a < 2u ? 2u : (a > MAX_FREQ / 2u - 18u ? MAX_FREQ / 2u - 18u : a);
+    } else a = 2;
+    m.FoundState = C_STATS(c);
+    S_FREQ_SET(m.FoundState, S_FREQ(m.FoundState) + a); C_SF_SET(c, summ + a);
+    C_FLAGS_SET(c, C_FLAGS(c) | 0x04u);
+}
+
+FS_DEV void UpdateModel(Coder& m, uint32_t MinContext)
+{
+    const uint32_t FSymbol = S_SYM(m.FoundState), FFreq = S_FREQ(m.FoundState);
+    uint32_t iSuccessor, iFSuccessor = S_SUCC(m.FoundState);
+    uint32_t ns1, ns, cf, sf, s0, pc, p = 0;
+    bool restart = false;
+    if (C_SUFF(MinContext)) {
+        pc = C_SUFF(MinContext);
+        if (C_NS(pc)) {
+            p = C_STATS(pc);
+            if (S_SYM(p) != FSymbol) {
+                do { p += 6; } while (S_SYM(p) != FSymbol);
+                if (S_FREQ(p) >= S_FREQ(p - 6)) { state_swap(m, p, p - 6); p -= 6; }
+            }
+            if (S_FREQ(p) < MAX_FREQ) { cf = 1 + (FFreq < 4 * 8); S_FREQ_SET(p, S_FREQ(p) + cf); C_SF_SET(pc, C_SF(pc) + cf); }
+        } else { p = C_ONE(pc); S_FREQ_SET(p, S_FREQ(p) + (S_FREQ(p) < 11)); }
+    }
+    pc = m.MaxContext;
+    if (!m.OrderFall && iFSuccessor) {
+        const uint32_t s = CreateSuccessors(m, true, p, MinContext);
+        S_SUCC_SET(m.FoundState, s);
+        if (!s) { RestoreModelRare(m); return; }
+        m.MaxContext = s; return;
+    }
+    fs_st8(HP(m.pText), FSymbol); m.pText++; iSuccessor = m.pText;
+    if (m.pText >= m.UnitsStart) { RestoreModelRare(m); return; }
+    if (iFSuccessor) {
+        if (iFSuccessor < m.UnitsStart) iFSuccessor = CreateSuccessors(m, false, p, MinContext);
+    } else iFSuccessor = ReduceOrder(m, p, MinContext);
+    if (!iFSuccessor) { RestoreModelRare(m); return; }
+    if (!--m.OrderFall) { iSuccessor = iFSuccessor; m.pText -= (m.MaxContext != MinContext); }
+    s0 = C_SF(MinContext) - FFreq; ns = C_NS(MinContext);
+    const uint32_t Flag = 0x08u * (FSymbol >= 0x40);
+    for (; pc != MinContext; pc = C_SUFF(pc)) {
+        uint32_t summ;
+        if ((ns1 = C_NS(pc)) != 0) {
+            if ((ns1 & 1) != 0) {
+                p = ExpandUnits(m, C_STATS(pc), (ns1 + 1) >> 1);
+                if (!p) { restart = true; break; }
+                C_STATS_SET(pc, p);
+            }
+            summ = C_SF(pc) + (m.sh->QT[ns + 4] >> 3);
+        } else {
+            p = AllocUnits(m, 1);
+            if (!p) { restart = true; break; }
+            const uint32_t o0 = S_SYMFREQ(C_ONE(pc)), o1 = S_SUCC(C_ONE(pc));
+            uint32_t fr = o0 >> 8;
+            fr = (fr <= MAX_FREQ / 3) ? (2 * fr - 1) : (MAX_FREQ - 15);
+            state_store(m, p, (o0 & 0xFFu) | (fr << 8), o1); C_STATS_SET(pc, p);
+            summ = fr + (ns > 1) + kExpEscape[m.sh->QT[m.BSumm >> 8]];
+        }
+        cf = 2 * FFreq * (summ + 4u); sf = s0 + summ;
+        if (cf <= 6 * sf) { cf = 1 + (cf > sf) + (cf > 3 * sf); summ += 4; }
+        else { cf = 4 + (cf > 8 * sf) + (cf > 10 * sf) + (cf > 13 * sf); summ += cf; }
+        C_SF_SET(pc, summ);
+        ns1 += 1; C_NS_SET(pc, ns1);
+        p = C_STATS(pc) + 6u * ns1;
+        state_store(m, p, FSymbol | (cf << 8), iSuccessor);
+        C_FLAGS_SET(pc, C_FLAGS(pc) | Flag);
+    }
+    if (restart) { RestoreModelRare(m); return; }
+    m.MaxContext = iFSuccessor;
+}
+
+FS_DEV void encodeBinSymbol(Coder& m, uint32_t c, int symbol)
+{
+    const uint32_t rs = C_ONE(c);
+    const uint32_t idx = m.sh->QT[S_FREQ(rs) - 1] * 64u + NS2BSIndx(C_NS(C_SUFF(c))) + m.PrevSuccess + C_FLAGS(c) +
+                         (uint32_t)((m.RunLength >> 26) & 0x20);
+    uint32_t bs = FS_UNI(m.sh->BinSumm[idx]);
+    m.BSumm = (int32_t)bs;
+    const uint32_t tmp = bs * (m.range >>= TOT_BITS);
+    bs -= (bs + ROUND) >> PERIOD_BITS;
+    if ((int)S_SYM(rs) == symbol) {
+        bs += INTERVAL; m.range = tmp;
+        m.FoundState = rs; S_FREQ_SET(rs, S_FREQ(rs) + (S_FREQ(rs) < 196));
+        m.RunLength++; m.PrevSuccess = 1;
+    } else {
+        m.low += tmp; m.range *= (uint32_t)(BIN_SCALE - m.BSumm);
+        m.sh->CharMask[S_SYM(rs)] = (uint8_t)m.EscCount;
+        m.NumMasked = m.PrevSuccess = 0; m.FoundState = 0;
+    }
+    m.sh->BinSumm[idx] = (uint16_t)bs;
+}
+
+FS_DEV void encodeSymbol1(Coder& m, uint32_t c, int symbol)
+{
+    uint32_t p = C_STATS(c);
+    uint32_t i, LoCnt = S_FREQ(p); m.rScale = C_SF(c);
+    if ((int)S_SYM(p) == symbol) {
+        m.PrevSuccess = (2 * (m.rHigh = LoCnt) > m.rScale);
+        m.FoundState = p; S_FREQ_SET(p, LoCnt += 4); C_SF_SET(c, m.rScale + 4);
+        if (LoCnt > MAX_FREQ) rescale(m, c);
+        m.rLow = 0; return;
+    }
+    i = C_NS(c); m.PrevSuccess = 0;
+    for (;;) {
+        p += 6;
+        if ((int)S_SYM(p) == symbol) break;
+        LoCnt += S_FREQ(p);
+        if (--i == 0) {
+            m.rLow = LoCnt; m.sh->CharMask[S_SYM(p)] = (uint8_t)m.EscCount;
+            i = m.NumMasked = C_NS(c); m.FoundState = 0;
+            do { p -= 6; m.sh->CharMask[S_SYM(p)] = (uint8_t)m.EscCount; } while (--i);
+            m.rHigh = m.rScale; return;
+        }
+    }
+    m.rHigh = (m.rLow = LoCnt) + S_FREQ(p);
+    // update1
+    m.FoundState = p; S_FREQ_SET(p, S_FREQ(p) + 4); C_SF_SET(c, m.rScale + 4);
+    if (S_FREQ(p) > S_FREQ(p - 6)) {
+        state_swap(m, p, p - 6); m.FoundState = (p -= 6);
+        if (S_FREQ(p) > MAX_FREQ) rescale(m, c);
+    }
+}
+
+FS_DEV void encodeSymbol2(Coder& m, uint32_t c, int symbol)
+{
+    // makeEscFreq2
+    const uint32_t nsC = C_NS(c);
+    uint32_t seeIdx = 0xFFFFFFFFu, see = 0;
+    if (nsC != 0xFF) {
+        seeIdx = (m.sh->QT[nsC + 3] - 4u) * 32u + (C_SF(c) > 10u * (nsC + 1u)) + 2u * (2u * nsC < C_NS(C_SUFF(c)) + m.NumMasked) + C_FLAGS(c);
+        see = FS_UNI(m.sh->SEE2[seeIdx]);
+        const uint32_t shift = (see >> 16) & 0xFFu; uint32_t summ = see & 0xFFFFu;
+        const uint32_t r = summ >> shift; summ = (summ - r) & 0xFFFFu;
+        see = (see & 0xFFFF0000u) | summ;
+        m.rScale = r + !r;
+    } else m.rScale = 1;
+    uint32_t Sym, LoCnt = 0, i = nsC - m.NumMasked;
+    uint32_t p1, p = C_STATS(c) - 6;
+    const uint8_t esc = (uint8_t)m.EscCount;
+    bool found = false;
+    do {
+        do { p += 6; Sym = S_SYM(p); } while (m.sh->CharMask[Sym] == esc);
+        m.sh->CharMask[Sym] = esc;
+        if ((int)Sym == symbol) { found = true; break; }
+        LoCnt += S_FREQ(p);
+    } while (--i);
+    if (!found) {
+        m.rHigh = (m.rScale += (m.rLow = LoCnt));
+        if (seeIdx != 0xFFFFFFFFu) m.sh->SEE2[seeIdx] = (see & 0xFFFF0000u) | ((see + m.rScale) & 0xFFFFu);
+        m.NumMasked = nsC;
+        return;
+    }
+    m.rLow = LoCnt; m.rHigh = (LoCnt += S_FREQ(p));
+    for (p1 = p; --i;) {
+        do { p1 += 6; Sym = S_SYM(p1); } while (m.sh->CharMask[Sym] == esc);
+        LoCnt += S_FREQ(p1);
+    }
+    m.rScale += LoCnt;
+    if (seeIdx != 0xFFFFFFFFu) {                                   // psee2c->update()
+        uint32_t summ = see & 0xFFFFu, shift = (see >> 16) & 0xFFu, count = (see >> 24) & 0xFFu;
+        count = (count - 1) & 0xFFu;
+        if (count == 0) {
+            uint32_t k = summ >> shift;
+            k = PERIOD_BITS - (k > 40) - (k > 280) - (k > 1020);
+            if (k < shift) { summ >>= 1; shift--; }
+            else if (k > shift) { summ = (summ << 1) & 0xFFFFu; shift++; }
+            count = (6u << shift) & 0xFFu;
+        }
+        m.sh->SEE2[seeIdx] = summ | (shift << 16) | (count << 24);
+    }
+    // update2
+    m.FoundState = p; S_FREQ_SET(p, S_FREQ(p) + 4); C_SF_SET(c, C_SF(c) + 4);
+    if (S_FREQ(p) > MAX_FREQ) rescale(m, c);
+    m.EscCount = (m.EscCount + 1) & 0xFFu; m.RunLength = m.InitRL;
+}
+
+// Encode one member.  `arena` = ARENA_BYTES of 16-byte aligned scratch (content irrelevant),
+// returns the member size (clipped at outCap like the reference's ByteStream::Put).
+FS_DEV uint32_t encode_member(uint8_t* arena, Shared* sh, const uint8_t* in, uint32_t n, uint8_t* out, uint32_t outCap,
+                              uint32_t* restartsOut)
+{
+    Coder m;
+    m.hb = arena - 1; m.sh = sh; m.out = out; m.outCap = outCap; m.outPos = 0; m.restarts = 0;
+    m.NumMasked = 0; m.FoundState = 0; m.BSumm = 0; m.rLow = m.rHigh = m.rScale = 0;
+    for (uint32_t i = (uint32_t)FS_LANE(); i < 260u; i += FS_WAVE) sh->QT[i] = (uint8_t)QTable(i);
+    // zero the 64-byte guard behind the heap: GlueFreeBlocks may read one stamp past the end
+    for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) *(uint32_t*)(arena + SA_SIZE + 4u * i) = 0u;
+    FS_WAVE_SYNC();
+    put_byte(m, 0xCA); put_byte(m, MAX_ORDER);
+    m.low = 0; m.range = 0xFFFFFFFFu;
+    StartModelRare(m);
+    uint32_t pos = 0;
+    for (uint32_t MinContext = m.MaxContext;;) {
+        const int c = (pos < n) ? (int)fs_ld8(in + pos) : -1; pos += (pos < n);
+        if (C_NS(MinContext)) { encodeSymbol1(m, MinContext, c); rc_encode(m); }
+        else encodeBinSymbol(m, MinContext, c);
+        bool stop = false;
+        while (!m.FoundState) {
+            rc_normalize(m);
+            do {
+                if (!C_SUFF(MinContext)) { stop = true; break; }
+                m.OrderFall++; MinContext = C_SUFF(MinContext);
+            } while (C_NS(MinContext) == m.NumMasked);
+            if (stop) break;
+            encodeSymbol2(m, MinContext, c); rc_encode(m);
+        }
+        if (stop) break;
+        const uint32_t succ = S_SUCC(m.FoundState);
+        if (!m.OrderFall && succ >= m.UnitsStart) m.MaxContext = succ;
+        else { UpdateModel(m, MinContext); if (m.EscCount == 0) clear_mask(m); }
+        rc_normalize(m); MinContext = m.MaxContext;
+    }
+    for (int i = 0; i < 4; i++) { put_byte(m, m.low >> 24); m.low <<= 8; }
+    if (restartsOut) *restartsOut = m.restarts;
+    return m.outPos;
+}
+
+#undef HP
+#undef BL
+}  // namespace fsppmd

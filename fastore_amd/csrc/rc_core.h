@@ -1,0 +1,152 @@
+// Order-k adaptive range coders, one stream per wavefront  (SURVEY §8 a7).
+//
+// Bit-exact restatement of the reference coder stack for the streams fastore_pack codes "in
+// place" (Rev, MatchBinary, LettersX, CLetters, read-id tokens/values, binary / 8-bin quality,
+// PE flag):
+//   RangeEncoder          /root/reference/fastore/rc/RangeCoder.h:40-84
+//   TSymbolCoderRC        /root/reference/fastore/rc/SymbolCoderRC.h:19-93
+//   TSimple/TAdvancedContextCoder   /root/reference/fastore/rc/ContextEncoder.h:84-206
+//   TEncoder::Start/End   /root/reference/fastore/rc/ContextEncoder.h:208-250
+//
+// MI355X mapping: the uint16 frequency table of a stream (up to 32 MiB for the <256,1> and <8,6>
+// models) sits in the wave's private HBM arena and is initialised by the wave itself with
+// 16-byte stores; for the 256-symbol alphabet every lane owns four symbols, so the
+// O(alphabet) accumulate / cumulative-frequency steps of the reference become one 8-byte load
+// per lane plus a wave prefix scan.  Small alphabets (2, 8) are one 16-byte uniform load.
+#pragma once
+#include "wave.h"
+
+namespace fsrc {
+
+struct Enc {
+    uint64_t low; uint32_t range;
+    uint8_t* out; uint32_t cap, pos;
+};
+
+FS_DEV void put(Enc& e, uint32_t b) { if (e.pos < e.cap) e.out[e.pos] = (uint8_t)b; e.pos++; }
+
+FS_DEV void encode_freq(Enc& e, uint32_t symFreq, uint32_t cumFreq, uint32_t total)
+{
+    e.range /= total;
+    e.low += (uint32_t)(e.range * cumFreq);
+    e.range *= symFreq;
+    while (e.range <= 0x00ffffffu) {
+        if ((e.low ^ (e.low + e.range)) & 0xff00000000000000ULL) {
+            const uint32_t x = (uint32_t)e.low;
+            e.range = (x | 0x00ffffffu) - x;
+        }
+        put(e, (uint32_t)(e.low >> 56));
+        e.low <<= 8; e.range <<= 8;
+    }
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// inclusive wave scan of one value per lane; returns exclusive prefix, *total = wave sum
+FS_DEV uint32_t wave_excl_scan(uint32_t v, uint32_t* total)
+{
+    uint32_t x = v;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d, 64); if (FS_LANE() >= d) x += y; }
+    *total = __shfl(x, 63, 64);
+    return x - v;
+}
+FS_DEV uint32_t wave_bcast(uint32_t v, int lane) { return __shfl(v, lane, 64); }
+#else
+FS_DEV uint32_t wave_excl_scan(uint32_t v, uint32_t* total) { *total = v; return 0; }
+FS_DEV uint32_t wave_bcast(uint32_t v, int) { return v; }
+#endif
+
+// table bytes needed for a model
+FS_DEV uint64_t table_bytes(int bits, int order, int adv) { return (1ULL << (bits * (order + (adv ? 1 : 0)))) * (1ULL << bits) * 2ULL; }
+
+// Encode n (symbol, ctx0) byte pairs; returns the stream size including the 8 flush bytes
+// (counted past `cap` like the reference's growing writer would; bytes beyond cap are dropped).
+template <int BITS, int ORDER, bool ADV>
+FS_DEV uint32_t encode_stream(uint8_t* table /*16-byte aligned, table_bytes()*/, const uint8_t* pairs, uint32_t n,
+                              uint8_t* out, uint32_t cap)
+{
+    constexpr uint32_t A = 1u << BITS;
+    constexpr uint64_t symMask = (1ULL << (ORDER * BITS)) - 1;
+    constexpr uint64_t nModels = 1ULL << (BITS * (ORDER + (ADV ? 1 : 0)));
+    constexpr uint32_t limit = (1u << 16) - A * 8u;
+    // Clear(): every statistic = 1
+    {
+        const uint64_t words = nModels * A / 2;                     // u32 words of two u16 ones
+        uint32_t* t32 = (uint32_t*)table;
+        if (words >= 4u * FS_WAVE) {
+            struct alignas(16) V4 { uint32_t a, b, c, d; };
+            V4* t128 = (V4*)table; const V4 ones = {0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u};
+            for (uint64_t i = (uint64_t)FS_LANE(); i < words / 4; i += FS_WAVE) t128[i] = ones;
+        } else {
+            for (uint64_t i = (uint64_t)FS_LANE(); i < words; i += FS_WAVE) t32[i] = 0x00010001u;
+        }
+        FS_WAVE_SYNC();
+    }
+    Enc e; e.low = 0; e.range = 0xffffffffu; e.out = out; e.cap = cap; e.pos = 0;
+    uint64_t hash = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t pr = fs_ld16(pairs + 2u * k);
+        const uint32_t sym = pr & 0xFFu, ctx = pr >> 8;
+        const uint32_t h = ADV ? (uint32_t)(((hash & symMask) << BITS) | ctx) : (uint32_t)(hash & symMask);
+        uint16_t* st = (uint16_t*)table + (uint64_t)h * A;
+        uint32_t acc, lo, f;
+        if constexpr (BITS == 8) {
+            constexpr int PER = 256 / FS_WAVE;                      // symbols owned by one lane
+            const int lane = FS_LANE();
+            uint32_t v[PER]; uint32_t s = 0;
+            for (int j = 0; j < PER; ++j) { v[j] = st[lane * PER + j]; s += v[j]; }
+            uint32_t ex = wave_excl_scan(s, &acc);
+            if (acc >= limit) {                                      // Rescale(): stats -= stats >> 1
+                s = 0;
+                for (int j = 0; j < PER; ++j) { v[j] -= v[j] >> 1; st[lane * PER + j] = (uint16_t)v[j]; s += v[j]; }
+                ex = wave_excl_scan(s, &acc);
+            }
+            const int owner = (int)(sym / PER), within = (int)(sym % PER);
+            uint32_t myLo = ex, myF = 0;
+            for (int j = 0; j < PER; ++j) { if (j < within) myLo += v[j]; if (j == within) myF = v[j]; }
+            lo = FS_UNI(wave_bcast(myLo, owner)); f = FS_UNI(wave_bcast(myF, owner)); acc = FS_UNI(acc);
+            if (lane == owner) st[sym] = (uint16_t)(f + 8);      // lanes only ever touch their own 4 symbols: no sync
+        } else {
+            uint32_t v[A]; acc = 0;
+            for (uint32_t j = 0; j < A; ++j) { v[j] = FS_UNI(st[j]); acc += v[j]; }
+            if (acc >= limit) {
+                acc = 0;
+                for (uint32_t j = 0; j < A; ++j) { v[j] -= v[j] >> 1; st[j] = (uint16_t)v[j]; acc += v[j]; }
+            }
+            lo = 0; f = 0;
+            for (uint32_t j = 0; j < A; ++j) { if (j < sym) lo += v[j]; if (j == sym) f = v[j]; }
+            st[sym] = (uint16_t)(f + 8);
+        }
+        encode_freq(e, f, lo, acc);
+        hash = (hash << BITS) | sym;
+    }
+    for (int i = 0; i < 8; ++i) { put(e, (uint32_t)(e.low >> 56)); e.low <<= 8; }
+    return e.pos;
+}
+
+// model ids shared by host and device
+enum Model : uint32_t { M_S2O4 = 0, M_S8O4 = 1, M_A8O4 = 2, M_A2O10 = 3, M_A8O6 = 4, M_A256O1 = 5, M_COUNT = 6 };
+
+FS_DEV uint32_t encode_model(uint32_t model, uint8_t* table, const uint8_t* pairs, uint32_t n, uint8_t* out, uint32_t cap)
+{
+    switch (model) {
+    case M_S2O4: return encode_stream<1, 4, false>(table, pairs, n, out, cap);
+    case M_S8O4: return encode_stream<3, 4, false>(table, pairs, n, out, cap);
+    case M_A8O4: return encode_stream<3, 4, true>(table, pairs, n, out, cap);
+    case M_A2O10: return encode_stream<1, 10, true>(table, pairs, n, out, cap);
+    case M_A8O6: return encode_stream<3, 6, true>(table, pairs, n, out, cap);
+    default: return encode_stream<8, 1, true>(table, pairs, n, out, cap);
+    }
+}
+FS_DEV uint64_t model_table_bytes(uint32_t model)
+{
+    switch (model) {
+    case M_S2O4: return table_bytes(1, 4, 0);
+    case M_S8O4: return table_bytes(3, 4, 0);
+    case M_A8O4: return table_bytes(3, 4, 1);
+    case M_A2O10: return table_bytes(1, 10, 1);
+    case M_A8O6: return table_bytes(3, 6, 1);
+    default: return table_bytes(8, 1, 1);
+    }
+}
+}  // namespace fsrc

@@ -1,0 +1,51 @@
+// Wave-execution model shared by the entropy-coder cores (ppmd_core.h, rc_core.h).
+//
+// On the device one entropy-coded stream is driven by ONE 64-lane wavefront.  Control flow is
+// wave-uniform: every lane executes the same branches, scalar state lives in SGPR-friendly
+// values (loads are made uniform with readfirstlane), and the O(n) inner steps -- table
+// fills, unit copies, symbol scans, frequency prefix sums -- are spread over the lanes.
+//
+// The same cores are compiled for the host (one "lane") for two purposes only:
+//   * the merged small-bins / N block ("block 0"), a single 100 MB-scale serial PPMd stream per
+//     archive that the design deliberately keeps on a host core;
+//   * a test-only emulation library (tests/emu) used to debug archive parity where no GPU is
+//     present.  The product never routes a standard bin through the host build.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIP_DEVICE_COMPILE__)
+  #define FS_DEV __device__ __forceinline__
+  #define FS_DEV_NOINLINE __device__ __noinline__
+  #define FS_WAVE 64
+  #define FS_LANE() ((int)(threadIdx.x & 63))
+  // make a loaded value wave-uniform (it already is by construction; this moves it to an SGPR)
+  #define FS_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+  // order this wave's cooperative memory phase against the uniform code that follows it
+  #define FS_WAVE_SYNC() __syncthreads()
+#else
+  #define FS_DEV static inline
+  #define FS_DEV_NOINLINE static
+  #define FS_WAVE 1
+  #define FS_LANE() 0
+  #define FS_UNI(x) ((uint32_t)(x))
+  #define FS_WAVE_SYNC() ((void)0)
+#endif
+
+// ---- uniform little-endian accessors on a byte heap (2-byte aligned addresses) ----
+FS_DEV uint32_t fs_ld8(const uint8_t* p) { return FS_UNI(*p); }
+FS_DEV uint32_t fs_ld16(const uint8_t* p) { return FS_UNI(*(const uint16_t*)p); }
+FS_DEV uint32_t fs_ld32h(const uint8_t* p)   // 32-bit value at a 2-byte aligned address
+{ return FS_UNI((uint32_t)((const uint16_t*)p)[0] | ((uint32_t)((const uint16_t*)p)[1] << 16)); }
+FS_DEV uint32_t fs_ld32(const uint8_t* p) { return FS_UNI(*(const uint32_t*)p); }
+FS_DEV void fs_st8(uint8_t* p, uint32_t v) { *p = (uint8_t)v; }
+FS_DEV void fs_st16(uint8_t* p, uint32_t v) { *(uint16_t*)p = (uint16_t)v; }
+FS_DEV void fs_st32h(uint8_t* p, uint32_t v) { ((uint16_t*)p)[0] = (uint16_t)v; ((uint16_t*)p)[1] = (uint16_t)(v >> 16); }
+FS_DEV void fs_st32(uint8_t* p, uint32_t v) { *(uint32_t*)p = v; }
+
+// cooperative copy / fill of 4-byte aligned regions (n bytes, n % 4 == 0), non-overlapping
+FS_DEV void fs_wave_copy4(uint8_t* d, const uint8_t* s, uint32_t n)
+{
+    for (uint32_t i = 4u * (uint32_t)FS_LANE(); i < n; i += 4u * FS_WAVE) *(uint32_t*)(d + i) = *(const uint32_t*)(s + i);
+    FS_WAVE_SYNC();
+}

@@ -1,0 +1,134 @@
+/* fastore_amd -- C ABI of the MI355X-native fastore_pack hot path.
+ *
+ * The reference (refresh-bio/FaStore v0.8.0) has no plugin API; the seam this library replaces is
+ * the per-bin call
+ *     FastqCompressor::Compress(reads, packCtx, signature, rawDnaSize, workBin, compBin)
+ *         fastore/fastore_pack/FastqCompressor.h:1215-1220, FastqCompressor.cpp:5689-5718
+ * and, one level up, the body of `fastore_pack e`
+ *     CompressorModuleSE/PE::Bin2Dnarch
+ *         fastore/fastore_pack/CompressorModule.h:29-49, CompressorModule.cpp:34-454, 599-1091.
+ * Plain pointers and sizes only; no exceptions cross this boundary; every function returns 0 on
+ * success or a negative code, and fsgpu_last_error() gives the text that the reference would have
+ * printed after "Error: " (fastore_pack/main.cpp:117-121).
+ * One context per GPU; a context is not re-entrant (like one reference compressor instance per
+ * worker thread, fastore_pack/CompressorOperator.h:45-59).
+ */
+#ifndef FASTORE_AMD_H
+#define FASTORE_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSGPU_OK 0
+#define FSGPU_ERR_ARG (-1)
+#define FSGPU_ERR_DEVICE (-2)   /* no usable HIP device / kernel failure: the product has no CPU fallback */
+#define FSGPU_ERR_FORMAT (-3)
+#define FSGPU_ERR_IO (-4)
+#define FSGPU_ERR_INTERNAL (-5)
+
+typedef struct fsgpu_ctx fsgpu_ctx;
+
+/* fastore_pack command-line knobs (fastore_pack/main.cpp:165-301, Params.h:18-147).
+ * Zero-initialise, then call fsgpu_config_defaults(). */
+typedef struct fsgpu_config {
+    uint32_t min_bin_size;              /* -f  (default 256: BinExtractorParams) */
+    int32_t encode_threshold;           /* -e  0 = auto */
+    int32_t pair_encode_threshold;      /* -E  0 = auto */
+    int32_t shift_cost;                 /* -s */
+    int32_t mismatch_cost;              /* -m */
+    uint32_t max_lz_window;             /* -w */
+    uint32_t max_pair_lz_window;        /* -W */
+    uint32_t extra_reduce_hard_reads;   /* -r */
+    uint32_t extra_reduce_expensive_lz; /* -l */
+    uint32_t max_record_shift_diff;     /* -q */
+    uint32_t max_new_variants_per_read; /* -n */
+    uint32_t max_hamming_distance;      /* -d */
+    uint32_t min_consensus_size;        /* -c */
+    int32_t device_id;                  /* HIP device ordinal */
+    uint32_t host_threads;              /* worker threads of the host stages (0 = all cores) */
+    uint32_t max_waves;                 /* resident coder wavefronts (0 = 16 per CU, memory permitting) */
+    uint64_t batch_bases;               /* bases per device batch (0 = default) */
+    uint32_t rank, world_size;          /* bin sharding: this context packs bins i with i % world_size == rank */
+} fsgpu_config;
+
+/* Unpacked reads of a batch of bins, structure-of-arrays (what the reference hands to Compress() as
+ * vector<FastqRecord> + PackContext; record/graph grammar: fastore_rebin/NodesPacker.cpp:567-979).
+ * bases/quals share offsets; a paired record stores mate 1 then mate 2 contiguously. */
+typedef struct fsgpu_record {
+    uint32_t seq_off, head_off;
+    uint16_t seq_len, aux_len, minim_pos;
+    uint8_t head_len, flags;            /* bit0 reverse-complemented, bit1 pair swapped */
+} fsgpu_record;
+typedef struct fsgpu_node { uint32_t rec, em_begin, em_count, tree_begin, tree_count; } fsgpu_node;
+typedef struct fsgpu_tree { uint32_t signature; int32_t main_signature_pos; uint32_t node_begin, node_count; } fsgpu_tree;
+typedef struct fsgpu_bin {
+    uint32_t signature, min_len, max_len;
+    uint64_t raw_dna_size;
+    uint32_t rec_begin, rec_count, top_begin, top_count;
+} fsgpu_bin;
+typedef struct fsgpu_bin_batch {
+    const uint8_t *bases, *quals, *heads;
+    size_t n_bases, n_heads;
+    const fsgpu_record* records; size_t n_records;
+    const fsgpu_node* nodes; size_t n_nodes;
+    const uint32_t* top_nodes; size_t n_top_nodes;
+    const uint32_t* em_records; size_t n_em_records;
+    const fsgpu_tree* trees; size_t n_trees;
+    const fsgpu_bin* bins; size_t n_bins;
+} fsgpu_bin_batch;
+
+/* Compressed blocks of a batch; memory is owned by the context and valid until the next call. */
+typedef struct fsgpu_block_batch {
+    const uint8_t* data;                /* blocks back to back, in bin order */
+    const uint64_t* sizes;              /* n_blocks entries */
+    size_t n_blocks;
+} fsgpu_block_batch;
+
+typedef struct fsgpu_stats {
+    double encode_kernel_ms, assemble_kernel_ms;   /* HIP-event time on the engine's stream */
+    double frontend_ms, block0_ms, io_ms, total_ms;
+    uint64_t kernel_launches, stream_items, ppmd_symbols, rc_symbols, ppmd_restarts;
+    uint64_t h2d_bytes, d2h_bytes;
+    uint64_t bins, records, algorithmic_bytes;      /* 2*(seq+aux)+head per record + block bytes */
+    uint64_t block0_records, block0_bytes, cdata_bytes;
+} fsgpu_stats;
+
+void fsgpu_config_defaults(fsgpu_config* cfg);
+int fsgpu_device_count(void);
+fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg);          /* NULL when no HIP device is usable; see fsgpu_create_error() */
+const char* fsgpu_create_error(void);
+void fsgpu_destroy(fsgpu_ctx* ctx);
+const char* fsgpu_last_error(const fsgpu_ctx* ctx);
+
+/* Archive-level parameters that travel inside .bmeta: the raw 88-byte BinModuleConfig
+ * (fastore_bin/Params.h:167-193) and the serialized read-id field table exactly as stored in the
+ * .bmeta footer (fastore_bin/BinFile.cpp:395-461; may be NULL/0 for header-less archives). */
+int fsgpu_set_archive_params(fsgpu_ctx* ctx, const void* bin_module_config, size_t config_bytes,
+                             const uint8_t* header_fields, size_t header_fields_bytes);
+
+/* The per-bin hot path on standard (LZ) bins: FastqCompressor::Compress for signature != 4^p. */
+int fsgpu_compress_bins(fsgpu_ctx* ctx, const fsgpu_bin_batch* in, fsgpu_block_batch* out);
+
+/* Entropy-coder entry points (one call = many independent streams on the device).
+ * PPMd var.J member as PpmdEncoder::EncodeNextMember emits it (ppmd/PPMd.cpp:44-70,119-154);
+ * range-coded stream of a TEncoder<model> (rc/ContextEncoder.h:208-250) over (symbol, ctx0) pairs;
+ * model: 0 <2,4> simple, 1 <8,4> simple, 2 <8,4> adv, 3 <2,10> adv, 4 <8,6> adv, 5 <256,1> adv. */
+int fsgpu_ppmd_encode(fsgpu_ctx* ctx, size_t n_streams, const uint8_t* const* in, const size_t* in_len,
+                      uint8_t* const* out, const size_t* out_cap, size_t* out_len);
+int fsgpu_rc_encode(fsgpu_ctx* ctx, size_t n_streams, const uint32_t* model, const uint8_t* const* pairs,
+                    const size_t* n_pairs, uint8_t* const* out, const size_t* out_cap, size_t* out_len);
+
+/* Whole `fastore_pack e -i<in_prefix> -o<out_prefix>`: reads .bmeta/.bdna/.bqua/.bhead, writes
+ * .cmeta/.cdata in the reference's -t1 block order. */
+int fsgpu_pack_file(fsgpu_ctx* ctx, const char* in_prefix, const char* out_prefix, int verbose);
+
+int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out);
+const char* fsgpu_device_name(const fsgpu_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

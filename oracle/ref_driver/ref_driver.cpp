@@ -19,7 +19,7 @@
 //            oracle's range-coder restatement
 //
 // usage: ref_driver <bin|rebin|pack|unpack> [flags]
-//        ref_driver ppmd <in> <out>
+//        ref_driver ppmd <in> <out>          ref_driver ppmdd <in> <out>   (PpmdDecoder: inverse, for debugging)
 //        ref_driver rc <model> <in: sym,ctx byte pairs> <out>     model = s2o4|s8o4|a8o4|a2o10|a8o6|a256o1
 
 #include <cstdio>
@@ -210,6 +210,19 @@ static void rc_put(TEncoder<TSimpleContextCoder<2, 4>>& x, unsigned s, unsigned)
 static void rc_put(TEncoder<TSimpleContextCoder<8, 4>>& x, unsigned s, unsigned) { x.coder.EncodeSymbol(x.rc, s); }
 template <class X> static void rc_put(X& x, unsigned s, unsigned c) { x.coder.EncodeSymbol(x.rc, s, c); }
 
+static int do_ppmdd(int argc, char** argv)
+{
+    if (argc != 4) return 2;
+    std::vector<unsigned char> in; if (!read_file(argv[2], in) || in.empty()) return 1;
+    std::vector<unsigned char> out(in.size() * 64 + (1 << 20));
+    PpmdDecoder dec; dec.StartDecompress(16);
+    uint64_t outSize = out.size();
+    bool ok = dec.DecodeNextMember(in.data(), in.size(), out.data(), outSize);
+    dec.FinishDecompress();
+    if (!ok) return 1;
+    return write_file(argv[3], out.data(), outSize) ? 0 : 1;
+}
+
 template <class TCoder, bool kCtx> static int run_rc(const std::vector<unsigned char>& in, const char* outFn)
 {
     Buffer buf(1 << 16);
@@ -252,6 +265,7 @@ int main(int argc, char** argv)
         if (cmd == "pack") return do_pack(argc, argv, false);
         if (cmd == "unpack") return do_pack(argc, argv, true);
         if (cmd == "ppmd") return do_ppmd(argc, argv);
+        if (cmd == "ppmdd") return do_ppmdd(argc, argv);
         if (cmd == "rc") return do_rc(argc, argv);
         fprintf(stderr, "unknown command %s\n", argv[1]);
         return 2;

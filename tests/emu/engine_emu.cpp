@@ -1,0 +1,74 @@
+// TEST-ONLY stand-in for fastore_amd/csrc/engine.hip: runs the same coder cores (ppmd_core.h,
+// rc_core.h) on the host, one "lane", so that archive parity of the whole host pipeline can be
+// checked in a container without a GPU.  Built into build/libfastore_emu.so by `make emu`; the
+// product library (libfastore_amd.so) never contains or loads this file.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <thread>
+#include <atomic>
+#include "../../fastore_amd/csrc/engine.h"
+#include "../../fastore_amd/csrc/ppmd_core.h"
+#include "../../fastore_amd/csrc/rc_core.h"
+
+using namespace fsdev;
+namespace fsengine {
+
+int device_count() { return 1; }
+int device_create(Device** out, int, uint32_t, char*, size_t)
+{ Device* d = new Device(); memset(d, 0, sizeof *d); snprintf(d->name, sizeof d->name, "host-emulation"); d->nWaves = 1; *out = d; return 0; }
+void device_destroy(Device* d) { delete d; }
+
+static void runItems(const uint8_t* input, std::vector<StreamItem>& items, std::vector<uint8_t>& scratch, std::vector<uint32_t>& sizes, BatchTiming* t)
+{
+    uint64_t sc = 0;
+    for (auto& it : items) { it.out_off = sc; sc += ((uint64_t)it.out_cap + 15u) & ~15ull; }
+    scratch.assign(sc + 16, 0); sizes.assign(items.size(), 0);
+    std::atomic<size_t> next(0);
+    const unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+    std::vector<std::thread> pool;
+    for (unsigned k = 0; k < nt; ++k) pool.emplace_back([&]() {
+        uint8_t* arena = (uint8_t*)aligned_alloc(64, (32ull << 20) + 65536);
+        fsppmd::Shared* sh = new fsppmd::Shared;
+        for (;;) {
+            const size_t i = next.fetch_add(1); if (i >= items.size()) break;
+            const StreamItem& it = items[i];
+            if (it.kind == KIND_PPMD) { if (it.in_len) sizes[i] = fsppmd::encode_member(arena, sh, input + it.in_off, it.in_len, scratch.data() + it.out_off, it.out_cap, nullptr); }
+            else sizes[i] = fsrc::encode_model(it.kind - KIND_RC_BASE, arena, input + it.in_off, it.in_len, scratch.data() + it.out_off, it.out_cap);
+        }
+        delete sh; free(arena);
+    });
+    for (auto& th : pool) th.join();
+    if (t) { t->launches++; t->items += items.size(); for (auto& it : items) { if (it.kind == KIND_PPMD) t->ppmd_symbols += it.in_len; else t->rc_symbols += it.in_len; } }
+}
+
+int encode_streams_raw(Device*, const uint8_t* input, size_t, std::vector<StreamItem>& items, std::vector<uint8_t>& raw, std::vector<uint32_t>& sizes, BatchTiming* t)
+{ runItems(input, items, raw, sizes, t); return 0; }
+
+static void putBe(uint8_t*& h, uint64_t v, int n) { for (int i = 0; i < n; ++i) *h++ = (uint8_t)(v >> (8 * (n - 1 - i))); }
+
+int encode_batch(Device* dev, const uint8_t* input, size_t, std::vector<StreamItem>& items, std::vector<BlockPlan>& plans,
+                 std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes, BatchTiming* t)
+{
+    std::vector<uint8_t> scratch; std::vector<uint32_t> sizes;
+    runItems(input, items, scratch, sizes, t);
+    for (size_t i = 0; i < items.size(); ++i) if (sizes[i] >= items[i].out_cap && items[i].in_len > 0) { snprintf(dev->err, sizeof dev->err, "stream overflow"); return -2; }
+    blocks.clear(); blockSizes.assign(plans.size(), 0);
+    for (size_t b = 0; b < plans.size(); ++b) {
+        BlockPlan& pl = plans[b];
+        const uint32_t N = pl.n_streams; const uint64_t headerSize = 42ull + 16ull * N;
+        uint64_t sz = headerSize + 1; for (uint32_t s = 0; s < N; ++s) sz += sizes[pl.first_item + s];
+        pl.block_off = blocks.size(); blockSizes[b] = sz; blocks.resize(blocks.size() + sz, 0);
+        uint8_t* blk = blocks.data() + pl.block_off; uint8_t* h = blk;
+        uint64_t pos = headerSize; uint64_t dstOff[MAX_STREAMS];
+        for (uint32_t k = 0; k < N; ++k) { const uint32_t s = pl.copy_order[k]; dstOff[s] = pos; pos += sizes[pl.first_item + s]; }
+        putBe(h, pl.signature, 4); putBe(h, pl.records, 8); *h++ = pl.min_len; *h++ = pl.max_len; putBe(h, pl.raw_dna_size, 8); putBe(h, pos, 8); putBe(h, 1, 4);
+        if (pl.has_headers) putBe(h, pl.raw_id_size, 8);
+        for (uint32_t s = 0; s < N; ++s) putBe(h, pl.work_size[s] == ~0ull ? (uint64_t)sizes[pl.first_item + s] : pl.work_size[s], 8);
+        for (uint32_t s = 0; s < N; ++s) putBe(h, sizes[pl.first_item + s], 8);
+        for (uint32_t s = 0; s < N; ++s) memcpy(blk + dstOff[s], scratch.data() + items[pl.first_item + s].out_off, sizes[pl.first_item + s]);
+        blk[pos] = 0;
+    }
+    return 0;
+}
+}  // namespace fsengine
