@@ -1,0 +1,161 @@
+"""fastore_amd -- MI355X-native `fastore_pack` hot path (ctypes binding of include/fastore_amd.h).
+
+The product is the C-ABI shared library ``libfastore_amd.so`` (host C++ + HIP kernels for gfx950)
+built in-tree by ``fastore_amd/csrc/Makefile``.  This module is plumbing only: it loads that library
+and fails loudly when it -- or a HIP device -- is missing.  There is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfastore_amd.so")
+PACK_CLI = os.path.join(_HERE, "fastore_pack")
+
+
+class FastoreError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("min_bin_size", C.c_uint32), ("encode_threshold", C.c_int32), ("pair_encode_threshold", C.c_int32),
+                ("shift_cost", C.c_int32), ("mismatch_cost", C.c_int32), ("max_lz_window", C.c_uint32),
+                ("max_pair_lz_window", C.c_uint32), ("extra_reduce_hard_reads", C.c_uint32),
+                ("extra_reduce_expensive_lz", C.c_uint32), ("max_record_shift_diff", C.c_uint32),
+                ("max_new_variants_per_read", C.c_uint32), ("max_hamming_distance", C.c_uint32),
+                ("min_consensus_size", C.c_uint32), ("device_id", C.c_int32), ("host_threads", C.c_uint32),
+                ("max_waves", C.c_uint32), ("batch_bases", C.c_uint64), ("rank", C.c_uint32), ("world_size", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("encode_kernel_ms", C.c_double), ("assemble_kernel_ms", C.c_double), ("frontend_ms", C.c_double),
+                ("block0_ms", C.c_double), ("io_ms", C.c_double), ("total_ms", C.c_double),
+                ("kernel_launches", C.c_uint64), ("stream_items", C.c_uint64), ("ppmd_symbols", C.c_uint64),
+                ("rc_symbols", C.c_uint64), ("ppmd_restarts", C.c_uint64), ("h2d_bytes", C.c_uint64),
+                ("d2h_bytes", C.c_uint64), ("bins", C.c_uint64), ("records", C.c_uint64),
+                ("algorithmic_bytes", C.c_uint64), ("block0_records", C.c_uint64), ("block0_bytes", C.c_uint64),
+                ("cdata_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libfastore_amd.so (in-tree).  Raises FastoreError when it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise FastoreError("%s not found: build it with `make -C fastore_amd/csrc` (or __graft_entry__.build())" % p)
+    lib = C.CDLL(p)
+    lib.fsgpu_config_defaults.argtypes = [C.POINTER(Config)]
+    lib.fsgpu_device_count.restype = C.c_int
+    lib.fsgpu_create.restype = C.c_void_p
+    lib.fsgpu_create.argtypes = [C.POINTER(Config)]
+    lib.fsgpu_create_error.restype = C.c_char_p
+    lib.fsgpu_destroy.argtypes = [C.c_void_p]
+    lib.fsgpu_last_error.restype = C.c_char_p
+    lib.fsgpu_last_error.argtypes = [C.c_void_p]
+    lib.fsgpu_device_name.restype = C.c_char_p
+    lib.fsgpu_device_name.argtypes = [C.c_void_p]
+    lib.fsgpu_pack_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+    lib.fsgpu_pack_files.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+    lib.fsgpu_reset_stats.argtypes = [C.c_void_p]
+    lib.fsgpu_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    lib.fsgpu_set_archive_params.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    pp = C.POINTER(C.c_char_p)
+    lib.fsgpu_ppmd_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fsgpu_rc_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    del pp
+    if path is None:
+        _lib = lib
+    return lib
+
+
+# C1 profile of the reference's scripts/fastore_compress.sh:146-148: -r -f256 -c10 -d8 -w1024 -W1024
+C1_PROFILE = dict(extra_reduce_hard_reads=1, min_bin_size=256, min_consensus_size=10, max_hamming_distance=8,
+                  max_lz_window=1024, max_pair_lz_window=1024)
+
+
+class Packer:
+    """One context = one GPU (mirrors one reference FastqCompressor instance per worker)."""
+
+    def __init__(self, device_id=0, host_threads=0, rank=0, world_size=1, lib=None, **knobs):
+        self.lib = lib or load_library()
+        cfg = Config()
+        self.lib.fsgpu_config_defaults(C.byref(cfg))
+        for k, v in dict(C1_PROFILE, **knobs).items():
+            if not hasattr(cfg, k):
+                raise FastoreError("unknown pack option %r" % k)
+            setattr(cfg, k, v)
+        cfg.device_id, cfg.host_threads, cfg.rank, cfg.world_size = device_id, host_threads, rank, world_size
+        self.cfg = cfg
+        self.ctx = self.lib.fsgpu_create(C.byref(cfg))
+        if not self.ctx:
+            raise FastoreError("fsgpu_create failed: " + self.lib.fsgpu_create_error().decode())
+
+    def close(self):
+        if self.ctx:
+            self.lib.fsgpu_destroy(self.ctx)
+            self.ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FastoreError("fastore_amd error %d: %s" % (rc, self.lib.fsgpu_last_error(self.ctx).decode()))
+
+    @property
+    def device_name(self):
+        return self.lib.fsgpu_device_name(self.ctx).decode()
+
+    def pack_file(self, in_prefix, out_prefix, verbose=False):
+        """`fastore_pack e -i<in_prefix> -o<out_prefix>`"""
+        self._check(self.lib.fsgpu_pack_file(self.ctx, in_prefix.encode(), out_prefix.encode(), int(verbose)))
+        return self.stats()
+
+    def pack_files(self, in_prefixes, out_prefixes, verbose=False):
+        """Several libraries in one go: their bins share the device batches."""
+        n = len(in_prefixes)
+        a = (C.c_char_p * n)(*[p.encode() for p in in_prefixes]); b = (C.c_char_p * n)(*[p.encode() for p in out_prefixes])
+        self._check(self.lib.fsgpu_pack_files(self.ctx, n, a, b, int(verbose)))
+        return self.stats()
+
+    def reset_stats(self):
+        self._check(self.lib.fsgpu_reset_stats(self.ctx))
+
+    def stats(self):
+        st = Stats()
+        self._check(self.lib.fsgpu_get_stats(self.ctx, C.byref(st)))
+        return st.as_dict()
+
+    def _encode(self, fn, streams, unit, extra=None):
+        n = len(streams)
+        ins = (C.c_char_p * n)(*[bytes(s) if len(s) else b"" for s in streams])
+        lens = (C.c_size_t * n)(*[len(s) // unit for s in streams])
+        caps = [2 * len(s) + 4096 for s in streams]
+        bufs = [C.create_string_buffer(c) for c in caps]
+        outs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+        capa = (C.c_size_t * n)(*caps)
+        outl = (C.c_size_t * n)()
+        if extra is None:
+            self._check(fn(self.ctx, n, ins, lens, outs, capa, outl))
+        else:
+            self._check(fn(self.ctx, n, extra, ins, lens, outs, capa, outl))
+        return [bufs[i].raw[:outl[i]] for i in range(n)]
+
+    def ppmd_encode(self, streams):
+        """PPMd var.J order-4 members, one per input stream (device)."""
+        return self._encode(self.lib.fsgpu_ppmd_encode, streams, 1)
+
+    def rc_encode(self, models, pair_streams):
+        """Range-coded streams; pair_streams[i] = interleaved (symbol, ctx0) bytes, models[i] in 0..5."""
+        m = (C.c_uint32 * len(models))(*models)
+        return self._encode(self.lib.fsgpu_rc_encode, pair_streams, 2, extra=m)

@@ -63,9 +63,11 @@ int fsgpu_set_archive_params(fsgpu_ctx* ctx, const void* cfgRaw, size_t cfgBytes
 {
     if (!ctx || !cfgRaw || cfgBytes != sizeof(fs::BinModuleConfigRaw)) return FSGPU_ERR_ARG;
     FS_GUARD(ctx, {
-        memcpy(&ctx->c.binCfg, cfgRaw, cfgBytes);
-        fs::parseHeaderFields(fields, fieldBytes, ctx->c.binCfg.archiveType.readType == fs::READ_PE, ctx->c.head);
-        if (ctx->c.binCfg.archiveType.readsHaveHeaders && ctx->c.head.fields.empty()) throw std::runtime_error("archive has read ids but no field table was given");
+        ctx->c.archives.assign(1, fs::ArchiveParams());
+        fs::ArchiveParams& a = ctx->c.archives[0];
+        memcpy(&a.cfg, cfgRaw, cfgBytes);
+        fs::parseHeaderFields(fields, fieldBytes, a.cfg.archiveType.readType == fs::READ_PE, a.head);
+        if (a.cfg.archiveType.readsHaveHeaders && a.head.fields.empty()) throw std::runtime_error("archive has read ids but no field table was given");
         ctx->c.haveArchive = true;
     });
 }
@@ -108,7 +110,7 @@ int fsgpu_compress_bins(fsgpu_ctx* ctx, const fsgpu_bin_batch* in, fsgpu_block_b
             bi.recBegin = x.rec_begin; bi.recCount = x.rec_count; bi.topBegin = x.top_begin; bi.topCount = x.top_count;
             b.bins[i] = bi;
         }
-        ctx->c.compressBatch(b);
+        ctx->c.compressBatch(b, std::vector<uint32_t>(b.bins.size(), 0u));
         out->data = ctx->c.blocks.data(); out->sizes = ctx->c.blockSizes.data(); out->n_blocks = ctx->c.blockSizes.size();
     });
 }
@@ -161,7 +163,24 @@ int fsgpu_rc_encode(fsgpu_ctx* ctx, size_t n, const uint32_t* model, const uint8
 int fsgpu_pack_file(fsgpu_ctx* ctx, const char* inPrefix, const char* outPrefix, int verbose)
 {
     if (!ctx || !inPrefix || !outPrefix) return FSGPU_ERR_ARG;
-    FS_GUARD(ctx, ctx->c.packFile(inPrefix, outPrefix, verbose != 0));
+    FS_GUARD(ctx, ctx->c.packFiles({std::string(inPrefix)}, {std::string(outPrefix)}, verbose != 0));
+}
+
+int fsgpu_pack_files(fsgpu_ctx* ctx, size_t n, const char* const* inPrefixes, const char* const* outPrefixes, int verbose)
+{
+    if (!ctx || !n || !inPrefixes || !outPrefixes) return FSGPU_ERR_ARG;
+    FS_GUARD(ctx, {
+        std::vector<std::string> a, b;
+        for (size_t i = 0; i < n; ++i) { a.emplace_back(inPrefixes[i]); b.emplace_back(outPrefixes[i]); }
+        ctx->c.packFiles(a, b, verbose != 0);
+    });
+}
+
+int fsgpu_reset_stats(fsgpu_ctx* ctx)
+{
+    if (!ctx) return FSGPU_ERR_ARG;
+    ctx->c.stats = fsgpu_stats(); ctx->c.timing = fsengine::BatchTiming();
+    return FSGPU_OK;
 }
 
 int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out)

@@ -162,11 +162,11 @@ void compressReadQuality(const BinModuleConfigRaw& cfg, const uint8_t* seq, cons
 
 // =================================================================================================
 struct BinEncoder::Impl {
-    const BinModuleConfigRaw cfg;
-    const HeaderStats& head;
+    BinModuleConfigRaw cfg{};
+    const HeaderStats* headp = nullptr;
     const PackParams par;
-    const uint32_t sigLen;
-    const bool pe, hasHeaders;
+    uint32_t sigLen = 8;
+    bool pe = false, hasHeaders = false;
     int8_t dnaToIdx[128];
 
     const Batch* B = nullptr;
@@ -185,13 +185,18 @@ struct BinEncoder::Impl {
     struct ConsEnc { int32_t lastMinimPos = 0; const Contig* def = nullptr; };
     std::vector<ConsEnc> consStack;
 
-    Impl(const BinModuleConfigRaw& c, const HeaderStats& h, const PackParams& p)
-        : cfg(c), head(h), par(p), sigLen(c.minimizer.signatureLen), pe(c.archiveType.readType == READ_PE),
-          hasHeaders(c.archiveType.readsHaveHeaders != 0)
+    explicit Impl(const PackParams& p) : par(p) { memset(dnaToIdx, -1, sizeof dnaToIdx); }
+    void setArchive(const ArchiveParams& a)
     {
+        const bool sameSig = a.cfg.minimizer.signatureLen == cfg.minimizer.signatureLen &&
+                             a.cfg.minimizer.signatureMaskCutoffBits == cfg.minimizer.signatureMaskCutoffBits;
+        cfg = a.cfg; headp = &a.head;
+        sigLen = cfg.minimizer.signatureLen; pe = cfg.archiveType.readType == READ_PE; hasHeaders = cfg.archiveType.readsHaveHeaders != 0;
         memset(dnaToIdx, -1, sizeof dnaToIdx);
-        for (int i = 0; i < 5; ++i) dnaToIdx[(int)c.minimizer.dnaSymbolOrder[i]] = (int8_t)i;
+        for (int i = 0; i < 5; ++i) dnaToIdx[(int)cfg.minimizer.dnaSymbolOrder[i]] = (int8_t)i;
+        if (!sameSig) dropPairState();
     }
+    void dropPairState();
 
     // ---- record accessors ----
     const Rec& R(int32_t v) const { return B->recs[vrecs[v].rec]; }
@@ -645,7 +650,7 @@ struct BinEncoder::Impl {
     {
         if (!hasHeaders) return;
         const Rec& r = R(v);
-        compressReadId(head, B->head.data() + r.headOff, r.headLen, out->s[S_IdToken], out->s[S_IdValue]);
+        compressReadId(*headp, B->head.data() + r.headOff, r.headLen, out->s[S_IdToken], out->s[S_IdValue]);
         out->rawIdSize += r.headLen;
     }
     void compressQuality(int32_t v) { compressReadQuality(cfg, seq(v), qua(v), seqLen(v), isReverse(v), out->s[S_Quality]); }
@@ -882,8 +887,9 @@ struct BinEncoder::Impl {
         contigs.clear();
     }
 
-    void encodeLz(const Batch& batch, const BinIn& bin, BinStreams& o)
+    void encodeLz(const Batch& batch, const BinIn& bin, const ArchiveParams& arch, BinStreams& o)
     {
+        setArchive(arch);
         B = &batch; out = &o; curSig = bin.signature;
         o.reset(pe ? S_PE_COUNT : S_SE_COUNT);
         initNodes(bin);
@@ -923,8 +929,8 @@ struct BinEncoder::Impl {
 
 namespace fs {
 
-BinEncoder::BinEncoder(const BinModuleConfigRaw& cfg, const HeaderStats& head, const PackParams& par) : impl_(new Impl(cfg, head, par)) {}
-BinEncoder::~BinEncoder() { if (impl_) { impl_->resetPair(); } delete impl_; }
-void BinEncoder::encodeLz(const Batch& batch, const BinIn& bin, BinStreams& out) { impl_->encodeLz(batch, bin, out); }
+BinEncoder::BinEncoder(const PackParams& par) : impl_(new Impl(par)) {}
+BinEncoder::~BinEncoder() { if (impl_) impl_->dropPairState(); delete impl_; }
+void BinEncoder::encodeLz(const Batch& batch, const BinIn& bin, const ArchiveParams& arch, BinStreams& out) { impl_->encodeLz(batch, bin, arch, out); }
 
 }  // namespace fs

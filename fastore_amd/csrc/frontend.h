@@ -50,11 +50,14 @@ struct BinStreams {
 bool streamIsRangeCoded(uint32_t stream, uint32_t qualityMethod);
 uint32_t streamModel(uint32_t stream, uint32_t qualityMethod);
 
+// archive-level parameters of one library (they travel inside .bmeta)
+struct ArchiveParams { BinModuleConfigRaw cfg{}; HeaderStats head; };
+
 class BinEncoder {
 public:
-    BinEncoder(const BinModuleConfigRaw& cfg, const HeaderStats& head, const PackParams& par);
+    explicit BinEncoder(const PackParams& par);
     // standard bin: LzCompressorSE/PE::Compress up to (not including) CompressBuffers
-    void encodeLz(const Batch& batch, const BinIn& bin, BinStreams& out);
+    void encodeLz(const Batch& batch, const BinIn& bin, const ArchiveParams& arch, BinStreams& out);
 
 private:
     struct Impl;

@@ -117,7 +117,7 @@ void ArchiveWriter::finish(const HeaderStats& head)
 }
 
 // ------------------------------------------------------------------------------------------------
-void Context::compressBatch(const Batch& batch)
+void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& binArch)
 {
     using namespace fsdev;
     const uint32_t nBins = (uint32_t)batch.bins.size();
@@ -128,16 +128,17 @@ void Context::compressBatch(const Batch& batch)
     {
         std::vector<std::unique_ptr<BinEncoder>> encs(hostThreads);
         parallelFor(nBins, hostThreads, [&](uint32_t b, uint32_t tid) {
-            if (!encs[tid]) encs[tid].reset(new BinEncoder(binCfg, head, par));
-            encs[tid]->encodeLz(batch, batch.bins[b], st[b]);
+            if (!encs[tid]) encs[tid].reset(new BinEncoder(par));
+            encs[tid]->encodeLz(batch, batch.bins[b], archives[binArch[b]], st[b]);
         });
     }
     stats.frontend_ms += nowMs() - t0;
-    const uint32_t qm = binCfg.quaParams.method;
     std::vector<StreamItem> items; std::vector<BlockPlan> plans(nBins);
     uint64_t inBytes = 0;
     for (uint32_t b = 0; b < nBins; ++b) {
         const BinIn& bin = batch.bins[b]; BinStreams& bs = st[b];
+        const BinModuleConfigRaw& binCfg = archives[binArch[b]].cfg;
+        const uint32_t qm = binCfg.quaParams.method;
         BlockPlan& pl = plans[b]; memset(&pl, 0, sizeof pl);
         pl.signature = bin.signature; pl.records = bin.recCount; pl.raw_dna_size = bin.rawDnaSize; pl.raw_id_size = bs.rawIdSize;
         pl.min_len = (uint8_t)bin.minLen; pl.max_len = (uint8_t)bin.maxLen; pl.has_headers = binCfg.archiveType.readsHaveHeaders != 0;
@@ -151,7 +152,10 @@ void Context::compressBatch(const Batch& batch)
             if (bytes > 0xF0000000ull) throw std::runtime_error("stream larger than 4 GiB");
             StreamItem it; memset(&it, 0, sizeof it);
             it.bin = b; it.in_off = inBytes;
-            if (rc) { it.kind = KIND_RC_BASE + streamModel(s, qm); it.in_len = (uint32_t)(bytes / 2); it.out_cap = 2 * it.in_len + 32; pl.work_size[s] = ~0ull; }
+            // header-less archives never create the read-id coders: their streams stay empty (FastqCompressor.cpp:923-930)
+            const bool absent = !pl.has_headers && (s == S_IdToken || s == S_IdValue);
+            if (absent) { it.kind = KIND_PPMD; it.in_len = 0; it.out_cap = 16; pl.work_size[s] = 0; }
+            else if (rc) { it.kind = KIND_RC_BASE + streamModel(s, qm); it.in_len = (uint32_t)(bytes / 2); it.out_cap = 2 * it.in_len + 32; pl.work_size[s] = ~0ull; }
             else { it.kind = KIND_PPMD; it.in_len = (uint32_t)bytes; it.out_cap = (uint32_t)(bytes + bytes / 8 + 64); pl.work_size[s] = bytes; }
             items.push_back(it);
             inBytes += (bytes + 15) & ~15ull;
@@ -181,8 +185,9 @@ void Context::compressBatch(const Batch& batch)
 // ------------------------------------------------------------------------------------------------
 // RawCompressorSE/PE::Compress (fastore_pack/FastqCompressor.cpp:3407-3600, 5426-5441) preceded by the
 // un-reverse-complement / un-swap pass of CompressorModule.cpp:136-149, 718-733.
-void Context::compressRawBlock(Batch& batch, std::vector<uint8_t>& out)
+void Context::compressRawBlock(Batch& batch, const ArchiveParams& arch, std::vector<uint8_t>& out) const
 {
+    const BinModuleConfigRaw& binCfg = arch.cfg; const HeaderStats& head = arch.head;
     const BinIn& bin = batch.bins.at(0);
     const bool pe = binCfg.archiveType.readType == READ_PE;
     const bool hasHeaders = binCfg.archiveType.readsHaveHeaders != 0;
@@ -231,76 +236,98 @@ void Context::compressRawBlock(Batch& batch, std::vector<uint8_t>& out)
     w.putBytes(cDna.data(), cDna.size()); w.putBytes(cQua.data(), cQua.size());
     w.put(0);                                               // footer
     out = std::move(w.b);
-    stats.block0_records = bin.recCount; stats.block0_bytes = out.size();
 }
 
 // ------------------------------------------------------------------------------------------------
-void Context::packFile(const std::string& inPrefix, const std::string& outPrefix, bool verbose)
+void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::vector<std::string>& outPrefixes, bool verbose)
 {
     const double tStart = nowMs();
-    BinFile bf;
-    bf.open(inPrefix, par.minBinSize);
-    binCfg = bf.config(); head = bf.headData(); haveArchive = true;
+    const size_t nLibs = inPrefixes.size();
+    if (nLibs == 0 || outPrefixes.size() != nLibs) throw std::runtime_error("pack: input/output prefix lists do not match");
     const uint32_t world = cfg.world_size ? cfg.world_size : 1, rank = cfg.rank;
-    ArchiveWriter aw;
-    aw.start(world > 1 ? outPrefix + ".part" + std::to_string(rank) : outPrefix, binCfg);
-
-    // block 0: merged small bins + N bin (rank 0 only); compressed on host cores while the GPU works
-    Batch b0; std::vector<uint8_t> block0; std::thread t0; std::string t0err; double t0ms = 0;
-    bool haveBlock0 = false;
-    if (rank == 0) {
-        uint64_t rawDna = 0;
-        for (uint32_t sig : bf.smallSignatures()) { bf.unpack(sig, b0, b0.bins.empty()); rawDna += bf.bins().at(sig).totalRawDnaSize; }
-        if (bf.hasNBin()) { bf.unpack(bf.nSignature(), b0, b0.bins.empty()); rawDna += bf.bins().at(bf.nSignature()).totalRawDnaSize; }
-        if (!b0.recs.empty()) {
-            haveBlock0 = true;
-            b0.bins[0].signature = bf.nSignature(); b0.bins[0].rawDnaSize = rawDna;
-            t0 = std::thread([&]() { const double a = nowMs(); try { compressRawBlock(b0, block0); } catch (const std::exception& e) { t0err = e.what(); } t0ms = nowMs() - a; });
-        }
-    }
-    const auto& stdSigs = bf.stdSignatures();
-    std::vector<uint32_t> mine;
-    for (uint32_t i = 0; i < stdSigs.size(); ++i) if (i % world == rank) mine.push_back(stdSigs[i]);
-    const uint64_t budget = cfg.batch_bases ? cfg.batch_bases : (512ull << 20);
-    struct Pending { std::vector<uint8_t> data; std::vector<uint64_t> sizes; std::vector<uint32_t> sigs; };
-    std::vector<Pending> pending;
-    bool block0Written = !haveBlock0;
-    auto flush = [&](bool wait) {
-        if (!block0Written) {
-            if (!wait) return;
-            t0.join(); if (!t0err.empty()) throw std::runtime_error(t0err);
-            stats.block0_ms = t0ms;
-            aw.writeBlock(block0.data(), block0.size(), bf.nSignature());
-            block0Written = true;
-        }
-        for (auto& p : pending) { uint64_t off = 0; for (size_t k = 0; k < p.sizes.size(); ++k) { aw.writeBlock(p.data.data() + off, p.sizes[k], p.sigs[k]); off += p.sizes[k]; } }
-        pending.clear();
+    struct Lib {
+        BinFile bf; ArchiveWriter aw;
+        Batch b0; std::vector<uint8_t> block0; std::thread t0; std::string t0err; double t0ms = 0;
+        bool haveBlock0 = false, block0Written = true;
+        struct Pending { std::vector<uint8_t> data; std::vector<uint64_t> sizes; std::vector<uint32_t> sigs; };
+        std::vector<Pending> pending;
     };
-    Batch batch; size_t next = 0, done = 0;
-    while (next < mine.size()) {
-        batch.clear();
-        double tio = nowMs();
-        while (next < mine.size() && (batch.bins.empty() || batch.seq.size() + bf.bins().at(mine[next]).totalRawDnaSize <= budget)) {
-            bf.unpack(mine[next], batch, true); ++next;
-        }
-        stats.io_ms += nowMs() - tio;
-        compressBatch(batch);
-        Pending p; p.data = std::move(blocks); p.sizes = blockSizes;
-        for (const auto& b : batch.bins) p.sigs.push_back(b.signature);
-        pending.push_back(std::move(p));
-        done += batch.bins.size();
-        tio = nowMs();
-        flush(false);
-        stats.io_ms += nowMs() - tio;
-        if (verbose) { fprintf(stderr, "\rParts processed: %zu (%zu%%) ", done, mine.empty() ? 100 : done * 100 / mine.size()); fflush(stderr); }
+    std::vector<std::unique_ptr<Lib>> libs;
+    archives.clear(); archives.resize(nLibs);
+    struct Work { uint32_t lib, sig; };
+    std::vector<Work> work;
+    for (size_t l = 0; l < nLibs; ++l) {
+        libs.emplace_back(new Lib());
+        Lib& L = *libs.back();
+        L.bf.open(inPrefixes[l], par.minBinSize);
+        archives[l].cfg = L.bf.config(); archives[l].head = L.bf.headData();
+        L.aw.start(world > 1 ? outPrefixes[l] + ".part" + std::to_string(rank) : outPrefixes[l], archives[l].cfg);
+        const auto& stdSigs = L.bf.stdSignatures();
+        for (uint32_t i = 0; i < stdSigs.size(); ++i) if (i % world == rank) work.push_back(Work{(uint32_t)l, stdSigs[i]});
     }
-    flush(true);
-    aw.finish(head);
-    stats.cdata_bytes = aw.dataBytes();
-    stats.encode_kernel_ms = timing.encode_ms; stats.assemble_kernel_ms = timing.assemble_ms;
-    stats.kernel_launches = timing.launches; stats.stream_items = timing.items; stats.ppmd_symbols = timing.ppmd_symbols;
-    stats.rc_symbols = timing.rc_symbols; stats.ppmd_restarts = timing.restarts; stats.h2d_bytes = timing.h2d_bytes; stats.d2h_bytes = timing.d2h_bytes;
-    stats.total_ms = nowMs() - tStart;
+    haveArchive = true;
+    // block 0 of every library (rank 0): merged small bins + N bin, compressed on host cores while the GPU works
+    if (rank == 0) {
+        for (size_t l = 0; l < nLibs; ++l) {
+            Lib& L = *libs[l];
+            uint64_t rawDna = 0;
+            for (uint32_t sig : L.bf.smallSignatures()) { L.bf.unpack(sig, L.b0, L.b0.bins.empty()); rawDna += L.bf.bins().at(sig).totalRawDnaSize; }
+            if (L.bf.hasNBin()) { L.bf.unpack(L.bf.nSignature(), L.b0, L.b0.bins.empty()); rawDna += L.bf.bins().at(L.bf.nSignature()).totalRawDnaSize; }
+            if (L.b0.recs.empty()) continue;
+            L.haveBlock0 = true; L.block0Written = false;
+            L.b0.bins[0].signature = L.bf.nSignature(); L.b0.bins[0].rawDnaSize = rawDna;
+            stats.block0_records += L.b0.recs.size();
+            const ArchiveParams* ap = &archives[l]; Lib* lp = &L;
+            L.t0 = std::thread([this, lp, ap]() { const double a = nowMs(); try { compressRawBlock(lp->b0, *ap, lp->block0); } catch (const std::exception& e) { lp->t0err = e.what(); } lp->t0ms = nowMs() - a; });
+        }
+    }
+    auto flush = [&](Lib& L, bool wait) {
+        if (!L.block0Written) {
+            if (!wait) return;
+            L.t0.join(); if (!L.t0err.empty()) throw std::runtime_error(L.t0err);
+            stats.block0_ms = std::max(stats.block0_ms, L.t0ms); stats.block0_bytes += L.block0.size();
+            L.aw.writeBlock(L.block0.data(), L.block0.size(), L.bf.nSignature());
+            L.block0Written = true; L.b0.clear(); L.block0.clear(); L.block0.shrink_to_fit();
+        }
+        for (auto& p : L.pending) { uint64_t off = 0; for (size_t k = 0; k < p.sizes.size(); ++k) { L.aw.writeBlock(p.data.data() + off, p.sizes[k], p.sigs[k]); off += p.sizes[k]; } }
+        L.pending.clear();
+    };
+    const uint64_t budget = cfg.batch_bases ? cfg.batch_bases : (768ull << 20);
+    Batch batch; std::vector<uint32_t> binArch; size_t next = 0, done = 0;
+    try {
+        while (next < work.size()) {
+            batch.clear(); binArch.clear();
+            double tio = nowMs();
+            while (next < work.size()) {
+                const Work& w = work[next];
+                const uint64_t add = libs[w.lib]->bf.bins().at(w.sig).totalRawDnaSize;
+                if (!batch.bins.empty() && batch.seq.size() + add > budget) break;
+                libs[w.lib]->bf.unpack(w.sig, batch, true); binArch.push_back(w.lib); ++next;
+            }
+            stats.io_ms += nowMs() - tio;
+            compressBatch(batch, binArch);
+            uint64_t off = 0;
+            for (size_t b = 0; b < batch.bins.size();) {              // route the blocks to their libraries (runs of equal lib)
+                const uint32_t l = binArch[b]; Lib::Pending p;
+                size_t e = b; uint64_t bytes = 0;
+                while (e < batch.bins.size() && binArch[e] == l) { p.sizes.push_back(blockSizes[e]); p.sigs.push_back(batch.bins[e].signature); bytes += blockSizes[e]; ++e; }
+                p.data.assign(blocks.begin() + off, blocks.begin() + off + bytes); off += bytes;
+                libs[l]->pending.push_back(std::move(p)); b = e;
+            }
+            done += batch.bins.size();
+            tio = nowMs();
+            for (auto& L : libs) flush(*L, false);
+            stats.io_ms += nowMs() - tio;
+            if (verbose) { fprintf(stderr, "\rParts processed: %zu (%zu%%) ", done, work.empty() ? 100 : done * 100 / work.size()); fflush(stderr); }
+        }
+        const double tio = nowMs();
+        for (size_t l = 0; l < nLibs; ++l) { flush(*libs[l], true); libs[l]->aw.finish(archives[l].head); stats.cdata_bytes += libs[l]->aw.dataBytes(); }
+        stats.io_ms += nowMs() - tio;
+    } catch (...) {
+        for (auto& L : libs) if (L->t0.joinable()) L->t0.join();
+        throw;
+    }
+    stats.total_ms += nowMs() - tStart;
     if (verbose) fprintf(stderr, "\n");
 }
 

@@ -32,8 +32,7 @@ struct Context {
     fsgpu_config cfg{};
     PackParams par;
     fsengine::Device* dev = nullptr;
-    BinModuleConfigRaw binCfg{};
-    HeaderStats head;
+    std::vector<ArchiveParams> archives;          // one per library being packed (index 0 for the single-library calls)
     bool haveArchive = false;
     std::string err;
     std::vector<uint8_t> blocks;
@@ -42,11 +41,12 @@ struct Context {
     fsengine::BatchTiming timing;
     uint32_t hostThreads = 1;
 
-    // standard bins of `batch` -> blocks/blockSizes (bin order)
-    void compressBatch(const Batch& batch);
+    // standard bins of `batch` -> blocks/blockSizes (bin order); binArch[b] = index into `archives`
+    void compressBatch(const Batch& batch, const std::vector<uint32_t>& binArch);
     // merged small bins + N bin (batch with ONE bin, records already in stored order): RawCompressorSE/PE
-    void compressRawBlock(Batch& batch, std::vector<uint8_t>& out);
-    void packFile(const std::string& inPrefix, const std::string& outPrefix, bool verbose);
+    void compressRawBlock(Batch& batch, const ArchiveParams& arch, std::vector<uint8_t>& out) const;
+    // `fastore_pack e` for one or several libraries; bins of all libraries share the device batches
+    void packFiles(const std::vector<std::string>& inPrefixes, const std::vector<std::string>& outPrefixes, bool verbose);
 };
 
 void parseHeaderFields(const uint8_t* p, size_t n, bool pairedEnd, HeaderStats& out);

@@ -125,7 +125,12 @@ int fsgpu_rc_encode(fsgpu_ctx* ctx, size_t n_streams, const uint32_t* model, con
  * .cmeta/.cdata in the reference's -t1 block order. */
 int fsgpu_pack_file(fsgpu_ctx* ctx, const char* in_prefix, const char* out_prefix, int verbose);
 
-int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out);
+/* The same for n libraries at once: their bins share the device batches (more independent streams in
+ * flight per launch), each library gets its own archive. */
+int fsgpu_pack_files(fsgpu_ctx* ctx, size_t n, const char* const* in_prefixes, const char* const* out_prefixes, int verbose);
+
+int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out);   /* cumulative since fsgpu_reset_stats() */
+int fsgpu_reset_stats(fsgpu_ctx* ctx);
 const char* fsgpu_device_name(const fsgpu_ctx* ctx);
 
 #ifdef __cplusplus

@@ -1,0 +1,75 @@
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+VECTORS = os.path.join(GOLDEN, "vectors")
+REF_DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+REF_DRIVER_GCC = os.path.join(ROOT, "oracle", "_ref", "ref_driver_gcc")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def _make(target_dir, *args):
+    subprocess.check_call(["make", "-C", target_dir, "-j", "8"] + list(args), stdout=subprocess.DEVNULL)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The plain-C restatement (oracle/liboracle.so) -- checker only."""
+    _make(os.path.join(ROOT, "oracle"), "oracle")
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+    lib.fso_ppmd_encode.restype = ctypes.c_size_t
+    lib.fso_ppmd_encode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.fso_rc_encode.restype = ctypes.c_size_t
+    lib.fso_rc_encode.argtypes = [ctypes.c_int] * 3 + [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    lib.fso_rle_binary.restype = ctypes.c_size_t
+    lib.fso_rle_binary.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    lib.fso_rle0.restype = ctypes.c_size_t
+    lib.fso_rle0.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    return lib
+
+
+MODELS = {"s2o4": (0, 1, 4, 0), "s8o4": (1, 3, 4, 0), "a8o4": (2, 3, 4, 1), "a2o10": (3, 1, 10, 1), "a8o6": (4, 3, 6, 1), "a256o1": (5, 8, 1, 1)}
+
+
+def oracle_ppmd(lib, data):
+    buf = ctypes.create_string_buffer(2 * len(data) + 4096)
+    n = lib.fso_ppmd_encode(data, len(data), buf, len(buf), None)
+    return buf.raw[:n]
+
+
+def oracle_rc(lib, model, pairs):
+    _, bits, order, adv = MODELS[model]
+    sym = pairs[0::2]; ctx = pairs[1::2]
+    buf = ctypes.create_string_buffer(2 * len(sym) + 64)
+    n = lib.fso_rc_encode(bits, order, adv, sym, ctx, len(sym), buf, len(buf))
+    return buf.raw[:n]
+
+
+def manifest():
+    out = []
+    for line in open(os.path.join(GOLDEN, "manifest.txt")):
+        parts = line.split()
+        out.append((parts[0], parts[1] == "1", parts[2:]))
+    return out
+
+
+def knobs_from_flags(flags):
+    """reference fastore_pack flag letters -> fastore_amd.Packer keyword arguments"""
+    m = {"f": "min_bin_size", "c": "min_consensus_size", "d": "max_hamming_distance", "w": "max_lz_window", "W": "max_pair_lz_window",
+         "e": "encode_threshold", "E": "pair_encode_threshold", "s": "shift_cost", "m": "mismatch_cost", "q": "max_record_shift_diff",
+         "n": "max_new_variants_per_read"}
+    kw = dict(extra_reduce_hard_reads=0, extra_reduce_expensive_lz=0)
+    for f in flags:
+        if f == "-r": kw["extra_reduce_hard_reads"] = 1
+        elif f == "-l": kw["extra_reduce_expensive_lz"] = 1
+        elif f[1] in m: kw[m[f[1]]] = int(f[2:])
+    return kw

@@ -1,0 +1,40 @@
+#!/bin/bash
+# Regenerates the golden fixtures: small synthetic libraries run through the REAL reference
+# (oracle/_ref, built from /root/reference by oracle/Makefile): fastore_bin -> 3 x fastore_rebin
+# (C1 profile of scripts/fastore_compress.sh:146-148,186-209) give the binned INPUT of the hot path,
+# `pack -t1` (clang build, canonical PE semantics) gives the EXPECTED archive.
+# Only data is stored: <name>.in.{bmeta,bdna,bqua,bhead} and <name>.ref.{cdata,cmeta}.
+set -euo pipefail
+cd "$(dirname "$0")"
+ROOT=../..
+G=$ROOT/oracle/_ref/ref_driver_gcc
+R=$ROOT/oracle/_ref/ref_driver
+GEN=$ROOT/build/gen_fastq
+[ -x "$GEN" ] || g++ -O2 -o "$GEN" $ROOT/tools/gen_fastq.cpp
+T=$(mktemp -d)
+# -f24: bins of >= 24 records are "standard" (LZ) bins, so that these small libraries exercise the LZ path and block 0
+PACKFLAGS="-r -f24 -c10 -d8 -w1024 -W1024"
+rm -f manifest.txt
+make_one() {   # name reads len genome seed paired qflag headerflags
+    local name=$1 reads=$2 len=$3 genome=$4 seed=$5 paired=$6 q=$7 hf=$8
+    local pe="" in="$T/$name"_1.fastq
+    if [ "$paired" = 1 ]; then $GEN --reads $reads --len $len --genome $genome --seed $seed --paired --out $T/$name; pe="-z"; in="$T/${name}_1.fastq $T/${name}_2.fastq"
+    else $GEN --reads $reads --len $len --genome $genome --seed $seed --out $T/$name; fi
+    $G bin "-i$in" -o$T/$name.b0 -t2 $hf -q$q -p8 -s0 -b256 $pe
+    $G rebin -i$T/$name.b0 -o$T/$name.b2 -t2 -r -w1024 -W1024 -p2 $pe
+    $G rebin -i$T/$name.b2 -o$T/$name.b4 -t2 -r -w1024 -W1024 -p4 $pe
+    $G rebin -i$T/$name.b4 -o$T/$name.b8 -t2 -r -w1024 -W1024 -p8 $pe
+    $R pack -i$T/$name.b8 -o$T/$name.ref -t1 $PACKFLAGS $pe
+    echo "$name $paired $PACKFLAGS" >> manifest.txt
+    for e in bmeta bdna bqua; do cp $T/$name.b8.$e $name.in.$e; done
+    [ -f $T/$name.b8.bhead ] && cp $T/$name.b8.bhead $name.in.bhead
+    cp $T/$name.ref.cdata $name.ref.cdata; cp $T/$name.ref.cmeta $name.ref.cmeta
+}
+#        name          reads len genome seed pe q  headers
+make_one se_lossless   9000  100 18000  11   0  0  "-H"
+make_one pe_lossless   4000  100 16000  12   1  0  "-H"
+make_one se_reduced    5000  100 10000  13   0  2  "-H -C"
+make_one se_noheader   4000  80  6400   14   0  0  ""
+make_one se_binary     4000  100 8000   15   0  1  ""
+rm -rf "$T"
+ls -la

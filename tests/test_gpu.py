@@ -1,0 +1,155 @@
+"""GPU parity tests (MI355X): everything goes through the C ABI of libfastore_amd.so and is compared
+bit-for-bit with (a) the oracle's C restatement on seeded inputs, (b) the committed golden archives
+made by the real reference, (c) the real reference itself (oracle/_ref) on freshly generated
+libraries when its binaries travelled with the checkout."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, MODELS, REF_DRIVER, REF_DRIVER_GCC, ROOT, VECTORS, knobs_from_flags, manifest, oracle_ppmd, oracle_rc
+from test_host import assert_same_archive
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def packer():
+    import fastore_amd
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "fastore_amd", "csrc"), "-j", "8"], stdout=subprocess.DEVNULL)
+    p = fastore_amd.Packer(device_id=0)
+    assert p.device_name.startswith("gfx950"), p.device_name
+    yield p
+    p.close()
+
+
+def test_ppmd_device_matches_reference_vectors(packer):
+    names = sorted(f[:-3] for f in os.listdir(VECTORS) if f.startswith("ppmd_") and f.endswith(".in"))
+    ins = [open(os.path.join(VECTORS, n + ".in"), "rb").read() for n in names]
+    outs = packer.ppmd_encode(ins)
+    for n, o in zip(names, outs):
+        assert o == open(os.path.join(VECTORS, n + ".out"), "rb").read(), n
+
+
+def test_rc_device_matches_reference_vectors(packer):
+    names = sorted(f[:-3] for f in os.listdir(VECTORS) if f.startswith("rc_") and f.endswith(".in") and f != "rc_empty.in")
+    ins = [open(os.path.join(VECTORS, n + ".in"), "rb").read() for n in names]
+    outs = packer.rc_encode([MODELS[n[3:]][0] for n in names], ins)
+    for n, o in zip(names, outs):
+        assert o == open(os.path.join(VECTORS, n + ".out"), "rb").read(), n
+    empty = packer.rc_encode(list(range(6)), [b""] * 6)
+    assert all(e == open(os.path.join(VECTORS, "rc_empty.out"), "rb").read() for e in empty)
+
+
+def test_ppmd_device_matches_oracle_many_ragged_streams(packer, oracle):
+    rng = np.random.default_rng(101)
+    streams = [b"", b"Q"]
+    for i in range(300):
+        n = int(rng.integers(1, 6000))
+        kind = i % 4
+        if kind == 0: s = np.clip(38 + np.cumsum(rng.integers(-1, 2, n)), 2, 40).astype(np.uint8)      # quality-like
+        elif kind == 1: s = rng.choice(np.frombuffer(b"ACGTN.", dtype=np.uint8), n)                     # hard reads
+        elif kind == 2: s = rng.integers(0, 9, n).astype(np.uint8)                                       # flags
+        else: s = rng.integers(0, 256, n).astype(np.uint8)                                               # incompressible
+        streams.append(s.tobytes())
+    got = packer.ppmd_encode(streams)
+    assert got[0] == b""
+    for s, g in zip(streams[1:], got[1:]):
+        assert g == oracle_ppmd(oracle, s)
+
+
+def test_ppmd_device_model_restart_and_allocator_exhaustion(packer, oracle):
+    # > 2 MiB of 41-symbol noise: the text area overruns and the model restarts; 3 MiB of bytes noise
+    # additionally drives the sub-allocator through GlueFreeBlocks / AllocUnitsRare
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, 41, 2_200_000, dtype=np.uint8).tobytes()
+    b = rng.integers(0, 256, 3 << 20, dtype=np.uint8).tobytes()
+    got = packer.ppmd_encode([a, b])
+    assert got[0] == oracle_ppmd(oracle, a)
+    assert got[1] == oracle_ppmd(oracle, b)
+
+
+def test_rc_device_matches_oracle_all_models_with_rescale(packer, oracle):
+    rng = np.random.default_rng(33)
+    models, ins = [], []
+    for name, (mid, bits, order, adv) in MODELS.items():
+        A = 1 << bits
+        for n in (1, 17, 5000, 120000):                       # 120000 symbols force TSymbolCoderRC::Rescale on hot models
+            sym = np.minimum(rng.geometric(0.3, n) - 1, A - 1).astype(np.uint8) if A > 2 else rng.integers(0, 2, n, dtype=np.uint8)
+            ctx = rng.integers(0, min(A, 8), n, dtype=np.uint8)
+            pairs = np.stack([sym, ctx], 1).tobytes()
+            models.append(mid); ins.append((name, pairs))
+    got = packer.rc_encode(models, [p for _, p in ins])
+    for (name, pairs), g in zip(ins, got):
+        assert g == oracle_rc(oracle, name, pairs), name
+
+
+@pytest.mark.parametrize("name,paired,flags", manifest())
+def test_gpu_pack_reproduces_reference_archives(tmp_path, name, paired, flags):
+    import fastore_amd
+    with fastore_amd.Packer(device_id=0, **knobs_from_flags(flags)) as p:
+        st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / "o"))
+        assert st["encode_kernel_ms"] > 0 and st["stream_items"] >= 15 * st["bins"]
+    assert_same_archive(str(tmp_path / "o"), os.path.join(GOLDEN, name + ".ref"))
+
+
+def test_cli_is_a_drop_in_for_fastore_pack_e(tmp_path):
+    cli = os.path.join(ROOT, "fastore_amd", "fastore_pack")
+    name, paired, flags = manifest()[0]
+    r = subprocess.run([cli, "e", "-i" + os.path.join(GOLDEN, name + ".in"), "-o" + str(tmp_path / "o"), "-t4", "-v"] + flags, capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert b"Parts processed" in r.stderr
+    assert_same_archive(str(tmp_path / "o"), os.path.join(GOLDEN, name + ".ref"))
+
+
+def _ref_pipeline(tmp, name, reads, length, genome, seed, paired, q):
+    gen = os.path.join(ROOT, "build", "gen_fastq")
+    if not os.path.exists(gen):
+        subprocess.check_call(["g++", "-O2", "-o", gen, os.path.join(ROOT, "tools", "gen_fastq.cpp")])
+    base = os.path.join(tmp, name)
+    subprocess.check_call([gen, "--reads", str(reads), "--len", str(length), "--genome", str(genome), "--seed", str(seed), "--out", base] + (["--paired"] if paired else []))
+    pe = ["-z"] if paired else []
+    inp = base + "_1.fastq" + ((" " + base + "_2.fastq") if paired else "")
+    subprocess.check_call([REF_DRIVER_GCC, "bin", "-i" + inp, "-o" + base + ".b0", "-t8", "-H", "-q%d" % q, "-p8", "-s0", "-b256"] + pe)
+    prev = base + ".b0"
+    for p in (2, 4, 8):
+        cur = base + ".b%d" % p
+        subprocess.check_call([REF_DRIVER_GCC, "rebin", "-i" + prev, "-o" + cur, "-t8", "-r", "-w1024", "-W1024", "-p%d" % p] + pe)
+        prev = cur
+    return prev, pe
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)), reason="reference binaries (oracle/_ref) not shipped")
+@pytest.mark.parametrize("paired,q,reads", [(False, 0, 120000), (True, 0, 60000), (False, 2, 60000)])
+def test_gpu_pack_equals_live_reference_on_fresh_library(tmp_path, paired, q, reads):
+    import fastore_amd
+    t = str(tmp_path)
+    binned, pe = _ref_pipeline(t, "lib", reads, 150, reads * 150 // 50, 77 + q + int(paired), paired, q)
+    flags = ["-r", "-f256", "-c10", "-d8", "-w1024", "-W1024"]
+    subprocess.check_call([REF_DRIVER, "pack", "-i" + binned, "-o" + os.path.join(t, "ref"), "-t1"] + flags + pe)
+    with fastore_amd.Packer(device_id=0) as p:
+        st = p.pack_file(binned, os.path.join(t, "gpu"))
+    assert_same_archive(os.path.join(t, "gpu"), os.path.join(t, "ref"))
+    assert st["bins"] >= 10
+    # independent check: the reference DECODER accepts our archive and returns the same multiset of reads
+    outs = [os.path.join(t, "dec_1.fastq")] + ([os.path.join(t, "dec_2.fastq")] if paired else [])
+    subprocess.check_call([REF_DRIVER, "unpack", "-i" + os.path.join(t, "gpu"), "-o" + " ".join(outs), "-t1"] + pe)
+    def records(path):
+        lines = open(path, "rb").read().split(b"\n")
+        return sorted(zip(lines[0::4], lines[1::4], lines[3::4]))
+    if q == 0:
+        assert records(outs[0]) == records(os.path.join(t, "lib_1.fastq"))
+        if paired:
+            assert records(outs[1]) == records(os.path.join(t, "lib_2.fastq"))
+
+
+def test_gpu_pack_is_deterministic_and_sizes_add_up(tmp_path):
+    import fastore_amd
+    name, paired, flags = manifest()[1]
+    outs = []
+    for i, waves in enumerate((0, 37)):                 # different wave counts change scheduling, never the bytes
+        with fastore_amd.Packer(device_id=0, max_waves=waves, **knobs_from_flags(flags)) as p:
+            p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o%d" % i)))
+        outs.append(open(str(tmp_path / ("o%d.cdata" % i)), "rb").read())
+    assert outs[0] == outs[1]

@@ -1,0 +1,127 @@
+"""CPU tests of the host logic and of the C-ABI surface.  No compute is launched on a device here.
+The archive-parity checks use the TEST-ONLY host emulation of the kernels (tests/emu, built into
+build/libfastore_emu.so) -- the same ppmd_core.h / rc_core.h sources compiled for one lane -- so the
+whole host pipeline (reader, unpacker, read-cluster front end, block layout, archive writer) is pinned
+against the reference's golden archives without a GPU.  The GPU suite repeats them on the device."""
+import ctypes
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT, knobs_from_flags, manifest
+
+CSRC = os.path.join(ROOT, "fastore_amd", "csrc")
+
+
+@pytest.fixture(scope="session")
+def product_lib():
+    subprocess.check_call(["make", "-C", CSRC, "-j", "8"], stdout=subprocess.DEVNULL)
+    return ctypes.CDLL(os.path.join(ROOT, "fastore_amd", "libfastore_amd.so"))
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    subprocess.check_call(["make", "-C", CSRC, "-j", "8", "emu"], stdout=subprocess.DEVNULL)
+    import fastore_amd
+    return fastore_amd.load_library(os.path.join(ROOT, "build", "libfastore_emu.so"))
+
+
+def test_c_abi_exports_every_declared_symbol(product_lib):
+    hdr = open(os.path.join(ROOT, "include", "fastore_amd.h")).read()
+    names = sorted(set(re.findall(r"\b(fsgpu_[a-z_]+)\s*\(", hdr)))
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(product_lib, n), n
+
+
+def test_structs_match_header_layout(product_lib):
+    import fastore_amd
+    assert ctypes.sizeof(fastore_amd.Config) == 80
+    assert ctypes.sizeof(fastore_amd.Stats) == 152
+    cfg = fastore_amd.Config()
+    product_lib.fsgpu_config_defaults(ctypes.byref(cfg))
+    # reference defaults: fastore_pack/Params.h:18-147, fastore_bin/Globals.h:61-62
+    assert (cfg.min_bin_size, cfg.shift_cost, cfg.mismatch_cost, cfg.max_lz_window, cfg.max_pair_lz_window) == (256, 1, 2, 255, 4096)
+    assert (cfg.max_new_variants_per_read, cfg.max_hamming_distance, cfg.min_consensus_size, cfg.world_size) == (1, 8, 10, 1)
+
+
+def test_no_device_means_loud_failure_not_fallback(product_lib):
+    product_lib.fsgpu_device_count.restype = ctypes.c_int
+    if product_lib.fsgpu_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    import fastore_amd
+    with pytest.raises(fastore_amd.FastoreError, match="no HIP device"):
+        fastore_amd.Packer()
+
+
+def test_cli_usage_and_errors():
+    subprocess.check_call(["make", "-C", CSRC, "-j", "8"], stdout=subprocess.DEVNULL)
+    cli = os.path.join(ROOT, "fastore_amd", "fastore_pack")
+    r = subprocess.run([cli], capture_output=True)
+    assert r.returncode == 255 and b"usage" in r.stderr          # < 3 args: usage, -1 (fastore_pack/main.cpp:26-33)
+    r = subprocess.run([cli, "x", "-ia", "-ob"], capture_output=True)
+    assert r.returncode == 255
+    r = subprocess.run([cli, "e", "-ofoo", "-t1"], capture_output=True)
+    assert r.returncode == 255 and b"Error: no input file specified" in r.stderr
+    r = subprocess.run([cli, "e", "-ifoo", "-t1"], capture_output=True)
+    assert r.returncode == 255 and b"Error: no output file(s) specified" in r.stderr
+    r = subprocess.run([cli, "e", "-ifoo", "-obar", "-t99"], capture_output=True)
+    assert r.returncode == 255 and b"invalid number of threads" in r.stderr
+
+
+def test_introsort_equals_libstdcxx_sort(tmp_path):
+    exe = str(tmp_path / "t_introsort")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "emu", "test_introsort.cpp")])
+    assert subprocess.run([exe], capture_output=True).stdout.strip() == b"OK"
+
+
+def read_cmeta(path):
+    m = open(path, "rb").read()
+    foff, fsize = struct.unpack_from("<QQ", m, 0)
+    n, = struct.unpack_from("<I", m, foff)
+    sizes = struct.unpack_from("<%dQ" % n, m, foff + 4)
+    sigs = struct.unpack_from("<%dI" % n, m, foff + 4 + 8 * n)
+    conf = m[foff + 4 + 12 * n: foff + 4 + 12 * n + 56]
+    tail = m[foff + 4 + 12 * n + 56: foff + fsize]
+    # ArchiveConfig fields that are a function of the input (padding / char* members are stack garbage in the reference)
+    fields = (conf[0:3], conf[3:11], conf[16:18], conf[24:28], conf[48:56])
+    return sizes, sigs, fields, tail, (foff, fsize, len(m))
+
+
+def assert_same_archive(got_prefix, want_prefix):
+    a = open(got_prefix + ".cdata", "rb").read(); b = open(want_prefix + ".cdata", "rb").read()
+    assert a == b, ".cdata differs"
+    ga, gb = read_cmeta(got_prefix + ".cmeta"), read_cmeta(want_prefix + ".cmeta")
+    assert ga == gb, ".cmeta differs field-wise"
+    assert sum(ga[0]) == len(a)
+
+
+@pytest.mark.parametrize("name,paired,flags", manifest())
+def test_host_pipeline_reproduces_reference_archives(emu_lib, tmp_path, name, paired, flags):
+    import fastore_amd
+    with fastore_amd.Packer(lib=emu_lib, host_threads=4, **knobs_from_flags(flags)) as p:
+        assert p.device_name == "host-emulation"
+        st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / "o"))
+    assert_same_archive(str(tmp_path / "o"), os.path.join(GOLDEN, name + ".ref"))
+    assert st["bins"] > 20 and st["block0_records"] > 0      # both the LZ path and block 0 are exercised
+
+
+def test_missing_input_is_an_error(emu_lib, tmp_path):
+    import fastore_amd
+    with fastore_amd.Packer(lib=emu_lib) as p:
+        with pytest.raises(fastore_amd.FastoreError, match="Cannot open file"):
+            p.pack_file(str(tmp_path / "nope"), str(tmp_path / "o"))
+
+
+def test_truncated_meta_is_an_error(emu_lib, tmp_path):
+    import fastore_amd, shutil
+    for e in ("bmeta", "bdna", "bqua", "bhead"):
+        shutil.copy(os.path.join(GOLDEN, "se_lossless.in." + e), str(tmp_path / ("x." + e)))
+    data = open(str(tmp_path / "x.bmeta"), "rb").read()
+    open(str(tmp_path / "x.bmeta"), "wb").write(data[:len(data) // 2])
+    with fastore_amd.Packer(lib=emu_lib) as p:
+        with pytest.raises(fastore_amd.FastoreError):
+            p.pack_file(str(tmp_path / "x"), str(tmp_path / "o"))
