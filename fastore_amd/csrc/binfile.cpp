@@ -1,5 +1,9 @@
 #include "binfile.h"
+#include <fcntl.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <stdexcept>
 #include "bitio.h"
 
@@ -10,13 +14,6 @@ namespace {
 struct FileHeader { uint64_t footerOffset, recordsCount, blockCount, footerSize; uint8_t usesHeaderStream; uint8_t reserved[7]; };
 static_assert(sizeof(FileHeader) == 40, "BinFileHeader::HeaderSize");
 
-FILE* openOrThrow(const std::string& name)
-{
-    FILE* f = fopen(name.c_str(), "rb");
-    if (!f) throw std::runtime_error("Cannot open file: " + name);
-    return f;
-}
-uint64_t fileSize(FILE* f) { fseeko(f, 0, SEEK_END); uint64_t n = (uint64_t)ftello(f); fseeko(f, 0, SEEK_SET); return n; }
 
 uint32_t bitLength(uint64_t x) { for (uint32_t i = 0; i < 32; ++i) if (x < (1ull << i)) return i; return 64; }
 const uint32_t kBitsPerClass[4] = {4, 8, 16, 30};
@@ -175,32 +172,48 @@ struct Unpacker {
 
 BinFile::~BinFile() { close(); }
 
-void BinFile::close()
-{
-    for (FILE** f : {&meta_, &dna_, &qua_, &headf_}) if (*f) { fclose(*f); *f = nullptr; }
-}
+void BinFile::close() { unmap(meta_); unmap(dna_); unmap(qua_); unmap(headf_); }
 
-void BinFile::readAt(FILE* f, uint64_t off, void* dst, uint64_t n, const char* what)
+// The four stream files are mapped read-only: a signature's slices are scattered over them in
+// thousands of small pieces (one per bin/rebin worker flush), which made seek+read the dominant cost.
+BinFile::Map BinFile::mapFile(const std::string& name)
+{
+    const int fd = ::open(name.c_str(), O_RDONLY);
+    if (fd < 0) throw std::runtime_error("Cannot open file: " + name);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error("Cannot open file: " + name); }
+    Map m; m.size = (uint64_t)st.st_size;
+    if (m.size) {
+        void* p = mmap(nullptr, m.size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (p == MAP_FAILED) { ::close(fd); throw std::runtime_error("Cannot open file: " + name); }
+        m.p = (const uint8_t*)p;
+    }
+    ::close(fd);
+    return m;
+}
+void BinFile::unmap(Map& m) { if (m.p) munmap((void*)m.p, m.size); m.p = nullptr; m.size = 0; }
+void BinFile::copyAt(const Map& m, uint64_t off, void* dst, uint64_t n, const char* what)
 {
     if (n == 0) return;
-    if (fseeko(f, (off_t)off, SEEK_SET) != 0 || fread(dst, 1, n, f) != n) throw std::runtime_error(std::string("Cannot read ") + what);
+    if (off + n > m.size) throw std::runtime_error(std::string("Cannot read ") + what);
+    memcpy(dst, m.p + off, n);
 }
 
 void BinFile::open(const std::string& prefix, uint32_t minBinSize)
 {
     close();
-    meta_ = openOrThrow(prefix + ".bmeta");
-    const uint64_t metaSize = fileSize(meta_);
+    meta_ = mapFile(prefix + ".bmeta");
+    const uint64_t metaSize = meta_.size;
     if (metaSize == 0) throw std::runtime_error("Empty file.");
-    dna_ = openOrThrow(prefix + ".bdna");
-    qua_ = openOrThrow(prefix + ".bqua");
+    dna_ = mapFile(prefix + ".bdna");
+    qua_ = mapFile(prefix + ".bqua");
     FileHeader fh; memset(&fh, 0, sizeof fh);
-    readAt(meta_, 0, &fh, sizeof fh, "bin header");
+    copyAt(meta_, 0, &fh, sizeof fh, "bin header");
     if (fh.blockCount == 0 || fh.footerOffset + fh.footerSize > metaSize) throw std::runtime_error("Corrupted archive header");
     usesHeaderStream_ = fh.usesHeaderStream != 0;
-    if (usesHeaderStream_) headf_ = openOrThrow(prefix + ".bhead");
+    if (usesHeaderStream_) headf_ = mapFile(prefix + ".bhead");
     std::vector<uint8_t> footer(fh.footerSize);
-    readAt(meta_, fh.footerOffset, footer.data(), fh.footerSize, "bin footer");
+    copyAt(meta_, fh.footerOffset, footer.data(), fh.footerSize, "bin footer");
     readFooter(footer);
     // BinFileExtractor::StartDecompress: split signatures (N bin excluded) by record count
     std_.clear(); small_.clear();
@@ -271,10 +284,10 @@ void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin)
     bHead_.resize(usesHeaderStream_ ? bi.totalHeadSize : 0);
     uint64_t mo = 0, dO = 0, qo = 0, ho = 0, rawDna = 0, records = 0;
     for (const BlockMetaDataRaw& blk : bi.blocks) {
-        readAt(meta_, blk.metaFileOffset, bMeta_.data() + mo, blk.metaSize, ".bmeta"); mo += blk.metaSize;
-        readAt(dna_, blk.dnaFileOffset, bDna_.data() + dO, blk.dnaSize, ".bdna"); dO += blk.dnaSize;
-        readAt(qua_, blk.quaFileOffset, bQua_.data() + qo, blk.quaSize, ".bqua"); qo += blk.quaSize;
-        if (usesHeaderStream_) { readAt(headf_, blk.headFileOffset, bHead_.data() + ho, blk.headSize, ".bhead"); ho += blk.headSize; }
+        copyAt(meta_, blk.metaFileOffset, bMeta_.data() + mo, blk.metaSize, ".bmeta"); mo += blk.metaSize;
+        copyAt(dna_, blk.dnaFileOffset, bDna_.data() + dO, blk.dnaSize, ".bdna"); dO += blk.dnaSize;
+        copyAt(qua_, blk.quaFileOffset, bQua_.data() + qo, blk.quaSize, ".bqua"); qo += blk.quaSize;
+        if (usesHeaderStream_) { copyAt(headf_, blk.headFileOffset, bHead_.data() + ho, blk.headSize, ".bhead"); ho += blk.headSize; }
         rawDna += blk.rawDnaSize; records += blk.recordsCount;
     }
     if (asNewBin || batch.bins.empty()) {
@@ -285,7 +298,6 @@ void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin)
     bin.rawDnaSize += rawDna;
     uint32_t recIdx = (uint32_t)batch.recs.size();
     batch.recs.resize(batch.recs.size() + records, Rec{});
-    batch.seq.reserve(batch.seq.size() + rawDna); batch.qua.reserve(batch.qua.size() + rawDna);
 
     Unpacker u(cfg_, batch, bMeta_, mo, bDna_, dO, bQua_, qo, bHead_, ho);
     Settings s;

@@ -6,7 +6,6 @@
 //   FastqNodesPackerSE/PE::ReadRecordData / ReadExactMatch     fastore_rebin/NodesPacker.cpp:705-979
 //   IFastqPacker::ReadNextRecord / ReadDna / ReadQuality / ReadHeader   fastore_bin/FastqPacker.cpp:62-411
 #pragma once
-#include <stdio.h>
 #include <map>
 #include <string>
 #include <vector>
@@ -36,9 +35,12 @@ public:
 
 private:
     void readFooter(const std::vector<uint8_t>& buf);
-    void readAt(FILE* f, uint64_t off, void* dst, uint64_t n, const char* what);
+    struct Map { const uint8_t* p = nullptr; uint64_t size = 0; };    // read-only mmap of one stream file
+    static Map mapFile(const std::string& name);
+    static void unmap(Map& m);
+    static void copyAt(const Map& m, uint64_t off, void* dst, uint64_t n, const char* what);
 
-    FILE *meta_ = nullptr, *dna_ = nullptr, *qua_ = nullptr, *headf_ = nullptr;
+    Map meta_, dna_, qua_, headf_;
     BinModuleConfigRaw cfg_{};
     bool usesHeaderStream_ = false;
     std::map<uint32_t, BinInfo> bins_;

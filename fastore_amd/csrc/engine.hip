@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <time.h>
 #include <algorithm>
 #include <vector>
 
@@ -122,8 +124,11 @@ int device_count()
     return n;
 }
 
+static double wallMs() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; }
+
 int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size_t errLen)
 {
+    const double tc0 = wallMs();
     Device* dev = new Device();
     memset(dev, 0, sizeof *dev);
     *out = dev;
@@ -151,6 +156,7 @@ int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size
     if ((e = hipMalloc((void**)&dev->queueHead, 64)) != hipSuccess) return fail("hipMalloc(queue)", e);
     if ((e = hipEventCreate((hipEvent_t*)&dev->ev[0])) != hipSuccess) return fail("hipEventCreate", e);
     for (int i = 1; i < 4; ++i) (void)hipEventCreate((hipEvent_t*)&dev->ev[i]);
+    if (getenv("FS_TRACE")) fprintf(stderr, "[trace] device_create: %u waves, %.1f GB of arenas, %.1f ms\n", waves, waves * (double)kArenaStride / 1e9, wallMs() - tc0);
     return 0;
 }
 
@@ -204,6 +210,7 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
                        (uint8_t*)dev->arenas, (uint32_t*)dev->queueHead);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));
+    if (getenv("FS_TRACE")) { HIP_TRY(hipStreamSynchronize(st)); }
     sizes.resize(nItems);
     std::vector<uint32_t> restarts(nItems);
     HIP_TRY(hipMemcpyAsync(sizes.data(), dev->dSizes, 4ull * nItems, hipMemcpyDeviceToHost, st));

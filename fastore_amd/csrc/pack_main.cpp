@@ -3,7 +3,8 @@
 // argument e|d, >= 3 arguments, -i<prefix> -o<prefix> -t<n> [-z] [-v] and the matcher/consensus
 // knobs; errors as "Error: <what>" on stderr with exit status 255.  `d` (decode) is outside this
 // build's scope: it is delegated to the reference binary when FASTORE_PACK_REF is set.
-// New flags: -g<device> (HIP device ordinal), -R<rank>/-N<world> (bin sharding).
+// New flags: -g<device> (HIP device ordinal), -j<n> (host threads beyond the reference's -t limit of 64),
+// -R<rank>/-N<world> (bin sharding).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -33,7 +34,7 @@ int main(int argc, char** argv)
         perror("Error: execv"); return 255;
     }
     fsgpu_config cfg; fsgpu_config_defaults(&cfg);
-    std::string in, out; int verbose = 0; int threads = 0; bool pe = false;
+    std::string in, out; int verbose = 0; int threads = 0, hostThreads = -1; bool pe = false;
     for (int i = 2; i < argc; ++i) {
         const char* p = argv[i];
         if (p[0] != '-') continue;
@@ -60,6 +61,7 @@ int main(int argc, char** argv)
         case 'd': cfg.max_hamming_distance = v; break;
         case 'c': cfg.min_consensus_size = v; break;
         case 'g': cfg.device_id = v; break;
+        case 'j': hostThreads = v; break;
         case 'R': cfg.rank = v; break;
         case 'N': cfg.world_size = v; break;
         }
@@ -68,16 +70,16 @@ int main(int argc, char** argv)
     if (in.empty()) { fprintf(stderr, "Error: no input file specified\n"); return 255; }
     if (out.empty()) { fprintf(stderr, "Error: no output file(s) specified\n"); return 255; }
     if (threads < 0 || threads > 64) { fprintf(stderr, "Error: invalid number of threads specified\n"); return 255; }
-    cfg.host_threads = (uint32_t)threads;
+    cfg.host_threads = hostThreads >= 0 ? (uint32_t)hostThreads : (uint32_t)threads;   // -j overrides -t (which keeps the reference's 1..64 range)
     fsgpu_ctx* ctx = fsgpu_create(&cfg);
     if (!ctx) { fprintf(stderr, "Error: %s\n", fsgpu_create_error()); return 255; }
     const int rc = fsgpu_pack_file(ctx, in.c_str(), out.c_str(), verbose);
     if (rc != 0) { fprintf(stderr, "Error: %s\n", fsgpu_last_error(ctx)); fsgpu_destroy(ctx); return 255; }
     if (verbose) {
         fsgpu_stats st; fsgpu_get_stats(ctx, &st);
-        fprintf(stderr, "device %s: %llu bins, %llu records, encode kernel %.1f ms, assemble %.1f ms, front end %.1f ms, block0 %.1f ms, total %.1f ms\n",
+        fprintf(stderr, "device %s: %llu bins, %llu records, encode kernel %.1f ms, assemble %.1f ms, front end %.1f ms, block0 %.1f ms, io %.1f ms, total %.1f ms\n",
                 fsgpu_device_name(ctx), (unsigned long long)st.bins, (unsigned long long)st.records, st.encode_kernel_ms, st.assemble_kernel_ms,
-                st.frontend_ms, st.block0_ms, st.total_ms);
+                st.frontend_ms, st.block0_ms, st.io_ms, st.total_ms);
     }
     fsgpu_destroy(ctx);
     return 0;

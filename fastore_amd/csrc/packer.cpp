@@ -1,5 +1,6 @@
 #include "packer.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <atomic>
@@ -162,6 +163,7 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
         }
         stats.records += bin.recCount;
     }
+    const double t1 = nowMs();
     std::vector<uint8_t> input(inBytes + 16);
     parallelFor(nBins, hostThreads, [&](uint32_t b, uint32_t) {
         const BlockPlan& pl = plans[b];
@@ -171,8 +173,10 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
         }
     });
     st.clear(); st.shrink_to_fit();
+    const double t2 = nowMs();
     if (fsengine::encode_batch(dev, input.data(), inBytes, items, plans, blocks, blockSizes, &timing) != 0)
         throw std::runtime_error(std::string("device: ") + dev->err);
+    if (getenv("FS_TRACE")) fprintf(stderr, "[trace] batch: %u bins, frontend %.1f ms, stage streams %.1f ms (%.1f MB), device call %.1f ms\n", nBins, t1 - t0, t2 - t1, inBytes / 1e6, nowMs() - t2);
     stats.bins += nBins;
     for (uint32_t b = 0; b < nBins; ++b) {
         const BinIn& bin = batch.bins[b];
