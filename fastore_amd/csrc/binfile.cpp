@@ -274,8 +274,9 @@ void BinFile::readFooter(const std::vector<uint8_t>& buf)
     }
 }
 
-void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin)
+void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin) const
 {
+    std::vector<uint8_t> bMeta_, bDna_, bQua_, bHead_;
     const auto it = bins_.find(signature);
     if (it == bins_.end()) throw std::runtime_error("signature not present in bin file");
     const BinInfo& bi = it->second;

@@ -31,7 +31,8 @@ public:
 
     // Unpack one signature into `batch`.  asNewBin: start a new BinIn; otherwise append the
     // records/nodes to the last bin of the batch (block-0 merge of small bins and the N bin).
-    void unpack(uint32_t signature, Batch& batch, bool asNewBin);
+    // Thread-safe: only reads the mapped files and the footer tables.
+    void unpack(uint32_t signature, Batch& batch, bool asNewBin) const;
 
 private:
     void readFooter(const std::vector<uint8_t>& buf);
@@ -47,7 +48,6 @@ private:
     HeaderStats head_;
     std::vector<uint8_t> qvzBytes_;
     std::vector<uint32_t> std_, small_;
-    std::vector<uint8_t> bMeta_, bDna_, bQua_, bHead_;   // scratch for one signature
 };
 
 }  // namespace fs

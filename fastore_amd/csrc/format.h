@@ -95,6 +95,8 @@ struct Batch {
     std::vector<uint32_t> emRecs;
     std::vector<TreeIn> trees;
     std::vector<BinIn> bins;
+    // append `o` (whole bins) behind this batch, re-basing every index
+    void append(const Batch& o);
     void clear() { seq.clear(); qua.clear(); head.clear(); recs.clear(); nodes.clear(); topNodes.clear(); emRecs.clear(); trees.clear(); bins.clear(); }
 };
 

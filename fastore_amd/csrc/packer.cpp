@@ -34,6 +34,23 @@ template <class F> void parallelFor(uint32_t n, uint32_t threads, F f)
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+void Batch::append(const Batch& o)
+{
+    const uint64_t seqBase = seq.size(), headBase = head.size();
+    const uint32_t recBase = (uint32_t)recs.size(), nodeBase = (uint32_t)nodes.size(), topBase = (uint32_t)topNodes.size(),
+                   emBase = (uint32_t)emRecs.size(), treeBase = (uint32_t)trees.size();
+    if (seqBase + o.seq.size() > 0xFFFFFFF0ull || headBase + o.head.size() > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB");
+    seq.insert(seq.end(), o.seq.begin(), o.seq.end()); qua.insert(qua.end(), o.qua.begin(), o.qua.end());
+    head.insert(head.end(), o.head.begin(), o.head.end());
+    for (Rec r : o.recs) { r.seqOff += (uint32_t)seqBase; r.headOff += (uint32_t)headBase; recs.push_back(r); }
+    for (NodeIn n : o.nodes) { n.rec += recBase; n.emBegin += emBase; n.treeBegin += treeBase; nodes.push_back(n); }
+    for (uint32_t t : o.topNodes) topNodes.push_back(t + nodeBase);
+    for (uint32_t e : o.emRecs) emRecs.push_back(e + recBase);
+    for (TreeIn t : o.trees) { t.nodeBegin += nodeBase; trees.push_back(t); }
+    for (BinIn b : o.bins) { b.recBegin += recBase; b.topBegin += topBase; bins.push_back(b); }
+}
+
+// ------------------------------------------------------------------------------------------------
 void parseHeaderFields(const uint8_t* p, size_t n, bool pairedEnd, HeaderStats& out)
 {
     out = HeaderStats();
@@ -296,18 +313,28 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         for (auto& p : L.pending) { uint64_t off = 0; for (size_t k = 0; k < p.sizes.size(); ++k) { L.aw.writeBlock(p.data.data() + off, p.sizes[k], p.sigs[k]); off += p.sizes[k]; } }
         L.pending.clear();
     };
-    const uint64_t budget = cfg.batch_bases ? cfg.batch_bases : (768ull << 20);
+    const uint64_t budget = cfg.batch_bases ? cfg.batch_bases : (3072ull << 20);
     Batch batch; std::vector<uint32_t> binArch; size_t next = 0, done = 0;
     try {
         while (next < work.size()) {
             batch.clear(); binArch.clear();
             double tio = nowMs();
+            // choose the bins of this batch by their (known) unpacked size, unpack them in parallel, then concatenate
+            const size_t first = next; uint64_t bases = 0;
             while (next < work.size()) {
-                const Work& w = work[next];
-                const uint64_t add = libs[w.lib]->bf.bins().at(w.sig).totalRawDnaSize;
-                if (!batch.bins.empty() && batch.seq.size() + add > budget) break;
-                libs[w.lib]->bf.unpack(w.sig, batch, true); binArch.push_back(w.lib); ++next;
+                const uint64_t add = libs[work[next].lib]->bf.bins().at(work[next].sig).totalRawDnaSize;
+                if (next > first && bases + add > budget) break;
+                bases += add; ++next;
             }
+            const uint32_t nb = (uint32_t)(next - first);
+            const uint32_t chunks = std::min<uint32_t>(nb, std::max(1u, hostThreads));
+            std::vector<Batch> parts(chunks);
+            parallelFor(chunks, hostThreads, [&](uint32_t c, uint32_t) {
+                for (size_t k = first + (size_t)nb * c / chunks; k < first + (size_t)nb * (c + 1) / chunks; ++k) libs[work[k].lib]->bf.unpack(work[k].sig, parts[c], true);
+            });
+            batch.seq.reserve(bases); batch.qua.reserve(bases);
+            for (auto& p : parts) { batch.append(p); p = Batch(); }
+            for (size_t k = first; k < next; ++k) binArch.push_back(work[k].lib);
             stats.io_ms += nowMs() - tio;
             compressBatch(batch, binArch);
             uint64_t off = 0;
