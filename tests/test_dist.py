@@ -1,0 +1,39 @@
+"""N > 1 path on CPU: two ranks over gloo shard the bins of ONE archive, exchange only the block sizes
+(all_gather) and each writes its own blocks at the derived offsets -- the result must equal the golden
+single-writer archive.  Uses the test-only host emulation of the kernels (no GPU in this container)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import GOLDEN, ROOT, knobs_from_flags, manifest
+from test_host import assert_same_archive, emu_lib  # noqa: F401  (fixture)
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+import fastore_amd
+from fastore_amd import shard
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=int(sys.argv[4]))
+lib = fastore_amd.load_library(os.path.join(sys.argv[1], "build", "libfastore_emu.so"))
+knobs = eval(sys.argv[7])
+with fastore_amd.Packer(lib=lib, host_threads=2, rank=dist.get_rank(), world_size=dist.get_world_size(), **knobs) as p:
+    shard.pack_sharded(p, sys.argv[5], sys.argv[6], dist)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("name", ["se_lossless", "pe_lossless"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pack_equals_single_writer(emu_lib, tmp_path, name, world):
+    flags = [m for m in manifest() if m[0] == name][0][2]
+    script = tmp_path / "w.py"; script.write_text(WORKER)
+    port = str(29500 + (os.getpid() + world) % 400)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(world), os.path.join(GOLDEN, name + ".in"),
+                               str(tmp_path / "o"), repr(knobs_from_flags(flags))]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    assert_same_archive(str(tmp_path / "o"), os.path.join(GOLDEN, name + ".ref"))
+    assert not [f for f in os.listdir(tmp_path) if ".part" in f]
