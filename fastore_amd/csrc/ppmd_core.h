@@ -274,11 +274,18 @@ FS_DEV void StartModelRare(Coder& m)
 
 FS_DEV void RestoreModelRare(Coder& m) { m.pText = 1u; StartModelRare(m); m.EscCount = 0; m.restarts++; }
 
-FS_DEV uint32_t find_sym(Coder& m, uint32_t pc, uint32_t sym)      // state of `sym` in a multi-symbol context (must exist)
+// state of `sym` in a multi-symbol context (it must exist): 64 states are probed per step, one per lane
+FS_DEV uint32_t find_sym(Coder& m, uint32_t pc, uint32_t sym)
 {
-    uint32_t p = C_STATS(pc);
-    if (S_SYM(p) != sym) do { p += 6; } while (S_SYM(p) != sym);
-    return p;
+    const uint32_t stats = C_STATS(pc), ns = C_NS(pc);
+    for (uint32_t base = 0;; base += FS_WAVE) {
+        const uint32_t i = base + (uint32_t)FS_LANE();
+        const bool valid = i <= ns;
+        const uint32_t s = valid ? (uint32_t)*HP(stats + 6u * i) : 0x100u;
+        const uint64_t hit = fs_ballot(valid && s == sym);
+        if (hit) return stats + 6u * (base + fs_ctz64(hit));
+        if (base + FS_WAVE > ns) return stats;          // unreachable for well-formed models; never spin
+    }
 }
 
 FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pc)
@@ -500,31 +507,48 @@ FS_DEV void encodeBinSymbol(Coder& m, uint32_t c, int symbol)
 FS_DEV void encodeSymbol1(Coder& m, uint32_t c, int symbol)
 {
     uint32_t p = C_STATS(c);
-    uint32_t i, LoCnt = S_FREQ(p); m.rScale = C_SF(c);
-    if ((int)S_SYM(p) == symbol) {
+    const uint32_t stats = p, ns = C_NS(c);
+    const uint32_t sf0 = S_SYMFREQ(p);
+    uint32_t LoCnt = sf0 >> 8; m.rScale = C_SF(c);
+    if ((int)(sf0 & 0xFFu) == symbol) {
         m.PrevSuccess = (2 * (m.rHigh = LoCnt) > m.rScale);
         m.FoundState = p; S_FREQ_SET(p, LoCnt += 4); C_SF_SET(c, m.rScale + 4);
         if (LoCnt > MAX_FREQ) rescale(m, c);
         m.rLow = 0; return;
     }
-    i = C_NS(c); m.PrevSuccess = 0;
-    for (;;) {
-        p += 6;
-        if ((int)S_SYM(p) == symbol) break;
-        LoCnt += S_FREQ(p);
-        if (--i == 0) {
-            m.rLow = LoCnt; m.sh->CharMask[S_SYM(p)] = (uint8_t)m.EscCount;
-            i = m.NumMasked = C_NS(c); m.FoundState = 0;
-            do { p -= 6; m.sh->CharMask[S_SYM(p)] = (uint8_t)m.EscCount; } while (--i);
-            m.rHigh = m.rScale; return;
+    m.PrevSuccess = 0;
+    // states 1..ns, 64 per step: symbol match by ballot, cumulative frequency by bit-sliced popcounts
+    bool found = false; uint32_t fFound = 0;
+    for (uint32_t base = 1; base <= ns; base += FS_WAVE) {
+        const uint32_t i = base + (uint32_t)FS_LANE();
+        const bool valid = i <= ns;
+        const uint32_t sf = valid ? (uint32_t)*(const uint16_t*)HP(stats + 6u * i) : 0u;
+        const uint64_t hit = fs_ballot(valid && (int)(sf & 0xFFu) == symbol);
+        if (hit) {
+            const uint32_t k = fs_ctz64(hit);
+            LoCnt += fs_wave_sum8(sf >> 8, valid && (uint32_t)FS_LANE() < k);
+            fFound = fs_readlane(sf >> 8, k);
+            p = stats + 6u * (base + k); found = true; break;
         }
+        LoCnt += fs_wave_sum8(sf >> 8, valid);
     }
-    m.rHigh = (m.rLow = LoCnt) + S_FREQ(p);
+    if (!found) {                                           // escape: mask every symbol of the context
+        m.rLow = LoCnt;
+        const uint8_t esc = (uint8_t)m.EscCount;
+        for (uint32_t base = 0; base <= ns; base += FS_WAVE) {
+            const uint32_t i = base + (uint32_t)FS_LANE();
+            if (i <= ns) m.sh->CharMask[*HP(stats + 6u * i)] = esc;
+        }
+        FS_WAVE_SYNC();
+        m.NumMasked = ns; m.FoundState = 0;
+        m.rHigh = m.rScale; return;
+    }
+    m.rHigh = (m.rLow = LoCnt) + fFound;
     // update1
-    m.FoundState = p; S_FREQ_SET(p, S_FREQ(p) + 4); C_SF_SET(c, m.rScale + 4);
-    if (S_FREQ(p) > S_FREQ(p - 6)) {
+    m.FoundState = p; S_FREQ_SET(p, fFound + 4); C_SF_SET(c, m.rScale + 4);
+    if (fFound + 4 > S_FREQ(p - 6)) {
         state_swap(m, p, p - 6); m.FoundState = (p -= 6);
-        if (S_FREQ(p) > MAX_FREQ) rescale(m, c);
+        if (fFound + 4 > MAX_FREQ) rescale(m, c);
     }
 }
 
@@ -541,28 +565,40 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, int symbol)
         see = (see & 0xFFFF0000u) | summ;
         m.rScale = r + !r;
     } else m.rScale = 1;
-    uint32_t Sym, LoCnt = 0, i = nsC - m.NumMasked;
-    uint32_t p1, p = C_STATS(c) - 6;
+    // unmasked states in list order: lane-parallel (64 states per step)
+    const uint32_t stats = C_STATS(c);
     const uint8_t esc = (uint8_t)m.EscCount;
-    bool found = false;
-    do {
-        do { p += 6; Sym = S_SYM(p); } while (m.sh->CharMask[Sym] == esc);
-        m.sh->CharMask[Sym] = esc;
-        if ((int)Sym == symbol) { found = true; break; }
-        LoCnt += S_FREQ(p);
-    } while (--i);
+    uint32_t LoCnt = 0, p = 0, fFound = 0; bool found = false;
+    uint32_t tail = 0;                                       // frequency of the unmasked states behind the hit
+    for (uint32_t base = 0; base <= nsC; base += FS_WAVE) {
+        const uint32_t i = base + (uint32_t)FS_LANE();
+        const bool valid = i <= nsC;
+        const uint32_t sf = valid ? (uint32_t)*(const uint16_t*)HP(stats + 6u * i) : 0u;
+        const uint32_t sy = sf & 0xFFu;
+        const bool unmasked = valid && m.sh->CharMask[sy] != esc;
+        if (found) { tail += fs_wave_sum8(sf >> 8, unmasked); continue; }
+        const uint64_t hit = fs_ballot(unmasked && (int)sy == symbol);
+        if (hit) {
+            const uint32_t k = fs_ctz64(hit);
+            LoCnt += fs_wave_sum8(sf >> 8, unmasked && (uint32_t)FS_LANE() < k);
+            tail += fs_wave_sum8(sf >> 8, unmasked && (uint32_t)FS_LANE() > k);
+            fFound = fs_readlane(sf >> 8, k);
+            if (unmasked && (uint32_t)FS_LANE() <= k) m.sh->CharMask[sy] = esc;     // visited states are marked
+            p = stats + 6u * (base + k); found = true;
+        } else {
+            LoCnt += fs_wave_sum8(sf >> 8, unmasked);
+            if (unmasked) m.sh->CharMask[sy] = esc;
+        }
+    }
+    FS_WAVE_SYNC();
     if (!found) {
         m.rHigh = (m.rScale += (m.rLow = LoCnt));
         if (seeIdx != 0xFFFFFFFFu) m.sh->SEE2[seeIdx] = (see & 0xFFFF0000u) | ((see + m.rScale) & 0xFFFFu);
         m.NumMasked = nsC;
         return;
     }
-    m.rLow = LoCnt; m.rHigh = (LoCnt += S_FREQ(p));
-    for (p1 = p; --i;) {
-        do { p1 += 6; Sym = S_SYM(p1); } while (m.sh->CharMask[Sym] == esc);
-        LoCnt += S_FREQ(p1);
-    }
-    m.rScale += LoCnt;
+    m.rLow = LoCnt; m.rHigh = LoCnt + fFound;
+    m.rScale += LoCnt + fFound + tail;
     if (seeIdx != 0xFFFFFFFFu) {                                   // psee2c->update()
         uint32_t summ = see & 0xFFFFu, shift = (see >> 16) & 0xFFu, count = (see >> 24) & 0xFFu;
         count = (count - 1) & 0xFFu;
@@ -576,8 +612,8 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, int symbol)
         m.sh->SEE2[seeIdx] = summ | (shift << 16) | (count << 24);
     }
     // update2
-    m.FoundState = p; S_FREQ_SET(p, S_FREQ(p) + 4); C_SF_SET(c, C_SF(c) + 4);
-    if (S_FREQ(p) > MAX_FREQ) rescale(m, c);
+    m.FoundState = p; S_FREQ_SET(p, fFound + 4); C_SF_SET(c, C_SF(c) + 4);
+    if (fFound + 4 > MAX_FREQ) rescale(m, c);
     m.EscCount = (m.EscCount + 1) & 0xFFu; m.RunLength = m.InitRL;
 }
 

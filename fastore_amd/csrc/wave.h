@@ -43,6 +43,32 @@ FS_DEV void fs_st16(uint8_t* p, uint32_t v) { *(uint16_t*)p = (uint16_t)v; }
 FS_DEV void fs_st32h(uint8_t* p, uint32_t v) { ((uint16_t*)p)[0] = (uint16_t)v; ((uint16_t*)p)[1] = (uint16_t)(v >> 16); }
 FS_DEV void fs_st32(uint8_t* p, uint32_t v) { *(uint32_t*)p = v; }
 
+// ---- cross-lane helpers (host build: one lane) ----
+#if defined(__HIP_DEVICE_COMPILE__)
+FS_DEV uint64_t fs_ballot(bool p) { return __ballot(p); }
+FS_DEV uint32_t fs_popc64(uint64_t x) { return (uint32_t)__popcll(x); }
+FS_DEV uint32_t fs_ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
+FS_DEV uint32_t fs_readlane(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+#else
+FS_DEV uint64_t fs_ballot(bool p) { return p ? 1u : 0u; }
+FS_DEV uint32_t fs_popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+FS_DEV uint32_t fs_ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
+FS_DEV uint32_t fs_readlane(uint32_t v, uint32_t) { return v; }
+#endif
+// sum over the lanes with `pred` of an 8-bit value per lane: bit-sliced ballots + scalar popcounts,
+// no cross-lane data movement (8 x {v_cmp, s_bcnt1})
+FS_DEV uint32_t fs_wave_sum8(uint32_t v, bool pred)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t s = 0;
+    #pragma unroll
+    for (int b = 0; b < 8; ++b) s += fs_popc64(fs_ballot(pred && ((v >> b) & 1u))) << b;
+    return s;
+#else
+    return pred ? v : 0u;
+#endif
+}
+
 // cooperative copy / fill of 4-byte aligned regions (n bytes, n % 4 == 0), non-overlapping
 FS_DEV void fs_wave_copy4(uint8_t* d, const uint8_t* s, uint32_t n)
 {
