@@ -28,11 +28,13 @@ struct Device {
     uint32_t* dRestarts; size_t capRestarts;
     void* dPlans; size_t capPlans;
     uint8_t* dBlocks; size_t capBlocks;
+    uint8_t* hStage; size_t capStage;
 };
 
 int device_count();
 int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size_t errLen);
 void device_destroy(Device* dev);
+uint8_t* staging_buffer(Device* dev, size_t bytes);     // grow-only pinned host buffer for the batch input
 int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,
                        std::vector<uint8_t>& raw, std::vector<uint32_t>& sizes, BatchTiming* timing);
 int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,

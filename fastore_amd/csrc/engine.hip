@@ -166,9 +166,21 @@ void device_destroy(Device* dev)
     (void)hipSetDevice(dev->deviceId);
     void* ptrs[] = {dev->arenas, dev->queueHead, dev->dIn, dev->dScratch, dev->dItems, dev->dOrder, dev->dSizes, dev->dRestarts, dev->dPlans, dev->dBlocks};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (dev->hStage) (void)hipHostFree(dev->hStage);
     for (int i = 0; i < 4; ++i) if (dev->ev[i]) (void)hipEventDestroy((hipEvent_t)dev->ev[i]);
     if (dev->stream) (void)hipStreamDestroy((hipStream_t)dev->stream);
     delete dev;
+}
+
+uint8_t* staging_buffer(Device* dev, size_t bytes)
+{
+    if (bytes <= dev->capStage && dev->hStage) return dev->hStage;
+    if (dev->hStage) (void)hipHostFree(dev->hStage);
+    dev->hStage = nullptr; dev->capStage = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc((void**)&dev->hStage, want, hipHostMallocDefault) != hipSuccess) { snprintf(dev->err, sizeof dev->err, "hipHostMalloc(%zu) failed", want); return nullptr; }
+    dev->capStage = want;
+    return dev->hStage;
 }
 
 // H2D + fs_encode_streams + D2H of the per-stream sizes.  Leaves the coded streams in dev->dScratch.

@@ -181,17 +181,18 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
         stats.records += bin.recCount;
     }
     const double t1 = nowMs();
-    std::vector<uint8_t> input(inBytes + 16);
+    uint8_t* input = fsengine::staging_buffer(dev, inBytes + 16);        // pinned host memory owned by the engine
+    if (!input) throw std::runtime_error(std::string("device: ") + dev->err);
     parallelFor(nBins, hostThreads, [&](uint32_t b, uint32_t) {
         const BlockPlan& pl = plans[b];
         for (uint32_t s = 0; s < pl.n_streams; ++s) {
             const auto& v = st[b].s[s];
-            if (!v.empty()) memcpy(input.data() + items[pl.first_item + s].in_off, v.data(), v.size());
+            if (!v.empty()) memcpy(input + items[pl.first_item + s].in_off, v.data(), v.size());
         }
     });
     st.clear(); st.shrink_to_fit();
     const double t2 = nowMs();
-    if (fsengine::encode_batch(dev, input.data(), inBytes, items, plans, blocks, blockSizes, &timing) != 0)
+    if (fsengine::encode_batch(dev, input, inBytes, items, plans, blocks, blockSizes, &timing) != 0)
         throw std::runtime_error(std::string("device: ") + dev->err);
     if (getenv("FS_TRACE")) fprintf(stderr, "[trace] batch: %u bins, frontend %.1f ms, stage streams %.1f ms (%.1f MB), device call %.1f ms\n", nBins, t1 - t0, t2 - t1, inBytes / 1e6, nowMs() - t2);
     stats.bins += nBins;
@@ -332,8 +333,30 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             parallelFor(chunks, hostThreads, [&](uint32_t c, uint32_t) {
                 for (size_t k = first + (size_t)nb * c / chunks; k < first + (size_t)nb * (c + 1) / chunks; ++k) libs[work[k].lib]->bf.unpack(work[k].sig, parts[c], true);
             });
-            batch.seq.reserve(bases); batch.qua.reserve(bases);
-            for (auto& p : parts) { batch.append(p); p = Batch(); }
+            {   // concatenate the parts in parallel: destination offsets are a prefix sum over the parts
+                std::vector<uint64_t> oSeq(chunks + 1, 0), oHead(chunks + 1, 0), oRec(chunks + 1, 0), oNode(chunks + 1, 0), oTop(chunks + 1, 0), oEm(chunks + 1, 0), oTree(chunks + 1, 0), oBin(chunks + 1, 0);
+                for (uint32_t c = 0; c < chunks; ++c) {
+                    oSeq[c + 1] = oSeq[c] + parts[c].seq.size(); oHead[c + 1] = oHead[c] + parts[c].head.size(); oRec[c + 1] = oRec[c] + parts[c].recs.size();
+                    oNode[c + 1] = oNode[c] + parts[c].nodes.size(); oTop[c + 1] = oTop[c] + parts[c].topNodes.size(); oEm[c + 1] = oEm[c] + parts[c].emRecs.size();
+                    oTree[c + 1] = oTree[c] + parts[c].trees.size(); oBin[c + 1] = oBin[c] + parts[c].bins.size();
+                }
+                if (oSeq[chunks] > 0xFFFFFFF0ull || oHead[chunks] > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB");
+                batch.seq.resize(oSeq[chunks]); batch.qua.resize(oSeq[chunks]); batch.head.resize(oHead[chunks]); batch.recs.resize(oRec[chunks]);
+                batch.nodes.resize(oNode[chunks]); batch.topNodes.resize(oTop[chunks]); batch.emRecs.resize(oEm[chunks]); batch.trees.resize(oTree[chunks]); batch.bins.resize(oBin[chunks]);
+                parallelFor(chunks, hostThreads, [&](uint32_t c, uint32_t) {
+                    Batch& o = parts[c];
+                    if (!o.seq.empty()) { memcpy(batch.seq.data() + oSeq[c], o.seq.data(), o.seq.size()); memcpy(batch.qua.data() + oSeq[c], o.qua.data(), o.qua.size()); }
+                    if (!o.head.empty()) memcpy(batch.head.data() + oHead[c], o.head.data(), o.head.size());
+                    const uint32_t sb = (uint32_t)oSeq[c], hb = (uint32_t)oHead[c], rb = (uint32_t)oRec[c], nb2 = (uint32_t)oNode[c], tb = (uint32_t)oTop[c], eb = (uint32_t)oEm[c], trb = (uint32_t)oTree[c];
+                    for (size_t i = 0; i < o.recs.size(); ++i) { Rec r = o.recs[i]; r.seqOff += sb; r.headOff += hb; batch.recs[rb + i] = r; }
+                    for (size_t i = 0; i < o.nodes.size(); ++i) { NodeIn n = o.nodes[i]; n.rec += rb; n.emBegin += eb; n.treeBegin += trb; batch.nodes[nb2 + i] = n; }
+                    for (size_t i = 0; i < o.topNodes.size(); ++i) batch.topNodes[tb + i] = o.topNodes[i] + nb2;
+                    for (size_t i = 0; i < o.emRecs.size(); ++i) batch.emRecs[eb + i] = o.emRecs[i] + rb;
+                    for (size_t i = 0; i < o.trees.size(); ++i) { TreeIn t = o.trees[i]; t.nodeBegin += nb2; batch.trees[trb + i] = t; }
+                    for (size_t i = 0; i < o.bins.size(); ++i) { BinIn b = o.bins[i]; b.recBegin += rb; b.topBegin += tb; batch.bins[oBin[c] + i] = b; }
+                    o = Batch();
+                });
+            }
             for (size_t k = first; k < next; ++k) binArch.push_back(work[k].lib);
             stats.io_ms += nowMs() - tio;
             compressBatch(batch, binArch);
