@@ -67,6 +67,7 @@ struct Coder {
     Shared* sh;
     uint32_t pText, UnitsStart, LoUnit, HiUnit, GlueCount, GlueCount1;
     uint32_t MaxContext, FoundState;
+    uint32_t fsSym, fsFreq, fsSucc;   // register copy of *FoundState (memory is always written through)
     uint32_t NumMasked, PrevSuccess, EscCount;
     int32_t BSumm, OrderFall, RunLength, InitRL;
     uint32_t low, range, rLow, rHigh, rScale;
@@ -112,6 +113,28 @@ FS_DEV void state_swap(Coder& m, uint32_t a, uint32_t b)
     state_store(m, a, b0, b1); state_store(m, b, a0, a1);
 }
 FS_DEV void state_cpy(Coder& m, uint32_t d, uint32_t s) { state_store(m, d, S_SYMFREQ(s), S_SUCC(s)); }
+
+// One context header = one 12-byte fetch (three dwords in flight together), then kept in SGPRs.
+struct Ctx { uint32_t ns, flags, sf, w1 /* iStats, or oneState.iSuccessor */, suff, oneSym, oneFreq; };
+FS_DEV Ctx ctx_load(Coder& m, uint32_t c)
+{
+    const uint32_t* q = (const uint32_t*)HP(c);
+    uint32_t a = q[0], b = q[1], d = q[2];
+    a = FS_UNI(a); b = FS_UNI(b); d = FS_UNI(d);
+    Ctx r; r.ns = a & 0xFFu; r.flags = (a >> 8) & 0xFFu; r.sf = a >> 16; r.w1 = b; r.suff = d; r.oneSym = (a >> 16) & 0xFFu; r.oneFreq = a >> 24;
+    return r;
+}
+// One state = three 16-bit fetches in flight together.
+struct St { uint32_t sym, freq, succ; };
+FS_DEV St st_load(Coder& m, uint32_t s)
+{
+    const uint16_t* q = (const uint16_t*)HP(s);
+    uint32_t a = q[0], b = q[1], c = q[2];
+    a = FS_UNI(a); b = FS_UNI(b); c = FS_UNI(c);
+    St r; r.sym = a & 0xFFu; r.freq = a >> 8; r.succ = b | (c << 16);
+    return r;
+}
+FS_DEV void fs_reload(Coder& m) { if (m.FoundState) { const St t = st_load(m, m.FoundState); m.fsSym = t.sym; m.fsFreq = t.freq; m.fsSucc = t.succ; } }
 
 // ---------------- sub-allocator ----------------
 FS_DEV uint32_t blk_remove(Coder& m, uint32_t n)
@@ -421,8 +444,8 @@ FS_DEV_NOINLINE void rescale(Coder& m, uint32_t c)
 
 FS_DEV void UpdateModel(Coder& m, uint32_t MinContext)
 {
-    const uint32_t FSymbol = S_SYM(m.FoundState), FFreq = S_FREQ(m.FoundState);
-    uint32_t iSuccessor, iFSuccessor = S_SUCC(m.FoundState);
+    const uint32_t FSymbol = m.fsSym, FFreq = m.fsFreq;
+    uint32_t iSuccessor, iFSuccessor = m.fsSucc;
     uint32_t ns1, ns, cf, sf, s0, pc, p = 0;
     bool restart = false;
     if (C_SUFF(MinContext)) {
@@ -483,112 +506,123 @@ FS_DEV void UpdateModel(Coder& m, uint32_t MinContext)
     m.MaxContext = iFSuccessor;
 }
 
-FS_DEV void encodeBinSymbol(Coder& m, uint32_t c, int symbol)
+FS_DEV void encodeBinSymbol(Coder& m, uint32_t c, const Ctx& mc, int symbol)
 {
     const uint32_t rs = C_ONE(c);
-    const uint32_t idx = m.sh->QT[S_FREQ(rs) - 1] * 64u + NS2BSIndx(C_NS(C_SUFF(c))) + m.PrevSuccess + C_FLAGS(c) +
-                         (uint32_t)((m.RunLength >> 26) & 0x20);
+    const uint32_t sufNs = fs_ld8(HP(mc.suff));
+    const uint32_t idx = m.sh->QT[mc.oneFreq - 1] * 64u + NS2BSIndx(sufNs) + m.PrevSuccess + mc.flags + (uint32_t)((m.RunLength >> 26) & 0x20);
     uint32_t bs = FS_UNI(m.sh->BinSumm[idx]);
     m.BSumm = (int32_t)bs;
     const uint32_t tmp = bs * (m.range >>= TOT_BITS);
     bs -= (bs + ROUND) >> PERIOD_BITS;
-    if ((int)S_SYM(rs) == symbol) {
+    if ((int)mc.oneSym == symbol) {
         bs += INTERVAL; m.range = tmp;
-        m.FoundState = rs; S_FREQ_SET(rs, S_FREQ(rs) + (S_FREQ(rs) < 196));
+        const uint32_t nf = mc.oneFreq + (mc.oneFreq < 196);
+        m.FoundState = rs; S_FREQ_SET(rs, nf);
+        m.fsSym = mc.oneSym; m.fsFreq = nf; m.fsSucc = mc.w1;
         m.RunLength++; m.PrevSuccess = 1;
     } else {
         m.low += tmp; m.range *= (uint32_t)(BIN_SCALE - m.BSumm);
-        m.sh->CharMask[S_SYM(rs)] = (uint8_t)m.EscCount;
+        m.sh->CharMask[mc.oneSym] = (uint8_t)m.EscCount;
         m.NumMasked = m.PrevSuccess = 0; m.FoundState = 0;
     }
     m.sh->BinSumm[idx] = (uint16_t)bs;
 }
 
-FS_DEV void encodeSymbol1(Coder& m, uint32_t c, int symbol)
+// per-lane view of 64 consecutive states of a context
+struct LaneStates { uint32_t sf, succ; bool valid; };
+FS_DEV LaneStates lane_states(Coder& m, uint32_t stats, uint32_t ns, uint32_t base)
 {
-    uint32_t p = C_STATS(c);
-    const uint32_t stats = p, ns = C_NS(c);
-    const uint32_t sf0 = S_SYMFREQ(p);
-    uint32_t LoCnt = sf0 >> 8; m.rScale = C_SF(c);
-    if ((int)(sf0 & 0xFFu) == symbol) {
-        m.PrevSuccess = (2 * (m.rHigh = LoCnt) > m.rScale);
-        m.FoundState = p; S_FREQ_SET(p, LoCnt += 4); C_SF_SET(c, m.rScale + 4);
-        if (LoCnt > MAX_FREQ) rescale(m, c);
-        m.rLow = 0; return;
-    }
-    m.PrevSuccess = 0;
-    // states 1..ns, 64 per step: symbol match by ballot, cumulative frequency by bit-sliced popcounts
-    bool found = false; uint32_t fFound = 0;
-    for (uint32_t base = 1; base <= ns; base += FS_WAVE) {
-        const uint32_t i = base + (uint32_t)FS_LANE();
-        const bool valid = i <= ns;
-        const uint32_t sf = valid ? (uint32_t)*(const uint16_t*)HP(stats + 6u * i) : 0u;
-        const uint64_t hit = fs_ballot(valid && (int)(sf & 0xFFu) == symbol);
-        if (hit) {
-            const uint32_t k = fs_ctz64(hit);
-            LoCnt += fs_wave_sum8(sf >> 8, valid && (uint32_t)FS_LANE() < k);
-            fFound = fs_readlane(sf >> 8, k);
-            p = stats + 6u * (base + k); found = true; break;
-        }
-        LoCnt += fs_wave_sum8(sf >> 8, valid);
+    LaneStates r; const uint32_t i = base + (uint32_t)FS_LANE();
+    r.valid = i <= ns; r.sf = 0; r.succ = 0;
+    if (r.valid) { const uint16_t* q = (const uint16_t*)HP(stats + 6u * i); const uint32_t a = q[0], b = q[1], c = q[2]; r.sf = a; r.succ = b | (c << 16); }
+    return r;
+}
+
+FS_DEV void encodeSymbol1(Coder& m, uint32_t c, const Ctx& mc, int symbol)
+{
+    const uint32_t stats = mc.w1, ns = mc.ns;
+    m.rScale = mc.sf;
+    uint32_t LoCnt = 0, p = 0, k = 0, base = 0; bool found = false;
+    LaneStates ls = lane_states(m, stats, ns, 0);
+    for (;;) {
+        const uint64_t hit = fs_ballot(ls.valid && (int)(ls.sf & 0xFFu) == symbol);
+        if (hit) { k = fs_ctz64(hit); LoCnt += fs_wave_sum8(ls.sf >> 8, ls.valid && (uint32_t)FS_LANE() < k); p = stats + 6u * (base + k); found = true; break; }
+        LoCnt += fs_wave_sum8(ls.sf >> 8, ls.valid);
+        if (base + FS_WAVE > ns) break;
+        base += FS_WAVE; ls = lane_states(m, stats, ns, base);
     }
     if (!found) {                                           // escape: mask every symbol of the context
-        m.rLow = LoCnt;
+        m.PrevSuccess = 0; m.rLow = LoCnt;
         const uint8_t esc = (uint8_t)m.EscCount;
-        for (uint32_t base = 0; base <= ns; base += FS_WAVE) {
-            const uint32_t i = base + (uint32_t)FS_LANE();
-            if (i <= ns) m.sh->CharMask[*HP(stats + 6u * i)] = esc;
-        }
+        if (ns < FS_WAVE) { if (ls.valid) m.sh->CharMask[ls.sf & 0xFFu] = esc; }
+        else for (uint32_t b2 = 0; b2 <= ns; b2 += FS_WAVE) { const uint32_t i = b2 + (uint32_t)FS_LANE(); if (i <= ns) m.sh->CharMask[*HP(stats + 6u * i)] = esc; }
         FS_WAVE_SYNC();
         m.NumMasked = ns; m.FoundState = 0;
         m.rHigh = m.rScale; return;
     }
-    m.rHigh = (m.rLow = LoCnt) + fFound;
-    // update1
-    m.FoundState = p; S_FREQ_SET(p, fFound + 4); C_SF_SET(c, m.rScale + 4);
-    if (fFound + 4 > S_FREQ(p - 6)) {
-        state_swap(m, p, p - 6); m.FoundState = (p -= 6);
-        if (fFound + 4 > MAX_FREQ) rescale(m, c);
+    const uint32_t fFound = FS_UNI(fs_readlane(ls.sf >> 8, k)), succ = FS_UNI(fs_readlane(ls.succ, k));
+    m.fsSym = (uint32_t)symbol; m.fsSucc = succ;
+    if (base + k == 0) {                                     // most probable symbol
+        m.PrevSuccess = (2 * (m.rHigh = fFound) > m.rScale);
+        m.FoundState = p; m.fsFreq = fFound + 4; S_FREQ_SET(p, fFound + 4); C_SF_SET(c, m.rScale + 4);
+        if (fFound + 4 > MAX_FREQ) { rescale(m, c); fs_reload(m); }
+        m.rLow = 0; return;
     }
+    m.PrevSuccess = 0;
+    m.rHigh = (m.rLow = LoCnt) + fFound;
+    // update1: +4, then bubble one position up if it now outweighs its predecessor
+    m.FoundState = p; m.fsFreq = fFound + 4; C_SF_SET(c, m.rScale + 4);
+    uint32_t prevSf, prevSucc;
+    if (k > 0) { prevSf = FS_UNI(fs_readlane(ls.sf, k - 1)); prevSucc = FS_UNI(fs_readlane(ls.succ, k - 1)); }
+    else { const St t = st_load(m, p - 6); prevSf = t.sym | (t.freq << 8); prevSucc = t.succ; }
+    if (fFound + 4 > (prevSf >> 8)) {
+        state_store(m, p - 6, (uint32_t)symbol | ((fFound + 4) << 8), succ);
+        state_store(m, p, prevSf, prevSucc);
+        m.FoundState = p - 6;
+        if (fFound + 4 > MAX_FREQ) { rescale(m, c); fs_reload(m); }
+    } else S_FREQ_SET(p, fFound + 4);
 }
 
-FS_DEV void encodeSymbol2(Coder& m, uint32_t c, int symbol)
+FS_DEV void encodeSymbol2(Coder& m, uint32_t c, const Ctx& mc, int symbol)
 {
+    const uint32_t nsC = mc.ns, stats = mc.w1;
+    const uint8_t sufNsRaw = *HP(mc.suff);                       // in flight together with the state fetch below
+    LaneStates ls = lane_states(m, stats, nsC, 0);
     // makeEscFreq2
-    const uint32_t nsC = C_NS(c);
     uint32_t seeIdx = 0xFFFFFFFFu, see = 0;
     if (nsC != 0xFF) {
-        seeIdx = (m.sh->QT[nsC + 3] - 4u) * 32u + (C_SF(c) > 10u * (nsC + 1u)) + 2u * (2u * nsC < C_NS(C_SUFF(c)) + m.NumMasked) + C_FLAGS(c);
+        const uint32_t sufNs = FS_UNI(sufNsRaw);
+        seeIdx = (m.sh->QT[nsC + 3] - 4u) * 32u + (mc.sf > 10u * (nsC + 1u)) + 2u * (2u * nsC < sufNs + m.NumMasked) + mc.flags;
         see = FS_UNI(m.sh->SEE2[seeIdx]);
         const uint32_t shift = (see >> 16) & 0xFFu; uint32_t summ = see & 0xFFFFu;
         const uint32_t r = summ >> shift; summ = (summ - r) & 0xFFFFu;
         see = (see & 0xFFFF0000u) | summ;
         m.rScale = r + !r;
     } else m.rScale = 1;
-    // unmasked states in list order: lane-parallel (64 states per step)
-    const uint32_t stats = C_STATS(c);
+    // unmasked states in list order, 64 per step
     const uint8_t esc = (uint8_t)m.EscCount;
-    uint32_t LoCnt = 0, p = 0, fFound = 0; bool found = false;
-    uint32_t tail = 0;                                       // frequency of the unmasked states behind the hit
-    for (uint32_t base = 0; base <= nsC; base += FS_WAVE) {
-        const uint32_t i = base + (uint32_t)FS_LANE();
-        const bool valid = i <= nsC;
-        const uint32_t sf = valid ? (uint32_t)*(const uint16_t*)HP(stats + 6u * i) : 0u;
-        const uint32_t sy = sf & 0xFFu;
-        const bool unmasked = valid && m.sh->CharMask[sy] != esc;
-        if (found) { tail += fs_wave_sum8(sf >> 8, unmasked); continue; }
-        const uint64_t hit = fs_ballot(unmasked && (int)sy == symbol);
-        if (hit) {
-            const uint32_t k = fs_ctz64(hit);
-            LoCnt += fs_wave_sum8(sf >> 8, unmasked && (uint32_t)FS_LANE() < k);
-            tail += fs_wave_sum8(sf >> 8, unmasked && (uint32_t)FS_LANE() > k);
-            fFound = fs_readlane(sf >> 8, k);
-            if (unmasked && (uint32_t)FS_LANE() <= k) m.sh->CharMask[sy] = esc;     // visited states are marked
-            p = stats + 6u * (base + k); found = true;
-        } else {
-            LoCnt += fs_wave_sum8(sf >> 8, unmasked);
-            if (unmasked) m.sh->CharMask[sy] = esc;
+    uint32_t LoCnt = 0, p = 0, fFound = 0, succ = 0, tail = 0; bool found = false;
+    for (uint32_t base = 0;;) {
+        const uint32_t sy = ls.sf & 0xFFu;
+        const bool unmasked = ls.valid && m.sh->CharMask[sy] != esc;
+        if (found) tail += fs_wave_sum8(ls.sf >> 8, unmasked);
+        else {
+            const uint64_t hit = fs_ballot(unmasked && (int)sy == symbol);
+            if (hit) {
+                const uint32_t k = fs_ctz64(hit);
+                LoCnt += fs_wave_sum8(ls.sf >> 8, unmasked && (uint32_t)FS_LANE() < k);
+                tail += fs_wave_sum8(ls.sf >> 8, unmasked && (uint32_t)FS_LANE() > k);
+                fFound = FS_UNI(fs_readlane(ls.sf >> 8, k)); succ = FS_UNI(fs_readlane(ls.succ, k));
+                if (unmasked && (uint32_t)FS_LANE() <= k) m.sh->CharMask[sy] = esc;     // visited states are marked
+                p = stats + 6u * (base + k); found = true;
+            } else {
+                LoCnt += fs_wave_sum8(ls.sf >> 8, unmasked);
+                if (unmasked) m.sh->CharMask[sy] = esc;
+            }
         }
+        if (base + FS_WAVE > nsC) break;
+        base += FS_WAVE; ls = lane_states(m, stats, nsC, base);
     }
     FS_WAVE_SYNC();
     if (!found) {
@@ -603,17 +637,18 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, int symbol)
         uint32_t summ = see & 0xFFFFu, shift = (see >> 16) & 0xFFu, count = (see >> 24) & 0xFFu;
         count = (count - 1) & 0xFFu;
         if (count == 0) {
-            uint32_t k = summ >> shift;
-            k = PERIOD_BITS - (k > 40) - (k > 280) - (k > 1020);
-            if (k < shift) { summ >>= 1; shift--; }
-            else if (k > shift) { summ = (summ << 1) & 0xFFFFu; shift++; }
+            uint32_t kk = summ >> shift;
+            kk = PERIOD_BITS - (kk > 40) - (kk > 280) - (kk > 1020);
+            if (kk < shift) { summ >>= 1; shift--; }
+            else if (kk > shift) { summ = (summ << 1) & 0xFFFFu; shift++; }
             count = (6u << shift) & 0xFFu;
         }
         m.sh->SEE2[seeIdx] = summ | (shift << 16) | (count << 24);
     }
     // update2
-    m.FoundState = p; S_FREQ_SET(p, fFound + 4); C_SF_SET(c, C_SF(c) + 4);
-    if (fFound + 4 > MAX_FREQ) rescale(m, c);
+    m.FoundState = p; m.fsSym = (uint32_t)symbol; m.fsFreq = fFound + 4; m.fsSucc = succ;
+    S_FREQ_SET(p, fFound + 4); C_SF_SET(c, mc.sf + 4);
+    if (fFound + 4 > MAX_FREQ) { rescale(m, c); fs_reload(m); }
     m.EscCount = (m.EscCount + 1) & 0xFFu; m.RunLength = m.InitRL;
 }
 
@@ -624,7 +659,7 @@ FS_DEV uint32_t encode_member(uint8_t* arena, Shared* sh, const uint8_t* in, uin
 {
     Coder m;
     m.hb = arena - 1; m.sh = sh; m.out = out; m.outCap = outCap; m.outPos = 0; m.restarts = 0;
-    m.NumMasked = 0; m.FoundState = 0; m.BSumm = 0; m.rLow = m.rHigh = m.rScale = 0;
+    m.NumMasked = 0; m.FoundState = 0; m.BSumm = 0; m.rLow = m.rHigh = m.rScale = 0; m.fsSym = m.fsFreq = m.fsSucc = 0;
     for (uint32_t i = (uint32_t)FS_LANE(); i < 260u; i += FS_WAVE) sh->QT[i] = (uint8_t)QTable(i);
     // zero the 64-byte guard behind the heap: GlueFreeBlocks may read one stamp past the end
     for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) *(uint32_t*)(arena + SA_SIZE + 4u * i) = 0u;
@@ -632,23 +667,34 @@ FS_DEV uint32_t encode_member(uint8_t* arena, Shared* sh, const uint8_t* in, uin
     put_byte(m, 0xCA); put_byte(m, MAX_ORDER);
     m.low = 0; m.range = 0xFFFFFFFFu;
     StartModelRare(m);
-    uint32_t pos = 0;
+    // input window: the next aligned dword is requested one step ahead of its first use
+    const bool wide = (((uintptr_t)in) & 3u) == 0;
+    uint32_t pos = 0, cur = 0, nxt = 0;
+    if (wide && n >= 4) nxt = *(const uint32_t*)in;
     for (uint32_t MinContext = m.MaxContext;;) {
-        const int c = (pos < n) ? (int)fs_ld8(in + pos) : -1; pos += (pos < n);
-        if (C_NS(MinContext)) { encodeSymbol1(m, MinContext, c); rc_encode(m); }
-        else encodeBinSymbol(m, MinContext, c);
+        int c = -1;
+        if (pos < n) {
+            if (wide && (pos | 3u) < n) {
+                if ((pos & 3u) == 0) { cur = FS_UNI(nxt); if (pos + 7u < n) nxt = *(const uint32_t*)(in + pos + 4u); }
+                c = (int)((cur >> (8u * (pos & 3u))) & 0xFFu);
+            } else c = (int)fs_ld8(in + pos);
+            pos++;
+        }
+        Ctx mc = ctx_load(m, MinContext);
+        if (mc.ns) { encodeSymbol1(m, MinContext, mc, c); rc_encode(m); }
+        else encodeBinSymbol(m, MinContext, mc, c);
         bool stop = false;
         while (!m.FoundState) {
             rc_normalize(m);
             do {
-                if (!C_SUFF(MinContext)) { stop = true; break; }
-                m.OrderFall++; MinContext = C_SUFF(MinContext);
-            } while (C_NS(MinContext) == m.NumMasked);
+                if (!mc.suff) { stop = true; break; }
+                m.OrderFall++; MinContext = mc.suff; mc = ctx_load(m, MinContext);
+            } while (mc.ns == m.NumMasked);
             if (stop) break;
-            encodeSymbol2(m, MinContext, c); rc_encode(m);
+            encodeSymbol2(m, MinContext, mc, c); rc_encode(m);
         }
         if (stop) break;
-        const uint32_t succ = S_SUCC(m.FoundState);
+        const uint32_t succ = m.fsSucc;
         if (!m.OrderFall && succ >= m.UnitsStart) m.MaxContext = succ;
         else { UpdateModel(m, MinContext); if (m.EscCount == 0) clear_mask(m); }
         rc_normalize(m); MinContext = m.MaxContext;
