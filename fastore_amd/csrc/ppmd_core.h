@@ -587,7 +587,9 @@ FS_DEV void encodeSymbol1(Coder& m, uint32_t c, const Ctx& mc, int symbol)
 FS_DEV void encodeSymbol2(Coder& m, uint32_t c, const Ctx& mc, int symbol)
 {
     const uint32_t nsC = mc.ns, stats = mc.w1;
-    const uint8_t sufNsRaw = *HP(mc.suff);                       // in flight together with the state fetch below
+    // NumStats of the suffix context, in flight together with the state fetch below (the root has no suffix and,
+    // with all 256 symbols, never needs it: Model.cpp:509)
+    const uint8_t sufNsRaw = mc.suff ? *HP(mc.suff) : (uint8_t)0;
     LaneStates ls = lane_states(m, stats, nsC, 0);
     // makeEscFreq2
     uint32_t seeIdx = 0xFFFFFFFFu, see = 0;
