@@ -156,7 +156,7 @@ int fsgpu_rc_encode(fsgpu_ctx* ctx, size_t n, const uint32_t* model, const uint8
 {
     if (!ctx || (n && (!model || !pairs || !nPairs || !out || !outCap || !outLen))) return FSGPU_ERR_ARG;
     std::vector<uint32_t> kinds(n);
-    for (size_t i = 0; i < n; ++i) { if (model[i] > 5) return FSGPU_ERR_ARG; kinds[i] = fsdev::KIND_RC_BASE + model[i]; }
+    for (size_t i = 0; i < n; ++i) { if (model[i] > 6) return FSGPU_ERR_ARG; kinds[i] = fsdev::KIND_RC_BASE + model[i]; }
     return encodeStreams(ctx, n, kinds.data(), pairs, nPairs, out, outCap, outLen);
 }
 

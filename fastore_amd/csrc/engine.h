@@ -19,7 +19,7 @@ struct Device {
     char err[256];
     void* stream;
     void* ev[4];
-    uint8_t* arenas; uint32_t* queueHead; uint32_t nWaves;
+    uint8_t* arenas; uint64_t arenaPoolBytes; uint32_t* queueHead; uint32_t nWaves /* resident-wave cap */;
     uint8_t* dIn; size_t capIn;
     uint8_t* dScratch; size_t capScratch;
     void* dItems; size_t capItems;

@@ -29,14 +29,15 @@ using namespace fsdev;
 
 namespace {
 
-constexpr uint64_t kArenaStride = (32ull << 20) + (64ull << 10);   // 32 MiB table / 16 MiB heap + guard
+constexpr uint64_t kGuard = 64ull << 10;
+constexpr uint32_t kWavesPerSimd = 6;                            // __launch_bounds__(64, 6): <= 80 VGPRs
 
-__global__ __launch_bounds__(64) void fs_encode_streams(const StreamItem* __restrict__ items, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(const StreamItem* __restrict__ items, const uint32_t* __restrict__ order,
                                                         uint32_t nItems, const uint8_t* in, uint8_t* out, uint32_t* outSizes,
-                                                        uint32_t* restarts, uint8_t* arenas, uint32_t* queueHead)
+                                                        uint32_t* restarts, uint8_t* arenas, uint64_t arenaStride, uint32_t* queueHead)
 {
     __shared__ fsppmd::Shared sh;
-    uint8_t* arena = arenas + (uint64_t)blockIdx.x * kArenaStride;
+    uint8_t* arena = arenas + (uint64_t)blockIdx.x * arenaStride;
     for (;;) {
         uint32_t q = 0;
         if (threadIdx.x == 0) q = atomicAdd(queueHead, 1u);
@@ -146,17 +147,20 @@ int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size
     if ((e = hipStreamCreate((hipStream_t*)&dev->stream)) != hipSuccess) return fail("hipStreamCreate", e);
     size_t freeB = 0, totalB = 0;
     if ((e = hipMemGetInfo(&freeB, &totalB)) != hipSuccess) return fail("hipMemGetInfo", e);
-    // resident waves: 16 per CU when memory allows (one private arena each), never more than half of HBM
-    uint32_t waves = maxWaves ? maxWaves : (uint32_t)dev->cus * 16u;
-    const uint64_t budget = freeB / 2;
-    if ((uint64_t)waves * kArenaStride > budget) waves = (uint32_t)(budget / kArenaStride);
-    if (waves == 0) { snprintf(err, errLen, "not enough device memory for one coder arena"); delete dev; *out = nullptr; return -1; }
-    dev->nWaves = waves;
-    if ((e = hipMalloc((void**)&dev->arenas, (uint64_t)waves * kArenaStride)) != hipSuccess) return fail("hipMalloc(arenas)", e);
+    // One arena per resident wavefront (kWavesPerSimd x 4 SIMDs per CU), carved per launch out of one pool that takes
+    // at most 55 % of the free HBM; the stride of a launch is the largest table/heap any of its streams needs.
+    uint32_t waves = maxWaves ? maxWaves : (uint32_t)dev->cus * 4u * kWavesPerSimd;
+    const uint64_t minStride = fsppmd::ARENA_BYTES + kGuard;
+    uint64_t pool = (uint64_t)waves * minStride;
+    const uint64_t budget = (uint64_t)((double)freeB * 0.55);
+    if (pool > budget) pool = budget;
+    if (pool < (33ull << 20)) { snprintf(err, errLen, "not enough device memory for one coder arena"); delete dev; *out = nullptr; return -1; }
+    dev->nWaves = waves; dev->arenaPoolBytes = pool;
+    if ((e = hipMalloc((void**)&dev->arenas, pool)) != hipSuccess) return fail("hipMalloc(arenas)", e);
     if ((e = hipMalloc((void**)&dev->queueHead, 64)) != hipSuccess) return fail("hipMalloc(queue)", e);
     if ((e = hipEventCreate((hipEvent_t*)&dev->ev[0])) != hipSuccess) return fail("hipEventCreate", e);
     for (int i = 1; i < 4; ++i) (void)hipEventCreate((hipEvent_t*)&dev->ev[i]);
-    if (getenv("FS_TRACE")) fprintf(stderr, "[trace] device_create: %u waves, %.1f GB of arenas, %.1f ms\n", waves, waves * (double)kArenaStride / 1e9, wallMs() - tc0);
+    if (getenv("FS_TRACE")) fprintf(stderr, "[trace] device_create: up to %u waves, %.1f GB arena pool, %.1f ms\n", waves, pool / 1e9, wallMs() - tc0);
     return 0;
 }
 
@@ -215,11 +219,15 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     HIP_TRY(hipMemcpyAsync(dev->dItems, items.data(), sizeof(StreamItem) * nItems, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dev->dOrder, order.data(), 4ull * nItems, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(dev->queueHead, 0, 64, st));
-    const uint32_t grid = std::min(nItems, dev->nWaves);
+    uint64_t need = fsppmd::ARENA_BYTES;
+    for (const auto& it : items) if (it.kind != KIND_PPMD) need = std::max<uint64_t>(need, fsrc::model_table_bytes(it.kind - KIND_RC_BASE));
+    const uint64_t stride = ((need + kGuard) + 4095ull) & ~4095ull;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nItems, dev->nWaves), dev->arenaPoolBytes / stride);
+    if (grid == 0) { snprintf(dev->err, sizeof dev->err, "arena pool too small for a %llu-byte coder table", (unsigned long long)need); return -1; }
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[0], st));
     hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, (const StreamItem*)dev->dItems, (const uint32_t*)dev->dOrder,
                        nItems, (const uint8_t*)dev->dIn, (uint8_t*)dev->dScratch, (uint32_t*)dev->dSizes, (uint32_t*)dev->dRestarts,
-                       (uint8_t*)dev->arenas, (uint32_t*)dev->queueHead);
+                       (uint8_t*)dev->arenas, stride, (uint32_t*)dev->queueHead);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));
     if (getenv("FS_TRACE")) { HIP_TRY(hipStreamSynchronize(st)); }

@@ -173,7 +173,9 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
             // header-less archives never create the read-id coders: their streams stay empty (FastqCompressor.cpp:923-930)
             const bool absent = !pl.has_headers && (s == S_IdToken || s == S_IdValue);
             if (absent) { it.kind = KIND_PPMD; it.in_len = 0; it.out_cap = 16; pl.work_size[s] = 0; }
-            else if (rc) { it.kind = KIND_RC_BASE + streamModel(s, qm); it.in_len = (uint32_t)(bytes / 2); it.out_cap = 2 * it.in_len + 32; pl.work_size[s] = ~0ull; }
+            else if (rc) { uint32_t model = streamModel(s, qm);
+                           if (model == 5 && archives[binArch[b]].head.fields.size() <= 16) model = 6;     // read-id ctx0 = fieldId*4+k < 64: dense 8 MiB table
+                           it.kind = KIND_RC_BASE + model; it.in_len = (uint32_t)(bytes / 2); it.out_cap = 2 * it.in_len + 32; pl.work_size[s] = ~0ull; }
             else { it.kind = KIND_PPMD; it.in_len = (uint32_t)bytes; it.out_cap = (uint32_t)(bytes + bytes / 8 + 64); pl.work_size[s] = bytes; }
             items.push_back(it);
             inBytes += (bytes + 15) & ~15ull;

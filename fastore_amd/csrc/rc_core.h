@@ -61,13 +61,16 @@ FS_DEV uint64_t table_bytes(int bits, int order, int adv) { return (1ULL << (bit
 
 // Encode n (symbol, ctx0) byte pairs; returns the stream size including the 8 flush bytes
 // (counted past `cap` like the reference's growing writer would; bytes beyond cap are dropped).
-template <int BITS, int ORDER, bool ADV>
+// CTXBITS: width of the ctx0 slot in the model index.  The reference uses BITS (ContextEncoder.h:184); a narrower slot
+// addresses the same models in a denser table when every ctx0 of the stream is known to fit (read-id streams: ctx0 =
+// fieldId*4+k < 64), which is only a change of memory layout.
+template <int BITS, int ORDER, bool ADV, int CTXBITS = BITS>
 FS_DEV uint32_t encode_stream(uint8_t* table /*16-byte aligned, table_bytes()*/, const uint8_t* pairs, uint32_t n,
                               uint8_t* out, uint32_t cap)
 {
     constexpr uint32_t A = 1u << BITS;
     constexpr uint64_t symMask = (1ULL << (ORDER * BITS)) - 1;
-    constexpr uint64_t nModels = 1ULL << (BITS * (ORDER + (ADV ? 1 : 0)));
+    constexpr uint64_t nModels = 1ULL << (BITS * ORDER + (ADV ? CTXBITS : 0));
     constexpr uint32_t limit = (1u << 16) - A * 8u;
     // Clear(): every statistic = 1
     {
@@ -87,7 +90,7 @@ FS_DEV uint32_t encode_stream(uint8_t* table /*16-byte aligned, table_bytes()*/,
     for (uint32_t k = 0; k < n; ++k) {
         const uint32_t pr = fs_ld16(pairs + 2u * k);
         const uint32_t sym = pr & 0xFFu, ctx = pr >> 8;
-        const uint32_t h = ADV ? (uint32_t)(((hash & symMask) << BITS) | ctx) : (uint32_t)(hash & symMask);
+        const uint32_t h = ADV ? (uint32_t)(((hash & symMask) << CTXBITS) | ctx) : (uint32_t)(hash & symMask);
         uint16_t* st = (uint16_t*)table + (uint64_t)h * A;
         uint32_t acc, lo, f;
         if constexpr (BITS == 8) {
@@ -125,7 +128,7 @@ FS_DEV uint32_t encode_stream(uint8_t* table /*16-byte aligned, table_bytes()*/,
 }
 
 // model ids shared by host and device
-enum Model : uint32_t { M_S2O4 = 0, M_S8O4 = 1, M_A8O4 = 2, M_A2O10 = 3, M_A8O6 = 4, M_A256O1 = 5, M_COUNT = 6 };
+enum Model : uint32_t { M_S2O4 = 0, M_S8O4 = 1, M_A8O4 = 2, M_A2O10 = 3, M_A8O6 = 4, M_A256O1 = 5, M_A256O1_C6 = 6 /* ctx0 < 64: 8 MiB table */, M_COUNT = 7 };
 
 FS_DEV uint32_t encode_model(uint32_t model, uint8_t* table, const uint8_t* pairs, uint32_t n, uint8_t* out, uint32_t cap)
 {
@@ -135,6 +138,7 @@ FS_DEV uint32_t encode_model(uint32_t model, uint8_t* table, const uint8_t* pair
     case M_A8O4: return encode_stream<3, 4, true>(table, pairs, n, out, cap);
     case M_A2O10: return encode_stream<1, 10, true>(table, pairs, n, out, cap);
     case M_A8O6: return encode_stream<3, 6, true>(table, pairs, n, out, cap);
+    case M_A256O1_C6: return encode_stream<8, 1, true, 6>(table, pairs, n, out, cap);
     default: return encode_stream<8, 1, true>(table, pairs, n, out, cap);
     }
 }
@@ -146,6 +150,7 @@ FS_DEV uint64_t model_table_bytes(uint32_t model)
     case M_A8O4: return table_bytes(3, 4, 1);
     case M_A2O10: return table_bytes(1, 10, 1);
     case M_A8O6: return table_bytes(3, 6, 1);
+    case M_A256O1_C6: return (1ULL << 14) * 512ULL;
     default: return table_bytes(8, 1, 1);
     }
 }

@@ -83,6 +83,11 @@ def test_rc_device_matches_oracle_all_models_with_rescale(packer, oracle):
     got = packer.rc_encode(models, [p for _, p in ins])
     for (name, pairs), g in zip(ins, got):
         assert g == oracle_rc(oracle, name, pairs), name
+    # model 6 = <256,1> with a 6-bit ctx0 slot (dense table for read-id streams): same bytes as model 5
+    dense = [(n, p) for n, p in ins if n == "a256o1"]
+    got6 = packer.rc_encode([6] * len(dense), [p for _, p in dense])
+    for (name, pairs), g in zip(dense, got6):
+        assert g == oracle_rc(oracle, name, pairs)
 
 
 @pytest.mark.parametrize("name,paired,flags", manifest())
