@@ -48,13 +48,14 @@ __global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(const Str
         const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.kind);
         const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.in_len);
         const uint32_t cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.out_cap);
-        const uint8_t* src = in + item.in_off;
-        uint8_t* dst = out + item.out_off;
+        fs_cgptr src = (fs_cgptr)(in + item.in_off);
+        fs_gptr dst = (fs_gptr)(out + item.out_off);
+        fs_gptr ar = (fs_gptr)arena;
         uint32_t size = 0, rs = 0;
         if (kind == KIND_PPMD) {
-            if (n > 0) size = fsppmd::encode_member(arena, &sh, src, n, dst, cap, &rs);
+            if (n > 0) size = fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs);
         } else {
-            size = fsrc::encode_model(kind - KIND_RC_BASE, arena, src, n, dst, cap);
+            size = fsrc::encode_model(kind - KIND_RC_BASE, ar, src, n, dst, cap);
         }
         if (threadIdx.x == 0) { outSizes[it] = size; restarts[it] = rs; }
         __syncthreads();

@@ -63,8 +63,8 @@ struct Shared {
 };
 
 struct Coder {
-    uint8_t* hb;                 // heap base - 1  (so that index ix lives at hb + ix)
-    Shared* sh;
+    fs_gptr hb;                  // heap base - 1  (so that index ix lives at hb + ix)
+    FS_LDS Shared* sh;
     uint32_t pText, UnitsStart, LoUnit, HiUnit, GlueCount, GlueCount1;
     uint32_t MaxContext, FoundState;
     uint32_t fsSym, fsFreq, fsSucc;   // register copy of *FoundState (memory is always written through)
@@ -72,7 +72,7 @@ struct Coder {
     int32_t BSumm, OrderFall, RunLength, InitRL;
     uint32_t low, range, rLow, rHigh, rScale;
     uint32_t dummySee;
-    uint8_t* out; uint32_t outCap, outPos;
+    fs_gptr out; uint32_t outCap, outPos;
     uint32_t restarts;
 };
 
@@ -118,7 +118,7 @@ FS_DEV void state_cpy(Coder& m, uint32_t d, uint32_t s) { state_store(m, d, S_SY
 struct Ctx { uint32_t ns, flags, sf, w1 /* iStats, or oneState.iSuccessor */, suff, oneSym, oneFreq; };
 FS_DEV Ctx ctx_load(Coder& m, uint32_t c)
 {
-    const uint32_t* q = (const uint32_t*)HP(c);
+    fs_cgptr32 q = (fs_cgptr32)HP(c);
     uint32_t a = q[0], b = q[1], d = q[2];
     a = FS_UNI(a); b = FS_UNI(b); d = FS_UNI(d);
     Ctx r; r.ns = a & 0xFFu; r.flags = (a >> 8) & 0xFFu; r.sf = a >> 16; r.w1 = b; r.suff = d; r.oneSym = (a >> 16) & 0xFFu; r.oneFreq = a >> 24;
@@ -128,7 +128,7 @@ FS_DEV Ctx ctx_load(Coder& m, uint32_t c)
 struct St { uint32_t sym, freq, succ; };
 FS_DEV St st_load(Coder& m, uint32_t s)
 {
-    const uint16_t* q = (const uint16_t*)HP(s);
+    fs_cgptr16 q = (fs_cgptr16)HP(s);
     uint32_t a = q[0], b = q[1], c = q[2];
     a = FS_UNI(a); b = FS_UNI(b); c = FS_UNI(c);
     St r; r.sym = a & 0xFFu; r.freq = a >> 8; r.succ = b | (c << 16);
@@ -157,7 +157,7 @@ FS_DEV void SplitBlock(Coder& m, uint32_t pv, uint32_t oldI, uint32_t newI)
 FS_DEV void InitSubAllocator(Coder& m)
 {
     // memset(BList, 0)  -- heads are 4-byte words behind the heap
-    for (uint32_t i = (uint32_t)FS_LANE(); i < 3u * (N_INDEXES + 2); i += FS_WAVE) *(uint32_t*)(HP(BL(0)) + 4u * i) = 0u;
+    for (uint32_t i = (uint32_t)FS_LANE(); i < 3u * (N_INDEXES + 2); i += FS_WAVE) *(fs_gptr32)(HP(BL(0)) + 4u * i) = 0u;
     FS_WAVE_SYNC();
     m.pText = 1u; m.HiUnit = 1u + SA_SIZE;
     const uint32_t Diff = 12u * (SA_SIZE / 8 / UNIT_SIZE * 7);
@@ -259,7 +259,7 @@ FS_DEV void rc_encode(Coder& m) { m.low += m.rLow * (m.range /= m.rScale); m.ran
 // ---------------- model ----------------
 FS_DEV void clear_mask(Coder& m)
 {
-    for (uint32_t i = (uint32_t)FS_LANE(); i < 64u; i += FS_WAVE) ((uint32_t*)m.sh->CharMask)[i] = 0u;
+    for (uint32_t i = (uint32_t)FS_LANE(); i < 64u; i += FS_WAVE) ((FS_LDS uint32_t*)m.sh->CharMask)[i] = 0u;
     FS_WAVE_SYNC();
     m.EscCount = 1;
 }
@@ -276,7 +276,7 @@ FS_DEV void StartModelRare(Coder& m)
     C_STATS_SET(m.MaxContext, st);
     m.PrevSuccess = 0; C_SUFF_SET(m.MaxContext, 0); C_FLAGS_SET(m.MaxContext, 0);
     for (uint32_t i = (uint32_t)FS_LANE(); i < 256u; i += FS_WAVE) {       // {Symbol=i, Freq=1, iSuccessor=0}
-        uint16_t* q = (uint16_t*)(HP(st) + 6u * i);
+        fs_gptr16 q = (fs_gptr16)(HP(st) + 6u * i);
         q[0] = (uint16_t)(i | 0x100u); q[1] = 0; q[2] = 0;
     }
     // binary SEE contexts: BinSumm[i][k] = BIN_SCALE - 128*clamp(sum coef)/i2f[i],  i2f[i] = (#k: QTable[k] <= i) + 1
@@ -535,7 +535,7 @@ FS_DEV LaneStates lane_states(Coder& m, uint32_t stats, uint32_t ns, uint32_t ba
 {
     LaneStates r; const uint32_t i = base + (uint32_t)FS_LANE();
     r.valid = i <= ns; r.sf = 0; r.succ = 0;
-    if (r.valid) { const uint16_t* q = (const uint16_t*)HP(stats + 6u * i); const uint32_t a = q[0], b = q[1], c = q[2]; r.sf = a; r.succ = b | (c << 16); }
+    if (r.valid) { fs_cgptr16 q = (fs_cgptr16)HP(stats + 6u * i); const uint32_t a = q[0], b = q[1], c = q[2]; r.sf = a; r.succ = b | (c << 16); }
     return r;
 }
 
@@ -656,7 +656,7 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, const Ctx& mc, int symbol)
 
 // Encode one member.  `arena` = ARENA_BYTES of 16-byte aligned scratch (content irrelevant),
 // returns the member size (clipped at outCap like the reference's ByteStream::Put).
-FS_DEV uint32_t encode_member(uint8_t* arena, Shared* sh, const uint8_t* in, uint32_t n, uint8_t* out, uint32_t outCap,
+FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uint32_t n, fs_gptr out, uint32_t outCap,
                               uint32_t* restartsOut)
 {
     Coder m;
@@ -664,7 +664,7 @@ FS_DEV uint32_t encode_member(uint8_t* arena, Shared* sh, const uint8_t* in, uin
     m.NumMasked = 0; m.FoundState = 0; m.BSumm = 0; m.rLow = m.rHigh = m.rScale = 0; m.fsSym = m.fsFreq = m.fsSucc = 0;
     for (uint32_t i = (uint32_t)FS_LANE(); i < 260u; i += FS_WAVE) sh->QT[i] = (uint8_t)QTable(i);
     // zero the 64-byte guard behind the heap: GlueFreeBlocks may read one stamp past the end
-    for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) *(uint32_t*)(arena + SA_SIZE + 4u * i) = 0u;
+    for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) *(fs_gptr32)(arena + SA_SIZE + 4u * i) = 0u;
     FS_WAVE_SYNC();
     put_byte(m, 0xCA); put_byte(m, MAX_ORDER);
     m.low = 0; m.range = 0xFFFFFFFFu;
@@ -672,12 +672,12 @@ FS_DEV uint32_t encode_member(uint8_t* arena, Shared* sh, const uint8_t* in, uin
     // input window: the next aligned dword is requested one step ahead of its first use
     const bool wide = (((uintptr_t)in) & 3u) == 0;
     uint32_t pos = 0, cur = 0, nxt = 0;
-    if (wide && n >= 4) nxt = *(const uint32_t*)in;
+    if (wide && n >= 4) nxt = *(fs_cgptr32)in;
     for (uint32_t MinContext = m.MaxContext;;) {
         int c = -1;
         if (pos < n) {
             if (wide && (pos | 3u) < n) {
-                if ((pos & 3u) == 0) { cur = FS_UNI(nxt); if (pos + 7u < n) nxt = *(const uint32_t*)(in + pos + 4u); }
+                if ((pos & 3u) == 0) { cur = FS_UNI(nxt); if (pos + 7u < n) nxt = *(fs_cgptr32)(in + pos + 4u); }
                 c = (int)((cur >> (8u * (pos & 3u))) & 0xFFu);
             } else c = (int)fs_ld8(in + pos);
             pos++;

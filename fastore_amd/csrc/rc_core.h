@@ -20,7 +20,7 @@ namespace fsrc {
 
 struct Enc {
     uint64_t low; uint32_t range;
-    uint8_t* out; uint32_t cap, pos;
+    fs_gptr out; uint32_t cap, pos;
 };
 
 FS_DEV void put(Enc& e, uint32_t b) { if (e.pos < e.cap) e.out[e.pos] = (uint8_t)b; e.pos++; }
@@ -65,8 +65,8 @@ FS_DEV uint64_t table_bytes(int bits, int order, int adv) { return (1ULL << (bit
 // addresses the same models in a denser table when every ctx0 of the stream is known to fit (read-id streams: ctx0 =
 // fieldId*4+k < 64), which is only a change of memory layout.
 template <int BITS, int ORDER, bool ADV, int CTXBITS = BITS>
-FS_DEV uint32_t encode_stream(uint8_t* table /*16-byte aligned, table_bytes()*/, const uint8_t* pairs, uint32_t n,
-                              uint8_t* out, uint32_t cap)
+FS_DEV uint32_t encode_stream(fs_gptr table /*16-byte aligned, table_bytes()*/, fs_cgptr pairs, uint32_t n,
+                              fs_gptr out, uint32_t cap)
 {
     constexpr uint32_t A = 1u << BITS;
     constexpr uint64_t symMask = (1ULL << (ORDER * BITS)) - 1;
@@ -75,10 +75,10 @@ FS_DEV uint32_t encode_stream(uint8_t* table /*16-byte aligned, table_bytes()*/,
     // Clear(): every statistic = 1
     {
         const uint64_t words = nModels * A / 2;                     // u32 words of two u16 ones
-        uint32_t* t32 = (uint32_t*)table;
+        fs_gptr32 t32 = (fs_gptr32)table;
         if (words >= 4u * FS_WAVE) {
             struct alignas(16) V4 { uint32_t a, b, c, d; };
-            V4* t128 = (V4*)table; const V4 ones = {0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u};
+            FS_GLOBAL V4* t128 = (FS_GLOBAL V4*)table; const V4 ones = {0x00010001u, 0x00010001u, 0x00010001u, 0x00010001u};
             for (uint64_t i = (uint64_t)FS_LANE(); i < words / 4; i += FS_WAVE) t128[i] = ones;
         } else {
             for (uint64_t i = (uint64_t)FS_LANE(); i < words; i += FS_WAVE) t32[i] = 0x00010001u;
@@ -91,7 +91,7 @@ FS_DEV uint32_t encode_stream(uint8_t* table /*16-byte aligned, table_bytes()*/,
         const uint32_t pr = fs_ld16(pairs + 2u * k);
         const uint32_t sym = pr & 0xFFu, ctx = pr >> 8;
         const uint32_t h = ADV ? (uint32_t)(((hash & symMask) << CTXBITS) | ctx) : (uint32_t)(hash & symMask);
-        uint16_t* st = (uint16_t*)table + (uint64_t)h * A;
+        fs_gptr16 st = (fs_gptr16)table + (uint64_t)h * A;
         uint32_t acc, lo, f;
         if constexpr (BITS == 8) {
             constexpr int PER = 256 / FS_WAVE;                      // symbols owned by one lane
@@ -130,7 +130,7 @@ FS_DEV uint32_t encode_stream(uint8_t* table /*16-byte aligned, table_bytes()*/,
 // model ids shared by host and device
 enum Model : uint32_t { M_S2O4 = 0, M_S8O4 = 1, M_A8O4 = 2, M_A2O10 = 3, M_A8O6 = 4, M_A256O1 = 5, M_A256O1_C6 = 6 /* ctx0 < 64: 8 MiB table */, M_COUNT = 7 };
 
-FS_DEV uint32_t encode_model(uint32_t model, uint8_t* table, const uint8_t* pairs, uint32_t n, uint8_t* out, uint32_t cap)
+FS_DEV uint32_t encode_model(uint32_t model, fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap)
 {
     switch (model) {
     case M_S2O4: return encode_stream<1, 4, false>(table, pairs, n, out, cap);

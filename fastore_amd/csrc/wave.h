@@ -15,6 +15,9 @@
 #include <string.h>
 
 #if defined(__HIP_DEVICE_COMPILE__)
+  // explicit address spaces: without them the heap pointer kept in a struct degrades to FLAT accesses
+  #define FS_GLOBAL __attribute__((address_space(1)))
+  #define FS_LDS __attribute__((address_space(3)))
   #define FS_DEV __device__ __forceinline__
   #define FS_DEV_NOINLINE __device__ __noinline__
   #define FS_WAVE 64
@@ -24,6 +27,8 @@
   // order this wave's cooperative memory phase against the uniform code that follows it
   #define FS_WAVE_SYNC() __syncthreads()
 #else
+  #define FS_GLOBAL
+  #define FS_LDS
   #define FS_DEV static inline
   #define FS_DEV_NOINLINE static
   #define FS_WAVE 1
@@ -32,16 +37,23 @@
   #define FS_WAVE_SYNC() ((void)0)
 #endif
 
+typedef FS_GLOBAL uint8_t* fs_gptr;                 // device: global address space; host: plain pointer
+typedef const FS_GLOBAL uint8_t* fs_cgptr;
+typedef const FS_GLOBAL uint16_t* fs_cgptr16;
+typedef FS_GLOBAL uint16_t* fs_gptr16;
+typedef const FS_GLOBAL uint32_t* fs_cgptr32;
+typedef FS_GLOBAL uint32_t* fs_gptr32;
+
 // ---- uniform little-endian accessors on a byte heap (2-byte aligned addresses) ----
-FS_DEV uint32_t fs_ld8(const uint8_t* p) { return FS_UNI(*p); }
-FS_DEV uint32_t fs_ld16(const uint8_t* p) { return FS_UNI(*(const uint16_t*)p); }
-FS_DEV uint32_t fs_ld32h(const uint8_t* p)   // 32-bit value at a 2-byte aligned address
-{ return FS_UNI((uint32_t)((const uint16_t*)p)[0] | ((uint32_t)((const uint16_t*)p)[1] << 16)); }
-FS_DEV uint32_t fs_ld32(const uint8_t* p) { return FS_UNI(*(const uint32_t*)p); }
-FS_DEV void fs_st8(uint8_t* p, uint32_t v) { *p = (uint8_t)v; }
-FS_DEV void fs_st16(uint8_t* p, uint32_t v) { *(uint16_t*)p = (uint16_t)v; }
-FS_DEV void fs_st32h(uint8_t* p, uint32_t v) { ((uint16_t*)p)[0] = (uint16_t)v; ((uint16_t*)p)[1] = (uint16_t)(v >> 16); }
-FS_DEV void fs_st32(uint8_t* p, uint32_t v) { *(uint32_t*)p = v; }
+FS_DEV uint32_t fs_ld8(fs_cgptr p) { return FS_UNI(*p); }
+FS_DEV uint32_t fs_ld16(fs_cgptr p) { return FS_UNI(*(fs_cgptr16)p); }
+FS_DEV uint32_t fs_ld32h(fs_cgptr p)   // 32-bit value at a 2-byte aligned address
+{ return FS_UNI((uint32_t)((fs_cgptr16)p)[0] | ((uint32_t)((fs_cgptr16)p)[1] << 16)); }
+FS_DEV uint32_t fs_ld32(fs_cgptr p) { return FS_UNI(*(fs_cgptr32)p); }
+FS_DEV void fs_st8(fs_gptr p, uint32_t v) { *p = (uint8_t)v; }
+FS_DEV void fs_st16(fs_gptr p, uint32_t v) { *(fs_gptr16)p = (uint16_t)v; }
+FS_DEV void fs_st32h(fs_gptr p, uint32_t v) { ((fs_gptr16)p)[0] = (uint16_t)v; ((fs_gptr16)p)[1] = (uint16_t)(v >> 16); }
+FS_DEV void fs_st32(fs_gptr p, uint32_t v) { *(fs_gptr32)p = v; }
 
 // ---- cross-lane helpers (host build: one lane) ----
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -70,8 +82,8 @@ FS_DEV uint32_t fs_wave_sum8(uint32_t v, bool pred)
 }
 
 // cooperative copy / fill of 4-byte aligned regions (n bytes, n % 4 == 0), non-overlapping
-FS_DEV void fs_wave_copy4(uint8_t* d, const uint8_t* s, uint32_t n)
+FS_DEV void fs_wave_copy4(fs_gptr d, fs_cgptr s, uint32_t n)
 {
-    for (uint32_t i = 4u * (uint32_t)FS_LANE(); i < n; i += 4u * FS_WAVE) *(uint32_t*)(d + i) = *(const uint32_t*)(s + i);
+    for (uint32_t i = 4u * (uint32_t)FS_LANE(); i < n; i += 4u * FS_WAVE) *(fs_gptr32)(d + i) = *(fs_cgptr32)(s + i);
     FS_WAVE_SYNC();
 }
