@@ -34,7 +34,7 @@ constexpr uint32_t kWavesPerSimd = 6;                            // __launch_bou
 
 __global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(const StreamItem* __restrict__ items, const uint32_t* __restrict__ order,
                                                         uint32_t nItems, const uint8_t* in, uint8_t* out, uint32_t* outSizes,
-                                                        uint32_t* restarts, uint8_t* arenas, uint64_t arenaStride, uint32_t* queueHead)
+                                                        uint32_t* restarts, uint8_t* arenas, uint64_t arenaStride, uint32_t* queueHead, uint32_t longLen)
 {
     __shared__ fsppmd::Shared sh;
     uint8_t* arena = arenas + (uint64_t)blockIdx.x * arenaStride;
@@ -48,6 +48,11 @@ __global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(const Str
         const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.kind);
         const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.in_len);
         const uint32_t cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.out_cap);
+        // The launch ends when its longest stream ends, so the long PPMd streams get issue priority over the thousands
+        // of short ones that share their SIMD (priority only reorders issue among resident waves).
+        if (kind == KIND_PPMD && n >= longLen) __builtin_amdgcn_s_setprio(3);
+        else if (kind == KIND_PPMD && 2u * n >= longLen) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
         fs_cgptr src = (fs_cgptr)(in + item.in_off);
         fs_gptr dst = (fs_gptr)(out + item.out_off);
         fs_gptr ar = (fs_gptr)arena;
@@ -224,11 +229,14 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     for (const auto& it : items) if (it.kind != KIND_PPMD) need = std::max<uint64_t>(need, fsrc::model_table_bytes(it.kind - KIND_RC_BASE));
     const uint64_t stride = ((need + kGuard) + 4095ull) & ~4095ull;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nItems, dev->nWaves), dev->arenaPoolBytes / stride);
+    uint32_t maxLen = 0;
+    for (const auto& it : items) if (it.kind == KIND_PPMD) maxLen = std::max(maxLen, it.in_len);
+    const uint32_t longLen = std::max(1u, maxLen / 2);                     // "long" = at least half of the longest PPMd stream
     if (grid == 0) { snprintf(dev->err, sizeof dev->err, "arena pool too small for a %llu-byte coder table", (unsigned long long)need); return -1; }
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[0], st));
     hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, (const StreamItem*)dev->dItems, (const uint32_t*)dev->dOrder,
                        nItems, (const uint8_t*)dev->dIn, (uint8_t*)dev->dScratch, (uint32_t*)dev->dSizes, (uint32_t*)dev->dRestarts,
-                       (uint8_t*)dev->arenas, stride, (uint32_t*)dev->queueHead);
+                       (uint8_t*)dev->arenas, stride, (uint32_t*)dev->queueHead, longLen);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));
     if (getenv("FS_TRACE")) { HIP_TRY(hipStreamSynchronize(st)); }
