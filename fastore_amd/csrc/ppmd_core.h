@@ -297,62 +297,82 @@ FS_DEV void StartModelRare(Coder& m)
 
 FS_DEV void RestoreModelRare(Coder& m) { m.pText = 1u; StartModelRare(m); m.EscCount = 0; m.restarts++; }
 
-// state of `sym` in a multi-symbol context (it must exist): 64 states are probed per step, one per lane
-FS_DEV uint32_t find_sym(Coder& m, uint32_t pc, uint32_t sym)
+// per-lane view of 64 consecutive states of a context: one fetch for the whole list
+struct LaneStates { uint32_t sf, succ; bool valid; };
+FS_DEV LaneStates lane_states(Coder& m, uint32_t stats, uint32_t ns, uint32_t base)
 {
-    const uint32_t stats = C_STATS(pc), ns = C_NS(pc);
+    LaneStates r; const uint32_t i = base + (uint32_t)FS_LANE();
+    r.valid = i <= ns; r.sf = 0; r.succ = 0;
+    if (r.valid) { fs_cgptr16 q = (fs_cgptr16)HP(stats + 6u * i); const uint32_t a = q[0], b = q[1], c = q[2]; r.sf = a; r.succ = b | (c << 16); }
+    return r;
+}
+
+// the state of `sym` in a multi-symbol context (it must exist), with its record and its predecessor's
+struct Hit { uint32_t p, freq, succ, prevSf, prevSucc; };
+FS_DEV Hit find_in(Coder& m, const Ctx& pc, uint32_t sym)
+{
+    Hit h; h.p = pc.w1; h.freq = 0; h.succ = 0; h.prevSf = 0; h.prevSucc = 0;
     for (uint32_t base = 0;; base += FS_WAVE) {
-        const uint32_t i = base + (uint32_t)FS_LANE();
-        const bool valid = i <= ns;
-        const uint32_t s = valid ? (uint32_t)*HP(stats + 6u * i) : 0x100u;
-        const uint64_t hit = fs_ballot(valid && s == sym);
-        if (hit) return stats + 6u * (base + fs_ctz64(hit));
-        if (base + FS_WAVE > ns) return stats;          // unreachable for well-formed models; never spin
+        const LaneStates ls = lane_states(m, pc.w1, pc.ns, base);
+        const uint64_t hit = fs_ballot(ls.valid && (ls.sf & 0xFFu) == sym);
+        if (hit) {
+            const uint32_t k = fs_ctz64(hit);
+            h.p = pc.w1 + 6u * (base + k);
+            h.freq = FS_UNI(fs_readlane(ls.sf >> 8, k)); h.succ = FS_UNI(fs_readlane(ls.succ, k));
+            if (k > 0) { h.prevSf = FS_UNI(fs_readlane(ls.sf, k - 1)); h.prevSucc = FS_UNI(fs_readlane(ls.succ, k - 1)); }
+            else if (base > 0) { const St t = st_load(m, h.p - 6); h.prevSf = t.sym | (t.freq << 8); h.prevSucc = t.succ; }
+            return h;
+        }
+        if (base + FS_WAVE > pc.ns) return h;            // unreachable for well-formed models; never spin
     }
 }
 
-FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pc)
+// CreateSuccessors (Model.cpp:282-337).  p/pSucc: state to start from in the suffix of pc (0 = none) and its successor.
+FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc, uint32_t pc, uint32_t fsSym, uint32_t fsSucc)
 {
-    const uint32_t iUpBranch = S_SUCC(m.FoundState);
+    const uint32_t iUpBranch = fsSucc;
     uint32_t ps[MAX_ORDER + 1]; uint32_t pps = 0;
     uint32_t cf, s0, tmp;
-    uint32_t sym = S_SYM(m.FoundState);
+    uint32_t sym = fsSym;
+    Ctx P = ctx_load(m, pc);
     bool toLoop = true;
     if (!Skip) {
         ps[pps++] = m.FoundState;
-        if (!C_SUFF(pc)) toLoop = false;
+        if (!P.suff) toLoop = false;
     }
     if (toLoop) {
         bool first = (p != 0);
-        if (first) pc = C_SUFF(pc);
+        if (first) { pc = P.suff; P = ctx_load(m, pc); }
         do {
             if (!first) {
-                pc = C_SUFF(pc);
-                if (C_NS(pc)) {
-                    p = find_sym(m, pc, sym);
-                    tmp = (S_FREQ(p) < MAX_FREQ);
-                    S_FREQ_SET(p, S_FREQ(p) + tmp); C_SF_SET(pc, C_SF(pc) + tmp);
+                pc = P.suff; P = ctx_load(m, pc);
+                if (P.ns) {
+                    const Hit h = find_in(m, P, sym);
+                    p = h.p; pSucc = h.succ;
+                    tmp = (h.freq < MAX_FREQ);
+                    S_FREQ_SET(p, h.freq + tmp); P.sf += tmp; C_SF_SET(pc, P.sf);
                 } else {
-                    p = C_ONE(pc);
-                    S_FREQ_SET(p, S_FREQ(p) + ((!C_NS(C_SUFF(pc))) & (S_FREQ(p) < 11)));
+                    p = C_ONE(pc); pSucc = P.w1;
+                    const uint32_t sufNs = fs_ld8(HP(P.suff));
+                    S_FREQ_SET(p, P.oneFreq + ((!sufNs) & (P.oneFreq < 11)));
                 }
             }
             first = false;
-            if (S_SUCC(p) != iUpBranch) { pc = S_SUCC(p); break; }
+            if (pSucc != iUpBranch) { pc = pSucc; P = ctx_load(m, pc); break; }
             ps[pps++] = p;
-        } while (C_SUFF(pc));
+        } while (P.suff);
     }
     if (pps == 0) return pc;
     uint32_t ctFlags = 0x10u * (sym >= 0x40);
     sym = fs_ld8(HP(iUpBranch));
     ctFlags |= 0x08u * (sym >= 0x40);
     uint32_t ctFreq;
-    if (C_NS(pc)) {
-        p = find_sym(m, pc, sym);
-        s0 = C_SF(pc) - C_NS(pc) - (cf = S_FREQ(p) - 1u);
+    if (P.ns) {
+        const Hit h = find_in(m, P, sym);
+        s0 = P.sf - P.ns - (cf = h.freq - 1u);
         cf = 1 + ((2 * cf <= s0) ? (uint32_t)(12 * cf > s0) : ((cf + 2 * s0) / s0));
         ctFreq = (cf < 7) ? cf : 7;
-    } else ctFreq = S_FREQ(C_ONE(pc));
+    } else ctFreq = P.oneFreq;
     const uint32_t w0 = (ctFlags << 8) | (sym << 16) | (ctFreq << 24);   // NumStats=0, Flags, oneState{Symbol,Freq}
     do {
         const uint32_t pc1 = AllocContext(m);
@@ -363,34 +383,38 @@ FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pc)
     return pc;
 }
 
-FS_DEV uint32_t ReduceOrder(Coder& m, uint32_t p, uint32_t pc)
+// ReduceOrder (Model.cpp:209-243)
+FS_DEV uint32_t ReduceOrder(Coder& m, uint32_t p, uint32_t pSucc, uint32_t pc)
 {
-    uint32_t p1, tmp; const uint32_t pc1 = pc;
+    uint32_t tmp; const uint32_t pc1 = pc;
     const uint32_t iUpBranch = m.pText; S_SUCC_SET(m.FoundState, iUpBranch);
-    const uint32_t sym = S_SYM(m.FoundState); m.OrderFall++;
+    const uint32_t sym = m.fsSym; m.OrderFall++;
+    Ctx P = ctx_load(m, pc);
     bool first = (p != 0);
-    if (first) pc = C_SUFF(pc);
+    if (first) { pc = P.suff; P = ctx_load(m, pc); }
     for (;;) {
         if (!first) {
-            if (!C_SUFF(pc)) return pc;
-            pc = C_SUFF(pc);
-            if (C_NS(pc)) {
-                p = find_sym(m, pc, sym);
-                tmp = 2u * (S_FREQ(p) < MAX_FREQ - 3);
-                S_FREQ_SET(p, S_FREQ(p) + tmp); C_SF_SET(pc, C_SF(pc) + tmp);
-            } else { p = C_ONE(pc); S_FREQ_SET(p, S_FREQ(p) + (S_FREQ(p) < 11)); }
+            if (!P.suff) return pc;
+            pc = P.suff; P = ctx_load(m, pc);
+            if (P.ns) {
+                const Hit h = find_in(m, P, sym);
+                p = h.p; pSucc = h.succ;
+                tmp = 2u * (h.freq < MAX_FREQ - 3);
+                S_FREQ_SET(p, h.freq + tmp); P.sf += tmp; C_SF_SET(pc, P.sf);
+            } else { p = C_ONE(pc); pSucc = P.w1; S_FREQ_SET(p, P.oneFreq + (P.oneFreq < 11)); }
         }
         first = false;
-        if (S_SUCC(p)) break;
+        if (pSucc) break;
         S_SUCC_SET(p, iUpBranch); m.OrderFall++;
     }
-    if (S_SUCC(p) <= iUpBranch) {
-        p1 = m.FoundState; m.FoundState = p;
-        S_SUCC_SET(p, CreateSuccessors(m, false, 0, pc));
+    if (pSucc <= iUpBranch) {
+        const uint32_t p1 = m.FoundState; m.FoundState = p;
+        pSucc = CreateSuccessors(m, false, 0, 0, pc, sym, pSucc);
+        S_SUCC_SET(p, pSucc);
         m.FoundState = p1;
     }
-    if (m.OrderFall == 1 && pc1 == m.MaxContext) { S_SUCC_SET(m.FoundState, S_SUCC(p)); m.pText--; }
-    return S_SUCC(p);
+    if (m.OrderFall == 1 && pc1 == m.MaxContext) { S_SUCC_SET(m.FoundState, pSucc); m.pText--; }
+    return pSucc;
 }
 
 FS_DEV_NOINLINE void rescale(Coder& m, uint32_t c)
@@ -446,34 +470,38 @@ FS_DEV void UpdateModel(Coder& m, uint32_t MinContext)
 {
     const uint32_t FSymbol = m.fsSym, FFreq = m.fsFreq;
     uint32_t iSuccessor, iFSuccessor = m.fsSucc;
-    uint32_t ns1, ns, cf, sf, s0, pc, p = 0;
+    uint32_t ns1, ns, cf, sf, s0, pc, p = 0, pSucc = 0;
     bool restart = false;
-    if (C_SUFF(MinContext)) {
-        pc = C_SUFF(MinContext);
-        if (C_NS(pc)) {
-            p = C_STATS(pc);
-            if (S_SYM(p) != FSymbol) {
-                do { p += 6; } while (S_SYM(p) != FSymbol);
-                if (S_FREQ(p) >= S_FREQ(p - 6)) { state_swap(m, p, p - 6); p -= 6; }
+    const Ctx mcMin = ctx_load(m, MinContext);               // fresh: the coding step has updated this context
+    if (mcMin.suff) {
+        pc = mcMin.suff;
+        Ctx P = ctx_load(m, pc);
+        if (P.ns) {
+            Hit h = find_in(m, P, FSymbol);
+            p = h.p; pSucc = h.succ;
+            if (p != P.w1 && h.freq >= (h.prevSf >> 8)) {      // bubble one position up
+                state_store(m, p - 6, FSymbol | (h.freq << 8), h.succ);
+                state_store(m, p, h.prevSf, h.prevSucc);
+                p -= 6;
             }
-            if (S_FREQ(p) < MAX_FREQ) { cf = 1 + (FFreq < 4 * 8); S_FREQ_SET(p, S_FREQ(p) + cf); C_SF_SET(pc, C_SF(pc) + cf); }
-        } else { p = C_ONE(pc); S_FREQ_SET(p, S_FREQ(p) + (S_FREQ(p) < 11)); }
+            if (h.freq < MAX_FREQ) { cf = 1 + (FFreq < 4 * 8); S_FREQ_SET(p, h.freq + cf); C_SF_SET(pc, P.sf + cf); }
+        } else { p = C_ONE(pc); pSucc = P.w1; S_FREQ_SET(p, P.oneFreq + (P.oneFreq < 11)); }
     }
     pc = m.MaxContext;
     if (!m.OrderFall && iFSuccessor) {
-        const uint32_t s = CreateSuccessors(m, true, p, MinContext);
-        S_SUCC_SET(m.FoundState, s);
-        if (!s) { RestoreModelRare(m); return; }
-        m.MaxContext = s; return;
+        const uint32_t sx = CreateSuccessors(m, true, p, pSucc, MinContext, FSymbol, iFSuccessor);
+        S_SUCC_SET(m.FoundState, sx);
+        if (!sx) { RestoreModelRare(m); return; }
+        m.MaxContext = sx; return;
     }
     fs_st8(HP(m.pText), FSymbol); m.pText++; iSuccessor = m.pText;
     if (m.pText >= m.UnitsStart) { RestoreModelRare(m); return; }
     if (iFSuccessor) {
-        if (iFSuccessor < m.UnitsStart) iFSuccessor = CreateSuccessors(m, false, p, MinContext);
-    } else iFSuccessor = ReduceOrder(m, p, MinContext);
+        if (iFSuccessor < m.UnitsStart) iFSuccessor = CreateSuccessors(m, false, p, pSucc, MinContext, FSymbol, iFSuccessor);
+    } else iFSuccessor = ReduceOrder(m, p, pSucc, MinContext);
     if (!iFSuccessor) { RestoreModelRare(m); return; }
     if (!--m.OrderFall) { iSuccessor = iFSuccessor; m.pText -= (m.MaxContext != MinContext); }
-    s0 = C_SF(MinContext) - FFreq; ns = C_NS(MinContext);
+    s0 = mcMin.sf - FFreq; ns = mcMin.ns;
     const uint32_t Flag = 0x08u * (FSymbol >= 0x40);
     for (; pc != MinContext; pc = C_SUFF(pc)) {
         uint32_t summ;
@@ -527,16 +555,6 @@ FS_DEV void encodeBinSymbol(Coder& m, uint32_t c, const Ctx& mc, int symbol)
         m.NumMasked = m.PrevSuccess = 0; m.FoundState = 0;
     }
     m.sh->BinSumm[idx] = (uint16_t)bs;
-}
-
-// per-lane view of 64 consecutive states of a context
-struct LaneStates { uint32_t sf, succ; bool valid; };
-FS_DEV LaneStates lane_states(Coder& m, uint32_t stats, uint32_t ns, uint32_t base)
-{
-    LaneStates r; const uint32_t i = base + (uint32_t)FS_LANE();
-    r.valid = i <= ns; r.sf = 0; r.succ = 0;
-    if (r.valid) { fs_cgptr16 q = (fs_cgptr16)HP(stats + 6u * i); const uint32_t a = q[0], b = q[1], c = q[2]; r.sf = a; r.succ = b | (c << 16); }
-    return r;
 }
 
 FS_DEV void encodeSymbol1(Coder& m, uint32_t c, const Ctx& mc, int symbol)
