@@ -30,7 +30,10 @@ using namespace fsdev;
 namespace {
 
 constexpr uint64_t kGuard = 64ull << 10;
-constexpr uint32_t kWavesPerSimd = 6;                            // __launch_bounds__(64, 6): <= 80 VGPRs
+// Resident coder waves per SIMD.  Measured on MI355X (tools/ppmd_microbench.py): aggregate PPMd throughput saturates
+// at ~0.8 G symbols/s from ~3000 waves on (L2 share per wave shrinks), while per-stream latency keeps growing, and a
+// launch ends with its longest stream -- so 3 waves/SIMD (3072 waves, no register spills) beats 6.
+constexpr uint32_t kWavesPerSimd = 3;
 
 __global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(const StreamItem* __restrict__ items, const uint32_t* __restrict__ order,
                                                         uint32_t nItems, const uint8_t* in, uint8_t* out, uint32_t* outSizes,

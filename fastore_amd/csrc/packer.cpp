@@ -335,6 +335,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             parallelFor(chunks, hostThreads, [&](uint32_t c, uint32_t) {
                 for (size_t k = first + (size_t)nb * c / chunks; k < first + (size_t)nb * (c + 1) / chunks; ++k) libs[work[k].lib]->bf.unpack(work[k].sig, parts[c], true);
             });
+            const double tUnpack = nowMs() - tio;
             {   // concatenate the parts in parallel: destination offsets are a prefix sum over the parts
                 std::vector<uint64_t> oSeq(chunks + 1, 0), oHead(chunks + 1, 0), oRec(chunks + 1, 0), oNode(chunks + 1, 0), oTop(chunks + 1, 0), oEm(chunks + 1, 0), oTree(chunks + 1, 0), oBin(chunks + 1, 0);
                 for (uint32_t c = 0; c < chunks; ++c) {
@@ -361,6 +362,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             }
             for (size_t k = first; k < next; ++k) binArch.push_back(work[k].lib);
             stats.io_ms += nowMs() - tio;
+            if (getenv("FS_TRACE")) fprintf(stderr, "[trace] unpack %.1f ms, concatenate %.1f ms (%u bins, %.1f MB bases)\n", tUnpack, nowMs() - tio - tUnpack, nb, bases / 1e6);
             compressBatch(batch, binArch);
             uint64_t off = 0;
             for (size_t b = 0; b < batch.bins.size();) {              // route the blocks to their libraries (runs of equal lib)
@@ -371,12 +373,15 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                 libs[l]->pending.push_back(std::move(p)); b = e;
             }
             done += batch.bins.size();
+            const double tRoute = nowMs();
             tio = nowMs();
             for (auto& L : libs) flush(*L, false);
             stats.io_ms += nowMs() - tio;
+            if (getenv("FS_TRACE")) fprintf(stderr, "[trace] route+write %.1f ms\n", nowMs() - tRoute);
             if (verbose) { fprintf(stderr, "\rParts processed: %zu (%zu%%) ", done, work.empty() ? 100 : done * 100 / work.size()); fflush(stderr); }
         }
         const double tio = nowMs();
+        if (getenv("FS_TRACE")) fprintf(stderr, "[trace] before final flush at %.1f ms\n", nowMs() - tStart);
         for (size_t l = 0; l < nLibs; ++l) { flush(*libs[l], true); libs[l]->aw.finish(archives[l].head); stats.cdata_bytes += libs[l]->aw.dataBytes(); }
         stats.io_ms += nowMs() - tio;
     } catch (...) {
@@ -384,6 +389,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         throw;
     }
     stats.total_ms += nowMs() - tStart;
+    if (getenv("FS_TRACE")) fprintf(stderr, "[trace] packFiles total %.1f ms\n", nowMs() - tStart);
     if (verbose) fprintf(stderr, "\n");
 }
 

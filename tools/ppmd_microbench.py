@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Device PPMd micro-benchmark: per-symbol latency of ONE stream and throughput of many copies."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import fastore_amd
+rng = np.random.default_rng(1)
+def quality(n):
+    steps = np.array([-3, -1, 0, 0, 0, 0, 1, 1])[rng.integers(0, 8, n)]
+    q = np.empty(n, dtype=np.int64); cur = 38
+    out = bytearray(n); L = 150
+    for i in range(n):
+        if i % L == 0: cur = 38
+        cur = min(40, max(2, cur + steps[i])); out[i] = cur
+    return bytes(out)
+base = quality(int(sys.argv[1]) if len(sys.argv) > 1 else 300000)
+with fastore_amd.Packer(device_id=0, max_waves=int(sys.argv[2]) if len(sys.argv) > 2 else 0) as p:
+    p.ppmd_encode([base[:1000]])
+    for copies in (1, 600, 3000, 6144, 12288):
+        p.reset_stats(); t = time.perf_counter(); out = p.ppmd_encode([base] * copies); dt = time.perf_counter() - t
+        st = p.stats()
+        print("copies %5d  len %d -> %d  kernel %.1f ms  per-symbol(one stream) %.2f us  aggregate %.1f Msym/s  wall %.2f s" % (
+            copies, len(base), len(out[0]), st["encode_kernel_ms"], st["encode_kernel_ms"] * 1e3 / len(base), copies * len(base) / st["encode_kernel_ms"] / 1e3, dt), flush=True)
