@@ -34,14 +34,16 @@ void generateMinimizer(const MinimizerParametersRaw& mp, uint32_t id, char* buf)
 
 struct Unpacker {
     const BinModuleConfigRaw& cfg;
-    Batch& b;
+    Batch& b;        // bases / qualities / headers / records
+    Batch& g;        // graph tables
     BitReader meta, dna, qua, head;
     bool pe;
     Settings pairSettings;
+    bool placed = false; uint64_t seqCur = 0, headCur = 0;
 
-    Unpacker(const BinModuleConfigRaw& c, Batch& batch, const std::vector<uint8_t>& m, uint64_t ms, const std::vector<uint8_t>& d, uint64_t ds,
+    Unpacker(const BinModuleConfigRaw& c, Batch& batch, Batch& graph, const std::vector<uint8_t>& m, uint64_t ms, const std::vector<uint8_t>& d, uint64_t ds,
              const std::vector<uint8_t>& q, uint64_t qs, const std::vector<uint8_t>& h, uint64_t hs)
-        : cfg(c), b(batch), meta(m.data(), ms), dna(d.data(), ds), qua(q.data(), qs), head(h.data(), hs), pe(c.archiveType.readType == READ_PE)
+        : cfg(c), b(batch), g(graph), meta(m.data(), ms), dna(d.data(), ds), qua(q.data(), qs), head(h.data(), hs), pe(c.archiveType.readType == READ_PE)
     {
         pairSettings.minLen = pairSettings.maxLen = 1; pairSettings.hasConstLen = true; pairSettings.usesHeaders = false;
     }
@@ -70,8 +72,8 @@ struct Unpacker {
     void readHeader(Rec& r)
     {
         r.headLen = (uint8_t)head.getBits(8);
-        r.headOff = (uint32_t)b.head.size();
-        b.head.resize(b.head.size() + r.headLen);
+        if (placed) { if (headCur + r.headLen > b.head.size()) throw std::runtime_error("bin footer understates the header bytes"); r.headOff = (uint32_t)headCur; headCur += r.headLen; }
+        else { r.headOff = (uint32_t)b.head.size(); b.head.resize(b.head.size() + r.headLen); }
         uint8_t* h = b.head.data() + r.headOff;
         if (r.headLen) h[0] = '@';
         for (uint32_t i = 1; i < r.headLen; ++i) h[i] = (uint8_t)head.getBits(7);
@@ -94,6 +96,7 @@ struct Unpacker {
     }
     uint32_t allocSeq(uint32_t n)
     {
+        if (placed) { if (seqCur + n > b.seq.size()) throw std::runtime_error("bin footer understates the bases"); const uint64_t o = seqCur; seqCur += n; return (uint32_t)o; }
         const uint64_t off = b.seq.size();
         if (off + n > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB of bases");
         b.seq.resize(off + n); b.qua.resize(off + n);
@@ -101,7 +104,7 @@ struct Unpacker {
     }
     void readRecordData(const Settings& s, Rec& r)
     {
-        r.flags = 0; r.minimPos = 0; r.headLen = 0; r.headOff = (uint32_t)b.head.size();
+        r.flags = 0; r.minimPos = 0; r.headLen = 0; r.headOff = (uint32_t)(placed ? headCur : b.head.size());
         if (s.hasConstLen) { r.seqLen = (uint16_t)s.minLen; r.auxLen = pe ? r.seqLen : 0; }
         else {
             r.seqLen = (uint16_t)(meta.getBits(s.bitsPerLen) + s.minLen);
@@ -115,7 +118,7 @@ struct Unpacker {
     }
     void readExactMatch(const Settings& s, const Rec& mainRec, Rec& r)
     {
-        r.flags = 0; r.headLen = 0; r.headOff = (uint32_t)b.head.size();
+        r.flags = 0; r.headLen = 0; r.headOff = (uint32_t)(placed ? headCur : b.head.size());
         if (meta.getBit()) r.flags |= FLAG_REVERSE;
         if (pe && meta.getBit()) r.flags |= FLAG_SWAPPED;
         r.seqLen = mainRec.seqLen; r.auxLen = pe ? mainRec.auxLen : 0;
@@ -131,34 +134,34 @@ struct Unpacker {
     {
         const uint32_t mainRec = recIdx++;
         readRecordData(s, b.recs[mainRec]);
-        b.nodes[nodeIdx].rec = mainRec;
+        g.nodes[nodeIdx].rec = mainRec;
         if (!s.hasReadGroups) return;
         const bool hasEm = meta.getBit() != 0;
         const bool hasTrees = meta.getBit() != 0;
         if (hasEm) {
             const uint32_t groupSize = meta.getBits(kBitsPerClass[meta.get2Bits()]);
-            b.nodes[nodeIdx].emBegin = (uint32_t)b.emRecs.size();
-            b.nodes[nodeIdx].emCount = groupSize;
-            b.emRecs.resize(b.emRecs.size() + groupSize);
+            g.nodes[nodeIdx].emBegin = (uint32_t)g.emRecs.size();
+            g.nodes[nodeIdx].emCount = groupSize;
+            g.emRecs.resize(g.emRecs.size() + groupSize);
             for (uint32_t i = 0; i < groupSize; ++i) {
                 const uint32_t em = recIdx++;
                 readExactMatch(s, b.recs[mainRec], b.recs[em]);
-                b.emRecs[b.nodes[nodeIdx].emBegin + i] = em;
+                g.emRecs[g.nodes[nodeIdx].emBegin + i] = em;
             }
         }
         if (hasTrees) {
             const uint32_t tCount = meta.getBits(kBitsPerClass[meta.get2Bits()]);
-            const uint32_t treeBegin = (uint32_t)b.trees.size();
-            b.nodes[nodeIdx].treeBegin = treeBegin; b.nodes[nodeIdx].treeCount = tCount;
-            b.trees.resize(b.trees.size() + tCount);
+            const uint32_t treeBegin = (uint32_t)g.trees.size();
+            g.nodes[nodeIdx].treeBegin = treeBegin; g.nodes[nodeIdx].treeCount = tCount;
+            g.trees.resize(g.trees.size() + tCount);
             for (uint32_t t = 0; t < tCount; ++t) {
                 TreeIn tr;
                 tr.signatureId = meta.getBits(cfg.minimizer.signatureLen * 2);
                 tr.mainSignaturePos = (int32_t)meta.getBits(8);
                 const uint32_t groupSize = meta.getBits(kBitsPerClass[meta.get2Bits()]);
-                tr.nodeBegin = (uint32_t)b.nodes.size(); tr.nodeCount = groupSize;
-                b.nodes.resize(b.nodes.size() + groupSize, NodeIn{0, 0, 0, 0, 0});
-                b.trees[treeBegin + t] = tr;
+                tr.nodeBegin = (uint32_t)g.nodes.size(); tr.nodeCount = groupSize;
+                g.nodes.resize(g.nodes.size() + groupSize, NodeIn{0, 0, 0, 0, 0});
+                g.trees[treeBegin + t] = tr;
                 Settings cs = s;
                 cs.signatureId = tr.signatureId; cs.suffixLen = cfg.minimizer.signatureLen;
                 generateMinimizer(cfg.minimizer, cs.signatureId, cs.signature);
@@ -274,7 +277,11 @@ void BinFile::readFooter(const std::vector<uint8_t>& buf)
     }
 }
 
-void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin) const
+void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin) const { unpackImpl(signature, batch, batch, asNewBin, false, 0, 0, 0); }
+void BinFile::unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, uint64_t headBase, uint32_t recBase, Batch& graph) const
+{ unpackImpl(signature, data, graph, true, true, seqBase, headBase, recBase); }
+
+void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase) const
 {
     std::vector<uint8_t> bMeta_, bDna_, bQua_, bHead_;
     const auto it = bins_.find(signature);
@@ -291,16 +298,20 @@ void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin) const
         if (usesHeaderStream_) { copyAt(headf_, blk.headFileOffset, bHead_.data() + ho, blk.headSize, ".bhead"); ho += blk.headSize; }
         rawDna += blk.rawDnaSize; records += blk.recordsCount;
     }
-    if (asNewBin || batch.bins.empty()) {
-        BinIn nb{}; nb.signature = signature; nb.recBegin = (uint32_t)batch.recs.size(); nb.topBegin = (uint32_t)batch.topNodes.size();
-        batch.bins.push_back(nb);
+    if (asNewBin || graph.bins.empty()) {
+        BinIn nb{}; nb.signature = signature; nb.topBegin = (uint32_t)graph.topNodes.size();
+        nb.recBegin = placed ? recBase : (uint32_t)data.recs.size();
+        graph.bins.push_back(nb);
     }
-    BinIn& bin = batch.bins.back();
+    BinIn& bin = graph.bins.back();
     bin.rawDnaSize += rawDna;
-    uint32_t recIdx = (uint32_t)batch.recs.size();
-    batch.recs.resize(batch.recs.size() + records, Rec{});
+    uint32_t recIdx;
+    if (placed) { recIdx = recBase; if ((uint64_t)recBase + records > data.recs.size()) throw std::runtime_error("bin footer understates the records"); }
+    else { recIdx = (uint32_t)data.recs.size(); data.recs.resize(data.recs.size() + records, Rec{}); }
+    const uint32_t recFirst = recIdx;
 
-    Unpacker u(cfg_, batch, bMeta_, mo, bDna_, dO, bQua_, qo, bHead_, ho);
+    Unpacker u(cfg_, data, graph, bMeta_, mo, bDna_, dO, bQua_, qo, bHead_, ho);
+    u.placed = placed; u.seqCur = seqBase; u.headCur = headBase;
     Settings s;
     s.signatureId = signature;
     if (signature != nSignature()) { s.suffixLen = cfg_.minimizer.signatureLen; generateMinimizer(cfg_.minimizer, signature, s.signature); }
@@ -312,16 +323,17 @@ void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin) const
         if (!s.hasConstLen) s.bitsPerLen = bitLength(s.maxLen - s.minLen);
         const uint32_t end = recIdx + (uint32_t)blk.recordsCount;
         while (recIdx < end) {
-            const uint32_t nodeIdx = (uint32_t)batch.nodes.size();
-            batch.nodes.push_back(NodeIn{0, 0, 0, 0, 0});
-            batch.topNodes.push_back(nodeIdx);
+            const uint32_t nodeIdx = (uint32_t)graph.nodes.size();
+            graph.nodes.push_back(NodeIn{0, 0, 0, 0, 0});
+            graph.topNodes.push_back(nodeIdx);
             u.readNextNode(nodeIdx, s, recIdx);
         }
         u.meta.flushWord(); u.dna.flushWord(); u.qua.flushWord(); u.head.flushWord();
     }
     bin.minLen = s.minLen; bin.maxLen = s.maxLen;     // the reference keeps the last slice's values (NodesPacker.cpp:560-563)
-    bin.recCount = (uint32_t)batch.recs.size() - bin.recBegin;
-    bin.topCount = (uint32_t)batch.topNodes.size() - bin.topBegin;
+    bin.recCount = (placed ? recIdx : (uint32_t)data.recs.size()) - bin.recBegin;
+    bin.topCount = (uint32_t)graph.topNodes.size() - bin.topBegin;
+    (void)recFirst;
 }
 
 }  // namespace fs

@@ -33,9 +33,13 @@ public:
     // records/nodes to the last bin of the batch (block-0 merge of small bins and the N bin).
     // Thread-safe: only reads the mapped files and the footer tables.
     void unpack(uint32_t signature, Batch& batch, bool asNewBin) const;
+    // Placed form for parallel batch assembly: bases/quals/headers/records go to pre-sized arrays of `data` at the given
+    // offsets (their sizes are known from the footer); the graph tables and the BinIn go to `graph` (node indices local to it).
+    void unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, uint64_t headBase, uint32_t recBase, Batch& graph) const;
 
 private:
     void readFooter(const std::vector<uint8_t>& buf);
+    void unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase) const;
     struct Map { const uint8_t* p = nullptr; uint64_t size = 0; };    // read-only mmap of one stream file
     static Map mapFile(const std::string& name);
     static void unmap(Map& m);

@@ -9,7 +9,9 @@
 #pragma once
 #include <stdint.h>
 #include <set>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace fs {
@@ -87,9 +89,19 @@ struct BinIn {            // one bin = one future archive block
     uint32_t topBegin, topCount;     // top-level nodes: Batch::topNodes[topBegin .. +topCount) -> Batch::nodes
 };
 
+// allocator whose resize() leaves new elements uninitialised: the big record arrays are written exactly once
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    template <class U> void construct(U* p) noexcept { ::new ((void*)p) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new ((void*)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<uint8_t, NoInitAlloc<uint8_t>> ByteVec;
+
 struct Batch {
-    std::vector<uint8_t> seq, qua, head;
-    std::vector<Rec> recs;
+    ByteVec seq, qua, head;
+    std::vector<Rec, NoInitAlloc<Rec>> recs;
     std::vector<NodeIn> nodes;
     std::vector<uint32_t> topNodes;
     std::vector<uint32_t> emRecs;

@@ -138,9 +138,14 @@ void compressReadQuality(const BinModuleConfigRaw& cfg, const uint8_t* seq, cons
                                    5, 5, 5, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7};
     const uint32_t off = cfg.archiveType.qualityOffset;
     switch (cfg.quaParams.method) {
-    case MET_NONE:
-        for (uint32_t i = 0; i < len; ++i) { const uint32_t ii = reverse ? len - 1 - i : i; out.push_back((uint8_t)(qua[ii] - off)); }
+    case MET_NONE: {
+        const size_t o = out.size();
+        out.resize(o + len);
+        uint8_t* d = out.data() + o;
+        if (!reverse) for (uint32_t i = 0; i < len; ++i) d[i] = (uint8_t)(qua[i] - off);
+        else for (uint32_t i = 0; i < len; ++i) d[i] = (uint8_t)(qua[len - 1 - i] - off);
         break;
+    }
     case MET_BINARY:
         for (uint32_t i = 0; i < len; ++i) {
             const uint32_t ii = reverse ? len - 1 - i : i;

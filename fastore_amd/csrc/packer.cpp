@@ -294,22 +294,28 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
     if (rank == 0) {
         for (size_t l = 0; l < nLibs; ++l) {
             Lib& L = *libs[l];
-            uint64_t rawDna = 0;
-            for (uint32_t sig : L.bf.smallSignatures()) { L.bf.unpack(sig, L.b0, L.b0.bins.empty()); rawDna += L.bf.bins().at(sig).totalRawDnaSize; }
-            if (L.bf.hasNBin()) { L.bf.unpack(L.bf.nSignature(), L.b0, L.b0.bins.empty()); rawDna += L.bf.bins().at(L.bf.nSignature()).totalRawDnaSize; }
-            if (L.b0.recs.empty()) continue;
+            if (L.bf.smallSignatures().empty() && !L.bf.hasNBin()) continue;
             L.haveBlock0 = true; L.block0Written = false;
-            L.b0.bins[0].signature = L.bf.nSignature(); L.b0.bins[0].rawDnaSize = rawDna;
-            stats.block0_records += L.b0.recs.size();
             const ArchiveParams* ap = &archives[l]; Lib* lp = &L;
-            L.t0 = std::thread([this, lp, ap]() { const double a = nowMs(); try { compressRawBlock(lp->b0, *ap, lp->block0); } catch (const std::exception& e) { lp->t0err = e.what(); } lp->t0ms = nowMs() - a; });
+            // unpack + compress in the background thread (BinFile::unpack only reads the mapped files)
+            L.t0 = std::thread([this, lp, ap]() {
+                const double a = nowMs();
+                try {
+                    uint64_t rawDna = 0;
+                    for (uint32_t sig : lp->bf.smallSignatures()) { lp->bf.unpack(sig, lp->b0, lp->b0.bins.empty()); rawDna += lp->bf.bins().at(sig).totalRawDnaSize; }
+                    if (lp->bf.hasNBin()) { lp->bf.unpack(lp->bf.nSignature(), lp->b0, lp->b0.bins.empty()); rawDna += lp->bf.bins().at(lp->bf.nSignature()).totalRawDnaSize; }
+                    lp->b0.bins[0].signature = lp->bf.nSignature(); lp->b0.bins[0].rawDnaSize = rawDna;
+                    compressRawBlock(lp->b0, *ap, lp->block0);
+                } catch (const std::exception& e) { lp->t0err = e.what(); }
+                lp->t0ms = nowMs() - a;
+            });
         }
     }
     auto flush = [&](Lib& L, bool wait) {
         if (!L.block0Written) {
             if (!wait) return;
             L.t0.join(); if (!L.t0err.empty()) throw std::runtime_error(L.t0err);
-            stats.block0_ms = std::max(stats.block0_ms, L.t0ms); stats.block0_bytes += L.block0.size();
+            stats.block0_ms = std::max(stats.block0_ms, L.t0ms); stats.block0_bytes += L.block0.size(); stats.block0_records += L.b0.recs.size();
             L.aw.writeBlock(L.block0.data(), L.block0.size(), L.bf.nSignature());
             L.block0Written = true; L.b0.clear(); L.block0.clear(); L.block0.shrink_to_fit();
         }
@@ -330,33 +336,36 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                 bases += add; ++next;
             }
             const uint32_t nb = (uint32_t)(next - first);
-            const uint32_t chunks = std::min<uint32_t>(nb, std::max(1u, hostThreads));
+            // record arrays are placed: their sizes are in the .bmeta footer, so every bin knows its offsets up front
+            std::vector<uint64_t> seqBase(nb + 1, 0), headBase(nb + 1, 0), recBase(nb + 1, 0);
+            for (uint32_t k = 0; k < nb; ++k) {
+                const BinInfo& bi = libs[work[first + k].lib]->bf.bins().at(work[first + k].sig);
+                seqBase[k + 1] = seqBase[k] + bi.totalRawDnaSize; headBase[k + 1] = headBase[k] + bi.totalRawHeadSize; recBase[k + 1] = recBase[k] + bi.totalRecordsCount;
+            }
+            if (seqBase[nb] > 0xFFFFFFF0ull || headBase[nb] > 0xFFFFFFF0ull || recBase[nb] > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB");
+            batch.seq.resize(seqBase[nb]); batch.qua.resize(seqBase[nb]); batch.head.resize(headBase[nb]); batch.recs.resize(recBase[nb]);
+            const uint32_t chunks = std::min<uint32_t>(nb, std::max(1u, 4u * hostThreads));
             std::vector<Batch> parts(chunks);
             parallelFor(chunks, hostThreads, [&](uint32_t c, uint32_t) {
-                for (size_t k = first + (size_t)nb * c / chunks; k < first + (size_t)nb * (c + 1) / chunks; ++k) libs[work[k].lib]->bf.unpack(work[k].sig, parts[c], true);
+                for (size_t k = (size_t)nb * c / chunks; k < (size_t)nb * (c + 1) / chunks; ++k)
+                    libs[work[first + k].lib]->bf.unpackPlaced(work[first + k].sig, batch, seqBase[k], headBase[k], (uint32_t)recBase[k], parts[c]);
             });
             const double tUnpack = nowMs() - tio;
-            {   // concatenate the parts in parallel: destination offsets are a prefix sum over the parts
-                std::vector<uint64_t> oSeq(chunks + 1, 0), oHead(chunks + 1, 0), oRec(chunks + 1, 0), oNode(chunks + 1, 0), oTop(chunks + 1, 0), oEm(chunks + 1, 0), oTree(chunks + 1, 0), oBin(chunks + 1, 0);
+            {   // graph tables: concatenate the per-chunk parts (node indices re-based; record indices are already global)
+                std::vector<uint64_t> oNode(chunks + 1, 0), oTop(chunks + 1, 0), oEm(chunks + 1, 0), oTree(chunks + 1, 0), oBin(chunks + 1, 0);
                 for (uint32_t c = 0; c < chunks; ++c) {
-                    oSeq[c + 1] = oSeq[c] + parts[c].seq.size(); oHead[c + 1] = oHead[c] + parts[c].head.size(); oRec[c + 1] = oRec[c] + parts[c].recs.size();
                     oNode[c + 1] = oNode[c] + parts[c].nodes.size(); oTop[c + 1] = oTop[c] + parts[c].topNodes.size(); oEm[c + 1] = oEm[c] + parts[c].emRecs.size();
                     oTree[c + 1] = oTree[c] + parts[c].trees.size(); oBin[c + 1] = oBin[c] + parts[c].bins.size();
                 }
-                if (oSeq[chunks] > 0xFFFFFFF0ull || oHead[chunks] > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB");
-                batch.seq.resize(oSeq[chunks]); batch.qua.resize(oSeq[chunks]); batch.head.resize(oHead[chunks]); batch.recs.resize(oRec[chunks]);
                 batch.nodes.resize(oNode[chunks]); batch.topNodes.resize(oTop[chunks]); batch.emRecs.resize(oEm[chunks]); batch.trees.resize(oTree[chunks]); batch.bins.resize(oBin[chunks]);
                 parallelFor(chunks, hostThreads, [&](uint32_t c, uint32_t) {
                     Batch& o = parts[c];
-                    if (!o.seq.empty()) { memcpy(batch.seq.data() + oSeq[c], o.seq.data(), o.seq.size()); memcpy(batch.qua.data() + oSeq[c], o.qua.data(), o.qua.size()); }
-                    if (!o.head.empty()) memcpy(batch.head.data() + oHead[c], o.head.data(), o.head.size());
-                    const uint32_t sb = (uint32_t)oSeq[c], hb = (uint32_t)oHead[c], rb = (uint32_t)oRec[c], nb2 = (uint32_t)oNode[c], tb = (uint32_t)oTop[c], eb = (uint32_t)oEm[c], trb = (uint32_t)oTree[c];
-                    for (size_t i = 0; i < o.recs.size(); ++i) { Rec r = o.recs[i]; r.seqOff += sb; r.headOff += hb; batch.recs[rb + i] = r; }
-                    for (size_t i = 0; i < o.nodes.size(); ++i) { NodeIn n = o.nodes[i]; n.rec += rb; n.emBegin += eb; n.treeBegin += trb; batch.nodes[nb2 + i] = n; }
+                    const uint32_t nb2 = (uint32_t)oNode[c], tb = (uint32_t)oTop[c], eb = (uint32_t)oEm[c], trb = (uint32_t)oTree[c];
+                    for (size_t i = 0; i < o.nodes.size(); ++i) { NodeIn n = o.nodes[i]; n.emBegin += eb; n.treeBegin += trb; batch.nodes[nb2 + i] = n; }
                     for (size_t i = 0; i < o.topNodes.size(); ++i) batch.topNodes[tb + i] = o.topNodes[i] + nb2;
-                    for (size_t i = 0; i < o.emRecs.size(); ++i) batch.emRecs[eb + i] = o.emRecs[i] + rb;
+                    for (size_t i = 0; i < o.emRecs.size(); ++i) batch.emRecs[eb + i] = o.emRecs[i];
                     for (size_t i = 0; i < o.trees.size(); ++i) { TreeIn t = o.trees[i]; t.nodeBegin += nb2; batch.trees[trb + i] = t; }
-                    for (size_t i = 0; i < o.bins.size(); ++i) { BinIn b = o.bins[i]; b.recBegin += rb; b.topBegin += tb; batch.bins[oBin[c] + i] = b; }
+                    for (size_t i = 0; i < o.bins.size(); ++i) { BinIn b = o.bins[i]; b.topBegin += tb; batch.bins[oBin[c] + i] = b; }
                     o = Batch();
                 });
             }
