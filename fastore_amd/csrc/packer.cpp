@@ -142,7 +142,8 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
     blocks.clear(); blockSizes.clear();
     if (nBins == 0) return;
     const double t0 = nowMs();
-    std::vector<BinStreams> st(nBins);
+    if (streamPool.size() < nBins) streamPool.resize(nBins);
+    std::vector<BinStreams>& st = streamPool;
     {
         std::vector<std::unique_ptr<BinEncoder>> encs(hostThreads);
         parallelFor(nBins, hostThreads, [&](uint32_t b, uint32_t tid) {
@@ -192,7 +193,6 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
             if (!v.empty()) memcpy(input + items[pl.first_item + s].in_off, v.data(), v.size());
         }
     });
-    st.clear(); st.shrink_to_fit();
     const double t2 = nowMs();
     if (fsengine::encode_batch(dev, input, inBytes, items, plans, blocks, blockSizes, &timing) != 0)
         throw std::runtime_error(std::string("device: ") + dev->err);
@@ -323,7 +323,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         L.pending.clear();
     };
     const uint64_t budget = cfg.batch_bases ? cfg.batch_bases : (3072ull << 20);
-    Batch batch; std::vector<uint32_t> binArch; size_t next = 0, done = 0;
+    Batch& batch = workBatch; std::vector<uint32_t> binArch; size_t next = 0, done = 0;
     try {
         while (next < work.size()) {
             batch.clear(); binArch.clear();

@@ -40,6 +40,9 @@ struct Context {
     fsgpu_stats stats{};
     fsengine::BatchTiming timing;
     uint32_t hostThreads = 1;
+    // buffers kept across calls (their pages stay mapped: no first-touch faults or munmap churn per batch)
+    Batch workBatch;
+    std::vector<BinStreams> streamPool;
 
     // standard bins of `batch` -> blocks/blockSizes (bin order); binArch[b] = index into `archives`
     void compressBatch(const Batch& batch, const std::vector<uint32_t>& binArch);
