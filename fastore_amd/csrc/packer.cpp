@@ -146,7 +146,12 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
     std::vector<BinStreams>& st = streamPool;
     {
         std::vector<std::unique_ptr<BinEncoder>> encs(hostThreads);
-        parallelFor(nBins, hostThreads, [&](uint32_t b, uint32_t tid) {
+        // largest bins first: the front end of a bin is sequential, so a big bin started last would be the tail
+        std::vector<uint32_t> byWork(nBins);
+        for (uint32_t b = 0; b < nBins; ++b) byWork[b] = b;
+        std::sort(byWork.begin(), byWork.end(), [&](uint32_t x, uint32_t y) { return batch.bins[x].recCount > batch.bins[y].recCount; });
+        parallelFor(nBins, hostThreads, [&](uint32_t k, uint32_t tid) {
+            const uint32_t b = byWork[k];
             if (!encs[tid]) encs[tid].reset(new BinEncoder(par));
             encs[tid]->encodeLz(batch, batch.bins[b], archives[binArch[b]], st[b]);
         });
