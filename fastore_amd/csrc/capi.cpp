@@ -45,7 +45,7 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
     c.par.extraReduceHardReads = cfg->extra_reduce_hard_reads != 0; c.par.extraReduceExpensiveLzMatches = cfg->extra_reduce_expensive_lz != 0;
     c.par.maxRecordShiftDifference = cfg->max_record_shift_diff; c.par.maxNewVariantsPerRead = cfg->max_new_variants_per_read;
     c.par.maxHammingDistance = cfg->max_hamming_distance; c.par.minConsensusSize = cfg->min_consensus_size;
-    c.hostThreads = cfg->host_threads ? cfg->host_threads : std::min(64u, std::max(1u, std::thread::hardware_concurrency()));   // more threads only add allocator contention
+    c.hostThreads = cfg->host_threads ? cfg->host_threads : std::min(24u, std::max(1u, std::thread::hardware_concurrency()));   // measured on a 2 x 64-core host: the front end stops scaling at ~16-24 threads and degrades beyond
     if (getenv("FS_HOST_THREADS")) c.hostThreads = std::max(1, atoi(getenv("FS_HOST_THREADS")));     // experiments
     if (c.par.mismatchCost <= 0 || c.par.maxLzWindowSize == 0 || c.par.maxPairLzWindowSize == 0) { g_createError = "invalid matcher parameters"; delete ctx; return nullptr; }
     if (fsengine::device_count() <= 0) {

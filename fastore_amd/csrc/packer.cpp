@@ -150,11 +150,20 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
         std::vector<uint32_t> byWork(nBins);
         for (uint32_t b = 0; b < nBins; ++b) byWork[b] = b;
         std::sort(byWork.begin(), byWork.end(), [&](uint32_t x, uint32_t y) { return batch.bins[x].recCount > batch.bins[y].recCount; });
+        const bool trace = getenv("FS_TRACE") != nullptr;
+        std::vector<double> busy(hostThreads, 0.0), maxBin(hostThreads, 0.0); std::vector<uint32_t> maxBinRecs(hostThreads, 0);
         parallelFor(nBins, hostThreads, [&](uint32_t k, uint32_t tid) {
             const uint32_t b = byWork[k];
             if (!encs[tid]) encs[tid].reset(new BinEncoder(par));
+            const double a = trace ? nowMs() : 0.0;
             encs[tid]->encodeLz(batch, batch.bins[b], archives[binArch[b]], st[b]);
+            if (trace) { const double d = nowMs() - a; busy[tid] += d; if (d > maxBin[tid]) { maxBin[tid] = d; maxBinRecs[tid] = batch.bins[b].recCount; } }
         });
+        if (trace) {
+            double tot = 0, mx = 0, mb = 0; uint32_t mr = 0;
+            for (uint32_t t = 0; t < hostThreads; ++t) { tot += busy[t]; mx = std::max(mx, busy[t]); if (maxBin[t] > mb) { mb = maxBin[t]; mr = maxBinRecs[t]; } }
+            fprintf(stderr, "[trace] front end: %u threads, busy sum %.1f ms, busiest thread %.1f ms, slowest bin %.1f ms (%u records), wall so far %.1f ms\n", hostThreads, tot, mx, mb, mr, nowMs() - t0);
+        }
     }
     stats.frontend_ms += nowMs() - t0;
     std::vector<StreamItem> items; std::vector<BlockPlan> plans(nBins);
