@@ -23,7 +23,8 @@ class Config(C.Structure):
                 ("extra_reduce_expensive_lz", C.c_uint32), ("max_record_shift_diff", C.c_uint32),
                 ("max_new_variants_per_read", C.c_uint32), ("max_hamming_distance", C.c_uint32),
                 ("min_consensus_size", C.c_uint32), ("device_id", C.c_int32), ("host_threads", C.c_uint32),
-                ("max_waves", C.c_uint32), ("batch_bases", C.c_uint64), ("rank", C.c_uint32), ("world_size", C.c_uint32)]
+                ("max_waves", C.c_uint32), ("batch_bases", C.c_uint64), ("rank", C.c_uint32), ("world_size", C.c_uint32),
+                ("pipeline_slices", C.c_uint32), ("pipeline_lanes", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -69,6 +70,8 @@ def load_library(path=None):
     pp = C.POINTER(C.c_char_p)
     lib.fsgpu_ppmd_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fsgpu_rc_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fsgpu_set_quality_codebook.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.fsgpu_qvz_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     del pp
     if path is None:
         _lib = lib
@@ -159,3 +162,22 @@ class Packer:
         """Range-coded streams; pair_streams[i] = interleaved (symbol, ctx0) bytes, models[i] in 0..5."""
         m = (C.c_uint32 * len(models))(*models)
         return self._encode(self.lib.fsgpu_rc_encode, pair_streams, 2, extra=m)
+
+    def qvz_encode(self, footer, blocks):
+        """QVZ (--lossy) quality streams; footer = the .bmeta quality section (WELL state, max read length, codebook),
+        blocks[i] = (read_lens uint32 array, quality values uint8 array) of one block in coding order."""
+        import numpy as np
+        n = len(blocks)
+        lens = [np.ascontiguousarray(b[0], dtype=np.uint32) for b in blocks]
+        quals = [np.ascontiguousarray(b[1], dtype=np.uint8) for b in blocks]
+        for l, q in zip(lens, quals):
+            if int(l.sum()) != len(q):
+                raise FastoreError("read lengths do not add up to the number of quality values")
+        qp = (C.c_void_p * n)(*[q.ctypes.data for q in quals]); lp = (C.c_void_p * n)(*[l.ctypes.data for l in lens])
+        nr = (C.c_size_t * n)(*[len(l) for l in lens])
+        caps = [3 * len(q) + 64 for q in quals]
+        bufs = [C.create_string_buffer(c) for c in caps]
+        outs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+        capa = (C.c_size_t * n)(*caps); outl = (C.c_size_t * n)()
+        self._check(self.lib.fsgpu_qvz_encode(self.ctx, bytes(footer), len(footer), n, qp, lp, nr, outs, capa, outl))
+        return [bufs[i].raw[:outl[i]] for i in range(n)]

@@ -246,9 +246,8 @@ void BinFile::readFooter(const std::vector<uint8_t>& buf)
         bi.blocks.resize(n);
         r.getBytes(bi.blocks.data(), n * sizeof(BlockMetaDataRaw));
     }
-    qvzBytes_.clear();
-    if (cfg_.quaParams.method == MET_QVZ)
-        throw std::runtime_error("QVZ (--lossy) archives are not supported by this build yet");
+    qvz_ = QvzModel();
+    if (cfg_.quaParams.method == MET_QVZ) qvz_.parse(r);      // WELL seed, max read length, codebook (BinFile.cpp:740-755)
     head_ = HeaderStats();
     if (usesHeaderStream_) {
         const uint32_t fields = r.getByte();

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include "format.h"
+#include "qvz.h"
 
 namespace fs {
 
@@ -21,7 +22,7 @@ public:
 
     const BinModuleConfigRaw& config() const { return cfg_; }
     const HeaderStats& headData() const { return head_; }
-    const std::vector<uint8_t>& qvzFooterBytes() const { return qvzBytes_; }
+    const QvzModel& qvz() const { return qvz_; }
     const std::map<uint32_t, BinInfo>& bins() const { return bins_; }
     const std::vector<uint32_t>& stdSignatures() const { return std_; }
     const std::vector<uint32_t>& smallSignatures() const { return small_; }
@@ -50,7 +51,7 @@ private:
     bool usesHeaderStream_ = false;
     std::map<uint32_t, BinInfo> bins_;
     HeaderStats head_;
-    std::vector<uint8_t> qvzBytes_;
+    QvzModel qvz_;
     std::vector<uint32_t> std_, small_;
 };
 

@@ -14,6 +14,7 @@ public:
     BitReader(const uint8_t* p, uint64_t size) : p_(p), size_(size) {}
     uint64_t position() const { return pos_; }
     uint64_t size() const { return size_; }
+    const uint8_t* data() const { return p_; }
     uint32_t getByte() { if (pos_ >= size_) throw std::runtime_error("bin stream truncated"); return p_[pos_++]; }
     uint32_t getBit()
     {

@@ -57,7 +57,13 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
     return ctx;
 }
 
-void fsgpu_destroy(fsgpu_ctx* ctx) { if (!ctx) return; fsengine::device_destroy(ctx->c.dev); delete ctx; }
+void fsgpu_destroy(fsgpu_ctx* ctx)
+{
+    if (!ctx) return;
+    for (size_t i = 1; i < ctx->c.lanes.size(); ++i) fsengine::device_destroy(ctx->c.lanes[i]);      // lanes[0] == dev
+    fsengine::device_destroy(ctx->c.dev);
+    delete ctx;
+}
 const char* fsgpu_last_error(const fsgpu_ctx* ctx) { return ctx ? ctx->c.err.c_str() : "null context"; }
 const char* fsgpu_device_name(const fsgpu_ctx* ctx) { return (ctx && ctx->c.dev) ? ctx->c.dev->name : ""; }
 
@@ -71,6 +77,51 @@ int fsgpu_set_archive_params(fsgpu_ctx* ctx, const void* cfgRaw, size_t cfgBytes
         fs::parseHeaderFields(fields, fieldBytes, a.cfg.archiveType.readType == fs::READ_PE, a.head);
         if (a.cfg.archiveType.readsHaveHeaders && a.head.fields.empty()) throw std::runtime_error("archive has read ids but no field table was given");
         ctx->c.haveArchive = true;
+    });
+}
+
+int fsgpu_set_quality_codebook(fsgpu_ctx* ctx, const uint8_t* footer, size_t bytes)
+{
+    if (!ctx || !footer) return FSGPU_ERR_ARG;
+    if (!ctx->c.haveArchive) { ctx->c.err = "fsgpu_set_archive_params() has not been called"; return FSGPU_ERR_ARG; }
+    FS_GUARD(ctx, {
+        fs::BitReader r(footer, bytes);
+        ctx->c.archives[0].qvz = fs::QvzModel();
+        ctx->c.archives[0].qvz.parse(r);
+    });
+}
+
+int fsgpu_qvz_encode(fsgpu_ctx* ctx, const uint8_t* footer, size_t footerBytes, size_t n, const uint8_t* const* quals,
+                     const uint32_t* const* readLens, const size_t* nReads, uint8_t* const* out, const size_t* outCap, size_t* outLen)
+{
+    using namespace fsdev;
+    if (!ctx || !footer || (n && (!quals || !readLens || !nReads || !out || !outCap || !outLen))) return FSGPU_ERR_ARG;
+    FS_GUARD(ctx, {
+        fs::BitReader r(footer, footerBytes);
+        fs::QvzModel model; model.parse(r);
+        std::vector<StreamItem> items(n);
+        std::vector<std::vector<uint8_t>> sym(n);
+        uint64_t inBytes = (model.blob.size() + 15) & ~15ull;
+        for (size_t i = 0; i < n; ++i) {
+            fs::WellRng rng; rng.reset(model.wellSeed);
+            const uint8_t* q = quals[i];
+            for (size_t k = 0; k < nReads[i]; ++k) { fs::qvzSymbolise(model, rng, q, readLens[i][k], 0, false, sym[i]); q += readLens[i][k]; }
+            if (sym[i].size() > 0xF0000000ull) throw std::runtime_error("stream larger than 4 GiB");
+            StreamItem it; memset(&it, 0, sizeof it);
+            it.kind = KIND_QVZ; it.in_len = (uint32_t)(sym[i].size() / 4); it.in_off = inBytes; it.aux_off = 0; it.out_cap = 3 * it.in_len + 64;
+            items[i] = it; inBytes += (sym[i].size() + 15) & ~15ull;
+        }
+        std::vector<uint8_t> input(inBytes + 16);
+        memcpy(input.data(), model.blob.data(), model.blob.size());
+        for (size_t i = 0; i < n; ++i) if (!sym[i].empty()) memcpy(input.data() + items[i].in_off, sym[i].data(), sym[i].size());
+        std::vector<uint8_t> raw; std::vector<uint32_t> rawSizes;
+        if (fsengine::encode_streams_raw(ctx->c.dev, input.data(), inBytes, items, raw, rawSizes, &ctx->c.timing) != 0) throw std::runtime_error(std::string("device: ") + ctx->c.dev->err);
+        for (size_t i = 0; i < n; ++i) {
+            if (rawSizes[i] == 0xFFFFFFFFu) throw std::runtime_error("QVZ stream: malformed symbol or output overflow");
+            outLen[i] = rawSizes[i];
+            const size_t c = std::min<size_t>(rawSizes[i], outCap[i]);
+            if (c) memcpy(out[i], raw.data() + items[i].out_off, c);
+        }
     });
 }
 
@@ -113,6 +164,7 @@ int fsgpu_compress_bins(fsgpu_ctx* ctx, const fsgpu_bin_batch* in, fsgpu_block_b
             b.bins[i] = bi;
         }
         ctx->c.compressBatch(b, std::vector<uint32_t>(b.bins.size(), 0u));
+        ctx->c.gatherBlocks();
         out->data = ctx->c.blocks.data(); out->sizes = ctx->c.blockSizes.data(); out->n_blocks = ctx->c.blockSizes.size();
     });
 }

@@ -4,16 +4,17 @@
 
 namespace fsdev {
 
-enum : uint32_t { KIND_PPMD = 0, KIND_RC_BASE = 1 /* + fsrc::Model */ };
+enum : uint32_t { KIND_PPMD = 0, KIND_RC_BASE = 1 /* + fsrc::Model */, KIND_QVZ = 64 /* fsqvz arithmetic coder */ };
 
 // one entropy-coded stream of one bin
 struct StreamItem {
     uint64_t in_off;      // byte offset into the batch input buffer (even for RC pair streams)
     uint64_t out_off;     // byte offset into the batch scratch-output buffer
-    uint32_t in_len;      // bytes (PPMd) or (symbol, ctx) pairs (RC)
+    uint32_t in_len;      // bytes (PPMd), (symbol, ctx) pairs (RC) or u32 symbols (QVZ)
     uint32_t out_cap;     // bytes available at out_off
-    uint32_t kind;        // KIND_PPMD or KIND_RC_BASE + model
+    uint32_t kind;        // KIND_PPMD, KIND_RC_BASE + model, or KIND_QVZ
     uint32_t bin;         // bin index inside the batch
+    uint64_t aux_off;     // KIND_QVZ: byte offset of the library's model blob in the batch input buffer (16-byte aligned)
 };
 
 enum : uint32_t { MAX_STREAMS = 23 };

@@ -24,6 +24,7 @@
 #include "engine.h"
 #include "ppmd_core.h"
 #include "rc_core.h"
+#include "qvz_core.h"
 
 using namespace fsdev;
 
@@ -62,6 +63,8 @@ __global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(const Str
         uint32_t size = 0, rs = 0;
         if (kind == KIND_PPMD) {
             if (n > 0) size = fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs);
+        } else if (kind == KIND_QVZ) {
+            size = fsqvz::encode_stream(ar, (fs_cgptr)(in + item.aux_off), src, n, dst, cap);
         } else {
             size = fsrc::encode_model(kind - KIND_RC_BASE, ar, src, n, dst, cap);
         }
@@ -206,12 +209,24 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     uint64_t scratch = 0;
     for (auto& it : items) { it.out_off = scratch; scratch += ((uint64_t)it.out_cap + 15u) & ~15ull; }
     scratchBytes = scratch;
+    // a QVZ stream adapts a private copy of its library's statistics image (model blob header in the input buffer)
+    auto qvzImageBytes = [&](const StreamItem& s) -> uint64_t {
+        fsqvz::ModelHeader h; memcpy(&h, input + s.aux_off, sizeof h);
+        return 4ull * h.image_words;
+    };
+    for (const auto& it : items)
+        if (it.kind == KIND_QVZ) {
+            if ((it.aux_off & 15u) || it.aux_off + sizeof(fsqvz::ModelHeader) > inputBytes) { snprintf(dev->err, sizeof dev->err, "QVZ stream item without a model blob"); return -1; }
+            fsqvz::ModelHeader h; memcpy(&h, input + it.aux_off, sizeof h);
+            if (it.aux_off + fsqvz::blob_bytes(h.n_ctx, h.image_words) > inputBytes || (it.in_off & 3u)) { snprintf(dev->err, sizeof dev->err, "QVZ model blob outside the batch input"); return -1; }
+        }
     // longest-first queue order (a PPMd symbol costs roughly 10x a range-coder symbol)
     std::vector<uint32_t> order(nItems);
     for (uint32_t i = 0; i < nItems; ++i) order[i] = i;
     auto cost = [&](uint32_t i) -> uint64_t {
         const StreamItem& s = items[i];
         if (s.kind == KIND_PPMD) return (uint64_t)s.in_len * 10u + 2000u;
+        if (s.kind == KIND_QVZ) return (uint64_t)s.in_len * 4u + qvzImageBytes(s) / 256u + 100u;
         const uint64_t tbl = fsrc::model_table_bytes(s.kind - KIND_RC_BASE);
         return (uint64_t)s.in_len * 2u + tbl / 512u + 100u;
     };
@@ -229,7 +244,10 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     HIP_TRY(hipMemcpyAsync(dev->dOrder, order.data(), 4ull * nItems, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(dev->queueHead, 0, 64, st));
     uint64_t need = fsppmd::ARENA_BYTES;
-    for (const auto& it : items) if (it.kind != KIND_PPMD) need = std::max<uint64_t>(need, fsrc::model_table_bytes(it.kind - KIND_RC_BASE));
+    for (const auto& it : items) {
+        if (it.kind == KIND_QVZ) need = std::max<uint64_t>(need, qvzImageBytes(it));
+        else if (it.kind != KIND_PPMD) need = std::max<uint64_t>(need, fsrc::model_table_bytes(it.kind - KIND_RC_BASE));
+    }
     const uint64_t stride = ((need + kGuard) + 4095ull) & ~4095ull;
     const uint32_t grid = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nItems, dev->nWaves), dev->arenaPoolBytes / stride);
     uint32_t maxLen = 0;

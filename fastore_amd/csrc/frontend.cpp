@@ -132,7 +132,8 @@ void compressReadId(const HeaderStats& head, const uint8_t* h, uint32_t headLen,
     }
 }
 
-void compressReadQuality(const BinModuleConfigRaw& cfg, const uint8_t* seq, const uint8_t* qua, uint32_t len, bool reverse, std::vector<uint8_t>& out)
+void compressReadQuality(const BinModuleConfigRaw& cfg, const uint8_t* seq, const uint8_t* qua, uint32_t len, bool reverse, std::vector<uint8_t>& out,
+                         const QvzModel* qvz, WellRng* rng)
 {
     static const uint8_t q8[64] = {0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5,
                                    5, 5, 5, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7};
@@ -161,7 +162,11 @@ void compressReadQuality(const BinModuleConfigRaw& cfg, const uint8_t* seq, cons
             out.push_back(q8[(qua[ii] - off) & 63]); out.push_back((uint8_t)((i * 8) / len));
         }
         break;
-    default: throw std::runtime_error("QVZ quality coding is not supported by this build yet");
+    case MET_QVZ:
+        if (!qvz || !qvz->present || !rng) throw std::runtime_error("QVZ quality coding needs the library's codebook");
+        qvzSymbolise(*qvz, *rng, qua, len, off, reverse, out);
+        break;
+    default: throw std::runtime_error("unknown quality coding method");
     }
 }
 
@@ -169,6 +174,7 @@ void compressReadQuality(const BinModuleConfigRaw& cfg, const uint8_t* seq, cons
 struct BinEncoder::Impl {
     BinModuleConfigRaw cfg{};
     const HeaderStats* headp = nullptr;
+    const QvzModel* qvzp = nullptr; WellRng well;
     const PackParams par;
     uint32_t sigLen = 8;
     bool pe = false, hasHeaders = false;
@@ -195,7 +201,7 @@ struct BinEncoder::Impl {
     {
         const bool sameSig = a.cfg.minimizer.signatureLen == cfg.minimizer.signatureLen &&
                              a.cfg.minimizer.signatureMaskCutoffBits == cfg.minimizer.signatureMaskCutoffBits;
-        cfg = a.cfg; headp = &a.head;
+        cfg = a.cfg; headp = &a.head; qvzp = &a.qvz;
         sigLen = cfg.minimizer.signatureLen; pe = cfg.archiveType.readType == READ_PE; hasHeaders = cfg.archiveType.readsHaveHeaders != 0;
         memset(dnaToIdx, -1, sizeof dnaToIdx);
         for (int i = 0; i < 5; ++i) dnaToIdx[(int)cfg.minimizer.dnaSymbolOrder[i]] = (int8_t)i;
@@ -658,7 +664,7 @@ struct BinEncoder::Impl {
         compressReadId(*headp, B->head.data() + r.headOff, r.headLen, out->s[S_IdToken], out->s[S_IdValue]);
         out->rawIdSize += r.headLen;
     }
-    void compressQuality(int32_t v) { compressReadQuality(cfg, seq(v), qua(v), seqLen(v), isReverse(v), out->s[S_Quality]); }
+    void compressQuality(int32_t v) { compressReadQuality(cfg, seq(v), qua(v), seqLen(v), isReverse(v), out->s[S_Quality], qvzp, &well); }
 
     void compressHardRead(int32_t v)
     {
@@ -897,6 +903,7 @@ struct BinEncoder::Impl {
         setArchive(arch);
         B = &batch; out = &o; curSig = bin.signature;
         o.reset(pe ? S_PE_COUNT : S_SE_COUNT);
+        if (cfg.quaParams.method == MET_QVZ) well.reset(arch.qvz.wellSeed);
         initNodes(bin);
         lzStack.clear(); consStack.clear();
         lzStack.push_back(LzContext());

@@ -10,6 +10,7 @@
 #include <deque>
 #include <vector>
 #include "format.h"
+#include "qvz.h"
 
 namespace fs {
 
@@ -51,7 +52,7 @@ bool streamIsRangeCoded(uint32_t stream, uint32_t qualityMethod);
 uint32_t streamModel(uint32_t stream, uint32_t qualityMethod);
 
 // archive-level parameters of one library (they travel inside .bmeta)
-struct ArchiveParams { BinModuleConfigRaw cfg{}; HeaderStats head; };
+struct ArchiveParams { BinModuleConfigRaw cfg{}; HeaderStats head; QvzModel qvz; };
 
 class BinEncoder {
 public:
@@ -73,8 +74,9 @@ public:
 struct FieldSpec { uint8_t method; };     // 0 const, 1 token, 2 raw numeric
 void compressReadId(const HeaderStats& head, const uint8_t* h, uint32_t headLen, std::vector<uint8_t>& tokenPairs,
                     std::vector<uint8_t>& valuePairs);
-// IQualityStoreBase::CompressReadQuality for MET_NONE / MET_BINARY / MET_8BIN (FastqCompressor.cpp:221-320)
+// IQualityStoreBase::CompressReadQuality (FastqCompressor.cpp:221-364); MET_QVZ needs the library's model and the
+// block's running WELL generator (reset at every block start, FastqCompressor.cpp:906-915)
 void compressReadQuality(const BinModuleConfigRaw& cfg, const uint8_t* seq, const uint8_t* qua, uint32_t len, bool reverse,
-                         std::vector<uint8_t>& out);
+                         std::vector<uint8_t>& out, const QvzModel* qvz = nullptr, WellRng* rng = nullptr);
 
 }  // namespace fs

@@ -7,6 +7,7 @@
 #include <stdexcept>
 #include "ppmd_core.h"
 #include "rc_core.h"
+#include "qvz_core.h"
 
 namespace fshost {
 
@@ -32,6 +33,18 @@ void rcEncode(uint32_t model, const uint8_t* pairs, size_t nPairs, std::vector<u
     out.resize(2 * nPairs + 64);
     const uint32_t sz = fsrc::encode_model(model, table, pairs, (uint32_t)nPairs, out.data(), (uint32_t)out.size());
     free(table);
+    out.resize(sz);
+}
+
+void qvzEncode(const uint8_t* modelBlob, const uint8_t* symbols, size_t nSymbols, std::vector<uint8_t>& out)
+{
+    if (nSymbols > 0x3FFFFFF0ull) throw std::runtime_error("block-0 QVZ stream too long");
+    fsqvz::ModelHeader h; memcpy(&h, modelBlob, sizeof h);
+    uint8_t* arena = (uint8_t*)aligned_alloc(64, (4ull * h.image_words + 127) & ~63ull);
+    out.resize(3 * nSymbols + 64);
+    const uint32_t sz = fsqvz::encode_stream(arena, modelBlob, symbols, (uint32_t)nSymbols, out.data(), (uint32_t)out.size());
+    free(arena);
+    if (sz == 0xFFFFFFFFu) throw std::runtime_error("block-0 QVZ stream: malformed symbol or output overflow");
     out.resize(sz);
 }
 

@@ -113,7 +113,7 @@ void ArchiveWriter::writeBlock(const uint8_t* data, uint64_t size, uint32_t sign
     dataBytes_ += size;
 }
 
-void ArchiveWriter::finish(const HeaderStats& head)
+void ArchiveWriter::finish(const HeaderStats& head, const QvzModel& qvz)
 {
     const uint64_t footerOffset = 24;
     const uint32_t count = (uint32_t)sizes_.size();
@@ -121,6 +121,11 @@ void ArchiveWriter::finish(const HeaderStats& head)
     fwrite(sizes_.data(), 8, sizes_.size(), meta_);
     fwrite(sigs_.data(), 4, sigs_.size(), meta_);
     fwrite(&conf_, sizeof conf_, 1, meta_);
+    // quality data first, then the read-id field table (ArchiveFile.cpp:126-150)
+    if (conf_.quaParams.method == MET_QVZ) {
+        if (!qvz.present) throw std::runtime_error("QVZ archive without its codebook");
+        fwrite(qvz.footerBytes.data(), 1, qvz.footerBytes.size(), meta_);
+    }
     if (conf_.archType.readsHaveHeaders) {
         std::vector<uint8_t> blob;
         serializeHeaderFields(head, conf_.archType.readType == READ_PE, blob);
@@ -135,82 +140,172 @@ void ArchiveWriter::finish(const HeaderStats& head)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Lanes: independent engine instances on the same GPU (own HIP stream, arena pool, buffers).  A batch is cut into
+// slices; while the device codes slice k on one lane, the host threads run the front end of slice k+1, and the kernels
+// of consecutive slices overlap on the device (the waves a draining kernel frees are taken by the next one).
+fsengine::Device* Context::lane(uint32_t i)
+{
+    if (lanes.empty()) lanes.push_back(dev);
+    while (lanes.size() <= i) {
+        fsengine::Device* d = nullptr; char e[256] = {0};
+        if (fsengine::device_create(&d, cfg.device_id, cfg.max_waves, e, sizeof e) != 0) {
+            if (getenv("FS_TRACE")) fprintf(stderr, "[trace] no further engine lane: %s\n", e);
+            return nullptr;
+        }
+        lanes.push_back(d);
+    }
+    return lanes[i];
+}
+
+void Context::gatherBlocks()
+{
+    const uint32_t nBins = (uint32_t)blockSizes.size();
+    uint64_t total = 0;
+    for (uint64_t v : blockSizes) total += v;
+    blocks.resize(total);
+    uint64_t off = 0;
+    for (uint32_t b = 0; b < nBins; ++b) { memcpy(blocks.data() + off, blockData(b), blockSizes[b]); off += blockSizes[b]; }
+}
+
 void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& binArch)
 {
     using namespace fsdev;
     const uint32_t nBins = (uint32_t)batch.bins.size();
-    blocks.clear(); blockSizes.clear();
+    blocks.clear(); blockSizes.assign(nBins, 0); blockSlice.assign(nBins, 0); blockOff.assign(nBins, 0);
     if (nBins == 0) return;
     const double t0 = nowMs();
+    const bool trace = getenv("FS_TRACE") != nullptr;
     if (streamPool.size() < nBins) streamPool.resize(nBins);
     std::vector<BinStreams>& st = streamPool;
-    {
-        std::vector<std::unique_ptr<BinEncoder>> encs(hostThreads);
-        // largest bins first: the front end of a bin is sequential, so a big bin started last would be the tail
-        std::vector<uint32_t> byWork(nBins);
-        for (uint32_t b = 0; b < nBins; ++b) byWork[b] = b;
-        std::sort(byWork.begin(), byWork.end(), [&](uint32_t x, uint32_t y) { return batch.bins[x].recCount > batch.bins[y].recCount; });
-        const bool trace = getenv("FS_TRACE") != nullptr;
-        std::vector<double> busy(hostThreads, 0.0), maxBin(hostThreads, 0.0); std::vector<uint32_t> maxBinRecs(hostThreads, 0);
-        parallelFor(nBins, hostThreads, [&](uint32_t k, uint32_t tid) {
-            const uint32_t b = byWork[k];
-            if (!encs[tid]) encs[tid].reset(new BinEncoder(par));
-            const double a = trace ? nowMs() : 0.0;
-            encs[tid]->encodeLz(batch, batch.bins[b], archives[binArch[b]], st[b]);
-            if (trace) { const double d = nowMs() - a; busy[tid] += d; if (d > maxBin[tid]) { maxBin[tid] = d; maxBinRecs[tid] = batch.bins[b].recCount; } }
-        });
-        if (trace) {
-            double tot = 0, mx = 0, mb = 0; uint32_t mr = 0;
-            for (uint32_t t = 0; t < hostThreads; ++t) { tot += busy[t]; mx = std::max(mx, busy[t]); if (maxBin[t] > mb) { mb = maxBin[t]; mr = maxBinRecs[t]; } }
-            fprintf(stderr, "[trace] front end: %u threads, busy sum %.1f ms, busiest thread %.1f ms, slowest bin %.1f ms (%u records), wall so far %.1f ms\n", hostThreads, tot, mx, mb, mr, nowMs() - t0);
+    // largest bins first: their streams are the longest (a launch ends with its longest stream) and the front end of
+    // a bin is sequential, so a big bin started last would be the tail on the host too
+    std::vector<uint32_t> byWork(nBins);
+    for (uint32_t b = 0; b < nBins; ++b) byWork[b] = b;
+    std::sort(byWork.begin(), byWork.end(), [&](uint32_t x, uint32_t y) { return batch.bins[x].recCount > batch.bins[y].recCount; });
+    uint64_t totalRecs = 0;
+    for (const BinIn& b : batch.bins) totalRecs += b.recCount;
+    // slice boundaries by cumulated records: a small first slice starts the device early, the rest keeps it fed
+    std::vector<uint32_t> cut{0};
+    const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalRecs >= 200000) ? 5u : 1u);
+    if (wantSlices > 1) {
+        static const double kFrac5[] = {0.10, 0.30, 0.55, 0.80, 1.0};
+        uint64_t acc = 0; uint32_t k = 0;
+        for (uint32_t i = 0; i < nBins && k + 1 < wantSlices; ++i) {
+            acc += batch.bins[byWork[i]].recCount;
+            const double f = wantSlices == 5 ? kFrac5[k] : (double)(k + 1) / wantSlices;
+            if ((double)acc >= f * (double)totalRecs && i + 1 < nBins) { cut.push_back(i + 1); ++k; }
         }
     }
-    stats.frontend_ms += nowMs() - t0;
-    std::vector<StreamItem> items; std::vector<BlockPlan> plans(nBins);
-    uint64_t inBytes = 0;
-    for (uint32_t b = 0; b < nBins; ++b) {
-        const BinIn& bin = batch.bins[b]; BinStreams& bs = st[b];
-        const BinModuleConfigRaw& binCfg = archives[binArch[b]].cfg;
-        const uint32_t qm = binCfg.quaParams.method;
-        BlockPlan& pl = plans[b]; memset(&pl, 0, sizeof pl);
-        pl.signature = bin.signature; pl.records = bin.recCount; pl.raw_dna_size = bin.rawDnaSize; pl.raw_id_size = bs.rawIdSize;
-        pl.min_len = (uint8_t)bin.minLen; pl.max_len = (uint8_t)bin.maxLen; pl.has_headers = binCfg.archiveType.readsHaveHeaders != 0;
-        pl.n_streams = bs.nStreams; pl.first_item = (uint32_t)items.size();
-        uint32_t k = 0;
-        for (uint32_t s = 0; s < bs.nStreams; ++s) if (streamIsRangeCoded(s, qm)) pl.copy_order[k++] = s;
-        for (uint32_t s = 0; s < bs.nStreams; ++s) if (!streamIsRangeCoded(s, qm)) pl.copy_order[k++] = s;
-        for (uint32_t s = 0; s < bs.nStreams; ++s) {
-            const bool rc = streamIsRangeCoded(s, qm);
-            const uint64_t bytes = bs.s[s].size();
-            if (bytes > 0xF0000000ull) throw std::runtime_error("stream larger than 4 GiB");
-            StreamItem it; memset(&it, 0, sizeof it);
-            it.bin = b; it.in_off = inBytes;
-            // header-less archives never create the read-id coders: their streams stay empty (FastqCompressor.cpp:923-930)
-            const bool absent = !pl.has_headers && (s == S_IdToken || s == S_IdValue);
-            if (absent) { it.kind = KIND_PPMD; it.in_len = 0; it.out_cap = 16; pl.work_size[s] = 0; }
-            else if (rc) { uint32_t model = streamModel(s, qm);
-                           if (model == 5 && archives[binArch[b]].head.fields.size() <= 16) model = 6;     // read-id ctx0 = fieldId*4+k < 64: dense 8 MiB table
-                           it.kind = KIND_RC_BASE + model; it.in_len = (uint32_t)(bytes / 2); it.out_cap = 2 * it.in_len + 32; pl.work_size[s] = ~0ull; }
-            else { it.kind = KIND_PPMD; it.in_len = (uint32_t)bytes; it.out_cap = (uint32_t)(bytes + bytes / 8 + 64); pl.work_size[s] = bytes; }
-            items.push_back(it);
-            inBytes += (bytes + 15) & ~15ull;
+    cut.push_back(nBins);
+    const uint32_t nSlices = (uint32_t)cut.size() - 1;
+    const uint32_t wantLanes = nSlices > 1 ? std::min<uint32_t>(nSlices, cfg.pipeline_lanes ? cfg.pipeline_lanes : 3) : 1;
+    uint32_t nLanes = 1;
+    while (nLanes < wantLanes && lane(nLanes)) ++nLanes;
+    (void)lane(0);
+
+    struct Slice {
+        std::vector<StreamItem> items; std::vector<BlockPlan> plans; std::vector<uint64_t> sizes;
+        fsengine::BatchTiming timing; std::string err; std::thread th; double tSubmit = 0, tDone = 0;
+    };
+    std::vector<Slice> slices(nSlices);
+    sliceBlocks.resize(std::max<size_t>(sliceBlocks.size(), nSlices));
+    std::vector<std::unique_ptr<BinEncoder>> encs(hostThreads);
+    auto joinAll = [&]() { for (Slice& s : slices) if (s.th.joinable()) s.th.join(); };
+    double feMs = 0;
+    try {
+        for (uint32_t si = 0; si < nSlices; ++si) {
+            Slice& S = slices[si];
+            const uint32_t first = cut[si], count = cut[si + 1] - cut[si];
+            const double tf = nowMs();
+            parallelFor(count, hostThreads, [&](uint32_t k, uint32_t tid) {
+                const uint32_t b = byWork[first + k];
+                if (!encs[tid]) encs[tid].reset(new BinEncoder(par));
+                encs[tid]->encodeLz(batch, batch.bins[b], archives[binArch[b]], st[b]);
+            });
+            feMs += nowMs() - tf;
+            // ---- stream items and block plans of the slice ----
+            S.plans.resize(count);
+            uint64_t inBytes = 0;
+            // --lossy libraries: one read-only model blob per library in front of the streams
+            std::vector<uint64_t> qvzOff(archives.size(), ~0ull);
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t a = binArch[byWork[first + k]];
+                if (archives[a].cfg.quaParams.method != MET_QVZ || qvzOff[a] != ~0ull) continue;
+                if (!archives[a].qvz.present) throw std::runtime_error("QVZ archive without its codebook (fsgpu_set_quality_codebook)");
+                qvzOff[a] = inBytes; inBytes += (archives[a].qvz.blob.size() + 15) & ~15ull;
+            }
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t b = byWork[first + k];
+                const BinIn& bin = batch.bins[b]; BinStreams& bs = st[b];
+                const BinModuleConfigRaw& binCfg = archives[binArch[b]].cfg;
+                const uint32_t qm = binCfg.quaParams.method;
+                BlockPlan& pl = S.plans[k]; memset(&pl, 0, sizeof pl);
+                pl.signature = bin.signature; pl.records = bin.recCount; pl.raw_dna_size = bin.rawDnaSize; pl.raw_id_size = bs.rawIdSize;
+                pl.min_len = (uint8_t)bin.minLen; pl.max_len = (uint8_t)bin.maxLen; pl.has_headers = binCfg.archiveType.readsHaveHeaders != 0;
+                pl.n_streams = bs.nStreams; pl.first_item = (uint32_t)S.items.size();
+                uint32_t c = 0;
+                for (uint32_t s = 0; s < bs.nStreams; ++s) if (streamIsRangeCoded(s, qm)) pl.copy_order[c++] = s;
+                for (uint32_t s = 0; s < bs.nStreams; ++s) if (!streamIsRangeCoded(s, qm)) pl.copy_order[c++] = s;
+                for (uint32_t s = 0; s < bs.nStreams; ++s) {
+                    const bool rc = streamIsRangeCoded(s, qm);
+                    const uint64_t bytes = bs.s[s].size();
+                    if (bytes > 0xF0000000ull) throw std::runtime_error("stream larger than 4 GiB");
+                    StreamItem it; memset(&it, 0, sizeof it);
+                    it.bin = k; it.in_off = inBytes;
+                    // header-less archives never create the read-id coders: their streams stay empty (FastqCompressor.cpp:923-930)
+                    const bool absent = !pl.has_headers && (s == S_IdToken || s == S_IdValue);
+                    if (absent) { it.kind = KIND_PPMD; it.in_len = 0; it.out_cap = 16; pl.work_size[s] = 0; }
+                    else if (rc && s == S_Quality && qm == MET_QVZ) {
+                        it.kind = KIND_QVZ; it.in_len = (uint32_t)(bytes / 4); it.out_cap = 3 * it.in_len + 64; it.aux_off = qvzOff[binArch[b]]; pl.work_size[s] = ~0ull; }
+                    else if (rc) { uint32_t model = streamModel(s, qm);
+                                   if (model == 5 && archives[binArch[b]].head.fields.size() <= 16) model = 6;     // read-id ctx0 = fieldId*4+k < 64: dense 8 MiB table
+                                   it.kind = KIND_RC_BASE + model; it.in_len = (uint32_t)(bytes / 2); it.out_cap = 2 * it.in_len + 32; pl.work_size[s] = ~0ull; }
+                    else { it.kind = KIND_PPMD; it.in_len = (uint32_t)bytes; it.out_cap = (uint32_t)(bytes + bytes / 8 + 64); pl.work_size[s] = bytes; }
+                    S.items.push_back(it);
+                    inBytes += (bytes + 15) & ~15ull;
+                }
+            }
+            // ---- the lane of this slice: wait for the slice that used it before, stage, submit ----
+            const uint32_t li = si % nLanes;
+            if (si >= nLanes && slices[si - nLanes].th.joinable()) slices[si - nLanes].th.join();
+            fsengine::Device* L = lanes[li];
+            const double ts = nowMs();
+            uint8_t* input = fsengine::staging_buffer(L, inBytes + 16);        // pinned host memory owned by the lane
+            if (!input) throw std::runtime_error(std::string("device: ") + L->err);
+            for (size_t a = 0; a < archives.size(); ++a) if (qvzOff[a] != ~0ull) memcpy(input + qvzOff[a], archives[a].qvz.blob.data(), archives[a].qvz.blob.size());
+            parallelFor(count, hostThreads, [&](uint32_t k, uint32_t) {
+                const BlockPlan& pl = S.plans[k]; const uint32_t b = byWork[first + k];
+                for (uint32_t s = 0; s < pl.n_streams; ++s) {
+                    const auto& v = st[b].s[s];
+                    if (!v.empty()) memcpy(input + S.items[pl.first_item + s].in_off, v.data(), v.size());
+                }
+            });
+            S.tSubmit = nowMs();
+            if (trace) fprintf(stderr, "[trace] slice %u/%u: %u bins, front end %.1f ms, stage %.1f ms (%.1f MB), submitted at %.1f ms on lane %u\n",
+                               si + 1, nSlices, count, ts - tf, S.tSubmit - ts, inBytes / 1e6, S.tSubmit - t0, li);
+            std::vector<uint8_t>* outBlocks = &sliceBlocks[si];
+            S.th = std::thread([&S, L, input, inBytes, outBlocks]() {
+                if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, *outBlocks, S.sizes, &S.timing) != 0) S.err = std::string("device: ") + L->err;
+                S.tDone = nowMs();
+            });
         }
-        stats.records += bin.recCount;
+        joinAll();
+    } catch (...) { joinAll(); throw; }
+    for (Slice& S : slices) if (!S.err.empty()) throw std::runtime_error(S.err);
+    stats.frontend_ms += feMs;
+    for (uint32_t si = 0; si < nSlices; ++si) {
+        Slice& S = slices[si];
+        uint64_t off = 0;
+        for (uint32_t k = 0; k < cut[si + 1] - cut[si]; ++k) {
+            const uint32_t b = byWork[cut[si] + k];
+            blockSizes[b] = S.sizes[k]; blockSlice[b] = si; blockOff[b] = off; off += S.sizes[k];
+        }
+        timing.encode_ms += S.timing.encode_ms; timing.assemble_ms += S.timing.assemble_ms; timing.launches += S.timing.launches; timing.items += S.timing.items;
+        timing.ppmd_symbols += S.timing.ppmd_symbols; timing.rc_symbols += S.timing.rc_symbols; timing.restarts += S.timing.restarts;
+        timing.h2d_bytes += S.timing.h2d_bytes; timing.d2h_bytes += S.timing.d2h_bytes;
+        if (trace) fprintf(stderr, "[trace] slice %u done at %.1f ms (device call %.1f ms, kernel %.1f ms)\n", si + 1, S.tDone - t0, S.tDone - S.tSubmit, S.timing.encode_ms);
     }
-    const double t1 = nowMs();
-    uint8_t* input = fsengine::staging_buffer(dev, inBytes + 16);        // pinned host memory owned by the engine
-    if (!input) throw std::runtime_error(std::string("device: ") + dev->err);
-    parallelFor(nBins, hostThreads, [&](uint32_t b, uint32_t) {
-        const BlockPlan& pl = plans[b];
-        for (uint32_t s = 0; s < pl.n_streams; ++s) {
-            const auto& v = st[b].s[s];
-            if (!v.empty()) memcpy(input + items[pl.first_item + s].in_off, v.data(), v.size());
-        }
-    });
-    const double t2 = nowMs();
-    if (fsengine::encode_batch(dev, input, inBytes, items, plans, blocks, blockSizes, &timing) != 0)
-        throw std::runtime_error(std::string("device: ") + dev->err);
-    if (getenv("FS_TRACE")) fprintf(stderr, "[trace] batch: %u bins, frontend %.1f ms, stage streams %.1f ms (%.1f MB), device call %.1f ms\n", nBins, t1 - t0, t2 - t1, inBytes / 1e6, nowMs() - t2);
+    if (trace) fprintf(stderr, "[trace] batch: %u bins in %u slices on %u lanes, front end %.1f ms, total %.1f ms\n", nBins, nSlices, nLanes, feMs, nowMs() - t0);
     stats.bins += nBins;
     for (uint32_t b = 0; b < nBins; ++b) {
         const BinIn& bin = batch.bins[b];
@@ -248,16 +343,20 @@ void Context::compressRawBlock(Batch& batch, const ArchiveParams& arch, std::vec
     }
     std::vector<uint8_t> tok, val, dna, quaStream;
     uint64_t rawId = 0;
+    WellRng well;
+    if (qm == MET_QVZ) well.reset(arch.qvz.wellSeed);            // RawCompressorSE::Compress resets the generator too (FastqCompressor.cpp:3704-3714)
     for (uint32_t i = bin.recBegin; i < bin.recBegin + bin.recCount; ++i) {
         const Rec& r = batch.recs[i];
         const uint8_t* s = batch.seq.data() + r.seqOff; const uint8_t* q = batch.qua.data() + r.seqOff;
         if (hasHeaders) { compressReadId(head, batch.head.data() + r.headOff, r.headLen, tok, val); rawId += r.headLen; }
         dna.insert(dna.end(), s, s + r.seqLen + r.auxLen);
-        compressReadQuality(binCfg, s, q, r.seqLen, false, quaStream);
-        if (pe) compressReadQuality(binCfg, s + r.seqLen, q + r.seqLen, r.auxLen, false, quaStream);
+        compressReadQuality(binCfg, s, q, r.seqLen, false, quaStream, &arch.qvz, &well);
+        if (pe) compressReadQuality(binCfg, s + r.seqLen, q + r.seqLen, r.auxLen, false, quaStream, &arch.qvz, &well);
     }
     std::vector<uint8_t> cTok, cVal, cDna, cQua;
-    std::thread tq([&]() { if (qm == MET_NONE) fshost::ppmdEncode(quaStream.data(), quaStream.size(), cQua); else fshost::rcEncode(streamModel(S_Quality, qm), quaStream.data(), quaStream.size() / 2, cQua); });
+    std::thread tq([&]() { if (qm == MET_NONE) fshost::ppmdEncode(quaStream.data(), quaStream.size(), cQua);
+                           else if (qm == MET_QVZ) fshost::qvzEncode(arch.qvz.blob.data(), quaStream.data(), quaStream.size() / 4, cQua);
+                           else fshost::rcEncode(streamModel(S_Quality, qm), quaStream.data(), quaStream.size() / 2, cQua); });
     std::thread ti([&]() { if (hasHeaders) { fshost::rcEncode(5, tok.data(), tok.size() / 2, cTok); fshost::rcEncode(5, val.data(), val.size() / 2, cVal); } });
     fshost::ppmdEncode(dna.data(), dna.size(), cDna);
     tq.join(); ti.join();
@@ -298,7 +397,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         libs.emplace_back(new Lib());
         Lib& L = *libs.back();
         L.bf.open(inPrefixes[l], par.minBinSize);
-        archives[l].cfg = L.bf.config(); archives[l].head = L.bf.headData();
+        archives[l].cfg = L.bf.config(); archives[l].head = L.bf.headData(); archives[l].qvz = L.bf.qvz();
         L.aw.start(world > 1 ? outPrefixes[l] + ".part" + std::to_string(rank) : outPrefixes[l], archives[l].cfg);
         const auto& stdSigs = L.bf.stdSignatures();
         for (uint32_t i = 0; i < stdSigs.size(); ++i) if (i % world == rank) work.push_back(Work{(uint32_t)l, stdSigs[i]});
@@ -387,12 +486,13 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             stats.io_ms += nowMs() - tio;
             if (getenv("FS_TRACE")) fprintf(stderr, "[trace] unpack %.1f ms, concatenate %.1f ms (%u bins, %.1f MB bases)\n", tUnpack, nowMs() - tio - tUnpack, nb, bases / 1e6);
             compressBatch(batch, binArch);
-            uint64_t off = 0;
             for (size_t b = 0; b < batch.bins.size();) {              // route the blocks to their libraries (runs of equal lib)
                 const uint32_t l = binArch[b]; Lib::Pending p;
                 size_t e = b; uint64_t bytes = 0;
                 while (e < batch.bins.size() && binArch[e] == l) { p.sizes.push_back(blockSizes[e]); p.sigs.push_back(batch.bins[e].signature); bytes += blockSizes[e]; ++e; }
-                p.data.assign(blocks.begin() + off, blocks.begin() + off + bytes); off += bytes;
+                p.data.resize(bytes);
+                uint64_t off = 0;
+                for (size_t k = b; k < e; ++k) { memcpy(p.data.data() + off, blockData((uint32_t)k), blockSizes[k]); off += blockSizes[k]; }
                 libs[l]->pending.push_back(std::move(p)); b = e;
             }
             done += batch.bins.size();
@@ -405,7 +505,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         }
         const double tio = nowMs();
         if (getenv("FS_TRACE")) fprintf(stderr, "[trace] before final flush at %.1f ms\n", nowMs() - tStart);
-        for (size_t l = 0; l < nLibs; ++l) { flush(*libs[l], true); libs[l]->aw.finish(archives[l].head); stats.cdata_bytes += libs[l]->aw.dataBytes(); }
+        for (size_t l = 0; l < nLibs; ++l) { flush(*libs[l], true); libs[l]->aw.finish(archives[l].head, archives[l].qvz); stats.cdata_bytes += libs[l]->aw.dataBytes(); }
         stats.io_ms += nowMs() - tio;
     } catch (...) {
         for (auto& L : libs) if (L->t0.joinable()) L->t0.join();

@@ -18,7 +18,7 @@ public:
     ~ArchiveWriter();
     void start(const std::string& prefix, const BinModuleConfigRaw& cfg);
     void writeBlock(const uint8_t* data, uint64_t size, uint32_t signature);
-    void finish(const HeaderStats& head);
+    void finish(const HeaderStats& head, const QvzModel& qvz);
     uint64_t dataBytes() const { return dataBytes_; }
 private:
     FILE *meta_ = nullptr, *data_ = nullptr;
@@ -35,8 +35,15 @@ struct Context {
     std::vector<ArchiveParams> archives;          // one per library being packed (index 0 for the single-library calls)
     bool haveArchive = false;
     std::string err;
-    std::vector<uint8_t> blocks;
+    // result of compressBatch: block b of the batch is blockSizes[b] bytes at blockData(b); gatherBlocks() makes them contiguous
     std::vector<uint64_t> blockSizes;
+    std::vector<uint32_t> blockSlice; std::vector<uint64_t> blockOff;
+    std::vector<std::vector<uint8_t>> sliceBlocks;
+    std::vector<uint8_t> blocks;
+    const uint8_t* blockData(uint32_t b) const { return sliceBlocks[blockSlice[b]].data() + blockOff[b]; }
+    void gatherBlocks();
+    std::vector<fsengine::Device*> lanes;         // lanes[0] == dev; further engine instances for the pipelined batches
+    fsengine::Device* lane(uint32_t i);
     fsgpu_stats stats{};
     fsengine::BatchTiming timing;
     uint32_t hostThreads = 1;

@@ -1,0 +1,148 @@
+// QVZ adaptive arithmetic coder: one quality stream per wavefront (device) or per call (host build).
+//
+// Restates the reference's coder for the quantizer-state symbols of --lossy archives:
+//   arithmetic_encoder_step / encoder_last_step   fastore_pack/arith.cpp:33-125 (m = 22 bit registers, E1/E2/E3 rescaling)
+//   update_stats / initialize_stream_stats        fastore_pack/qv_stream.cpp:19-71 (step 8, halve-plus-one past 2^19)
+//   QVZEncoder::Start / EncodeNext / End          fastore_pack/qv_compressor.h:139-160
+//   bit output                                    fastore_bin/BitMemory.h:251-313, 392-404 (MSB first, zero padded to a byte)
+//
+// Input: one u32 per quality value, context | state << 24, produced by the front end (qvz.cpp), where a
+// context is one conditional quantizer (column, previous quantized value, low/high).  The model blob is
+// read-only and shared by every stream of the library:
+//     ModelHeader | Desc[n_ctx] | image[image_words]
+// `image` is the initial statistics of all contexts; each context owns image[off .. off + card]:
+// word 0 = n (the total), words 1..card = the counts.  A stream copies the image into its private arena
+// and adapts it there.  Lane j of the wave always touches word j of a context block, so a wave's own
+// program order is all the ordering the updates need.
+#pragma once
+#include "wave.h"
+
+namespace fsqvz {
+
+enum : uint32_t { M_BITS = 22, STEP = 8, RESCALE_AT = 1u << (M_BITS - 3), MAX_CARD = 72 };
+
+struct ModelHeader { uint32_t n_ctx, image_words, columns, reserved; };
+struct Desc { uint32_t off, card; };
+
+FS_DEV uint32_t blob_bytes(uint32_t n_ctx, uint32_t image_words) { return (uint32_t)sizeof(ModelHeader) + n_ctx * (uint32_t)sizeof(Desc) + image_words * 4u; }
+
+struct BitOut {
+    fs_gptr out; uint32_t pos, cap; uint64_t acc; uint32_t nb; uint32_t overflow;
+};
+FS_DEV void put_bits(BitOut& o, uint32_t v, uint32_t k)        // k <= 32, fewer than 8 bits pending on entry
+{
+    o.acc = (o.acc << k) | v; o.nb += k;
+    while (o.nb >= 8) {
+        o.nb -= 8;
+        if (o.pos < o.cap) o.out[o.pos] = (uint8_t)(o.acc >> o.nb); else o.overflow = 1;
+        o.pos++;
+    }
+}
+// one decided bit followed by the pending opposite bits (arith.cpp:80-92)
+FS_DEV void put_decided(BitOut& o, uint32_t bit, uint32_t& scale3)
+{
+    put_bits(o, bit, 1);
+    const uint32_t inv = bit ^ 1u;
+    while (scale3 >= 24) { put_bits(o, inv ? 0xFFFFFFu : 0u, 24); scale3 -= 24; }
+    if (scale3) { put_bits(o, inv ? ((1u << scale3) - 1u) : 0u, scale3); scale3 = 0; }
+}
+
+// cumulative count below x, the count of x and the total of the context block `blk`; then the adaptive update
+FS_DEV void model_step(FS_GLOBAL uint32_t* blk, uint32_t card, uint32_t x, uint32_t& cumLo, uint32_t& cnt, uint32_t& total)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lane = (uint32_t)FS_LANE();
+    // words 0..card of the block: lane j holds word j, lanes 0..8 also hold word 64 + j (card <= 72)
+    uint32_t v = lane <= card ? blk[lane] : 0u;
+    uint32_t part = (lane >= 1u && lane <= x) ? v : 0u;
+    uint32_t v2 = 0;
+    if (card >= 64u) {                                   // uniform
+        v2 = 64u + lane <= card ? blk[64u + lane] : 0u;
+        part += (64u + lane <= x) ? v2 : 0u;
+    }
+    #pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) part += (uint32_t)__shfl_xor((int)part, s, 64);
+    cumLo = FS_UNI(part);
+    total = fs_readlane(v, 0);
+    const uint32_t w = x + 1u;                           // word of the coded symbol
+    cnt = w < 64u ? fs_readlane(v, w) : fs_readlane(v2, w - 64u);
+    uint32_t nt = total + STEP;
+    if (nt > RESCALE_AT) {                               // uniform, once per 65536 uses of a context at most
+        uint32_t c = (lane == w) ? v + STEP : v;
+        uint32_t c2 = (64u + lane == w) ? v2 + STEP : v2;
+        if (lane >= 1u && lane <= card && c) c = (c >> 1) + 1u;
+        if (64u + lane <= card && c2) c2 = (c2 >> 1) + 1u;
+        uint32_t s = ((lane >= 1u && lane <= card) ? c : 0u) + ((64u + lane <= card) ? c2 : 0u);
+        #pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) s += (uint32_t)__shfl_xor((int)s, k, 64);
+        nt = FS_UNI(s);
+        if (lane >= 1u && lane <= card) blk[lane] = c;
+        if (64u + lane <= card) blk[64u + lane] = c2;
+        if (lane == 0u) blk[0] = nt;
+    } else {
+        if (lane == 0u) blk[0] = nt;
+        if (lane == w) blk[w] = v + STEP;
+        if (64u + lane == w) blk[w] = v2 + STEP;
+    }
+#else
+    uint32_t lo = 0;
+    for (uint32_t i = 0; i < x; ++i) lo += blk[1 + i];
+    cumLo = lo; cnt = blk[1 + x]; total = blk[0];
+    blk[1 + x] += STEP; blk[0] += STEP;
+    if (blk[0] > RESCALE_AT) {
+        uint32_t n = 0;
+        for (uint32_t i = 0; i < card; ++i) if (blk[1 + i]) { blk[1 + i] = (blk[1 + i] >> 1) + 1u; n += blk[1 + i]; }
+        blk[0] = n;
+    }
+#endif
+}
+
+// returns the stream size in bytes, or 0xFFFFFFFF when `cap` is too small or a symbol is malformed
+FS_DEV uint32_t encode_stream(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32_t n, fs_gptr out, uint32_t cap)
+{
+    const FS_GLOBAL ModelHeader* hdr = (const FS_GLOBAL ModelHeader*)model;
+    const uint32_t nCtx = FS_UNI(hdr->n_ctx), words = FS_UNI(hdr->image_words);
+    const FS_GLOBAL Desc* desc = (const FS_GLOBAL Desc*)(model + sizeof(ModelHeader));
+    fs_cgptr image = model + sizeof(ModelHeader) + (uint64_t)nCtx * sizeof(Desc);
+    fs_wave_copy4(arena, image, words * 4u);
+    FS_GLOBAL uint32_t* stat = (FS_GLOBAL uint32_t*)arena;
+
+    BitOut o; o.out = out; o.pos = 0; o.cap = cap; o.acc = 0; o.nb = 0; o.overflow = 0;
+    uint32_t l = 0, u = (1u << M_BITS) - 1u, scale3 = 0, bad = 0;
+    const uint32_t msbShift = M_BITS - 1, smsbShift = M_BITS - 2, clearMask = (1u << msbShift) - 1u;
+    const FS_GLOBAL uint32_t* sym = (const FS_GLOBAL uint32_t*)in;
+
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t w = FS_UNI(sym[i]);
+        const uint32_t ctx = w & 0xFFFFFFu, x = w >> 24;
+        if (ctx >= nCtx) { bad = 1; break; }
+        const uint32_t off = FS_UNI(desc[ctx].off), card = FS_UNI(desc[ctx].card);
+        if (x >= card || card > MAX_CARD) { bad = 1; break; }
+        uint32_t cumLo, cnt, total;
+        model_step(stat + off, card, x, cumLo, cnt, total);
+        const uint64_t range = (uint64_t)u - l + 1u;
+        u = l + (uint32_t)((range * (cumLo + cnt)) / total) - 1u;
+        l = l + (uint32_t)((range * cumLo) / total);
+        for (;;) {
+            const uint32_t msbL = l >> msbShift, msbU = u >> msbShift;
+            if (msbL == msbU) {
+                put_decided(o, msbL, scale3);
+                l = (l & clearMask) << 1;
+                u = ((u & clearMask) << 1) + 1u;
+            } else if ((l >> smsbShift) == 1u && (u >> smsbShift) == 2u) {
+                scale3 += 1u;
+                u = (((u << 1) & clearMask) | (1u << msbShift)) + 1u;
+                l = (l << 1) & clearMask;
+            } else break;
+        }
+    }
+    // encoder_last_step: the msb of the tag, the pending bits, the other m-1 tag bits, zero padding
+    const uint32_t msbL = l >> msbShift;
+    put_decided(o, msbL, scale3);
+    put_bits(o, l & clearMask, M_BITS - 1);
+    if (o.nb) put_bits(o, 0u, 8u - o.nb);
+    FS_WAVE_SYNC();
+    return (o.overflow || bad) ? 0xFFFFFFFFu : o.pos;
+}
+
+}  // namespace fsqvz

@@ -52,6 +52,8 @@ typedef struct fsgpu_config {
     uint32_t max_waves;                 /* resident coder wavefronts (0 = 16 per CU, memory permitting) */
     uint64_t batch_bases;               /* bases per device batch (0 = default) */
     uint32_t rank, world_size;          /* bin sharding: this context packs bins i with i % world_size == rank */
+    uint32_t pipeline_slices;           /* slices a batch is cut into so that host front end and device overlap (0 = default 5, 1 = off) */
+    uint32_t pipeline_lanes;            /* engine instances (stream + arena pool) whose kernels may overlap on the GPU (0 = default 3) */
 } fsgpu_config;
 
 /* Unpacked reads of a batch of bins, structure-of-arrays (what the reference hands to Compress() as
@@ -109,6 +111,11 @@ const char* fsgpu_last_error(const fsgpu_ctx* ctx);
 int fsgpu_set_archive_params(fsgpu_ctx* ctx, const void* bin_module_config, size_t config_bytes,
                              const uint8_t* header_fields, size_t header_fields_bytes);
 
+/* --lossy (QVZ) libraries only: the quality section of the .bmeta footer -- WELL-1024a state (128 bytes),
+ * max_read_length (u32), codebook -- exactly as BinFileWriter stores it (fastore_bin/BinFile.cpp:386-394,
+ * fastore_bin/QVZ.cpp:165-222).  Call after fsgpu_set_archive_params(); trailing bytes are ignored. */
+int fsgpu_set_quality_codebook(fsgpu_ctx* ctx, const uint8_t* qvz_footer, size_t qvz_footer_bytes);
+
 /* The per-bin hot path on standard (LZ) bins: FastqCompressor::Compress for signature != 4^p. */
 int fsgpu_compress_bins(fsgpu_ctx* ctx, const fsgpu_bin_batch* in, fsgpu_block_batch* out);
 
@@ -120,6 +127,14 @@ int fsgpu_ppmd_encode(fsgpu_ctx* ctx, size_t n_streams, const uint8_t* const* in
                       uint8_t* const* out, const size_t* out_cap, size_t* out_len);
 int fsgpu_rc_encode(fsgpu_ctx* ctx, size_t n_streams, const uint32_t* model, const uint8_t* const* pairs,
                     const size_t* n_pairs, uint8_t* const* out, const size_t* out_cap, size_t* out_len);
+
+/* QVZ quality stream of one block per stream: QVZEncoder (fastore_pack/qv_compressor.h:127-160, arith.cpp:33-125,
+ * qv_stream.cpp:19-71) driven by IQualityStoreBase::CompressReadQuality's MET_QVZ loop (FastqCompressor.cpp:318-364)
+ * with the WELL generator reset at the block start.  quals[i]: the block's quality values (offset removed, < 72),
+ * read after read in coding order; read_lens[i][n_reads[i]].  The model is parsed from `qvz_footer` as above. */
+int fsgpu_qvz_encode(fsgpu_ctx* ctx, const uint8_t* qvz_footer, size_t qvz_footer_bytes, size_t n_streams,
+                     const uint8_t* const* quals, const uint32_t* const* read_lens, const size_t* n_reads,
+                     uint8_t* const* out, const size_t* out_cap, size_t* out_len);
 
 /* Whole `fastore_pack e -i<in_prefix> -o<out_prefix>`: reads .bmeta/.bdna/.bqua/.bhead, writes
  * .cmeta/.cdata in the reference's -t1 block order. */

@@ -18,7 +18,14 @@
 //            478-480,1076 driven with (symbol, ctx0) byte pairs: golden vectors for the
 //            oracle's range-coder restatement
 //
+//   qvz   -> the reference's --lossy quality path on a list of reads: QvzCodebook::ReadCodebook
+//            (fastore_bin/QVZ.cpp:225-302) on the .bmeta footer section, then per read the loop of
+//            IQualityStoreBase::CompressReadQuality (fastore_pack/FastqCompressor.cpp:318-364) --
+//            choose_quantizer with the WELL generator, quantize, QVZEncoder::EncodeNext -- and End():
+//            golden vectors for the oracle's QVZ restatement
+//
 // usage: ref_driver <bin|rebin|pack|unpack> [flags]
+//        ref_driver qvz <footer: WELL state, max_read_length, codebook> <reads: u32 n, u32 len[n], quality values> <out>
 //        ref_driver ppmd <in> <out>          ref_driver ppmdd <in> <out>   (PpmdDecoder: inverse, for debugging)
 //        ref_driver rc <model> <in: sym,ctx byte pairs> <out>     model = s2o4|s8o4|a8o4|a2o10|a8o6|a256o1
 
@@ -41,6 +48,8 @@
 #include "fastore_bin/BitMemory.h"
 #include "rc/ContextEncoder.h"
 #include "ppmd/PPMd.h"
+#include "fastore_bin/QVZ.h"
+#include "fastore_pack/qv_compressor.h"
 
 static std::vector<std::string> split_ws(const char* s)
 {
@@ -252,6 +261,60 @@ static int do_rc(int argc, char** argv)
     return 2;
 }
 
+static std::vector<unsigned char> slurp(const char* path)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+    std::vector<unsigned char> v; unsigned char buf[65536]; size_t k;
+    while ((k = fread(buf, 1, sizeof buf, f)) > 0) v.insert(v.end(), buf, buf + k);
+    fclose(f);
+    return v;
+}
+
+static int do_qvz(int argc, char** argv)
+{
+    if (argc != 5) { fprintf(stderr, "usage: ref_driver qvz <footer> <reads> <out>\n"); return 2; }
+    std::vector<unsigned char> foot = slurp(argv[2]), reads = slurp(argv[3]);
+    QualityCompressionData qd;
+    {
+        Buffer mem(foot.size() + 16);
+        memcpy(mem.Pointer(), foot.data(), foot.size());
+        BitMemoryReader reader(mem, foot.size());
+        reader.GetBytes((byte*)qd.well.state, sizeof(qd.well.state));
+        reader.GetBytes((byte*)&qd.max_read_length, sizeof(qd.max_read_length));
+        struct alphabet_t* A = alloc_alphabet(ALPHABET_SIZE);
+        qd.codebook.ReadCodebook(reader, A, qd.max_read_length);
+    }
+    uint32_t n; memcpy(&n, reads.data(), 4);
+    const uint32_t* lens = (const uint32_t*)(reads.data() + 4);
+    const unsigned char* q = reads.data() + 4 + 4ull * n;
+    uint64_t total = 0; for (uint32_t i = 0; i < n; ++i) total += lens[i];
+    Buffer outBuf(3 * total + 1024);
+    BitMemoryWriter writer(outBuf);
+    struct cond_quantizer_list_t* qlist = qd.codebook.qlist;
+    QVZEncoder* enc = new QVZEncoder(&writer, qlist);
+    enc->Start();
+    well_state_t well; memset(&well, 0, sizeof well);
+    memcpy(well.state, qd.well.state, sizeof well.state);
+    for (uint32_t r = 0; r < n; ++r) {
+        uint32_t idx = 0, prev = 0;
+        for (uint32_t i = 0; i < lens[r]; ++i) {
+            struct quantizer_t* qz = choose_quantizer(qlist, &well, i, prev, &idx);
+            const uint32_t hat = qz->q[q[i]];
+            enc->EncodeNext(get_symbol_index(qz->output_alphabet, hat), i, idx);
+            prev = hat;
+        }
+        q += lens[r];
+    }
+    enc->End();
+    delete enc;
+    writer.Flush();
+    FILE* f = fopen(argv[4], "wb");
+    fwrite(outBuf.Pointer(), 1, writer.Position(), f);
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 3) {
@@ -267,6 +330,7 @@ int main(int argc, char** argv)
         if (cmd == "ppmd") return do_ppmd(argc, argv);
         if (cmd == "ppmdd") return do_ppmdd(argc, argv);
         if (cmd == "rc") return do_rc(argc, argv);
+        if (cmd == "qvz") return do_qvz(argc, argv);
         fprintf(stderr, "unknown command %s\n", argv[1]);
         return 2;
     } catch (const std::exception& e) {

@@ -54,6 +54,18 @@ def oracle_rc(lib, model, pairs):
     return buf.raw[:n]
 
 
+def oracle_qvz(lib, footer, lens, quals):
+    """One block's QVZ quality stream by the oracle (oracle/src/qvz_oracle.c); lens uint32[n], quals uint8[]."""
+    import numpy as np
+    lens = np.ascontiguousarray(lens, dtype=np.uint32); quals = np.ascontiguousarray(quals, dtype=np.uint8)
+    buf = ctypes.create_string_buffer(3 * len(quals) + 64)
+    lib.fso_qvz_encode.restype = ctypes.c_long
+    lib.fso_qvz_encode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
+    n = lib.fso_qvz_encode(footer, len(footer), quals.ctypes.data, lens.ctypes.data, len(lens), buf, len(buf))
+    assert n >= 0, "oracle rejected the QVZ input"
+    return buf.raw[:n]
+
+
 def manifest():
     out = []
     for line in open(os.path.join(GOLDEN, "manifest.txt")):

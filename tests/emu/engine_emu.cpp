@@ -10,6 +10,7 @@
 #include "../../fastore_amd/csrc/engine.h"
 #include "../../fastore_amd/csrc/ppmd_core.h"
 #include "../../fastore_amd/csrc/rc_core.h"
+#include "../../fastore_amd/csrc/qvz_core.h"
 
 using namespace fsdev;
 namespace fsengine {
@@ -36,6 +37,7 @@ static void runItems(const uint8_t* input, std::vector<StreamItem>& items, std::
             const size_t i = next.fetch_add(1); if (i >= items.size()) break;
             const StreamItem& it = items[i];
             if (it.kind == KIND_PPMD) { if (it.in_len) sizes[i] = fsppmd::encode_member(arena, sh, input + it.in_off, it.in_len, scratch.data() + it.out_off, it.out_cap, nullptr); }
+            else if (it.kind == KIND_QVZ) sizes[i] = fsqvz::encode_stream(arena, input + it.aux_off, input + it.in_off, it.in_len, scratch.data() + it.out_off, it.out_cap);
             else sizes[i] = fsrc::encode_model(it.kind - KIND_RC_BASE, arena, input + it.in_off, it.in_len, scratch.data() + it.out_off, it.out_cap);
         }
         delete sh; free(arena);

@@ -14,9 +14,11 @@ GEN=$ROOT/build/gen_fastq
 T=$(mktemp -d)
 # -f24: bins of >= 24 records are "standard" (LZ) bins, so that these small libraries exercise the LZ path and block 0
 PACKFLAGS="-r -f24 -c10 -d8 -w1024 -W1024"
-rm -f manifest.txt
+ONLY=${1:-}                     # optional: regenerate just this fixture
+[ -z "$ONLY" ] && rm -f manifest.txt
 make_one() {   # name reads len genome seed paired qflag headerflags
     local name=$1 reads=$2 len=$3 genome=$4 seed=$5 paired=$6 q=$7 hf=$8
+    if [ -n "$ONLY" ] && [ "$ONLY" != "$name" ]; then return; fi
     local pe="" in="$T/$name"_1.fastq
     if [ "$paired" = 1 ]; then $GEN --reads $reads --len $len --genome $genome --seed $seed --paired --out $T/$name; pe="-z"; in="$T/${name}_1.fastq $T/${name}_2.fastq"
     else $GEN --reads $reads --len $len --genome $genome --seed $seed --out $T/$name; fi
@@ -25,7 +27,7 @@ make_one() {   # name reads len genome seed paired qflag headerflags
     $G rebin -i$T/$name.b2 -o$T/$name.b4 -t2 -r -w1024 -W1024 -p4 $pe
     $G rebin -i$T/$name.b4 -o$T/$name.b8 -t2 -r -w1024 -W1024 -p8 $pe
     $R pack -i$T/$name.b8 -o$T/$name.ref -t1 $PACKFLAGS $pe
-    echo "$name $paired $PACKFLAGS" >> manifest.txt
+    grep -q "^$name " manifest.txt 2>/dev/null || echo "$name $paired $PACKFLAGS" >> manifest.txt
     for e in bmeta bdna bqua; do cp $T/$name.b8.$e $name.in.$e; done
     [ -f $T/$name.b8.bhead ] && cp $T/$name.b8.bhead $name.in.bhead
     cp $T/$name.ref.cdata $name.ref.cdata; cp $T/$name.ref.cmeta $name.ref.cmeta
@@ -36,5 +38,6 @@ make_one pe_lossless   4000  100 16000  12   1  0  "-H"
 make_one se_reduced    5000  100 10000  13   0  2  "-H -C"
 make_one se_noheader   4000  80  6400   14   0  0  ""
 make_one se_binary     4000  100 8000   15   0  1  ""
+make_one se_qvz        3000  60  3600   16   0  3  "-H"       # --lossy: QVZ codebook + WELL seed in the footer
 rm -rf "$T"
 ls -la

@@ -28,3 +28,14 @@ for m, A in models.items():
 open(f"{V}/rc_empty.in", "wb").write(b"")
 subprocess.check_call([R, "rc", "a256o1", f"{V}/rc_empty.in", f"{V}/rc_empty.out"])
 print(sorted(os.listdir(V)))
+# ---- QVZ (--lossy) quality streams: the reference's codebook reader, WELL generator, quantizer choice and
+# arithmetic coder (`ref_driver qvz`) on seeded reads; footer = the one of the se_qvz golden archive ----
+import tempfile
+from qvz_inputs import CASES, footer_for, reads_case, reads_blob
+with tempfile.TemporaryDirectory() as T:
+    for name in CASES:
+        open(f"{T}/footer", "wb").write(footer_for(name))
+        lens, quals = reads_case(name)
+        open(f"{T}/reads", "wb").write(reads_blob(lens, quals))
+        subprocess.check_call([R, "qvz", f"{T}/footer", f"{T}/reads", f"{V}/{name}.out"])
+print(sorted(os.listdir(V)))

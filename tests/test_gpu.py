@@ -8,7 +8,11 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, MODELS, REF_DRIVER, REF_DRIVER_GCC, ROOT, VECTORS, knobs_from_flags, manifest, oracle_ppmd, oracle_rc
+from conftest import GOLDEN, MODELS, REF_DRIVER, REF_DRIVER_GCC, ROOT, VECTORS, knobs_from_flags, manifest, oracle_ppmd, oracle_qvz, oracle_rc
+
+import sys
+sys.path.insert(0, GOLDEN)
+import qvz_inputs
 from test_host import assert_same_archive
 
 pytestmark = pytest.mark.gpu
@@ -90,6 +94,37 @@ def test_rc_device_matches_oracle_all_models_with_rescale(packer, oracle):
         assert g == oracle_rc(oracle, name, pairs)
 
 
+def test_qvz_device_matches_reference_vectors(packer):
+    for name in qvz_inputs.CASES:                        # incl. the count rescaling and the > 64-symbol alphabets
+        lens, quals = qvz_inputs.reads_case(name)
+        got = packer.qvz_encode(qvz_inputs.footer_for(name), [(lens, quals)])[0]
+        assert got == open(os.path.join(VECTORS, name + ".out"), "rb").read(), name
+
+
+def test_qvz_device_matches_oracle_many_ragged_blocks(packer, oracle):
+    rng = np.random.default_rng(303)
+    for footer, top, maxlen in ((qvz_inputs.qvz_footer(), 42, 60), (qvz_inputs.wide_footer(), 72, 3)):
+        blocks = []
+        for i in range(200):
+            lens = rng.integers(1, maxlen + 1, int(rng.integers(1, 400))).astype(np.uint32)
+            blocks.append((lens, rng.integers(2 if top == 42 else 0, top, int(lens.sum())).astype(np.uint8)))
+        blocks.append((np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint8)))          # empty block: just the coder's tail
+        got = packer.qvz_encode(footer, blocks)
+        for (lens, quals), g in zip(blocks, got):
+            assert g == oracle_qvz(oracle, footer, lens, quals)
+
+
+def test_qvz_device_rejects_bad_input(packer):
+    import fastore_amd
+    f = qvz_inputs.qvz_footer()
+    with pytest.raises(fastore_amd.FastoreError):
+        packer.qvz_encode(f[:1000], [(np.array([1], dtype=np.uint32), np.array([3], dtype=np.uint8))])      # truncated codebook
+    with pytest.raises(fastore_amd.FastoreError):
+        packer.qvz_encode(f, [(np.array([1], dtype=np.uint32), np.array([99], dtype=np.uint8))])             # value outside the alphabet
+    with pytest.raises(fastore_amd.FastoreError):
+        packer.qvz_encode(f, [(np.array([61], dtype=np.uint32), np.full(61, 30, dtype=np.uint8))])           # read longer than the codebook
+
+
 @pytest.mark.parametrize("name,paired,flags", manifest())
 def test_gpu_pack_reproduces_reference_archives(tmp_path, name, paired, flags):
     import fastore_amd
@@ -126,7 +161,7 @@ def _ref_pipeline(tmp, name, reads, length, genome, seed, paired, q):
 
 
 @pytest.mark.skipif(not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)), reason="reference binaries (oracle/_ref) not shipped")
-@pytest.mark.parametrize("paired,q,reads", [(False, 0, 120000), (True, 0, 60000), (False, 2, 60000)])
+@pytest.mark.parametrize("paired,q,reads", [(False, 0, 120000), (True, 0, 60000), (False, 2, 60000), (False, 3, 40000), (True, 3, 60000)])
 def test_gpu_pack_equals_live_reference_on_fresh_library(tmp_path, paired, q, reads):
     import fastore_amd
     t = str(tmp_path)
@@ -153,8 +188,9 @@ def test_gpu_pack_is_deterministic_and_sizes_add_up(tmp_path):
     import fastore_amd
     name, paired, flags = manifest()[1]
     outs = []
-    for i, waves in enumerate((0, 37)):                 # different wave counts change scheduling, never the bytes
-        with fastore_amd.Packer(device_id=0, max_waves=waves, **knobs_from_flags(flags)) as p:
+    for i, (waves, slices) in enumerate(((0, 1), (37, 1), (0, 6), (300, 3))):       # wave counts and pipeline slicing change scheduling, never the bytes
+        with fastore_amd.Packer(device_id=0, max_waves=waves, pipeline_slices=slices, **knobs_from_flags(flags)) as p:
             p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o%d" % i)))
         outs.append(open(str(tmp_path / ("o%d.cdata" % i)), "rb").read())
-    assert outs[0] == outs[1]
+    assert all(o == outs[0] for o in outs[1:])
+    assert outs[0] == open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()

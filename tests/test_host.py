@@ -39,7 +39,7 @@ def test_c_abi_exports_every_declared_symbol(product_lib):
 
 def test_structs_match_header_layout(product_lib):
     import fastore_amd
-    assert ctypes.sizeof(fastore_amd.Config) == 80
+    assert ctypes.sizeof(fastore_amd.Config) == 88
     assert ctypes.sizeof(fastore_amd.Stats) == 152
     cfg = fastore_amd.Config()
     product_lib.fsgpu_config_defaults(ctypes.byref(cfg))
@@ -107,6 +107,29 @@ def test_host_pipeline_reproduces_reference_archives(emu_lib, tmp_path, name, pa
         st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / "o"))
     assert_same_archive(str(tmp_path / "o"), os.path.join(GOLDEN, name + ".ref"))
     assert st["bins"] > 20 and st["block0_records"] > 0      # both the LZ path and block 0 are exercised
+
+
+@pytest.mark.parametrize("slices,lanes", [(4, 2), (7, 3), (2, 1)])
+def test_sliced_pipeline_does_not_change_the_archive(emu_lib, tmp_path, slices, lanes):
+    # a batch cut into slices (front end of slice k+1 overlapping the device work of slice k) yields the same blocks
+    import fastore_amd
+    for name, paired, flags in manifest()[:2]:
+        with fastore_amd.Packer(lib=emu_lib, host_threads=4, pipeline_slices=slices, pipeline_lanes=lanes, **knobs_from_flags(flags)) as p:
+            p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / "o"))
+        assert_same_archive(str(tmp_path / "o"), os.path.join(GOLDEN, name + ".ref"))
+
+
+def test_host_build_of_the_qvz_core_matches_reference_vectors(emu_lib):
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import fastore_amd, qvz_inputs
+    with fastore_amd.Packer(lib=emu_lib) as p:
+        for name in qvz_inputs.CASES:
+            lens, quals = qvz_inputs.reads_case(name)
+            got = p.qvz_encode(qvz_inputs.footer_for(name), [(lens, quals)])[0]
+            assert got == open(os.path.join(GOLDEN, "vectors", name + ".out"), "rb").read(), name
+        with pytest.raises(fastore_amd.FastoreError):
+            p.qvz_encode(qvz_inputs.qvz_footer()[:500], [(lens, quals)])
 
 
 def test_missing_input_is_an_error(emu_lib, tmp_path):

@@ -7,7 +7,11 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import MODELS, REF_DRIVER, VECTORS, oracle_ppmd, oracle_rc
+from conftest import GOLDEN, MODELS, REF_DRIVER, VECTORS, oracle_ppmd, oracle_qvz, oracle_rc
+
+import sys
+sys.path.insert(0, GOLDEN)
+import qvz_inputs
 
 PPMD_VECTORS = sorted(f[:-3] for f in os.listdir(VECTORS) if f.startswith("ppmd_") and f.endswith(".in"))
 RC_VECTORS = sorted(f[:-3] for f in os.listdir(VECTORS) if f.startswith("rc_") and f.endswith(".in") and f != "rc_empty.in")
@@ -25,6 +29,23 @@ def test_rc_oracle_matches_reference_vector(oracle, name):
     pairs = open(os.path.join(VECTORS, name + ".in"), "rb").read()
     want = open(os.path.join(VECTORS, name + ".out"), "rb").read()
     assert oracle_rc(oracle, name[3:], pairs) == want
+
+
+@pytest.mark.parametrize("name", qvz_inputs.CASES)
+def test_qvz_oracle_matches_reference_vector(oracle, name):
+    # vectors: the reference's ReadCodebook + choose_quantizer + WELL + QVZEncoder on these seeded reads (ref_driver qvz)
+    lens, quals = qvz_inputs.reads_case(name)
+    want = open(os.path.join(VECTORS, name + ".out"), "rb").read()
+    assert oracle_qvz(oracle, qvz_inputs.footer_for(name), lens, quals) == want
+
+
+def test_qvz_oracle_rejects_truncated_codebook(oracle):
+    import ctypes
+    oracle.fso_qvz_footer_size.restype = ctypes.c_long
+    f = qvz_inputs.qvz_footer()
+    size = oracle.fso_qvz_footer_size(f, len(f))
+    assert 132 < size <= len(f)
+    assert oracle.fso_qvz_footer_size(f, size - 1) == -1
 
 
 def test_rc_empty_stream_is_eight_flush_bytes(oracle):

@@ -16,7 +16,7 @@ def quality(n):
 base = quality(int(sys.argv[1]) if len(sys.argv) > 1 else 300000)
 with fastore_amd.Packer(device_id=0, max_waves=int(sys.argv[2]) if len(sys.argv) > 2 else 0) as p:
     p.ppmd_encode([base[:1000]])
-    for copies in (1, 600, 3000, 6144, 12288):
+    for copies in [int(c) for c in os.environ.get("COPIES", "1,600,3000,6144,12288").split(",")]:
         p.reset_stats(); t = time.perf_counter(); out = p.ppmd_encode([base] * copies); dt = time.perf_counter() - t
         st = p.stats()
         print("copies %5d  len %d -> %d  kernel %.1f ms  per-symbol(one stream) %.2f us  aggregate %.1f Msym/s  wall %.2f s" % (

@@ -9,10 +9,5 @@ mkdir -p gpurun_out
 python3 bench.py --steps 2 --warmup 1 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_stats.err
 python3 tools/pmc_summary.py stats gpurun_out/${tag}_stats > gpurun_out/${tag}_kernel_stats.json
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d gpurun_out/${tag}_pmc_$c -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/${tag}_pmc_$c.json 2> gpurun_out/${tag}_pmc_$c.err
-  python3 tools/pmc_summary.py pmc gpurun_out/${tag}_pmc_$c > gpurun_out/${tag}_pmc_${c}_summary.json
-  rm -rf gpurun_out/${tag}_pmc_$c
-done
-find gpurun_out/${tag}_stats -name "*_kernel_trace.csv" -delete
 cat gpurun_out/${tag}_bench.json
+exec bash tools/pmc_passes.sh "$tag"
