@@ -98,7 +98,9 @@ def main():
     outs = [os.path.join(args.work, "out_r%d_%02d" % (rank, i)) for i in range(len(libs))]
 
     import fastore_amd
-    packer = fastore_amd.Packer(device_id=local if world > 1 else 0)
+    # FASTORE_AMD_LIB: A/B runs of alternative builds of the library (kernel experiments); default = the in-tree build
+    alt = os.environ.get("FASTORE_AMD_LIB")
+    packer = fastore_amd.Packer(device_id=local if world > 1 else 0, lib=fastore_amd.load_library(alt) if alt else None)
 
     def step():
         packer.pack_files(ins, outs)
@@ -125,6 +127,12 @@ def main():
         launches = max(1, st["kernel_launches"])
         avg_launch_s = st["encode_kernel_ms"] / 1e3 / launches
         achieved = st["algorithmic_bytes"] / launches / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # HBM traffic of the dominant kernel: PMC passes cannot run inside this process; the committed summary of the
+        # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command is reported per launch
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tf) and args.libs == 10 and args.reads_per_lib == 1_000_000:
+            traffic = json.load(open(tf))["hbm_bytes_per_step"] / (launches / args.steps)
         out = {
             "metric": "fastore_pack compressed MB/s (input FASTQ)", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
@@ -133,7 +141,8 @@ def main():
                                    % (len(libs), args.reads_per_lib, L, len(libs) * args.reads_per_lib / 1e6),
                        "fastq_bytes_per_gpu": fastq_bytes, "pack_flags": " ".join(PACK_FLAGS), "parallelism": "bins sharded per GPU; no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "fs_encode_streams", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic,
+                         "traffic_unit": "bytes per launch (profiles/r01_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)",
                          "avg_launch_ms": round(avg_launch_s * 1e3, 3), "launches": launches,
                          "algorithmic_bytes_per_launch": st["algorithmic_bytes"] // launches,
                          "ppmd_symbols_per_s": round(st["ppmd_symbols"] / (st["encode_kernel_ms"] / 1e3), 1) if st["encode_kernel_ms"] else None},

@@ -13,13 +13,18 @@ struct BatchTiming {
     uint64_t h2d_bytes = 0, d2h_bytes = 0;
 };
 
+// What the lanes of one GPU share: the arena pool and its slot rings (see engine.hip).
+struct Pool;
+
+// One engine lane = one HIP stream with its own buffers.  Lanes of a GPU share the arena pool, so their kernels can
+// be in flight together (the host front end of the next slice overlaps the device work of the previous ones).
 struct Device {
     int deviceId, cus;
     char name[64];
     char err[256];
     void* stream;
     void* ev[4];
-    uint8_t* arenas; uint64_t arenaPoolBytes; uint32_t* queueHead; uint32_t nWaves /* resident-wave cap */;
+    Pool* pool; uint32_t* queueHead; uint32_t nWaves /* resident-wave cap */;
     uint8_t* dIn; size_t capIn;
     uint8_t* dScratch; size_t capScratch;
     void* dItems; size_t capItems;
@@ -33,7 +38,8 @@ struct Device {
 
 int device_count();
 int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size_t errLen);
-void device_destroy(Device* dev);
+int lane_create(Device* first, Device** out, char* err, size_t errLen);      // another lane on the GPU (and pool) of `first`
+void device_destroy(Device* dev);                                            // a lane; the pool goes with its last lane
 uint8_t* staging_buffer(Device* dev, size_t bytes);     // grow-only pinned host buffer for the batch input
 int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,
                        std::vector<uint8_t>& raw, std::vector<uint32_t>& sizes, BatchTiming* timing);

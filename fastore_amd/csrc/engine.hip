@@ -18,6 +18,8 @@
 #include <stdlib.h>
 #include <time.h>
 #include <algorithm>
+#include <mutex>
+#include <shared_mutex>
 #include <vector>
 
 #include "device_types.h"
@@ -36,12 +38,42 @@ constexpr uint64_t kGuard = 64ull << 10;
 // launch ends with its longest stream -- so 3 waves/SIMD (3072 waves, no register spills) beats 6.
 constexpr uint32_t kWavesPerSimd = 3;
 
+// Arena slots.  The pool is cut into kXcc partitions of `slotsPerXcc` arenas; a wave takes a slot of the XCD it runs
+// on from that XCD's ring and returns it when its queue is empty.  Slots never migrate between XCDs: the per-XCD L2s
+// are not coherent with each other, so an arena reused from another XCD inside one cache epoch could be clobbered by
+// a late write-back of the previous owner's dead lines.  Ring entry = ticket << 32 | slot (Vyukov-style tickets):
+// pop k of a ring reads entry k % S once its ticket is k; push k writes entry k % S with ticket k + S.  A pop only
+// waits while more workgroups are resident on the XCD than it has slots (several launches in flight with a small
+// --max-waves); the holders do not depend on the waiters, so every wave reaches its exit.
+constexpr uint32_t kXcc = 8;
+struct SlotRing { uint32_t head; uint32_t pad0[15]; uint32_t tail; uint32_t pad1[15]; };
+
+__device__ __forceinline__ uint32_t xcc_id()
+{ uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & (kXcc - 1u); }
+
 __global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(const StreamItem* __restrict__ items, const uint32_t* __restrict__ order,
                                                         uint32_t nItems, const uint8_t* in, uint8_t* out, uint32_t* outSizes,
-                                                        uint32_t* restarts, uint8_t* arenas, uint64_t arenaStride, uint32_t* queueHead, uint32_t longLen)
+                                                        uint32_t* restarts, uint8_t* arenas, uint64_t arenaStride, uint32_t* queueHead, uint32_t longLen,
+                                                        SlotRing* rings, unsigned long long* ringEntries, uint32_t slotsPerXcc)
 {
     __shared__ fsppmd::Shared sh;
-    uint8_t* arena = arenas + (uint64_t)blockIdx.x * arenaStride;
+    // rings == nullptr: exclusive launch (no other kernel in flight), one arena per workgroup index
+    uint32_t slot = blockIdx.x, xcc = 0;
+    if (rings) {
+        xcc = xcc_id();
+        uint32_t s = 0;
+        if (threadIdx.x == 0) {
+            const uint32_t t = atomicAdd(&rings[xcc].head, 1u);
+            unsigned long long* e = ringEntries + (uint64_t)xcc * slotsPerXcc + t % slotsPerXcc;
+            for (;;) {
+                const unsigned long long v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(v >> 32) == t) { s = (uint32_t)v; break; }
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
+        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
+    }
+    uint8_t* arena = arenas + (uint64_t)slot * arenaStride;
     for (;;) {
         uint32_t q = 0;
         if (threadIdx.x == 0) q = atomicAdd(queueHead, 1u);
@@ -70,6 +102,11 @@ __global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(const Str
         }
         if (threadIdx.x == 0) { outSizes[it] = size; restarts[it] = rs; }
         __syncthreads();
+    }
+    if (rings && threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(&rings[xcc].tail, 1u);
+        unsigned long long* e = ringEntries + (uint64_t)xcc * slotsPerXcc + t % slotsPerXcc;
+        __hip_atomic_store(e, ((unsigned long long)(t + slotsPerXcc) << 32) | slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -139,15 +176,41 @@ int device_count()
 
 static double wallMs() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; }
 
+// Shared by the lanes of one GPU.  `gate`: launches that take their arenas from the rings hold it shared; a launch
+// whose coder table does not fit a slot (the sparse <256,1> read-id model of archives with > 16 header fields) runs
+// alone, with one arena per workgroup index carved at its own stride.
+struct Pool {
+    uint8_t* arenas = nullptr; uint64_t bytes = 0, slotStride = 0;
+    uint32_t slotsPerXcc = 0;
+    SlotRing* rings = nullptr; unsigned long long* entries = nullptr;
+    std::shared_mutex gate;
+    std::mutex m; int lanes = 0;
+};
+
+static int lane_init(Device* dev, char* err, size_t errLen)
+{
+    hipError_t e;
+    auto fail = [&](const char* what, hipError_t c) { snprintf(err, errLen, "%s: %s", what, hipGetErrorString(c)); return -1; };
+    if ((e = hipSetDevice(dev->deviceId)) != hipSuccess) return fail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags((hipStream_t*)&dev->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipMalloc((void**)&dev->queueHead, 64)) != hipSuccess) return fail("hipMalloc(queue)", e);
+    for (int i = 0; i < 4; ++i) if ((e = hipEventCreate((hipEvent_t*)&dev->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
+    return 0;
+}
+
 int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size_t errLen)
 {
     const double tc0 = wallMs();
     Device* dev = new Device();
     memset(dev, 0, sizeof *dev);
-    *out = dev;
+    *out = nullptr;
+    Pool* pool = new Pool();
     auto fail = [&](const char* what, hipError_t e) {
         snprintf(err, errLen, "%s: %s", what, hipGetErrorString(e));
-        delete dev; *out = nullptr; return -1;
+        if (pool->arenas) (void)hipFree(pool->arenas);
+        if (pool->rings) (void)hipFree(pool->rings);
+        if (pool->entries) (void)hipFree(pool->entries);
+        delete pool; delete dev; return -1;
     };
     hipError_t e;
     if ((e = hipSetDevice(deviceId)) != hipSuccess) return fail("hipSetDevice", e);
@@ -156,23 +219,44 @@ int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size
     dev->deviceId = deviceId;
     dev->cus = prop.multiProcessorCount;
     snprintf(dev->name, sizeof dev->name, "%s", prop.gcnArchName);
-    if ((e = hipStreamCreate((hipStream_t*)&dev->stream)) != hipSuccess) return fail("hipStreamCreate", e);
     size_t freeB = 0, totalB = 0;
     if ((e = hipMemGetInfo(&freeB, &totalB)) != hipSuccess) return fail("hipMemGetInfo", e);
-    // One arena per resident wavefront (kWavesPerSimd x 4 SIMDs per CU), carved per launch out of one pool that takes
-    // at most 55 % of the free HBM; the stride of a launch is the largest table/heap any of its streams needs.
-    uint32_t waves = maxWaves ? maxWaves : (uint32_t)dev->cus * 4u * kWavesPerSimd;
-    const uint64_t minStride = fsppmd::ARENA_BYTES + kGuard;
-    uint64_t pool = (uint64_t)waves * minStride;
+    // One arena slot per resident wavefront (kWavesPerSimd x 4 SIMDs per CU), in kXcc equal partitions; the pool takes
+    // at most 55 % of the free HBM.
+    const uint32_t waves = maxWaves ? maxWaves : (uint32_t)dev->cus * 4u * kWavesPerSimd;
+    const uint64_t stride = ((fsppmd::ARENA_BYTES + kGuard) + 4095ull) & ~4095ull;
+    uint32_t perXcc = (waves + kXcc - 1) / kXcc;
     const uint64_t budget = (uint64_t)((double)freeB * 0.55);
-    if (pool > budget) pool = budget;
-    if (pool < (33ull << 20)) { snprintf(err, errLen, "not enough device memory for one coder arena"); delete dev; *out = nullptr; return -1; }
-    dev->nWaves = waves; dev->arenaPoolBytes = pool;
-    if ((e = hipMalloc((void**)&dev->arenas, pool)) != hipSuccess) return fail("hipMalloc(arenas)", e);
-    if ((e = hipMalloc((void**)&dev->queueHead, 64)) != hipSuccess) return fail("hipMalloc(queue)", e);
-    if ((e = hipEventCreate((hipEvent_t*)&dev->ev[0])) != hipSuccess) return fail("hipEventCreate", e);
-    for (int i = 1; i < 4; ++i) (void)hipEventCreate((hipEvent_t*)&dev->ev[i]);
-    if (getenv("FS_TRACE")) fprintf(stderr, "[trace] device_create: up to %u waves, %.1f GB arena pool, %.1f ms\n", waves, pool / 1e9, wallMs() - tc0);
+    while (perXcc > 1 && (uint64_t)perXcc * kXcc * stride > budget) --perXcc;
+    pool->slotStride = stride; pool->slotsPerXcc = perXcc; pool->bytes = (uint64_t)perXcc * kXcc * stride;
+    if (pool->bytes > budget) { snprintf(err, errLen, "not enough device memory for the coder arenas"); delete pool; delete dev; return -1; }
+    dev->nWaves = waves; dev->pool = pool;
+    if ((e = hipMalloc((void**)&pool->arenas, pool->bytes)) != hipSuccess) return fail("hipMalloc(arenas)", e);
+    if ((e = hipMalloc((void**)&pool->rings, sizeof(SlotRing) * kXcc)) != hipSuccess) return fail("hipMalloc(rings)", e);
+    if ((e = hipMalloc((void**)&pool->entries, 8ull * kXcc * perXcc)) != hipSuccess) return fail("hipMalloc(ring entries)", e);
+    {   // every ring full: entry k holds ticket k and its own slot
+        std::vector<unsigned long long> init((size_t)kXcc * perXcc);
+        for (uint32_t x = 0; x < kXcc; ++x) for (uint32_t k = 0; k < perXcc; ++k) init[(size_t)x * perXcc + k] = ((unsigned long long)k << 32) | (x * perXcc + k);
+        if ((e = hipMemcpy(pool->entries, init.data(), init.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(ring entries)", e);
+        if ((e = hipMemset(pool->rings, 0, sizeof(SlotRing) * kXcc)) != hipSuccess) return fail("hipMemset(rings)", e);
+    }
+    if (lane_init(dev, err, errLen) != 0) { (void)hipFree(pool->arenas); (void)hipFree(pool->rings); (void)hipFree(pool->entries); delete pool; delete dev; return -1; }
+    pool->lanes = 1;
+    *out = dev;
+    if (getenv("FS_TRACE")) fprintf(stderr, "[trace] device_create: up to %u waves, %u slots per XCD, %.1f GB arena pool, %.1f ms\n", waves, perXcc, pool->bytes / 1e9, wallMs() - tc0);
+    return 0;
+}
+
+int lane_create(Device* first, Device** out, char* err, size_t errLen)
+{
+    Device* dev = new Device();
+    memset(dev, 0, sizeof *dev);
+    *out = nullptr;
+    dev->deviceId = first->deviceId; dev->cus = first->cus; dev->nWaves = first->nWaves; dev->pool = first->pool;
+    memcpy(dev->name, first->name, sizeof dev->name);
+    if (lane_init(dev, err, errLen) != 0) { delete dev; return -1; }
+    { std::lock_guard<std::mutex> g(dev->pool->m); dev->pool->lanes++; }
+    *out = dev;
     return 0;
 }
 
@@ -180,11 +264,17 @@ void device_destroy(Device* dev)
 {
     if (!dev) return;
     (void)hipSetDevice(dev->deviceId);
-    void* ptrs[] = {dev->arenas, dev->queueHead, dev->dIn, dev->dScratch, dev->dItems, dev->dOrder, dev->dSizes, dev->dRestarts, dev->dPlans, dev->dBlocks};
+    if (dev->stream) (void)hipStreamSynchronize((hipStream_t)dev->stream);
+    void* ptrs[] = {dev->queueHead, dev->dIn, dev->dScratch, dev->dItems, dev->dOrder, dev->dSizes, dev->dRestarts, dev->dPlans, dev->dBlocks};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (dev->hStage) (void)hipHostFree(dev->hStage);
     for (int i = 0; i < 4; ++i) if (dev->ev[i]) (void)hipEventDestroy((hipEvent_t)dev->ev[i]);
     if (dev->stream) (void)hipStreamDestroy((hipStream_t)dev->stream);
+    if (Pool* pool = dev->pool) {
+        bool last;
+        { std::lock_guard<std::mutex> g(pool->m); last = --pool->lanes == 0; }
+        if (last) { (void)hipFree(pool->arenas); (void)hipFree(pool->rings); (void)hipFree(pool->entries); delete pool; }
+    }
     delete dev;
 }
 
@@ -248,16 +338,24 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         if (it.kind == KIND_QVZ) need = std::max<uint64_t>(need, qvzImageBytes(it));
         else if (it.kind != KIND_PPMD) need = std::max<uint64_t>(need, fsrc::model_table_bytes(it.kind - KIND_RC_BASE));
     }
-    const uint64_t stride = ((need + kGuard) + 4095ull) & ~4095ull;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nItems, dev->nWaves), dev->arenaPoolBytes / stride);
+    Pool* pool = dev->pool;
+    const bool exclusive = ((need + kGuard + 4095ull) & ~4095ull) > pool->slotStride;      // table larger than an arena slot
+    const uint64_t stride = exclusive ? ((need + kGuard) + 4095ull) & ~4095ull : pool->slotStride;
+    const uint32_t grid = exclusive ? (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nItems, dev->nWaves), pool->bytes / stride)
+                                    : std::min<uint32_t>(nItems, dev->nWaves);
     uint32_t maxLen = 0;
     for (const auto& it : items) if (it.kind == KIND_PPMD) maxLen = std::max(maxLen, it.in_len);
     const uint32_t longLen = std::max(1u, maxLen / 2);                     // "long" = at least half of the longest PPMd stream
     if (grid == 0) { snprintf(dev->err, sizeof dev->err, "arena pool too small for a %llu-byte coder table", (unsigned long long)need); return -1; }
+    // the gate is held until this launch has drained: exclusive launches never overlap ring launches
+    std::shared_lock<std::shared_mutex> shared(pool->gate, std::defer_lock);
+    std::unique_lock<std::shared_mutex> alone(pool->gate, std::defer_lock);
+    if (exclusive) alone.lock(); else shared.lock();
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[0], st));
     hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, (const StreamItem*)dev->dItems, (const uint32_t*)dev->dOrder,
                        nItems, (const uint8_t*)dev->dIn, (uint8_t*)dev->dScratch, (uint32_t*)dev->dSizes, (uint32_t*)dev->dRestarts,
-                       (uint8_t*)dev->arenas, stride, (uint32_t*)dev->queueHead, longLen);
+                       pool->arenas, stride, (uint32_t*)dev->queueHead, longLen,
+                       exclusive ? (SlotRing*)nullptr : pool->rings, exclusive ? (unsigned long long*)nullptr : pool->entries, pool->slotsPerXcc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));
     if (getenv("FS_TRACE")) { HIP_TRY(hipStreamSynchronize(st)); }

@@ -148,7 +148,7 @@ fsengine::Device* Context::lane(uint32_t i)
     if (lanes.empty()) lanes.push_back(dev);
     while (lanes.size() <= i) {
         fsengine::Device* d = nullptr; char e[256] = {0};
-        if (fsengine::device_create(&d, cfg.device_id, cfg.max_waves, e, sizeof e) != 0) {
+        if (fsengine::lane_create(dev, &d, e, sizeof e) != 0) {
             if (getenv("FS_TRACE")) fprintf(stderr, "[trace] no further engine lane: %s\n", e);
             return nullptr;
         }
@@ -198,7 +198,7 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
     }
     cut.push_back(nBins);
     const uint32_t nSlices = (uint32_t)cut.size() - 1;
-    const uint32_t wantLanes = nSlices > 1 ? std::min<uint32_t>(nSlices, cfg.pipeline_lanes ? cfg.pipeline_lanes : 3) : 1;
+    const uint32_t wantLanes = nSlices > 1 ? std::min<uint32_t>(nSlices, cfg.pipeline_lanes ? cfg.pipeline_lanes : nSlices) : 1;
     uint32_t nLanes = 1;
     while (nLanes < wantLanes && lane(nLanes)) ++nLanes;
     (void)lane(0);

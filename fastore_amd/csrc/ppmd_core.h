@@ -106,7 +106,7 @@ struct Coder {
 #define BL(i) (1u + HEADS_OFF + 12u * (uint32_t)(i))
 
 FS_DEV void state_store(Coder& m, uint32_t s, uint32_t symfreq, uint32_t succ)
-{ fs_st16(HP(s), symfreq); fs_st32h(HP(s) + 2, succ); }
+{ fs_st48(HP(s), symfreq, succ & 0xFFFFu, succ >> 16); }
 FS_DEV void state_swap(Coder& m, uint32_t a, uint32_t b)
 {
     uint32_t a0 = S_SYMFREQ(a), a1 = S_SUCC(a), b0 = S_SYMFREQ(b), b1 = S_SUCC(b);
@@ -118,9 +118,16 @@ FS_DEV void state_cpy(Coder& m, uint32_t d, uint32_t s) { state_store(m, d, S_SY
 struct Ctx { uint32_t ns, flags, sf, w1 /* iStats, or oneState.iSuccessor */, suff, oneSym, oneFreq; };
 FS_DEV Ctx ctx_load(Coder& m, uint32_t c)
 {
+    FS_CNT(g_ld[0]);
     fs_cgptr32 q = (fs_cgptr32)HP(c);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FS_LD1)
+    uint32_t w = 0; const uint32_t l = (uint32_t)FS_LANE();
+    if (l < 3u) w = q[l];
+    const uint32_t a = fs_readlane(w, 0), b = fs_readlane(w, 1), d = fs_readlane(w, 2);
+#else
     uint32_t a = q[0], b = q[1], d = q[2];
     a = FS_UNI(a); b = FS_UNI(b); d = FS_UNI(d);
+#endif
     Ctx r; r.ns = a & 0xFFu; r.flags = (a >> 8) & 0xFFu; r.sf = a >> 16; r.w1 = b; r.suff = d; r.oneSym = (a >> 16) & 0xFFu; r.oneFreq = a >> 24;
     return r;
 }
@@ -128,9 +135,16 @@ FS_DEV Ctx ctx_load(Coder& m, uint32_t c)
 struct St { uint32_t sym, freq, succ; };
 FS_DEV St st_load(Coder& m, uint32_t s)
 {
+    FS_CNT(g_ld[1]);
     fs_cgptr16 q = (fs_cgptr16)HP(s);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FS_LD1)
+    uint32_t w = 0; const uint32_t l = (uint32_t)FS_LANE();
+    if (l < 3u) w = q[l];                                   // lane i fetches word i: one instruction
+    const uint32_t a = fs_readlane(w, 0), b = fs_readlane(w, 1), c = fs_readlane(w, 2);
+#else
     uint32_t a = q[0], b = q[1], c = q[2];
     a = FS_UNI(a); b = FS_UNI(b); c = FS_UNI(c);
+#endif
     St r; r.sym = a & 0xFFu; r.freq = a >> 8; r.succ = b | (c << 16);
     return r;
 }
@@ -246,7 +260,7 @@ FS_DEV void FreeUnits(Coder& m, uint32_t ptr, uint32_t NU)
 { uint32_t indx = kUnits2Indx[NU - 1]; blk_insert(m, BL(indx), ptr, kIndx2Units[indx]); }
 
 // ---------------- range coder ----------------
-FS_DEV void put_byte(Coder& m, uint32_t c) { if (m.outPos < m.outCap) m.out[m.outPos] = (uint8_t)c; m.outPos += (m.outPos < m.outCap); }
+FS_DEV void put_byte(Coder& m, uint32_t c) { if (m.outPos < m.outCap) fs_st8(m.out + m.outPos, c); m.outPos += (m.outPos < m.outCap); }
 FS_DEV void rc_normalize(Coder& m)
 {
     while ((m.low ^ (m.low + m.range)) < TOP || (m.range < BOT && ((m.range = (0u - m.low) & (BOT - 1)), true))) {
@@ -301,6 +315,7 @@ FS_DEV void RestoreModelRare(Coder& m) { m.pText = 1u; StartModelRare(m); m.EscC
 struct LaneStates { uint32_t sf, succ; bool valid; };
 FS_DEV LaneStates lane_states(Coder& m, uint32_t stats, uint32_t ns, uint32_t base)
 {
+    FS_CNT(g_ld[2]);
     LaneStates r; const uint32_t i = base + (uint32_t)FS_LANE();
     r.valid = i <= ns; r.sf = 0; r.succ = 0;
     if (r.valid) { fs_cgptr16 q = (fs_cgptr16)HP(stats + 6u * i); const uint32_t a = q[0], b = q[1], c = q[2]; r.sf = a; r.succ = b | (c << 16); }
@@ -330,6 +345,7 @@ FS_DEV Hit find_in(Coder& m, const Ctx& pc, uint32_t sym)
 // CreateSuccessors (Model.cpp:282-337).  p/pSucc: state to start from in the suffix of pc (0 = none) and its successor.
 FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc, uint32_t pc, uint32_t fsSym, uint32_t fsSucc)
 {
+    FS_CNT(g_path[9]);
     const uint32_t iUpBranch = fsSucc;
     uint32_t ps[MAX_ORDER + 1]; uint32_t pps = 0;
     uint32_t cf, s0, tmp;
@@ -386,6 +402,7 @@ FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc
 // ReduceOrder (Model.cpp:209-243)
 FS_DEV uint32_t ReduceOrder(Coder& m, uint32_t p, uint32_t pSucc, uint32_t pc)
 {
+    FS_CNT(g_path[10]);
     uint32_t tmp; const uint32_t pc1 = pc;
     const uint32_t iUpBranch = m.pText; S_SUCC_SET(m.FoundState, iUpBranch);
     const uint32_t sym = m.fsSym; m.OrderFall++;
@@ -419,6 +436,7 @@ FS_DEV uint32_t ReduceOrder(Coder& m, uint32_t p, uint32_t pSucc, uint32_t pc)
 
 FS_DEV_NOINLINE void rescale(Coder& m, uint32_t c)
 {
+    FS_CNT(g_path[11]);
     uint32_t f0, sf, EscFreq, a = (m.OrderFall != 0), i = C_NS(c);
     uint32_t p1, p;
     C_FLAGS_SET(c, C_FLAGS(c) & 0x14u);
@@ -468,6 +486,7 @@ FS_DEV_NOINLINE void rescale(Coder& m, uint32_t c)
 
 FS_DEV void UpdateModel(Coder& m, uint32_t MinContext)
 {
+    FS_CNT(g_path[8]);
     const uint32_t FSymbol = m.fsSym, FFreq = m.fsFreq;
     uint32_t iSuccessor, iFSuccessor = m.fsSucc;
     uint32_t ns1, ns, cf, sf, s0, pc, p = 0, pSucc = 0;
@@ -505,6 +524,7 @@ FS_DEV void UpdateModel(Coder& m, uint32_t MinContext)
     const uint32_t Flag = 0x08u * (FSymbol >= 0x40);
     for (; pc != MinContext; pc = C_SUFF(pc)) {
         uint32_t summ;
+        FS_CNT(g_path[12]);
         if ((ns1 = C_NS(pc)) != 0) {
             if ((ns1 & 1) != 0) {
                 p = ExpandUnits(m, C_STATS(pc), (ns1 + 1) >> 1);
@@ -701,8 +721,9 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
             pos++;
         }
         Ctx mc = ctx_load(m, MinContext);
-        if (mc.ns) { encodeSymbol1(m, MinContext, mc, c); rc_encode(m); }
-        else encodeBinSymbol(m, MinContext, mc, c);
+        FS_CNT(g_path[0]);
+        if (mc.ns) { FS_CNT(g_path[2]); encodeSymbol1(m, MinContext, mc, c); rc_encode(m); if (m.FoundState) { if (m.rLow == 0) FS_CNT(g_path[3]); else FS_CNT(g_path[4]); } }
+        else { FS_CNT(g_path[1]); encodeBinSymbol(m, MinContext, mc, c); }
         bool stop = false;
         while (!m.FoundState) {
             rc_normalize(m);
@@ -711,11 +732,13 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
                 m.OrderFall++; MinContext = mc.suff; mc = ctx_load(m, MinContext);
             } while (mc.ns == m.NumMasked);
             if (stop) break;
+            FS_CNT(g_path[5]);
             encodeSymbol2(m, MinContext, mc, c); rc_encode(m);
+            if (m.FoundState) FS_CNT(g_path[6]);
         }
         if (stop) break;
         const uint32_t succ = m.fsSucc;
-        if (!m.OrderFall && succ >= m.UnitsStart) m.MaxContext = succ;
+        if (!m.OrderFall && succ >= m.UnitsStart) { FS_CNT(g_path[7]); m.MaxContext = succ; }
         else { UpdateModel(m, MinContext); if (m.EscCount == 0) clear_mask(m); }
         rc_normalize(m); MinContext = m.MaxContext;
     }

@@ -23,7 +23,7 @@ struct Enc {
     fs_gptr out; uint32_t cap, pos;
 };
 
-FS_DEV void put(Enc& e, uint32_t b) { if (e.pos < e.cap) e.out[e.pos] = (uint8_t)b; e.pos++; }
+FS_DEV void put(Enc& e, uint32_t b) { if (e.pos < e.cap) fs_st8(e.out + e.pos, b); e.pos++; }
 
 FS_DEV void encode_freq(Enc& e, uint32_t symFreq, uint32_t cumFreq, uint32_t total)
 {
@@ -110,15 +110,26 @@ FS_DEV uint32_t encode_stream(fs_gptr table /*16-byte aligned, table_bytes()*/, 
             lo = FS_UNI(wave_bcast(myLo, owner)); f = FS_UNI(wave_bcast(myF, owner)); acc = FS_UNI(acc);
             if (lane == owner) st[sym] = (uint16_t)(f + 8);      // lanes only ever touch their own 4 symbols: no sync
         } else {
+            // the model's A statistics: lane j fetches statistic j (one instruction), broadcast to scalars
             uint32_t v[A]; acc = 0;
-            for (uint32_t j = 0; j < A; ++j) { v[j] = FS_UNI(st[j]); acc += v[j]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t mine = (uint32_t)FS_LANE() < A ? (uint32_t)st[FS_LANE()] : 0u;
+            for (uint32_t j = 0; j < A; ++j) { v[j] = fs_readlane(mine, j); acc += v[j]; }
+            if (acc >= limit) {
+                acc = 0;
+                for (uint32_t j = 0; j < A; ++j) { v[j] -= v[j] >> 1; acc += v[j]; }
+                if ((uint32_t)FS_LANE() < A) st[FS_LANE()] = (uint16_t)(mine - (mine >> 1));
+            }
+#else
+            for (uint32_t j = 0; j < A; ++j) { v[j] = st[j]; acc += v[j]; }
             if (acc >= limit) {
                 acc = 0;
                 for (uint32_t j = 0; j < A; ++j) { v[j] -= v[j] >> 1; st[j] = (uint16_t)v[j]; acc += v[j]; }
             }
+#endif
             lo = 0; f = 0;
             for (uint32_t j = 0; j < A; ++j) { if (j < sym) lo += v[j]; if (j == sym) f = v[j]; }
-            st[sym] = (uint16_t)(f + 8);
+            fs_st16((fs_gptr)(st + sym), f + 8);
         }
         encode_freq(e, f, lo, acc);
         hash = (hash << BITS) | sym;

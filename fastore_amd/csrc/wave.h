@@ -37,6 +37,13 @@
   #define FS_WAVE_SYNC() ((void)0)
 #endif
 
+// host-only event counters for design studies (tools/ppmd_paths.cpp); compiled out everywhere else
+#if defined(FS_COUNTERS) && !defined(__HIP_DEVICE_COMPILE__)
+  #define FS_CNT(x) (++(x))
+#else
+  #define FS_CNT(x) ((void)0)
+#endif
+
 typedef FS_GLOBAL uint8_t* fs_gptr;                 // device: global address space; host: plain pointer
 typedef const FS_GLOBAL uint8_t* fs_cgptr;
 typedef const FS_GLOBAL uint16_t* fs_cgptr16;
@@ -45,15 +52,57 @@ typedef const FS_GLOBAL uint32_t* fs_cgptr32;
 typedef FS_GLOBAL uint32_t* fs_gptr32;
 
 // ---- uniform little-endian accessors on a byte heap (2-byte aligned addresses) ----
-FS_DEV uint32_t fs_ld8(fs_cgptr p) { return FS_UNI(*p); }
-FS_DEV uint32_t fs_ld16(fs_cgptr p) { return FS_UNI(*(fs_cgptr16)p); }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FS_LD1)
+// experiment: uniform loads issued by lane 0 only (one quad through the texture-address unit instead of sixteen)
+FS_DEV uint32_t fs_ld8(fs_cgptr p) { uint32_t v = 0; if (FS_LANE() == 0) v = *p; return FS_UNI(v); }
+FS_DEV uint32_t fs_ld16(fs_cgptr p) { uint32_t v = 0; if (FS_LANE() == 0) v = *(fs_cgptr16)p; return FS_UNI(v); }
+FS_DEV uint32_t fs_ld32h(fs_cgptr p)
+{
+    uint32_t v = 0; const uint32_t l = (uint32_t)FS_LANE();
+    if (l < 2u) v = ((fs_cgptr16)p)[l];
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | ((uint32_t)__builtin_amdgcn_readlane((int)v, 1) << 16);
+}
+FS_DEV uint32_t fs_ld32(fs_cgptr p) { uint32_t v = 0; if (FS_LANE() == 0) v = *(fs_cgptr32)p; return FS_UNI(v); }
+#else
+FS_DEV uint32_t fs_ld8(fs_cgptr p) { FS_CNT(g_ld[3]); return FS_UNI(*p); }
+FS_DEV uint32_t fs_ld16(fs_cgptr p) { FS_CNT(g_ld[4]); return FS_UNI(*(fs_cgptr16)p); }
 FS_DEV uint32_t fs_ld32h(fs_cgptr p)   // 32-bit value at a 2-byte aligned address
-{ return FS_UNI((uint32_t)((fs_cgptr16)p)[0] | ((uint32_t)((fs_cgptr16)p)[1] << 16)); }
-FS_DEV uint32_t fs_ld32(fs_cgptr p) { return FS_UNI(*(fs_cgptr32)p); }
-FS_DEV void fs_st8(fs_gptr p, uint32_t v) { *p = (uint8_t)v; }
-FS_DEV void fs_st16(fs_gptr p, uint32_t v) { *(fs_gptr16)p = (uint16_t)v; }
-FS_DEV void fs_st32h(fs_gptr p, uint32_t v) { ((fs_gptr16)p)[0] = (uint16_t)v; ((fs_gptr16)p)[1] = (uint16_t)(v >> 16); }
-FS_DEV void fs_st32(fs_gptr p, uint32_t v) { *(fs_gptr32)p = v; }
+{ FS_CNT(g_ld[6]); return FS_UNI((uint32_t)((fs_cgptr16)p)[0] | ((uint32_t)((fs_cgptr16)p)[1] << 16)); }
+FS_DEV uint32_t fs_ld32(fs_cgptr p) { FS_CNT(g_ld[5]); return FS_UNI(*(fs_cgptr32)p); }
+#endif
+// Uniform stores are issued by ONE lane: a store executed by all 64 lanes to one address reaches the L2 as one write
+// request per 16-lane group (measured: 3.7 requests per store instruction, each forwarded to the fabric as a 32-byte
+// partial write), and occupies the texture-address unit for all 16 quads.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_ST1)
+  #define FS_ONE_LANE if (FS_LANE() == 0)
+#else
+  #define FS_ONE_LANE
+#endif
+FS_DEV void fs_st8(fs_gptr p, uint32_t v) { FS_CNT(g_st); FS_ONE_LANE *p = (uint8_t)v; }
+FS_DEV void fs_st16(fs_gptr p, uint32_t v) { FS_CNT(g_st); FS_ONE_LANE *(fs_gptr16)p = (uint16_t)v; }
+FS_DEV void fs_st32(fs_gptr p, uint32_t v) { FS_CNT(g_st); FS_ONE_LANE *(fs_gptr32)p = v; }
+// 32-bit value at a 2-byte aligned address: lanes 0 and 1 store one half each (one instruction)
+FS_DEV void fs_st32h(fs_gptr p, uint32_t v)
+{
+    FS_CNT(g_st);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_ST1)
+    const uint32_t l = (uint32_t)FS_LANE();
+    if (l < 2u) ((fs_gptr16)p)[l] = (uint16_t)(l ? v >> 16 : v);
+#else
+    ((fs_gptr16)p)[0] = (uint16_t)v; ((fs_gptr16)p)[1] = (uint16_t)(v >> 16);
+#endif
+}
+// three consecutive 16-bit words (a 6-byte PPMd state) in one instruction: lane i stores word i
+FS_DEV void fs_st48(fs_gptr p, uint32_t w0, uint32_t w1, uint32_t w2)
+{
+    FS_CNT(g_st);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_ST1)
+    const uint32_t l = (uint32_t)FS_LANE();
+    if (l < 3u) ((fs_gptr16)p)[l] = (uint16_t)(l == 0u ? w0 : (l == 1u ? w1 : w2));
+#else
+    ((fs_gptr16)p)[0] = (uint16_t)w0; ((fs_gptr16)p)[1] = (uint16_t)w1; ((fs_gptr16)p)[2] = (uint16_t)w2;
+#endif
+}
 
 // ---- cross-lane helpers (host build: one lane) ----
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -14,7 +14,8 @@ def quality(n):
         cur = min(40, max(2, cur + steps[i])); out[i] = cur
     return bytes(out)
 base = quality(int(sys.argv[1]) if len(sys.argv) > 1 else 300000)
-with fastore_amd.Packer(device_id=0, max_waves=int(sys.argv[2]) if len(sys.argv) > 2 else 0) as p:
+_lib = fastore_amd.load_library(os.environ['FS_LIB']) if os.environ.get('FS_LIB') else None
+with fastore_amd.Packer(lib=_lib, device_id=0, max_waves=int(sys.argv[2]) if len(sys.argv) > 2 else 0) as p:
     p.ppmd_encode([base[:1000]])
     for copies in [int(c) for c in os.environ.get("COPIES", "1,600,3000,6144,12288").split(",")]:
         p.reset_stats(); t = time.perf_counter(); out = p.ppmd_encode([base] * copies); dt = time.perf_counter() - t
