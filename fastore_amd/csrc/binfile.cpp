@@ -53,8 +53,13 @@ struct Unpacker {
         const bool plain = meta.getBit() != 0;
         const char* idxToDna = cfg.minimizer.dnaSymbolOrder;
         if (plain) {
-            for (uint32_t i = 0; i < minimPos; ++i) seq[i] = (uint8_t)idxToDna[dna.get2Bits()];
-            for (uint32_t i = minimPos + suffixLen; i < seqLen; ++i) seq[i] = (uint8_t)idxToDna[dna.get2Bits()];
+            // four bases per window read
+            auto run = [&](uint32_t from, uint32_t to) {
+                uint32_t i = from;
+                for (; i + 4 <= to; i += 4) { const uint32_t w = dna.getBits(8); seq[i] = (uint8_t)idxToDna[w >> 6]; seq[i + 1] = (uint8_t)idxToDna[(w >> 4) & 3]; seq[i + 2] = (uint8_t)idxToDna[(w >> 2) & 3]; seq[i + 3] = (uint8_t)idxToDna[w & 3]; }
+                for (; i < to; ++i) seq[i] = (uint8_t)idxToDna[dna.get2Bits()];
+            };
+            run(0, minimPos); run(minimPos + suffixLen, seqLen);
         } else {
             for (uint32_t i = 0; i < minimPos; ++i) seq[i] = (uint8_t)idxToDna[dna.getBits(3) & 7];
             for (uint32_t i = minimPos + suffixLen; i < seqLen; ++i) seq[i] = (uint8_t)idxToDna[dna.getBits(3) & 7];
@@ -66,7 +71,12 @@ struct Unpacker {
         switch (cfg.quaParams.method) {
         case MET_BINARY: for (uint32_t i = 0; i < n; ++i) q[i] = (uint8_t)(off + (qua.getBit() ? 40 : 6)); break;
         case MET_8BIN: for (uint32_t i = 0; i < n; ++i) q[i] = (uint8_t)(off + kIdxToQua8[qua.getBits(3)]); break;
-        default: for (uint32_t i = 0; i < n; ++i) q[i] = (uint8_t)(qua.getBits(6) + off); break;
+        default: {
+            uint32_t i = 0;
+            for (; i + 4 <= n; i += 4) { const uint32_t w = qua.getBits(24); q[i] = (uint8_t)((w >> 18) + off); q[i + 1] = (uint8_t)(((w >> 12) & 63) + off); q[i + 2] = (uint8_t)(((w >> 6) & 63) + off); q[i + 3] = (uint8_t)((w & 63) + off); }
+            for (; i < n; ++i) q[i] = (uint8_t)(qua.getBits(6) + off);
+            break;
+        }
         }
     }
     void readHeader(Rec& r)
@@ -76,7 +86,9 @@ struct Unpacker {
         else { r.headOff = (uint32_t)b.head.size(); b.head.resize(b.head.size() + r.headLen); }
         uint8_t* h = b.head.data() + r.headOff;
         if (r.headLen) h[0] = '@';
-        for (uint32_t i = 1; i < r.headLen; ++i) h[i] = (uint8_t)head.getBits(7);
+        uint32_t i = 1;
+        for (; i + 4 <= r.headLen; i += 4) { const uint32_t w = head.getBits(28); h[i] = (uint8_t)(w >> 21); h[i + 1] = (uint8_t)((w >> 14) & 127); h[i + 2] = (uint8_t)((w >> 7) & 127); h[i + 3] = (uint8_t)(w & 127); }
+        for (; i < r.headLen; ++i) h[i] = (uint8_t)head.getBits(7);
     }
     // IFastqPacker::ReadNextRecord on the bytes [seq, seq+len): returns false when the dna stream is exhausted
     bool readNextRecord(const Settings& s, Rec& r, uint32_t seqOff, uint32_t len, bool isMate2)

@@ -12,41 +12,49 @@ namespace fs {
 class BitReader {
 public:
     BitReader(const uint8_t* p, uint64_t size) : p_(p), size_(size) {}
-    uint64_t position() const { return pos_; }
+    // bytes consumed, counting a partly read byte as consumed (the reference's reader holds it in its word buffer)
+    uint64_t position() const { return pos_ - cnt_ / 8; }
     uint64_t size() const { return size_; }
     const uint8_t* data() const { return p_; }
-    uint32_t getByte() { if (pos_ >= size_) throw std::runtime_error("bin stream truncated"); return p_[pos_++]; }
-    uint32_t getBit()
-    {
-        if (wpos_ == 0) { word_ = getByte(); wpos_ = 7; return (word_ >> 7) & 1; }
-        return (word_ >> (--wpos_)) & 1;
-    }
-    uint32_t get2Bits()
-    {
-        if (wpos_ >= 2) { wpos_ -= 2; return (word_ >> wpos_) & 3; }
-        if (wpos_ == 0) { word_ = getByte(); wpos_ = 6; return (word_ >> wpos_) & 3; }
-        uint32_t w = (word_ & 1) << 1;
-        word_ = getByte(); wpos_ = 7;
-        w += word_ >> wpos_;
-        return w & 3;
-    }
+    uint32_t getBit() { return getBits(1); }
+    uint32_t get2Bits() { return getBits(2); }
+    // n <= 32.  The window holds up to 64 bits, MSB first, refilled a byte at a time, so that dropping the rest of
+    // a partly read byte (flushWord) is just dropping cnt_ % 8 bits.
     uint32_t getBits(uint32_t n)
     {
-        uint32_t w = 0;
-        while (n) {
-            if (wpos_ == 0) { word_ = getByte(); wpos_ = 8; }
-            if (n > wpos_) { w <<= wpos_; w += word_ & ((1u << wpos_) - 1); n -= wpos_; wpos_ = 0; }
-            else { w <<= n; wpos_ -= n; w += (word_ >> wpos_) & ((1u << n) - 1); break; }
-        }
-        return w;
+        if (n == 0) return 0;
+        if (cnt_ < n) refill(n);
+        const uint32_t v = (uint32_t)(acc_ >> (64 - n));
+        acc_ <<= n; cnt_ -= n;
+        return v;
     }
-    void getBytes(void* dst, uint64_t n) { if (pos_ + n > size_) throw std::runtime_error("bin stream truncated"); memcpy(dst, p_ + pos_, n); pos_ += n; }
-    uint32_t get2Bytes() { uint32_t a = getByte(); return (a << 8) | getByte(); }
-    uint32_t get4Bytes() { uint32_t c = getByte(); c = (c << 8) | getByte(); c = (c << 8) | getByte(); return (c << 8) | getByte(); }
-    uint64_t get8Bytes() { uint64_t c = 0; for (int i = 0; i < 8; ++i) c = (c << 8) | getByte(); return c; }
-    void flushWord() { wpos_ = 0; }
+    uint32_t getByte() { return getBits(8); }
+    void getBytes(void* dst, uint64_t n)
+    {
+        uint8_t* d = (uint8_t*)dst;
+        flushWord();                                                 // the rest of a partly read byte is not part of a byte run
+        while (n && cnt_ >= 8) { *d++ = (uint8_t)(acc_ >> 56); acc_ <<= 8; cnt_ -= 8; --n; }      // whole bytes still in the window
+        if (n == 0) return;
+        cnt_ = 0; acc_ = 0;                                          // callers read byte runs at byte boundaries
+        if (pos_ + n > size_) throw std::runtime_error("bin stream truncated");
+        memcpy(d, p_ + pos_, n); pos_ += n;
+    }
+    uint32_t get2Bytes() { return getBits(16); }
+    uint32_t get4Bytes() { return getBits(32); }
+    uint64_t get8Bytes() { const uint64_t hi = getBits(32); return (hi << 32) | getBits(32); }
+    void flushWord() { const uint32_t r = cnt_ & 7u; acc_ <<= r; cnt_ -= r; }
 private:
-    const uint8_t* p_; uint64_t size_; uint64_t pos_ = 0; uint32_t word_ = 0, wpos_ = 0;
+    void refill(uint32_t need)
+    {
+        if (pos_ + 8 <= size_ && cnt_ <= 32) {                       // fast path: four bytes at once
+            const uint64_t w = ((uint64_t)p_[pos_] << 24) | ((uint64_t)p_[pos_ + 1] << 16) | ((uint64_t)p_[pos_ + 2] << 8) | (uint64_t)p_[pos_ + 3];
+            acc_ |= w << (32 - cnt_); cnt_ += 32; pos_ += 4;
+            return;
+        }
+        while (cnt_ <= 56 && pos_ < size_) { acc_ |= (uint64_t)p_[pos_++] << (56 - cnt_); cnt_ += 8; }
+        if (cnt_ < need) throw std::runtime_error("bin stream truncated");
+    }
+    const uint8_t* p_; uint64_t size_; uint64_t pos_ = 0; uint64_t acc_ = 0; uint32_t cnt_ = 0;
 };
 
 struct ByteWriter {

@@ -47,8 +47,8 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
     c.par.maxHammingDistance = cfg->max_hamming_distance; c.par.minConsensusSize = cfg->min_consensus_size;
     c.hostThreads = cfg->host_threads ? cfg->host_threads : std::min(24u, std::max(1u, std::thread::hardware_concurrency()));   // measured on a 2 x 64-core host: the front end stops scaling at ~16-24 threads and degrades beyond
     if (getenv("FS_HOST_THREADS")) c.hostThreads = std::max(1, atoi(getenv("FS_HOST_THREADS")));     // experiments
-    if (getenv("FS_PIPELINE_SLICES")) c.cfg.pipeline_slices = (uint32_t)std::max(1, atoi(getenv("FS_PIPELINE_SLICES")));
-    if (getenv("FS_MAX_WAVES")) c.cfg.max_waves = (uint32_t)std::max(1, atoi(getenv("FS_MAX_WAVES")));
+    if (getenv("FS_PIPELINE_SLICES") && atoi(getenv("FS_PIPELINE_SLICES")) > 0) c.cfg.pipeline_slices = (uint32_t)atoi(getenv("FS_PIPELINE_SLICES"));
+    if (getenv("FS_MAX_WAVES") && atoi(getenv("FS_MAX_WAVES")) > 0) c.cfg.max_waves = (uint32_t)atoi(getenv("FS_MAX_WAVES"));
     if (c.par.mismatchCost <= 0 || c.par.maxLzWindowSize == 0 || c.par.maxPairLzWindowSize == 0) { g_createError = "invalid matcher parameters"; delete ctx; return nullptr; }
     if (fsengine::device_count() <= 0) {
         g_createError = "no HIP device available: the fastore_pack hot path has no CPU fallback";

@@ -62,6 +62,9 @@ struct Shared {
     uint8_t QT[260];             // QTable, tabulated once per wave
 };
 
+// the three words of a context record as fetched (per-lane values, fetch still in flight): issue early, finish at first use
+struct CtxRaw { uint32_t a, b, d; };
+
 struct Coder {
     fs_gptr hb;                  // heap base - 1  (so that index ix lives at hb + ix)
     FS_LDS Shared* sh;
@@ -74,6 +77,7 @@ struct Coder {
     uint32_t dummySee;
     fs_gptr out; uint32_t outCap, outPos;
     uint32_t restarts;
+    uint32_t pfCtx; CtxRaw pf;     // record of the next symbol's first context, requested ahead of this symbol's stores (0 = none)
 };
 
 #define HP(ix) (m.hb + (ix))
@@ -116,21 +120,27 @@ FS_DEV void state_cpy(Coder& m, uint32_t d, uint32_t s) { state_store(m, d, S_SY
 
 // One context header = one 12-byte fetch (three dwords in flight together), then kept in SGPRs.
 struct Ctx { uint32_t ns, flags, sf, w1 /* iStats, or oneState.iSuccessor */, suff, oneSym, oneFreq; };
-FS_DEV Ctx ctx_load(Coder& m, uint32_t c)
+FS_DEV CtxRaw ctx_issue(Coder& m, uint32_t c)
 {
     FS_CNT(g_ld[0]);
     fs_cgptr32 q = (fs_cgptr32)HP(c);
+    CtxRaw r;
 #if defined(__HIP_DEVICE_COMPILE__) && defined(FS_LD1)
     uint32_t w = 0; const uint32_t l = (uint32_t)FS_LANE();
     if (l < 3u) w = q[l];
-    const uint32_t a = fs_readlane(w, 0), b = fs_readlane(w, 1), d = fs_readlane(w, 2);
+    r.a = fs_readlane(w, 0); r.b = fs_readlane(w, 1); r.d = fs_readlane(w, 2);
 #else
-    uint32_t a = q[0], b = q[1], d = q[2];
-    a = FS_UNI(a); b = FS_UNI(b); d = FS_UNI(d);
+    r.a = q[0]; r.b = q[1]; r.d = q[2];
 #endif
+    return r;
+}
+FS_DEV Ctx ctx_finish(const CtxRaw& x)
+{
+    const uint32_t a = FS_UNI(x.a), b = FS_UNI(x.b), d = FS_UNI(x.d);
     Ctx r; r.ns = a & 0xFFu; r.flags = (a >> 8) & 0xFFu; r.sf = a >> 16; r.w1 = b; r.suff = d; r.oneSym = (a >> 16) & 0xFFu; r.oneFreq = a >> 24;
     return r;
 }
+FS_DEV Ctx ctx_load(Coder& m, uint32_t c) { return ctx_finish(ctx_issue(m, c)); }
 // One state = three 16-bit fetches in flight together.
 struct St { uint32_t sym, freq, succ; };
 FS_DEV St st_load(Coder& m, uint32_t s)
@@ -180,6 +190,7 @@ FS_DEV void InitSubAllocator(Coder& m)
 
 FS_DEV_NOINLINE void GlueFreeBlocks(Coder& m)
 {
+    FS_REGION(7);
     uint32_t i, k, sz, p, p0, p1;
     const uint32_t s0 = BL(N_INDEXES + 1);
     if (m.LoUnit != m.HiUnit) fs_st8(HP(m.LoUnit), 0);
@@ -204,6 +215,7 @@ FS_DEV_NOINLINE void GlueFreeBlocks(Coder& m)
 
 FS_DEV_NOINLINE uint32_t AllocUnitsRare(Coder& m, uint32_t indx)
 {
+    FS_REGION(7);
     uint32_t i = indx;
     do {
         if (++i == N_INDEXES) {
@@ -222,6 +234,7 @@ FS_DEV_NOINLINE uint32_t AllocUnitsRare(Coder& m, uint32_t indx)
 
 FS_DEV uint32_t AllocUnits(Coder& m, uint32_t NU)
 {
+    FS_REGION(6);
     uint32_t indx = kUnits2Indx[NU - 1];
     if (blk_avail(m, BL(indx))) return blk_remove(m, BL(indx));
     uint32_t r = m.LoUnit; m.LoUnit += 12u * kIndx2Units[indx];
@@ -231,12 +244,14 @@ FS_DEV uint32_t AllocUnits(Coder& m, uint32_t NU)
 
 FS_DEV uint32_t AllocContext(Coder& m)
 {
+    FS_REGION(6);
     if (m.HiUnit != m.LoUnit) return (m.HiUnit -= UNIT_SIZE);
     return blk_avail(m, BL(0)) ? blk_remove(m, BL(0)) : AllocUnitsRare(m, 0);
 }
 
 FS_DEV uint32_t ExpandUnits(Coder& m, uint32_t oldPtr, uint32_t oldNU)
 {
+    FS_REGION(6);
     uint32_t i0 = kUnits2Indx[oldNU - 1], i1 = kUnits2Indx[oldNU - 1 + 1];
     if (i0 == i1) return oldPtr;
     uint32_t ptr = AllocUnits(m, oldNU + 1);
@@ -246,6 +261,7 @@ FS_DEV uint32_t ExpandUnits(Coder& m, uint32_t oldPtr, uint32_t oldNU)
 
 FS_DEV uint32_t ShrinkUnits(Coder& m, uint32_t oldPtr, uint32_t oldNU, uint32_t newNU)
 {
+    FS_REGION(6);
     uint32_t i0 = kUnits2Indx[oldNU - 1], i1 = kUnits2Indx[newNU - 1];
     if (i0 == i1) return oldPtr;
     if (blk_avail(m, BL(i1))) {
@@ -280,6 +296,7 @@ FS_DEV void clear_mask(Coder& m)
 
 FS_DEV void StartModelRare(Coder& m)
 {
+    FS_REGION(9);
     clear_mask(m);
     m.OrderFall = MAX_ORDER;
     InitSubAllocator(m);
@@ -315,7 +332,9 @@ FS_DEV void RestoreModelRare(Coder& m) { m.pText = 1u; StartModelRare(m); m.EscC
 struct LaneStates { uint32_t sf, succ; bool valid; };
 FS_DEV LaneStates lane_states(Coder& m, uint32_t stats, uint32_t ns, uint32_t base)
 {
-    FS_CNT(g_ld[2]);
+#if defined(FS_COUNTERS) && !defined(__HIP_DEVICE_COMPILE__)
+    if ((base & 63u) == 0) { FS_CNT(g_ld[2]); FS_CNT(g_ld[2]); FS_CNT(g_ld[2]); }      // what the 64-lane build issues: three fetches per 64 states
+#endif
     LaneStates r; const uint32_t i = base + (uint32_t)FS_LANE();
     r.valid = i <= ns; r.sf = 0; r.succ = 0;
     if (r.valid) { fs_cgptr16 q = (fs_cgptr16)HP(stats + 6u * i); const uint32_t a = q[0], b = q[1], c = q[2]; r.sf = a; r.succ = b | (c << 16); }
@@ -343,14 +362,17 @@ FS_DEV Hit find_in(Coder& m, const Ctx& pc, uint32_t sym)
 }
 
 // CreateSuccessors (Model.cpp:282-337).  p/pSucc: state to start from in the suffix of pc (0 = none) and its successor.
-FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc, uint32_t pc, uint32_t fsSym, uint32_t fsSucc)
+// pcRec / sufRec: register copies of the records of pc and (when p != 0) of its suffix, when the caller holds them
+FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc, uint32_t pc, uint32_t fsSym, uint32_t fsSucc,
+                                 const Ctx* pcRec = nullptr, const Ctx* sufRec = nullptr)
 {
-    FS_CNT(g_path[9]);
+    FS_REGION(3);
+    FS_PATH(g_path[9]);
     const uint32_t iUpBranch = fsSucc;
     uint32_t ps[MAX_ORDER + 1]; uint32_t pps = 0;
     uint32_t cf, s0, tmp;
     uint32_t sym = fsSym;
-    Ctx P = ctx_load(m, pc);
+    Ctx P = pcRec ? *pcRec : ctx_load(m, pc);
     bool toLoop = true;
     if (!Skip) {
         ps[pps++] = m.FoundState;
@@ -358,7 +380,7 @@ FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc
     }
     if (toLoop) {
         bool first = (p != 0);
-        if (first) { pc = P.suff; P = ctx_load(m, pc); }
+        if (first) { pc = P.suff; P = sufRec ? *sufRec : ctx_load(m, pc); }
         do {
             if (!first) {
                 pc = P.suff; P = ctx_load(m, pc);
@@ -402,7 +424,8 @@ FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc
 // ReduceOrder (Model.cpp:209-243)
 FS_DEV uint32_t ReduceOrder(Coder& m, uint32_t p, uint32_t pSucc, uint32_t pc)
 {
-    FS_CNT(g_path[10]);
+    FS_REGION(4);
+    FS_PATH(g_path[10]);
     uint32_t tmp; const uint32_t pc1 = pc;
     const uint32_t iUpBranch = m.pText; S_SUCC_SET(m.FoundState, iUpBranch);
     const uint32_t sym = m.fsSym; m.OrderFall++;
@@ -434,9 +457,91 @@ FS_DEV uint32_t ReduceOrder(Coder& m, uint32_t p, uint32_t pSucc, uint32_t pc)
     return pSucc;
 }
 
+// The reference's rescale (Model.cpp:246-280) is a move-to-front of the found state, a halving pass and an insertion
+// sort, one state at a time.  Its result is a stable sort of the rotated list by the halved frequencies (the found
+// state stays first: it is the only one above MAX_FREQ), so for contexts of up to 64 states every lane takes one state,
+// computes its final position by counting, and the list goes back in one step; the sums are wave reductions.
+FS_DEV_NOINLINE void rescale_serial(Coder& m, uint32_t c);
 FS_DEV_NOINLINE void rescale(Coder& m, uint32_t c)
 {
-    FS_CNT(g_path[11]);
+    const Ctx R = ctx_load(m, c);
+    const uint32_t ns = R.ns, stats = R.w1;
+    if (ns >= 64u) { rescale_serial(m, c); return; }
+    FS_REGION(5);
+    FS_PATH(g_path[11]);
+    const uint32_t kf = (m.FoundState - stats) / 6u, a0 = (m.OrderFall != 0);
+    uint32_t sumF, summ, zeros, f0, nf0, sym0, succ0; bool hiAny;
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        const uint32_t i = (uint32_t)FS_LANE();
+        const LaneStates ls = lane_states(m, stats, ns, 0);
+        const uint32_t sym = ls.sf & 0xFFu, f = ls.sf >> 8;
+        const uint32_t nf = ls.valid ? (f + a0) >> 1 : 0u;
+        sumF = fs_wave_sum8(f, ls.valid); summ = fs_wave_sum8(nf, ls.valid);
+        hiAny = fs_ballot(ls.valid && i != kf && nf != 0u && sym >= 0x40u) != 0ull;
+        zeros = fs_popc64(fs_ballot(ls.valid && i != kf && nf == 0u));
+        const uint32_t r = i == kf ? 0u : (i < kf ? i + 1u : i);             // place after the move-to-front
+        uint32_t pos = 1u;
+        for (uint32_t j = 0; j <= ns; ++j) {                                  // uniform loop, one comparison per lane
+            const uint32_t nj = fs_readlane(nf, j), rj = j == kf ? 0u : (j < kf ? j + 1u : j);
+            pos += (j != kf && (nj > nf || (nj == nf && rj < r))) ? 1u : 0u;
+        }
+        if (i == kf) pos = 0u;
+        f0 = fs_readlane(f, kf); nf0 = fs_readlane(nf, kf); sym0 = fs_readlane(sym, kf); succ0 = fs_readlane(ls.succ, kf);
+        if (ls.valid) {
+            fs_gptr16 q = (fs_gptr16)HP(stats + 6u * pos);
+            q[0] = (uint16_t)(sym | (nf << 8)); q[1] = (uint16_t)ls.succ; q[2] = (uint16_t)(ls.succ >> 16);
+        }
+        FS_WAVE_SYNC();
+    }
+#else
+    {
+        uint32_t sym[64], f[64], nf[64], succ[64], r[64];
+        for (uint32_t i = 0; i <= ns; ++i) { const St t = st_load(m, stats + 6u * i); sym[i] = t.sym; f[i] = t.freq; succ[i] = t.succ; nf[i] = (t.freq + a0) >> 1; r[i] = i == kf ? 0u : (i < kf ? i + 1u : i); }
+        sumF = summ = zeros = 0; hiAny = false;
+        for (uint32_t i = 0; i <= ns; ++i) { sumF += f[i]; summ += nf[i]; if (i != kf) { hiAny |= nf[i] != 0u && sym[i] >= 0x40u; zeros += nf[i] == 0u; } }
+        for (uint32_t i = 0; i <= ns; ++i) {
+            uint32_t pos = 1u;
+            for (uint32_t j = 0; j <= ns; ++j) pos += (j != kf && (nf[j] > nf[i] || (nf[j] == nf[i] && r[j] < r[i]))) ? 1u : 0u;
+            if (i == kf) pos = 0u;
+            state_store(m, stats + 6u * pos, sym[i] | (nf[i] << 8), succ[i]);
+        }
+        f0 = f[kf]; nf0 = nf[kf]; sym0 = sym[kf]; succ0 = succ[kf];
+    }
+#endif
+    uint32_t flags = (R.flags & 0x14u) | (hiAny ? 0x08u : 0u);
+    uint32_t EscFreq = R.sf - sumF, nsNew = ns, statsNew = stats, a;
+    if (zeros) {
+        EscFreq += zeros;
+        const uint32_t oldNU = (ns + 2u) >> 1;
+        nsNew = ns - zeros;
+        if (nsNew == 0) {                                                      // one state left: back to a binary context
+            uint32_t tf = (2u * nf0 + EscFreq - 1) / EscFreq;
+            if (tf > MAX_FREQ / 3) tf = MAX_FREQ / 3;
+            FreeUnits(m, stats, oldNU);
+            fs_st32(HP(c), ((flags & 0x18u) << 8) | (sym0 << 16) | (tf << 24));
+            fs_st32(HP(c) + 4, succ0);
+            m.FoundState = C_ONE(c); return;
+        }
+        statsNew = ShrinkUnits(m, stats, oldNU, (nsNew + 2u) >> 1);
+    }
+    summ += (EscFreq + 1) >> 1;
+    if (m.OrderFall || (flags & 0x04u) == 0) {
+        const uint32_t sf = R.sf - EscFreq;
+        a = sf - f0;
+        a = (f0 * summ - sf * nf0 + a - 1) / a;
+        a = a < 2u ? 2u : (a > MAX_FREQ / 2u - 18u ? MAX_FREQ / 2u - 18u : a);
+    } else a = 2;
+    m.FoundState = statsNew;
+    S_FREQ_SET(statsNew, nf0 + a);
+    fs_st32(HP(c), (nsNew & 0xFFu) | ((flags | 0x04u) << 8) | (((summ + a) & 0xFFFFu) << 16));
+    if (statsNew != stats) fs_st32(HP(c) + 4, statsNew);
+}
+
+FS_DEV_NOINLINE void rescale_serial(Coder& m, uint32_t c)
+{
+    FS_REGION(5);
+    FS_PATH(g_path[11]);
     uint32_t f0, sf, EscFreq, a = (m.OrderFall != 0), i = C_NS(c);
     uint32_t p1, p;
     C_FLAGS_SET(c, C_FLAGS(c) & 0x14u);
@@ -484,31 +589,34 @@ FS_DEV_NOINLINE void rescale(Coder& m, uint32_t c)
     C_FLAGS_SET(c, C_FLAGS(c) | 0x04u);
 }
 
-FS_DEV void UpdateModel(Coder& m, uint32_t MinContext)
+FS_DEV void UpdateModel(Coder& m, uint32_t MinContext, const Ctx& mcMin, const Ctx* sufRec)
 {
-    FS_CNT(g_path[8]);
+    FS_REGION(2);
+    FS_PATH(g_path[8]);
     const uint32_t FSymbol = m.fsSym, FFreq = m.fsFreq;
     uint32_t iSuccessor, iFSuccessor = m.fsSucc;
     uint32_t ns1, ns, cf, sf, s0, pc, p = 0, pSucc = 0;
     bool restart = false;
-    const Ctx mcMin = ctx_load(m, MinContext);               // fresh: the coding step has updated this context
+    // mcMin: the caller's register copy of the context, kept in step with the stores of the coding step
+    Ctx P; P.ns = 0; P.flags = 0; P.sf = 0; P.w1 = 0; P.suff = 0; P.oneSym = 0; P.oneFreq = 0;
     if (mcMin.suff) {
         pc = mcMin.suff;
-        Ctx P = ctx_load(m, pc);
+        P = sufRec ? *sufRec : ctx_load(m, pc);
         if (P.ns) {
             Hit h = find_in(m, P, FSymbol);
             p = h.p; pSucc = h.succ;
-            if (p != P.w1 && h.freq >= (h.prevSf >> 8)) {      // bubble one position up
-                state_store(m, p - 6, FSymbol | (h.freq << 8), h.succ);
+            cf = h.freq < MAX_FREQ ? 1 + (FFreq < 4 * 8) : 0;
+            if (p != P.w1 && h.freq >= (h.prevSf >> 8)) {      // bubble one position up, the frequency update folded in
+                state_store(m, p - 6, FSymbol | ((h.freq + cf) << 8), h.succ);
                 state_store(m, p, h.prevSf, h.prevSucc);
                 p -= 6;
-            }
-            if (h.freq < MAX_FREQ) { cf = 1 + (FFreq < 4 * 8); S_FREQ_SET(p, h.freq + cf); C_SF_SET(pc, P.sf + cf); }
-        } else { p = C_ONE(pc); pSucc = P.w1; S_FREQ_SET(p, P.oneFreq + (P.oneFreq < 11)); }
+            } else if (cf) S_FREQ_SET(p, h.freq + cf);
+            if (cf) { P.sf += cf; C_SF_SET(pc, P.sf); }
+        } else { p = C_ONE(pc); pSucc = P.w1; P.oneFreq += (P.oneFreq < 11); P.sf = P.oneSym | (P.oneFreq << 8); S_FREQ_SET(p, P.oneFreq); }
     }
     pc = m.MaxContext;
     if (!m.OrderFall && iFSuccessor) {
-        const uint32_t sx = CreateSuccessors(m, true, p, pSucc, MinContext, FSymbol, iFSuccessor);
+        const uint32_t sx = CreateSuccessors(m, true, p, pSucc, MinContext, FSymbol, iFSuccessor, &mcMin, &P);
         S_SUCC_SET(m.FoundState, sx);
         if (!sx) { RestoreModelRare(m); return; }
         m.MaxContext = sx; return;
@@ -516,58 +624,77 @@ FS_DEV void UpdateModel(Coder& m, uint32_t MinContext)
     fs_st8(HP(m.pText), FSymbol); m.pText++; iSuccessor = m.pText;
     if (m.pText >= m.UnitsStart) { RestoreModelRare(m); return; }
     if (iFSuccessor) {
-        if (iFSuccessor < m.UnitsStart) iFSuccessor = CreateSuccessors(m, false, p, pSucc, MinContext, FSymbol, iFSuccessor);
+        if (iFSuccessor < m.UnitsStart) iFSuccessor = CreateSuccessors(m, false, p, pSucc, MinContext, FSymbol, iFSuccessor, &mcMin, &P);
     } else iFSuccessor = ReduceOrder(m, p, pSucc, MinContext);
     if (!iFSuccessor) { RestoreModelRare(m); return; }
     if (!--m.OrderFall) { iSuccessor = iFSuccessor; m.pText -= (m.MaxContext != MinContext); }
     s0 = mcMin.sf - FFreq; ns = mcMin.ns;
     const uint32_t Flag = 0x08u * (FSymbol >= 0x40);
-    for (; pc != MinContext; pc = C_SUFF(pc)) {
-        uint32_t summ;
-        FS_CNT(g_path[12]);
-        if ((ns1 = C_NS(pc)) != 0) {
+    // one record fetch per context on the way down to MinContext; NumStats, Flags and SummFreq go back as one word
+    while (pc != MinContext) {
+        uint32_t summ, stats;
+        FS_PATH(g_path[12]);
+        const Ctx R = ctx_load(m, pc);
+        if ((ns1 = R.ns) != 0) {
+            stats = R.w1;
             if ((ns1 & 1) != 0) {
-                p = ExpandUnits(m, C_STATS(pc), (ns1 + 1) >> 1);
+                p = ExpandUnits(m, stats, (ns1 + 1) >> 1);
                 if (!p) { restart = true; break; }
-                C_STATS_SET(pc, p);
+                stats = p;
             }
-            summ = C_SF(pc) + (m.sh->QT[ns + 4] >> 3);
+            summ = R.sf + (m.sh->QT[ns + 4] >> 3);
         } else {
             p = AllocUnits(m, 1);
             if (!p) { restart = true; break; }
-            const uint32_t o0 = S_SYMFREQ(C_ONE(pc)), o1 = S_SUCC(C_ONE(pc));
-            uint32_t fr = o0 >> 8;
+            uint32_t fr = R.oneFreq;
             fr = (fr <= MAX_FREQ / 3) ? (2 * fr - 1) : (MAX_FREQ - 15);
-            state_store(m, p, (o0 & 0xFFu) | (fr << 8), o1); C_STATS_SET(pc, p);
+            state_store(m, p, R.oneSym | (fr << 8), R.w1);           // oneState moves into its own unit
+            stats = p;
             summ = fr + (ns > 1) + kExpEscape[m.sh->QT[m.BSumm >> 8]];
         }
         cf = 2 * FFreq * (summ + 4u); sf = s0 + summ;
         if (cf <= 6 * sf) { cf = 1 + (cf > sf) + (cf > 3 * sf); summ += 4; }
         else { cf = 4 + (cf > 8 * sf) + (cf > 10 * sf) + (cf > 13 * sf); summ += cf; }
-        C_SF_SET(pc, summ);
-        ns1 += 1; C_NS_SET(pc, ns1);
-        p = C_STATS(pc) + 6u * ns1;
-        state_store(m, p, FSymbol | (cf << 8), iSuccessor);
-        C_FLAGS_SET(pc, C_FLAGS(pc) | Flag);
+        ns1 += 1;
+        state_store(m, stats + 6u * ns1, FSymbol | (cf << 8), iSuccessor);
+        fs_st32(HP(pc), (ns1 & 0xFFu) | (((R.flags | Flag) & 0xFFu) << 8) | ((summ & 0xFFFFu) << 16));
+        if (stats != R.w1 || R.ns == 0) fs_st32(HP(pc) + 4, stats);
+        pc = R.suff;
     }
     if (restart) { RestoreModelRare(m); return; }
     m.MaxContext = iFSuccessor;
 }
 
-FS_DEV void encodeBinSymbol(Coder& m, uint32_t c, const Ctx& mc, int symbol)
+// The next symbol starts in the found state's successor when the model needs no update (main loop: !OrderFall and a
+// real context).  Its record is requested HERE, ahead of this symbol's stores: the memory pipeline completes in issue
+// order, so a fetch issued behind the stores would also wait for their acknowledgements.  A context that succeeds
+// itself needs no fetch at all: the caller's register copy is kept current.
+FS_DEV void prefetch_successor(Coder& m, uint32_t c, uint32_t succ)
 {
+    m.pfCtx = 0;
+    if (!m.OrderFall && succ >= m.UnitsStart && succ != c) { m.pf = ctx_issue(m, succ); m.pfCtx = succ; }
+}
+
+// sufRec/sufCtx (here and in encodeSymbol2): the suffix context's record comes with the NumStats these functions need
+// from it, and is handed on -- the next escape step and UpdateModel start from it instead of fetching it again.
+FS_DEV void encodeBinSymbol(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec, uint32_t& sufCtx)
+{
+    FS_REGION(1);
     const uint32_t rs = C_ONE(c);
-    const uint32_t sufNs = fs_ld8(HP(mc.suff));
+    sufRec = ctx_load(m, mc.suff); sufCtx = mc.suff;
+    const uint32_t sufNs = sufRec.ns;
     const uint32_t idx = m.sh->QT[mc.oneFreq - 1] * 64u + NS2BSIndx(sufNs) + m.PrevSuccess + mc.flags + (uint32_t)((m.RunLength >> 26) & 0x20);
     uint32_t bs = FS_UNI(m.sh->BinSumm[idx]);
     m.BSumm = (int32_t)bs;
     const uint32_t tmp = bs * (m.range >>= TOT_BITS);
     bs -= (bs + ROUND) >> PERIOD_BITS;
     if ((int)mc.oneSym == symbol) {
+        prefetch_successor(m, c, mc.w1);
         bs += INTERVAL; m.range = tmp;
         const uint32_t nf = mc.oneFreq + (mc.oneFreq < 196);
         m.FoundState = rs; S_FREQ_SET(rs, nf);
         m.fsSym = mc.oneSym; m.fsFreq = nf; m.fsSucc = mc.w1;
+        mc.oneFreq = nf; mc.sf = mc.oneSym | (nf << 8);          // the caller's copy of the record follows the store
         m.RunLength++; m.PrevSuccess = 1;
     } else {
         m.low += tmp; m.range *= (uint32_t)(BIN_SCALE - m.BSumm);
@@ -577,8 +704,9 @@ FS_DEV void encodeBinSymbol(Coder& m, uint32_t c, const Ctx& mc, int symbol)
     m.sh->BinSumm[idx] = (uint16_t)bs;
 }
 
-FS_DEV void encodeSymbol1(Coder& m, uint32_t c, const Ctx& mc, int symbol)
+FS_DEV void encodeSymbol1(Coder& m, uint32_t c, Ctx& mc, int symbol)
 {
+    FS_REGION(1);
     const uint32_t stats = mc.w1, ns = mc.ns;
     m.rScale = mc.sf;
     uint32_t LoCnt = 0, p = 0, k = 0, base = 0; bool found = false;
@@ -601,16 +729,19 @@ FS_DEV void encodeSymbol1(Coder& m, uint32_t c, const Ctx& mc, int symbol)
     }
     const uint32_t fFound = FS_UNI(fs_readlane(ls.sf >> 8, k)), succ = FS_UNI(fs_readlane(ls.succ, k));
     m.fsSym = (uint32_t)symbol; m.fsSucc = succ;
+    prefetch_successor(m, c, succ);
     if (base + k == 0) {                                     // most probable symbol
         m.PrevSuccess = (2 * (m.rHigh = fFound) > m.rScale);
         m.FoundState = p; m.fsFreq = fFound + 4; S_FREQ_SET(p, fFound + 4); C_SF_SET(c, m.rScale + 4);
-        if (fFound + 4 > MAX_FREQ) { rescale(m, c); fs_reload(m); }
+        mc.sf = m.rScale + 4;
+        if (fFound + 4 > MAX_FREQ) { rescale(m, c); fs_reload(m); mc = ctx_load(m, c); }
         m.rLow = 0; return;
     }
     m.PrevSuccess = 0;
     m.rHigh = (m.rLow = LoCnt) + fFound;
     // update1: +4, then bubble one position up if it now outweighs its predecessor
     m.FoundState = p; m.fsFreq = fFound + 4; C_SF_SET(c, m.rScale + 4);
+    mc.sf = m.rScale + 4;
     uint32_t prevSf, prevSucc;
     if (k > 0) { prevSf = FS_UNI(fs_readlane(ls.sf, k - 1)); prevSucc = FS_UNI(fs_readlane(ls.succ, k - 1)); }
     else { const St t = st_load(m, p - 6); prevSf = t.sym | (t.freq << 8); prevSucc = t.succ; }
@@ -618,21 +749,25 @@ FS_DEV void encodeSymbol1(Coder& m, uint32_t c, const Ctx& mc, int symbol)
         state_store(m, p - 6, (uint32_t)symbol | ((fFound + 4) << 8), succ);
         state_store(m, p, prevSf, prevSucc);
         m.FoundState = p - 6;
-        if (fFound + 4 > MAX_FREQ) { rescale(m, c); fs_reload(m); }
+        if (fFound + 4 > MAX_FREQ) { rescale(m, c); fs_reload(m); mc = ctx_load(m, c); }
     } else S_FREQ_SET(p, fFound + 4);
 }
 
-FS_DEV void encodeSymbol2(Coder& m, uint32_t c, const Ctx& mc, int symbol)
+FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec, uint32_t& sufCtx)
 {
+    FS_REGION(8);
     const uint32_t nsC = mc.ns, stats = mc.w1;
     // NumStats of the suffix context, in flight together with the state fetch below (the root has no suffix and,
     // with all 256 symbols, never needs it: Model.cpp:509)
-    const uint8_t sufNsRaw = mc.suff ? *HP(mc.suff) : (uint8_t)0;
+    CtxRaw sr; sr.a = sr.b = sr.d = 0;
+    if (mc.suff) sr = ctx_issue(m, mc.suff);
     LaneStates ls = lane_states(m, stats, nsC, 0);
+    sufCtx = mc.suff;
+    if (mc.suff) sufRec = ctx_finish(sr);
     // makeEscFreq2
     uint32_t seeIdx = 0xFFFFFFFFu, see = 0;
     if (nsC != 0xFF) {
-        const uint32_t sufNs = FS_UNI(sufNsRaw);
+        const uint32_t sufNs = mc.suff ? sufRec.ns : 0u;
         seeIdx = (m.sh->QT[nsC + 3] - 4u) * 32u + (mc.sf > 10u * (nsC + 1u)) + 2u * (2u * nsC < sufNs + m.NumMasked) + mc.flags;
         see = FS_UNI(m.sh->SEE2[seeIdx]);
         const uint32_t shift = (see >> 16) & 0xFFu; uint32_t summ = see & 0xFFFFu;
@@ -688,7 +823,8 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, const Ctx& mc, int symbol)
     // update2
     m.FoundState = p; m.fsSym = (uint32_t)symbol; m.fsFreq = fFound + 4; m.fsSucc = succ;
     S_FREQ_SET(p, fFound + 4); C_SF_SET(c, mc.sf + 4);
-    if (fFound + 4 > MAX_FREQ) { rescale(m, c); fs_reload(m); }
+    mc.sf += 4;
+    if (fFound + 4 > MAX_FREQ) { rescale(m, c); fs_reload(m); mc = ctx_load(m, c); }
     m.EscCount = (m.EscCount + 1) & 0xFFu; m.RunLength = m.InitRL;
 }
 
@@ -711,6 +847,10 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
     const bool wide = (((uintptr_t)in) & 3u) == 0;
     uint32_t pos = 0, cur = 0, nxt = 0;
     if (wide && n >= 4) nxt = *(fs_cgptr32)in;
+    Ctx mc; mc.ns = mc.flags = mc.sf = mc.w1 = mc.suff = mc.oneSym = mc.oneFreq = 0;
+    bool keep = false; uint32_t prevCtx = 0;
+    Ctx sufRec = mc; uint32_t sufCtx = 0;
+    m.pfCtx = 0; m.pf.a = m.pf.b = m.pf.d = 0;
     for (uint32_t MinContext = m.MaxContext;;) {
         int c = -1;
         if (pos < n) {
@@ -720,26 +860,32 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
             } else c = (int)fs_ld8(in + pos);
             pos++;
         }
-        Ctx mc = ctx_load(m, MinContext);
-        FS_CNT(g_path[0]);
-        if (mc.ns) { FS_CNT(g_path[2]); encodeSymbol1(m, MinContext, mc, c); rc_encode(m); if (m.FoundState) { if (m.rLow == 0) FS_CNT(g_path[3]); else FS_CNT(g_path[4]); } }
-        else { FS_CNT(g_path[1]); encodeBinSymbol(m, MinContext, mc, c); }
+        // first context of the symbol: still in registers (a context that succeeded itself), requested during the
+        // previous symbol, or fetched now
+        if (m.pfCtx == MinContext) mc = ctx_finish(m.pf);
+        else if (!(keep && MinContext == prevCtx)) mc = ctx_load(m, MinContext);
+        m.pfCtx = 0; keep = false; prevCtx = MinContext; sufCtx = 0;
+        FS_PATH(g_path[0]);
+        if (mc.ns) { FS_PATH(g_path[2]); encodeSymbol1(m, MinContext, mc, c); rc_encode(m); if (m.FoundState) { if (m.rLow == 0) FS_PATH(g_path[3]); else FS_PATH(g_path[4]); } }
+        else { FS_PATH(g_path[1]); encodeBinSymbol(m, MinContext, mc, c, sufRec, sufCtx); }
         bool stop = false;
         while (!m.FoundState) {
             rc_normalize(m);
             do {
                 if (!mc.suff) { stop = true; break; }
-                m.OrderFall++; MinContext = mc.suff; mc = ctx_load(m, MinContext);
+                m.OrderFall++; MinContext = mc.suff;
+                if (sufCtx == MinContext) mc = sufRec; else mc = ctx_load(m, MinContext);
+                sufCtx = 0;
             } while (mc.ns == m.NumMasked);
             if (stop) break;
-            FS_CNT(g_path[5]);
-            encodeSymbol2(m, MinContext, mc, c); rc_encode(m);
-            if (m.FoundState) FS_CNT(g_path[6]);
+            FS_PATH(g_path[5]);
+            encodeSymbol2(m, MinContext, mc, c, sufRec, sufCtx); rc_encode(m);
+            if (m.FoundState) FS_PATH(g_path[6]);
         }
         if (stop) break;
         const uint32_t succ = m.fsSucc;
-        if (!m.OrderFall && succ >= m.UnitsStart) { FS_CNT(g_path[7]); m.MaxContext = succ; }
-        else { UpdateModel(m, MinContext); if (m.EscCount == 0) clear_mask(m); }
+        if (!m.OrderFall && succ >= m.UnitsStart) { FS_PATH(g_path[7]); m.MaxContext = succ; keep = (succ == MinContext); }
+        else { UpdateModel(m, MinContext, mc, (sufCtx && sufCtx == mc.suff) ? &sufRec : nullptr); if (m.EscCount == 0) clear_mask(m); }
         rc_normalize(m); MinContext = m.MaxContext;
     }
     for (int i = 0; i < 4; i++) { put_byte(m, m.low >> 24); m.low <<= 8; }

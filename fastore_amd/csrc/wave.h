@@ -19,7 +19,13 @@
   #define FS_GLOBAL __attribute__((address_space(1)))
   #define FS_LDS __attribute__((address_space(3)))
   #define FS_DEV __device__ __forceinline__
-  #define FS_DEV_NOINLINE __device__ __noinline__
+  // everything is inlined into the kernel: an out-of-line callee takes the coder state by reference, which pins that
+  // whole struct in scratch memory and turns every field access of the hot loop into a vector-memory instruction
+  #if defined(FS_KEEP_NOINLINE)
+    #define FS_DEV_NOINLINE __device__ __noinline__
+  #else
+    #define FS_DEV_NOINLINE __device__ __forceinline__
+  #endif
   #define FS_WAVE 64
   #define FS_LANE() ((int)(threadIdx.x & 63))
   // make a loaded value wave-uniform (it already is by construction; this moves it to an SGPR)
@@ -39,9 +45,14 @@
 
 // host-only event counters for design studies (tools/ppmd_paths.cpp); compiled out everywhere else
 #if defined(FS_COUNTERS) && !defined(__HIP_DEVICE_COMPILE__)
-  #define FS_CNT(x) (++(x))
+  #define FS_CNT(x) (++(x), ++g_region_ops[g_region])
+  struct FsRegion { int prev; explicit FsRegion(int r) : prev(g_region) { g_region = r; ++g_region_calls[r]; } ~FsRegion() { g_region = prev; } };
+  #define FS_REGION(id) FsRegion fs_region_guard_(id)
+  #define FS_PATH(x) (++(x))
 #else
+  #define FS_PATH(x) ((void)0)
   #define FS_CNT(x) ((void)0)
+  #define FS_REGION(id) ((void)0)
 #endif
 
 typedef FS_GLOBAL uint8_t* fs_gptr;                 // device: global address space; host: plain pointer

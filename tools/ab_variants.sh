@@ -5,14 +5,16 @@ set -u
 tag=$1; shift
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1     # prepares (and caches) the libraries
+timeout 300 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1     # prepares (and caches) the libraries
 for lib in "$@"; do
   name=$(basename $lib .so)
   if [ "$lib" = default ]; then unset FS_LIB FASTORE_AMD_LIB; else export FS_LIB=$PWD/$lib FASTORE_AMD_LIB=$PWD/$lib; fi
   echo "== $name" >> gpurun_out/${tag}_ab.log
-  COPIES=1,3072 python3 tools/ppmd_microbench.py 100000 >> gpurun_out/${tag}_ab.log 2>&1
-  python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>> gpurun_out/${tag}_ab.err | python3 -c "
+  COPIES=1,3072 timeout 120 python3 tools/ppmd_microbench.py 100000 >> gpurun_out/${tag}_ab.log 2>&1
+  for sl in ${SLICES:-5}; do
+  FS_PIPELINE_SLICES=$sl timeout 200 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>> gpurun_out/${tag}_ab.err | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('bench MB/s', d['value'], 'ms/step', d['ms_per_step'], 'kernel ms/step', d['stages_ms_per_step']['encode_kernel_ms'], 'ppmd sym/s', d['roofline']['ppmd_symbols_per_s'], 'parity n/a')" >> gpurun_out/${tag}_ab.log
+d=json.loads(sys.stdin.read()); print('slices $sl: bench MB/s', d['value'], 'ms/step', d['ms_per_step'], 'stages', d['stages_ms_per_step'])" >> gpurun_out/${tag}_ab.log
+  done
 done
 cat gpurun_out/${tag}_ab.log

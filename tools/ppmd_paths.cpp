@@ -4,7 +4,8 @@
 #include <stdlib.h>
 #include <random>
 #include <vector>
-static unsigned long long g_ld[8], g_st, g_path[16];
+static unsigned long long g_ld[8], g_st, g_path[16], g_region_ops[16], g_region_calls[16];
+static int g_region = 0;
 #define FS_COUNTERS 1
 #include "wave.h"
 #include "ppmd_core.h"
@@ -22,5 +23,8 @@ int main(int argc, char** argv)
     for (int i = 0; i < 13; i++) printf("%-24s %10llu  %.3f/sym\n", names[i], g_path[i], (double)g_path[i] / n);
     printf("loads per symbol: ctx %.3f  state %.3f  state-list %.3f  u8 %.3f  u16 %.3f  u32 %.3f  u32h %.3f   | stores %.3f\n", (double)g_ld[0] / n, (double)g_ld[1] / n,
            (double)g_ld[2] / n, (double)g_ld[3] / n, (double)g_ld[4] / n, (double)g_ld[5] / n, (double)g_ld[6] / n, (double)g_st / n);
+    const char* regions[] = {"main loop (ctx loads, input)", "encode in first context", "UpdateModel body", "CreateSuccessors", "ReduceOrder", "rescale", "allocator", "allocator rare paths", "encode after escape (sym2)", "StartModel"};
+    printf("memory operations by region (host build: a state list costs one operation per state here, one per 64 states on the device)\n");
+    for (int i = 0; i < 10; i++) printf("  %-34s calls %9llu  ops %10llu  %.3f/sym  %.1f per call\n", regions[i], g_region_calls[i], g_region_ops[i], (double)g_region_ops[i] / n, g_region_calls[i] ? (double)g_region_ops[i] / g_region_calls[i] : 0.0);
     return 0;
 }
