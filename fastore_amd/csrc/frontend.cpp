@@ -180,7 +180,8 @@ struct BinEncoder::Impl {
     bool pe = false, hasHeaders = false;
     int8_t dnaToIdx[128];
 
-    const Batch* B = nullptr;
+    const Batch* B = nullptr;         // bases, qualities, headers, records
+    const Batch* G = nullptr;         // stored graph tables (nodes, top nodes, exact-match records, sub-trees); may be B
     BinStreams* out = nullptr;
     uint32_t recBase = 0, curSig = 0;
     std::vector<VRec> vrecs;
@@ -833,7 +834,7 @@ struct BinEncoder::Impl {
         const int32_t rootV = nodes[n].vrec;
         const std::vector<uint32_t> treeList = nodes[n].trees;      // copy: nodes may reallocate below
         for (uint32_t t : treeList) {
-            const TreeIn& tree = B->trees[t];
+            const TreeIn& tree = G->trees[t];
             consStack.push_back(ConsEnc());
             consStack.back().lastMinimPos = tree.mainSignaturePos;
             const uint32_t rl = seqLen(rootV);
@@ -877,31 +878,31 @@ struct BinEncoder::Impl {
     void initNodes(const BinIn& bin)
     {
         // node table: Batch nodes [nodeBase, nodeEnd) of this bin; bins own contiguous node ranges
-        nodeBase = B->topNodes[bin.topBegin];
+        nodeBase = G->topNodes[bin.topBegin];
         uint32_t nodeEnd = nodeBase;
-        for (uint32_t k = 0; k < bin.topCount; ++k) nodeEnd = std::max(nodeEnd, B->topNodes[bin.topBegin + k] + 1);
+        for (uint32_t k = 0; k < bin.topCount; ++k) nodeEnd = std::max(nodeEnd, G->topNodes[bin.topBegin + k] + 1);
         // sub-tree nodes are allocated after their owner, so scan trees reachable from the range
         for (uint32_t i = nodeBase; i < nodeEnd; ++i) {
-            const NodeIn& ni = B->nodes[i];
-            for (uint32_t t = 0; t < ni.treeCount; ++t) nodeEnd = std::max(nodeEnd, B->trees[ni.treeBegin + t].nodeBegin + B->trees[ni.treeBegin + t].nodeCount);
+            const NodeIn& ni = G->nodes[i];
+            for (uint32_t t = 0; t < ni.treeCount; ++t) nodeEnd = std::max(nodeEnd, G->trees[ni.treeBegin + t].nodeBegin + G->trees[ni.treeBegin + t].nodeCount);
         }
         recBase = bin.recBegin;
         vrecs.resize(bin.recCount);
         for (uint32_t i = 0; i < bin.recCount; ++i) vrecs[i] = VRec{recBase + i, B->recs[recBase + i].minimPos};
         nodes.clear(); nodes.resize(nodeEnd - nodeBase);
         for (uint32_t i = nodeBase; i < nodeEnd; ++i) {
-            const NodeIn& ni = B->nodes[i]; Node& n = nodes[i - nodeBase];
+            const NodeIn& ni = G->nodes[i]; Node& n = nodes[i - nodeBase];
             n.vrec = (int32_t)(ni.rec - recBase);
-            if (ni.emCount) { n.hasEm = true; n.em.resize(ni.emCount); for (uint32_t k = 0; k < ni.emCount; ++k) n.em[k] = (int32_t)(B->emRecs[ni.emBegin + k] - recBase); }
+            if (ni.emCount) { n.hasEm = true; n.em.resize(ni.emCount); for (uint32_t k = 0; k < ni.emCount; ++k) n.em[k] = (int32_t)(G->emRecs[ni.emBegin + k] - recBase); }
             if (ni.treeCount) { n.trees.resize(ni.treeCount); for (uint32_t k = 0; k < ni.treeCount; ++k) n.trees[k] = ni.treeBegin + k; }
         }
         contigs.clear();
     }
 
-    void encodeLz(const Batch& batch, const BinIn& bin, const ArchiveParams& arch, BinStreams& o)
+    void encodeLz(const Batch& batch, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, BinStreams& o)
     {
         setArchive(arch);
-        B = &batch; out = &o; curSig = bin.signature;
+        B = &batch; G = &graph; out = &o; curSig = bin.signature;
         o.reset(pe ? S_PE_COUNT : S_SE_COUNT);
         if (cfg.quaParams.method == MET_QVZ) well.reset(arch.qvz.wellSeed);
         initNodes(bin);
@@ -911,7 +912,7 @@ struct BinEncoder::Impl {
         if (pe) { matchRlePE.start(&o.s[S_MatchRlePE]); resetPair(); }
         // CompressRecords (FastqCompressor.cpp:1228-1276): sort the top-level nodes, match, then per root contigs + BFS
         std::vector<int32_t> order(bin.topCount);
-        for (uint32_t k = 0; k < bin.topCount; ++k) order[k] = (int32_t)(B->topNodes[bin.topBegin + k] - nodeBase);
+        for (uint32_t k = 0; k < bin.topCount; ++k) order[k] = (int32_t)(G->topNodes[bin.topBegin + k] - nodeBase);
         introsort(order.data(), order.size(), [&](int32_t a, int32_t b) { return compareReads(nodes[a].vrec, nodes[b].vrec); });
         std::vector<int32_t> roots;
         constructMatchTree(order, roots, -1);
@@ -943,6 +944,7 @@ namespace fs {
 
 BinEncoder::BinEncoder(const PackParams& par) : impl_(new Impl(par)) {}
 BinEncoder::~BinEncoder() { if (impl_) impl_->dropPairState(); delete impl_; }
-void BinEncoder::encodeLz(const Batch& batch, const BinIn& bin, const ArchiveParams& arch, BinStreams& out) { impl_->encodeLz(batch, bin, arch, out); }
+void BinEncoder::encodeLz(const Batch& batch, const BinIn& bin, const ArchiveParams& arch, BinStreams& out) { impl_->encodeLz(batch, batch, bin, arch, out); }
+void BinEncoder::encodeLz(const Batch& data, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, BinStreams& out) { impl_->encodeLz(data, graph, bin, arch, out); }
 
 }  // namespace fs

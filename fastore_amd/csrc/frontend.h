@@ -59,6 +59,8 @@ public:
     explicit BinEncoder(const PackParams& par);
     // standard bin: LzCompressorSE/PE::Compress up to (not including) CompressBuffers
     void encodeLz(const Batch& batch, const BinIn& bin, const ArchiveParams& arch, BinStreams& out);
+    // the same with the bin's stored graph in a batch of its own (node indices local to `graph`, record indices into `data`)
+    void encodeLz(const Batch& data, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, BinStreams& out);
 
 private:
     struct Impl;

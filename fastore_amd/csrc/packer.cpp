@@ -4,6 +4,8 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <memory>
 #include <chrono>
 #include <stdexcept>
@@ -169,31 +171,49 @@ void Context::gatherBlocks()
 
 void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& binArch)
 {
-    using namespace fsdev;
     const uint32_t nBins = (uint32_t)batch.bins.size();
+    std::vector<uint64_t> weight(nBins);
+    for (uint32_t b = 0; b < nBins; ++b) weight[b] = batch.bins[b].recCount;
+    compressBins(nBins, weight, binArch, [&](uint32_t b, BinEncoder& enc, BinStreams& out, BinIn& info, uint64_t& recBytes) {
+        info = batch.bins[b];
+        enc.encodeLz(batch, info, archives[binArch[b]], out);
+        uint64_t a = 0;
+        for (uint32_t r = info.recBegin; r < info.recBegin + info.recCount; ++r) { const Rec& rc = batch.recs[r]; a += 2ull * (rc.seqLen + rc.auxLen) + rc.headLen; }
+        recBytes = a;
+    });
+}
+
+// The front end of the bins runs as one stream of tasks over the host threads (largest bins first); the bins are cut
+// into slices, and the moment the last bin of a slice is done its lane thread builds the slice's stream items, stages
+// them and runs the device call -- so the host front end of the later slices, the staging and the device work of the
+// earlier ones all overlap, and the kernels of consecutive slices overlap on the device (shared arena pool).
+void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, const std::vector<uint32_t>& binArch, const BinProducer& produce)
+{
+    using namespace fsdev;
     blocks.clear(); blockSizes.assign(nBins, 0); blockSlice.assign(nBins, 0); blockOff.assign(nBins, 0);
     if (nBins == 0) return;
     const double t0 = nowMs();
     const bool trace = getenv("FS_TRACE") != nullptr;
     if (streamPool.size() < nBins) streamPool.resize(nBins);
     std::vector<BinStreams>& st = streamPool;
+    std::vector<BinIn> info(nBins); std::vector<uint64_t> recBytes(nBins, 0);
     // largest bins first: their streams are the longest (a launch ends with its longest stream) and the front end of
     // a bin is sequential, so a big bin started last would be the tail on the host too
     std::vector<uint32_t> byWork(nBins);
     for (uint32_t b = 0; b < nBins; ++b) byWork[b] = b;
-    std::sort(byWork.begin(), byWork.end(), [&](uint32_t x, uint32_t y) { return batch.bins[x].recCount > batch.bins[y].recCount; });
-    uint64_t totalRecs = 0;
-    for (const BinIn& b : batch.bins) totalRecs += b.recCount;
-    // slice boundaries by cumulated records: a small first slice starts the device early, the rest keeps it fed
+    std::sort(byWork.begin(), byWork.end(), [&](uint32_t x, uint32_t y) { return weight[x] > weight[y]; });
+    uint64_t totalW = 0;
+    for (uint64_t w : weight) totalW += w;
+    // slice boundaries by cumulated weight: a small first slice starts the device early, the rest keeps it fed
     std::vector<uint32_t> cut{0};
-    const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalRecs >= 200000) ? 5u : 1u);
+    const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? 5u : 1u);
     if (wantSlices > 1) {
         static const double kFrac5[] = {0.10, 0.30, 0.55, 0.80, 1.0};
         uint64_t acc = 0; uint32_t k = 0;
         for (uint32_t i = 0; i < nBins && k + 1 < wantSlices; ++i) {
-            acc += batch.bins[byWork[i]].recCount;
+            acc += weight[byWork[i]];
             const double f = wantSlices == 5 ? kFrac5[k] : (double)(k + 1) / wantSlices;
-            if ((double)acc >= f * (double)totalRecs && i + 1 < nBins) { cut.push_back(i + 1); ++k; }
+            if ((double)acc >= f * (double)totalW && i + 1 < nBins) { cut.push_back(i + 1); ++k; }
         }
     }
     cut.push_back(nBins);
@@ -205,25 +225,30 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
 
     struct Slice {
         std::vector<StreamItem> items; std::vector<BlockPlan> plans; std::vector<uint64_t> sizes;
-        fsengine::BatchTiming timing; std::string err; std::thread th; double tSubmit = 0, tDone = 0;
+        fsengine::BatchTiming timing; std::string err; std::thread th; double tReady = 0, tSubmit = 0, tDone = 0;
+        std::mutex mx; std::condition_variable cv; uint32_t pending = 0; bool done = false;
     };
     std::vector<Slice> slices(nSlices);
+    std::vector<uint32_t> sliceOf(nBins);
+    for (uint32_t si = 0; si < nSlices; ++si) { slices[si].pending = cut[si + 1] - cut[si]; for (uint32_t k = cut[si]; k < cut[si + 1]; ++k) sliceOf[k] = si; }
     sliceBlocks.resize(std::max<size_t>(sliceBlocks.size(), nSlices));
-    std::vector<std::unique_ptr<BinEncoder>> encs(hostThreads);
-    auto joinAll = [&]() { for (Slice& s : slices) if (s.th.joinable()) s.th.join(); };
-    double feMs = 0;
-    try {
-        for (uint32_t si = 0; si < nSlices; ++si) {
-            Slice& S = slices[si];
+    std::atomic<bool> abort(false);
+
+    auto runSlice = [&](uint32_t si) {
+        Slice& S = slices[si];
+        {   // the slice's bins have all been through the front end
+            std::unique_lock<std::mutex> lk(S.mx);
+            S.cv.wait(lk, [&]() { return S.pending == 0 || abort.load(); });
+        }
+        if (si >= nLanes) {   // the lane is still busy with an earlier slice
+            Slice& P = slices[si - nLanes];
+            std::unique_lock<std::mutex> lk(P.mx);
+            P.cv.wait(lk, [&]() { return P.done || abort.load(); });
+        }
+        if (abort.load()) return;
+        S.tReady = nowMs();
+        try {
             const uint32_t first = cut[si], count = cut[si + 1] - cut[si];
-            const double tf = nowMs();
-            parallelFor(count, hostThreads, [&](uint32_t k, uint32_t tid) {
-                const uint32_t b = byWork[first + k];
-                if (!encs[tid]) encs[tid].reset(new BinEncoder(par));
-                encs[tid]->encodeLz(batch, batch.bins[b], archives[binArch[b]], st[b]);
-            });
-            feMs += nowMs() - tf;
-            // ---- stream items and block plans of the slice ----
             S.plans.resize(count);
             uint64_t inBytes = 0;
             // --lossy libraries: one read-only model blob per library in front of the streams
@@ -236,7 +261,7 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
             }
             for (uint32_t k = 0; k < count; ++k) {
                 const uint32_t b = byWork[first + k];
-                const BinIn& bin = batch.bins[b]; BinStreams& bs = st[b];
+                const BinIn& bin = info[b]; BinStreams& bs = st[b];
                 const BinModuleConfigRaw& binCfg = archives[binArch[b]].cfg;
                 const uint32_t qm = binCfg.quaParams.method;
                 BlockPlan& pl = S.plans[k]; memset(&pl, 0, sizeof pl);
@@ -265,15 +290,12 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
                     inBytes += (bytes + 15) & ~15ull;
                 }
             }
-            // ---- the lane of this slice: wait for the slice that used it before, stage, submit ----
-            const uint32_t li = si % nLanes;
-            if (si >= nLanes && slices[si - nLanes].th.joinable()) slices[si - nLanes].th.join();
-            fsengine::Device* L = lanes[li];
-            const double ts = nowMs();
+            fsengine::Device* L = lanes[si % nLanes];
             uint8_t* input = fsengine::staging_buffer(L, inBytes + 16);        // pinned host memory owned by the lane
             if (!input) throw std::runtime_error(std::string("device: ") + L->err);
             for (size_t a = 0; a < archives.size(); ++a) if (qvzOff[a] != ~0ull) memcpy(input + qvzOff[a], archives[a].qvz.blob.data(), archives[a].qvz.blob.size());
-            parallelFor(count, hostThreads, [&](uint32_t k, uint32_t) {
+            // staging copy on a few helper threads of its own (the host threads are busy with the next slices' front end)
+            parallelFor(count, 4, [&](uint32_t k, uint32_t) {
                 const BlockPlan& pl = S.plans[k]; const uint32_t b = byWork[first + k];
                 for (uint32_t s = 0; s < pl.n_streams; ++s) {
                     const auto& v = st[b].s[s];
@@ -281,16 +303,35 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
                 }
             });
             S.tSubmit = nowMs();
-            if (trace) fprintf(stderr, "[trace] slice %u/%u: %u bins, front end %.1f ms, stage %.1f ms (%.1f MB), submitted at %.1f ms on lane %u\n",
-                               si + 1, nSlices, count, ts - tf, S.tSubmit - ts, inBytes / 1e6, S.tSubmit - t0, li);
-            std::vector<uint8_t>* outBlocks = &sliceBlocks[si];
-            S.th = std::thread([&S, L, input, inBytes, outBlocks]() {
-                if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, *outBlocks, S.sizes, &S.timing) != 0) S.err = std::string("device: ") + L->err;
-                S.tDone = nowMs();
-            });
-        }
+            if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, sliceBlocks[si], S.sizes, &S.timing) != 0) S.err = std::string("device: ") + L->err;
+        } catch (const std::exception& e) { S.err = e.what(); }
+        S.tDone = nowMs();
+        { std::lock_guard<std::mutex> lk(S.mx); S.done = true; }
+        S.cv.notify_all();
+    };
+    for (uint32_t si = 0; si < nSlices; ++si) slices[si].th = std::thread(runSlice, si);
+    auto joinAll = [&]() { for (Slice& s : slices) if (s.th.joinable()) s.th.join(); };
+
+    std::vector<std::unique_ptr<BinEncoder>> encs(hostThreads);
+    const double tf = nowMs();
+    try {
+        parallelFor(nBins, hostThreads, [&](uint32_t k, uint32_t tid) {
+            const uint32_t b = byWork[k];
+            if (!encs[tid]) encs[tid].reset(new BinEncoder(par));
+            produce(b, *encs[tid], st[b], info[b], recBytes[b]);
+            Slice& S = slices[sliceOf[k]];
+            bool last;
+            { std::lock_guard<std::mutex> lk(S.mx); last = --S.pending == 0; }
+            if (last) S.cv.notify_all();
+        });
+    } catch (...) {
+        abort.store(true);
+        for (Slice& s : slices) { std::lock_guard<std::mutex> lk(s.mx); s.cv.notify_all(); }
         joinAll();
-    } catch (...) { joinAll(); throw; }
+        throw;
+    }
+    const double feMs = nowMs() - tf;
+    joinAll();
     for (Slice& S : slices) if (!S.err.empty()) throw std::runtime_error(S.err);
     stats.frontend_ms += feMs;
     for (uint32_t si = 0; si < nSlices; ++si) {
@@ -303,16 +344,13 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
         timing.encode_ms += S.timing.encode_ms; timing.assemble_ms += S.timing.assemble_ms; timing.launches += S.timing.launches; timing.items += S.timing.items;
         timing.ppmd_symbols += S.timing.ppmd_symbols; timing.rc_symbols += S.timing.rc_symbols; timing.restarts += S.timing.restarts;
         timing.h2d_bytes += S.timing.h2d_bytes; timing.d2h_bytes += S.timing.d2h_bytes;
-        if (trace) fprintf(stderr, "[trace] slice %u done at %.1f ms (device call %.1f ms, kernel %.1f ms)\n", si + 1, S.tDone - t0, S.tDone - S.tSubmit, S.timing.encode_ms);
+        if (trace) fprintf(stderr, "[trace] slice %u/%u: %u bins, front end done at %.1f ms, staged+submitted at %.1f ms, device done at %.1f ms (kernel %.1f ms)\n",
+                           si + 1, nSlices, cut[si + 1] - cut[si], S.tReady - t0, S.tSubmit - t0, S.tDone - t0, S.timing.encode_ms);
     }
-    if (trace) fprintf(stderr, "[trace] batch: %u bins in %u slices on %u lanes, front end %.1f ms, total %.1f ms\n", nBins, nSlices, nLanes, feMs, nowMs() - t0);
+    if (trace) fprintf(stderr, "[trace] batch: %u bins in %u slices on %u lanes, host tasks %.1f ms, total %.1f ms\n", nBins, nSlices, nLanes, feMs, nowMs() - t0);
     stats.bins += nBins;
-    for (uint32_t b = 0; b < nBins; ++b) {
-        const BinIn& bin = batch.bins[b];
-        uint64_t a = blockSizes[b];
-        for (uint32_t r = bin.recBegin; r < bin.recBegin + bin.recCount; ++r) { const Rec& rc = batch.recs[r]; a += 2ull * (rc.seqLen + rc.auxLen) + rc.headLen; }
-        stats.algorithmic_bytes += a;
-    }
+    binInfo.swap(info);
+    for (uint32_t b = 0; b < nBins; ++b) { stats.records += binInfo[b].recCount; stats.algorithmic_bytes += blockSizes[b] + recBytes[b]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -449,54 +487,38 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                 bases += add; ++next;
             }
             const uint32_t nb = (uint32_t)(next - first);
-            // record arrays are placed: their sizes are in the .bmeta footer, so every bin knows its offsets up front
-            std::vector<uint64_t> seqBase(nb + 1, 0), headBase(nb + 1, 0), recBase(nb + 1, 0);
+            // record arrays are placed: their sizes are in the .bmeta footer, so every bin knows its offsets up front and
+            // is unpacked by the same host task that runs its front end (no barrier between the two stages)
+            std::vector<uint64_t> seqBase(nb + 1, 0), headBase(nb + 1, 0), recBase(nb + 1, 0), weight(nb);
             for (uint32_t k = 0; k < nb; ++k) {
                 const BinInfo& bi = libs[work[first + k].lib]->bf.bins().at(work[first + k].sig);
                 seqBase[k + 1] = seqBase[k] + bi.totalRawDnaSize; headBase[k + 1] = headBase[k] + bi.totalRawHeadSize; recBase[k + 1] = recBase[k] + bi.totalRecordsCount;
+                weight[k] = bi.totalRecordsCount;
             }
             if (seqBase[nb] > 0xFFFFFFF0ull || headBase[nb] > 0xFFFFFFF0ull || recBase[nb] > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB");
             batch.seq.resize(seqBase[nb]); batch.qua.resize(seqBase[nb]); batch.head.resize(headBase[nb]); batch.recs.resize(recBase[nb]);
-            const uint32_t chunks = std::min<uint32_t>(nb, std::max(1u, 4u * hostThreads));
-            std::vector<Batch> parts(chunks);
-            parallelFor(chunks, hostThreads, [&](uint32_t c, uint32_t) {
-                for (size_t k = (size_t)nb * c / chunks; k < (size_t)nb * (c + 1) / chunks; ++k)
-                    libs[work[first + k].lib]->bf.unpackPlaced(work[first + k].sig, batch, seqBase[k], headBase[k], (uint32_t)recBase[k], parts[c]);
-            });
-            const double tUnpack = nowMs() - tio;
-            {   // graph tables: concatenate the per-chunk parts (node indices re-based; record indices are already global)
-                std::vector<uint64_t> oNode(chunks + 1, 0), oTop(chunks + 1, 0), oEm(chunks + 1, 0), oTree(chunks + 1, 0), oBin(chunks + 1, 0);
-                for (uint32_t c = 0; c < chunks; ++c) {
-                    oNode[c + 1] = oNode[c] + parts[c].nodes.size(); oTop[c + 1] = oTop[c] + parts[c].topNodes.size(); oEm[c + 1] = oEm[c] + parts[c].emRecs.size();
-                    oTree[c + 1] = oTree[c] + parts[c].trees.size(); oBin[c + 1] = oBin[c] + parts[c].bins.size();
-                }
-                batch.nodes.resize(oNode[chunks]); batch.topNodes.resize(oTop[chunks]); batch.emRecs.resize(oEm[chunks]); batch.trees.resize(oTree[chunks]); batch.bins.resize(oBin[chunks]);
-                parallelFor(chunks, hostThreads, [&](uint32_t c, uint32_t) {
-                    Batch& o = parts[c];
-                    const uint32_t nb2 = (uint32_t)oNode[c], tb = (uint32_t)oTop[c], eb = (uint32_t)oEm[c], trb = (uint32_t)oTree[c];
-                    for (size_t i = 0; i < o.nodes.size(); ++i) { NodeIn n = o.nodes[i]; n.emBegin += eb; n.treeBegin += trb; batch.nodes[nb2 + i] = n; }
-                    for (size_t i = 0; i < o.topNodes.size(); ++i) batch.topNodes[tb + i] = o.topNodes[i] + nb2;
-                    for (size_t i = 0; i < o.emRecs.size(); ++i) batch.emRecs[eb + i] = o.emRecs[i];
-                    for (size_t i = 0; i < o.trees.size(); ++i) { TreeIn t = o.trees[i]; t.nodeBegin += nb2; batch.trees[trb + i] = t; }
-                    for (size_t i = 0; i < o.bins.size(); ++i) { BinIn b = o.bins[i]; b.topBegin += tb; batch.bins[oBin[c] + i] = b; }
-                    o = Batch();
-                });
-            }
+            std::vector<Batch> graph(nb);                              // per bin: its stored graph (node indices local to it)
             for (size_t k = first; k < next; ++k) binArch.push_back(work[k].lib);
             stats.io_ms += nowMs() - tio;
-            if (getenv("FS_TRACE")) fprintf(stderr, "[trace] unpack %.1f ms, concatenate %.1f ms (%u bins, %.1f MB bases)\n", tUnpack, nowMs() - tio - tUnpack, nb, bases / 1e6);
-            compressBatch(batch, binArch);
-            for (size_t b = 0; b < batch.bins.size();) {              // route the blocks to their libraries (runs of equal lib)
+            compressBins(nb, weight, binArch, [&](uint32_t k, BinEncoder& enc, BinStreams& out, BinIn& info, uint64_t& recBytes) {
+                const Work& w = work[first + k];
+                libs[w.lib]->bf.unpackPlaced(w.sig, batch, seqBase[k], headBase[k], (uint32_t)recBase[k], graph[k]);
+                info = graph[k].bins.at(0);
+                enc.encodeLz(batch, graph[k], info, archives[w.lib], out);
+                recBytes = 2ull * (seqBase[k + 1] - seqBase[k]) + (headBase[k + 1] - headBase[k]);
+                graph[k] = Batch();
+            });
+            const double tRoute = nowMs();
+            for (size_t b = 0; b < nb;) {                              // route the blocks to their libraries (runs of equal lib)
                 const uint32_t l = binArch[b]; Lib::Pending p;
                 size_t e = b; uint64_t bytes = 0;
-                while (e < batch.bins.size() && binArch[e] == l) { p.sizes.push_back(blockSizes[e]); p.sigs.push_back(batch.bins[e].signature); bytes += blockSizes[e]; ++e; }
+                while (e < nb && binArch[e] == l) { p.sizes.push_back(blockSizes[e]); p.sigs.push_back(binInfo[e].signature); bytes += blockSizes[e]; ++e; }
                 p.data.resize(bytes);
                 uint64_t off = 0;
                 for (size_t k = b; k < e; ++k) { memcpy(p.data.data() + off, blockData((uint32_t)k), blockSizes[k]); off += blockSizes[k]; }
                 libs[l]->pending.push_back(std::move(p)); b = e;
             }
-            done += batch.bins.size();
-            const double tRoute = nowMs();
+            done += nb;
             tio = nowMs();
             for (auto& L : libs) flush(*L, false);
             stats.io_ms += nowMs() - tio;

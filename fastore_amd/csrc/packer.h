@@ -2,6 +2,7 @@
 // blocks; plus the merged small-bins/N block and the archive writer (drop-in boundary).
 #pragma once
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../include/fastore_amd.h"
@@ -53,6 +54,11 @@ struct Context {
 
     // standard bins of `batch` -> blocks/blockSizes (bin order); binArch[b] = index into `archives`
     void compressBatch(const Batch& batch, const std::vector<uint32_t>& binArch);
+    // the same with the bins produced on demand: produce(b, encoder, streams, info, recBytes) runs the front end of bin b
+    // (after unpacking it, for the file path) on one of the host threads
+    typedef std::function<void(uint32_t, BinEncoder&, BinStreams&, BinIn&, uint64_t&)> BinProducer;
+    void compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, const std::vector<uint32_t>& binArch, const BinProducer& produce);
+    std::vector<BinIn> binInfo;                   // per bin of the last compressBins call
     // merged small bins + N bin (batch with ONE bin, records already in stored order): RawCompressorSE/PE
     void compressRawBlock(Batch& batch, const ArchiveParams& arch, std::vector<uint8_t>& out) const;
     // `fastore_pack e` for one or several libraries; bins of all libraries share the device batches

@@ -316,7 +316,7 @@ FS_DEV void StartModelRare(Coder& m)
         int s = 0;
         for (int b = 0; b < 6; ++b) s += kEscCoef[2 * b + ((k >> b) & 1u)];
         s = 128 * (s < 32 ? 32 : (s > 256 - 32 ? 256 - 32 : s));
-        uint32_t kk = 0; while (m.sh->QT[kk] <= i) kk++;              // first k with QTable[k] > i
+        uint32_t kk = 0; while (FS_UNI(m.sh->QT[kk]) <= i) kk++;              // first k with QTable[k] > i
         m.sh->BinSumm[e] = (uint16_t)(BIN_SCALE - s / (int)(kk + 1));
     }
     for (uint32_t e = (uint32_t)FS_LANE(); e < 23u * 32u; e += FS_WAVE) {
@@ -362,9 +362,9 @@ FS_DEV Hit find_in(Coder& m, const Ctx& pc, uint32_t sym)
 }
 
 // CreateSuccessors (Model.cpp:282-337).  p/pSucc: state to start from in the suffix of pc (0 = none) and its successor.
-// pcRec / sufRec: register copies of the records of pc and (when p != 0) of its suffix, when the caller holds them
+// haveRecs: pcRec / sufRec are register copies of the records of pc and (when p != 0) of its suffix
 FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc, uint32_t pc, uint32_t fsSym, uint32_t fsSucc,
-                                 const Ctx* pcRec = nullptr, const Ctx* sufRec = nullptr)
+                                 bool haveRecs, const Ctx& pcRec, const Ctx& sufRec)
 {
     FS_REGION(3);
     FS_PATH(g_path[9]);
@@ -372,7 +372,7 @@ FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc
     uint32_t ps[MAX_ORDER + 1]; uint32_t pps = 0;
     uint32_t cf, s0, tmp;
     uint32_t sym = fsSym;
-    Ctx P = pcRec ? *pcRec : ctx_load(m, pc);
+    Ctx P; if (haveRecs) P = pcRec; else P = ctx_load(m, pc);
     bool toLoop = true;
     if (!Skip) {
         ps[pps++] = m.FoundState;
@@ -380,7 +380,7 @@ FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc
     }
     if (toLoop) {
         bool first = (p != 0);
-        if (first) { pc = P.suff; P = sufRec ? *sufRec : ctx_load(m, pc); }
+        if (first) { pc = P.suff; if (haveRecs) P = sufRec; else P = ctx_load(m, pc); }
         do {
             if (!first) {
                 pc = P.suff; P = ctx_load(m, pc);
@@ -449,7 +449,7 @@ FS_DEV uint32_t ReduceOrder(Coder& m, uint32_t p, uint32_t pSucc, uint32_t pc)
     }
     if (pSucc <= iUpBranch) {
         const uint32_t p1 = m.FoundState; m.FoundState = p;
-        pSucc = CreateSuccessors(m, false, 0, 0, pc, sym, pSucc);
+        pSucc = CreateSuccessors(m, false, 0, 0, pc, sym, pSucc, true, P, P);
         S_SUCC_SET(p, pSucc);
         m.FoundState = p1;
     }
@@ -589,7 +589,7 @@ FS_DEV_NOINLINE void rescale_serial(Coder& m, uint32_t c)
     C_FLAGS_SET(c, C_FLAGS(c) | 0x04u);
 }
 
-FS_DEV void UpdateModel(Coder& m, uint32_t MinContext, const Ctx& mcMin, const Ctx* sufRec)
+FS_DEV void UpdateModel(Coder& m, uint32_t MinContext, const Ctx& mcMin, bool haveSuf, const Ctx& sufRec)
 {
     FS_REGION(2);
     FS_PATH(g_path[8]);
@@ -601,7 +601,7 @@ FS_DEV void UpdateModel(Coder& m, uint32_t MinContext, const Ctx& mcMin, const C
     Ctx P; P.ns = 0; P.flags = 0; P.sf = 0; P.w1 = 0; P.suff = 0; P.oneSym = 0; P.oneFreq = 0;
     if (mcMin.suff) {
         pc = mcMin.suff;
-        P = sufRec ? *sufRec : ctx_load(m, pc);
+        if (haveSuf) P = sufRec; else P = ctx_load(m, pc);
         if (P.ns) {
             Hit h = find_in(m, P, FSymbol);
             p = h.p; pSucc = h.succ;
@@ -616,7 +616,7 @@ FS_DEV void UpdateModel(Coder& m, uint32_t MinContext, const Ctx& mcMin, const C
     }
     pc = m.MaxContext;
     if (!m.OrderFall && iFSuccessor) {
-        const uint32_t sx = CreateSuccessors(m, true, p, pSucc, MinContext, FSymbol, iFSuccessor, &mcMin, &P);
+        const uint32_t sx = CreateSuccessors(m, true, p, pSucc, MinContext, FSymbol, iFSuccessor, true, mcMin, P);
         S_SUCC_SET(m.FoundState, sx);
         if (!sx) { RestoreModelRare(m); return; }
         m.MaxContext = sx; return;
@@ -624,7 +624,7 @@ FS_DEV void UpdateModel(Coder& m, uint32_t MinContext, const Ctx& mcMin, const C
     fs_st8(HP(m.pText), FSymbol); m.pText++; iSuccessor = m.pText;
     if (m.pText >= m.UnitsStart) { RestoreModelRare(m); return; }
     if (iFSuccessor) {
-        if (iFSuccessor < m.UnitsStart) iFSuccessor = CreateSuccessors(m, false, p, pSucc, MinContext, FSymbol, iFSuccessor, &mcMin, &P);
+        if (iFSuccessor < m.UnitsStart) iFSuccessor = CreateSuccessors(m, false, p, pSucc, MinContext, FSymbol, iFSuccessor, true, mcMin, P);
     } else iFSuccessor = ReduceOrder(m, p, pSucc, MinContext);
     if (!iFSuccessor) { RestoreModelRare(m); return; }
     if (!--m.OrderFall) { iSuccessor = iFSuccessor; m.pText -= (m.MaxContext != MinContext); }
@@ -642,7 +642,7 @@ FS_DEV void UpdateModel(Coder& m, uint32_t MinContext, const Ctx& mcMin, const C
                 if (!p) { restart = true; break; }
                 stats = p;
             }
-            summ = R.sf + (m.sh->QT[ns + 4] >> 3);
+            summ = R.sf + (FS_UNI(m.sh->QT[ns + 4]) >> 3);
         } else {
             p = AllocUnits(m, 1);
             if (!p) { restart = true; break; }
@@ -650,7 +650,7 @@ FS_DEV void UpdateModel(Coder& m, uint32_t MinContext, const Ctx& mcMin, const C
             fr = (fr <= MAX_FREQ / 3) ? (2 * fr - 1) : (MAX_FREQ - 15);
             state_store(m, p, R.oneSym | (fr << 8), R.w1);           // oneState moves into its own unit
             stats = p;
-            summ = fr + (ns > 1) + kExpEscape[m.sh->QT[m.BSumm >> 8]];
+            summ = fr + (ns > 1) + kExpEscape[FS_UNI(m.sh->QT[m.BSumm >> 8])];
         }
         cf = 2 * FFreq * (summ + 4u); sf = s0 + summ;
         if (cf <= 6 * sf) { cf = 1 + (cf > sf) + (cf > 3 * sf); summ += 4; }
@@ -683,7 +683,7 @@ FS_DEV void encodeBinSymbol(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufR
     const uint32_t rs = C_ONE(c);
     sufRec = ctx_load(m, mc.suff); sufCtx = mc.suff;
     const uint32_t sufNs = sufRec.ns;
-    const uint32_t idx = m.sh->QT[mc.oneFreq - 1] * 64u + NS2BSIndx(sufNs) + m.PrevSuccess + mc.flags + (uint32_t)((m.RunLength >> 26) & 0x20);
+    const uint32_t idx = FS_UNI(m.sh->QT[mc.oneFreq - 1]) * 64u + NS2BSIndx(sufNs) + m.PrevSuccess + mc.flags + (uint32_t)((m.RunLength >> 26) & 0x20);
     uint32_t bs = FS_UNI(m.sh->BinSumm[idx]);
     m.BSumm = (int32_t)bs;
     const uint32_t tmp = bs * (m.range >>= TOT_BITS);
@@ -713,7 +713,7 @@ FS_DEV void encodeSymbol1(Coder& m, uint32_t c, Ctx& mc, int symbol)
     LaneStates ls = lane_states(m, stats, ns, 0);
     for (;;) {
         const uint64_t hit = fs_ballot(ls.valid && (int)(ls.sf & 0xFFu) == symbol);
-        if (hit) { k = fs_ctz64(hit); LoCnt += fs_wave_sum8(ls.sf >> 8, ls.valid && (uint32_t)FS_LANE() < k); p = stats + 6u * (base + k); found = true; break; }
+        if (hit) { k = fs_ctz64(hit); if (k) LoCnt += fs_wave_sum8(ls.sf >> 8, ls.valid && (uint32_t)FS_LANE() < k); p = stats + 6u * (base + k); found = true; break; }
         LoCnt += fs_wave_sum8(ls.sf >> 8, ls.valid);
         if (base + FS_WAVE > ns) break;
         base += FS_WAVE; ls = lane_states(m, stats, ns, base);
@@ -768,7 +768,7 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
     uint32_t seeIdx = 0xFFFFFFFFu, see = 0;
     if (nsC != 0xFF) {
         const uint32_t sufNs = mc.suff ? sufRec.ns : 0u;
-        seeIdx = (m.sh->QT[nsC + 3] - 4u) * 32u + (mc.sf > 10u * (nsC + 1u)) + 2u * (2u * nsC < sufNs + m.NumMasked) + mc.flags;
+        seeIdx = (FS_UNI(m.sh->QT[nsC + 3]) - 4u) * 32u + (mc.sf > 10u * (nsC + 1u)) + 2u * (2u * nsC < sufNs + m.NumMasked) + mc.flags;
         see = FS_UNI(m.sh->SEE2[seeIdx]);
         const uint32_t shift = (see >> 16) & 0xFFu; uint32_t summ = see & 0xFFFFu;
         const uint32_t r = summ >> shift; summ = (summ - r) & 0xFFFFu;
@@ -853,39 +853,48 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
     m.pfCtx = 0; m.pf.a = m.pf.b = m.pf.d = 0;
     for (uint32_t MinContext = m.MaxContext;;) {
         int c = -1;
-        if (pos < n) {
-            if (wide && (pos | 3u) < n) {
+        if (FS_UB(pos < n)) {
+            if (FS_UB(wide && (pos | 3u) < n)) {
                 if ((pos & 3u) == 0) { cur = FS_UNI(nxt); if (pos + 7u < n) nxt = *(fs_cgptr32)(in + pos + 4u); }
                 c = (int)((cur >> (8u * (pos & 3u))) & 0xFFu);
             } else c = (int)fs_ld8(in + pos);
             pos++;
         }
+        // everything carried from symbol to symbol is wave-uniform by construction; saying so here keeps one value the
+        // compiler could not prove uniform from turning the whole loop body into exec-masked (divergent) code
+        MinContext = FS_UNI(MinContext); prevCtx = FS_UNI(prevCtx);
+        mc.ns = FS_UNI(mc.ns); mc.flags = FS_UNI(mc.flags); mc.sf = FS_UNI(mc.sf); mc.w1 = FS_UNI(mc.w1); mc.suff = FS_UNI(mc.suff); mc.oneSym = FS_UNI(mc.oneSym); mc.oneFreq = FS_UNI(mc.oneFreq);
+        m.OrderFall = (int32_t)FS_UNI(m.OrderFall); m.RunLength = (int32_t)FS_UNI(m.RunLength); m.pfCtx = FS_UNI(m.pfCtx);
+        m.low = FS_UNI(m.low); m.range = FS_UNI(m.range); m.NumMasked = FS_UNI(m.NumMasked); m.EscCount = FS_UNI(m.EscCount); m.PrevSuccess = FS_UNI(m.PrevSuccess);
+        m.pText = FS_UNI(m.pText); m.UnitsStart = FS_UNI(m.UnitsStart); m.LoUnit = FS_UNI(m.LoUnit); m.HiUnit = FS_UNI(m.HiUnit); m.outPos = FS_UNI(m.outPos);
+        m.MaxContext = FS_UNI(m.MaxContext); m.InitRL = (int32_t)FS_UNI(m.InitRL); m.BSumm = (int32_t)FS_UNI(m.BSumm); m.GlueCount = FS_UNI(m.GlueCount);
         // first context of the symbol: still in registers (a context that succeeded itself), requested during the
         // previous symbol, or fetched now
-        if (m.pfCtx == MinContext) mc = ctx_finish(m.pf);
-        else if (!(keep && MinContext == prevCtx)) mc = ctx_load(m, MinContext);
+        if (FS_UB(m.pfCtx == MinContext)) mc = ctx_finish(m.pf);
+        else if (FS_UB(!(keep && MinContext == prevCtx))) mc = ctx_load(m, MinContext);
         m.pfCtx = 0; keep = false; prevCtx = MinContext; sufCtx = 0;
+        mc.ns = FS_UNI(mc.ns); mc.flags = FS_UNI(mc.flags); mc.sf = FS_UNI(mc.sf); mc.w1 = FS_UNI(mc.w1); mc.suff = FS_UNI(mc.suff); mc.oneSym = FS_UNI(mc.oneSym); mc.oneFreq = FS_UNI(mc.oneFreq);
         FS_PATH(g_path[0]);
-        if (mc.ns) { FS_PATH(g_path[2]); encodeSymbol1(m, MinContext, mc, c); rc_encode(m); if (m.FoundState) { if (m.rLow == 0) FS_PATH(g_path[3]); else FS_PATH(g_path[4]); } }
+        if (FS_UB(mc.ns != 0)) { FS_PATH(g_path[2]); encodeSymbol1(m, MinContext, mc, c); rc_encode(m); if (m.FoundState) { if (m.rLow == 0) FS_PATH(g_path[3]); else FS_PATH(g_path[4]); } }
         else { FS_PATH(g_path[1]); encodeBinSymbol(m, MinContext, mc, c, sufRec, sufCtx); }
         bool stop = false;
-        while (!m.FoundState) {
+        while (FS_UB(!m.FoundState)) {
             rc_normalize(m);
             do {
-                if (!mc.suff) { stop = true; break; }
+                if (FS_UB(!mc.suff)) { stop = true; break; }
                 m.OrderFall++; MinContext = mc.suff;
-                if (sufCtx == MinContext) mc = sufRec; else mc = ctx_load(m, MinContext);
+                if (FS_UB(sufCtx == MinContext)) mc = sufRec; else mc = ctx_load(m, MinContext);
                 sufCtx = 0;
-            } while (mc.ns == m.NumMasked);
-            if (stop) break;
+            } while (FS_UB(mc.ns == m.NumMasked));
+            if (FS_UB(stop)) break;
             FS_PATH(g_path[5]);
             encodeSymbol2(m, MinContext, mc, c, sufRec, sufCtx); rc_encode(m);
             if (m.FoundState) FS_PATH(g_path[6]);
         }
-        if (stop) break;
+        if (FS_UB(stop)) break;
         const uint32_t succ = m.fsSucc;
-        if (!m.OrderFall && succ >= m.UnitsStart) { FS_PATH(g_path[7]); m.MaxContext = succ; keep = (succ == MinContext); }
-        else { UpdateModel(m, MinContext, mc, (sufCtx && sufCtx == mc.suff) ? &sufRec : nullptr); if (m.EscCount == 0) clear_mask(m); }
+        if (FS_UB(!m.OrderFall && succ >= m.UnitsStart)) { FS_PATH(g_path[7]); m.MaxContext = succ; keep = (succ == MinContext); }
+        else { UpdateModel(m, MinContext, mc, FS_UB(sufCtx && sufCtx == mc.suff), sufRec); if (FS_UB(m.EscCount == 0)) clear_mask(m); }
         rc_normalize(m); MinContext = m.MaxContext;
     }
     for (int i = 0; i < 4; i++) { put_byte(m, m.low >> 24); m.low <<= 8; }

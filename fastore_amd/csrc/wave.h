@@ -30,6 +30,9 @@
   #define FS_LANE() ((int)(threadIdx.x & 63))
   // make a loaded value wave-uniform (it already is by construction; this moves it to an SGPR)
   #define FS_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+  // a wave-uniform condition, said so (a branch the compiler takes for divergent is compiled with exec masking and
+  // drags every value merged behind it into vector registers)
+  #define FS_UB(c) (__builtin_amdgcn_readfirstlane((int)(c)) != 0)
   // order this wave's cooperative memory phase against the uniform code that follows it
   #define FS_WAVE_SYNC() __syncthreads()
 #else
@@ -40,6 +43,7 @@
   #define FS_WAVE 1
   #define FS_LANE() 0
   #define FS_UNI(x) ((uint32_t)(x))
+  #define FS_UB(c) (c)
   #define FS_WAVE_SYNC() ((void)0)
 #endif
 
@@ -81,10 +85,10 @@ FS_DEV uint32_t fs_ld32h(fs_cgptr p)   // 32-bit value at a 2-byte aligned addre
 { FS_CNT(g_ld[6]); return FS_UNI((uint32_t)((fs_cgptr16)p)[0] | ((uint32_t)((fs_cgptr16)p)[1] << 16)); }
 FS_DEV uint32_t fs_ld32(fs_cgptr p) { FS_CNT(g_ld[5]); return FS_UNI(*(fs_cgptr32)p); }
 #endif
-// Uniform stores are issued by ONE lane: a store executed by all 64 lanes to one address reaches the L2 as one write
-// request per 16-lane group (measured: 3.7 requests per store instruction, each forwarded to the fabric as a 32-byte
-// partial write), and occupies the texture-address unit for all 16 quads.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_ST1)
+// Uniform stores are executed by all lanes (same address, same value).  Issuing them from one lane (FS_ST1) was
+// measured: the same number of L1->L2 write requests and the same run time, but a divergent `if` per store, which
+// makes the compiler structurize the surrounding uniform control flow with exec masks (+14 % code).
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FS_ST1)
   #define FS_ONE_LANE if (FS_LANE() == 0)
 #else
   #define FS_ONE_LANE
@@ -96,7 +100,7 @@ FS_DEV void fs_st32(fs_gptr p, uint32_t v) { FS_CNT(g_st); FS_ONE_LANE *(fs_gptr
 FS_DEV void fs_st32h(fs_gptr p, uint32_t v)
 {
     FS_CNT(g_st);
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_ST1)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_ST48)
     const uint32_t l = (uint32_t)FS_LANE();
     if (l < 2u) ((fs_gptr16)p)[l] = (uint16_t)(l ? v >> 16 : v);
 #else
@@ -107,7 +111,7 @@ FS_DEV void fs_st32h(fs_gptr p, uint32_t v)
 FS_DEV void fs_st48(fs_gptr p, uint32_t w0, uint32_t w1, uint32_t w2)
 {
     FS_CNT(g_st);
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_ST1)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_ST48)
     const uint32_t l = (uint32_t)FS_LANE();
     if (l < 3u) ((fs_gptr16)p)[l] = (uint16_t)(l == 0u ? w0 : (l == 1u ? w1 : w2));
 #else
@@ -127,15 +131,20 @@ FS_DEV uint32_t fs_popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x)
 FS_DEV uint32_t fs_ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
 FS_DEV uint32_t fs_readlane(uint32_t v, uint32_t) { return v; }
 #endif
-// sum over the lanes with `pred` of an 8-bit value per lane: bit-sliced ballots + scalar popcounts,
-// no cross-lane data movement (8 x {v_cmp, s_bcnt1})
+// sum over the lanes with `pred` of a small value per lane: the DPP wave scan (row_shr 1/2/4/8 inside each row of 16,
+// then row_bcast:15 and row_bcast:31 carry the row totals on), total read from lane 63 -- 6 adds instead of the 8
+// ballot + popcount rounds of a bit-sliced sum
 FS_DEV uint32_t fs_wave_sum8(uint32_t v, bool pred)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t s = 0;
-    #pragma unroll
-    for (int b = 0; b < 8; ++b) s += fs_popc64(fs_ballot(pred && ((v >> b) & 1u))) << b;
-    return s;
+    int x = pred ? (int)v : 0;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 #else
     return pred ? v : 0u;
 #endif
