@@ -20,6 +20,10 @@ import subprocess
 import sys
 import time
 
+# the pack context runs one HIP stream per pipeline slice; they need their own hardware queues to overlap
+# (the runtime default is 4, shared round-robin) -- must be in the environment before HIP initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 REF = os.path.join(ROOT, "oracle", "_ref", "ref_driver")

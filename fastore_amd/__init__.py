@@ -43,6 +43,9 @@ class Stats(C.Structure):
 _lib = None
 
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one hardware queue per pipeline lane (see engine.hip)
+
+
 def load_library(path=None):
     """Load libfastore_amd.so (in-tree).  Raises FastoreError when it is missing."""
     global _lib

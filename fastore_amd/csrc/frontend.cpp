@@ -1,4 +1,7 @@
 #include "frontend.h"
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <string.h>
 #include <algorithm>
 #include <map>
@@ -256,7 +259,17 @@ struct BinEncoder::Impl {
         const uint8_t *s1 = s + recOff, *s2 = lz + lzOff;
         const uint32_t a = sLen - recOff, b = lzLen - lzOff, minLen = a < b ? a : b;
         int32_t cc = insertCost;
-        for (uint32_t i = 0; i < minLen && cc < res.cost; ++i) cc += (s1[i] != s2[i]) * par.mismatchCost;
+        uint32_t i = 0;
+#if defined(__SSE2__)
+        // 16 bases per step.  The scan may run past the base at which the cost first reaches res.cost, but the cost only
+        // grows, so the outcome (rejected) is the same; below res.cost the count is exact.
+        for (; i + 16 <= minLen && cc < res.cost; i += 16) {
+            const __m128i a = _mm_loadu_si128((const __m128i*)(s1 + i)), b = _mm_loadu_si128((const __m128i*)(s2 + i));
+            const uint32_t eq = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(a, b));
+            cc += (16 - (int32_t)__builtin_popcount(eq)) * par.mismatchCost;
+        }
+#endif
+        for (; i < minLen && cc < res.cost; ++i) cc += (s1[i] != s2[i]) * par.mismatchCost;
         if (cc < res.cost) { res.cost = cc; res.noMismatches = (cc - insertCost == 0); res.shift = shift; return true; }
         return false;
     }

@@ -312,7 +312,8 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     for (uint32_t si = 0; si < nSlices; ++si) slices[si].th = std::thread(runSlice, si);
     auto joinAll = [&]() { for (Slice& s : slices) if (s.th.joinable()) s.th.join(); };
 
-    std::vector<std::unique_ptr<BinEncoder>> encs(hostThreads);
+    std::vector<std::unique_ptr<BinEncoder>>& encs = encoders;        // kept across calls: their work buffers stay mapped
+    if (encs.size() < hostThreads) encs.resize(hostThreads);
     const double tf = nowMs();
     try {
         parallelFor(nBins, hostThreads, [&](uint32_t k, uint32_t tid) {
@@ -423,7 +424,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
     struct Lib {
         BinFile bf; ArchiveWriter aw;
         Batch b0; std::vector<uint8_t> block0; std::thread t0; std::string t0err; double t0ms = 0;
-        bool haveBlock0 = false, block0Written = true;
+        bool haveBlock0 = false, block0Written = true, finished = false;
         struct Pending { std::vector<uint8_t> data; std::vector<uint64_t> sizes; std::vector<uint32_t> sigs; };
         std::vector<Pending> pending;
     };
@@ -509,25 +510,53 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                 graph[k] = Batch();
             });
             const double tRoute = nowMs();
-            for (size_t b = 0; b < nb;) {                              // route the blocks to their libraries (runs of equal lib)
-                const uint32_t l = binArch[b]; Lib::Pending p;
-                size_t e = b; uint64_t bytes = 0;
-                while (e < nb && binArch[e] == l) { p.sizes.push_back(blockSizes[e]); p.sigs.push_back(binInfo[e].signature); bytes += blockSizes[e]; ++e; }
-                p.data.resize(bytes);
-                uint64_t off = 0;
-                for (size_t k = b; k < e; ++k) { memcpy(p.data.data() + off, blockData((uint32_t)k), blockSizes[k]); off += blockSizes[k]; }
-                libs[l]->pending.push_back(std::move(p)); b = e;
+            const bool lastBatch = next >= work.size();
+            if (!lastBatch) {
+                for (size_t b = 0; b < nb;) {                          // route the blocks to their libraries (runs of equal lib)
+                    const uint32_t l = binArch[b]; Lib::Pending p;
+                    size_t e = b; uint64_t bytes = 0;
+                    while (e < nb && binArch[e] == l) { p.sizes.push_back(blockSizes[e]); p.sigs.push_back(binInfo[e].signature); bytes += blockSizes[e]; ++e; }
+                    p.data.resize(bytes);
+                    uint64_t off = 0;
+                    for (size_t k = b; k < e; ++k) { memcpy(p.data.data() + off, blockData((uint32_t)k), blockSizes[k]); off += blockSizes[k]; }
+                    libs[l]->pending.push_back(std::move(p)); b = e;
+                }
+                tio = nowMs();
+                for (auto& L : libs) flush(*L, false);
+                stats.io_ms += nowMs() - tio;
+            } else {
+                // last batch: every library is finished by a task of its own -- block 0, what is pending, then this batch's
+                // blocks straight from the slice buffers (no routing copy), then the .cmeta footer
+                tio = nowMs();
+                std::vector<std::pair<size_t, size_t>> runOf(nLibs, {0, 0});
+                for (size_t b2 = 0; b2 < nb;) { size_t e = b2; while (e < nb && binArch[e] == binArch[b2]) ++e; runOf[binArch[b2]] = {b2, e}; b2 = e; }
+                std::mutex statMx;
+                parallelFor((uint32_t)nLibs, std::min<uint32_t>((uint32_t)nLibs, hostThreads), [&](uint32_t l, uint32_t) {
+                    Lib& L = *libs[l];
+                    if (!L.block0Written) {
+                        L.t0.join(); if (!L.t0err.empty()) throw std::runtime_error(L.t0err);
+                        { std::lock_guard<std::mutex> g(statMx); stats.block0_ms = std::max(stats.block0_ms, L.t0ms); stats.block0_bytes += L.block0.size(); stats.block0_records += L.b0.recs.size(); }
+                        L.aw.writeBlock(L.block0.data(), L.block0.size(), L.bf.nSignature());
+                        L.block0Written = true; L.b0.clear(); L.block0.clear(); L.block0.shrink_to_fit();
+                    }
+                    for (auto& p : L.pending) { uint64_t off = 0; for (size_t k = 0; k < p.sizes.size(); ++k) { L.aw.writeBlock(p.data.data() + off, p.sizes[k], p.sigs[k]); off += p.sizes[k]; } }
+                    L.pending.clear();
+                    for (size_t k = runOf[l].first; k < runOf[l].second; ++k) L.aw.writeBlock(blockData((uint32_t)k), blockSizes[k], binInfo[k].signature);
+                    L.aw.finish(archives[l].head, archives[l].qvz);
+                    L.finished = true;
+                });
+                stats.io_ms += nowMs() - tio;
             }
             done += nb;
-            tio = nowMs();
-            for (auto& L : libs) flush(*L, false);
-            stats.io_ms += nowMs() - tio;
             if (getenv("FS_TRACE")) fprintf(stderr, "[trace] route+write %.1f ms\n", nowMs() - tRoute);
             if (verbose) { fprintf(stderr, "\rParts processed: %zu (%zu%%) ", done, work.empty() ? 100 : done * 100 / work.size()); fflush(stderr); }
         }
         const double tio = nowMs();
         if (getenv("FS_TRACE")) fprintf(stderr, "[trace] before final flush at %.1f ms\n", nowMs() - tStart);
-        for (size_t l = 0; l < nLibs; ++l) { flush(*libs[l], true); libs[l]->aw.finish(archives[l].head, archives[l].qvz); stats.cdata_bytes += libs[l]->aw.dataBytes(); }
+        for (size_t l = 0; l < nLibs; ++l) {
+            if (!libs[l]->finished) { flush(*libs[l], true); libs[l]->aw.finish(archives[l].head, archives[l].qvz); }      // libraries without standard bins on this rank
+            stats.cdata_bytes += libs[l]->aw.dataBytes();
+        }
         stats.io_ms += nowMs() - tio;
     } catch (...) {
         for (auto& L : libs) if (L->t0.joinable()) L->t0.join();
