@@ -197,23 +197,32 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     if (streamPool.size() < nBins) streamPool.resize(nBins);
     std::vector<BinStreams>& st = streamPool;
     std::vector<BinIn> info(nBins); std::vector<uint64_t> recBytes(nBins, 0);
+    std::atomic<uint32_t> longestStream(0);
     // largest bins first: their streams are the longest (a launch ends with its longest stream) and the front end of
     // a bin is sequential, so a big bin started last would be the tail on the host too
     std::vector<uint32_t> byWork(nBins);
     for (uint32_t b = 0; b < nBins; ++b) byWork[b] = b;
     std::sort(byWork.begin(), byWork.end(), [&](uint32_t x, uint32_t y) { return weight[x] > weight[y]; });
-    uint64_t totalW = 0;
-    for (uint64_t w : weight) totalW += w;
+    uint64_t totalW = 0, maxW = 0;
+    for (uint64_t w : weight) { totalW += w; maxW = std::max(maxW, w); }
+    // The device step ends with its longest streams.  A bin's longest stream (the qualities) has about weight x read
+    // length symbols; streams within a factor two of the longest of the whole batch -- and long in absolute terms --
+    // are coded one wave per SIMD (see engine.hip).  The estimate only steers scheduling, never the bytes.
     // slice boundaries by cumulated weight: a small first slice starts the device early, the rest keeps it fed
     std::vector<uint32_t> cut{0};
-    const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? 5u : 1u);
+    const bool autoSlices = cfg.pipeline_slices == 0;
+    const uint32_t wantSlices = !autoSlices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? 6u : 1u);
     if (wantSlices > 1) {
-        static const double kFrac5[] = {0.10, 0.30, 0.55, 0.80, 1.0};
+        // default: a head slice of one bin per host thread (the heaviest bins: the device step ends with their streams,
+        // so they are submitted the moment their own front end is done), then five slices by cumulated weight
+        static const double kFrac[] = {0.0, 0.10, 0.30, 0.55, 0.80, 1.0};
         uint64_t acc = 0; uint32_t k = 0;
         for (uint32_t i = 0; i < nBins && k + 1 < wantSlices; ++i) {
             acc += weight[byWork[i]];
-            const double f = wantSlices == 5 ? kFrac5[k] : (double)(k + 1) / wantSlices;
-            if ((double)acc >= f * (double)totalW && i + 1 < nBins) { cut.push_back(i + 1); ++k; }
+            bool here;
+            if (autoSlices && k == 0) here = i + 1 >= hostThreads;
+            else here = (double)acc >= (autoSlices ? kFrac[k] : (double)(k + 1) / wantSlices) * (double)totalW;
+            if (here && i + 1 < nBins) { cut.push_back(i + 1); ++k; }
         }
     }
     cut.push_back(nBins);
@@ -247,6 +256,9 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         }
         if (abort.load()) return;
         S.tReady = nowMs();
+        // one-wave-per-SIMD kernel for the longest streams: off unless asked for (measured on the 10 M-read workload: the
+        // longest stream ends 0.2 s earlier, but the SIMDs taken from the other 92 k streams cost 0.6 s)
+        const uint32_t soloMin = cfg.solo_min_symbols <= 1 ? 0u : std::max<uint32_t>(cfg.solo_min_symbols, longestStream.load() / 2u);
         try {
             const uint32_t first = cut[si], count = cut[si + 1] - cut[si];
             S.plans.resize(count);
@@ -303,7 +315,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 }
             });
             S.tSubmit = nowMs();
-            if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, sliceBlocks[si], S.sizes, &S.timing) != 0) S.err = std::string("device: ") + L->err;
+            if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, sliceBlocks[si], S.sizes, &S.timing, soloMin) != 0) S.err = std::string("device: ") + L->err;
         } catch (const std::exception& e) { S.err = e.what(); }
         S.tDone = nowMs();
         { std::lock_guard<std::mutex> lk(S.mx); S.done = true; }
@@ -320,6 +332,10 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             const uint32_t b = byWork[k];
             if (!encs[tid]) encs[tid].reset(new BinEncoder(par));
             produce(b, *encs[tid], st[b], info[b], recBytes[b]);
+            if (k == 0) {   // byWork[0] is the heaviest bin: its longest stream sets the bar for the one-wave-per-SIMD kernel
+                uint32_t mx = 0; for (const auto& v : st[b].s) mx = std::max<uint32_t>(mx, (uint32_t)v.size());
+                longestStream.store(mx);
+            }
             Slice& S = slices[sliceOf[k]];
             bool last;
             { std::lock_guard<std::mutex> lk(S.mx); last = --S.pending == 0; }
@@ -561,6 +577,11 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
     } catch (...) {
         for (auto& L : libs) if (L->t0.joinable()) L->t0.join();
         throw;
+    }
+    {   // unmapping ~4 GB of input per library takes a while: one task per library
+        const double tc = nowMs();
+        parallelFor((uint32_t)nLibs, std::min<uint32_t>((uint32_t)nLibs, hostThreads), [&](uint32_t l, uint32_t) { libs[l].reset(); });
+        if (getenv("FS_TRACE")) fprintf(stderr, "[trace] close inputs %.1f ms\n", nowMs() - tc);
     }
     stats.total_ms += nowMs() - tStart;
     if (getenv("FS_TRACE")) fprintf(stderr, "[trace] packFiles total %.1f ms\n", nowMs() - tStart);
