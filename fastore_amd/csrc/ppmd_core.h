@@ -336,8 +336,11 @@ FS_DEV LaneStates lane_states(Coder& m, uint32_t stats, uint32_t ns, uint32_t ba
     if ((base & 63u) == 0) { FS_CNT(g_ld[2]); FS_CNT(g_ld[2]); FS_CNT(g_ld[2]); }      // what the 64-lane build issues: three fetches per 64 states
 #endif
     LaneStates r; const uint32_t i = base + (uint32_t)FS_LANE();
-    r.valid = i <= ns; r.sf = 0; r.succ = 0;
-    if (r.valid) { fs_cgptr16 q = (fs_cgptr16)HP(stats + 6u * i); const uint32_t a = q[0], b = q[1], c = q[2]; r.sf = a; r.succ = b | (c << 16); }
+    r.valid = i <= ns;
+    // lanes past the end re-read the last state: an unconditional fetch keeps this off the exec-masked path
+    const uint32_t ii = r.valid ? i : ns;
+    fs_cgptr16 q = (fs_cgptr16)HP(stats + 6u * ii); const uint32_t a = q[0], b = q[1], c = q[2];
+    r.sf = r.valid ? a : 0u; r.succ = r.valid ? (b | (c << 16)) : 0u;
     return r;
 }
 
@@ -346,6 +349,18 @@ struct Hit { uint32_t p, freq, succ, prevSf, prevSucc; };
 FS_DEV Hit find_in(Coder& m, const Ctx& pc, uint32_t sym)
 {
     Hit h; h.p = pc.w1; h.freq = 0; h.succ = 0; h.prevSf = 0; h.prevSucc = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FS_UB(pc.ns < FS_WAVE)) {                          // the whole list in one fetch: no loop
+        const LaneStates ls = lane_states(m, pc.w1, pc.ns, 0);
+        const uint64_t hit = fs_ballot(ls.valid && (ls.sf & 0xFFu) == sym);
+        const uint32_t k = hit ? fs_ctz64(hit) : 0u;
+        h.p = pc.w1 + 6u * k;
+        h.freq = FS_UNI(fs_readlane(ls.sf >> 8, k)); h.succ = FS_UNI(fs_readlane(ls.succ, k));
+        const uint32_t kp = k ? k - 1u : 0u;
+        h.prevSf = k ? FS_UNI(fs_readlane(ls.sf, kp)) : 0u; h.prevSucc = k ? FS_UNI(fs_readlane(ls.succ, kp)) : 0u;
+        return h;
+    }
+#endif
     for (uint32_t base = 0;; base += FS_WAVE) {
         const LaneStates ls = lane_states(m, pc.w1, pc.ns, base);
         const uint64_t hit = fs_ballot(ls.valid && (ls.sf & 0xFFu) == sym);
@@ -711,6 +726,13 @@ FS_DEV void encodeSymbol1(Coder& m, uint32_t c, Ctx& mc, int symbol)
     m.rScale = mc.sf;
     uint32_t LoCnt = 0, p = 0, k = 0, base = 0; bool found = false;
     LaneStates ls = lane_states(m, stats, ns, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FS_UB(ns < FS_WAVE)) {                              // the usual case: the whole list is in the lanes, no loop
+        const uint64_t hit = fs_ballot(ls.valid && (int)(ls.sf & 0xFFu) == symbol);
+        if (FS_UB(hit != 0)) { k = fs_ctz64(hit); if (FS_UB(k != 0)) LoCnt = fs_wave_sum8(ls.sf >> 8, ls.valid && (uint32_t)FS_LANE() < k); p = stats + 6u * k; found = true; }
+        else LoCnt = fs_wave_sum8(ls.sf >> 8, ls.valid);
+    } else
+#endif
     for (;;) {
         const uint64_t hit = fs_ballot(ls.valid && (int)(ls.sf & 0xFFu) == symbol);
         if (hit) { k = fs_ctz64(hit); if (k) LoCnt += fs_wave_sum8(ls.sf >> 8, ls.valid && (uint32_t)FS_LANE() < k); p = stats + 6u * (base + k); found = true; break; }
@@ -718,7 +740,7 @@ FS_DEV void encodeSymbol1(Coder& m, uint32_t c, Ctx& mc, int symbol)
         if (base + FS_WAVE > ns) break;
         base += FS_WAVE; ls = lane_states(m, stats, ns, base);
     }
-    if (!found) {                                           // escape: mask every symbol of the context
+    if (FS_UB(!found)) {                                    // escape: mask every symbol of the context
         m.PrevSuccess = 0; m.rLow = LoCnt;
         const uint8_t esc = (uint8_t)m.EscCount;
         if (ns < FS_WAVE) { if (ls.valid) m.sh->CharMask[ls.sf & 0xFFu] = esc; }
@@ -730,7 +752,7 @@ FS_DEV void encodeSymbol1(Coder& m, uint32_t c, Ctx& mc, int symbol)
     const uint32_t fFound = FS_UNI(fs_readlane(ls.sf >> 8, k)), succ = FS_UNI(fs_readlane(ls.succ, k));
     m.fsSym = (uint32_t)symbol; m.fsSucc = succ;
     prefetch_successor(m, c, succ);
-    if (base + k == 0) {                                     // most probable symbol
+    if (FS_UB(base + k == 0)) {                              // most probable symbol
         m.PrevSuccess = (2 * (m.rHigh = fFound) > m.rScale);
         m.FoundState = p; m.fsFreq = fFound + 4; S_FREQ_SET(p, fFound + 4); C_SF_SET(c, m.rScale + 4);
         mc.sf = m.rScale + 4;
@@ -778,6 +800,25 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
     // unmasked states in list order, 64 per step
     const uint8_t esc = (uint8_t)m.EscCount;
     uint32_t LoCnt = 0, p = 0, fFound = 0, succ = 0, tail = 0; bool found = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (FS_UB(nsC < FS_WAVE)) {                             // the whole list is in the lanes: no loop
+        const uint32_t sy = ls.sf & 0xFFu;
+        const bool unmasked = ls.valid && m.sh->CharMask[sy] != esc;
+        const uint64_t hit = fs_ballot(unmasked && (int)sy == symbol);
+        const uint32_t all = fs_wave_sum8(ls.sf >> 8, unmasked);
+        if (FS_UB(hit != 0)) {
+            const uint32_t k = fs_ctz64(hit);
+            LoCnt = FS_UB(k != 0) ? fs_wave_sum8(ls.sf >> 8, unmasked && (uint32_t)FS_LANE() < k) : 0u;
+            fFound = FS_UNI(fs_readlane(ls.sf >> 8, k)); succ = FS_UNI(fs_readlane(ls.succ, k));
+            tail = all - LoCnt - fFound;
+            if (unmasked && (uint32_t)FS_LANE() <= k) m.sh->CharMask[sy] = esc;     // visited states are marked
+            p = stats + 6u * k; found = true;
+        } else {
+            LoCnt = all;
+            if (unmasked) m.sh->CharMask[sy] = esc;
+        }
+    } else
+#endif
     for (uint32_t base = 0;;) {
         const uint32_t sy = ls.sf & 0xFFu;
         const bool unmasked = ls.valid && m.sh->CharMask[sy] != esc;
@@ -800,7 +841,7 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
         base += FS_WAVE; ls = lane_states(m, stats, nsC, base);
     }
     FS_WAVE_SYNC();
-    if (!found) {
+    if (FS_UB(!found)) {
         m.rHigh = (m.rScale += (m.rLow = LoCnt));
         if (seeIdx != 0xFFFFFFFFu) m.sh->SEE2[seeIdx] = (see & 0xFFFF0000u) | ((see + m.rScale) & 0xFFFFu);
         m.NumMasked = nsC;
