@@ -210,19 +210,13 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     // are coded one wave per SIMD (see engine.hip).  The estimate only steers scheduling, never the bytes.
     // slice boundaries by cumulated weight: a small first slice starts the device early, the rest keeps it fed
     std::vector<uint32_t> cut{0};
-    const bool autoSlices = cfg.pipeline_slices == 0;
-    const uint32_t wantSlices = !autoSlices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? 6u : 1u);
+    // default: eight slices of equal weight, one per hardware queue (measured 5 / 6-with-a-small-head / 8: 8 is best)
+    const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? 8u : 1u);
     if (wantSlices > 1) {
-        // default: a head slice of one bin per host thread (the heaviest bins: the device step ends with their streams,
-        // so they are submitted the moment their own front end is done), then five slices by cumulated weight
-        static const double kFrac[] = {0.0, 0.10, 0.30, 0.55, 0.80, 1.0};
         uint64_t acc = 0; uint32_t k = 0;
         for (uint32_t i = 0; i < nBins && k + 1 < wantSlices; ++i) {
             acc += weight[byWork[i]];
-            bool here;
-            if (autoSlices && k == 0) here = i + 1 >= hostThreads;
-            else here = (double)acc >= (autoSlices ? kFrac[k] : (double)(k + 1) / wantSlices) * (double)totalW;
-            if (here && i + 1 < nBins) { cut.push_back(i + 1); ++k; }
+            if ((double)acc >= (double)(k + 1) / wantSlices * (double)totalW && i + 1 < nBins) { cut.push_back(i + 1); ++k; }
         }
     }
     cut.push_back(nBins);

@@ -22,6 +22,7 @@ enum { UNIT_SIZE = 12, N1 = 4, N2 = 4, N3 = 4, N4 = (128 + 3 - 1 * N1 - 2 * N2 -
 enum { INT_BITS = 7, PERIOD_BITS = 7, TOT_BITS = INT_BITS + PERIOD_BITS, INTERVAL = 1 << INT_BITS,
        BIN_SCALE = 1 << TOT_BITS, ROUND = 16, MAX_FREQ = 124 };
 enum : uint32_t { TOP = 1u << 24, BOT = 1u << 15 };
+constexpr int32_t INIT_RL = -4;      // InitRL of an order-4 model (the value StartModelRare computes from MaxOrder)
 enum : uint32_t { SA_SIZE = 16u << 20, MAX_ORDER = 4,
                   // list heads BList[0..N_INDEXES] + one scratch head live behind the heap proper
                   HEADS_OFF = SA_SIZE + 64u, ARENA_BYTES = HEADS_OFF + 12u * (N_INDEXES + 2) + 16u };
@@ -60,6 +61,7 @@ struct Shared {
     uint32_t SEE2[23 * 32];      // Summ | Shift << 16 | Count << 24
     uint8_t CharMask[256];
     uint8_t QT[260];             // QTable, tabulated once per wave
+    uint32_t GlueCount, GlueCount1, restarts;   // touched only by the allocator's rare paths / model restarts: kept out of the registers
 };
 
 // the three words of a context record as fetched (per-lane values, fetch still in flight): issue early, finish at first use
@@ -68,15 +70,13 @@ struct CtxRaw { uint32_t a, b, d; };
 struct Coder {
     fs_gptr hb;                  // heap base - 1  (so that index ix lives at hb + ix)
     FS_LDS Shared* sh;
-    uint32_t pText, UnitsStart, LoUnit, HiUnit, GlueCount, GlueCount1;
+    uint32_t pText, UnitsStart, LoUnit, HiUnit;
     uint32_t MaxContext, FoundState;
     uint32_t fsSym, fsFreq, fsSucc;   // register copy of *FoundState (memory is always written through)
     uint32_t NumMasked, PrevSuccess, EscCount;
-    int32_t BSumm, OrderFall, RunLength, InitRL;
+    int32_t BSumm, OrderFall, RunLength;
     uint32_t low, range, rLow, rHigh, rScale;
-    uint32_t dummySee;
     fs_gptr out; uint32_t outCap, outPos;
-    uint32_t restarts;
     uint32_t pfCtx; CtxRaw pf;     // record of the next symbol's first context, requested ahead of this symbol's stores (0 = none)
 };
 
@@ -125,13 +125,7 @@ FS_DEV CtxRaw ctx_issue(Coder& m, uint32_t c)
     FS_CNT(g_ld[0]);
     fs_cgptr32 q = (fs_cgptr32)HP(c);
     CtxRaw r;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(FS_LD1)
-    uint32_t w = 0; const uint32_t l = (uint32_t)FS_LANE();
-    if (l < 3u) w = q[l];
-    r.a = fs_readlane(w, 0); r.b = fs_readlane(w, 1); r.d = fs_readlane(w, 2);
-#else
     r.a = q[0]; r.b = q[1]; r.d = q[2];
-#endif
     return r;
 }
 FS_DEV Ctx ctx_finish(const CtxRaw& x)
@@ -147,14 +141,8 @@ FS_DEV St st_load(Coder& m, uint32_t s)
 {
     FS_CNT(g_ld[1]);
     fs_cgptr16 q = (fs_cgptr16)HP(s);
-#if defined(__HIP_DEVICE_COMPILE__) && defined(FS_LD1)
-    uint32_t w = 0; const uint32_t l = (uint32_t)FS_LANE();
-    if (l < 3u) w = q[l];                                   // lane i fetches word i: one instruction
-    const uint32_t a = fs_readlane(w, 0), b = fs_readlane(w, 1), c = fs_readlane(w, 2);
-#else
     uint32_t a = q[0], b = q[1], c = q[2];
     a = FS_UNI(a); b = FS_UNI(b); c = FS_UNI(c);
-#endif
     St r; r.sym = a & 0xFFu; r.freq = a >> 8; r.succ = b | (c << 16);
     return r;
 }
@@ -185,7 +173,7 @@ FS_DEV void InitSubAllocator(Coder& m)
     FS_WAVE_SYNC();
     m.pText = 1u; m.HiUnit = 1u + SA_SIZE;
     const uint32_t Diff = 12u * (SA_SIZE / 8 / UNIT_SIZE * 7);
-    m.LoUnit = m.UnitsStart = m.HiUnit - Diff; m.GlueCount = m.GlueCount1 = 0;
+    m.LoUnit = m.UnitsStart = m.HiUnit - Diff; m.sh->GlueCount = m.sh->GlueCount1 = 0;
 }
 
 FS_DEV_NOINLINE void GlueFreeBlocks(Coder& m)
@@ -210,7 +198,7 @@ FS_DEV_NOINLINE void GlueFreeBlocks(Coder& m)
         if (kIndx2Units[i = kUnits2Indx[sz - 1]] != sz) { k = sz - kIndx2Units[--i]; blk_insert(m, BL(k - 1), p + 12u * (sz - k), k); }
         blk_insert(m, BL(i), p, kIndx2Units[i]);
     }
-    m.GlueCount = 1u << (13 + m.GlueCount1++);
+    { const uint32_t g1 = FS_UNI(m.sh->GlueCount1); m.sh->GlueCount = 1u << (13 + g1); m.sh->GlueCount1 = g1 + 1u; }
 }
 
 FS_DEV_NOINLINE uint32_t AllocUnitsRare(Coder& m, uint32_t indx)
@@ -219,7 +207,8 @@ FS_DEV_NOINLINE uint32_t AllocUnitsRare(Coder& m, uint32_t indx)
     uint32_t i = indx;
     do {
         if (++i == N_INDEXES) {
-            if (!m.GlueCount--) {
+            const uint32_t gc = FS_UNI(m.sh->GlueCount); m.sh->GlueCount = gc - 1u;
+            if (!gc) {
                 GlueFreeBlocks(m);
                 if (blk_avail(m, BL(i = indx))) return blk_remove(m, BL(i));
             } else {
@@ -300,7 +289,7 @@ FS_DEV void StartModelRare(Coder& m)
     clear_mask(m);
     m.OrderFall = MAX_ORDER;
     InitSubAllocator(m);
-    m.RunLength = m.InitRL = -(int32_t)MAX_ORDER;
+    m.RunLength = INIT_RL;
     m.MaxContext = AllocContext(m);
     C_NS_SET(m.MaxContext, 255); C_SF_SET(m.MaxContext, 257);
     const uint32_t st = AllocUnits(m, 128);
@@ -326,7 +315,7 @@ FS_DEV void StartModelRare(Coder& m)
     FS_WAVE_SYNC();
 }
 
-FS_DEV void RestoreModelRare(Coder& m) { m.pText = 1u; StartModelRare(m); m.EscCount = 0; m.restarts++; }
+FS_DEV void RestoreModelRare(Coder& m) { m.pText = 1u; StartModelRare(m); m.EscCount = 0; m.sh->restarts = FS_UNI(m.sh->restarts) + 1u; }
 
 // per-lane view of 64 consecutive states of a context: one fetch for the whole list
 struct LaneStates { uint32_t sf, succ; bool valid; };
@@ -866,7 +855,7 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
     S_FREQ_SET(p, fFound + 4); C_SF_SET(c, mc.sf + 4);
     mc.sf += 4;
     if (fFound + 4 > MAX_FREQ) { rescale(m, c); fs_reload(m); mc = ctx_load(m, c); }
-    m.EscCount = (m.EscCount + 1) & 0xFFu; m.RunLength = m.InitRL;
+    m.EscCount = (m.EscCount + 1) & 0xFFu; m.RunLength = INIT_RL;
 }
 
 // Encode one member.  `arena` = ARENA_BYTES of 16-byte aligned scratch (content irrelevant),
@@ -875,7 +864,7 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
                               uint32_t* restartsOut)
 {
     Coder m;
-    m.hb = arena - 1; m.sh = sh; m.out = out; m.outCap = outCap; m.outPos = 0; m.restarts = 0;
+    m.hb = arena - 1; m.sh = sh; m.out = out; m.outCap = outCap; m.outPos = 0; sh->restarts = 0;
     m.NumMasked = 0; m.FoundState = 0; m.BSumm = 0; m.rLow = m.rHigh = m.rScale = 0; m.fsSym = m.fsFreq = m.fsSucc = 0;
     for (uint32_t i = (uint32_t)FS_LANE(); i < 260u; i += FS_WAVE) sh->QT[i] = (uint8_t)QTable(i);
     // zero the 64-byte guard behind the heap: GlueFreeBlocks may read one stamp past the end
@@ -908,7 +897,7 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
         m.OrderFall = (int32_t)FS_UNI(m.OrderFall); m.RunLength = (int32_t)FS_UNI(m.RunLength); m.pfCtx = FS_UNI(m.pfCtx);
         m.low = FS_UNI(m.low); m.range = FS_UNI(m.range); m.NumMasked = FS_UNI(m.NumMasked); m.EscCount = FS_UNI(m.EscCount); m.PrevSuccess = FS_UNI(m.PrevSuccess);
         m.pText = FS_UNI(m.pText); m.UnitsStart = FS_UNI(m.UnitsStart); m.LoUnit = FS_UNI(m.LoUnit); m.HiUnit = FS_UNI(m.HiUnit); m.outPos = FS_UNI(m.outPos);
-        m.MaxContext = FS_UNI(m.MaxContext); m.InitRL = (int32_t)FS_UNI(m.InitRL); m.BSumm = (int32_t)FS_UNI(m.BSumm); m.GlueCount = FS_UNI(m.GlueCount);
+        m.MaxContext = FS_UNI(m.MaxContext); m.BSumm = (int32_t)FS_UNI(m.BSumm);
         // first context of the symbol: still in registers (a context that succeeded itself), requested during the
         // previous symbol, or fetched now
         if (FS_UB(m.pfCtx == MinContext)) mc = ctx_finish(m.pf);
@@ -939,7 +928,7 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
         rc_normalize(m); MinContext = m.MaxContext;
     }
     for (int i = 0; i < 4; i++) { put_byte(m, m.low >> 24); m.low <<= 8; }
-    if (restartsOut) *restartsOut = m.restarts;
+    if (restartsOut) *restartsOut = FS_UNI(m.sh->restarts);
     return m.outPos;
 }
 

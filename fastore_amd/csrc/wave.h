@@ -67,35 +67,17 @@ typedef const FS_GLOBAL uint32_t* fs_cgptr32;
 typedef FS_GLOBAL uint32_t* fs_gptr32;
 
 // ---- uniform little-endian accessors on a byte heap (2-byte aligned addresses) ----
-#if defined(__HIP_DEVICE_COMPILE__) && defined(FS_LD1)
-// experiment: uniform loads issued by lane 0 only (one quad through the texture-address unit instead of sixteen)
-FS_DEV uint32_t fs_ld8(fs_cgptr p) { uint32_t v = 0; if (FS_LANE() == 0) v = *p; return FS_UNI(v); }
-FS_DEV uint32_t fs_ld16(fs_cgptr p) { uint32_t v = 0; if (FS_LANE() == 0) v = *(fs_cgptr16)p; return FS_UNI(v); }
-FS_DEV uint32_t fs_ld32h(fs_cgptr p)
-{
-    uint32_t v = 0; const uint32_t l = (uint32_t)FS_LANE();
-    if (l < 2u) v = ((fs_cgptr16)p)[l];
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | ((uint32_t)__builtin_amdgcn_readlane((int)v, 1) << 16);
-}
-FS_DEV uint32_t fs_ld32(fs_cgptr p) { uint32_t v = 0; if (FS_LANE() == 0) v = *(fs_cgptr32)p; return FS_UNI(v); }
-#else
 FS_DEV uint32_t fs_ld8(fs_cgptr p) { FS_CNT(g_ld[3]); return FS_UNI(*p); }
 FS_DEV uint32_t fs_ld16(fs_cgptr p) { FS_CNT(g_ld[4]); return FS_UNI(*(fs_cgptr16)p); }
 FS_DEV uint32_t fs_ld32h(fs_cgptr p)   // 32-bit value at a 2-byte aligned address
 { FS_CNT(g_ld[6]); return FS_UNI((uint32_t)((fs_cgptr16)p)[0] | ((uint32_t)((fs_cgptr16)p)[1] << 16)); }
 FS_DEV uint32_t fs_ld32(fs_cgptr p) { FS_CNT(g_ld[5]); return FS_UNI(*(fs_cgptr32)p); }
-#endif
-// Uniform stores are executed by all lanes (same address, same value).  Issuing them from one lane (FS_ST1) was
+// Uniform stores are executed by all lanes (same address, same value).  Issuing them from one lane was
 // measured: the same number of L1->L2 write requests and the same run time, but a divergent `if` per store, which
 // makes the compiler structurize the surrounding uniform control flow with exec masks (+14 % code).
-#if defined(__HIP_DEVICE_COMPILE__) && defined(FS_ST1)
-  #define FS_ONE_LANE if (FS_LANE() == 0)
-#else
-  #define FS_ONE_LANE
-#endif
-FS_DEV void fs_st8(fs_gptr p, uint32_t v) { FS_CNT(g_st); FS_ONE_LANE *p = (uint8_t)v; }
-FS_DEV void fs_st16(fs_gptr p, uint32_t v) { FS_CNT(g_st); FS_ONE_LANE *(fs_gptr16)p = (uint16_t)v; }
-FS_DEV void fs_st32(fs_gptr p, uint32_t v) { FS_CNT(g_st); FS_ONE_LANE *(fs_gptr32)p = v; }
+FS_DEV void fs_st8(fs_gptr p, uint32_t v) { FS_CNT(g_st); *p = (uint8_t)v; }
+FS_DEV void fs_st16(fs_gptr p, uint32_t v) { FS_CNT(g_st); *(fs_gptr16)p = (uint16_t)v; }
+FS_DEV void fs_st32(fs_gptr p, uint32_t v) { FS_CNT(g_st); *(fs_gptr32)p = v; }
 // 32-bit value at a 2-byte aligned address: lanes 0 and 1 store one half each (one instruction)
 FS_DEV void fs_st32h(fs_gptr p, uint32_t v)
 {
