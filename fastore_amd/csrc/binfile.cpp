@@ -294,13 +294,17 @@ void BinFile::unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, ui
 
 void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase) const
 {
-    std::vector<uint8_t> bMeta_, bDna_, bQua_, bHead_;
+    // gather buffers of the calling thread, kept across bins: fresh vectors of this size are mmap'ed by malloc, and the
+    // map/unmap/first-touch churn of thousands of them per second serialises the host threads in the kernel
+    static thread_local std::vector<uint8_t> bMeta_, bDna_, bQua_, bHead_;
     const auto it = bins_.find(signature);
     if (it == bins_.end()) throw std::runtime_error("signature not present in bin file");
     const BinInfo& bi = it->second;
     // BinFileReader::ReadBlock: gather the signature's slices from the four streams
-    bMeta_.resize(bi.totalMetaSize); bDna_.resize(bi.totalDnaSize); bQua_.resize(bi.totalQuaSize);
-    bHead_.resize(usesHeaderStream_ ? bi.totalHeadSize : 0);
+    if (bMeta_.size() < bi.totalMetaSize) bMeta_.resize(bi.totalMetaSize);
+    if (bDna_.size() < bi.totalDnaSize) bDna_.resize(bi.totalDnaSize);
+    if (bQua_.size() < bi.totalQuaSize) bQua_.resize(bi.totalQuaSize);
+    if (usesHeaderStream_ && bHead_.size() < bi.totalHeadSize) bHead_.resize(bi.totalHeadSize);
     uint64_t mo = 0, dO = 0, qo = 0, ho = 0, rawDna = 0, records = 0;
     for (const BlockMetaDataRaw& blk : bi.blocks) {
         copyAt(meta_, blk.metaFileOffset, bMeta_.data() + mo, blk.metaSize, ".bmeta"); mo += blk.metaSize;

@@ -315,6 +315,7 @@ void device_destroy(Device* dev)
 uint8_t* staging_buffer(Device* dev, size_t bytes)
 {
     if (bytes <= dev->capStage && dev->hStage) return dev->hStage;
+    (void)hipSetDevice(dev->deviceId);                   // lane threads start on device 0
     if (dev->hStage) (void)hipHostFree(dev->hStage);
     dev->hStage = nullptr; dev->capStage = 0;
     const size_t want = bytes + bytes / 4 + 4096;
@@ -462,8 +463,8 @@ int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vect
                  BatchTiming* timing, uint32_t soloMin)
 {
     const uint32_t nItems = (uint32_t)items.size(), nBins = (uint32_t)plans.size();
-    blocks.clear(); blockSizes.assign(nBins, 0);
-    if (nItems == 0) return 0;
+    blockSizes.assign(nBins, 0);                 // `blocks` keeps its size between calls: resize() below does not re-zero what is overwritten anyway
+    if (nItems == 0) { blocks.clear(); return 0; }
     std::vector<uint32_t> sizes; uint64_t scratch = 0;
     if (run_encode(dev, input, inputBytes, items, sizes, scratch, timing, soloMin)) return -1;
     hipStream_t st = (hipStream_t)dev->stream;

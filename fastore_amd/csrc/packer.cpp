@@ -256,6 +256,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         try {
             const uint32_t first = cut[si], count = cut[si + 1] - cut[si];
             S.plans.resize(count);
+            S.items.reserve((size_t)count * S_PE_COUNT);
             uint64_t inBytes = 0;
             // --lossy libraries: one read-only model blob per library in front of the streams
             std::vector<uint64_t> qvzOff(archives.size(), ~0ull);
@@ -318,6 +319,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     for (uint32_t si = 0; si < nSlices; ++si) slices[si].th = std::thread(runSlice, si);
     auto joinAll = [&]() { for (Slice& s : slices) if (s.th.joinable()) s.th.join(); };
 
+    std::vector<double> busyMs(hostThreads, 0.0);
     std::vector<std::unique_ptr<BinEncoder>>& encs = encoders;        // kept across calls: their work buffers stay mapped
     if (encs.size() < hostThreads) encs.resize(hostThreads);
     const double tf = nowMs();
@@ -325,7 +327,9 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         parallelFor(nBins, hostThreads, [&](uint32_t k, uint32_t tid) {
             const uint32_t b = byWork[k];
             if (!encs[tid]) encs[tid].reset(new BinEncoder(par));
+            const double ta = trace ? nowMs() : 0.0;
             produce(b, *encs[tid], st[b], info[b], recBytes[b]);
+            if (trace) busyMs[tid] += nowMs() - ta;
             if (k == 0) {   // byWork[0] is the heaviest bin: its longest stream sets the bar for the one-wave-per-SIMD kernel
                 uint32_t mx = 0; for (const auto& v : st[b].s) mx = std::max<uint32_t>(mx, (uint32_t)v.size());
                 longestStream.store(mx);
@@ -358,7 +362,11 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         if (trace) fprintf(stderr, "[trace] slice %u/%u: %u bins, front end done at %.1f ms, staged+submitted at %.1f ms, device done at %.1f ms (kernel %.1f ms)\n",
                            si + 1, nSlices, cut[si + 1] - cut[si], S.tReady - t0, S.tSubmit - t0, S.tDone - t0, S.timing.encode_ms);
     }
-    if (trace) fprintf(stderr, "[trace] batch: %u bins in %u slices on %u lanes, host tasks %.1f ms, total %.1f ms\n", nBins, nSlices, nLanes, feMs, nowMs() - t0);
+    if (trace) {
+        double sum = 0, mx = 0; for (double v : busyMs) { sum += v; mx = std::max(mx, v); }
+        fprintf(stderr, "[trace] batch: %u bins in %u slices on %u lanes, host tasks %.1f ms (%u threads: busy sum %.0f ms, busiest %.0f ms), total %.1f ms\n",
+                nBins, nSlices, nLanes, feMs, hostThreads, sum, mx, nowMs() - t0);
+    }
     stats.bins += nBins;
     binInfo.swap(info);
     for (uint32_t b = 0; b < nBins; ++b) { stats.records += binInfo[b].recCount; stats.algorithmic_bytes += blockSizes[b] + recBytes[b]; }

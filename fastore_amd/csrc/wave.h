@@ -31,8 +31,9 @@
   // make a loaded value wave-uniform (it already is by construction; this moves it to an SGPR)
   #define FS_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
   // a wave-uniform condition, said so (a branch the compiler takes for divergent is compiled with exec masking and
-  // drags every value merged behind it into vector registers)
-  #define FS_UB(c) (__builtin_amdgcn_readfirstlane((int)(c)) != 0)
+  // drags every value merged behind it into vector registers).  Via ballot: the result is a scalar mask compare, where
+  // readfirstlane of the boolean would cost a round trip through a vector register.
+  #define FS_UB(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
   // order this wave's cooperative memory phase against the uniform code that follows it
   #define FS_WAVE_SYNC() __syncthreads()
 #else
