@@ -25,6 +25,7 @@ struct Device {
     char err[256];
     void* stream;
     void* ev[4];
+    void* evWait;                                          // blocking-sync event: a waiting lane thread sleeps instead of spinning
     void* stream2; void* ev2[3]; uint32_t* queueHead2;     // side stream of the one-wave-per-SIMD kernel for the longest streams
     uint32_t* dOrder2; size_t capOrder2;
     Pool* pool; uint32_t* queueHead; uint32_t nWaves /* resident-wave cap */;

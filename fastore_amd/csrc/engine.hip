@@ -170,6 +170,15 @@ __global__ __launch_bounds__(256) void fs_assemble_blocks(const BlockPlan* __res
     }
 }
 
+// Waiting for a lane's stream: a blocking event, not hipStreamSynchronize.  The runtime's default wait spins on a core
+// for the whole device call; with eight lanes that is eight cores taken from the host front end.
+static hipError_t wait_stream(fsengine::Device* dev, hipStream_t st)
+{
+    hipError_t e = hipEventRecord((hipEvent_t)dev->evWait, st);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize((hipEvent_t)dev->evWait);
+}
+
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(dev->err, sizeof dev->err, "%s failed: %s", #x, hipGetErrorString(e_)); return -1; } } while (0)
 
 template <class T> int ensure(fsengine::Device* dev, T*& p, size_t& capBytes, size_t needBytes)
@@ -225,6 +234,7 @@ static int lane_init(Device* dev, char* err, size_t errLen)
     if ((e = hipMalloc((void**)&dev->queueHead2, 64)) != hipSuccess) return fail("hipMalloc(queue)", e);
     for (int i = 0; i < 4; ++i) if ((e = hipEventCreate((hipEvent_t*)&dev->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
     for (int i = 0; i < 3; ++i) if ((e = hipEventCreate((hipEvent_t*)&dev->ev2[i])) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags((hipEvent_t*)&dev->evWait, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     return 0;
 }
 
@@ -300,6 +310,7 @@ void device_destroy(Device* dev)
     void* ptrs[] = {dev->queueHead, dev->queueHead2, dev->dOrder2, dev->dIn, dev->dScratch, dev->dItems, dev->dOrder, dev->dSizes, dev->dRestarts, dev->dPlans, dev->dBlocks};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 3; ++i) if (dev->ev2[i]) (void)hipEventDestroy((hipEvent_t)dev->ev2[i]);
+    if (dev->evWait) (void)hipEventDestroy((hipEvent_t)dev->evWait);
     if (dev->stream2) (void)hipStreamDestroy((hipStream_t)dev->stream2);
     if (dev->hStage) (void)hipHostFree(dev->hStage);
     for (int i = 0; i < 4; ++i) if (dev->ev[i]) (void)hipEventDestroy((hipEvent_t)dev->ev[i]);
@@ -426,12 +437,12 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     }
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));
     if (nSolo) HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)dev->ev2[2], 0));      // the size read-back below needs both kernels
-    if (getenv("FS_TRACE")) { HIP_TRY(hipStreamSynchronize(st)); }
+    if (getenv("FS_TRACE")) { HIP_TRY(wait_stream(dev, st)); }
     sizes.resize(nItems);
     std::vector<uint32_t> restarts(nItems);
     HIP_TRY(hipMemcpyAsync(sizes.data(), dev->dSizes, 4ull * nItems, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(restarts.data(), dev->dRestarts, 4ull * nItems, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(wait_stream(dev, st));
     if (timing) {
         float a = 0;
         (void)hipEventElapsedTime(&a, (hipEvent_t)dev->ev[0], (hipEvent_t)dev->ev[1]);
@@ -491,7 +502,7 @@ int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vect
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[3], st));
     blocks.resize(total);
     HIP_TRY(hipMemcpyAsync(blocks.data(), dev->dBlocks, total, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(wait_stream(dev, st));
     if (timing) {
         float b = 0;
         (void)hipEventElapsedTime(&b, (hipEvent_t)dev->ev[2], (hipEvent_t)dev->ev[3]);

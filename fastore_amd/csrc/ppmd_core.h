@@ -119,7 +119,18 @@ FS_DEV void state_swap(Coder& m, uint32_t a, uint32_t b)
 FS_DEV void state_cpy(Coder& m, uint32_t d, uint32_t s) { state_store(m, d, S_SYMFREQ(s), S_SUCC(s)); }
 
 // One context header = one 12-byte fetch (three dwords in flight together), then kept in SGPRs.
-struct Ctx { uint32_t ns, flags, sf, w1 /* iStats, or oneState.iSuccessor */, suff, oneSym, oneFreq; };
+// kept packed as fetched (three SGPRs per record instead of seven): word 0 = NumStats | Flags << 8 | SummFreq << 16, where
+// the SummFreq half is oneState {Symbol, Freq} in a binary context
+struct Ctx {
+    uint32_t a, w1 /* iStats, or oneState.iSuccessor */, suff;
+    FS_DEV_M uint32_t ns() const { return a & 0xFFu; }
+    FS_DEV_M uint32_t flags() const { return (a >> 8) & 0xFFu; }
+    FS_DEV_M uint32_t sf() const { return a >> 16; }
+    FS_DEV_M uint32_t oneSym() const { return (a >> 16) & 0xFFu; }
+    FS_DEV_M uint32_t oneFreq() const { return a >> 24; }
+    FS_DEV_M void set_sf(uint32_t v) { a = (a & 0xFFFFu) | (v << 16); }
+    FS_DEV_M void set_one_freq(uint32_t v) { a = (a & 0x00FFFFFFu) | (v << 24); }
+};
 FS_DEV CtxRaw ctx_issue(Coder& m, uint32_t c)
 {
     FS_CNT(g_ld[0]);
@@ -131,7 +142,7 @@ FS_DEV CtxRaw ctx_issue(Coder& m, uint32_t c)
 FS_DEV Ctx ctx_finish(const CtxRaw& x)
 {
     const uint32_t a = FS_UNI(x.a), b = FS_UNI(x.b), d = FS_UNI(x.d);
-    Ctx r; r.ns = a & 0xFFu; r.flags = (a >> 8) & 0xFFu; r.sf = a >> 16; r.w1 = b; r.suff = d; r.oneSym = (a >> 16) & 0xFFu; r.oneFreq = a >> 24;
+    Ctx r; r.a = a; r.w1 = b; r.suff = d;
     return r;
 }
 FS_DEV Ctx ctx_load(Coder& m, uint32_t c) { return ctx_finish(ctx_issue(m, c)); }
@@ -339,8 +350,8 @@ FS_DEV Hit find_in(Coder& m, const Ctx& pc, uint32_t sym)
 {
     Hit h; h.p = pc.w1; h.freq = 0; h.succ = 0; h.prevSf = 0; h.prevSucc = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (FS_UB(pc.ns < FS_WAVE)) {                          // the whole list in one fetch: no loop
-        const LaneStates ls = lane_states(m, pc.w1, pc.ns, 0);
+    if (FS_UNI(pc.ns()) < FS_WAVE) {                          // the whole list in one fetch: no loop
+        const LaneStates ls = lane_states(m, pc.w1, pc.ns(), 0);
         const uint64_t hit = fs_ballot(ls.valid && (ls.sf & 0xFFu) == sym);
         const uint32_t k = hit ? fs_ctz64(hit) : 0u;
         h.p = pc.w1 + 6u * k;
@@ -351,7 +362,7 @@ FS_DEV Hit find_in(Coder& m, const Ctx& pc, uint32_t sym)
     }
 #endif
     for (uint32_t base = 0;; base += FS_WAVE) {
-        const LaneStates ls = lane_states(m, pc.w1, pc.ns, base);
+        const LaneStates ls = lane_states(m, pc.w1, pc.ns(), base);
         const uint64_t hit = fs_ballot(ls.valid && (ls.sf & 0xFFu) == sym);
         if (hit) {
             const uint32_t k = fs_ctz64(hit);
@@ -361,7 +372,7 @@ FS_DEV Hit find_in(Coder& m, const Ctx& pc, uint32_t sym)
             else if (base > 0) { const St t = st_load(m, h.p - 6); h.prevSf = t.sym | (t.freq << 8); h.prevSucc = t.succ; }
             return h;
         }
-        if (base + FS_WAVE > pc.ns) return h;            // unreachable for well-formed models; never spin
+        if (base + FS_WAVE > pc.ns()) return h;            // unreachable for well-formed models; never spin
     }
 }
 
@@ -388,15 +399,15 @@ FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc
         do {
             if (!first) {
                 pc = P.suff; P = ctx_load(m, pc);
-                if (P.ns) {
+                if (P.ns()) {
                     const Hit h = find_in(m, P, sym);
                     p = h.p; pSucc = h.succ;
                     tmp = (h.freq < MAX_FREQ);
-                    S_FREQ_SET(p, h.freq + tmp); P.sf += tmp; C_SF_SET(pc, P.sf);
+                    S_FREQ_SET(p, h.freq + tmp); P.set_sf(P.sf() + tmp); C_SF_SET(pc, P.sf());
                 } else {
                     p = C_ONE(pc); pSucc = P.w1;
                     const uint32_t sufNs = fs_ld8(HP(P.suff));
-                    S_FREQ_SET(p, P.oneFreq + ((!sufNs) & (P.oneFreq < 11)));
+                    S_FREQ_SET(p, P.oneFreq() + ((!sufNs) & (P.oneFreq() < 11)));
                 }
             }
             first = false;
@@ -409,12 +420,12 @@ FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc
     sym = fs_ld8(HP(iUpBranch));
     ctFlags |= 0x08u * (sym >= 0x40);
     uint32_t ctFreq;
-    if (P.ns) {
+    if (P.ns()) {
         const Hit h = find_in(m, P, sym);
-        s0 = P.sf - P.ns - (cf = h.freq - 1u);
+        s0 = P.sf() - P.ns() - (cf = h.freq - 1u);
         cf = 1 + ((2 * cf <= s0) ? (uint32_t)(12 * cf > s0) : ((cf + 2 * s0) / s0));
         ctFreq = (cf < 7) ? cf : 7;
-    } else ctFreq = P.oneFreq;
+    } else ctFreq = P.oneFreq();
     const uint32_t w0 = (ctFlags << 8) | (sym << 16) | (ctFreq << 24);   // NumStats=0, Flags, oneState{Symbol,Freq}
     do {
         const uint32_t pc1 = AllocContext(m);
@@ -440,12 +451,12 @@ FS_DEV uint32_t ReduceOrder(Coder& m, uint32_t p, uint32_t pSucc, uint32_t pc)
         if (!first) {
             if (!P.suff) return pc;
             pc = P.suff; P = ctx_load(m, pc);
-            if (P.ns) {
+            if (P.ns()) {
                 const Hit h = find_in(m, P, sym);
                 p = h.p; pSucc = h.succ;
                 tmp = 2u * (h.freq < MAX_FREQ - 3);
-                S_FREQ_SET(p, h.freq + tmp); P.sf += tmp; C_SF_SET(pc, P.sf);
-            } else { p = C_ONE(pc); pSucc = P.w1; S_FREQ_SET(p, P.oneFreq + (P.oneFreq < 11)); }
+                S_FREQ_SET(p, h.freq + tmp); P.set_sf(P.sf() + tmp); C_SF_SET(pc, P.sf());
+            } else { p = C_ONE(pc); pSucc = P.w1; S_FREQ_SET(p, P.oneFreq() + (P.oneFreq() < 11)); }
         }
         first = false;
         if (pSucc) break;
@@ -469,7 +480,7 @@ FS_DEV_NOINLINE void rescale_serial(Coder& m, uint32_t c);
 FS_DEV_NOINLINE void rescale(Coder& m, uint32_t c)
 {
     const Ctx R = ctx_load(m, c);
-    const uint32_t ns = R.ns, stats = R.w1;
+    const uint32_t ns = R.ns(), stats = R.w1;
     if (ns >= 64u) { rescale_serial(m, c); return; }
     FS_REGION(5);
     FS_PATH(g_path[11]);
@@ -513,8 +524,8 @@ FS_DEV_NOINLINE void rescale(Coder& m, uint32_t c)
         f0 = f[kf]; nf0 = nf[kf]; sym0 = sym[kf]; succ0 = succ[kf];
     }
 #endif
-    uint32_t flags = (R.flags & 0x14u) | (hiAny ? 0x08u : 0u);
-    uint32_t EscFreq = R.sf - sumF, nsNew = ns, statsNew = stats, a;
+    uint32_t flags = (R.flags() & 0x14u) | (hiAny ? 0x08u : 0u);
+    uint32_t EscFreq = R.sf() - sumF, nsNew = ns, statsNew = stats, a;
     if (zeros) {
         EscFreq += zeros;
         const uint32_t oldNU = (ns + 2u) >> 1;
@@ -531,7 +542,7 @@ FS_DEV_NOINLINE void rescale(Coder& m, uint32_t c)
     }
     summ += (EscFreq + 1) >> 1;
     if (m.OrderFall || (flags & 0x04u) == 0) {
-        const uint32_t sf = R.sf - EscFreq;
+        const uint32_t sf = R.sf() - EscFreq;
         a = sf - f0;
         a = (f0 * summ - sf * nf0 + a - 1) / a;
         a = a < 2u ? 2u : (a > MAX_FREQ / 2u - 18u ? MAX_FREQ / 2u - 18u : a);
@@ -602,11 +613,11 @@ FS_DEV void UpdateModel(Coder& m, uint32_t MinContext, const Ctx& mcMin, bool ha
     uint32_t ns1, ns, cf, sf, s0, pc, p = 0, pSucc = 0;
     bool restart = false;
     // mcMin: the caller's register copy of the context, kept in step with the stores of the coding step
-    Ctx P; P.ns = 0; P.flags = 0; P.sf = 0; P.w1 = 0; P.suff = 0; P.oneSym = 0; P.oneFreq = 0;
+    Ctx P; P.a = 0; P.w1 = 0; P.suff = 0;
     if (mcMin.suff) {
         pc = mcMin.suff;
         if (haveSuf) P = sufRec; else P = ctx_load(m, pc);
-        if (P.ns) {
+        if (P.ns()) {
             Hit h = find_in(m, P, FSymbol);
             p = h.p; pSucc = h.succ;
             cf = h.freq < MAX_FREQ ? 1 + (FFreq < 4 * 8) : 0;
@@ -615,8 +626,8 @@ FS_DEV void UpdateModel(Coder& m, uint32_t MinContext, const Ctx& mcMin, bool ha
                 state_store(m, p, h.prevSf, h.prevSucc);
                 p -= 6;
             } else if (cf) S_FREQ_SET(p, h.freq + cf);
-            if (cf) { P.sf += cf; C_SF_SET(pc, P.sf); }
-        } else { p = C_ONE(pc); pSucc = P.w1; P.oneFreq += (P.oneFreq < 11); P.sf = P.oneSym | (P.oneFreq << 8); S_FREQ_SET(p, P.oneFreq); }
+            if (cf) { P.set_sf(P.sf() + cf); C_SF_SET(pc, P.sf()); }
+        } else { p = C_ONE(pc); pSucc = P.w1; P.set_one_freq(P.oneFreq() + (P.oneFreq() < 11)); S_FREQ_SET(p, P.oneFreq()); }
     }
     pc = m.MaxContext;
     if (!m.OrderFall && iFSuccessor) {
@@ -632,27 +643,27 @@ FS_DEV void UpdateModel(Coder& m, uint32_t MinContext, const Ctx& mcMin, bool ha
     } else iFSuccessor = ReduceOrder(m, p, pSucc, MinContext);
     if (!iFSuccessor) { RestoreModelRare(m); return; }
     if (!--m.OrderFall) { iSuccessor = iFSuccessor; m.pText -= (m.MaxContext != MinContext); }
-    s0 = mcMin.sf - FFreq; ns = mcMin.ns;
+    s0 = mcMin.sf() - FFreq; ns = mcMin.ns();
     const uint32_t Flag = 0x08u * (FSymbol >= 0x40);
     // one record fetch per context on the way down to MinContext; NumStats, Flags and SummFreq go back as one word
     while (pc != MinContext) {
         uint32_t summ, stats;
         FS_PATH(g_path[12]);
         const Ctx R = ctx_load(m, pc);
-        if ((ns1 = R.ns) != 0) {
+        if ((ns1 = R.ns()) != 0) {
             stats = R.w1;
             if ((ns1 & 1) != 0) {
                 p = ExpandUnits(m, stats, (ns1 + 1) >> 1);
                 if (!p) { restart = true; break; }
                 stats = p;
             }
-            summ = R.sf + (FS_UNI(m.sh->QT[ns + 4]) >> 3);
+            summ = R.sf() + (FS_UNI(m.sh->QT[ns + 4]) >> 3);
         } else {
             p = AllocUnits(m, 1);
             if (!p) { restart = true; break; }
-            uint32_t fr = R.oneFreq;
+            uint32_t fr = R.oneFreq();
             fr = (fr <= MAX_FREQ / 3) ? (2 * fr - 1) : (MAX_FREQ - 15);
-            state_store(m, p, R.oneSym | (fr << 8), R.w1);           // oneState moves into its own unit
+            state_store(m, p, R.oneSym() | (fr << 8), R.w1);           // oneState moves into its own unit
             stats = p;
             summ = fr + (ns > 1) + kExpEscape[FS_UNI(m.sh->QT[m.BSumm >> 8])];
         }
@@ -661,8 +672,8 @@ FS_DEV void UpdateModel(Coder& m, uint32_t MinContext, const Ctx& mcMin, bool ha
         else { cf = 4 + (cf > 8 * sf) + (cf > 10 * sf) + (cf > 13 * sf); summ += cf; }
         ns1 += 1;
         state_store(m, stats + 6u * ns1, FSymbol | (cf << 8), iSuccessor);
-        fs_st32(HP(pc), (ns1 & 0xFFu) | (((R.flags | Flag) & 0xFFu) << 8) | ((summ & 0xFFFFu) << 16));
-        if (stats != R.w1 || R.ns == 0) fs_st32(HP(pc) + 4, stats);
+        fs_st32(HP(pc), (ns1 & 0xFFu) | (((R.flags() | Flag) & 0xFFu) << 8) | ((summ & 0xFFFFu) << 16));
+        if (stats != R.w1 || R.ns() == 0) fs_st32(HP(pc) + 4, stats);
         pc = R.suff;
     }
     if (restart) { RestoreModelRare(m); return; }
@@ -686,23 +697,23 @@ FS_DEV void encodeBinSymbol(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufR
     FS_REGION(1);
     const uint32_t rs = C_ONE(c);
     sufRec = ctx_load(m, mc.suff); sufCtx = mc.suff;
-    const uint32_t sufNs = sufRec.ns;
-    const uint32_t idx = FS_UNI(m.sh->QT[mc.oneFreq - 1]) * 64u + NS2BSIndx(sufNs) + m.PrevSuccess + mc.flags + (uint32_t)((m.RunLength >> 26) & 0x20);
+    const uint32_t sufNs = sufRec.ns();
+    const uint32_t idx = FS_UNI(m.sh->QT[mc.oneFreq() - 1]) * 64u + NS2BSIndx(sufNs) + m.PrevSuccess + mc.flags() + (uint32_t)((m.RunLength >> 26) & 0x20);
     uint32_t bs = FS_UNI(m.sh->BinSumm[idx]);
     m.BSumm = (int32_t)bs;
     const uint32_t tmp = bs * (m.range >>= TOT_BITS);
     bs -= (bs + ROUND) >> PERIOD_BITS;
-    if ((int)mc.oneSym == symbol) {
+    if ((int)mc.oneSym() == symbol) {
         prefetch_successor(m, c, mc.w1);
         bs += INTERVAL; m.range = tmp;
-        const uint32_t nf = mc.oneFreq + (mc.oneFreq < 196);
+        const uint32_t nf = mc.oneFreq() + (mc.oneFreq() < 196);
         m.FoundState = rs; S_FREQ_SET(rs, nf);
-        m.fsSym = mc.oneSym; m.fsFreq = nf; m.fsSucc = mc.w1;
-        mc.oneFreq = nf; mc.sf = mc.oneSym | (nf << 8);          // the caller's copy of the record follows the store
+        m.fsSym = mc.oneSym(); m.fsFreq = nf; m.fsSucc = mc.w1;
+        mc.set_one_freq(nf);          // the caller's copy of the record follows the store
         m.RunLength++; m.PrevSuccess = 1;
     } else {
         m.low += tmp; m.range *= (uint32_t)(BIN_SCALE - m.BSumm);
-        m.sh->CharMask[mc.oneSym] = (uint8_t)m.EscCount;
+        m.sh->CharMask[mc.oneSym()] = (uint8_t)m.EscCount;
         m.NumMasked = m.PrevSuccess = 0; m.FoundState = 0;
     }
     m.sh->BinSumm[idx] = (uint16_t)bs;
@@ -711,14 +722,14 @@ FS_DEV void encodeBinSymbol(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufR
 FS_DEV void encodeSymbol1(Coder& m, uint32_t c, Ctx& mc, int symbol)
 {
     FS_REGION(1);
-    const uint32_t stats = mc.w1, ns = mc.ns;
-    m.rScale = mc.sf;
+    const uint32_t stats = mc.w1, ns = mc.ns();
+    m.rScale = mc.sf();
     uint32_t LoCnt = 0, p = 0, k = 0, base = 0; bool found = false;
     LaneStates ls = lane_states(m, stats, ns, 0);
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (FS_UB(ns < FS_WAVE)) {                              // the usual case: the whole list is in the lanes, no loop
+    if (FS_UNI(ns) < FS_WAVE) {                              // the usual case: the whole list is in the lanes, no loop
         const uint64_t hit = fs_ballot(ls.valid && (int)(ls.sf & 0xFFu) == symbol);
-        if (FS_UB(hit != 0)) { k = fs_ctz64(hit); if (FS_UB(k != 0)) LoCnt = fs_wave_sum8(ls.sf >> 8, ls.valid && (uint32_t)FS_LANE() < k); p = stats + 6u * k; found = true; }
+        if (hit != 0) { k = FS_UNI(fs_ctz64(hit)); if (k != 0) LoCnt = fs_wave_sum8(ls.sf >> 8, ls.valid && (uint32_t)FS_LANE() < k); p = stats + 6u * k; found = true; }
         else LoCnt = fs_wave_sum8(ls.sf >> 8, ls.valid);
     } else
 #endif
@@ -729,7 +740,7 @@ FS_DEV void encodeSymbol1(Coder& m, uint32_t c, Ctx& mc, int symbol)
         if (base + FS_WAVE > ns) break;
         base += FS_WAVE; ls = lane_states(m, stats, ns, base);
     }
-    if (FS_UB(!found)) {                                    // escape: mask every symbol of the context
+    if (FS_UNI((uint32_t)found) == 0) {                     // escape: mask every symbol of the context
         m.PrevSuccess = 0; m.rLow = LoCnt;
         const uint8_t esc = (uint8_t)m.EscCount;
         if (ns < FS_WAVE) { if (ls.valid) m.sh->CharMask[ls.sf & 0xFFu] = esc; }
@@ -741,10 +752,10 @@ FS_DEV void encodeSymbol1(Coder& m, uint32_t c, Ctx& mc, int symbol)
     const uint32_t fFound = FS_UNI(fs_readlane(ls.sf >> 8, k)), succ = FS_UNI(fs_readlane(ls.succ, k));
     m.fsSym = (uint32_t)symbol; m.fsSucc = succ;
     prefetch_successor(m, c, succ);
-    if (FS_UB(base + k == 0)) {                              // most probable symbol
+    if (FS_UNI(base + k) == 0) {                              // most probable symbol
         m.PrevSuccess = (2 * (m.rHigh = fFound) > m.rScale);
         m.FoundState = p; m.fsFreq = fFound + 4; S_FREQ_SET(p, fFound + 4); C_SF_SET(c, m.rScale + 4);
-        mc.sf = m.rScale + 4;
+        mc.set_sf(m.rScale + 4);
         if (fFound + 4 > MAX_FREQ) { rescale(m, c); fs_reload(m); mc = ctx_load(m, c); }
         m.rLow = 0; return;
     }
@@ -752,7 +763,7 @@ FS_DEV void encodeSymbol1(Coder& m, uint32_t c, Ctx& mc, int symbol)
     m.rHigh = (m.rLow = LoCnt) + fFound;
     // update1: +4, then bubble one position up if it now outweighs its predecessor
     m.FoundState = p; m.fsFreq = fFound + 4; C_SF_SET(c, m.rScale + 4);
-    mc.sf = m.rScale + 4;
+    mc.set_sf(m.rScale + 4);
     uint32_t prevSf, prevSucc;
     if (k > 0) { prevSf = FS_UNI(fs_readlane(ls.sf, k - 1)); prevSucc = FS_UNI(fs_readlane(ls.succ, k - 1)); }
     else { const St t = st_load(m, p - 6); prevSf = t.sym | (t.freq << 8); prevSucc = t.succ; }
@@ -767,7 +778,7 @@ FS_DEV void encodeSymbol1(Coder& m, uint32_t c, Ctx& mc, int symbol)
 FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec, uint32_t& sufCtx)
 {
     FS_REGION(8);
-    const uint32_t nsC = mc.ns, stats = mc.w1;
+    const uint32_t nsC = mc.ns(), stats = mc.w1;
     // NumStats of the suffix context, in flight together with the state fetch below (the root has no suffix and,
     // with all 256 symbols, never needs it: Model.cpp:509)
     CtxRaw sr; sr.a = sr.b = sr.d = 0;
@@ -778,8 +789,8 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
     // makeEscFreq2
     uint32_t seeIdx = 0xFFFFFFFFu, see = 0;
     if (nsC != 0xFF) {
-        const uint32_t sufNs = mc.suff ? sufRec.ns : 0u;
-        seeIdx = (FS_UNI(m.sh->QT[nsC + 3]) - 4u) * 32u + (mc.sf > 10u * (nsC + 1u)) + 2u * (2u * nsC < sufNs + m.NumMasked) + mc.flags;
+        const uint32_t sufNs = mc.suff ? sufRec.ns() : 0u;
+        seeIdx = (FS_UNI(m.sh->QT[nsC + 3]) - 4u) * 32u + (mc.sf() > 10u * (nsC + 1u)) + 2u * (2u * nsC < sufNs + m.NumMasked) + mc.flags();
         see = FS_UNI(m.sh->SEE2[seeIdx]);
         const uint32_t shift = (see >> 16) & 0xFFu; uint32_t summ = see & 0xFFFFu;
         const uint32_t r = summ >> shift; summ = (summ - r) & 0xFFFFu;
@@ -790,14 +801,14 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
     const uint8_t esc = (uint8_t)m.EscCount;
     uint32_t LoCnt = 0, p = 0, fFound = 0, succ = 0, tail = 0; bool found = false;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (FS_UB(nsC < FS_WAVE)) {                             // the whole list is in the lanes: no loop
+    if (FS_UNI(nsC) < FS_WAVE) {                             // the whole list is in the lanes: no loop
         const uint32_t sy = ls.sf & 0xFFu;
         const bool unmasked = ls.valid && m.sh->CharMask[sy] != esc;
         const uint64_t hit = fs_ballot(unmasked && (int)sy == symbol);
         const uint32_t all = fs_wave_sum8(ls.sf >> 8, unmasked);
-        if (FS_UB(hit != 0)) {
-            const uint32_t k = fs_ctz64(hit);
-            LoCnt = FS_UB(k != 0) ? fs_wave_sum8(ls.sf >> 8, unmasked && (uint32_t)FS_LANE() < k) : 0u;
+        if (hit != 0) {
+            const uint32_t k = FS_UNI(fs_ctz64(hit));
+            LoCnt = k != 0 ? fs_wave_sum8(ls.sf >> 8, unmasked && (uint32_t)FS_LANE() < k) : 0u;
             fFound = FS_UNI(fs_readlane(ls.sf >> 8, k)); succ = FS_UNI(fs_readlane(ls.succ, k));
             tail = all - LoCnt - fFound;
             if (unmasked && (uint32_t)FS_LANE() <= k) m.sh->CharMask[sy] = esc;     // visited states are marked
@@ -830,7 +841,7 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
         base += FS_WAVE; ls = lane_states(m, stats, nsC, base);
     }
     FS_WAVE_SYNC();
-    if (FS_UB(!found)) {
+    if (FS_UNI((uint32_t)found) == 0) {
         m.rHigh = (m.rScale += (m.rLow = LoCnt));
         if (seeIdx != 0xFFFFFFFFu) m.sh->SEE2[seeIdx] = (see & 0xFFFF0000u) | ((see + m.rScale) & 0xFFFFu);
         m.NumMasked = nsC;
@@ -852,8 +863,8 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
     }
     // update2
     m.FoundState = p; m.fsSym = (uint32_t)symbol; m.fsFreq = fFound + 4; m.fsSucc = succ;
-    S_FREQ_SET(p, fFound + 4); C_SF_SET(c, mc.sf + 4);
-    mc.sf += 4;
+    S_FREQ_SET(p, fFound + 4); C_SF_SET(c, mc.sf() + 4);
+    mc.set_sf(mc.sf() + 4);
     if (fFound + 4 > MAX_FREQ) { rescale(m, c); fs_reload(m); mc = ctx_load(m, c); }
     m.EscCount = (m.EscCount + 1) & 0xFFu; m.RunLength = INIT_RL;
 }
@@ -877,14 +888,14 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
     const bool wide = (((uintptr_t)in) & 3u) == 0;
     uint32_t pos = 0, cur = 0, nxt = 0;
     if (wide && n >= 4) nxt = *(fs_cgptr32)in;
-    Ctx mc; mc.ns = mc.flags = mc.sf = mc.w1 = mc.suff = mc.oneSym = mc.oneFreq = 0;
-    bool keep = false; uint32_t prevCtx = 0;
+    Ctx mc; mc.a = mc.w1 = mc.suff = 0;
+    uint32_t keep = 0, prevCtx = 0;
     Ctx sufRec = mc; uint32_t sufCtx = 0;
     m.pfCtx = 0; m.pf.a = m.pf.b = m.pf.d = 0;
     for (uint32_t MinContext = m.MaxContext;;) {
         int c = -1;
-        if (FS_UB(pos < n)) {
-            if (FS_UB(wide && (pos | 3u) < n)) {
+        if (FS_UNI(pos) < n) {
+            if (wide && (FS_UNI(pos) | 3u) < n) {
                 if ((pos & 3u) == 0) { cur = FS_UNI(nxt); if (pos + 7u < n) nxt = *(fs_cgptr32)(in + pos + 4u); }
                 c = (int)((cur >> (8u * (pos & 3u))) & 0xFFu);
             } else c = (int)fs_ld8(in + pos);
@@ -893,38 +904,38 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
         // everything carried from symbol to symbol is wave-uniform by construction; saying so here keeps one value the
         // compiler could not prove uniform from turning the whole loop body into exec-masked (divergent) code
         MinContext = FS_UNI(MinContext); prevCtx = FS_UNI(prevCtx);
-        mc.ns = FS_UNI(mc.ns); mc.flags = FS_UNI(mc.flags); mc.sf = FS_UNI(mc.sf); mc.w1 = FS_UNI(mc.w1); mc.suff = FS_UNI(mc.suff); mc.oneSym = FS_UNI(mc.oneSym); mc.oneFreq = FS_UNI(mc.oneFreq);
+        mc.a = FS_UNI(mc.a); mc.w1 = FS_UNI(mc.w1); mc.suff = FS_UNI(mc.suff);
         m.OrderFall = (int32_t)FS_UNI(m.OrderFall); m.RunLength = (int32_t)FS_UNI(m.RunLength); m.pfCtx = FS_UNI(m.pfCtx);
         m.low = FS_UNI(m.low); m.range = FS_UNI(m.range); m.NumMasked = FS_UNI(m.NumMasked); m.EscCount = FS_UNI(m.EscCount); m.PrevSuccess = FS_UNI(m.PrevSuccess);
         m.pText = FS_UNI(m.pText); m.UnitsStart = FS_UNI(m.UnitsStart); m.LoUnit = FS_UNI(m.LoUnit); m.HiUnit = FS_UNI(m.HiUnit); m.outPos = FS_UNI(m.outPos);
         m.MaxContext = FS_UNI(m.MaxContext); m.BSumm = (int32_t)FS_UNI(m.BSumm);
         // first context of the symbol: still in registers (a context that succeeded itself), requested during the
         // previous symbol, or fetched now
-        if (FS_UB(m.pfCtx == MinContext)) mc = ctx_finish(m.pf);
-        else if (FS_UB(!(keep && MinContext == prevCtx))) mc = ctx_load(m, MinContext);
-        m.pfCtx = 0; keep = false; prevCtx = MinContext; sufCtx = 0;
-        mc.ns = FS_UNI(mc.ns); mc.flags = FS_UNI(mc.flags); mc.sf = FS_UNI(mc.sf); mc.w1 = FS_UNI(mc.w1); mc.suff = FS_UNI(mc.suff); mc.oneSym = FS_UNI(mc.oneSym); mc.oneFreq = FS_UNI(mc.oneFreq);
+        if (m.pfCtx == MinContext) mc = ctx_finish(m.pf);
+        else if (!(FS_UNI(keep) && MinContext == prevCtx)) mc = ctx_load(m, MinContext);
+        m.pfCtx = 0; keep = 0; prevCtx = MinContext; sufCtx = 0;
+        mc.a = FS_UNI(mc.a); mc.w1 = FS_UNI(mc.w1); mc.suff = FS_UNI(mc.suff);
         FS_PATH(g_path[0]);
-        if (FS_UB(mc.ns != 0)) { FS_PATH(g_path[2]); encodeSymbol1(m, MinContext, mc, c); rc_encode(m); if (m.FoundState) { if (m.rLow == 0) FS_PATH(g_path[3]); else FS_PATH(g_path[4]); } }
+        if (mc.ns() != 0) { FS_PATH(g_path[2]); encodeSymbol1(m, MinContext, mc, c); rc_encode(m); if (m.FoundState) { if (m.rLow == 0) FS_PATH(g_path[3]); else FS_PATH(g_path[4]); } }
         else { FS_PATH(g_path[1]); encodeBinSymbol(m, MinContext, mc, c, sufRec, sufCtx); }
-        bool stop = false;
-        while (FS_UB(!m.FoundState)) {
+        uint32_t stop = 0;
+        while (FS_UNI(m.FoundState) == 0) {
             rc_normalize(m);
             do {
-                if (FS_UB(!mc.suff)) { stop = true; break; }
+                if (FS_UNI(mc.suff) == 0) { stop = 1; break; }
                 m.OrderFall++; MinContext = mc.suff;
-                if (FS_UB(sufCtx == MinContext)) mc = sufRec; else mc = ctx_load(m, MinContext);
+                if (FS_UNI(sufCtx) == FS_UNI(MinContext)) mc = sufRec; else mc = ctx_load(m, MinContext);
                 sufCtx = 0;
-            } while (FS_UB(mc.ns == m.NumMasked));
-            if (FS_UB(stop)) break;
+            } while (FS_UNI(mc.ns()) == FS_UNI(m.NumMasked));
+            if (FS_UNI(stop)) break;
             FS_PATH(g_path[5]);
             encodeSymbol2(m, MinContext, mc, c, sufRec, sufCtx); rc_encode(m);
             if (m.FoundState) FS_PATH(g_path[6]);
         }
-        if (FS_UB(stop)) break;
-        const uint32_t succ = m.fsSucc;
-        if (FS_UB(!m.OrderFall && succ >= m.UnitsStart)) { FS_PATH(g_path[7]); m.MaxContext = succ; keep = (succ == MinContext); }
-        else { UpdateModel(m, MinContext, mc, FS_UB(sufCtx && sufCtx == mc.suff), sufRec); if (FS_UB(m.EscCount == 0)) clear_mask(m); }
+        if (FS_UNI(stop)) break;
+        const uint32_t succ = FS_UNI(m.fsSucc);
+        if (FS_UNI((uint32_t)m.OrderFall) == 0 && succ >= FS_UNI(m.UnitsStart)) { FS_PATH(g_path[7]); m.MaxContext = succ; keep = (succ == MinContext) ? 1u : 0u; }
+        else { UpdateModel(m, MinContext, mc, FS_UNI(sufCtx) != 0 && FS_UNI(sufCtx) == FS_UNI(mc.suff), sufRec); if (FS_UNI(m.EscCount) == 0) clear_mask(m); }
         rc_normalize(m); MinContext = m.MaxContext;
     }
     for (int i = 0; i < 4; i++) { put_byte(m, m.low >> 24); m.low <<= 8; }

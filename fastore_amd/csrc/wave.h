@@ -19,6 +19,7 @@
   #define FS_GLOBAL __attribute__((address_space(1)))
   #define FS_LDS __attribute__((address_space(3)))
   #define FS_DEV __device__ __forceinline__
+  #define FS_DEV_M __device__ __forceinline__        // member functions
   // everything is inlined into the kernel: an out-of-line callee takes the coder state by reference, which pins that
   // whole struct in scratch memory and turns every field access of the hot loop into a vector-memory instruction
   #if defined(FS_KEEP_NOINLINE)
@@ -40,6 +41,7 @@
   #define FS_GLOBAL
   #define FS_LDS
   #define FS_DEV static inline
+  #define FS_DEV_M inline
   #define FS_DEV_NOINLINE static
   #define FS_WAVE 1
   #define FS_LANE() 0

@@ -1,15 +1,14 @@
 cd $GRAFT_REPO_ROOT
-which perf strace ltrace gdb 2>&1 | head -5 > gpurun_out/exp16.log
-timeout 500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 >> gpurun_out/exp16.log
-COPIES=1,3072 timeout 100 python3 tools/ppmd_microbench.py 100000 >> gpurun_out/exp16.log 2>&1
-run() { # label, env...
-  echo "== $1" >> gpurun_out/exp16.log; shift
-  env "$@" FS_TRACE=1 timeout 200 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline 2> gpurun_out/exp16.err | python3 -c "
+(cat /sys/fs/cgroup/cpu.max; nproc; grep Cpus_allowed_list /proc/self/status; cat /sys/fs/cgroup/cpu.stat | head -6; cat /sys/fs/cgroup/memory.max) > gpurun_out/exp19.log 2>&1
+build/cpu_scaling_probe >> gpurun_out/exp19.log 2>&1
+timeout 300 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+run() { echo "== $1" >> gpurun_out/exp19.log; shift
+  FS_TRACE=1 timeout 200 "$@" python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline 2> gpurun_out/exp19.err | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('MB/s', d['value'], 'ms/step', d['ms_per_step'], d['stages_ms_per_step'])" >> gpurun_out/exp16.log
-  grep -E "batch:" gpurun_out/exp16.err | tail -2 | cut -c1-220 >> gpurun_out/exp16.log
+d=json.loads(sys.stdin.read()); print('MB/s', d['value'], 'ms/step', d['ms_per_step'], d['stages_ms_per_step'])" >> gpurun_out/exp19.log
+  grep -E "batch:" gpurun_out/exp19.err | tail -1 | cut -c1-220 >> gpurun_out/exp19.log
 }
-run "24 threads" A=1
-run "48 threads" FS_HOST_THREADS=48
-run "12 threads" FS_HOST_THREADS=12
-cat gpurun_out/exp16.log
+run "blocking waits, 24 threads" env A=1
+run "blocking waits, 48 threads" env FS_HOST_THREADS=48
+(cat /sys/fs/cgroup/cpu.stat | head -6) >> gpurun_out/exp19.log 2>&1
+cat gpurun_out/exp19.log
