@@ -40,12 +40,15 @@ struct Unpacker {
     bool pe;
     Settings pairSettings;
     bool placed = false; uint64_t seqCur = 0, headCur = 0;
+    uint32_t dna4[256];      // byte of packed bases -> four characters
 
     Unpacker(const BinModuleConfigRaw& c, Batch& batch, Batch& graph, const std::vector<uint8_t>& m, uint64_t ms, const std::vector<uint8_t>& d, uint64_t ds,
              const std::vector<uint8_t>& q, uint64_t qs, const std::vector<uint8_t>& h, uint64_t hs)
         : cfg(c), b(batch), g(graph), meta(m.data(), ms), dna(d.data(), ds), qua(q.data(), qs), head(h.data(), hs), pe(c.archiveType.readType == READ_PE)
     {
         pairSettings.minLen = pairSettings.maxLen = 1; pairSettings.hasConstLen = true; pairSettings.usesHeaders = false;
+        const char* o = c.minimizer.dnaSymbolOrder;
+        for (uint32_t w = 0; w < 256; ++w) { const uint8_t q[4] = {(uint8_t)o[w >> 6], (uint8_t)o[(w >> 4) & 3], (uint8_t)o[(w >> 2) & 3], (uint8_t)o[w & 3]}; memcpy(&dna4[w], q, 4); }
     }
 
     void readDna(uint8_t* seq, uint32_t seqLen, uint32_t minimPos, uint32_t suffixLen)
@@ -53,10 +56,14 @@ struct Unpacker {
         const bool plain = meta.getBit() != 0;
         const char* idxToDna = cfg.minimizer.dnaSymbolOrder;
         if (plain) {
-            // four bases per window read
+            // sixteen bases per window read: four table look-ups of four bases each
             auto run = [&](uint32_t from, uint32_t to) {
                 uint32_t i = from;
-                for (; i + 4 <= to; i += 4) { const uint32_t w = dna.getBits(8); seq[i] = (uint8_t)idxToDna[w >> 6]; seq[i + 1] = (uint8_t)idxToDna[(w >> 4) & 3]; seq[i + 2] = (uint8_t)idxToDna[(w >> 2) & 3]; seq[i + 3] = (uint8_t)idxToDna[w & 3]; }
+                for (; i + 16 <= to; i += 16) {
+                    const uint32_t w = dna.getBits(32);
+                    memcpy(seq + i, &dna4[w >> 24], 4); memcpy(seq + i + 4, &dna4[(w >> 16) & 255], 4); memcpy(seq + i + 8, &dna4[(w >> 8) & 255], 4); memcpy(seq + i + 12, &dna4[w & 255], 4);
+                }
+                for (; i + 4 <= to; i += 4) { const uint32_t w = dna.getBits(8); memcpy(seq + i, &dna4[w], 4); }
                 for (; i < to; ++i) seq[i] = (uint8_t)idxToDna[dna.get2Bits()];
             };
             run(0, minimPos); run(minimPos + suffixLen, seqLen);
@@ -73,7 +80,11 @@ struct Unpacker {
         case MET_8BIN: for (uint32_t i = 0; i < n; ++i) q[i] = (uint8_t)(off + kIdxToQua8[qua.getBits(3)]); break;
         default: {
             uint32_t i = 0;
-            for (; i + 4 <= n; i += 4) { const uint32_t w = qua.getBits(24); q[i] = (uint8_t)((w >> 18) + off); q[i + 1] = (uint8_t)(((w >> 12) & 63) + off); q[i + 2] = (uint8_t)(((w >> 6) & 63) + off); q[i + 3] = (uint8_t)((w & 63) + off); }
+            for (; i + 5 <= n; i += 5) {
+                const uint32_t w = qua.getBits(30);
+                q[i] = (uint8_t)((w >> 24) + off); q[i + 1] = (uint8_t)(((w >> 18) & 63) + off); q[i + 2] = (uint8_t)(((w >> 12) & 63) + off);
+                q[i + 3] = (uint8_t)(((w >> 6) & 63) + off); q[i + 4] = (uint8_t)((w & 63) + off);
+            }
             for (; i < n; ++i) q[i] = (uint8_t)(qua.getBits(6) + off);
             break;
         }

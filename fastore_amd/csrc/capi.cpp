@@ -1,5 +1,6 @@
 // extern "C" boundary (include/fastore_amd.h).  No exceptions cross it.
 #include <stdlib.h>
+#include <sched.h>
 #include <string.h>
 #include <stdexcept>
 #include <string>
@@ -33,6 +34,25 @@ void fsgpu_config_defaults(fsgpu_config* cfg)
 int fsgpu_device_count(void) { return fsengine::device_count(); }
 const char* fsgpu_create_error(void) { return g_createError.c_str(); }
 
+static unsigned usableCores()
+{
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+    // cgroup v2: "<quota> <period>" or "max <period>"; cgroup v1: cpu.cfs_quota_us / cpu.cfs_period_us
+    long long quota = -1, period = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else {
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
+    }
+    if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    return n;
+}
+
 fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
 {
     if (!cfg) { g_createError = "null config"; return nullptr; }
@@ -45,7 +65,11 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
     c.par.extraReduceHardReads = cfg->extra_reduce_hard_reads != 0; c.par.extraReduceExpensiveLzMatches = cfg->extra_reduce_expensive_lz != 0;
     c.par.maxRecordShiftDifference = cfg->max_record_shift_diff; c.par.maxNewVariantsPerRead = cfg->max_new_variants_per_read;
     c.par.maxHammingDistance = cfg->max_hamming_distance; c.par.minConsensusSize = cfg->min_consensus_size;
-    c.hostThreads = cfg->host_threads ? cfg->host_threads : std::min(24u, std::max(1u, std::thread::hardware_concurrency()));   // measured on a 2 x 64-core host: the front end stops scaling at ~16-24 threads and degrades beyond
+    // default: 1.5 host threads per core this process may really use (the smaller of the hardware count, the affinity
+    // mask and the cgroup CPU quota), at most 24.  The measurement box shows 256 CPUs but its container is capped at 16
+    // cores: measured 12 / 14 / 16 / 20 / 24 / 32 / 48 threads -> 24 is best (the workers compete with the lane, block-0
+    // and runtime threads for the same 16 cores), more only time-slice.
+    c.hostThreads = cfg->host_threads ? cfg->host_threads : std::max(1u, std::min(24u, usableCores() * 3u / 2u));
     if (getenv("FS_HOST_THREADS")) c.hostThreads = std::max(1, atoi(getenv("FS_HOST_THREADS")));     // experiments
     if (getenv("FS_PIPELINE_SLICES") && atoi(getenv("FS_PIPELINE_SLICES")) > 0) c.cfg.pipeline_slices = (uint32_t)atoi(getenv("FS_PIPELINE_SLICES"));
     if (getenv("FS_MAX_WAVES") && atoi(getenv("FS_MAX_WAVES")) > 0) c.cfg.max_waves = (uint32_t)atoi(getenv("FS_MAX_WAVES"));

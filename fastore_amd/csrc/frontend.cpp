@@ -275,6 +275,18 @@ struct BinEncoder::Impl {
     }
 
     struct WinEntry { const uint8_t* seq; int32_t node; uint16_t seqLen, minPos; };
+    // the LZ window, newest entry first: a power-of-two ring (the scan over it is the hottest loop of the front end; a
+    // std::deque pays a block lookup per index)
+    struct WinRing {
+        std::vector<WinEntry> buf; uint32_t head = 0, count = 0, mask = 0;
+        void reset(uint32_t capacity) { uint32_t c = 1; while (c < capacity + 2) c <<= 1; if (buf.size() != c) buf.resize(c); mask = c - 1; head = 0; count = 0; }
+        uint32_t size() const { return count; }
+        const WinEntry& operator[](uint32_t i) const { return buf[(head + i) & mask]; }
+        void push_front(const WinEntry& e) { head = (head - 1) & mask; buf[head] = e; ++count; }
+        void pop_back() { --count; }
+    };
+    WinRing winRings[8];                      // one per nesting level of sub-trees (constructMatchTree re-enters itself)
+    uint32_t winDepth = 0;
 
     // ReadsClassifierSE::ConstructMatchTree (fastore_pack/ReadsClassifier.cpp:95-442).
     // order: node ids in processing order; auxRoot: node id of the sub-tree root copy or -1.
@@ -284,7 +296,10 @@ struct BinEncoder::Impl {
         if (!dummyInit) { memset(dummy, 'N', sizeof dummy); dummyInit = true; }
         roots.clear();
         const uint32_t W = par.maxLzWindowSize;
-        std::deque<WinEntry> win;                 // real entries, newest first
+        struct DepthGuard { uint32_t& d; explicit DepthGuard(uint32_t& x) : d(x) { ++d; } ~DepthGuard() { --d; } } depthGuard(winDepth);
+        if (winDepth > 8) throw std::runtime_error("sub-trees nested deeper than 8 levels");
+        WinRing& win = winRings[winDepth - 1];    // real entries, newest first
+        win.reset(W);
         uint32_t numDummies = W; bool dupAtBack = false;
         const bool usePrefix = par.extraReduceHardReads || par.extraReduceExpensiveLzMatches;
         std::vector<int32_t> rp[25];              // the 25 std::set<MatchNode*, prefixFun> as sorted vectors
