@@ -285,6 +285,7 @@ struct BinEncoder::Impl {
         void push_front(const WinEntry& e) { head = (head - 1) & mask; buf[head] = e; ++count; }
         void pop_back() { --count; }
     };
+    std::vector<uint64_t> prefKey;            // per node: the packed start of its reversed prefix (see constructMatchTree)
     WinRing winRings[8];                      // one per nesting level of sub-trees (constructMatchTree re-enters itself)
     uint32_t winDepth = 0;
 
@@ -304,7 +305,16 @@ struct BinEncoder::Impl {
         const bool usePrefix = par.extraReduceHardReads || par.extraReduceExpensiveLzMatches;
         std::vector<int32_t> rp[25];              // the 25 std::set<MatchNode*, prefixFun> as sorted vectors
 
+        // every node that enters a prefix buffer has minimPos >= 8, so the first six bases before the signature (in
+        // comparison order) are inside the compared range of any pair: packed into one word they decide most comparisons
+        if (usePrefix && prefKey.size() < nodes.size()) prefKey.resize(nodes.size());
+        auto makeKey = [&](int32_t x) {
+            const int32_t mx = (int32_t)minimPos(nodes[x].vrec); const uint8_t* px = seq(nodes[x].vrec) + mx - 2;
+            uint64_t k = 0; for (int i = 0; i < 6; ++i) k = (k << 8) | px[-i];
+            prefKey[x] = k;
+        };
         auto prefixLess = [&](int32_t x, int32_t y) {
+            if (prefKey[x] != prefKey[y]) return prefKey[x] < prefKey[y];
             const int32_t mx = (int32_t)minimPos(nodes[x].vrec), my = (int32_t)minimPos(nodes[y].vrec);
             const int32_t maxRange = (mx < my ? mx : my) - 2;
             const uint8_t *px = seq(nodes[x].vrec) + mx - 2, *py = seq(nodes[y].vrec) + my - 2;
@@ -374,6 +384,7 @@ struct BinEncoder::Impl {
                         int32_t bi = dnaToIdxAcgtn(rs[rm - 2]);
                         bi = bi * 5 + dnaToIdxAcgtn(rs[rm - 1]);
                         rpb = &rp[bi];
+                        makeKey(cur);
                     }
                     if (searchRev && rm >= 8) {
                         MatchResult fwd, rev; int32_t fwdNode = -1, revNode = -1;
@@ -463,6 +474,31 @@ struct BinEncoder::Impl {
         if (first) { bi.cons.rangeFirst = f; bi.cons.rangeSecond = s; }
         else { bi.cons.rangeFirst = std::min(bi.cons.rangeFirst, f); bi.cons.rangeSecond = std::max(bi.cons.rangeSecond, s); }
     }
+    // consensus update of one member read: unset positions take its base, set positions that differ count a variant,
+    // every covered position counts the record (ContigBuilder.cpp:232-244)
+    void mergeIntoConsensus(BuildInfo& bi, const uint8_t* s, uint32_t consBegin, uint32_t L)
+    {
+        uint32_t i = par.beginCut; const uint32_t end = L - par.endCut;
+        char* cs = bi.cons.sequence.data() + consBegin;
+        uint16_t* rpp = bi.recordsPerPos.data() + consBegin; uint16_t* vf = bi.variantFreqPerPos.data() + consBegin;
+#if defined(__SSE2__)
+        const __m128i dot = _mm_set1_epi8('.'), one16 = _mm_set1_epi16(1);
+        for (; i + 16 <= end; i += 16) {
+            const __m128i c = _mm_loadu_si128((const __m128i*)(cs + i)), r = _mm_loadu_si128((const __m128i*)(s + i));
+            const __m128i isDot = _mm_cmpeq_epi8(c, dot);
+            _mm_storeu_si128((__m128i*)(cs + i), _mm_or_si128(_mm_and_si128(isDot, r), _mm_andnot_si128(isDot, c)));
+            uint32_t diff = ((uint32_t)_mm_movemask_epi8(_mm_or_si128(isDot, _mm_cmpeq_epi8(c, r))) ^ 0xFFFFu) & 0xFFFFu;   // set and different
+            while (diff) { const uint32_t j = (uint32_t)__builtin_ctz(diff); diff &= diff - 1; vf[i + j]++; }
+            _mm_storeu_si128((__m128i*)(rpp + i), _mm_add_epi16(_mm_loadu_si128((const __m128i*)(rpp + i)), one16));
+            _mm_storeu_si128((__m128i*)(rpp + i + 8), _mm_add_epi16(_mm_loadu_si128((const __m128i*)(rpp + i + 8)), one16));
+        }
+#endif
+        for (; i < end; ++i) {
+            if (cs[i] == '.') cs[i] = (char)s[i];
+            else if (cs[i] != (char)s[i]) vf[i]++;
+            rpp[i]++;
+        }
+    }
     bool addRecord(BuildInfo& bi, int32_t n, bool fullMatchOnly)
     {
         const Node& node = nodes[n];
@@ -473,10 +509,32 @@ struct BinEncoder::Impl {
         const uint32_t consBegin = L - m, consEnd = consBegin + L;
         if (!bi.nodes.empty()) {
             WorkNode w; uint32_t ham = 0;
-            for (uint32_t i = par.beginCut; i < L - par.endCut; ++i) {
-                const uint32_t p = consBegin + i;
-                if (bi.cons.sequence[p] != '.' && bi.cons.sequence[p] != (char)s[i]) { ham++; if (bi.variantFreqPerPos[p] == 0) w.newVariantPositions.push_back((uint16_t)p); }
-                else if (bi.cons.sequence[p] == '.' && s[i] == 'N') return false;
+            {
+                uint32_t i = par.beginCut; const uint32_t end = L - par.endCut;
+                const char* cs = bi.cons.sequence.data() + consBegin;
+#if defined(__SSE2__)
+                // 16 positions per step: mismatches against a set consensus base and 'N' on an unset one are both rare, so
+                // the per-position work only runs for the flagged lanes (in position order, like the scalar loop)
+                const __m128i dot = _mm_set1_epi8('.'), en = _mm_set1_epi8('N');
+                for (; i + 16 <= end; i += 16) {
+                    const __m128i c = _mm_loadu_si128((const __m128i*)(cs + i)), r = _mm_loadu_si128((const __m128i*)(s + i));
+                    const uint32_t isDot = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(c, dot));
+                    const uint32_t same = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(c, r));
+                    const uint32_t isN = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(r, en));
+                    uint32_t flagged = ((~isDot & ~same) | (isDot & isN)) & 0xFFFFu;
+                    while (flagged) {
+                        const uint32_t j = (uint32_t)__builtin_ctz(flagged); flagged &= flagged - 1;
+                        const uint32_t p = consBegin + i + j;
+                        if ((isDot >> j) & 1u) return false;           // unset consensus position under an 'N'
+                        ham++; if (bi.variantFreqPerPos[p] == 0) w.newVariantPositions.push_back((uint16_t)p);
+                    }
+                }
+#endif
+                for (; i < end; ++i) {
+                    const uint32_t p = consBegin + i;
+                    if (cs[i] != '.' && cs[i] != (char)s[i]) { ham++; if (bi.variantFreqPerPos[p] == 0) w.newVariantPositions.push_back((uint16_t)p); }
+                    else if (cs[i] == '.' && s[i] == 'N') return false;
+                }
             }
             if (fullMatchOnly) { if (!w.newVariantPositions.empty()) return false; }
             else {
@@ -494,12 +552,7 @@ struct BinEncoder::Impl {
                     return false;
             }
             bi.cons.variantsCount += (uint32_t)w.newVariantPositions.size();
-            for (uint32_t i = par.beginCut; i < L - par.endCut; ++i) {
-                const uint32_t p = consBegin + i;
-                if (bi.cons.sequence[p] == '.') bi.cons.sequence[p] = (char)s[i];
-                else if (bi.cons.sequence[p] != (char)s[i]) bi.variantFreqPerPos[p]++;
-                bi.recordsPerPos[p]++;
-            }
+            mergeIntoConsensus(bi, s, consBegin, L);
             updateRange(bi, m, consBegin, consEnd, L, false);
             w.match = n; bi.nodes.push_back(std::move(w));
         } else {
@@ -547,12 +600,7 @@ struct BinEncoder::Impl {
                 if (bi.cons.sequence[p] != '.' && bi.cons.sequence[p] != (char)s[i]) if (bi.variantFreqPerPos[p] == 0) w.newVariantPositions.push_back((uint16_t)p);
             }
             bi.cons.variantsCount += (uint32_t)w.newVariantPositions.size();
-            for (uint32_t i = par.beginCut; i < L - par.endCut; ++i) {
-                const uint32_t p = consBegin + i;
-                if (bi.cons.sequence[p] == '.') bi.cons.sequence[p] = (char)s[i];
-                else if (bi.cons.sequence[p] != (char)s[i]) bi.variantFreqPerPos[p]++;
-                bi.recordsPerPos[p]++;
-            }
+            mergeIntoConsensus(bi, s, consBegin, L);
             updateRange(bi, m, consBegin, consEnd, L, false);
         }
     }
