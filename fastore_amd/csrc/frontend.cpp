@@ -278,11 +278,12 @@ struct BinEncoder::Impl {
     // the LZ window, newest entry first: a power-of-two ring (the scan over it is the hottest loop of the front end; a
     // std::deque pays a block lookup per index)
     struct WinRing {
-        std::vector<WinEntry> buf; uint32_t head = 0, count = 0, mask = 0;
-        void reset(uint32_t capacity) { uint32_t c = 1; while (c < capacity + 2) c <<= 1; if (buf.size() != c) buf.resize(c); mask = c - 1; head = 0; count = 0; }
+        std::vector<WinEntry> buf; std::vector<int16_t> mp;      // mp: the entries' minPos again, packed for the vector pre-filter
+        uint32_t head = 0, count = 0, mask = 0;
+        void reset(uint32_t capacity) { uint32_t c = 1; while (c < capacity + 2) c <<= 1; if (buf.size() != c) { buf.resize(c); mp.assign(c + 8, 0); } mask = c - 1; head = 0; count = 0; }
         uint32_t size() const { return count; }
         const WinEntry& operator[](uint32_t i) const { return buf[(head + i) & mask]; }
-        void push_front(const WinEntry& e) { head = (head - 1) & mask; buf[head] = e; ++count; }
+        void push_front(const WinEntry& e) { head = (head - 1) & mask; buf[head] = e; mp[head] = (int16_t)e.minPos; ++count; }
         void pop_back() { --count; }
     };
     std::vector<uint64_t> prefKey;            // per node: the packed start of its reversed prefix (see constructMatchTree)
@@ -341,12 +342,48 @@ struct BinEncoder::Impl {
             // FindBestLzMatch (ReadsClassifier.cpp:55-83)
             MatchResult mr; mr.cost = encodeThreshold + 1;
             bool stop = false;
+#if defined(__SSE2__)
+            {
+                // Eight entries per step are tested for |minPos - rm| * shiftCost <= best cost so far (and <= 127): an entry
+                // that fails cannot improve the match (updateLzMatch rejects it on the same test; the best cost only
+                // falls), so only the survivors are compared, in window order.
+                const uint32_t n = win.size(), cap = win.mask + 1;
+                const __m128i vrm = _mm_set1_epi16((int16_t)rm);
+                uint32_t i = 0;
+                while (i < n && !stop) {
+                    const uint32_t pos = (win.head + i) & win.mask;
+                    const uint32_t run = std::min(n - i, cap - pos);                 // contiguous stretch of the ring
+                    uint32_t k = 0;
+                    for (; k + 8 <= run && !stop; k += 8) {
+                        int32_t bound = mr.cost / par.shiftCost; if (bound > 127) bound = 127;
+                        const __m128i d = _mm_sub_epi16(_mm_loadu_si128((const __m128i*)(win.mp.data() + pos + k)), vrm);
+                        const __m128i ad = _mm_max_epi16(d, _mm_sub_epi16(_mm_setzero_si128(), d));
+                        uint32_t pass = (uint32_t)_mm_movemask_epi8(_mm_cmpgt_epi16(_mm_set1_epi16((int16_t)(bound + 1)), ad));   // two bits per entry
+                        while (pass) {
+                            const uint32_t j = (uint32_t)__builtin_ctz(pass) >> 1; pass &= ~(3u << (2 * j));
+                            const WinEntry& lz = win.buf[pos + k + j];
+                            if (!updateLzMatch(mr, rs, rl, rm, lz.seq, lz.seqLen, lz.minPos)) continue;
+                            mr.prevId = (int32_t)(i + k + j);
+                            if (mr.cost == 0) { stop = true; break; }
+                        }
+                    }
+                    for (; k < run && !stop; ++k) {
+                        const WinEntry& lz = win.buf[pos + k];
+                        if (!updateLzMatch(mr, rs, rl, rm, lz.seq, lz.seqLen, lz.minPos)) continue;
+                        mr.prevId = (int32_t)(i + k);
+                        if (mr.cost == 0) stop = true;
+                    }
+                    i += run;
+                }
+            }
+#else
             for (uint32_t i = 0; i < win.size(); ++i) {
                 const WinEntry& lz = win[i];
                 if (!updateLzMatch(mr, rs, rl, rm, lz.seq, lz.seqLen, lz.minPos)) continue;
                 mr.prevId = (int32_t)i;
                 if (mr.cost == 0) { stop = true; break; }
             }
+#endif
             if (!stop && numDummies > 0) {
                 // dummy entries (256 x 'N', minPos 0) can only win for reads that are >= 1/3 'N' or with a manual
                 // threshold; all dummies are identical, so the first one decides
