@@ -78,16 +78,7 @@ struct Unpacker {
         switch (cfg.quaParams.method) {
         case MET_BINARY: for (uint32_t i = 0; i < n; ++i) q[i] = (uint8_t)(off + (qua.getBit() ? 40 : 6)); break;
         case MET_8BIN: for (uint32_t i = 0; i < n; ++i) q[i] = (uint8_t)(off + kIdxToQua8[qua.getBits(3)]); break;
-        default: {
-            uint32_t i = 0;
-            for (; i + 5 <= n; i += 5) {
-                const uint32_t w = qua.getBits(30);
-                q[i] = (uint8_t)((w >> 24) + off); q[i + 1] = (uint8_t)(((w >> 18) & 63) + off); q[i + 2] = (uint8_t)(((w >> 12) & 63) + off);
-                q[i + 3] = (uint8_t)(((w >> 6) & 63) + off); q[i + 4] = (uint8_t)((w & 63) + off);
-            }
-            for (; i < n; ++i) q[i] = (uint8_t)(qua.getBits(6) + off);
-            break;
-        }
+        default: qua.unpack6(q, n, off); break;
         }
     }
     void readHeader(Rec& r)

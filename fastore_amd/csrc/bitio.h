@@ -43,6 +43,25 @@ public:
     uint32_t get4Bytes() { return getBits(32); }
     uint64_t get8Bytes() { const uint64_t hi = getBits(32); return (hi << 32) | getBits(32); }
     void flushWord() { const uint32_t r = cnt_ & 7u; acc_ <<= r; cnt_ -= r; }
+    // n 6-bit fields -> bytes (+ add): eight fields per 48-bit bite of the window
+    void unpack6(uint8_t* dst, uint32_t n, uint32_t add)
+    {
+        while (n >= 8) {
+            if (cnt_ < 48) {
+                if (pos_ + 8 > size_) break;
+                uint64_t w; memcpy(&w, p_ + pos_, 8); w = __builtin_bswap64(w);
+                const uint32_t take = (64u - cnt_) >> 3;                   // whole bytes that fit behind the valid bits
+                acc_ |= cnt_ ? (w >> cnt_) : w;
+                pos_ += take; cnt_ += 8u * take;
+                if (cnt_ < 64) acc_ &= ~0ull << (64 - cnt_);                // drop the partial byte that came along
+            }
+            const uint64_t x = acc_ >> 16;
+            dst[0] = (uint8_t)(((x >> 42) & 63) + add); dst[1] = (uint8_t)(((x >> 36) & 63) + add); dst[2] = (uint8_t)(((x >> 30) & 63) + add); dst[3] = (uint8_t)(((x >> 24) & 63) + add);
+            dst[4] = (uint8_t)(((x >> 18) & 63) + add); dst[5] = (uint8_t)(((x >> 12) & 63) + add); dst[6] = (uint8_t)(((x >> 6) & 63) + add); dst[7] = (uint8_t)((x & 63) + add);
+            acc_ <<= 48; cnt_ -= 48; dst += 8; n -= 8;
+        }
+        for (; n; --n) *dst++ = (uint8_t)(getBits(6) + add);
+    }
 private:
     void refill(uint32_t need)
     {
