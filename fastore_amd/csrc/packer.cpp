@@ -346,6 +346,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         throw;
     }
     const double feMs = nowMs() - tf;
+    if (onHostTasksDone) onHostTasksDone();
     joinAll();
     for (Slice& S : slices) if (!S.err.empty()) throw std::runtime_error(S.err);
     stats.frontend_ms += feMs;
@@ -450,17 +451,24 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
     archives.clear(); archives.resize(nLibs);
     struct Work { uint32_t lib, sig; };
     std::vector<Work> work;
-    for (size_t l = 0; l < nLibs; ++l) {
-        libs.emplace_back(new Lib());
-        Lib& L = *libs.back();
+    for (size_t l = 0; l < nLibs; ++l) libs.emplace_back(new Lib());
+    parallelFor((uint32_t)nLibs, std::min<uint32_t>((uint32_t)nLibs, hostThreads), [&](uint32_t l, uint32_t) {      // footers are parsed side by side
+        Lib& L = *libs[l];
         L.bf.open(inPrefixes[l], par.minBinSize);
         archives[l].cfg = L.bf.config(); archives[l].head = L.bf.headData(); archives[l].qvz = L.bf.qvz();
         L.aw.start(world > 1 ? outPrefixes[l] + ".part" + std::to_string(rank) : outPrefixes[l], archives[l].cfg);
-        const auto& stdSigs = L.bf.stdSignatures();
+    });
+    for (size_t l = 0; l < nLibs; ++l) {
+        const auto& stdSigs = libs[l]->bf.stdSignatures();
         for (uint32_t i = 0; i < stdSigs.size(); ++i) if (i % world == rank) work.push_back(Work{(uint32_t)l, stdSigs[i]});
     }
     haveArchive = true;
-    // block 0 of every library (rank 0): merged small bins + N bin, compressed on host cores while the GPU works
+    // block 0 of every library (rank 0): merged small bins + N bin, compressed on host cores.  Its threads start when the
+    // host tasks of the last batch are done: until then every core is needed by the front end, afterwards the host only
+    // waits for the device.  When they have unpacked their bins the inputs are not needed any more and are unmapped by a
+    // thread of their own, also inside the device's tail.
+    std::mutex gateMx; std::condition_variable gateCv; bool hostTasksDone = work.empty(); size_t block0Unpacked = 0, block0Threads = 0;
+    std::thread closer;
     if (rank == 0) {
         for (size_t l = 0; l < nLibs; ++l) {
             Lib& L = *libs[l];
@@ -468,15 +476,23 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             L.haveBlock0 = true; L.block0Written = false;
             const ArchiveParams* ap = &archives[l]; Lib* lp = &L;
             // unpack + compress in the background thread (BinFile::unpack only reads the mapped files)
-            L.t0 = std::thread([this, lp, ap]() {
+            ++block0Threads;
+            L.t0 = std::thread([this, lp, ap, &gateMx, &gateCv, &hostTasksDone, &block0Unpacked]() {
+                { std::unique_lock<std::mutex> lk(gateMx); gateCv.wait(lk, [&]() { return hostTasksDone; }); }
                 const double a = nowMs();
                 try {
                     uint64_t rawDna = 0;
                     for (uint32_t sig : lp->bf.smallSignatures()) { lp->bf.unpack(sig, lp->b0, lp->b0.bins.empty()); rawDna += lp->bf.bins().at(sig).totalRawDnaSize; }
                     if (lp->bf.hasNBin()) { lp->bf.unpack(lp->bf.nSignature(), lp->b0, lp->b0.bins.empty()); rawDna += lp->bf.bins().at(lp->bf.nSignature()).totalRawDnaSize; }
                     lp->b0.bins[0].signature = lp->bf.nSignature(); lp->b0.bins[0].rawDnaSize = rawDna;
+                    { std::lock_guard<std::mutex> lk(gateMx); ++block0Unpacked; }
+                    gateCv.notify_all();
                     compressRawBlock(lp->b0, *ap, lp->block0);
-                } catch (const std::exception& e) { lp->t0err = e.what(); }
+                } catch (const std::exception& e) {
+                    lp->t0err = e.what();
+                    { std::lock_guard<std::mutex> lk(gateMx); ++block0Unpacked; }       // never leave the closer waiting
+                    gateCv.notify_all();
+                }
                 lp->t0ms = nowMs() - a;
             });
         }
@@ -519,6 +535,16 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             std::vector<Batch> graph(nb);                              // per bin: its stored graph (node indices local to it)
             for (size_t k = first; k < next; ++k) binArch.push_back(work[k].lib);
             stats.io_ms += nowMs() - tio;
+            const bool lastBatchNow = next >= work.size();
+            onHostTasksDone = [&, lastBatchNow]() {
+                if (!lastBatchNow) return;
+                { std::lock_guard<std::mutex> lk(gateMx); hostTasksDone = true; }
+                gateCv.notify_all();
+                closer = std::thread([&]() {                       // the mapped inputs have been read for the last time
+                    { std::unique_lock<std::mutex> lk(gateMx); gateCv.wait(lk, [&]() { return block0Unpacked >= block0Threads; }); }
+                    parallelFor((uint32_t)nLibs, std::min<uint32_t>((uint32_t)nLibs, 8u), [&](uint32_t l, uint32_t) { libs[l]->bf.close(); });
+                });
+            };
             compressBins(nb, weight, binArch, [&](uint32_t k, BinEncoder& enc, BinStreams& out, BinIn& info, uint64_t& recBytes) {
                 const Work& w = work[first + k];
                 libs[w.lib]->bf.unpackPlaced(w.sig, batch, seqBase[k], headBase[k], (uint32_t)recBase[k], graph[k]);
@@ -577,10 +603,18 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         }
         stats.io_ms += nowMs() - tio;
     } catch (...) {
+        onHostTasksDone = nullptr;
+        { std::lock_guard<std::mutex> lk(gateMx); hostTasksDone = true; }
+        gateCv.notify_all();
         for (auto& L : libs) if (L->t0.joinable()) L->t0.join();
+        if (closer.joinable()) closer.join();
         throw;
     }
-    {   // unmapping ~4 GB of input per library takes a while: one task per library
+    onHostTasksDone = nullptr;
+    { std::lock_guard<std::mutex> lk(gateMx); hostTasksDone = true; }          // no standard bins at all: block 0 starts here
+    gateCv.notify_all();
+    if (closer.joinable()) closer.join();
+    {   // whatever is still mapped (no standard bins on this rank): one task per library
         const double tc = nowMs();
         parallelFor((uint32_t)nLibs, std::min<uint32_t>((uint32_t)nLibs, hostThreads), [&](uint32_t l, uint32_t) { libs[l].reset(); });
         if (getenv("FS_TRACE")) fprintf(stderr, "[trace] close inputs %.1f ms\n", nowMs() - tc);

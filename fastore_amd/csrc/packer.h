@@ -60,6 +60,7 @@ struct Context {
     typedef std::function<void(uint32_t, BinEncoder&, BinStreams&, BinIn&, uint64_t&)> BinProducer;
     void compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, const std::vector<uint32_t>& binArch, const BinProducer& produce);
     std::vector<BinIn> binInfo;                   // per bin of the last compressBins call
+    std::function<void()> onHostTasksDone;        // called by compressBins when its host tasks are done (the device may still run)
     std::vector<std::unique_ptr<BinEncoder>> encoders;   // one per host thread
     // merged small bins + N bin (batch with ONE bin, records already in stored order): RawCompressorSE/PE
     void compressRawBlock(Batch& batch, const ArchiveParams& arch, std::vector<uint8_t>& out) const;
