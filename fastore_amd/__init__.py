@@ -24,7 +24,7 @@ class Config(C.Structure):
                 ("max_new_variants_per_read", C.c_uint32), ("max_hamming_distance", C.c_uint32),
                 ("min_consensus_size", C.c_uint32), ("device_id", C.c_int32), ("host_threads", C.c_uint32),
                 ("max_waves", C.c_uint32), ("batch_bases", C.c_uint64), ("rank", C.c_uint32), ("world_size", C.c_uint32),
-                ("pipeline_slices", C.c_uint32), ("pipeline_lanes", C.c_uint32), ("solo_min_symbols", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("pipeline_slices", C.c_uint32), ("pipeline_lanes", C.c_uint32), ("reserved0", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
 class Stats(C.Structure):

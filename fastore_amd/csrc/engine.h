@@ -9,8 +9,7 @@ namespace fsengine {
 
 struct BatchTiming {
     double encode_ms = 0, assemble_ms = 0;      // HIP-event time of the two kernels (summed over launches)
-    uint64_t launches = 0, items = 0, ppmd_symbols = 0, rc_symbols = 0, restarts = 0, solo_items = 0;
-    double solo_ms = 0;                          // HIP-event time of the fs_encode_streams_solo launches (included in encode_ms)
+    uint64_t launches = 0, items = 0, ppmd_symbols = 0, rc_symbols = 0, restarts = 0;
     uint64_t h2d_bytes = 0, d2h_bytes = 0;
 };
 
@@ -26,8 +25,6 @@ struct Device {
     void* stream;
     void* ev[4];
     void* evWait;                                          // blocking-sync event: a waiting lane thread sleeps instead of spinning
-    void* stream2; void* ev2[3]; uint32_t* queueHead2;     // side stream of the one-wave-per-SIMD kernel for the longest streams
-    uint32_t* dOrder2; size_t capOrder2;
     Pool* pool; uint32_t* queueHead; uint32_t nWaves /* resident-wave cap */;
     uint8_t* dIn; size_t capIn;
     uint8_t* dScratch; size_t capScratch;
@@ -47,9 +44,8 @@ void device_destroy(Device* dev);                                            // 
 uint8_t* staging_buffer(Device* dev, size_t bytes);     // grow-only pinned host buffer for the batch input
 int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,
                        std::vector<uint8_t>& raw, std::vector<uint32_t>& sizes, BatchTiming* timing);
-// soloMin: PPMd streams of at least this many symbols run on the one-wave-per-SIMD kernel (0 = none)
 int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,
                  std::vector<fsdev::BlockPlan>& plans, std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes,
-                 BatchTiming* timing, uint32_t soloMin = 0);
+                 BatchTiming* timing);
 
 }  // namespace fsengine

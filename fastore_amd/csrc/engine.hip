@@ -51,7 +51,6 @@ struct SlotRing { uint32_t head; uint32_t pad0[15]; uint32_t tail; uint32_t pad1
 __device__ __forceinline__ uint32_t xcc_id()
 { uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & (kXcc - 1u); }
 
-template <bool PPMD_ONLY>
 __device__ __forceinline__ void encode_streams_body(const StreamItem* __restrict__ items, const uint32_t* __restrict__ order,
                                                     uint32_t nItems, const uint8_t* in, uint8_t* out, uint32_t* outSizes,
                                                     uint32_t* restarts, uint8_t* arenas, uint64_t arenaStride, uint32_t* queueHead, uint32_t longLen,
@@ -96,8 +95,6 @@ __device__ __forceinline__ void encode_streams_body(const StreamItem* __restrict
         uint32_t size = 0, rs = 0;
         if (kind == KIND_PPMD) {
             if (n > 0) size = fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs);
-        } else if (PPMD_ONLY) {
-            size = 0xFFFFFFFFu;                         // not queued here by the host; reported as an overflow if it ever is
         } else if (kind == KIND_QVZ) {
             size = fsqvz::encode_stream(ar, (fs_cgptr)(in + item.aux_off), src, n, dst, cap);
         } else {
@@ -118,17 +115,7 @@ __device__ __forceinline__ void encode_streams_body(const StreamItem* __restrict
                          SlotRing* rings, unsigned long long* ringEntries, uint32_t slotsPerXcc
 #define FS_ENCODE_ARGS items, order, nItems, in, out, outSizes, restarts, arenas, arenaStride, queueHead, longLen, rings, ringEntries, slotsPerXcc
 
-__global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(FS_ENCODE_PARAMS) { encode_streams_body<false>(FS_ENCODE_ARGS); }
-
-// The same coder for the few longest PPMd streams of a launch, one wave per SIMD: the launch ends with its longest
-// stream, and a wave that shares its SIMD with others takes 1.7 x as long per symbol as one that has it alone.  The
-// kernel claims the whole register file of a SIMD (highest VGPR and AGPR marked as used), so the hardware cannot place
-// another wave beside it.
-__global__ __launch_bounds__(64, 1) void fs_encode_streams_solo(FS_ENCODE_PARAMS)
-{
-    asm volatile("; claim the register file" ::: "v255", "a255");
-    encode_streams_body<true>(FS_ENCODE_ARGS);
-}
+__global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(FS_ENCODE_PARAMS) { encode_streams_body(FS_ENCODE_ARGS); }
 
 __device__ __forceinline__ void put_be(uint8_t* p, uint64_t v, int nbytes)
 { for (int i = 0; i < nbytes; ++i) p[i] = (uint8_t)(v >> (8 * (nbytes - 1 - i))); }
@@ -229,11 +216,8 @@ static int lane_init(Device* dev, char* err, size_t errLen)
     auto fail = [&](const char* what, hipError_t c) { snprintf(err, errLen, "%s: %s", what, hipGetErrorString(c)); return -1; };
     if ((e = hipSetDevice(dev->deviceId)) != hipSuccess) return fail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags((hipStream_t*)&dev->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
-    if ((e = hipStreamCreateWithFlags((hipStream_t*)&dev->stream2, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipMalloc((void**)&dev->queueHead, 64)) != hipSuccess) return fail("hipMalloc(queue)", e);
-    if ((e = hipMalloc((void**)&dev->queueHead2, 64)) != hipSuccess) return fail("hipMalloc(queue)", e);
     for (int i = 0; i < 4; ++i) if ((e = hipEventCreate((hipEvent_t*)&dev->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
-    for (int i = 0; i < 3; ++i) if ((e = hipEventCreate((hipEvent_t*)&dev->ev2[i])) != hipSuccess) return fail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags((hipEvent_t*)&dev->evWait, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     return 0;
 }
@@ -306,12 +290,9 @@ void device_destroy(Device* dev)
     if (!dev) return;
     (void)hipSetDevice(dev->deviceId);
     if (dev->stream) (void)hipStreamSynchronize((hipStream_t)dev->stream);
-    if (dev->stream2) (void)hipStreamSynchronize((hipStream_t)dev->stream2);
-    void* ptrs[] = {dev->queueHead, dev->queueHead2, dev->dOrder2, dev->dIn, dev->dScratch, dev->dItems, dev->dOrder, dev->dSizes, dev->dRestarts, dev->dPlans, dev->dBlocks};
+    void* ptrs[] = {dev->queueHead, dev->dIn, dev->dScratch, dev->dItems, dev->dOrder, dev->dSizes, dev->dRestarts, dev->dPlans, dev->dBlocks};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (int i = 0; i < 3; ++i) if (dev->ev2[i]) (void)hipEventDestroy((hipEvent_t)dev->ev2[i]);
     if (dev->evWait) (void)hipEventDestroy((hipEvent_t)dev->evWait);
-    if (dev->stream2) (void)hipStreamDestroy((hipStream_t)dev->stream2);
     if (dev->hStage) (void)hipHostFree(dev->hStage);
     for (int i = 0; i < 4; ++i) if (dev->ev[i]) (void)hipEventDestroy((hipEvent_t)dev->ev[i]);
     if (dev->stream) (void)hipStreamDestroy((hipStream_t)dev->stream);
@@ -337,7 +318,7 @@ uint8_t* staging_buffer(Device* dev, size_t bytes)
 
 // H2D + fs_encode_streams + D2H of the per-stream sizes.  Leaves the coded streams in dev->dScratch.
 static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items,
-                      std::vector<uint32_t>& sizes, uint64_t& scratchBytes, BatchTiming* timing, uint32_t soloMin)
+                      std::vector<uint32_t>& sizes, uint64_t& scratchBytes, BatchTiming* timing)
 {
     HIP_TRY(hipSetDevice(dev->deviceId));
     hipStream_t st = (hipStream_t)dev->stream;
@@ -387,29 +368,11 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     for (const auto& it : items) if (it.kind == KIND_PPMD) maxLen = std::max(maxLen, it.in_len);
     const uint32_t longLen = std::max(1u, maxLen / 2);                     // "long" = at least half of the longest PPMd stream
 
-    // The longest PPMd streams go to the one-wave-per-SIMD kernel on the side stream: a launch ends with its longest
-    // stream.  Only streams that are long in absolute terms qualify, and at most an eighth of the SIMDs is given away.
-    std::vector<uint32_t> solo;
-    if (getenv("FS_SOLO_MIN")) soloMin = (uint32_t)atoi(getenv("FS_SOLO_MIN"));          // experiments (0 = off)
-    if (!exclusive && soloMin && nItems > 64) {
-        const uint32_t cap = std::max(1u, (uint32_t)dev->cus * 4u / 8u);
-        std::vector<uint32_t> rest; rest.reserve(nItems);
-        for (uint32_t i : order) {
-            const StreamItem& s = items[i];
-            if (solo.size() < cap && s.kind == KIND_PPMD && s.in_len >= soloMin) solo.push_back(i); else rest.push_back(i);
-        }
-        order.swap(rest);
-    }
-    const uint32_t nSolo = (uint32_t)solo.size(), nRest = (uint32_t)order.size();
-    if (nSolo && ensure(dev, dev->dOrder2, dev->capOrder2, 4ull * nSolo)) return -1;
-    hipStream_t st2 = (hipStream_t)dev->stream2;
-
+    const uint32_t nRest = nItems;
     HIP_TRY(hipMemcpyAsync(dev->dIn, input, inputBytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dev->dItems, items.data(), sizeof(StreamItem) * nItems, hipMemcpyHostToDevice, st));
-    if (nRest) HIP_TRY(hipMemcpyAsync(dev->dOrder, order.data(), 4ull * nRest, hipMemcpyHostToDevice, st));
-    if (nSolo) HIP_TRY(hipMemcpyAsync(dev->dOrder2, solo.data(), 4ull * nSolo, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dev->dOrder, order.data(), 4ull * nRest, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(dev->queueHead, 0, 64, st));
-    HIP_TRY(hipMemsetAsync(dev->queueHead2, 0, 64, st));
     const uint32_t grid = exclusive ? (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nItems, dev->nWaves), pool->bytes / stride)
                                     : std::min<uint32_t>(std::max(nRest, 1u), dev->nWaves);
     if (grid == 0) { snprintf(dev->err, sizeof dev->err, "arena pool too small for a %llu-byte coder table", (unsigned long long)need); return -1; }
@@ -417,18 +380,8 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     std::shared_lock<std::shared_mutex> shared(pool->gate, std::defer_lock);
     std::unique_lock<std::shared_mutex> alone(pool->gate, std::defer_lock);
     if (exclusive) alone.lock(); else shared.lock();
-    if (nSolo) {
-        HIP_TRY(hipEventRecord((hipEvent_t)dev->ev2[0], st));               // inputs are on the device
-        HIP_TRY(hipStreamWaitEvent(st2, (hipEvent_t)dev->ev2[0], 0));
-        HIP_TRY(hipEventRecord((hipEvent_t)dev->ev2[1], st2));
-        hipLaunchKernelGGL(fs_encode_streams_solo, dim3(nSolo), dim3(64), 0, st2, (const StreamItem*)dev->dItems, (const uint32_t*)dev->dOrder2,
-                           nSolo, (const uint8_t*)dev->dIn, (uint8_t*)dev->dScratch, (uint32_t*)dev->dSizes, (uint32_t*)dev->dRestarts,
-                           pool->arenas, stride, (uint32_t*)dev->queueHead2, longLen, pool->rings, pool->entries, pool->slotsPerXcc);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord((hipEvent_t)dev->ev2[2], st2));
-    }
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[0], st));
-    if (nRest) {
+    {
         hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, (const StreamItem*)dev->dItems, (const uint32_t*)dev->dOrder,
                            nRest, (const uint8_t*)dev->dIn, (uint8_t*)dev->dScratch, (uint32_t*)dev->dSizes, (uint32_t*)dev->dRestarts,
                            pool->arenas, stride, (uint32_t*)dev->queueHead, longLen,
@@ -436,7 +389,6 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));
-    if (nSolo) HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)dev->ev2[2], 0));      // the size read-back below needs both kernels
     if (getenv("FS_TRACE")) { HIP_TRY(wait_stream(dev, st)); }
     sizes.resize(nItems);
     std::vector<uint32_t> restarts(nItems);
@@ -447,7 +399,6 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         float a = 0;
         (void)hipEventElapsedTime(&a, (hipEvent_t)dev->ev[0], (hipEvent_t)dev->ev[1]);
         timing->encode_ms += a; timing->launches += 1; timing->items += nItems; timing->h2d_bytes += inputBytes;
-        if (nSolo) { float b2 = 0; (void)hipEventElapsedTime(&b2, (hipEvent_t)dev->ev2[1], (hipEvent_t)dev->ev2[2]); timing->solo_ms += b2; timing->solo_items += nSolo; if (b2 > a) timing->encode_ms += b2 - a; }
         for (uint32_t i = 0; i < nItems; ++i) { timing->restarts += restarts[i]; if (items[i].kind == KIND_PPMD) timing->ppmd_symbols += items[i].in_len; else timing->rc_symbols += items[i].in_len; }
     }
     return 0;
@@ -460,7 +411,7 @@ int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std
     raw.clear(); sizes.clear();
     if (items.empty()) return 0;
     uint64_t scratch = 0;
-    if (run_encode(dev, input, inputBytes, items, sizes, scratch, timing, 0)) return -1;
+    if (run_encode(dev, input, inputBytes, items, sizes, scratch, timing)) return -1;
     raw.resize(scratch);
     HIP_TRY(hipMemcpy(raw.data(), dev->dScratch, scratch, hipMemcpyDeviceToHost));
     if (timing) timing->d2h_bytes += scratch;
@@ -471,13 +422,13 @@ int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std
 // bytes / (symbol, ctx) pairs.
 int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items,
                  std::vector<BlockPlan>& plans, std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes,
-                 BatchTiming* timing, uint32_t soloMin)
+                 BatchTiming* timing)
 {
     const uint32_t nItems = (uint32_t)items.size(), nBins = (uint32_t)plans.size();
     blockSizes.assign(nBins, 0);                 // `blocks` keeps its size between calls: resize() below does not re-zero what is overwritten anyway
     if (nItems == 0) { blocks.clear(); return 0; }
     std::vector<uint32_t> sizes; uint64_t scratch = 0;
-    if (run_encode(dev, input, inputBytes, items, sizes, scratch, timing, soloMin)) return -1;
+    if (run_encode(dev, input, inputBytes, items, sizes, scratch, timing)) return -1;
     hipStream_t st = (hipStream_t)dev->stream;
     if (ensure(dev, dev->dPlans, dev->capPlans, sizeof(BlockPlan) * nBins)) return -1;
     // a stream that filled its scratch slot was clipped: refuse rather than emit a corrupt block

@@ -197,18 +197,14 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     if (streamPool.size() < nBins) streamPool.resize(nBins);
     std::vector<BinStreams>& st = streamPool;
     std::vector<BinIn> info(nBins); std::vector<uint64_t> recBytes(nBins, 0);
-    std::atomic<uint32_t> longestStream(0);
     // largest bins first: their streams are the longest (a launch ends with its longest stream) and the front end of
     // a bin is sequential, so a big bin started last would be the tail on the host too
     std::vector<uint32_t> byWork(nBins);
     for (uint32_t b = 0; b < nBins; ++b) byWork[b] = b;
     std::sort(byWork.begin(), byWork.end(), [&](uint32_t x, uint32_t y) { return weight[x] > weight[y]; });
-    uint64_t totalW = 0, maxW = 0;
-    for (uint64_t w : weight) { totalW += w; maxW = std::max(maxW, w); }
-    // The device step ends with its longest streams.  A bin's longest stream (the qualities) has about weight x read
-    // length symbols; streams within a factor two of the longest of the whole batch -- and long in absolute terms --
-    // are coded one wave per SIMD (see engine.hip).  The estimate only steers scheduling, never the bytes.
-    // slice boundaries by cumulated weight: a small first slice starts the device early, the rest keeps it fed
+    uint64_t totalW = 0;
+    for (uint64_t w : weight) totalW += w;
+    // slice boundaries by cumulated weight
     std::vector<uint32_t> cut{0};
     // default: eight slices of equal weight, one per hardware queue (measured 5 / 6-with-a-small-head / 8: 8 is best)
     const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? 8u : 1u);
@@ -250,9 +246,6 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         }
         if (abort.load()) return;
         S.tReady = nowMs();
-        // one-wave-per-SIMD kernel for the longest streams: off unless asked for (measured on the 10 M-read workload: the
-        // longest stream ends 0.2 s earlier, but the SIMDs taken from the other 92 k streams cost 0.6 s)
-        const uint32_t soloMin = cfg.solo_min_symbols <= 1 ? 0u : std::max<uint32_t>(cfg.solo_min_symbols, longestStream.load() / 2u);
         try {
             const uint32_t first = cut[si], count = cut[si + 1] - cut[si];
             S.plans.resize(count);
@@ -310,7 +303,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 }
             });
             S.tSubmit = nowMs();
-            if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, sliceBlocks[si], S.sizes, &S.timing, soloMin) != 0) S.err = std::string("device: ") + L->err;
+            if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, sliceBlocks[si], S.sizes, &S.timing) != 0) S.err = std::string("device: ") + L->err;
         } catch (const std::exception& e) { S.err = e.what(); }
         S.tDone = nowMs();
         { std::lock_guard<std::mutex> lk(S.mx); S.done = true; }
@@ -330,10 +323,6 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             const double ta = trace ? nowMs() : 0.0;
             produce(b, *encs[tid], st[b], info[b], recBytes[b]);
             if (trace) busyMs[tid] += nowMs() - ta;
-            if (k == 0) {   // byWork[0] is the heaviest bin: its longest stream sets the bar for the one-wave-per-SIMD kernel
-                uint32_t mx = 0; for (const auto& v : st[b].s) mx = std::max<uint32_t>(mx, (uint32_t)v.size());
-                longestStream.store(mx);
-            }
             Slice& S = slices[sliceOf[k]];
             bool last;
             { std::lock_guard<std::mutex> lk(S.mx); last = --S.pending == 0; }

@@ -54,8 +54,7 @@ typedef struct fsgpu_config {
     uint32_t rank, world_size;          /* bin sharding: this context packs bins i with i % world_size == rank */
     uint32_t pipeline_slices;           /* slices a batch is cut into so that host front end and device overlap (0 = default 8, 1 = off) */
     uint32_t pipeline_lanes;            /* engine instances (HIP streams) whose kernels may overlap on the GPU (0 = one per slice) */
-    uint32_t solo_min_symbols;          /* > 1: PPMd streams at least this long (and within 2x of the batch's longest) get a SIMD to themselves (default 0 = never) */
-    uint32_t reserved0;
+    uint32_t reserved0, reserved1;
 } fsgpu_config;
 
 /* Unpacked reads of a batch of bins, structure-of-arrays (what the reference hands to Compress() as

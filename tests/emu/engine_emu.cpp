@@ -53,7 +53,7 @@ int encode_streams_raw(Device*, const uint8_t* input, size_t, std::vector<Stream
 static void putBe(uint8_t*& h, uint64_t v, int n) { for (int i = 0; i < n; ++i) *h++ = (uint8_t)(v >> (8 * (n - 1 - i))); }
 
 int encode_batch(Device* dev, const uint8_t* input, size_t, std::vector<StreamItem>& items, std::vector<BlockPlan>& plans,
-                 std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes, BatchTiming* t, uint32_t)
+                 std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes, BatchTiming* t)
 {
     std::vector<uint8_t> scratch; std::vector<uint32_t> sizes;
     runItems(input, items, scratch, sizes, t);
