@@ -51,20 +51,35 @@ struct SlotRing { uint32_t head; uint32_t pad0[15]; uint32_t tail; uint32_t pad1
 __device__ __forceinline__ uint32_t xcc_id()
 { uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & (kXcc - 1u); }
 
-__device__ __forceinline__ void encode_streams_body(const StreamItem* __restrict__ items, const uint32_t* __restrict__ order,
-                                                    uint32_t nItems, const uint8_t* in, uint8_t* out, uint32_t* outSizes,
-                                                    uint32_t* restarts, uint8_t* arenas, uint64_t arenaStride, uint32_t* queueHead, uint32_t longLen,
-                                                    SlotRing* rings, unsigned long long* ringEntries, uint32_t slotsPerXcc)
+// The launch parameters stay in the kernarg segment and are re-read (scalar loads, a few per stream) where they are
+// needed: held in SGPRs for the whole kernel they were ~20 registers of pressure on the coder loops, which already
+// spill scalars to vector lanes.  `kernargs()` hides the pointer from the optimiser so that the loads are not hoisted.
+struct EncodeArgs {
+    const StreamItem* items; const uint32_t* order; const uint8_t* in; uint8_t* out; uint32_t* outSizes; uint32_t* restarts;
+    uint8_t* arenas; uint64_t arenaStride; uint32_t* queueHead; SlotRing* rings; unsigned long long* ringEntries;
+    uint32_t nItems, longLen, slotsPerXcc, pad;
+};
+typedef const __attribute__((address_space(4))) EncodeArgs* KernArgs;
+__device__ __forceinline__ KernArgs kernargs()
+{
+    KernArgs k = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
+}
+
+__global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(EncodeArgs /* read through kernargs() */)
 {
     __shared__ fsppmd::Shared sh;
     // rings == nullptr: exclusive launch (no other kernel in flight), one arena per workgroup index
     uint32_t slot = blockIdx.x, xcc = 0;
-    if (rings) {
+    const bool useRings = kernargs()->rings != nullptr;
+    if (useRings) {
+        KernArgs k = kernargs();
         xcc = xcc_id();
         uint32_t s = 0;
         if (threadIdx.x == 0) {
-            const uint32_t t = atomicAdd(&rings[xcc].head, 1u);
-            unsigned long long* e = ringEntries + (uint64_t)xcc * slotsPerXcc + t % slotsPerXcc;
+            const uint32_t t = atomicAdd(&k->rings[xcc].head, 1u);
+            unsigned long long* e = k->ringEntries + (uint64_t)xcc * k->slotsPerXcc + t % k->slotsPerXcc;
             for (;;) {
                 const unsigned long long v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((uint32_t)(v >> 32) == t) { s = (uint32_t)v; break; }
@@ -73,49 +88,46 @@ __device__ __forceinline__ void encode_streams_body(const StreamItem* __restrict
         }
         slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
     }
-    uint8_t* arena = arenas + (uint64_t)slot * arenaStride;
+    uint8_t* arena;
+    { KernArgs k = kernargs(); arena = k->arenas + (uint64_t)slot * k->arenaStride; }
     for (;;) {
+        KernArgs k = kernargs();
         uint32_t q = 0;
-        if (threadIdx.x == 0) q = atomicAdd(queueHead, 1u);
+        if (threadIdx.x == 0) q = atomicAdd(k->queueHead, 1u);
         q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
-        if (q >= nItems) break;                       // every wave reaches this exit: the queue is finite
-        const uint32_t it = order[q];
-        const StreamItem item = items[it];
+        if (q >= k->nItems) break;                    // every wave reaches this exit: the queue is finite
+        const uint32_t it = k->order[q];
+        const StreamItem item = k->items[it];
         const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.kind);
         const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.in_len);
         const uint32_t cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.out_cap);
         // The launch ends when its longest stream ends, so the long PPMd streams get issue priority over the thousands
         // of short ones that share their SIMD (priority only reorders issue among resident waves).
+        const uint32_t longLen = k->longLen;
         if (kind == KIND_PPMD && n >= longLen) __builtin_amdgcn_s_setprio(3);
         else if (kind == KIND_PPMD && 2u * n >= longLen) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(0);
-        fs_cgptr src = (fs_cgptr)(in + item.in_off);
-        fs_gptr dst = (fs_gptr)(out + item.out_off);
+        fs_cgptr src = (fs_cgptr)(k->in + item.in_off);
+        fs_gptr dst = (fs_gptr)(k->out + item.out_off);
         fs_gptr ar = (fs_gptr)arena;
         uint32_t size = 0, rs = 0;
         if (kind == KIND_PPMD) {
             if (n > 0) size = fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs);
         } else if (kind == KIND_QVZ) {
-            size = fsqvz::encode_stream(ar, (fs_cgptr)(in + item.aux_off), src, n, dst, cap);
+            size = fsqvz::encode_stream(ar, (fs_cgptr)(k->in + item.aux_off), src, n, dst, cap);
         } else {
             size = fsrc::encode_model(kind - KIND_RC_BASE, ar, src, n, dst, cap);
         }
-        if (threadIdx.x == 0) { outSizes[it] = size; restarts[it] = rs; }
+        if (threadIdx.x == 0) { KernArgs k2 = kernargs(); k2->outSizes[it] = size; k2->restarts[it] = rs; }
         __syncthreads();
     }
-    if (rings && threadIdx.x == 0) {
-        const uint32_t t = atomicAdd(&rings[xcc].tail, 1u);
-        unsigned long long* e = ringEntries + (uint64_t)xcc * slotsPerXcc + t % slotsPerXcc;
-        __hip_atomic_store(e, ((unsigned long long)(t + slotsPerXcc) << 32) | slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (useRings && threadIdx.x == 0) {
+        KernArgs k = kernargs();
+        const uint32_t t = atomicAdd(&k->rings[xcc].tail, 1u);
+        unsigned long long* e = k->ringEntries + (uint64_t)xcc * k->slotsPerXcc + t % k->slotsPerXcc;
+        __hip_atomic_store(e, ((unsigned long long)(t + k->slotsPerXcc) << 32) | slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-
-#define FS_ENCODE_PARAMS const StreamItem* __restrict__ items, const uint32_t* __restrict__ order, uint32_t nItems, const uint8_t* in, uint8_t* out, \
-                         uint32_t* outSizes, uint32_t* restarts, uint8_t* arenas, uint64_t arenaStride, uint32_t* queueHead, uint32_t longLen, \
-                         SlotRing* rings, unsigned long long* ringEntries, uint32_t slotsPerXcc
-#define FS_ENCODE_ARGS items, order, nItems, in, out, outSizes, restarts, arenas, arenaStride, queueHead, longLen, rings, ringEntries, slotsPerXcc
-
-__global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(FS_ENCODE_PARAMS) { encode_streams_body(FS_ENCODE_ARGS); }
 
 __device__ __forceinline__ void put_be(uint8_t* p, uint64_t v, int nbytes)
 { for (int i = 0; i < nbytes; ++i) p[i] = (uint8_t)(v >> (8 * (nbytes - 1 - i))); }
@@ -382,10 +394,13 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     if (exclusive) alone.lock(); else shared.lock();
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[0], st));
     {
-        hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, (const StreamItem*)dev->dItems, (const uint32_t*)dev->dOrder,
-                           nRest, (const uint8_t*)dev->dIn, (uint8_t*)dev->dScratch, (uint32_t*)dev->dSizes, (uint32_t*)dev->dRestarts,
-                           pool->arenas, stride, (uint32_t*)dev->queueHead, longLen,
-                           exclusive ? (SlotRing*)nullptr : pool->rings, exclusive ? (unsigned long long*)nullptr : pool->entries, pool->slotsPerXcc);
+        EncodeArgs ka;
+        ka.items = (const StreamItem*)dev->dItems; ka.order = (const uint32_t*)dev->dOrder; ka.in = (const uint8_t*)dev->dIn; ka.out = (uint8_t*)dev->dScratch;
+        ka.outSizes = (uint32_t*)dev->dSizes; ka.restarts = (uint32_t*)dev->dRestarts; ka.arenas = pool->arenas; ka.arenaStride = stride;
+        ka.queueHead = (uint32_t*)dev->queueHead; ka.rings = exclusive ? (SlotRing*)nullptr : pool->rings;
+        ka.ringEntries = exclusive ? (unsigned long long*)nullptr : pool->entries;
+        ka.nItems = nRest; ka.longLen = longLen; ka.slotsPerXcc = pool->slotsPerXcc; ka.pad = 0;
+        hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, ka);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));

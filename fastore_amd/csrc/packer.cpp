@@ -206,7 +206,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     for (uint64_t w : weight) totalW += w;
     // slice boundaries by cumulated weight
     std::vector<uint32_t> cut{0};
-    // default: eight slices of equal weight, one per hardware queue (measured 5 / 6-with-a-small-head / 8: 8 is best)
+    // default: eight slices of equal weight, one per hardware queue (measured 5, 6, 8 and 8 with a small head slice of the heaviest bins: plain 8 is best)
     const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? 8u : 1u);
     if (wantSlices > 1) {
         uint64_t acc = 0; uint32_t k = 0;
