@@ -69,7 +69,11 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
     // mask and the cgroup CPU quota), at most 24.  The measurement box shows 256 CPUs but its container is capped at 16
     // cores: measured 12 / 14 / 16 / 20 / 24 / 32 / 48 threads -> 24 is best (the workers compete with the lane, block-0
     // and runtime threads for the same 16 cores), more only time-slice.
-    c.hostThreads = cfg->host_threads ? cfg->host_threads : std::max(1u, std::min(24u, usableCores() * 3u / 2u));
+    // Ranks of one node (one process per GPU under torch.distributed.run, which exports LOCAL_WORLD_SIZE) share the cores.
+    unsigned localRanks = 1;
+    if (const char* lw = getenv("LOCAL_WORLD_SIZE")) localRanks = (unsigned)std::max(1, atoi(lw));
+    const unsigned share = usableCores() * 3u / 2u / localRanks;
+    c.hostThreads = cfg->host_threads ? cfg->host_threads : std::max(localRanks > 1 ? 4u : 1u, std::min(24u, share));
     if (getenv("FS_HOST_THREADS")) c.hostThreads = std::max(1, atoi(getenv("FS_HOST_THREADS")));     // experiments
     if (getenv("FS_PIPELINE_SLICES") && atoi(getenv("FS_PIPELINE_SLICES")) > 0) c.cfg.pipeline_slices = (uint32_t)atoi(getenv("FS_PIPELINE_SLICES"));
     if (getenv("FS_MAX_WAVES") && atoi(getenv("FS_MAX_WAVES")) > 0) c.cfg.max_waves = (uint32_t)atoi(getenv("FS_MAX_WAVES"));

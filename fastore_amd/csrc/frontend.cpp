@@ -542,6 +542,10 @@ struct BinEncoder::Impl {
         if (!node.trees.empty()) return false;                  // AvoidTreesInConsensus
         const uint32_t L = bi.cons.readLen;
         const int32_t v = node.vrec;
+        // The consensus frame is laid out for reads of the first member's length; the reference indexes it the same way
+        // for every member (ContigBuilder::AddRecord) and reads outside its buffers when lengths differ ("TODO: verify
+        // for variable-length reads", FastqCompressor.cpp:1766).  That has no defined result to reproduce: refuse.
+        if (seqLen(v) != L) throw std::runtime_error("reads of different lengths in one read cluster: variable-length libraries are not supported (neither by the reference encoder)");
         const uint8_t* s = seq(v); const uint32_t m = minimPos(v);
         const uint32_t consBegin = L - m, consEnd = consBegin + L;
         if (!bi.nodes.empty()) {
@@ -834,6 +838,7 @@ struct BinEncoder::Impl {
         putSym(S_Rev, isReverse(v));
         const uint32_t consStart = readLen - m;
         const uint8_t* s = seq(v); const Contig& def = *ce.def;
+        if (readLen != def.readLen) throw std::runtime_error("reads of different lengths in one read cluster: variable-length libraries are not supported (neither by the reference encoder)");
         uint32_t it = 0;
         while (it < par.beginCut) {
             if (it == (uint32_t)m) { it += sigLen; continue; }

@@ -39,5 +39,14 @@ make_one se_reduced    5000  100 10000  13   0  2  "-H -C"
 make_one se_noheader   4000  80  6400   14   0  0  ""
 make_one se_binary     4000  100 8000   15   0  1  ""
 make_one se_qvz        3000  60  3600   16   0  3  "-H"       # --lossy: QVZ codebook + WELL seed in the footer
+# Reads of different lengths: the reference pack (and rebin) index their consensus buffers by the first read's length and
+# crash on such a library, so there is no expected archive -- the fixture is the bin-stage output only (bin -t1: -t2 races)
+# and the test expects a clean error from the product.
+if [ -z "$ONLY" ] || [ "$ONLY" = se_varlen ]; then
+    $GEN --reads 2500 --len 100 --genome 5000 --seed 17 --out $T/vl
+    awk 'NR%4==1{n=60+(int((NR-1)/4)*37)%41} NR%4==2||NR%4==0{print substr($0,1,n);next}{print}' $T/vl_1.fastq > $T/varlen_1.fastq
+    $G bin -i$T/varlen_1.fastq -o$T/varlen.b0 -t1 -q0 -p8 -s0 -b256
+    for e in bmeta bdna bqua; do cp $T/varlen.b0.$e se_varlen.in.$e; done
+fi
 rm -rf "$T"
 ls -la

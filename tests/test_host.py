@@ -148,3 +148,14 @@ def test_truncated_meta_is_an_error(emu_lib, tmp_path):
     with fastore_amd.Packer(lib=emu_lib) as p:
         with pytest.raises(fastore_amd.FastoreError):
             p.pack_file(str(tmp_path / "x"), str(tmp_path / "o"))
+
+
+def test_variable_length_library_is_refused_not_read_out_of_bounds(emu_lib, tmp_path):
+    # Reads of different lengths in one cluster: the reference indexes its consensus buffers by the first read's length
+    # (ContigBuilder::AddRecord; "TODO: verify for variable-length reads", FastqCompressor.cpp:1766), reads outside them
+    # and its archive does not decode back to the input -- there is no defined result to reproduce.  The fixture is the
+    # reference's bin-stage output for such a library (tests/golden/make_golden.sh); the product must fail cleanly.
+    import fastore_amd
+    with fastore_amd.Packer(lib=emu_lib, host_threads=2, min_bin_size=24, max_lz_window=256, max_pair_lz_window=256) as p:
+        with pytest.raises(fastore_amd.FastoreError, match="different lengths"):
+            p.pack_file(os.path.join(GOLDEN, "se_varlen.in"), str(tmp_path / "o"))
