@@ -77,7 +77,7 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
     if (getenv("FS_HOST_THREADS")) c.hostThreads = std::max(1, atoi(getenv("FS_HOST_THREADS")));     // experiments
     if (getenv("FS_PIPELINE_SLICES") && atoi(getenv("FS_PIPELINE_SLICES")) > 0) c.cfg.pipeline_slices = (uint32_t)atoi(getenv("FS_PIPELINE_SLICES"));
     if (getenv("FS_MAX_WAVES") && atoi(getenv("FS_MAX_WAVES")) > 0) c.cfg.max_waves = (uint32_t)atoi(getenv("FS_MAX_WAVES"));
-    if (c.par.mismatchCost <= 0 || c.par.maxLzWindowSize == 0 || c.par.maxPairLzWindowSize == 0) { g_createError = "invalid matcher parameters"; delete ctx; return nullptr; }
+    if (c.par.mismatchCost <= 0 || c.par.shiftCost < 0 || c.par.maxLzWindowSize == 0 || c.par.maxPairLzWindowSize == 0) { g_createError = "invalid matcher parameters"; delete ctx; return nullptr; }
     if (fsengine::device_count() <= 0) {
         g_createError = "no HIP device available: the fastore_pack hot path has no CPU fallback";
         delete ctx; return nullptr;

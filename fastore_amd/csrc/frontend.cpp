@@ -355,7 +355,7 @@ struct BinEncoder::Impl {
                     const uint32_t run = std::min(n - i, cap - pos);                 // contiguous stretch of the ring
                     uint32_t k = 0;
                     for (; k + 8 <= run && !stop; k += 8) {
-                        int32_t bound = mr.cost / par.shiftCost; if (bound > 127) bound = 127;
+                        int32_t bound = par.shiftCost > 0 ? mr.cost / par.shiftCost : 127; if (bound > 127) bound = 127;      // -s0: shifts are free
                         const __m128i d = _mm_sub_epi16(_mm_loadu_si128((const __m128i*)(win.mp.data() + pos + k)), vrm);
                         const __m128i ad = _mm_max_epi16(d, _mm_sub_epi16(_mm_setzero_si128(), d));
                         uint32_t pass = (uint32_t)_mm_movemask_epi8(_mm_cmpgt_epi16(_mm_set1_epi16((int16_t)(bound + 1)), ad));   // two bits per entry

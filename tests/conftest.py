@@ -85,3 +85,13 @@ def knobs_from_flags(flags):
         elif f == "-l": kw["extra_reduce_expensive_lz"] = 1
         elif f[1] in m: kw[m[f[1]]] = int(f[2:])
     return kw
+
+
+def flag_variants():
+    """(name, paired, sha256 of the reference .cdata, flags): tests/golden/flag_variants.txt (made by make_golden.sh)"""
+    out = []
+    for line in open(os.path.join(GOLDEN, "flag_variants.txt")):
+        f = line.split()
+        if f:
+            out.append((f[0], f[1] == "1", f[2], f[3:]))
+    return out

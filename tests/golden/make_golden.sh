@@ -39,6 +39,36 @@ make_one se_reduced    5000  100 10000  13   0  2  "-H -C"
 make_one se_noheader   4000  80  6400   14   0  0  ""
 make_one se_binary     4000  100 8000   15   0  1  ""
 make_one se_qvz        3000  60  3600   16   0  3  "-H"       # --lossy: QVZ codebook + WELL seed in the footer
+# Non-default matcher / consensus flags on the fixtures above: only the SHA-256 of the reference's .cdata is kept.
+# (The reference itself crashes on these inputs with -e below the automatic threshold, -s2 and, SE, -m9: not listed.)
+if [ -z "$ONLY" ] || [ "$ONLY" = flag_variants ]; then
+    : > flag_variants.txt
+    variant() {   # name paired flags...
+        local name=$1 paired=$2; shift 2
+        local pe=""; [ "$paired" = 1 ] && pe="-z"
+        $R pack -i$name.in -o$T/fv -t1 "$@" $pe
+        echo "$name $paired $(sha256sum < $T/fv.cdata | cut -d' ' -f1) $*" >> flag_variants.txt
+    }
+    variant se_lossless 0 -r -l -f24 -c3 -d20 -w1024 -W1024 -q3 -n1
+    variant se_lossless 0 -f24 -c10 -d8 -w8 -W4
+    variant se_lossless 0 -r -f24 -c2 -d1 -w1024 -W1024 -e80 -E80
+    variant pe_lossless 1 -r -l -f24 -c3 -d20 -w1024 -W1024 -q3 -n1 -m9
+    variant pe_lossless 1 -f24 -c10 -d8 -w8 -W4
+    variant pe_lossless 1 -r -f40 -c2 -d1 -w1024 -W1024 -e80 -E80
+    variant se_reduced 0 -r -l -f24 -c2 -d1 -w16 -W16 -q1 -n0 -m9
+    variant se_qvz 0 -l -f30 -c4 -d3 -w1024 -W1024
+fi
+# C0 profile of scripts/fastore_compress.sh: fastore_bin output packed directly (the bin-stage writer flavour of the
+# record grammar, no read groups; no -r; 256-entry windows)
+if [ -z "$ONLY" ] || [ "$ONLY" = se_c0 ]; then
+    C0FLAGS="-f24 -c10 -d8 -w256 -W256"
+    $GEN --reads 3000 --len 100 --genome 6000 --seed 23 --out $T/c0
+    $G bin -i$T/c0_1.fastq -o$T/c0.b0 -t1 -H -q0 -p8 -s0 -b256
+    $R pack -i$T/c0.b0 -o$T/c0.ref -t1 $C0FLAGS
+    grep -q "^se_c0 " manifest.txt 2>/dev/null || echo "se_c0 0 $C0FLAGS" >> manifest.txt
+    for e in bmeta bdna bqua bhead; do cp $T/c0.b0.$e se_c0.in.$e; done
+    cp $T/c0.ref.cdata se_c0.ref.cdata; cp $T/c0.ref.cmeta se_c0.ref.cmeta
+fi
 # Reads of different lengths: the reference pack (and rebin) index their consensus buffers by the first read's length and
 # crash on such a library, so there is no expected archive -- the fixture is the bin-stage output only (bin -t1: -t2 races)
 # and the test expects a clean error from the product.

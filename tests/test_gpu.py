@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, MODELS, REF_DRIVER, REF_DRIVER_GCC, ROOT, VECTORS, knobs_from_flags, manifest, oracle_ppmd, oracle_qvz, oracle_rc
+from conftest import GOLDEN, MODELS, REF_DRIVER, REF_DRIVER_GCC, ROOT, VECTORS, flag_variants, knobs_from_flags, manifest, oracle_ppmd, oracle_qvz, oracle_rc
 
 import sys
 sys.path.insert(0, GOLDEN)
@@ -194,3 +194,11 @@ def test_gpu_pack_is_deterministic_and_sizes_add_up(tmp_path):
         outs.append(open(str(tmp_path / ("o%d.cdata" % i)), "rb").read())
     assert all(o == outs[0] for o in outs[1:])
     assert outs[0] == open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
+
+
+@pytest.mark.parametrize("name,paired,sha,flags", flag_variants())
+def test_gpu_pack_under_non_default_flags(tmp_path, name, paired, sha, flags):
+    import fastore_amd, hashlib
+    with fastore_amd.Packer(device_id=0, **knobs_from_flags(flags)) as p:
+        p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / "o"))
+    assert hashlib.sha256(open(str(tmp_path / "o.cdata"), "rb").read()).hexdigest() == sha

@@ -11,7 +11,7 @@ import subprocess
 
 import pytest
 
-from conftest import GOLDEN, ROOT, knobs_from_flags, manifest
+from conftest import GOLDEN, ROOT, flag_variants, knobs_from_flags, manifest
 
 CSRC = os.path.join(ROOT, "fastore_amd", "csrc")
 
@@ -159,3 +159,12 @@ def test_variable_length_library_is_refused_not_read_out_of_bounds(emu_lib, tmp_
     with fastore_amd.Packer(lib=emu_lib, host_threads=2, min_bin_size=24, max_lz_window=256, max_pair_lz_window=256) as p:
         with pytest.raises(fastore_amd.FastoreError, match="different lengths"):
             p.pack_file(os.path.join(GOLDEN, "se_varlen.in"), str(tmp_path / "o"))
+
+
+@pytest.mark.parametrize("name,paired,sha,flags", flag_variants())
+def test_host_pipeline_under_non_default_flags(emu_lib, tmp_path, name, paired, sha, flags):
+    # matcher / consensus knobs away from the C1 profile (-l, -e/-E, -m, -q, -n, tiny windows): same bytes as the reference
+    import fastore_amd, hashlib
+    with fastore_amd.Packer(lib=emu_lib, host_threads=3, **knobs_from_flags(flags)) as p:
+        p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / "o"))
+    assert hashlib.sha256(open(str(tmp_path / "o.cdata"), "rb").read()).hexdigest() == sha
