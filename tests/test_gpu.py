@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, MODELS, REF_DRIVER, REF_DRIVER_GCC, ROOT, VECTORS, flag_variants, knobs_from_flags, manifest, oracle_ppmd, oracle_qvz, oracle_rc
+from conftest import GOLDEN, MODELS, REF_DRIVER, REF_DRIVER_GCC, ROOT, VECTORS, flag_variants, knobs_from_flags, manifest, ref_pipeline, oracle_ppmd, oracle_qvz, oracle_rc
 
 import sys
 sys.path.insert(0, GOLDEN)
@@ -143,29 +143,12 @@ def test_cli_is_a_drop_in_for_fastore_pack_e(tmp_path):
     assert_same_archive(str(tmp_path / "o"), os.path.join(GOLDEN, name + ".ref"))
 
 
-def _ref_pipeline(tmp, name, reads, length, genome, seed, paired, q):
-    gen = os.path.join(ROOT, "build", "gen_fastq")
-    if not os.path.exists(gen):
-        subprocess.check_call(["g++", "-O2", "-o", gen, os.path.join(ROOT, "tools", "gen_fastq.cpp")])
-    base = os.path.join(tmp, name)
-    subprocess.check_call([gen, "--reads", str(reads), "--len", str(length), "--genome", str(genome), "--seed", str(seed), "--out", base] + (["--paired"] if paired else []))
-    pe = ["-z"] if paired else []
-    inp = base + "_1.fastq" + ((" " + base + "_2.fastq") if paired else "")
-    subprocess.check_call([REF_DRIVER_GCC, "bin", "-i" + inp, "-o" + base + ".b0", "-t8", "-H", "-q%d" % q, "-p8", "-s0", "-b256"] + pe)
-    prev = base + ".b0"
-    for p in (2, 4, 8):
-        cur = base + ".b%d" % p
-        subprocess.check_call([REF_DRIVER_GCC, "rebin", "-i" + prev, "-o" + cur, "-t8", "-r", "-w1024", "-W1024", "-p%d" % p] + pe)
-        prev = cur
-    return prev, pe
-
-
 @pytest.mark.skipif(not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)), reason="reference binaries (oracle/_ref) not shipped")
 @pytest.mark.parametrize("paired,q,reads", [(False, 0, 120000), (True, 0, 60000), (False, 2, 60000), (False, 3, 40000), (True, 3, 60000)])
 def test_gpu_pack_equals_live_reference_on_fresh_library(tmp_path, paired, q, reads):
     import fastore_amd
     t = str(tmp_path)
-    binned, pe = _ref_pipeline(t, "lib", reads, 150, reads * 150 // 50, 77 + q + int(paired), paired, q)
+    binned, pe = ref_pipeline(t, "lib", reads, 150, reads * 150 // 50, 77 + q + int(paired), paired, q)
     flags = ["-r", "-f256", "-c10", "-d8", "-w1024", "-W1024"]
     subprocess.check_call([REF_DRIVER, "pack", "-i" + binned, "-o" + os.path.join(t, "ref"), "-t1"] + flags + pe)
     with fastore_amd.Packer(device_id=0) as p:

@@ -11,7 +11,7 @@ import subprocess
 
 import pytest
 
-from conftest import GOLDEN, ROOT, flag_variants, knobs_from_flags, manifest
+from conftest import GOLDEN, REF_DRIVER, REF_DRIVER_GCC, ROOT, flag_variants, knobs_from_flags, manifest, ref_pipeline
 
 CSRC = os.path.join(ROOT, "fastore_amd", "csrc")
 
@@ -168,3 +168,19 @@ def test_host_pipeline_under_non_default_flags(emu_lib, tmp_path, name, paired, 
     with fastore_amd.Packer(lib=emu_lib, host_threads=3, **knobs_from_flags(flags)) as p:
         p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / "o"))
     assert hashlib.sha256(open(str(tmp_path / "o.cdata"), "rb").read()).hexdigest() == sha
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)), reason="reference binaries (oracle/_ref) not built")
+@pytest.mark.parametrize("length,paired,q", [(36, False, 0), (36, True, 2), (250, False, 0), (250, True, 0), (200, False, 3)])
+def test_host_pipeline_equals_live_reference_across_read_lengths(emu_lib, tmp_path, length, paired, q):
+    # short and long reads (>= 128 bp switches the contig shift coding to absolute positions, FastqCompressor.cpp
+    # CompressContigRead), binned and packed by the real reference here, then packed by the host pipeline
+    import fastore_amd
+    t = str(tmp_path)
+    binned, pe = ref_pipeline(t, "lib", 3000, length, length * 60, 300 + length, paired, q, threads=1)
+    flags = ["-r", "-f24", "-c10", "-d8", "-w1024", "-W1024"]
+    subprocess.check_call([REF_DRIVER, "pack", "-i" + binned, "-o" + os.path.join(t, "ref"), "-t1"] + flags + pe)
+    with fastore_amd.Packer(lib=emu_lib, host_threads=3, **knobs_from_flags(flags)) as p:
+        st = p.pack_file(binned, os.path.join(t, "emu"))
+    assert open(os.path.join(t, "emu.cdata"), "rb").read() == open(os.path.join(t, "ref.cdata"), "rb").read()
+    assert st["bins"] > 5
