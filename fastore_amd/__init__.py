@@ -40,6 +40,18 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class BinBatch(C.Structure):
+    """fsgpu_bin_batch: unpacked reads and stored match graph of a batch of standard bins (include/fastore_amd.h)"""
+    _fields_ = [("bases", C.c_void_p), ("quals", C.c_void_p), ("heads", C.c_void_p), ("n_bases", C.c_size_t), ("n_heads", C.c_size_t),
+                ("records", C.c_void_p), ("n_records", C.c_size_t), ("nodes", C.c_void_p), ("n_nodes", C.c_size_t),
+                ("top_nodes", C.c_void_p), ("n_top_nodes", C.c_size_t), ("em_records", C.c_void_p), ("n_em_records", C.c_size_t),
+                ("trees", C.c_void_p), ("n_trees", C.c_size_t), ("bins", C.c_void_p), ("n_bins", C.c_size_t)]
+
+
+class BlockBatch(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("sizes", C.POINTER(C.c_uint64)), ("n_blocks", C.c_size_t)]
+
+
 _lib = None
 
 
@@ -76,6 +88,15 @@ def load_library(path=None):
     lib.fsgpu_set_quality_codebook.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     lib.fsgpu_qvz_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     del pp
+    lib.fsgpu_library_open.restype = C.c_void_p
+    lib.fsgpu_library_open.argtypes = [C.c_char_p, C.c_uint32]
+    lib.fsgpu_library_close.argtypes = [C.c_void_p]
+    lib.fsgpu_library_std_bins.restype = C.POINTER(BinBatch)
+    lib.fsgpu_library_std_bins.argtypes = [C.c_void_p]
+    for f in (lib.fsgpu_library_config, lib.fsgpu_library_header_fields, lib.fsgpu_library_quality_codebook):
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.fsgpu_compress_bins.argtypes = [C.c_void_p, C.POINTER(BinBatch), C.POINTER(BlockBatch)]
     if path is None:
         _lib = lib
     return lib
@@ -84,6 +105,55 @@ def load_library(path=None):
 # C1 profile of the reference's scripts/fastore_compress.sh:146-148: -r -f256 -c10 -d8 -w1024 -W1024
 C1_PROFILE = dict(extra_reduce_hard_reads=1, min_bin_size=256, min_consensus_size=10, max_hamming_distance=8,
                   max_lz_window=1024, max_pair_lz_window=1024)
+
+
+class Library:
+    """The standard bins of a binned library, unpacked into the flat batch that fsgpu_compress_bins takes, plus the
+    archive-level parameters of its .bmeta footer (host only; see fsgpu_library_open in include/fastore_amd.h)."""
+
+    def __init__(self, in_prefix, min_bin_size=256, lib=None):
+        self.lib = lib or load_library()
+        self.h = self.lib.fsgpu_library_open(in_prefix.encode(), min_bin_size)
+        if not self.h:
+            raise FastoreError("fsgpu_library_open failed: " + self.lib.fsgpu_create_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.fsgpu_library_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def batch(self):
+        return self.lib.fsgpu_library_std_bins(self.h).contents
+
+    def _blob(self, fn):
+        n = C.c_size_t(0)
+        p = fn(self.h, C.byref(n))
+        return C.string_at(p, n.value) if p and n.value else b""
+
+    @property
+    def config(self):
+        return self._blob(self.lib.fsgpu_library_config)
+
+    @property
+    def header_fields(self):
+        return self._blob(self.lib.fsgpu_library_header_fields)
+
+    @property
+    def quality_codebook(self):
+        return self._blob(self.lib.fsgpu_library_quality_codebook)
+
+    def signatures(self):
+        b = self.batch
+        raw = C.string_at(b.bins, b.n_bins * 40)         # sizeof(fsgpu_bin) = 40
+        import struct
+        return [struct.unpack_from("<I", raw, 40 * i)[0] for i in range(b.n_bins)]
 
 
 class Packer:
@@ -133,6 +203,23 @@ class Packer:
         a = (C.c_char_p * n)(*[p.encode() for p in in_prefixes]); b = (C.c_char_p * n)(*[p.encode() for p in out_prefixes])
         self._check(self.lib.fsgpu_pack_files(self.ctx, n, a, b, int(verbose)))
         return self.stats()
+
+    def set_archive_params(self, config, header_fields=b"", quality_codebook=b""):
+        """Archive-level parameters for compress_bins(): raw BinModuleConfig, serialized read-id field table, QVZ section."""
+        self._check(self.lib.fsgpu_set_archive_params(self.ctx, config, len(config), header_fields or None, len(header_fields)))
+        if quality_codebook:
+            self._check(self.lib.fsgpu_set_quality_codebook(self.ctx, quality_codebook, len(quality_codebook)))
+
+    def compress_bins(self, batch):
+        """The per-bin seam (FastqCompressor::Compress for standard bins): one archive block per bin of `batch`."""
+        out = BlockBatch()
+        self._check(self.lib.fsgpu_compress_bins(self.ctx, C.byref(batch), C.byref(out)))
+        blocks, off = [], 0
+        for i in range(out.n_blocks):
+            n = out.sizes[i]
+            blocks.append(C.string_at(out.data + off, n))
+            off += n
+        return blocks
 
     def reset_stats(self):
         self._check(self.lib.fsgpu_reset_stats(self.ctx))

@@ -199,6 +199,57 @@ int fsgpu_compress_bins(fsgpu_ctx* ctx, const fsgpu_bin_batch* in, fsgpu_block_b
     });
 }
 
+struct fsgpu_library {
+    fs::Batch batch;
+    fs::BinModuleConfigRaw cfg;
+    std::vector<uint8_t> fields, qvz;
+    std::vector<fsgpu_record> records; std::vector<fsgpu_node> nodes; std::vector<fsgpu_tree> trees; std::vector<fsgpu_bin> bins;
+    fsgpu_bin_batch view;
+};
+
+fsgpu_library* fsgpu_library_open(const char* inPrefix, uint32_t minBinSize)
+{
+    if (!inPrefix) { g_createError = "null prefix"; return nullptr; }
+    fsgpu_library* lib = nullptr;
+    try {
+        lib = new fsgpu_library();
+        fs::BinFile bf; bf.open(inPrefix, minBinSize);
+        lib->cfg = bf.config();
+        if (lib->cfg.archiveType.readsHaveHeaders) fs::serializeHeaderFields(bf.headData(), lib->cfg.archiveType.readType == fs::READ_PE, lib->fields);
+        if (bf.qvz().present) lib->qvz = bf.qvz().footerBytes;
+        fs::Batch& b = lib->batch;
+        for (uint32_t sig : bf.stdSignatures()) bf.unpack(sig, b, true);
+        lib->records.resize(b.recs.size());
+        for (size_t i = 0; i < b.recs.size(); ++i) { const fs::Rec& r = b.recs[i]; lib->records[i] = fsgpu_record{r.seqOff, r.headOff, r.seqLen, r.auxLen, r.minimPos, r.headLen, r.flags}; }
+        lib->nodes.resize(b.nodes.size());
+        for (size_t i = 0; i < b.nodes.size(); ++i) { const fs::NodeIn& n = b.nodes[i]; lib->nodes[i] = fsgpu_node{n.rec, n.emBegin, n.emCount, n.treeBegin, n.treeCount}; }
+        lib->trees.resize(b.trees.size());
+        for (size_t i = 0; i < b.trees.size(); ++i) { const fs::TreeIn& t = b.trees[i]; lib->trees[i] = fsgpu_tree{t.signatureId, t.mainSignaturePos, t.nodeBegin, t.nodeCount}; }
+        lib->bins.resize(b.bins.size());
+        for (size_t i = 0; i < b.bins.size(); ++i) { const fs::BinIn& x = b.bins[i]; lib->bins[i] = fsgpu_bin{x.signature, x.minLen, x.maxLen, x.rawDnaSize, x.recBegin, x.recCount, x.topBegin, x.topCount}; }
+        fsgpu_bin_batch& v = lib->view;
+        v.bases = b.seq.data(); v.quals = b.qua.data(); v.heads = b.head.data(); v.n_bases = b.seq.size(); v.n_heads = b.head.size();
+        v.records = lib->records.data(); v.n_records = lib->records.size();
+        v.nodes = lib->nodes.data(); v.n_nodes = lib->nodes.size();
+        v.top_nodes = b.topNodes.data(); v.n_top_nodes = b.topNodes.size();
+        v.em_records = b.emRecs.data(); v.n_em_records = b.emRecs.size();
+        v.trees = lib->trees.data(); v.n_trees = lib->trees.size();
+        v.bins = lib->bins.data(); v.n_bins = lib->bins.size();
+        return lib;
+    } catch (const std::exception& e) { g_createError = e.what(); }
+    catch (...) { g_createError = "unknown error"; }
+    delete lib;
+    return nullptr;
+}
+void fsgpu_library_close(fsgpu_library* lib) { delete lib; }
+const fsgpu_bin_batch* fsgpu_library_std_bins(const fsgpu_library* lib) { return lib ? &lib->view : nullptr; }
+const void* fsgpu_library_config(const fsgpu_library* lib, size_t* bytes)
+{ if (!lib) return nullptr; if (bytes) *bytes = sizeof lib->cfg; return &lib->cfg; }
+const uint8_t* fsgpu_library_header_fields(const fsgpu_library* lib, size_t* bytes)
+{ if (!lib) return nullptr; if (bytes) *bytes = lib->fields.size(); return lib->fields.empty() ? nullptr : lib->fields.data(); }
+const uint8_t* fsgpu_library_quality_codebook(const fsgpu_library* lib, size_t* bytes)
+{ if (!lib) return nullptr; if (bytes) *bytes = lib->qvz.size(); return lib->qvz.empty() ? nullptr : lib->qvz.data(); }
+
 static int encodeStreams(fsgpu_ctx* ctx, size_t n, const uint32_t* kinds, const uint8_t* const* in, const size_t* inLen,
                          uint8_t* const* out, const size_t* outCap, size_t* outLen)
 {

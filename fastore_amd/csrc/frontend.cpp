@@ -412,7 +412,7 @@ struct BinEncoder::Impl {
                 dupAtBack = true;                 // lzBuffer.push_back(newLz): recycled by the next read
             } else {
                 int32_t parentNode = -1;
-                std::vector<int32_t>* rpb = nullptr;
+                std::vector<int32_t>* rpb = nullptr; size_t lbPos = ~(size_t)0;      // lower bound of `cur` in *rpb once known
                 if (usePrefix) {
                     const uint32_t expensiveLzThreshold = (uint32_t)encodeThreshold / 2;
                     const bool searchRev = isHard || (par.extraReduceExpensiveLzMatches && mr.cost > (int32_t)expensiveLzThreshold);
@@ -427,6 +427,7 @@ struct BinEncoder::Impl {
                         MatchResult fwd, rev; int32_t fwdNode = -1, revNode = -1;
                         fwd.cost = encodeThreshold + 1; rev.cost = encodeThreshold + 1;
                         const size_t lb = std::lower_bound(rpb->begin(), rpb->end(), cur, prefixLess) - rpb->begin();
+                        lbPos = lb;
                         const uint32_t maxCnt = W / 2 + 1;
                         for (size_t p = lb, cnt = 0; p < rpb->size() && cnt < maxCnt; ++p, ++cnt) {
                             const int32_t lv = nodes[(*rpb)[p]].vrec;
@@ -456,7 +457,7 @@ struct BinEncoder::Impl {
                 }
                 win.push_front(newLz);
                 if (rpb) {                        // std::set::insert: skipped when an equivalent node is present
-                    const auto it = std::lower_bound(rpb->begin(), rpb->end(), cur, prefixLess);
+                    const auto it = lbPos != ~(size_t)0 ? rpb->begin() + (ptrdiff_t)lbPos : std::lower_bound(rpb->begin(), rpb->end(), cur, prefixLess);
                     if (it == rpb->end() || prefixLess(cur, *it)) rpb->insert(it, cur);
                 }
             }

@@ -145,6 +145,20 @@ int fsgpu_pack_file(fsgpu_ctx* ctx, const char* in_prefix, const char* out_prefi
  * flight per launch), each library gets its own archive. */
 int fsgpu_pack_files(fsgpu_ctx* ctx, size_t n, const char* const* in_prefixes, const char* const* out_prefixes, int verbose);
 
+/* Adapter for callers (and tests) that do not hold unpacked records yet: every standard bin (signature != 4^p,
+ * >= min_bin_size records) of a binned library as one flat batch, in ascending signature order -- what the reference's
+ * BinFileExtractor::ExtractNextStdBin + IFastqNodesPacker::UnpackFromBin produce bin by bin
+ * (fastore_pack/BinFileExtractor.cpp:21-103, fastore_rebin/NodesPacker.cpp:416-679) -- together with the archive-level
+ * parameters of the .bmeta footer in the form fsgpu_set_archive_params()/fsgpu_set_quality_codebook() take.
+ * No device needed.  fsgpu_library_open returns NULL on error (message: fsgpu_create_error()). */
+typedef struct fsgpu_library fsgpu_library;
+fsgpu_library* fsgpu_library_open(const char* in_prefix, uint32_t min_bin_size);
+void fsgpu_library_close(fsgpu_library* lib);
+const fsgpu_bin_batch* fsgpu_library_std_bins(const fsgpu_library* lib);
+const void* fsgpu_library_config(const fsgpu_library* lib, size_t* bytes);                 /* raw BinModuleConfig */
+const uint8_t* fsgpu_library_header_fields(const fsgpu_library* lib, size_t* bytes);       /* NULL/0 without read ids */
+const uint8_t* fsgpu_library_quality_codebook(const fsgpu_library* lib, size_t* bytes);    /* NULL/0 unless --lossy */
+
 int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out);   /* cumulative since fsgpu_reset_stats() */
 int fsgpu_reset_stats(fsgpu_ctx* ctx);
 const char* fsgpu_device_name(const fsgpu_ctx* ctx);

@@ -113,3 +113,32 @@ def ref_pipeline(tmp, name, reads, length, genome, seed, paired, q, threads=8):
         subprocess.check_call([REF_DRIVER_GCC, "rebin", "-i" + prev, "-o" + cur, "-t%d" % threads, "-r", "-w1024", "-W1024", "-p%d" % p] + pe)
         prev = cur
     return prev, pe
+
+
+def reference_blocks(prefix):
+    """signature -> block bytes of a reference archive (<prefix>.cmeta footer: u32 n, u64 sizes[n], u32 signatures[n])"""
+    import struct
+    m = open(prefix + ".cmeta", "rb").read(); d = open(prefix + ".cdata", "rb").read()
+    foff, _ = struct.unpack_from("<QQ", m, 0)
+    n, = struct.unpack_from("<I", m, foff)
+    sizes = struct.unpack_from("<%dQ" % n, m, foff + 4)
+    sigs = struct.unpack_from("<%dI" % n, m, foff + 4 + 8 * n)
+    out, off = {}, 0
+    for sz, sg in zip(sizes, sigs):
+        out[sg] = d[off:off + sz]; off += sz
+    return out
+
+
+def check_compress_bins_seam(fastore_amd, packer, name, flags, lib=None):
+    """fsgpu_compress_bins on the unpacked standard bins of a golden library == the reference's blocks, bin by bin"""
+    kn = knobs_from_flags(flags)
+    with fastore_amd.Library(os.path.join(GOLDEN, name + ".in"), kn["min_bin_size"], lib=lib) as L:
+        packer.set_archive_params(L.config, L.header_fields, L.quality_codebook)
+        blocks = packer.compress_bins(L.batch)
+        sigs = L.signatures()
+    want = reference_blocks(os.path.join(GOLDEN, name + ".ref"))
+    assert len(blocks) == len(sigs) > 20
+    assert sorted(sigs) == sigs
+    for sg, blk in zip(sigs, blocks):
+        assert blk == want[sg], "block of signature %d differs" % sg
+    assert len(want) == len(sigs) + 1          # + block 0 (small bins and the N bin), which is not part of this seam

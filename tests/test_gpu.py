@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, MODELS, REF_DRIVER, REF_DRIVER_GCC, ROOT, VECTORS, flag_variants, knobs_from_flags, manifest, ref_pipeline, oracle_ppmd, oracle_qvz, oracle_rc
+from conftest import check_compress_bins_seam, GOLDEN, MODELS, REF_DRIVER, REF_DRIVER_GCC, ROOT, VECTORS, flag_variants, knobs_from_flags, manifest, ref_pipeline, oracle_ppmd, oracle_qvz, oracle_rc
 
 import sys
 sys.path.insert(0, GOLDEN)
@@ -185,3 +185,11 @@ def test_gpu_pack_under_non_default_flags(tmp_path, name, paired, sha, flags):
     with fastore_amd.Packer(device_id=0, **knobs_from_flags(flags)) as p:
         p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / "o"))
     assert hashlib.sha256(open(str(tmp_path / "o.cdata"), "rb").read()).hexdigest() == sha
+
+
+@pytest.mark.parametrize("name,paired,flags", manifest())
+def test_gpu_compress_bins_seam(name, paired, flags):
+    # fsgpu_compress_bins: unpacked standard bins in, the reference's blocks out (bin by bin)
+    import fastore_amd
+    with fastore_amd.Packer(device_id=0, **knobs_from_flags(flags)) as p:
+        check_compress_bins_seam(fastore_amd, p, name, flags)

@@ -11,7 +11,7 @@ import subprocess
 
 import pytest
 
-from conftest import GOLDEN, REF_DRIVER, REF_DRIVER_GCC, ROOT, flag_variants, knobs_from_flags, manifest, ref_pipeline
+from conftest import check_compress_bins_seam, GOLDEN, REF_DRIVER, REF_DRIVER_GCC, ROOT, flag_variants, knobs_from_flags, manifest, ref_pipeline
 
 CSRC = os.path.join(ROOT, "fastore_amd", "csrc")
 
@@ -184,3 +184,11 @@ def test_host_pipeline_equals_live_reference_across_read_lengths(emu_lib, tmp_pa
         st = p.pack_file(binned, os.path.join(t, "emu"))
     assert open(os.path.join(t, "emu.cdata"), "rb").read() == open(os.path.join(t, "ref.cdata"), "rb").read()
     assert st["bins"] > 5
+
+
+@pytest.mark.parametrize("name,paired,flags", manifest())
+def test_compress_bins_seam_on_the_host_pipeline(emu_lib, name, paired, flags):
+    # the per-bin C-ABI seam (what FastqCompressor::Compress would bind): flat batch in, one block per bin out
+    import fastore_amd
+    with fastore_amd.Packer(lib=emu_lib, host_threads=3, **knobs_from_flags(flags)) as p:
+        check_compress_bins_seam(fastore_amd, p, name, flags, lib=emu_lib)
