@@ -37,23 +37,25 @@ def sh(cmd):
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
-def prepare_library(work, name, reads, length, genome, seed, threads):
+def prepare_library(work, name, reads, length, genome, seed, threads, paired=False):
     """FASTQ -> fastore_bin -> 3 x fastore_rebin with the real reference (C1 profile). Cached."""
     base = os.path.join(work, name)
     binned = base + ".b8"
+    pe = ["-z"] if paired else []
     if not (os.path.exists(binned + ".bmeta") and os.path.exists(base + ".done")):
-        sh([GEN, "--reads", str(reads), "--len", str(length), "--genome", str(genome), "--seed", str(seed), "--out", base])
-        sh([REF_GCC, "bin", "-i" + base + "_1.fastq", "-o" + base + ".b0", "-t%d" % threads, "-H", "-q0", "-p8", "-s0", "-b256"])
+        sh([GEN, "--reads", str(reads), "--len", str(length), "--genome", str(genome), "--seed", str(seed), "--out", base] + (["--paired"] if paired else []))
+        inp = base + "_1.fastq" + ((" " + base + "_2.fastq") if paired else "")
+        sh([REF_GCC, "bin", "-i" + inp, "-o" + base + ".b0", "-t%d" % threads, "-H", "-q0", "-p8", "-s0", "-b256"] + pe)
         prev = base + ".b0"
         for p in (2, 4, 8):
             cur = base + ".b%d" % p
-            sh([REF_GCC, "rebin", "-i" + prev, "-o" + cur, "-t%d" % threads, "-r", "-w1024", "-W1024", "-p%d" % p])
+            sh([REF_GCC, "rebin", "-i" + prev, "-o" + cur, "-t%d" % threads, "-r", "-w1024", "-W1024", "-p%d" % p] + pe)
             for e in ("bmeta", "bdna", "bqua", "bhead"):
                 if os.path.exists(prev + "." + e):
                     os.remove(prev + "." + e)
             prev = cur
         open(base + ".done", "w").write("ok")
-    return binned, os.path.getsize(base + "_1.fastq")
+    return binned, os.path.getsize(base + "_1.fastq") + (os.path.getsize(base + "_2.fastq") if paired else 0)
 
 
 def main():
@@ -65,6 +67,7 @@ def main():
     ap.add_argument("--reads-per-lib", type=int, default=1_000_000)
     ap.add_argument("--work", default=os.environ.get("FASTORE_BENCH_DIR", "/tmp/fastore_bench"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--paired", action="store_true", help="paired-end libraries (--reads-per-lib pairs each): configs[2]-shaped side measurement, not the default line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -88,15 +91,19 @@ def main():
         t0 = time.time()
         per = max(2, min(8, cores // max(1, args.libs + 1)))
         with cf.ThreadPoolExecutor(max_workers=max(1, min(args.libs + 1, cores // 2))) as ex:
-            futs = [ex.submit(prepare_library, args.work, "lib%02d" % i, args.reads_per_lib, L, args.reads_per_lib * L // 50, 8 + i, per) for i in range(args.libs)]
-            fs = ex.submit(prepare_library, args.work, "sample", 200_000, L, 200_000 * L // 50, 99, per)
+            tag = "pe" if args.paired else "lib"
+            cov = 2 if args.paired else 1        # bases per record: the genome is sized for ~50x coverage either way
+            futs = [ex.submit(prepare_library, args.work, "%s%02d" % (tag, i), args.reads_per_lib, L, cov * args.reads_per_lib * L // 50, 8 + i, per, args.paired) for i in range(args.libs)]
+            fs = ex.submit(prepare_library, args.work, "sample_pe" if args.paired else "sample", 200_000, L, cov * 200_000 * L // 50, 99, per, args.paired)
             libs = [f.result() for f in futs]
             sample = fs.result()
         prep_s = time.time() - t0
     if world > 1:
         dist.barrier()
         if rank != 0:
-            libs = [(os.path.join(args.work, "lib%02d.b8" % i), os.path.getsize(os.path.join(args.work, "lib%02d_1.fastq" % i))) for i in range(args.libs)]
+            tag = "pe" if args.paired else "lib"
+            libs = [(os.path.join(args.work, "%s%02d.b8" % (tag, i)),
+                     sum(os.path.getsize(os.path.join(args.work, "%s%02d_%d.fastq" % (tag, i, m))) for m in ((1, 2) if args.paired else (1,)))) for i in range(args.libs)]
     fastq_bytes = sum(s for _, s in libs)
     ins = [b for b, _ in libs]
     outs = [os.path.join(args.work, "out_r%d_%02d" % (rank, i)) for i in range(len(libs))]
@@ -135,14 +142,14 @@ def main():
         # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command is reported per launch
         traffic = None
         tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tf) and args.libs == 10 and args.reads_per_lib == 1_000_000:
+        if os.path.exists(tf) and args.libs == 10 and args.reads_per_lib == 1_000_000 and not args.paired:
             traffic = json.load(open(tf))["hbm_bytes_per_step"] / (launches / args.steps)
         out = {
             "metric": "fastore_pack compressed MB/s (input FASTQ)", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%d x (%d x %d bp SE synthetic FASTQ, --lossless, C1 profile) = %.1f M reads per GPU, packed as one job"
-                                   % (len(libs), args.reads_per_lib, L, len(libs) * args.reads_per_lib / 1e6),
+            "config": {"workload": "%d x (%d x %d bp %s synthetic FASTQ, --lossless, C1 profile) = %.1f M %s per GPU, packed as one job"
+                                   % (len(libs), args.reads_per_lib, L, "PE" if args.paired else "SE", len(libs) * args.reads_per_lib / 1e6, "pairs" if args.paired else "reads"),
                        "fastq_bytes_per_gpu": fastq_bytes, "pack_flags": " ".join(PACK_FLAGS), "parallelism": "bins sharded per GPU; no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "fs_encode_streams", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic,
@@ -161,8 +168,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             # reference CPU fastore_pack on a bounded sample (200 k x 150 bp, same generator/profile), and parity on it
             sb, sbytes = sample
-            sp = os.path.join(args.work, "sample")
-            t = time.perf_counter(); sh([REF, "pack", "-i" + sb, "-o" + sp + ".t1", "-t1"] + PACK_FLAGS); t1 = time.perf_counter() - t
+            sp = os.path.join(args.work, "sample_pe" if args.paired else "sample")
+            pe = ["-z"] if args.paired else []
+            t = time.perf_counter(); sh([REF, "pack", "-i" + sb, "-o" + sp + ".t1", "-t1"] + PACK_FLAGS + pe); t1 = time.perf_counter() - t
             # the reference's multi-threaded pack dead-locks at -t64 (observed here and in the build container), so the
             # all-cores leg uses at most 32 workers, under a timeout, stepping down if it still hangs
             nt, tn = None, None
@@ -171,7 +179,7 @@ def main():
                     continue
                 try:
                     t = time.perf_counter()
-                    subprocess.run([REF, "pack", "-i" + sb, "-o" + sp + ".tn", "-t%d" % cand] + PACK_FLAGS, stdout=subprocess.DEVNULL,
+                    subprocess.run([REF, "pack", "-i" + sb, "-o" + sp + ".tn", "-t%d" % cand] + PACK_FLAGS + pe, stdout=subprocess.DEVNULL,
                                    stderr=subprocess.DEVNULL, timeout=180, check=True)
                     nt, tn = cand, time.perf_counter() - t
                     break
@@ -182,7 +190,7 @@ def main():
             packer.pack_file(sb, sp + ".gpu")
             same = open(sp + ".gpu.cdata", "rb").read() == open(sp + ".t1.cdata", "rb").read()
             out["cpu_baseline"] = {"value": round(sbytes / tn / 1e6, 2), "unit": "MB/s", "cores": nt, "kind": "reference",
-                                   "sample": "reference fastore_pack e -t%d on 200 k x 150 bp SE of the same generator (%.1f MB FASTQ)" % (nt, sbytes / 1e6),
+                                   "sample": "reference fastore_pack e -t%d on 200 k x 150 bp %s of the same generator (%.1f MB FASTQ)" % (nt, "pairs" if args.paired else "SE", sbytes / 1e6),
                                    "t1_value": round(sbytes / t1 / 1e6, 2), "t1_seconds": round(t1, 2), "tn_seconds": round(tn, 2)}
             out["parity"] = {"cdata_bit_identical_to_reference_t1": bool(same), "on": "the cpu_baseline sample"}
         print(json.dumps(out), flush=True)
