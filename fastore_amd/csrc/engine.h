@@ -41,6 +41,8 @@ int device_count();
 int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size_t errLen);
 int lane_create(Device* first, Device** out, char* err, size_t errLen);      // another lane on the GPU (and pool) of `first`
 void device_destroy(Device* dev);                                            // a lane; the pool goes with its last lane
+// diagnostic: progress of the lane's current launch (work-queue head) and the pool's slot rings, read on a stream of its own
+int lane_debug(Device* dev, char* out, size_t outLen);
 uint8_t* staging_buffer(Device* dev, size_t bytes);     // grow-only pinned host buffer for the batch input
 int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,
                        std::vector<uint8_t>& raw, std::vector<uint32_t>& sizes, BatchTiming* timing);

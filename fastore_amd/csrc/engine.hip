@@ -338,6 +338,24 @@ void device_destroy(Device* dev)
     delete dev;
 }
 
+int lane_debug(Device* dev, char* out, size_t outLen)
+{
+    if (!dev || !out || outLen == 0) return -1;
+    out[0] = 0;
+    if (hipSetDevice(dev->deviceId) != hipSuccess) return -1;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return -1;
+    uint32_t head = 0; SlotRing rings[kXcc]; memset(rings, 0, sizeof rings);
+    bool ok = hipMemcpyAsync(&head, dev->queueHead, 4, hipMemcpyDeviceToHost, s) == hipSuccess;
+    ok = ok && hipMemcpyAsync(rings, dev->pool->rings, sizeof rings, hipMemcpyDeviceToHost, s) == hipSuccess;
+    ok = ok && hipStreamSynchronize(s) == hipSuccess;
+    (void)hipStreamDestroy(s);
+    if (!ok) { snprintf(out, outLen, "device read failed"); return -1; }
+    int n = snprintf(out, outLen, "queue head %u, stream %s; rings (head-tail):", head, hipStreamQuery((hipStream_t)dev->stream) == hipSuccess ? "idle" : "busy");
+    for (uint32_t x = 0; x < kXcc && n > 0 && (size_t)n < outLen; ++x) n += snprintf(out + n, outLen - n, " %u-%u", rings[x].head, rings[x].tail);
+    return 0;
+}
+
 uint8_t* staging_buffer(Device* dev, size_t bytes)
 {
     if (bytes <= dev->capStage && dev->hStage) return dev->hStage;

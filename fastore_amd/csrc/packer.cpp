@@ -10,6 +10,7 @@
 #include <chrono>
 #include <stdexcept>
 #include <thread>
+#include <unistd.h>
 #include "bitio.h"
 #include "hostcoders.h"
 
@@ -187,6 +188,8 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
 // into slices, and the moment the last bin of a slice is done its lane thread builds the slice's stream items, stages
 // them and runs the device call -- so the host front end of the later slices, the staging and the device work of the
 // earlier ones all overlap, and the kernels of consecutive slices overlap on the device (shared arena pool).
+enum : uint32_t { kMaxLanes = 4 };
+
 void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, const std::vector<uint32_t>& binArch, const BinProducer& produce)
 {
     using namespace fsdev;
@@ -206,8 +209,12 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     for (uint64_t w : weight) totalW += w;
     // slice boundaries by cumulated weight
     std::vector<uint32_t> cut{0};
-    // default: eight slices of equal weight, one per hardware queue (measured 5, 6, 8 and 8 with a small head slice of the heaviest bins: plain 8 is best)
-    const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? 8u : 1u);
+    // default: four slices of equal weight on four lanes.  Eight concurrent launches were 5-10 % faster when they
+    // worked, but on some MI355X boxes the device stopped making progress with more than four kernels in flight (all
+    // eight submitted, none finishing, even a fresh stream's 4-byte copy blocked; never with four: profiles/
+    // r01_stall_bisect.txt) -- the compute front end has four pipes, and a pipe whose kernel cannot place its remaining
+    // workgroups (the GPU is full of waves waiting for arena slots) holds up the queues that share it.
+    const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? kMaxLanes : 1u);
     if (wantSlices > 1) {
         uint64_t acc = 0; uint32_t k = 0;
         for (uint32_t i = 0; i < nBins && k + 1 < wantSlices; ++i) {
@@ -217,7 +224,8 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     }
     cut.push_back(nBins);
     const uint32_t nSlices = (uint32_t)cut.size() - 1;
-    const uint32_t wantLanes = nSlices > 1 ? std::min<uint32_t>(nSlices, cfg.pipeline_lanes ? cfg.pipeline_lanes : nSlices) : 1;
+    // never more than kMaxLanes kernels in flight unless the caller insists (pipeline_lanes); extra slices queue behind
+    const uint32_t wantLanes = nSlices > 1 ? std::min<uint32_t>(nSlices, cfg.pipeline_lanes ? cfg.pipeline_lanes : kMaxLanes) : 1;
     uint32_t nLanes = 1;
     while (nLanes < wantLanes && lane(nLanes)) ++nLanes;
     (void)lane(0);
@@ -310,7 +318,36 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         S.cv.notify_all();
     };
     for (uint32_t si = 0; si < nSlices; ++si) slices[si].th = std::thread(runSlice, si);
-    auto joinAll = [&]() { for (Slice& s : slices) if (s.th.joinable()) s.th.join(); };
+    // FS_WATCHDOG=<seconds> (diagnostic): a batch that has not finished by then reports where it stands and ends the process
+    std::mutex wdMx; std::condition_variable wdCv; bool wdStop = false; std::thread watchdog;
+    if (const char* wd = getenv("FS_WATCHDOG")) {
+        const int secs = atoi(wd);
+        if (secs > 0) watchdog = std::thread([&, secs]() {
+            std::unique_lock<std::mutex> lk(wdMx);
+            if (wdCv.wait_for(lk, std::chrono::seconds(secs), [&]() { return wdStop; })) return;
+            fprintf(stderr, "[watchdog] batch of %u bins in %u slices on %u lanes not finished after %d s\n", nBins, nSlices, nLanes, secs);
+            for (uint32_t si = 0; si < nSlices; ++si) {
+                Slice& S = slices[si];
+                uint32_t pend; bool dn; { std::lock_guard<std::mutex> g(S.mx); pend = S.pending; dn = S.done; }
+                fprintf(stderr, "[watchdog] slice %u: bins pending %u, ready %.0f ms, submitted %.0f ms, done %d, streams %zu\n", si, pend, S.tReady, S.tSubmit, (int)dn, S.items.size());
+            }
+            fflush(stderr);
+            for (uint32_t si = 0; si < nSlices; ++si) {
+                Slice& S = slices[si];
+                bool dn; { std::lock_guard<std::mutex> g(S.mx); dn = S.done; }
+                if (dn || S.tSubmit <= 0) continue;
+                fprintf(stderr, "[watchdog] slice %u device state: ", si); fflush(stderr);
+                char buf[512] = {0};
+                fsengine::lane_debug(lanes[si % nLanes], buf, sizeof buf);
+                fprintf(stderr, "%s\n", buf); fflush(stderr);
+            }
+            _exit(86);
+        });
+    }
+    auto joinAll = [&]() {
+        for (Slice& s : slices) if (s.th.joinable()) s.th.join();
+        if (watchdog.joinable()) { { std::lock_guard<std::mutex> g(wdMx); wdStop = true; } wdCv.notify_all(); watchdog.join(); }
+    };
 
     std::vector<double> busyMs(hostThreads, 0.0);
     std::vector<std::unique_ptr<BinEncoder>>& encs = encoders;        // kept across calls: their work buffers stay mapped
