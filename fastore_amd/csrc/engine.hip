@@ -131,15 +131,6 @@ __device__ __forceinline__ void encode_streams_body()
 
 __global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(EncodeArgs /* read through kernargs() */) { encode_streams_body(); }
 
-// The same coder for the few longest streams of a launch, one wave per SIMD: a launch ends with its longest stream, and
-// a wave that shares its SIMD with two others takes 1.7 x as long per symbol as one that has it alone.  The kernel
-// claims the whole register file of a SIMD (highest VGPR and AGPR marked as used), so no other wave is placed beside it.
-__global__ __launch_bounds__(64, 1) void fs_encode_streams_solo(EncodeArgs /* read through kernargs() */)
-{
-    asm volatile("; claim the register file" ::: "v255", "a255");
-    encode_streams_body();
-}
-
 __device__ __forceinline__ void put_be(uint8_t* p, uint64_t v, int nbytes)
 { for (int i = 0; i < nbytes; ++i) p[i] = (uint8_t)(v >> (8 * (nbytes - 1 - i))); }
 
@@ -231,12 +222,7 @@ struct Pool {
     SlotRing* rings = nullptr; unsigned long long* entries = nullptr;
     std::shared_mutex gate;
     std::mutex m; int lanes = 0;
-    // side stream of the one-wave-per-SIMD kernel: used by one launch at a time (the first slice of a batch, which holds
-    // the longest streams)
-    std::mutex soloMx; hipStream_t soloStream = nullptr; uint32_t* soloQueue = nullptr; uint32_t* soloOrder = nullptr;
-    hipEvent_t soloEv[3] = {nullptr, nullptr, nullptr};
 };
-enum : uint32_t { kSoloCap = 256 };
 
 static int lane_init(Device* dev, char* err, size_t errLen)
 {
@@ -327,13 +313,7 @@ void device_destroy(Device* dev)
     if (Pool* pool = dev->pool) {
         bool last;
         { std::lock_guard<std::mutex> g(pool->m); last = --pool->lanes == 0; }
-        if (last) {
-            if (pool->soloStream) { (void)hipStreamSynchronize(pool->soloStream); (void)hipStreamDestroy(pool->soloStream); }
-            for (hipEvent_t ev : pool->soloEv) if (ev) (void)hipEventDestroy(ev);
-            if (pool->soloQueue) (void)hipFree(pool->soloQueue);
-            if (pool->soloOrder) (void)hipFree(pool->soloOrder);
-            (void)hipFree(pool->arenas); (void)hipFree(pool->rings); (void)hipFree(pool->entries); delete pool;
-        }
+        if (last) { (void)hipFree(pool->arenas); (void)hipFree(pool->rings); (void)hipFree(pool->entries); delete pool; }
     }
     delete dev;
 }
@@ -420,59 +400,20 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     for (const auto& it : items) if (it.kind == KIND_PPMD) maxLen = std::max(maxLen, it.in_len);
     const uint32_t longLen = std::max(1u, maxLen / 2);                     // "long" = at least half of the longest PPMd stream
 
-    // The longest PPMd streams of the launch go to the one-wave-per-SIMD kernel on the pool's side stream, if it is free
-    // (FS_SOLO = how many at most, FS_SOLO_MIN = from which length on).
-    static const uint32_t soloMax = getenv("FS_SOLO") ? std::min<uint32_t>(kSoloCap, (uint32_t)std::max(0, atoi(getenv("FS_SOLO")))) : 0u;
-    static const uint32_t soloMin = getenv("FS_SOLO_MIN") ? (uint32_t)std::max(1, atoi(getenv("FS_SOLO_MIN"))) : 150000u;
-    std::vector<uint32_t> solo;
-    std::unique_lock<std::mutex> soloLock(pool->soloMx, std::defer_lock);
-    if (soloMax && !exclusive && nItems > 4 * soloMax && maxLen >= soloMin && soloLock.try_lock()) {
-        if (!pool->soloStream) {
-            HIP_TRY(hipStreamCreateWithFlags(&pool->soloStream, hipStreamNonBlocking));
-            HIP_TRY(hipMalloc((void**)&pool->soloQueue, 64));
-            HIP_TRY(hipMalloc((void**)&pool->soloOrder, 4ull * kSoloCap));
-            for (hipEvent_t& ev : pool->soloEv) HIP_TRY(hipEventCreate(&ev));
-        }
-        std::vector<uint32_t> rest; rest.reserve(nItems);
-        for (uint32_t i : order) {
-            const StreamItem& it = items[i];
-            if (solo.size() < soloMax && it.kind == KIND_PPMD && it.in_len >= soloMin) solo.push_back(i); else rest.push_back(i);
-        }
-        order.swap(rest);
-        if (solo.empty()) soloLock.unlock();
-    }
-    const uint32_t nSolo = (uint32_t)solo.size(), nRest = nItems - nSolo;
+    const uint32_t nRest = nItems;
     HIP_TRY(hipMemcpyAsync(dev->dIn, input, inputBytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dev->dItems, items.data(), sizeof(StreamItem) * nItems, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dev->dOrder, order.data(), 4ull * nRest, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(dev->queueHead, 0, 64, st));
-    // every wave in flight holds an arena slot until it exits: the two kernels together stay within the wave budget
     const uint32_t grid = exclusive ? (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nItems, dev->nWaves), pool->bytes / stride)
-                                    : std::min<uint32_t>(std::max(nRest, 1u), dev->nWaves - std::min(nSolo, dev->nWaves / 2));
+                                    : std::min<uint32_t>(std::max(nRest, 1u), dev->nWaves);
     if (grid == 0) { snprintf(dev->err, sizeof dev->err, "arena pool too small for a %llu-byte coder table", (unsigned long long)need); return -1; }
     // the gate is held until this launch has drained: exclusive launches never overlap ring launches
     std::shared_lock<std::shared_mutex> shared(pool->gate, std::defer_lock);
     std::unique_lock<std::shared_mutex> alone(pool->gate, std::defer_lock);
     if (exclusive) alone.lock(); else shared.lock();
-    EncodeArgs kaSolo;
-    if (nSolo) {
-        // first in host order: its waves need SIMDs with nothing else on them, which the launch below is about to fill
-        hipStream_t st2 = pool->soloStream;
-        HIP_TRY(hipEventRecord(pool->soloEv[0], st));                       // inputs are on the device
-        HIP_TRY(hipStreamWaitEvent(st2, pool->soloEv[0], 0));
-        HIP_TRY(hipMemcpyAsync(pool->soloOrder, solo.data(), 4ull * nSolo, hipMemcpyHostToDevice, st2));
-        HIP_TRY(hipMemsetAsync(pool->soloQueue, 0, 64, st2));
-        HIP_TRY(hipEventRecord(pool->soloEv[1], st2));
-        kaSolo.items = (const StreamItem*)dev->dItems; kaSolo.order = pool->soloOrder; kaSolo.in = (const uint8_t*)dev->dIn; kaSolo.out = (uint8_t*)dev->dScratch;
-        kaSolo.outSizes = (uint32_t*)dev->dSizes; kaSolo.restarts = (uint32_t*)dev->dRestarts; kaSolo.arenas = pool->arenas; kaSolo.arenaStride = stride;
-        kaSolo.queueHead = pool->soloQueue; kaSolo.rings = pool->rings; kaSolo.ringEntries = pool->entries;
-        kaSolo.nItems = nSolo; kaSolo.longLen = longLen; kaSolo.slotsPerXcc = pool->slotsPerXcc; kaSolo.pad = 0;
-        hipLaunchKernelGGL(fs_encode_streams_solo, dim3(nSolo), dim3(64), 0, st2, kaSolo);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(pool->soloEv[2], st2));
-    }
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[0], st));
-    if (nRest) {
+    {
         EncodeArgs ka;
         ka.items = (const StreamItem*)dev->dItems; ka.order = (const uint32_t*)dev->dOrder; ka.in = (const uint8_t*)dev->dIn; ka.out = (uint8_t*)dev->dScratch;
         ka.outSizes = (uint32_t*)dev->dSizes; ka.restarts = (uint32_t*)dev->dRestarts; ka.arenas = pool->arenas; ka.arenaStride = stride;
@@ -482,7 +423,6 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, ka);
         HIP_TRY(hipGetLastError());
     }
-    if (nSolo) HIP_TRY(hipStreamWaitEvent(st, pool->soloEv[2], 0));       // the read-back below needs both kernels
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));
     if (getenv("FS_TRACE")) { HIP_TRY(wait_stream(dev, st)); }
     sizes.resize(nItems);
@@ -494,7 +434,6 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         float a = 0;
         (void)hipEventElapsedTime(&a, (hipEvent_t)dev->ev[0], (hipEvent_t)dev->ev[1]);
         timing->encode_ms += a; timing->launches += 1; timing->items += nItems; timing->h2d_bytes += inputBytes;
-        if (nSolo && getenv("FS_TRACE")) { float b2 = 0; (void)hipEventElapsedTime(&b2, pool->soloEv[1], pool->soloEv[2]); fprintf(stderr, "[trace] solo kernel: %u streams (longest %u), %.1f ms; launch %.1f ms\n", nSolo, maxLen, b2, a); }
         for (uint32_t i = 0; i < nItems; ++i) { timing->restarts += restarts[i]; if (items[i].kind == KIND_PPMD) timing->ppmd_symbols += items[i].in_len; else timing->rc_symbols += items[i].in_len; }
     }
     return 0;
