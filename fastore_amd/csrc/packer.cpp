@@ -216,10 +216,18 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     // workgroups (the GPU is full of waves waiting for arena slots) holds up the queues that share it.
     const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? kMaxLanes : 1u);
     if (wantSlices > 1) {
-        uint64_t acc = 0; uint32_t k = 0;
+        // relative slice weights: equal, or FS_SLICE_WEIGHTS="1,2,2,3" (experiment: a light first slice starts the
+        // device -- and the longest streams -- earlier)
+        std::vector<double> share(wantSlices, 1.0);
+        if (const char* sw = getenv("FS_SLICE_WEIGHTS")) {
+            uint32_t n = 0;
+            for (const char* q = sw; *q && n < wantSlices; ) { const double v = atof(q); if (v > 0) share[n] = v; ++n; while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+        }
+        double shareSum = 0; for (double v : share) shareSum += v;
+        uint64_t acc = 0; uint32_t k = 0; double upTo = share[0];
         for (uint32_t i = 0; i < nBins && k + 1 < wantSlices; ++i) {
             acc += weight[byWork[i]];
-            if ((double)acc >= (double)(k + 1) / wantSlices * (double)totalW && i + 1 < nBins) { cut.push_back(i + 1); ++k; }
+            if ((double)acc >= upTo / shareSum * (double)totalW && i + 1 < nBins) { cut.push_back(i + 1); ++k; upTo += share[k]; }
         }
     }
     cut.push_back(nBins);
