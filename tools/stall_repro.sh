@@ -1,3 +1,7 @@
+#!/bin/bash
+# Repeats the default bench step under FS_WATCHDOG to catch the device stall seen with more than four concurrent launches
+# (profiles/r01_stall_bisect.txt).  Edit the run lines for other settings (FS_PIPELINE_SLICES,
+# GPU_MAX_HW_QUEUES, FASTORE_AMD_LIB=<variant build>).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 L=gpurun_out/exp30.log; : > $L
