@@ -40,6 +40,9 @@ struct Unpacker {
     bool pe;
     Settings pairSettings;
     bool placed = false; uint64_t seqCur = 0, headCur = 0;
+    uint32_t recEnd = 0;     // one past the last record of the slice being read: group sizes in a damaged stream cannot walk past it
+    uint32_t takeRec(uint32_t& recIdx) { if (recIdx >= recEnd) throw std::runtime_error("Corrupted bin: more records in the graph than in the footer"); return recIdx++; }
+    void checkGroup(uint32_t groupSize, uint32_t recIdx, uint32_t slack) const { if ((uint64_t)groupSize > (uint64_t)(recEnd - recIdx) + slack) throw std::runtime_error("Corrupted bin: group larger than the bin"); }
     uint32_t dna4[256];      // byte of packed bases -> four characters
 
     Unpacker(const BinModuleConfigRaw& c, Batch& batch, Batch& graph, const std::vector<uint8_t>& m, uint64_t ms, const std::vector<uint8_t>& d, uint64_t ds,
@@ -127,7 +130,10 @@ struct Unpacker {
         if (pe && s.suffixLen) { if (meta.getBit()) r.flags |= FLAG_SWAPPED; }
         r.seqOff = allocSeq((uint32_t)r.seqLen + r.auxLen);
         readNextRecord(s, r, r.seqOff, r.seqLen, false);
-        if (s.suffixLen > 0) memcpy(b.seq.data() + r.seqOff + r.minimPos, s.signature, cfg.minimizer.signatureLen);
+        if (s.suffixLen > 0) {
+            if ((uint32_t)r.minimPos + cfg.minimizer.signatureLen > r.seqLen) throw std::runtime_error("Corrupted bin: signature position outside the read");
+            memcpy(b.seq.data() + r.seqOff + r.minimPos, s.signature, cfg.minimizer.signatureLen);
+        }
         if (pe) readNextRecord(pairSettings, r, r.seqOff + r.seqLen, r.auxLen, true);
     }
     void readExactMatch(const Settings& s, const Rec& mainRec, Rec& r)
@@ -146,7 +152,7 @@ struct Unpacker {
     // IFastqNodesPacker::ReadNextNode -- node slot `nodeIdx` must already exist
     void readNextNode(uint32_t nodeIdx, const Settings& s, uint32_t& recIdx)
     {
-        const uint32_t mainRec = recIdx++;
+        const uint32_t mainRec = takeRec(recIdx);
         readRecordData(s, b.recs[mainRec]);
         g.nodes[nodeIdx].rec = mainRec;
         if (!s.hasReadGroups) return;
@@ -154,17 +160,19 @@ struct Unpacker {
         const bool hasTrees = meta.getBit() != 0;
         if (hasEm) {
             const uint32_t groupSize = meta.getBits(kBitsPerClass[meta.get2Bits()]);
+            checkGroup(groupSize, recIdx, 0);
             g.nodes[nodeIdx].emBegin = (uint32_t)g.emRecs.size();
             g.nodes[nodeIdx].emCount = groupSize;
             g.emRecs.resize(g.emRecs.size() + groupSize);
             for (uint32_t i = 0; i < groupSize; ++i) {
-                const uint32_t em = recIdx++;
+                const uint32_t em = takeRec(recIdx);
                 readExactMatch(s, b.recs[mainRec], b.recs[em]);
                 g.emRecs[g.nodes[nodeIdx].emBegin + i] = em;
             }
         }
         if (hasTrees) {
             const uint32_t tCount = meta.getBits(kBitsPerClass[meta.get2Bits()]);
+            checkGroup(tCount, recIdx, 16);
             const uint32_t treeBegin = (uint32_t)g.trees.size();
             g.nodes[nodeIdx].treeBegin = treeBegin; g.nodes[nodeIdx].treeCount = tCount;
             g.trees.resize(g.trees.size() + tCount);
@@ -173,6 +181,7 @@ struct Unpacker {
                 tr.signatureId = meta.getBits(cfg.minimizer.signatureLen * 2);
                 tr.mainSignaturePos = (int32_t)meta.getBits(8);
                 const uint32_t groupSize = meta.getBits(kBitsPerClass[meta.get2Bits()]);
+                checkGroup(groupSize, recIdx, 0);
                 tr.nodeBegin = (uint32_t)g.nodes.size(); tr.nodeCount = groupSize;
                 g.nodes.resize(g.nodes.size() + groupSize, NodeIn{0, 0, 0, 0, 0});
                 g.trees[treeBegin + t] = tr;
@@ -257,8 +266,30 @@ void BinFile::readFooter(const std::vector<uint8_t>& buf)
         bi.totalRawDnaSize = r.get8Bytes(); bi.totalRecordsCount = r.get8Bytes();
         if (usesHeaderStream_) { bi.totalHeadSize = r.get8Bytes(); bi.totalRawHeadSize = r.get8Bytes(); }
         const uint64_t n = r.get8Bytes();
+        if (n > (buf.size() - std::min<uint64_t>(buf.size(), r.position())) / sizeof(BlockMetaDataRaw)) throw std::runtime_error("Corrupted archive header");
         bi.blocks.resize(n);
         r.getBytes(bi.blocks.data(), n * sizeof(BlockMetaDataRaw));
+        // The totals size the unpack buffers: hold them against what the stream files can hold (every base has a
+        // quality of at least one bit -- exact duplicates store no bases, but they do store qualities; positions under an
+        // 'N' may be skipped, and fewer than a third of a read is 'N'; a record costs at least one bit; 7 bits per read-id
+        // character), so that a damaged footer is an error, not a terabyte allocation or a copy past a buffer.
+        const uint64_t sigLen = cfg_.minimizer.signatureLen;
+        auto plausible = [&](uint64_t meta, uint64_t dna, uint64_t qua, uint64_t head, uint64_t rawDna, uint64_t recs, uint64_t rawHead) {
+            if (meta > meta_.size || dna > dna_.size || qua > qua_.size || head > headf_.size) return false;
+            if (recs > 8 * (meta + dna) + 64) return false;
+            if (rawDna > 12 * qua + (sigLen + 64) * recs + 64) return false;
+            if (rawHead > 2 * head + 64) return false;
+            return true;
+        };
+        uint64_t sm = 0, sd = 0, sq = 0, sh = 0, sr = 0, sn = 0, srh = 0;
+        for (const BlockMetaDataRaw& b : bi.blocks) {
+            if (!plausible(b.metaSize, b.dnaSize, b.quaSize, usesHeaderStream_ ? b.headSize : 0, b.rawDnaSize, b.recordsCount, usesHeaderStream_ ? b.rawHeadSize : 0)) throw std::runtime_error("Corrupted archive header");
+            sm += b.metaSize; sd += b.dnaSize; sq += b.quaSize; sh += b.headSize; sr += b.rawDnaSize; sn += b.recordsCount; srh += b.rawHeadSize;
+        }
+        if (!plausible(bi.totalMetaSize, bi.totalDnaSize, bi.totalQuaSize, bi.totalHeadSize, bi.totalRawDnaSize, bi.totalRecordsCount, bi.totalRawHeadSize)
+            || sm > bi.totalMetaSize || sd > bi.totalDnaSize || sq > bi.totalQuaSize || (usesHeaderStream_ && sh > bi.totalHeadSize)
+            || sr > bi.totalRawDnaSize || sn > bi.totalRecordsCount || (usesHeaderStream_ && srh > bi.totalRawHeadSize))
+            throw std::runtime_error("Corrupted archive header");
     }
     qvz_ = QvzModel();
     if (cfg_.quaParams.method == MET_QVZ) qvz_.parse(r);      // WELL seed, max read length, codebook (BinFile.cpp:740-755)
@@ -339,6 +370,7 @@ void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asN
         s.hasConstLen = (s.minLen == s.maxLen);
         if (!s.hasConstLen) s.bitsPerLen = bitLength(s.maxLen - s.minLen);
         const uint32_t end = recIdx + (uint32_t)blk.recordsCount;
+        u.recEnd = end;
         while (recIdx < end) {
             const uint32_t nodeIdx = (uint32_t)graph.nodes.size();
             graph.nodes.push_back(NodeIn{0, 0, 0, 0, 0});

@@ -272,6 +272,7 @@ static int encodeStreams(fsgpu_ctx* ctx, size_t n, const uint32_t* kinds, const 
         std::vector<uint8_t> raw; std::vector<uint32_t> rawSizes;
         if (fsengine::encode_streams_raw(ctx->c.dev, input.data(), inBytes, items, raw, rawSizes, &ctx->c.timing) != 0) throw std::runtime_error(std::string("device: ") + ctx->c.dev->err);
         for (size_t i = 0; i < n; ++i) {
+            if (rawSizes[i] == 0xFFFFFFFFu) throw std::runtime_error("stream " + std::to_string(i) + ": symbol or context outside its coder's alphabet");
             outLen[i] = rawSizes[i];
             const size_t c = std::min<size_t>(rawSizes[i], outCap[i]);
             if (c) memcpy(out[i], raw.data() + items[i].out_off, c);

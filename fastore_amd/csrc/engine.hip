@@ -468,7 +468,10 @@ int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vect
     if (ensure(dev, dev->dPlans, dev->capPlans, sizeof(BlockPlan) * nBins)) return -1;
     // a stream that filled its scratch slot was clipped: refuse rather than emit a corrupt block
     for (uint32_t i = 0; i < nItems; ++i)
-        if (sizes[i] >= items[i].out_cap && items[i].in_len > 0) {
+        if (sizes[i] == 0xFFFFFFFFu) {
+            snprintf(dev->err, sizeof dev->err, "stream item %u: symbol or context outside its coder's alphabet (corrupted input)", i);
+            return -2;
+        } else if (sizes[i] >= items[i].out_cap && items[i].in_len > 0) {
             snprintf(dev->err, sizeof dev->err, "stream item %u overflowed its output slot (%u >= %u)", i, sizes[i], items[i].out_cap);
             return -2;
         }

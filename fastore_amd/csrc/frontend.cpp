@@ -997,6 +997,7 @@ struct BinEncoder::Impl {
     void initNodes(const BinIn& bin)
     {
         // node table: Batch nodes [nodeBase, nodeEnd) of this bin; bins own contiguous node ranges
+        if (bin.topCount == 0 || bin.recCount == 0 || (size_t)bin.topBegin + bin.topCount > G->topNodes.size()) throw std::runtime_error("Corrupted bin: no records in a standard bin");
         nodeBase = G->topNodes[bin.topBegin];
         uint32_t nodeEnd = nodeBase;
         for (uint32_t k = 0; k < bin.topCount; ++k) nodeEnd = std::max(nodeEnd, G->topNodes[bin.topBegin + k] + 1);

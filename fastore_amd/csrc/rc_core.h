@@ -90,6 +90,10 @@ FS_DEV uint32_t encode_stream(fs_gptr table /*16-byte aligned, table_bytes()*/, 
     for (uint32_t k = 0; k < n; ++k) {
         const uint32_t pr = fs_ld16(pairs + 2u * k);
         const uint32_t sym = pr & 0xFFu, ctx = pr >> 8;
+        // a symbol outside the alphabet has no statistic (its frequency would read as 0 and the normalisation loop below
+        // would never end); a context outside its field would index past the table.  Both only come from corrupted input
+        // or a wrong caller: give the stream up (reported as 0xFFFFFFFF, like the QVZ coder does).
+        if ((BITS < 8 && sym >= A) || (ADV && CTXBITS < 8 && ctx >= (1u << CTXBITS))) return 0xFFFFFFFFu;
         const uint32_t h = ADV ? (uint32_t)(((hash & symMask) << CTXBITS) | ctx) : (uint32_t)(hash & symMask);
         fs_gptr16 st = (fs_gptr16)table + (uint64_t)h * A;
         uint32_t acc, lo, f;

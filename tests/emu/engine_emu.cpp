@@ -59,7 +59,10 @@ int encode_batch(Device* dev, const uint8_t* input, size_t, std::vector<StreamIt
 {
     std::vector<uint8_t> scratch; std::vector<uint32_t> sizes;
     runItems(input, items, scratch, sizes, t);
-    for (size_t i = 0; i < items.size(); ++i) if (sizes[i] >= items[i].out_cap && items[i].in_len > 0) { snprintf(dev->err, sizeof dev->err, "stream overflow"); return -2; }
+    for (size_t i = 0; i < items.size(); ++i) {
+        if (sizes[i] == 0xFFFFFFFFu) { snprintf(dev->err, sizeof dev->err, "stream item %zu: symbol or context outside its coder's alphabet (corrupted input)", i); return -2; }
+        if (sizes[i] >= items[i].out_cap && items[i].in_len > 0) { snprintf(dev->err, sizeof dev->err, "stream overflow"); return -2; }
+    }
     blocks.clear(); blockSizes.assign(plans.size(), 0);
     for (size_t b = 0; b < plans.size(); ++b) {
         BlockPlan& pl = plans[b];

@@ -193,3 +193,16 @@ def test_gpu_compress_bins_seam(name, paired, flags):
     import fastore_amd
     with fastore_amd.Packer(device_id=0, **knobs_from_flags(flags)) as p:
         check_compress_bins_seam(fastore_amd, p, name, flags)
+
+
+def test_rc_device_rejects_symbols_outside_the_alphabet(packer):
+    # a symbol or context a model has no statistic for must end the stream with an error, not spin in the coder's
+    # normalisation loop (frequency 0) or index past its table
+    import fastore_amd
+    ok = bytes([1, 0, 3, 1, 7, 2])
+    assert len(packer.rc_encode([MODELS["a8o4"][0]], [ok])[0]) >= 8
+    for name, bad in (("s2o4", bytes([2, 0])), ("a8o4", bytes([1, 0, 9, 0])), ("a8o6", bytes([0, 0, 200, 1])), ("a2o10", bytes([1, 0, 0, 3]))):
+        with pytest.raises(fastore_amd.FastoreError, match="alphabet"):
+            packer.rc_encode([MODELS[name][0]], [bad])
+    with pytest.raises(fastore_amd.FastoreError, match="alphabet"):
+        packer.rc_encode([6], [bytes([65, 3, 66, 64])])          # model 6: ctx0 must be < 64

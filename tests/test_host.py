@@ -11,7 +11,7 @@ import subprocess
 
 import pytest
 
-from conftest import check_compress_bins_seam, GOLDEN, REF_DRIVER, REF_DRIVER_GCC, ROOT, flag_variants, knobs_from_flags, manifest, ref_pipeline
+from conftest import check_compress_bins_seam, GOLDEN, MODELS, REF_DRIVER, REF_DRIVER_GCC, ROOT, flag_variants, knobs_from_flags, manifest, ref_pipeline
 
 CSRC = os.path.join(ROOT, "fastore_amd", "csrc")
 
@@ -192,3 +192,15 @@ def test_compress_bins_seam_on_the_host_pipeline(emu_lib, name, paired, flags):
     import fastore_amd
     with fastore_amd.Packer(lib=emu_lib, host_threads=3, **knobs_from_flags(flags)) as p:
         check_compress_bins_seam(fastore_amd, p, name, flags, lib=emu_lib)
+
+
+def test_host_build_of_the_rc_core_rejects_symbols_outside_the_alphabet(emu_lib):
+    # same core header as the device: a symbol without a statistic must end the stream, not loop in the normalisation
+    import fastore_amd
+    with fastore_amd.Packer(lib=emu_lib) as p:
+        assert len(p.rc_encode([MODELS["a8o4"][0]], [bytes([1, 0, 3, 1, 7, 2])])[0]) >= 8
+        for name, bad in (("s2o4", bytes([2, 0])), ("a8o4", bytes([1, 0, 9, 0])), ("a8o6", bytes([0, 0, 200, 1])), ("a2o10", bytes([1, 0, 0, 3]))):
+            with pytest.raises(fastore_amd.FastoreError, match="alphabet"):
+                p.rc_encode([MODELS[name][0]], [bad])
+        with pytest.raises(fastore_amd.FastoreError, match="alphabet"):
+            p.rc_encode([6], [bytes([65, 3, 66, 64])])
