@@ -221,7 +221,7 @@ void BinFile::unmap(Map& m) { if (m.p) munmap((void*)m.p, m.size); m.p = nullptr
 void BinFile::copyAt(const Map& m, uint64_t off, void* dst, uint64_t n, const char* what)
 {
     if (n == 0) return;
-    if (off + n > m.size) throw std::runtime_error(std::string("Cannot read ") + what);
+    if (off > m.size || n > m.size - off) throw std::runtime_error(std::string("Cannot read ") + what);      // (off + n may wrap)
     memcpy(dst, m.p + off, n);
 }
 
@@ -235,7 +235,7 @@ void BinFile::open(const std::string& prefix, uint32_t minBinSize)
     qua_ = mapFile(prefix + ".bqua");
     FileHeader fh; memset(&fh, 0, sizeof fh);
     copyAt(meta_, 0, &fh, sizeof fh, "bin header");
-    if (fh.blockCount == 0 || fh.footerOffset + fh.footerSize > metaSize) throw std::runtime_error("Corrupted archive header");
+    if (fh.blockCount == 0 || fh.footerOffset > metaSize || fh.footerSize > metaSize - fh.footerOffset) throw std::runtime_error("Corrupted archive header");
     usesHeaderStream_ = fh.usesHeaderStream != 0;
     if (usesHeaderStream_) headf_ = mapFile(prefix + ".bhead");
     std::vector<uint8_t> footer(fh.footerSize);

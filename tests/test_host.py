@@ -204,3 +204,42 @@ def test_host_build_of_the_rc_core_rejects_symbols_outside_the_alphabet(emu_lib)
                 p.rc_encode([MODELS[name][0]], [bad])
         with pytest.raises(fastore_amd.FastoreError, match="alphabet"):
             p.rc_encode([6], [bytes([65, 3, 66, 64])])
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_damaged_inputs_end_in_an_error_or_an_archive_never_a_hang(emu_lib, tmp_path, seed):
+    # bit flips, truncation, runs of 0x00 / 0xFF in each of the four stream files (a longer run of the same generator
+    # went through 1 000 cases under AddressSanitizer).  Whatever comes out, the call has to return: the footer totals
+    # are held against the file sizes, group sizes against the bin, and a range-coder symbol outside its alphabet stops
+    # its stream instead of spinning in the coder (on the device that would be a wave that never ends).
+    import fastore_amd, random, shutil
+    rnd = random.Random(seed)
+    with fastore_amd.Packer(lib=emu_lib, host_threads=2, min_bin_size=24) as p:
+        for it in range(12):
+            name = rnd.choice(["se_lossless", "pe_lossless", "se_qvz", "se_reduced", "se_noheader"])
+            for e in ("bmeta", "bdna", "bqua", "bhead"):
+                src = os.path.join(GOLDEN, name + ".in." + e)
+                dst = str(tmp_path / ("x." + e))
+                if os.path.exists(src):
+                    shutil.copy(src, dst)
+                elif os.path.exists(dst):
+                    os.remove(dst)
+            target = rnd.choice(["bmeta", "bmeta", "bmeta", "bdna", "bqua", "bhead"])
+            path = str(tmp_path / ("x." + target))
+            if not os.path.exists(path):
+                continue
+            d = bytearray(open(path, "rb").read())
+            mode = rnd.choice(["flip", "flip", "trunc", "zero", "ff"])
+            if mode == "flip":
+                for _ in range(rnd.randint(1, 8)):
+                    i = rnd.randrange(len(d)); d[i] ^= 1 << rnd.randrange(8)
+            elif mode == "trunc":
+                d = d[:rnd.randrange(len(d))]
+            else:
+                i = rnd.randrange(len(d)); n = rnd.randint(1, 64); d[i:i + n] = bytes([0 if mode == "zero" else 255]) * n
+            open(path, "wb").write(d)
+            try:
+                p.pack_file(str(tmp_path / "x"), str(tmp_path / "o"))
+            except fastore_amd.FastoreError:
+                pass
