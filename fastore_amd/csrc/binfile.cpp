@@ -71,8 +71,10 @@ struct Unpacker {
             };
             run(0, minimPos); run(minimPos + suffixLen, seqLen);
         } else {
-            for (uint32_t i = 0; i < minimPos; ++i) seq[i] = (uint8_t)idxToDna[dna.getBits(3) & 7];
-            for (uint32_t i = minimPos + suffixLen; i < seqLen; ++i) seq[i] = (uint8_t)idxToDna[dna.getBits(3) & 7];
+            // three bits per base: codes 5-7 do not exist (dnaSymbolOrder has five entries)
+            auto base3 = [&]() -> uint8_t { const uint32_t c = dna.getBits(3); if (c > 4) throw std::runtime_error("Corrupted bin: invalid base code"); return (uint8_t)idxToDna[c]; };
+            for (uint32_t i = 0; i < minimPos; ++i) seq[i] = base3();
+            for (uint32_t i = minimPos + suffixLen; i < seqLen; ++i) seq[i] = base3();
         }
     }
     void readQuality(uint8_t* q, uint32_t n)
@@ -254,6 +256,13 @@ void BinFile::readFooter(const std::vector<uint8_t>& buf)
 {
     BitReader r(buf.data(), buf.size());
     r.getBytes(&cfg_, sizeof cfg_);
+    {   // the raw config steers table sizes and the base alphabet: refuse values the writers never produce
+        const MinimizerParametersRaw& mp = cfg_.minimizer;
+        bool ok = mp.signatureLen >= 4 && mp.signatureLen <= 12 && mp.signatureMaskCutoffBits <= 2 * mp.signatureLen && cfg_.quaParams.method <= MET_QVZ && cfg_.archiveType.readType <= READ_PE;
+        uint32_t seen = 0;
+        for (char c : mp.dnaSymbolOrder) { const char* at = strchr("ACGTN", c); if (!c || !at) { ok = false; break; } seen |= 1u << (at - "ACGTN"); }
+        if (!ok || seen != 31u) throw std::runtime_error("Corrupted archive header");
+    }
     const uint32_t total = (1u << (2 * cfg_.minimizer.signatureLen)) + 1;
     std::vector<bool> bitmap(total);
     for (uint32_t i = 0; i < total; ++i) bitmap[i] = r.getBit() != 0;

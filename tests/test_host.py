@@ -243,3 +243,6 @@ def test_damaged_inputs_end_in_an_error_or_an_archive_never_a_hang(emu_lib, tmp_
                 p.pack_file(str(tmp_path / "x"), str(tmp_path / "o"))
             except fastore_amd.FastoreError:
                 pass
+        # the context is still good after the failures
+        p.pack_file(os.path.join(GOLDEN, "se_lossless.in"), str(tmp_path / "good"))
+        assert_same_archive(str(tmp_path / "good"), os.path.join(GOLDEN, "se_lossless.ref"))
