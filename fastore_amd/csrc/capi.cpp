@@ -161,18 +161,26 @@ int fsgpu_compress_bins(fsgpu_ctx* ctx, const fsgpu_bin_batch* in, fsgpu_block_b
     if (!ctx->c.haveArchive) { ctx->c.err = "fsgpu_set_archive_params() has not been called"; return FSGPU_ERR_ARG; }
     FS_GUARD(ctx, {
         fs::Batch b;
+        const uint32_t sigLen = ctx->c.archives[0].cfg.minimizer.signatureLen;
+        if ((in->n_bases && (!in->bases || !in->quals)) || (in->n_heads && !in->heads) || (in->n_records && !in->records) || (in->n_nodes && !in->nodes)
+            || (in->n_top_nodes && !in->top_nodes) || (in->n_em_records && !in->em_records) || (in->n_trees && !in->trees) || (in->n_bins && !in->bins))
+            throw std::runtime_error("null array in the bin batch");
         b.seq.assign(in->bases, in->bases + in->n_bases); b.qua.assign(in->quals, in->quals + in->n_bases);
         if (in->n_heads) b.head.assign(in->heads, in->heads + in->n_heads);
         b.recs.resize(in->n_records);
         for (size_t i = 0; i < in->n_records; ++i) {
             const fsgpu_record& r = in->records[i];
             if ((uint64_t)r.seq_off + r.seq_len + r.aux_len > in->n_bases || (uint64_t)r.head_off + r.head_len > in->n_heads) throw std::runtime_error("record outside the batch buffers");
+            if ((uint32_t)r.minim_pos + sigLen > r.seq_len) throw std::runtime_error("record with its signature outside the read");
             b.recs[i] = fs::Rec{r.seq_off, r.head_off, r.seq_len, r.aux_len, r.minim_pos, r.head_len, r.flags};
         }
         b.nodes.resize(in->n_nodes);
         for (size_t i = 0; i < in->n_nodes; ++i) {
             const fsgpu_node& n = in->nodes[i];
             if (n.rec >= in->n_records || (uint64_t)n.em_begin + n.em_count > in->n_em_records || (uint64_t)n.tree_begin + n.tree_count > in->n_trees) throw std::runtime_error("node references outside the batch");
+            // sub-tree nodes come after their owner (NodesPacker.cpp:567-679 writes them depth first): anything else could
+            // make the graph cyclic
+            for (uint32_t t = 0; t < n.tree_count; ++t) if (in->trees[n.tree_begin + t].node_begin <= i) throw std::runtime_error("sub-tree nodes must follow their owner");
             b.nodes[i] = fs::NodeIn{n.rec, n.em_begin, n.em_count, n.tree_begin, n.tree_count};
         }
         b.topNodes.assign(in->top_nodes, in->top_nodes + in->n_top_nodes);

@@ -246,3 +246,35 @@ def test_damaged_inputs_end_in_an_error_or_an_archive_never_a_hang(emu_lib, tmp_
         # the context is still good after the failures
         p.pack_file(os.path.join(GOLDEN, "se_lossless.in"), str(tmp_path / "good"))
         assert_same_archive(str(tmp_path / "good"), os.path.join(GOLDEN, "se_lossless.ref"))
+
+
+def test_compress_bins_rejects_a_malformed_batch(emu_lib):
+    # the seam takes caller-built tables: indices and positions are checked before the front end walks them
+    import ctypes as C, struct
+    import fastore_amd
+    with fastore_amd.Packer(lib=emu_lib, host_threads=2, min_bin_size=24) as p, \
+            fastore_amd.Library(os.path.join(GOLDEN, "se_lossless.in"), 24, lib=emu_lib) as L:
+        p.set_archive_params(L.config, L.header_fields, L.quality_codebook)
+        good = L.batch
+        def variant(**kw):
+            b = fastore_amd.BinBatch()
+            C.memmove(C.byref(b), C.byref(good), C.sizeof(b))
+            keep = []
+            for field, (index, fmt, offset, value, size) in kw.items():
+                n = getattr(b, "n_" + field)
+                raw = bytearray(C.string_at(getattr(b, field), n * size))
+                struct.pack_into(fmt, raw, index * size + offset, value)
+                buf = (C.c_char * len(raw)).from_buffer(raw); keep.append((raw, buf))
+                setattr(b, field, C.addressof(buf))
+            return b, keep
+        cases = {
+            "signature outside the read": dict(records=(3, "<H", 12, 250, 16)),          # minim_pos of record 3
+            "record outside the batch": dict(records=(0, "<I", 0, 0xFFFFFF00, 16)),        # seq_off
+            "node references outside": dict(nodes=(1, "<I", 0, 0x7FFFFFFF, 20)),           # rec of node 1
+            "bin ranges outside": dict(bins=(0, "<I", 28, 0x7FFFFFFF, 40)),                # rec_count of bin 0
+        }
+        for msg, kw in cases.items():
+            b, keep = variant(**kw)
+            with pytest.raises(fastore_amd.FastoreError, match=msg):
+                p.compress_bins(b)
+        assert len(p.compress_bins(good)) == good.n_bins                                   # and the context still works
