@@ -206,3 +206,15 @@ def test_rc_device_rejects_symbols_outside_the_alphabet(packer):
             packer.rc_encode([MODELS[name][0]], [bad])
     with pytest.raises(fastore_amd.FastoreError, match="alphabet"):
         packer.rc_encode([6], [bytes([65, 3, 66, 64])])          # model 6: ctx0 must be < 64
+
+
+def test_gpu_libraries_larger_than_a_device_batch(tmp_path):
+    # several device batches per library (and libraries sharing batches): same bytes
+    import fastore_amd
+    fx = manifest()[:2]
+    with fastore_amd.Packer(device_id=0, batch_bases=300_000, **knobs_from_flags(fx[0][2])) as p:
+        ins = [os.path.join(GOLDEN, name + ".in") for name, _, _ in fx]
+        outs = [str(tmp_path / ("m_" + name)) for name, _, _ in fx]
+        p.pack_files(ins, outs)
+        for (name, _, _), o in zip(fx, outs):
+            assert open(o + ".cdata", "rb").read() == open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()

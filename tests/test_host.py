@@ -278,3 +278,21 @@ def test_compress_bins_rejects_a_malformed_batch(emu_lib):
             with pytest.raises(fastore_amd.FastoreError, match=msg):
                 p.compress_bins(b)
         assert len(p.compress_bins(good)) == good.n_bins                                   # and the context still works
+
+
+@pytest.mark.parametrize("batch_bases", [40_000, 300_000])
+def test_libraries_larger_than_a_device_batch(emu_lib, tmp_path, batch_bases):
+    # a library that does not fit one device batch is packed in several (the 100 M-pair configurations); blocks of
+    # earlier batches are routed to their archives while later ones are coded -- same bytes, for one library and for
+    # several libraries sharing the batches
+    import fastore_amd
+    fx = manifest()[:3]
+    with fastore_amd.Packer(lib=emu_lib, host_threads=3, batch_bases=batch_bases, **knobs_from_flags(fx[0][2])) as p:
+        for name, paired, flags in fx:
+            st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / name))
+            assert_same_archive(str(tmp_path / name), os.path.join(GOLDEN, name + ".ref"))
+        ins = [os.path.join(GOLDEN, name + ".in") for name, _, _ in fx]
+        outs = [str(tmp_path / ("m_" + name)) for name, _, _ in fx]
+        p.pack_files(ins, outs)
+        for (name, _, _), o in zip(fx, outs):
+            assert_same_archive(o, os.path.join(GOLDEN, name + ".ref"))
