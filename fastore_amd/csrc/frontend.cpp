@@ -294,8 +294,9 @@ struct BinEncoder::Impl {
     // order: node ids in processing order; auxRoot: node id of the sub-tree root copy or -1.
     void constructMatchTree(const std::vector<int32_t>& order, std::vector<int32_t>& roots, int32_t auxRoot)
     {
-        static uint8_t dummy[256]; static bool dummyInit = false;
-        if (!dummyInit) { memset(dummy, 'N', sizeof dummy); dummyInit = true; }
+        struct Dummy { uint8_t b[256]; Dummy() { memset(b, 'N', sizeof b); } };
+        static const Dummy dummyEntry;                        // (initialised once, thread-safe: the encoders run side by side)
+        const uint8_t* dummy = dummyEntry.b;
         roots.clear();
         const uint32_t W = par.maxLzWindowSize;
         struct DepthGuard { uint32_t& d; explicit DepthGuard(uint32_t& x) : d(x) { ++d; } ~DepthGuard() { --d; } } depthGuard(winDepth);

@@ -478,6 +478,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         BinFile bf; ArchiveWriter aw;
         Batch b0; std::vector<uint8_t> block0; std::thread t0; std::string t0err; double t0ms = 0;
         bool haveBlock0 = false, block0Written = true, finished = false;
+        std::atomic<bool> t0done{false};        // the block-0 thread has finished (its block can be written without waiting)
         struct Pending { std::vector<uint8_t> data; std::vector<uint64_t> sizes; std::vector<uint32_t> sigs; };
         std::vector<Pending> pending;
     };
@@ -501,7 +502,12 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
     // host tasks of the last batch are done: until then every core is needed by the front end, afterwards the host only
     // waits for the device.  When they have unpacked their bins the inputs are not needed any more and are unmapped by a
     // thread of their own, also inside the device's tail.
-    std::mutex gateMx; std::condition_variable gateCv; bool hostTasksDone = work.empty(); size_t block0Unpacked = 0, block0Threads = 0;
+    // (With several device batches the threads start at once instead: the cores idle between batches anyway, and the
+    // blocks of the finished batches can only be written -- and their memory released -- behind block 0.)
+    const uint64_t budget = cfg.batch_bases ? cfg.batch_bases : (3072ull << 20);
+    uint64_t stdBases = 0;
+    for (const Work& w : work) stdBases += libs[w.lib]->bf.bins().at(w.sig).totalRawDnaSize;
+    std::mutex gateMx; std::condition_variable gateCv; bool hostTasksDone = work.empty() || stdBases > budget; size_t block0Unpacked = 0, block0Threads = 0;
     std::thread closer;
     if (rank == 0) {
         for (size_t l = 0; l < nLibs; ++l) {
@@ -528,12 +534,13 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                     gateCv.notify_all();
                 }
                 lp->t0ms = nowMs() - a;
+                lp->t0done.store(true);
             });
         }
     }
     auto flush = [&](Lib& L, bool wait) {
         if (!L.block0Written) {
-            if (!wait) return;
+            if (!wait && !L.t0done.load()) return;
             L.t0.join(); if (!L.t0err.empty()) throw std::runtime_error(L.t0err);
             stats.block0_ms = std::max(stats.block0_ms, L.t0ms); stats.block0_bytes += L.block0.size(); stats.block0_records += L.b0.recs.size();
             L.aw.writeBlock(L.block0.data(), L.block0.size(), L.bf.nSignature());
@@ -542,7 +549,6 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         for (auto& p : L.pending) { uint64_t off = 0; for (size_t k = 0; k < p.sizes.size(); ++k) { L.aw.writeBlock(p.data.data() + off, p.sizes[k], p.sigs[k]); off += p.sizes[k]; } }
         L.pending.clear();
     };
-    const uint64_t budget = cfg.batch_bases ? cfg.batch_bases : (3072ull << 20);
     Batch& batch = workBatch; std::vector<uint32_t> binArch; size_t next = 0, done = 0;
     try {
         while (next < work.size()) {
