@@ -97,6 +97,7 @@ def load_library(path=None):
         f.restype = C.c_void_p
         f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     lib.fsgpu_compress_bins.argtypes = [C.c_void_p, C.POINTER(BinBatch), C.POINTER(BlockBatch)]
+    lib.fsgpu_merge_parts.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_size_t]
     if path is None:
         _lib = lib
     return lib
@@ -105,6 +106,14 @@ def load_library(path=None):
 # C1 profile of the reference's scripts/fastore_compress.sh:146-148: -r -f256 -c10 -d8 -w1024 -W1024
 C1_PROFILE = dict(extra_reduce_hard_reads=1, min_bin_size=256, min_consensus_size=10, max_hamming_distance=8,
                   max_lz_window=1024, max_pair_lz_window=1024)
+
+
+def merge_parts(out_prefix, world_size, lib=None):
+    """Merge <out_prefix>.part<r>.{cdata,cmeta}, r < world_size, written by rank-sharded Packers into one archive."""
+    lib = lib or load_library()
+    err = C.create_string_buffer(256)
+    if lib.fsgpu_merge_parts(out_prefix.encode(), world_size, err, len(err)) != 0:
+        raise FastoreError("fsgpu_merge_parts: " + err.value.decode())
 
 
 class Library:

@@ -258,6 +258,81 @@ const uint8_t* fsgpu_library_header_fields(const fsgpu_library* lib, size_t* byt
 const uint8_t* fsgpu_library_quality_codebook(const fsgpu_library* lib, size_t* bytes)
 { if (!lib) return nullptr; if (bytes) *bytes = lib->qvz.size(); return lib->qvz.empty() ? nullptr : lib->qvz.data(); }
 
+int fsgpu_merge_parts(const char* outPrefix, uint32_t world, char* err, size_t errLen)
+{
+    auto fail = [&](const std::string& m) { if (err && errLen) snprintf(err, errLen, "%s", m.c_str()); return (int)FSGPU_ERR_IO; };
+    if (!outPrefix || world == 0) return fail("bad arguments");
+    try {
+        struct Part { std::vector<uint64_t> sizes; std::vector<uint32_t> sigs; std::vector<uint8_t> rest; std::string data; };
+        std::vector<Part> parts(world);
+        auto slurp = [](const std::string& name) {
+            FILE* f = fopen(name.c_str(), "rb"); if (!f) throw std::runtime_error("Cannot open file: " + name);
+            std::vector<uint8_t> v; uint8_t buf[1 << 16]; size_t n;
+            while ((n = fread(buf, 1, sizeof buf, f)) > 0) v.insert(v.end(), buf, buf + n);
+            fclose(f); return v;
+        };
+        for (uint32_t r = 0; r < world; ++r) {
+            const std::string base = std::string(outPrefix) + ".part" + std::to_string(r);
+            const std::vector<uint8_t> m = slurp(base + ".cmeta");
+            uint64_t foff = 0, fsize = 0;
+            if (m.size() < 24) throw std::runtime_error("Corrupted archive header");
+            memcpy(&foff, m.data(), 8); memcpy(&fsize, m.data() + 8, 8);
+            if (foff > m.size() || fsize > m.size() - foff || fsize < 4) throw std::runtime_error("Corrupted archive header");
+            uint32_t n = 0; memcpy(&n, m.data() + foff, 4);
+            if ((uint64_t)n * 12 + 4 > fsize) throw std::runtime_error("Corrupted archive header");
+            Part& p = parts[r];
+            p.sizes.resize(n); p.sigs.resize(n);
+            if (n) { memcpy(p.sizes.data(), m.data() + foff + 4, 8ull * n); memcpy(p.sigs.data(), m.data() + foff + 4 + 8ull * n, 4ull * n); }
+            p.rest.assign(m.begin() + (ptrdiff_t)(foff + 4 + 12ull * n), m.begin() + (ptrdiff_t)(foff + fsize));
+            p.data = base + ".cdata";
+        }
+        // global order: rank 0's first block when it is the merged small-bins/N block (signature 4^p), then ascending signature
+        struct Ent { uint32_t sig, rank, idx; uint64_t size, off; };
+        std::vector<Ent> order, rest;
+        auto rawSig = [](uint32_t sg) { return sg > 0 && (sg & (sg - 1)) == 0 && (31 - __builtin_clz(sg)) % 2 == 0; };
+        for (uint32_t r = 0; r < world; ++r) {
+            uint64_t off = 0;
+            for (uint32_t i = 0; i < parts[r].sizes.size(); ++i) {
+                const Ent e{parts[r].sigs[i], r, i, parts[r].sizes[i], off}; off += parts[r].sizes[i];
+                if (r == 0 && i == 0 && rawSig(e.sig)) order.push_back(e); else rest.push_back(e);
+            }
+        }
+        std::sort(rest.begin(), rest.end(), [](const Ent& a, const Ent& b) { return a.sig != b.sig ? a.sig < b.sig : (a.rank != b.rank ? a.rank < b.rank : a.idx < b.idx); });
+        order.insert(order.end(), rest.begin(), rest.end());
+        std::vector<FILE*> src(world, nullptr);
+        FILE* dst = fopen((std::string(outPrefix) + ".cdata").c_str(), "wb");
+        if (!dst) throw std::runtime_error(std::string("Cannot open file: ") + outPrefix + ".cdata");
+        std::string problem;
+        std::vector<uint8_t> buf;
+        for (const Ent& e : order) {
+            if (!src[e.rank]) src[e.rank] = fopen(parts[e.rank].data.c_str(), "rb");
+            if (!src[e.rank]) { problem = "Cannot open file: " + parts[e.rank].data; break; }
+            buf.resize(e.size);
+            if (fseeko(src[e.rank], (off_t)e.off, SEEK_SET) != 0 || (e.size && fread(buf.data(), 1, e.size, src[e.rank]) != e.size)) { problem = "Cannot read " + parts[e.rank].data; break; }
+            if (e.size && fwrite(buf.data(), 1, e.size, dst) != e.size) { problem = "Cannot write the archive"; break; }
+        }
+        for (FILE* f : src) if (f) fclose(f);
+        if (fclose(dst) != 0 && problem.empty()) problem = "Cannot write the archive";
+        if (!problem.empty()) throw std::runtime_error(problem);
+        // footer: count, sizes, signatures, then the ArchiveConfig + field table of rank 0's part
+        std::vector<uint8_t> body;
+        const uint32_t n = (uint32_t)order.size();
+        body.resize(4 + 12ull * n);
+        memcpy(body.data(), &n, 4);
+        for (uint32_t i = 0; i < n; ++i) { memcpy(body.data() + 4 + 8ull * i, &order[i].size, 8); memcpy(body.data() + 4 + 8ull * n + 4ull * i, &order[i].sig, 4); }
+        body.insert(body.end(), parts[0].rest.begin(), parts[0].rest.end());
+        FILE* cm = fopen((std::string(outPrefix) + ".cmeta").c_str(), "wb");
+        if (!cm) throw std::runtime_error(std::string("Cannot open file: ") + outPrefix + ".cmeta");
+        uint8_t head[24] = {0}; const uint64_t foff = 24, fsize = body.size();
+        memcpy(head, &foff, 8); memcpy(head + 8, &fsize, 8);
+        const bool ok = fwrite(head, 1, 24, cm) == 24 && fwrite(body.data(), 1, body.size(), cm) == body.size();
+        if (fclose(cm) != 0 || !ok) throw std::runtime_error("Cannot write the archive");
+        for (uint32_t r = 0; r < world; ++r) { const std::string base = std::string(outPrefix) + ".part" + std::to_string(r); remove((base + ".cdata").c_str()); remove((base + ".cmeta").c_str()); }
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+    catch (...) { return fail("unknown error"); }
+}
+
 static int encodeStreams(fsgpu_ctx* ctx, size_t n, const uint32_t* kinds, const uint8_t* const* in, const size_t* inLen,
                          uint8_t* const* out, const size_t* outCap, size_t* outLen)
 {

@@ -4,12 +4,15 @@
 // knobs; errors as "Error: <what>" on stderr with exit status 255.  `d` (decode) is outside this
 // build's scope: it is delegated to the reference binary when FASTORE_PACK_REF is set.
 // New flags: -g<device> (HIP device ordinal), -j<n> (host threads beyond the reference's -t limit of 64),
-// -R<rank>/-N<world> (bin sharding).
+// -R<rank>/-N<world> (bin sharding: this process packs its share into <out>.part<rank>), -G<n> (one process, n GPUs:
+// devices g .. g+n-1 each pack their share of the bins side by side, then the parts are merged in -t1 order).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 #include <string>
+#include <thread>
+#include <vector>
 #include "../../include/fastore_amd.h"
 
 static void usage()
@@ -20,7 +23,7 @@ static void usage()
                     "\t-i<file>\t: input file(s) prefix\t-o<file>\t: output files prefix\n"
                     "\t-z\t\t: use paired-end mode\n"
                     "\t-f<n> -e<n> -m<n> -s<n> -w<n> -r -l -E<n> -W<n> -c<n> -q<n> -n<n> -d<n>\t: as the reference\n"
-                    "\t-t<n>\t\t: host threads\n\t-g<n>\t\t: HIP device ordinal\n\t-v\t\t: verbose mode\n");
+                    "\t-t<n>\t\t: host threads\n\t-g<n>\t\t: HIP device ordinal\t-G<n>\t\t: number of devices (from -g on)\n\t-v\t\t: verbose mode\n");
 }
 
 int main(int argc, char** argv)
@@ -34,7 +37,7 @@ int main(int argc, char** argv)
         perror("Error: execv"); return 255;
     }
     fsgpu_config cfg; fsgpu_config_defaults(&cfg);
-    std::string in, out; int verbose = 0; int threads = 0, hostThreads = -1; bool pe = false;
+    std::string in, out; int verbose = 0; int threads = 0, hostThreads = -1, gpus = 1; bool pe = false;
     for (int i = 2; i < argc; ++i) {
         const char* p = argv[i];
         if (p[0] != '-') continue;
@@ -61,6 +64,7 @@ int main(int argc, char** argv)
         case 'd': cfg.max_hamming_distance = v; break;
         case 'c': cfg.min_consensus_size = v; break;
         case 'g': cfg.device_id = v; break;
+        case 'G': gpus = v; break;
         case 'j': hostThreads = v; break;
         case 'R': cfg.rank = v; break;
         case 'N': cfg.world_size = v; break;
@@ -71,6 +75,27 @@ int main(int argc, char** argv)
     if (out.empty()) { fprintf(stderr, "Error: no output file(s) specified\n"); return 255; }
     if (threads < 0 || threads > 64) { fprintf(stderr, "Error: invalid number of threads specified\n"); return 255; }
     cfg.host_threads = hostThreads >= 0 ? (uint32_t)hostThreads : (uint32_t)threads;   // -j overrides -t (which keeps the reference's 1..64 range)
+    if (gpus < 1 || gpus > 64) { fprintf(stderr, "Error: invalid number of devices specified\n"); return 255; }
+    if (gpus > 1) {
+        // one context (and one set of host threads) per device; bins are sharded round-robin, no data crosses devices
+        std::vector<fsgpu_ctx*> ctxs(gpus, nullptr);
+        for (int r = 0; r < gpus; ++r) {
+            fsgpu_config c = cfg; c.device_id = cfg.device_id + r; c.rank = (uint32_t)r; c.world_size = (uint32_t)gpus;
+            if (c.host_threads) c.host_threads = (c.host_threads + gpus - 1) / gpus;
+            ctxs[r] = fsgpu_create(&c);
+            if (!ctxs[r]) { fprintf(stderr, "Error: %s\n", fsgpu_create_error()); for (fsgpu_ctx* x : ctxs) if (x) fsgpu_destroy(x); return 255; }
+        }
+        std::vector<int> rcs(gpus, 0); std::vector<std::thread> th;
+        for (int r = 0; r < gpus; ++r) th.emplace_back([&, r]() { rcs[r] = fsgpu_pack_file(ctxs[r], in.c_str(), out.c_str(), r == 0 ? verbose : 0); });
+        for (auto& t : th) t.join();
+        int bad = -1; for (int r = 0; r < gpus; ++r) if (rcs[r] != 0 && bad < 0) bad = r;
+        if (bad >= 0) fprintf(stderr, "Error: %s\n", fsgpu_last_error(ctxs[bad]));
+        for (fsgpu_ctx* x : ctxs) fsgpu_destroy(x);
+        if (bad >= 0) return 255;
+        char err[256] = {0};
+        if (fsgpu_merge_parts(out.c_str(), (uint32_t)gpus, err, sizeof err) != 0) { fprintf(stderr, "Error: %s\n", err); return 255; }
+        return 0;
+    }
     fsgpu_ctx* ctx = fsgpu_create(&cfg);
     if (!ctx) { fprintf(stderr, "Error: %s\n", fsgpu_create_error()); return 255; }
     const int rc = fsgpu_pack_file(ctx, in.c_str(), out.c_str(), verbose);

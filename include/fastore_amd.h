@@ -159,6 +159,13 @@ const void* fsgpu_library_config(const fsgpu_library* lib, size_t* bytes);      
 const uint8_t* fsgpu_library_header_fields(const fsgpu_library* lib, size_t* bytes);       /* NULL/0 without read ids */
 const uint8_t* fsgpu_library_quality_codebook(const fsgpu_library* lib, size_t* bytes);    /* NULL/0 unless --lossy */
 
+/* Bin-sharded packing of one library by `world_size` contexts (one per GPU; fsgpu_config.rank / world_size): every
+ * context writes <out_prefix>.part<rank>.{cdata,cmeta}; this call merges the parts into <out_prefix>.{cdata,cmeta} in
+ * the reference's -t1 order (the merged small-bins/N block of rank 0 first, then ascending signature) and removes them.
+ * Host only.  The multi-process form of the same exchange (all-gather of sizes over RCCL) is fastore_amd/shard.py.
+ * Returns 0 or a negative FSGPU_ERR_*; the message goes to `err` (may be NULL). */
+int fsgpu_merge_parts(const char* out_prefix, uint32_t world_size, char* err, size_t err_len);
+
 int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out);   /* cumulative since fsgpu_reset_stats() */
 int fsgpu_reset_stats(fsgpu_ctx* ctx);
 const char* fsgpu_device_name(const fsgpu_ctx* ctx);

@@ -296,3 +296,28 @@ def test_libraries_larger_than_a_device_batch(emu_lib, tmp_path, batch_bases):
         p.pack_files(ins, outs)
         for (name, _, _), o in zip(fx, outs):
             assert_same_archive(o, os.path.join(GOLDEN, name + ".ref"))
+
+
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_cli_packs_one_library_on_several_devices(tmp_path, gpus):
+    # fastore_pack e ... -G<n>: one context per device packs its share of the bins, the parts are merged in -t1 order
+    cli = os.path.join(ROOT, "build", "fastore_pack_emu")
+    for name, paired, flags in manifest()[:2]:
+        out = str(tmp_path / ("g_" + name))
+        r = subprocess.run([cli, "e", "-i" + os.path.join(GOLDEN, name + ".in"), "-o" + out, "-t4", "-G%d" % gpus] + flags + (["-z"] if paired else []), capture_output=True)
+        assert r.returncode == 0, r.stderr
+        assert_same_archive(out, os.path.join(GOLDEN, name + ".ref"))
+        assert not [f for f in os.listdir(str(tmp_path)) if ".part" in f]
+
+
+def test_merge_parts_of_rank_sharded_contexts(emu_lib, tmp_path):
+    import fastore_amd
+    name, paired, flags = manifest()[1]
+    out = str(tmp_path / "o")
+    for r in range(3):
+        with fastore_amd.Packer(lib=emu_lib, host_threads=2, rank=r, world_size=3, **knobs_from_flags(flags)) as p:
+            p.pack_file(os.path.join(GOLDEN, name + ".in"), out)
+    fastore_amd.merge_parts(out, 3, lib=emu_lib)
+    assert_same_archive(out, os.path.join(GOLDEN, name + ".ref"))
+    with pytest.raises(fastore_amd.FastoreError, match="Cannot open"):
+        fastore_amd.merge_parts(out, 3, lib=emu_lib)            # the parts are gone
