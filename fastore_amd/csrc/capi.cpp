@@ -285,6 +285,10 @@ int fsgpu_merge_parts(const char* outPrefix, uint32_t world, char* err, size_t e
             if (n) { memcpy(p.sizes.data(), m.data() + foff + 4, 8ull * n); memcpy(p.sigs.data(), m.data() + foff + 4 + 8ull * n, 4ull * n); }
             p.rest.assign(m.begin() + (ptrdiff_t)(foff + 4 + 12ull * n), m.begin() + (ptrdiff_t)(foff + fsize));
             p.data = base + ".cdata";
+            uint64_t sum = 0; for (uint64_t z : p.sizes) { if (z > (1ull << 40)) throw std::runtime_error("Corrupted archive header"); sum += z; }
+            FILE* f = fopen(p.data.c_str(), "rb"); if (!f) throw std::runtime_error("Cannot open file: " + p.data);
+            fseeko(f, 0, SEEK_END); const uint64_t have = (uint64_t)ftello(f); fclose(f);
+            if (sum != have) throw std::runtime_error("Corrupted archive: " + p.data + " does not hold the blocks its footer lists");
         }
         // global order: rank 0's first block when it is the merged small-bins/N block (signature 4^p), then ascending signature
         struct Ent { uint32_t sig, rank, idx; uint64_t size, off; };
