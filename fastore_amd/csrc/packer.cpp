@@ -107,13 +107,42 @@ void ArchiveWriter::start(const std::string& prefix, const BinModuleConfigRaw& c
     conf_.quaParams.qvzOpts.D = cfg.quaParams.qvzOpts.D;    // the two char* members are process-local garbage: left null
     static const uint8_t zeros[24] = {0};
     fwrite(zeros, 1, 24, meta_);
+    nStreams_ = cfg.archiveType.readType == READ_PE ? 23u : 15u; hasHeaders_ = cfg.archiveType.readsHaveHeaders != 0;
+    rawSignature_ = 1u << (2 * cfg.minimizer.signatureLen);
 }
 
 void ArchiveWriter::writeBlock(const uint8_t* data, uint64_t size, uint32_t signature)
 {
     sizes_.push_back(size); sigs_.push_back(signature);
+    {   // -v statistics from the block's own header (big-endian u64s behind the 34 fixed bytes [+ raw id size])
+        auto be8 = [&](uint64_t off) { uint64_t v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | data[off + i]; return v; };
+        const uint64_t base = 34 + (hasHeaders_ ? 8 : 0);
+        if (signature == rawSignature_) {
+            if (size >= 74) { haveRaw_ = true; rawComp_[0] = be8(base); rawComp_[1] = be8(base + 8); if (hasHeaders_) { rawComp_[2] = be8(base + 16); rawComp_[3] = be8(base + 24); } }
+        } else if (size >= base + 16ull * nStreams_) {
+            if (streamComp_.size() < nStreams_) streamComp_.resize(nStreams_, 0);
+            for (uint32_t i = 0; i < nStreams_; ++i) streamComp_[i] += be8(base + 8ull * nStreams_ + 8ull * i);
+        }
+    }
     if (fwrite(data, 1, size, data_) != size) throw std::runtime_error("Cannot write .cdata");
     dataBytes_ += size;
+}
+
+void ArchiveWriter::printStreamSizes(FILE* to) const
+{
+    // FastqWorkBuffersSE/PE::GetBufferNames (fastore_pack/CompressedBlockData.h:129-168)
+    static const char* const names[] = {"Flag", "LettersX", "Rev", "HardReads", "LzId", "Shift", "Match", "MatchBinary", "TreeShift", "CMatch", "CShift",
+                                        "CLetters", "Quality", "ReadIdToken", "ReadIdValue", "PE_Flag", "PE_LettersX", "PE_Swap", "PE_Hard", "PE_LzId",
+                                        "PE_Shift", "PE_MatchRLE", "PE_MatchBinary"};
+    fprintf(to, "\n");
+    if (!streamComp_.empty()) {
+        fprintf(to, "StreamSizes:\n");
+        for (uint32_t i = 0; i < streamComp_.size() && i < sizeof names / sizeof names[0]; ++i) fprintf(to, "%s %llu\n", names[i], (unsigned long long)streamComp_[i]);
+        fprintf(to, "NDna: %llu\nNQua: %llu\nNReadIdToken: %llu\nNReadIdValue: %llu\n\n", (unsigned long long)(haveRaw_ ? rawComp_[0] : 0), (unsigned long long)(haveRaw_ ? rawComp_[1] : 0),
+                (unsigned long long)(haveRaw_ ? rawComp_[2] : 0), (unsigned long long)(haveRaw_ ? rawComp_[3] : 0));
+    }
+    fprintf(to, "**** **** **** ****\n");
+    fflush(to);
 }
 
 void ArchiveWriter::finish(const HeaderStats& head, const QvzModel& qvz)
@@ -641,6 +670,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             if (!libs[l]->finished) { flush(*libs[l], true); libs[l]->aw.finish(archives[l].head, archives[l].qvz); }      // libraries without standard bins on this rank
             stats.cdata_bytes += libs[l]->aw.dataBytes();
         }
+        if (verbose) { fprintf(stderr, "\n"); for (size_t l = 0; l < nLibs; ++l) libs[l]->aw.printStreamSizes(stdout); }
         stats.io_ms += nowMs() - tio;
     } catch (...) {
         onHostTasksDone = nullptr;
@@ -661,7 +691,6 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
     }
     stats.total_ms += nowMs() - tStart;
     if (getenv("FS_TRACE")) fprintf(stderr, "[trace] packFiles total %.1f ms\n", nowMs() - tStart);
-    if (verbose) fprintf(stderr, "\n");
 }
 
 }  // namespace fs

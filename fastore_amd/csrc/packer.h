@@ -22,7 +22,12 @@ public:
     void writeBlock(const uint8_t* data, uint64_t size, uint32_t signature);
     void finish(const HeaderStats& head, const QvzModel& qvz);
     uint64_t dataBytes() const { return dataBytes_; }
+    // the reference's -v statistics (CompressorModule.cpp:357-387): compressed bytes per stream summed over the standard
+    // blocks (block header, FastqCompressor.cpp:1216-1219) and the four stream sizes of the raw block (:3592-3596)
+    void printStreamSizes(FILE* to) const;
 private:
+    std::vector<uint64_t> streamComp_; uint64_t rawComp_[4] = {0, 0, 0, 0}; bool haveRaw_ = false;
+    uint32_t nStreams_ = 0; bool hasHeaders_ = false; uint32_t rawSignature_ = 0;
     FILE *meta_ = nullptr, *data_ = nullptr;
     ArchiveConfigRaw conf_{};
     std::vector<uint64_t> sizes_;

@@ -31,6 +31,8 @@ make_one() {   # name reads len genome seed paired qflag headerflags
     for e in bmeta bdna bqua; do cp $T/$name.b8.$e $name.in.$e; done
     [ -f $T/$name.b8.bhead ] && cp $T/$name.b8.bhead $name.in.bhead
     cp $T/$name.ref.cdata $name.ref.cdata; cp $T/$name.ref.cmeta $name.ref.cmeta
+    # the reference's -v statistics on stdout (CompressorModule.cpp:357-387), for the two lossless fixtures
+    case $name in se_lossless|pe_lossless) $R pack -i$T/$name.b8 -o$T/$name.v -t1 -v $PACKFLAGS $pe > $name.ref.vout 2>/dev/null;; esac
 }
 #        name          reads len genome seed pe q  headers
 make_one se_lossless   9000  100 18000  11   0  0  "-H"

@@ -140,6 +140,7 @@ def test_cli_is_a_drop_in_for_fastore_pack_e(tmp_path):
     r = subprocess.run([cli, "e", "-i" + os.path.join(GOLDEN, name + ".in"), "-o" + str(tmp_path / "o"), "-t4", "-v"] + flags, capture_output=True)
     assert r.returncode == 0, r.stderr
     assert b"Parts processed" in r.stderr
+    assert open(os.path.join(GOLDEN, name + ".ref.vout"), "rb").read() in r.stdout      # the reference's -v statistics
     assert_same_archive(str(tmp_path / "o"), os.path.join(GOLDEN, name + ".ref"))
 
 

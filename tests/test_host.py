@@ -321,3 +321,14 @@ def test_merge_parts_of_rank_sharded_contexts(emu_lib, tmp_path):
     assert_same_archive(out, os.path.join(GOLDEN, name + ".ref"))
     with pytest.raises(fastore_amd.FastoreError, match="Cannot open"):
         fastore_amd.merge_parts(out, 3, lib=emu_lib)            # the parts are gone
+
+
+@pytest.mark.parametrize("name,paired", [("se_lossless", False), ("pe_lossless", True)])
+def test_cli_verbose_statistics_match_the_reference(tmp_path, name, paired):
+    # -v: "StreamSizes:" + compressed bytes per stream summed over the standard blocks + the raw block's four sizes
+    cli = os.path.join(ROOT, "build", "fastore_pack_emu")
+    flags = [f for n, p, f in manifest() if n == name][0]
+    r = subprocess.run([cli, "e", "-i" + os.path.join(GOLDEN, name + ".in"), "-o" + str(tmp_path / "o"), "-t3", "-v"] + flags + (["-z"] if paired else []), capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == open(os.path.join(GOLDEN, name + ".ref.vout"), "rb").read()
+    assert b"Parts processed" in r.stderr
