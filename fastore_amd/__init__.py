@@ -34,7 +34,7 @@ class Stats(C.Structure):
                 ("rc_symbols", C.c_uint64), ("ppmd_restarts", C.c_uint64), ("h2d_bytes", C.c_uint64),
                 ("d2h_bytes", C.c_uint64), ("bins", C.c_uint64), ("records", C.c_uint64),
                 ("algorithmic_bytes", C.c_uint64), ("block0_records", C.c_uint64), ("block0_bytes", C.c_uint64),
-                ("cdata_bytes", C.c_uint64)]
+                ("cdata_bytes", C.c_uint64), ("host_coded_symbols", C.c_uint64), ("host_coded_streams", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

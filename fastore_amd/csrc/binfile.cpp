@@ -4,6 +4,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <algorithm>
 #include <stdexcept>
 #include "bitio.h"
 
@@ -40,6 +41,7 @@ struct Unpacker {
     bool pe;
     Settings pairSettings;
     bool placed = false; uint64_t seqCur = 0, headCur = 0;
+    uint64_t seqEnd = 0, headEnd = 0;     // placed mode: the bin's own range of the shared arrays ends here (the next bin's begins)
     uint32_t recEnd = 0;     // one past the last record of the slice being read: group sizes in a damaged stream cannot walk past it
     uint32_t takeRec(uint32_t& recIdx) { if (recIdx >= recEnd) throw std::runtime_error("Corrupted bin: more records in the graph than in the footer"); return recIdx++; }
     void checkGroup(uint32_t groupSize, uint32_t recIdx, uint32_t slack) const { if ((uint64_t)groupSize > (uint64_t)(recEnd - recIdx) + slack) throw std::runtime_error("Corrupted bin: group larger than the bin"); }
@@ -89,7 +91,7 @@ struct Unpacker {
     void readHeader(Rec& r)
     {
         r.headLen = (uint8_t)head.getBits(8);
-        if (placed) { if (headCur + r.headLen > b.head.size()) throw std::runtime_error("bin footer understates the header bytes"); r.headOff = (uint32_t)headCur; headCur += r.headLen; }
+        if (placed) { if (headCur + r.headLen > headEnd) throw std::runtime_error("bin footer understates the header bytes"); r.headOff = (uint32_t)headCur; headCur += r.headLen; }
         else { r.headOff = (uint32_t)b.head.size(); b.head.resize(b.head.size() + r.headLen); }
         uint8_t* h = b.head.data() + r.headOff;
         if (r.headLen) h[0] = '@';
@@ -108,6 +110,8 @@ struct Unpacker {
             r.minimPos = (uint16_t)meta.getBits(8);
             minimPos = r.minimPos;
         } else if (!isMate2) { r.flags &= ~FLAG_REVERSE; r.minimPos = 0; }
+        // before any base is stored: the position comes from 8 untrusted bits
+        if (s.suffixLen != 0 && minimPos + s.suffixLen > len) throw std::runtime_error("Corrupted bin: signature position outside the read");
         readDna(b.seq.data() + seqOff, len, minimPos, s.suffixLen);
         readQuality(b.qua.data() + seqOff, len);
         if (s.usesHeaders) readHeader(r);
@@ -115,7 +119,7 @@ struct Unpacker {
     }
     uint32_t allocSeq(uint32_t n)
     {
-        if (placed) { if (seqCur + n > b.seq.size()) throw std::runtime_error("bin footer understates the bases"); const uint64_t o = seqCur; seqCur += n; return (uint32_t)o; }
+        if (placed) { if (seqCur + n > seqEnd) throw std::runtime_error("bin footer understates the bases"); const uint64_t o = seqCur; seqCur += n; return (uint32_t)o; }
         const uint64_t off = b.seq.size();
         if (off + n > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB of bases");
         b.seq.resize(off + n); b.qua.resize(off + n);
@@ -369,6 +373,9 @@ void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asN
 
     Unpacker u(cfg_, data, graph, bMeta_, mo, bDna_, dO, bQua_, qo, bHead_, ho);
     u.placed = placed; u.seqCur = seqBase; u.headCur = headBase;
+    // a placed bin owns exactly the footer's totals of the shared arrays; a footer that understates them must not spill
+    // into the neighbouring bin (another host thread is filling it)
+    u.seqEnd = std::min<uint64_t>(data.seq.size(), seqBase + bi.totalRawDnaSize); u.headEnd = std::min<uint64_t>(data.head.size(), headBase + bi.totalRawHeadSize);
     Settings s;
     s.signatureId = signature;
     if (signature != nSignature()) { s.suffixLen = cfg_.minimizer.signatureLen; generateMinimizer(cfg_.minimizer, signature, s.signature); }

@@ -337,6 +337,42 @@ int fsgpu_merge_parts(const char* outPrefix, uint32_t world, char* err, size_t e
     catch (...) { return fail("unknown error"); }
 }
 
+int fsgpu_print_stream_sizes(const char* outPrefix, char* err, size_t errLen)
+{
+    auto fail = [&](const std::string& m) { if (err && errLen) snprintf(err, errLen, "%s", m.c_str()); return (int)FSGPU_ERR_IO; };
+    if (!outPrefix) return fail("bad arguments");
+    FILE *fm = nullptr, *fd = nullptr;
+    try {
+        const std::string mname = std::string(outPrefix) + ".cmeta", dname = std::string(outPrefix) + ".cdata";
+        fm = fopen(mname.c_str(), "rb"); if (!fm) throw std::runtime_error("Cannot open file: " + mname);
+        uint64_t hdr[3] = {0, 0, 0};
+        if (fread(hdr, 1, 24, fm) != 24) throw std::runtime_error("Corrupted archive header");
+        if (hdr[1] < 4 || hdr[1] > (1ull << 34) || fseeko(fm, (off_t)hdr[0], SEEK_SET) != 0) throw std::runtime_error("Corrupted archive header");
+        std::vector<uint8_t> foot(hdr[1]);
+        if (fread(foot.data(), 1, foot.size(), fm) != foot.size()) throw std::runtime_error("Corrupted archive header");
+        fclose(fm); fm = nullptr;
+        uint32_t n = 0; memcpy(&n, foot.data(), 4);
+        if (4 + 12ull * n + sizeof(fs::ArchiveConfigRaw) > foot.size()) throw std::runtime_error("Corrupted archive header");
+        fs::ArchiveConfigRaw conf; memcpy(&conf, foot.data() + 4 + 12ull * n, sizeof conf);
+        if (conf.minParams.signatureLen == 0 || conf.minParams.signatureLen > 15) throw std::runtime_error("Corrupted archive header");
+        fs::StreamSizeStats st; st.start(conf.archType, conf.minParams);
+        fd = fopen(dname.c_str(), "rb"); if (!fd) throw std::runtime_error("Cannot open file: " + dname);
+        std::vector<uint8_t> head(std::max<uint64_t>(st.headerBytes(), 74));
+        uint64_t off = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            uint64_t size; uint32_t sig; memcpy(&size, foot.data() + 4 + 8ull * i, 8); memcpy(&sig, foot.data() + 4 + 8ull * n + 4ull * i, 4);
+            const size_t want = (size_t)std::min<uint64_t>(size, head.size());
+            if (fseeko(fd, (off_t)off, SEEK_SET) != 0 || fread(head.data(), 1, want, fd) != want) throw std::runtime_error("Cannot read " + dname);
+            st.addBlock(head.data(), size, sig);
+            off += size;
+        }
+        fclose(fd); fd = nullptr;
+        st.print(stdout);
+        return 0;
+    } catch (const std::exception& e) { if (fm) fclose(fm); if (fd) fclose(fd); return fail(e.what()); }
+    catch (...) { if (fm) fclose(fm); if (fd) fclose(fd); return fail("unknown error"); }
+}
+
 static int encodeStreams(fsgpu_ctx* ctx, size_t n, const uint32_t* kinds, const uint8_t* const* in, const size_t* inLen,
                          uint8_t* const* out, const size_t* outCap, size_t* outLen)
 {
@@ -386,7 +422,7 @@ int fsgpu_rc_encode(fsgpu_ctx* ctx, size_t n, const uint32_t* model, const uint8
 int fsgpu_pack_file(fsgpu_ctx* ctx, const char* inPrefix, const char* outPrefix, int verbose)
 {
     if (!ctx || !inPrefix || !outPrefix) return FSGPU_ERR_ARG;
-    FS_GUARD(ctx, ctx->c.packFiles({std::string(inPrefix)}, {std::string(outPrefix)}, verbose != 0));
+    FS_GUARD(ctx, ctx->c.packFiles({std::string(inPrefix)}, {std::string(outPrefix)}, verbose));
 }
 
 int fsgpu_pack_files(fsgpu_ctx* ctx, size_t n, const char* const* inPrefixes, const char* const* outPrefixes, int verbose)
@@ -395,7 +431,7 @@ int fsgpu_pack_files(fsgpu_ctx* ctx, size_t n, const char* const* inPrefixes, co
     FS_GUARD(ctx, {
         std::vector<std::string> a, b;
         for (size_t i = 0; i < n; ++i) { a.emplace_back(inPrefixes[i]); b.emplace_back(outPrefixes[i]); }
-        ctx->c.packFiles(a, b, verbose != 0);
+        ctx->c.packFiles(a, b, verbose);
     });
 }
 

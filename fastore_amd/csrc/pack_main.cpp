@@ -2,14 +2,19 @@
 // Keeps the reference's `fastore_pack e` surface (fastore_pack/main.cpp:26-41, 165-330): first
 // argument e|d, >= 3 arguments, -i<prefix> -o<prefix> -t<n> [-z] [-v] and the matcher/consensus
 // knobs; errors as "Error: <what>" on stderr with exit status 255.  `d` (decode) is outside this
-// build's scope: it is delegated to the reference binary when FASTORE_PACK_REF is set.
+// build's scope: the reference binary named by FASTORE_PACK_REF is started as a child process (never exec'ed over this
+// one: a process that may have initialised the GPU -- e.g. under a preloaded profiler -- must not be replaced).
 // New flags: -g<device> (HIP device ordinal), -j<n> (host threads beyond the reference's -t limit of 64),
 // -R<rank>/-N<world> (bin sharding: this process packs its share into <out>.part<rank>), -G<n> (one process, n GPUs:
 // devices g .. g+n-1 each pack their share of the bins side by side, then the parts are merged in -t1 order).
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <spawn.h>
+#include <sys/wait.h>
+#include <algorithm>
 #include <string>
 #include <thread>
 #include <vector>
@@ -32,12 +37,17 @@ int main(int argc, char** argv)
     if (argv[1][0] == 'd') {
         const char* ref = getenv("FASTORE_PACK_REF");
         if (!ref) { fprintf(stderr, "Error: decode mode is served by the reference fastore_pack; set FASTORE_PACK_REF to its path\n"); return 255; }
+        extern char** environ;
         argv[0] = (char*)ref;
-        execv(ref, argv);
-        perror("Error: execv"); return 255;
+        pid_t pid = 0;
+        const int rc = posix_spawn(&pid, ref, nullptr, nullptr, argv, environ);
+        if (rc != 0) { fprintf(stderr, "Error: cannot start %s: %s\n", ref, strerror(rc)); return 255; }
+        int status = 0;
+        while (waitpid(pid, &status, 0) < 0) { if (errno != EINTR) { perror("Error: waitpid"); return 255; } }
+        return WIFEXITED(status) ? WEXITSTATUS(status) : 255;
     }
     fsgpu_config cfg; fsgpu_config_defaults(&cfg);
-    std::string in, out; int verbose = 0; int threads = 0, hostThreads = -1, gpus = 1; bool pe = false;
+    std::string in, out; int verbose = 0; int threads = 0, hostThreads = -1, gpus = 1; bool pe = false, threadsGiven = false;
     for (int i = 2; i < argc; ++i) {
         const char* p = argv[i];
         if (p[0] != '-') continue;
@@ -47,7 +57,7 @@ int main(int argc, char** argv)
         switch (p[1]) {
         case 'i': in = p + 2; break;
         case 'o': out = p + 2; { size_t sp = out.find_first_of(" \n"); if (sp != std::string::npos) out = out.substr(0, sp); } break;
-        case 't': threads = v; break;
+        case 't': threads = v; threadsGiven = true; break;
         case 'v': verbose = 1; break;
         case 'z': pe = true; break;
         case 'f': cfg.min_bin_size = v; break;
@@ -68,12 +78,17 @@ int main(int argc, char** argv)
         case 'j': hostThreads = v; break;
         case 'R': cfg.rank = v; break;
         case 'N': cfg.world_size = v; break;
+        // accepted by the reference's parser, without effect on `e` with a binned input (QVZ training options of the bin
+        // stage, dry-run / FASTQ output of the decoder): said so instead of silently dropped
+        case 'U': case 'F': case 'M': case 'T': case 'D':
+            fprintf(stderr, "Warning: option -%c has no effect on the pack step and is ignored\n", p[1]); break;
         }
     }
     (void)pe;   // the read type is taken from the .bmeta config, as the reference effectively does for the data path
     if (in.empty()) { fprintf(stderr, "Error: no input file specified\n"); return 255; }
     if (out.empty()) { fprintf(stderr, "Error: no output file(s) specified\n"); return 255; }
-    if (threads < 0 || threads > 64) { fprintf(stderr, "Error: invalid number of threads specified\n"); return 255; }
+    // fastore_pack/main.cpp:326: 1 <= t <= 64 (no -t at all = this build's default, all cores)
+    if (threads < 0 || threads > 64 || (threadsGiven && threads == 0)) { fprintf(stderr, "Error: invalid number of threads specified\n"); return 255; }
     cfg.host_threads = hostThreads >= 0 ? (uint32_t)hostThreads : (uint32_t)threads;   // -j overrides -t (which keeps the reference's 1..64 range)
     if (gpus < 1 || gpus > 64) { fprintf(stderr, "Error: invalid number of devices specified\n"); return 255; }
     if (gpus > 1) {
@@ -81,19 +96,24 @@ int main(int argc, char** argv)
         std::vector<fsgpu_ctx*> ctxs(gpus, nullptr);
         for (int r = 0; r < gpus; ++r) {
             fsgpu_config c = cfg; c.device_id = cfg.device_id + r; c.rank = (uint32_t)r; c.world_size = (uint32_t)gpus;
-            if (c.host_threads) c.host_threads = (c.host_threads + gpus - 1) / gpus;
+            // the host cores are shared by the contexts: each gets its share of -t/-j, or of the machine
+            const uint32_t budget = c.host_threads ? c.host_threads : std::max(1u, std::thread::hardware_concurrency());
+            c.host_threads = std::max(1u, (budget + (uint32_t)gpus - 1) / (uint32_t)gpus);
             ctxs[r] = fsgpu_create(&c);
             if (!ctxs[r]) { fprintf(stderr, "Error: %s\n", fsgpu_create_error()); for (fsgpu_ctx* x : ctxs) if (x) fsgpu_destroy(x); return 255; }
         }
         std::vector<int> rcs(gpus, 0); std::vector<std::thread> th;
-        for (int r = 0; r < gpus; ++r) th.emplace_back([&, r]() { rcs[r] = fsgpu_pack_file(ctxs[r], in.c_str(), out.c_str(), r == 0 ? verbose : 0); });
+        // -v: progress from the first context only; the StreamSizes statistics are taken from the merged archive below
+        for (int r = 0; r < gpus; ++r) th.emplace_back([&, r]() { rcs[r] = fsgpu_pack_file(ctxs[r], in.c_str(), out.c_str(), (r == 0 && verbose) ? 2 : 0); });
         for (auto& t : th) t.join();
         int bad = -1; for (int r = 0; r < gpus; ++r) if (rcs[r] != 0 && bad < 0) bad = r;
         if (bad >= 0) fprintf(stderr, "Error: %s\n", fsgpu_last_error(ctxs[bad]));
         for (fsgpu_ctx* x : ctxs) fsgpu_destroy(x);
-        if (bad >= 0) return 255;
+        auto dropParts = [&]() { for (int r = 0; r < gpus; ++r) { const std::string b = out + ".part" + std::to_string(r); remove((b + ".cdata").c_str()); remove((b + ".cmeta").c_str()); } };
+        if (bad >= 0) { dropParts(); return 255; }
         char err[256] = {0};
-        if (fsgpu_merge_parts(out.c_str(), (uint32_t)gpus, err, sizeof err) != 0) { fprintf(stderr, "Error: %s\n", err); return 255; }
+        if (fsgpu_merge_parts(out.c_str(), (uint32_t)gpus, err, sizeof err) != 0) { fprintf(stderr, "Error: %s\n", err); dropParts(); return 255; }
+        if (verbose && fsgpu_print_stream_sizes(out.c_str(), err, sizeof err) != 0) { fprintf(stderr, "Error: %s\n", err); return 255; }
         return 0;
     }
     fsgpu_ctx* ctx = fsgpu_create(&cfg);

@@ -94,41 +94,27 @@ void serializeHeaderFields(const HeaderStats& head, bool pairedEnd, std::vector<
 // ------------------------------------------------------------------------------------------------
 ArchiveWriter::~ArchiveWriter() { if (meta_) fclose(meta_); if (data_) fclose(data_); }
 
-void ArchiveWriter::start(const std::string& prefix, const BinModuleConfigRaw& cfg)
+void StreamSizeStats::start(const ArchiveTypeRaw& type, const MinimizerParametersRaw& mp)
 {
-    meta_ = fopen((prefix + ".cmeta").c_str(), "wb");
-    data_ = fopen((prefix + ".cdata").c_str(), "wb");
-    if (!meta_ || !data_) throw std::runtime_error("Cannot open file: " + prefix + ".cmeta/.cdata");
-    memset(&conf_, 0, sizeof conf_);                       // padding bytes are zero here (stack garbage in the reference)
-    conf_.archType = cfg.archiveType; conf_.minParams = cfg.minimizer;
-    conf_.quaParams.method = cfg.quaParams.method; conf_.quaParams.binaryThreshold = cfg.quaParams.binaryThreshold;
-    conf_.quaParams.qvzOpts.verbose = cfg.quaParams.qvzOpts.verbose; conf_.quaParams.qvzOpts.stats = cfg.quaParams.qvzOpts.stats;
-    conf_.quaParams.qvzOpts.uncompressed = cfg.quaParams.qvzOpts.uncompressed; conf_.quaParams.qvzOpts.distortion = cfg.quaParams.qvzOpts.distortion;
-    conf_.quaParams.qvzOpts.D = cfg.quaParams.qvzOpts.D;    // the two char* members are process-local garbage: left null
-    static const uint8_t zeros[24] = {0};
-    fwrite(zeros, 1, 24, meta_);
-    nStreams_ = cfg.archiveType.readType == READ_PE ? 23u : 15u; hasHeaders_ = cfg.archiveType.readsHaveHeaders != 0;
-    rawSignature_ = 1u << (2 * cfg.minimizer.signatureLen);
+    nStreams_ = type.readType == READ_PE ? 23u : 15u; hasHeaders_ = type.readsHaveHeaders != 0;
+    rawSignature_ = 1u << (2 * mp.signatureLen);
+    streamComp_.clear(); haveRaw_ = false; memset(rawComp_, 0, sizeof rawComp_);
 }
 
-void ArchiveWriter::writeBlock(const uint8_t* data, uint64_t size, uint32_t signature)
+void StreamSizeStats::addBlock(const uint8_t* data, uint64_t size, uint32_t signature)
 {
-    sizes_.push_back(size); sigs_.push_back(signature);
-    {   // -v statistics from the block's own header (big-endian u64s behind the 34 fixed bytes [+ raw id size])
-        auto be8 = [&](uint64_t off) { uint64_t v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | data[off + i]; return v; };
-        const uint64_t base = 34 + (hasHeaders_ ? 8 : 0);
-        if (signature == rawSignature_) {
-            if (size >= 74) { haveRaw_ = true; rawComp_[0] = be8(base); rawComp_[1] = be8(base + 8); if (hasHeaders_) { rawComp_[2] = be8(base + 16); rawComp_[3] = be8(base + 24); } }
-        } else if (size >= base + 16ull * nStreams_) {
-            if (streamComp_.size() < nStreams_) streamComp_.resize(nStreams_, 0);
-            for (uint32_t i = 0; i < nStreams_; ++i) streamComp_[i] += be8(base + 8ull * nStreams_ + 8ull * i);
-        }
+    // big-endian u64s behind the 34 fixed bytes [+ raw id size]
+    auto be8 = [&](uint64_t off) { uint64_t v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | data[off + i]; return v; };
+    const uint64_t base = 34 + (hasHeaders_ ? 8 : 0);
+    if (signature == rawSignature_) {
+        if (size >= 74) { haveRaw_ = true; rawComp_[0] = be8(base); rawComp_[1] = be8(base + 8); if (hasHeaders_) { rawComp_[2] = be8(base + 16); rawComp_[3] = be8(base + 24); } }
+    } else if (size >= base + 16ull * nStreams_) {
+        if (streamComp_.size() < nStreams_) streamComp_.resize(nStreams_, 0);
+        for (uint32_t i = 0; i < nStreams_; ++i) streamComp_[i] += be8(base + 8ull * nStreams_ + 8ull * i);
     }
-    if (fwrite(data, 1, size, data_) != size) throw std::runtime_error("Cannot write .cdata");
-    dataBytes_ += size;
 }
 
-void ArchiveWriter::printStreamSizes(FILE* to) const
+void StreamSizeStats::print(FILE* to) const
 {
     // FastqWorkBuffersSE/PE::GetBufferNames (fastore_pack/CompressedBlockData.h:129-168)
     static const char* const names[] = {"Flag", "LettersX", "Rev", "HardReads", "LzId", "Shift", "Match", "MatchBinary", "TreeShift", "CMatch", "CShift",
@@ -145,30 +131,61 @@ void ArchiveWriter::printStreamSizes(FILE* to) const
     fflush(to);
 }
 
+void ArchiveWriter::start(const std::string& prefix, const BinModuleConfigRaw& cfg)
+{
+    prefix_ = prefix;
+    meta_ = fopen((prefix + ".cmeta").c_str(), "wb");
+    data_ = fopen((prefix + ".cdata").c_str(), "wb");
+    if (!meta_ || !data_) throw std::runtime_error("Cannot open file: " + prefix + ".cmeta/.cdata");
+    memset(&conf_, 0, sizeof conf_);                       // padding bytes are zero here (stack garbage in the reference)
+    conf_.archType = cfg.archiveType; conf_.minParams = cfg.minimizer;
+    conf_.quaParams.method = cfg.quaParams.method; conf_.quaParams.binaryThreshold = cfg.quaParams.binaryThreshold;
+    conf_.quaParams.qvzOpts.verbose = cfg.quaParams.qvzOpts.verbose; conf_.quaParams.qvzOpts.stats = cfg.quaParams.qvzOpts.stats;
+    conf_.quaParams.qvzOpts.uncompressed = cfg.quaParams.qvzOpts.uncompressed; conf_.quaParams.qvzOpts.distortion = cfg.quaParams.qvzOpts.distortion;
+    conf_.quaParams.qvzOpts.D = cfg.quaParams.qvzOpts.D;    // the two char* members are process-local garbage: left null
+    static const uint8_t zeros[24] = {0};
+    if (fwrite(zeros, 1, 24, meta_) != 24) throw std::runtime_error("Cannot write " + prefix_ + ".cmeta");
+    sizeStats_.start(cfg.archiveType, cfg.minimizer);
+}
+
+void ArchiveWriter::writeBlock(const uint8_t* data, uint64_t size, uint32_t signature)
+{
+    sizes_.push_back(size); sigs_.push_back(signature);
+    sizeStats_.addBlock(data, size, signature);
+    if (fwrite(data, 1, size, data_) != size) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
+    dataBytes_ += size;
+}
+
+// every write is checked: a full disk must end in "Error: Cannot write ..." (FSGPU_ERR_IO), not in a truncated archive
 void ArchiveWriter::finish(const HeaderStats& head, const QvzModel& qvz)
 {
+    const std::string what = "Cannot write " + prefix_ + ".cmeta";
+    auto put = [&](const void* p, size_t n) { if (n && fwrite(p, 1, n, meta_) != n) throw std::runtime_error(what); };
     const uint64_t footerOffset = 24;
     const uint32_t count = (uint32_t)sizes_.size();
-    fwrite(&count, 4, 1, meta_);
-    fwrite(sizes_.data(), 8, sizes_.size(), meta_);
-    fwrite(sigs_.data(), 4, sigs_.size(), meta_);
-    fwrite(&conf_, sizeof conf_, 1, meta_);
+    put(&count, 4);
+    put(sizes_.data(), 8 * sizes_.size());
+    put(sigs_.data(), 4 * sigs_.size());
+    put(&conf_, sizeof conf_);
     // quality data first, then the read-id field table (ArchiveFile.cpp:126-150)
     if (conf_.quaParams.method == MET_QVZ) {
         if (!qvz.present) throw std::runtime_error("QVZ archive without its codebook");
-        fwrite(qvz.footerBytes.data(), 1, qvz.footerBytes.size(), meta_);
+        put(qvz.footerBytes.data(), qvz.footerBytes.size());
     }
     if (conf_.archType.readsHaveHeaders) {
         std::vector<uint8_t> blob;
         serializeHeaderFields(head, conf_.archType.readType == READ_PE, blob);
-        fwrite(blob.data(), 1, blob.size(), meta_);
+        put(blob.data(), blob.size());
     }
-    const uint64_t end = (uint64_t)ftello(meta_);
-    const uint64_t footerSize = end - footerOffset;
-    fseeko(meta_, 0, SEEK_SET);
-    fwrite(&footerOffset, 8, 1, meta_); fwrite(&footerSize, 8, 1, meta_);
-    fclose(meta_); meta_ = nullptr;
-    fclose(data_); data_ = nullptr;
+    const off_t endPos = ftello(meta_);
+    if (endPos < 0) throw std::runtime_error(what);
+    const uint64_t footerSize = (uint64_t)endPos - footerOffset;
+    if (fseeko(meta_, 0, SEEK_SET) != 0) throw std::runtime_error(what);
+    put(&footerOffset, 8); put(&footerSize, 8);
+    FILE* m = meta_; meta_ = nullptr;
+    if (fclose(m) != 0) throw std::runtime_error(what);
+    FILE* d = data_; data_ = nullptr;
+    if (fclose(d) != 0) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -497,7 +514,7 @@ void Context::compressRawBlock(Batch& batch, const ArchiveParams& arch, std::vec
 }
 
 // ------------------------------------------------------------------------------------------------
-void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::vector<std::string>& outPrefixes, bool verbose)
+void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::vector<std::string>& outPrefixes, int verbose)
 {
     const double tStart = nowMs();
     const size_t nLibs = inPrefixes.size();
@@ -670,7 +687,8 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             if (!libs[l]->finished) { flush(*libs[l], true); libs[l]->aw.finish(archives[l].head, archives[l].qvz); }      // libraries without standard bins on this rank
             stats.cdata_bytes += libs[l]->aw.dataBytes();
         }
-        if (verbose) { fprintf(stderr, "\n"); for (size_t l = 0; l < nLibs; ++l) libs[l]->aw.printStreamSizes(stdout); }
+        if (verbose) fprintf(stderr, "\n");
+        if (verbose == 1) for (size_t l = 0; l < nLibs; ++l) libs[l]->aw.printStreamSizes(stdout);
         stats.io_ms += nowMs() - tio;
     } catch (...) {
         onHostTasksDone = nullptr;

@@ -14,6 +14,20 @@
 
 namespace fs {
 
+// the reference's -v statistics (CompressorModule.cpp:357-387): compressed bytes per stream summed over the standard
+// blocks (block header, FastqCompressor.cpp:1216-1219) and the four stream sizes of the raw block (:3592-3596), read
+// from the blocks' own headers -- so they can be taken from a finished archive as well (merged multi-GPU parts)
+class StreamSizeStats {
+public:
+    void start(const ArchiveTypeRaw& type, const MinimizerParametersRaw& mp);
+    void addBlock(const uint8_t* header, uint64_t size, uint32_t signature);     // `header`: at least min(size, headerBytes()) bytes of the block
+    uint64_t headerBytes() const { return 34 + (hasHeaders_ ? 8 : 0) + 16ull * nStreams_; }
+    void print(FILE* to) const;
+private:
+    std::vector<uint64_t> streamComp_; uint64_t rawComp_[4] = {0, 0, 0, 0}; bool haveRaw_ = false;
+    uint32_t nStreams_ = 0; bool hasHeaders_ = false; uint32_t rawSignature_ = 0;
+};
+
 // .cmeta/.cdata writer: ArchiveFileWriter (fastore_pack/ArchiveFile.cpp:21-204)
 class ArchiveWriter {
 public:
@@ -22,12 +36,10 @@ public:
     void writeBlock(const uint8_t* data, uint64_t size, uint32_t signature);
     void finish(const HeaderStats& head, const QvzModel& qvz);
     uint64_t dataBytes() const { return dataBytes_; }
-    // the reference's -v statistics (CompressorModule.cpp:357-387): compressed bytes per stream summed over the standard
-    // blocks (block header, FastqCompressor.cpp:1216-1219) and the four stream sizes of the raw block (:3592-3596)
-    void printStreamSizes(FILE* to) const;
+    void printStreamSizes(FILE* to) const { sizeStats_.print(to); }
 private:
-    std::vector<uint64_t> streamComp_; uint64_t rawComp_[4] = {0, 0, 0, 0}; bool haveRaw_ = false;
-    uint32_t nStreams_ = 0; bool hasHeaders_ = false; uint32_t rawSignature_ = 0;
+    StreamSizeStats sizeStats_;
+    std::string prefix_;
     FILE *meta_ = nullptr, *data_ = nullptr;
     ArchiveConfigRaw conf_{};
     std::vector<uint64_t> sizes_;
@@ -70,7 +82,8 @@ struct Context {
     // merged small bins + N bin (batch with ONE bin, records already in stored order): RawCompressorSE/PE
     void compressRawBlock(Batch& batch, const ArchiveParams& arch, std::vector<uint8_t>& out) const;
     // `fastore_pack e` for one or several libraries; bins of all libraries share the device batches
-    void packFiles(const std::vector<std::string>& inPrefixes, const std::vector<std::string>& outPrefixes, bool verbose);
+    // verbose: 0 quiet, 1 = the reference's -v (progress on stderr, StreamSizes on stdout), 2 = progress only
+    void packFiles(const std::vector<std::string>& inPrefixes, const std::vector<std::string>& outPrefixes, int verbose);
 };
 
 void parseHeaderFields(const uint8_t* p, size_t n, bool pairedEnd, HeaderStats& out);

@@ -934,6 +934,7 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
         }
         if (FS_UNI(stop)) break;
         const uint32_t succ = FS_UNI(m.fsSucc);
+        FS_SYMHOOK(prevCtx, MinContext, mc, m, succ);
         if (FS_UNI((uint32_t)m.OrderFall) == 0 && succ >= FS_UNI(m.UnitsStart)) { FS_PATH(g_path[7]); m.MaxContext = succ; keep = (succ == MinContext) ? 1u : 0u; }
         else { UpdateModel(m, MinContext, mc, FS_UNI(sufCtx) != 0 && FS_UNI(sufCtx) == FS_UNI(mc.suff), sufRec); if (FS_UNI(m.EscCount) == 0) clear_mask(m); }
         rc_normalize(m); MinContext = m.MaxContext;

@@ -62,6 +62,10 @@
   #define FS_REGION(id) ((void)0)
 #endif
 
+#if !defined(FS_SYMHOOK)
+  #define FS_SYMHOOK(firstCtx, lastCtx, rec, coder, succ) ((void)0)      // design-study hook (tools/ppmd_windows.cpp)
+#endif
+
 typedef FS_GLOBAL uint8_t* fs_gptr;                 // device: global address space; host: plain pointer
 typedef const FS_GLOBAL uint8_t* fs_cgptr;
 typedef const FS_GLOBAL uint16_t* fs_cgptr16;

@@ -97,6 +97,9 @@ typedef struct fsgpu_stats {
     uint64_t h2d_bytes, d2h_bytes;
     uint64_t bins, records, algorithmic_bytes;      /* 2*(seq+aux)+head per record + block bytes */
     uint64_t block0_records, block0_bytes, cdata_bytes;
+    /* standard-bin PPMd streams that the scheduler gave to idle host cores (same coder core, one lane -- what block 0
+     * always does) because they were predicted to outlast the balanced device step; 0 unless host_residue is enabled */
+    uint64_t host_coded_symbols, host_coded_streams;
 } fsgpu_stats;
 
 void fsgpu_config_defaults(fsgpu_config* cfg);
@@ -139,7 +142,7 @@ int fsgpu_qvz_encode(fsgpu_ctx* ctx, const uint8_t* qvz_footer, size_t qvz_foote
 
 /* Whole `fastore_pack e -i<in_prefix> -o<out_prefix>`: reads .bmeta/.bdna/.bqua/.bhead, writes
  * .cmeta/.cdata in the reference's -t1 block order. */
-int fsgpu_pack_file(fsgpu_ctx* ctx, const char* in_prefix, const char* out_prefix, int verbose);
+int fsgpu_pack_file(fsgpu_ctx* ctx, const char* in_prefix, const char* out_prefix, int verbose /* 0 quiet, 1 = -v, 2 = progress line only */);
 
 /* The same for n libraries at once: their bins share the device batches (more independent streams in
  * flight per launch), each library gets its own archive. */
@@ -165,6 +168,11 @@ const uint8_t* fsgpu_library_quality_codebook(const fsgpu_library* lib, size_t* 
  * Host only.  The multi-process form of the same exchange (all-gather of sizes over RCCL) is fastore_amd/shard.py.
  * Returns 0 or a negative FSGPU_ERR_*; the message goes to `err` (may be NULL). */
 int fsgpu_merge_parts(const char* out_prefix, uint32_t world_size, char* err, size_t err_len);
+
+/* The reference's -v statistics (`StreamSizes:` ... on stdout, fastore_pack/CompressorModule.cpp:357-387) of a finished
+ * archive <out_prefix>.{cmeta,cdata}, summed from the block headers -- what `fastore_pack e -v -G<n>` prints after the
+ * merge.  Host only. */
+int fsgpu_print_stream_sizes(const char* out_prefix, char* err, size_t err_len);
 
 int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out);   /* cumulative since fsgpu_reset_stats() */
 int fsgpu_reset_stats(fsgpu_ctx* ctx);

@@ -145,7 +145,7 @@ def test_cli_is_a_drop_in_for_fastore_pack_e(tmp_path):
 
 
 @pytest.mark.skipif(not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)), reason="reference binaries (oracle/_ref) not shipped")
-@pytest.mark.parametrize("paired,q,reads", [(False, 0, 120000), (True, 0, 60000), (False, 2, 60000), (False, 3, 40000), (True, 3, 60000)])
+@pytest.mark.parametrize("paired,q,reads", [(False, 0, 120000), (True, 0, 60000), (False, 2, 60000), (True, 2, 60000), (False, 3, 40000), (True, 3, 60000)])
 def test_gpu_pack_equals_live_reference_on_fresh_library(tmp_path, paired, q, reads):
     import fastore_amd
     t = str(tmp_path)
@@ -219,3 +219,71 @@ def test_gpu_libraries_larger_than_a_device_batch(tmp_path):
         p.pack_files(ins, outs)
         for (name, _, _), o in zip(fx, outs):
             assert open(o + ".cdata", "rb").read() == open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)), reason="reference binaries (oracle/_ref) not shipped")
+@pytest.mark.parametrize("paired,reads", [(False, 5_000_000), (True, 1_500_000)])
+def test_gpu_pack_equals_live_reference_on_a_library_with_long_streams(tmp_path, paired, reads):
+    # BASELINE-shaped bins: a 5 M-read SE library has bins of > 20 000 reads (quality streams of > 3 M PPMd symbols), a
+    # 1.5 M-pair PE library quality streams of > 2 M symbols (both mates in one stream) -- the tail of a device step.
+    # The reference runs multi-threaded here (its block order then differs), so blocks are compared by signature and the
+    # product's own order is checked against the -t1 rule (block 0, then ascending signature).
+    import fastore_amd
+    from conftest import reference_blocks
+    t = str(tmp_path)
+    cores = len(os.sched_getaffinity(0))
+    binned, pe = ref_pipeline(t, "big", reads, 150, (2 if paired else 1) * reads * 150 // 50, 8, paired, 0, threads=min(16, cores))
+    for f in os.listdir(t):
+        if f.endswith(".fastq") or ".b0." in f or ".b2." in f or ".b4." in f:
+            os.remove(os.path.join(t, f))
+    flags = ["-r", "-f256", "-c10", "-d8", "-w1024", "-W1024"]
+    subprocess.check_call([REF_DRIVER, "pack", "-i" + binned, "-o" + os.path.join(t, "ref"), "-t%d" % min(16, cores)] + flags + pe)
+    with fastore_amd.Packer(device_id=0) as p:
+        st = p.pack_file(binned, os.path.join(t, "gpu"))
+    want = reference_blocks(os.path.join(t, "ref")); got = reference_blocks(os.path.join(t, "gpu"))
+    assert sorted(want) == sorted(got)
+    for sg in want:
+        assert got[sg] == want[sg], "block of signature %d differs" % sg
+    import struct
+    m = open(os.path.join(t, "gpu.cmeta"), "rb").read(); foff, _ = struct.unpack_from("<QQ", m, 0); n, = struct.unpack_from("<I", m, foff)
+    sigs = list(struct.unpack_from("<%dI" % n, m, foff + 4 + 8 * n))
+    assert sigs[0] == max(sigs) and sigs[1:] == sorted(sigs[1:])
+    # the longest quality stream of the library: records of the largest standard block x 150 (x 2 mates)
+    biggest = max(struct.unpack_from(">Q", b, 4)[0] for sg, b in got.items() if sg != max(sigs))
+    assert biggest * 150 * (2 if paired else 1) > (2 << 20), biggest
+    assert st["host_coded_symbols"] == 0          # everything above ran on the device (host_residue is off by default)
+
+
+def test_gpu_rank_sharded_pack_on_one_device(tmp_path):
+    # the multi-GPU path (fsgpu_config.rank/world_size + fsgpu_merge_parts), both ranks on device 0 one after the other:
+    # the merged archive must be the single-writer archive, for SE and PE and an odd world size
+    import fastore_amd
+    for (name, paired, flags), world in zip(manifest()[:2], (2, 3)):
+        out = str(tmp_path / ("s_" + name))
+        records = 0
+        for r in range(world):
+            with fastore_amd.Packer(device_id=0, rank=r, world_size=world, **knobs_from_flags(flags)) as p:
+                st = p.pack_file(os.path.join(GOLDEN, name + ".in"), out)
+                records += st["records"] + st["block0_records"]
+                assert st["bins"] > 0
+        fastore_amd.merge_parts(out, world)
+        assert_same_archive(out, os.path.join(GOLDEN, name + ".ref"))
+        assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+
+
+def test_gpu_cli_two_contexts_on_one_box(tmp_path):
+    # `fastore_pack e -G2` needs two devices; on a one-GPU box the same code path is driven with -R/-N + merge
+    import fastore_amd
+    cli = os.path.join(ROOT, "fastore_amd", "fastore_pack")
+    name, paired, flags = manifest()[0]
+    lib = fastore_amd.load_library()
+    out = str(tmp_path / "o")
+    if lib.fsgpu_device_count() >= 2:
+        r = subprocess.run([cli, "e", "-i" + os.path.join(GOLDEN, name + ".in"), "-o" + out, "-G2", "-v"] + flags, capture_output=True)
+        assert r.returncode == 0, r.stderr
+        assert open(os.path.join(GOLDEN, name + ".ref.vout"), "rb").read() in r.stdout
+    else:
+        for r in range(2):
+            assert subprocess.run([cli, "e", "-i" + os.path.join(GOLDEN, name + ".in"), "-o" + out, "-R%d" % r, "-N2"] + flags).returncode == 0
+        fastore_amd.merge_parts(out, 2)
+    assert_same_archive(out, os.path.join(GOLDEN, name + ".ref"))
