@@ -25,7 +25,9 @@ enum : uint32_t { TOP = 1u << 24, BOT = 1u << 15 };
 constexpr int32_t INIT_RL = -4;      // InitRL of an order-4 model (the value StartModelRare computes from MaxOrder)
 enum : uint32_t { SA_SIZE = 16u << 20, MAX_ORDER = 4,
                   // list heads BList[0..N_INDEXES] + one scratch head live behind the heap proper
-                  HEADS_OFF = SA_SIZE + 64u, ARENA_BYTES = HEADS_OFF + 12u * (N_INDEXES + 2) + 16u };
+                  HEADS_OFF = SA_SIZE + 64u,
+                  // hint table of the windowed hit path (ppmd_window.h): 2^16 entries {last four bytes, context index}
+                  HINT_OFF = (HEADS_OFF + 12u * (N_INDEXES + 2) + 16u + 63u) & ~63u, ARENA_BYTES = HINT_OFF + (8u << 16) };
 
 #if defined(__HIP_DEVICE_COMPILE__)
   #define FS_TABLE __constant__ static const
@@ -62,6 +64,7 @@ struct Shared {
     uint8_t CharMask[256];
     uint8_t QT[260];             // QTable, tabulated once per wave
     uint32_t GlueCount, GlueCount1, restarts;   // touched only by the allocator's rare paths / model restarts: kept out of the registers
+    uint32_t winStats[8];        // windowed hit path: attempts, windows, symbols covered, rounds, redone windows
 };
 
 // the three words of a context record as fetched (per-lane values, fetch still in flight): issue early, finish at first use
@@ -137,6 +140,7 @@ FS_DEV CtxRaw ctx_issue(Coder& m, uint32_t c)
     fs_cgptr32 q = (fs_cgptr32)HP(c);
     CtxRaw r;
     r.a = q[0]; r.b = q[1]; r.d = q[2];
+    FS_EMU_MEET();
     return r;
 }
 FS_DEV Ctx ctx_finish(const CtxRaw& x)
@@ -153,6 +157,7 @@ FS_DEV St st_load(Coder& m, uint32_t s)
     FS_CNT(g_ld[1]);
     fs_cgptr16 q = (fs_cgptr16)HP(s);
     uint32_t a = q[0], b = q[1], c = q[2];
+    FS_EMU_MEET();
     a = FS_UNI(a); b = FS_UNI(b); c = FS_UNI(c);
     St r; r.sym = a & 0xFFu; r.freq = a >> 8; r.succ = b | (c << 16);
     return r;
@@ -209,7 +214,7 @@ FS_DEV_NOINLINE void GlueFreeBlocks(Coder& m)
         if (kIndx2Units[i = kUnits2Indx[sz - 1]] != sz) { k = sz - kIndx2Units[--i]; blk_insert(m, BL(k - 1), p + 12u * (sz - k), k); }
         blk_insert(m, BL(i), p, kIndx2Units[i]);
     }
-    { const uint32_t g1 = FS_UNI(m.sh->GlueCount1); m.sh->GlueCount = 1u << (13 + g1); m.sh->GlueCount1 = g1 + 1u; }
+    { const uint32_t g1 = FS_LDS_RD(m.sh->GlueCount1); m.sh->GlueCount = 1u << (13 + g1); m.sh->GlueCount1 = g1 + 1u; }
 }
 
 FS_DEV_NOINLINE uint32_t AllocUnitsRare(Coder& m, uint32_t indx)
@@ -218,7 +223,7 @@ FS_DEV_NOINLINE uint32_t AllocUnitsRare(Coder& m, uint32_t indx)
     uint32_t i = indx;
     do {
         if (++i == N_INDEXES) {
-            const uint32_t gc = FS_UNI(m.sh->GlueCount); m.sh->GlueCount = gc - 1u;
+            const uint32_t gc = FS_LDS_RD(m.sh->GlueCount); m.sh->GlueCount = gc - 1u;
             if (!gc) {
                 GlueFreeBlocks(m);
                 if (blk_avail(m, BL(i = indx))) return blk_remove(m, BL(i));
@@ -326,7 +331,7 @@ FS_DEV void StartModelRare(Coder& m)
     FS_WAVE_SYNC();
 }
 
-FS_DEV void RestoreModelRare(Coder& m) { m.pText = 1u; StartModelRare(m); m.EscCount = 0; m.sh->restarts = FS_UNI(m.sh->restarts) + 1u; }
+FS_DEV void RestoreModelRare(Coder& m) { m.pText = 1u; StartModelRare(m); m.EscCount = 0; m.sh->restarts = FS_LDS_RD(m.sh->restarts) + 1u; }
 
 // per-lane view of 64 consecutive states of a context: one fetch for the whole list
 struct LaneStates { uint32_t sf, succ; bool valid; };
@@ -340,6 +345,7 @@ FS_DEV LaneStates lane_states(Coder& m, uint32_t stats, uint32_t ns, uint32_t ba
     // lanes past the end re-read the last state: an unconditional fetch keeps this off the exec-masked path
     const uint32_t ii = r.valid ? i : ns;
     fs_cgptr16 q = (fs_cgptr16)HP(stats + 6u * ii); const uint32_t a = q[0], b = q[1], c = q[2];
+    FS_EMU_MEET();
     r.sf = r.valid ? a : 0u; r.succ = r.valid ? (b | (c << 16)) : 0u;
     return r;
 }
@@ -349,7 +355,7 @@ struct Hit { uint32_t p, freq, succ, prevSf, prevSucc; };
 FS_DEV Hit find_in(Coder& m, const Ctx& pc, uint32_t sym)
 {
     Hit h; h.p = pc.w1; h.freq = 0; h.succ = 0; h.prevSf = 0; h.prevSucc = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if FS_WIDE
     if (FS_UNI(pc.ns()) < FS_WAVE) {                          // the whole list in one fetch: no loop
         const LaneStates ls = lane_states(m, pc.w1, pc.ns(), 0);
         const uint64_t hit = fs_ballot(ls.valid && (ls.sf & 0xFFu) == sym);
@@ -486,7 +492,7 @@ FS_DEV_NOINLINE void rescale(Coder& m, uint32_t c)
     FS_PATH(g_path[11]);
     const uint32_t kf = (m.FoundState - stats) / 6u, a0 = (m.OrderFall != 0);
     uint32_t sumF, summ, zeros, f0, nf0, sym0, succ0; bool hiAny;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if FS_WIDE
     {
         const uint32_t i = (uint32_t)FS_LANE();
         const LaneStates ls = lane_states(m, stats, ns, 0);
@@ -699,7 +705,7 @@ FS_DEV void encodeBinSymbol(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufR
     sufRec = ctx_load(m, mc.suff); sufCtx = mc.suff;
     const uint32_t sufNs = sufRec.ns();
     const uint32_t idx = FS_UNI(m.sh->QT[mc.oneFreq() - 1]) * 64u + NS2BSIndx(sufNs) + m.PrevSuccess + mc.flags() + (uint32_t)((m.RunLength >> 26) & 0x20);
-    uint32_t bs = FS_UNI(m.sh->BinSumm[idx]);
+    uint32_t bs = FS_LDS_RD(m.sh->BinSumm[idx]);
     m.BSumm = (int32_t)bs;
     const uint32_t tmp = bs * (m.range >>= TOT_BITS);
     bs -= (bs + ROUND) >> PERIOD_BITS;
@@ -726,7 +732,7 @@ FS_DEV void encodeSymbol1(Coder& m, uint32_t c, Ctx& mc, int symbol)
     m.rScale = mc.sf();
     uint32_t LoCnt = 0, p = 0, k = 0, base = 0; bool found = false;
     LaneStates ls = lane_states(m, stats, ns, 0);
-#if defined(__HIP_DEVICE_COMPILE__)
+#if FS_WIDE
     if (FS_UNI(ns) < FS_WAVE) {                              // the usual case: the whole list is in the lanes, no loop
         const uint64_t hit = fs_ballot(ls.valid && (int)(ls.sf & 0xFFu) == symbol);
         if (hit != 0) { k = FS_UNI(fs_ctz64(hit)); if (k != 0) LoCnt = fs_wave_sum8(ls.sf >> 8, ls.valid && (uint32_t)FS_LANE() < k); p = stats + 6u * k; found = true; }
@@ -791,7 +797,7 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
     if (nsC != 0xFF) {
         const uint32_t sufNs = mc.suff ? sufRec.ns() : 0u;
         seeIdx = (FS_UNI(m.sh->QT[nsC + 3]) - 4u) * 32u + (mc.sf() > 10u * (nsC + 1u)) + 2u * (2u * nsC < sufNs + m.NumMasked) + mc.flags();
-        see = FS_UNI(m.sh->SEE2[seeIdx]);
+        see = FS_LDS_RD(m.sh->SEE2[seeIdx]);
         const uint32_t shift = (see >> 16) & 0xFFu; uint32_t summ = see & 0xFFFFu;
         const uint32_t r = summ >> shift; summ = (summ - r) & 0xFFFFu;
         see = (see & 0xFFFF0000u) | summ;
@@ -800,7 +806,7 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
     // unmasked states in list order, 64 per step
     const uint8_t esc = (uint8_t)m.EscCount;
     uint32_t LoCnt = 0, p = 0, fFound = 0, succ = 0, tail = 0; bool found = false;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if FS_WIDE
     if (FS_UNI(nsC) < FS_WAVE) {                             // the whole list is in the lanes: no loop
         const uint32_t sy = ls.sf & 0xFFu;
         const bool unmasked = ls.valid && m.sh->CharMask[sy] != esc;
@@ -869,6 +875,10 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
     m.EscCount = (m.EscCount + 1) & 0xFFu; m.RunLength = INIT_RL;
 }
 
+#if FS_WIDE
+#include "ppmd_window.h"
+#endif
+
 // Encode one member.  `arena` = ARENA_BYTES of 16-byte aligned scratch (content irrelevant),
 // returns the member size (clipped at outCap like the reference's ByteStream::Put).
 FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uint32_t n, fs_gptr out, uint32_t outCap,
@@ -877,6 +887,7 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
     Coder m;
     m.hb = arena - 1; m.sh = sh; m.out = out; m.outCap = outCap; m.outPos = 0; sh->restarts = 0;
     m.NumMasked = 0; m.FoundState = 0; m.BSumm = 0; m.rLow = m.rHigh = m.rScale = 0; m.fsSym = m.fsFreq = m.fsSucc = 0;
+    for (uint32_t i = (uint32_t)FS_LANE(); i < 8u; i += FS_WAVE) sh->winStats[i] = 0u;
     for (uint32_t i = (uint32_t)FS_LANE(); i < 260u; i += FS_WAVE) sh->QT[i] = (uint8_t)QTable(i);
     // zero the 64-byte guard behind the heap: GlueFreeBlocks may read one stamp past the end
     for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) *(fs_gptr32)(arena + SA_SIZE + 4u * i) = 0u;
@@ -892,7 +903,30 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
     uint32_t keep = 0, prevCtx = 0;
     Ctx sufRec = mc; uint32_t sufCtx = 0;
     m.pfCtx = 0; m.pf.a = m.pf.b = m.pf.d = 0;
+#if FS_WIDE
+    // windowed hit path: `hist` = the four bytes in front of `pos`; after a short window the next attempts are put off
+    // (winSkip serial symbols, doubling up to 64 while the windows stay short) so that unpredictable streams and the
+    // learning phase of a model pay next to nothing for it
+    uint32_t hist = 0, winSkip = 0, winPenalty = 0;
+    const bool windows = wide && n >= 64u;
+#endif
     for (uint32_t MinContext = m.MaxContext;;) {
+#if FS_WIDE
+        if (windows && FS_UNI((uint32_t)m.OrderFall) == 0u && FS_UNI(pos) >= 4u && FS_UNI(pos) < n) {
+            hint_learn(m, FS_UNI(hist), FS_UNI(MinContext));
+            if (FS_UNI(winSkip) != 0u) --winSkip;
+            else {
+                const uint32_t done = window_step(m, in, n, FS_UNI(pos), FS_UNI(MinContext), hist);
+                if (done >= 24u) winPenalty = 0; else { winPenalty = winPenalty >= 32u ? 64u : 2u * winPenalty + 1u; winSkip = winPenalty; }
+                if (done != 0u) {
+                    pos += done; MinContext = m.MaxContext; m.pfCtx = 0; keep = 0; prevCtx = 0;
+                    if ((pos & 3u) != 0u && (pos | 3u) < n) { cur = *(fs_cgptr32)(in + (pos & ~3u)); if ((pos & ~3u) + 8u <= n) nxt = *(fs_cgptr32)(in + (pos & ~3u) + 4u); }
+                    else if ((pos | 3u) < n) nxt = *(fs_cgptr32)(in + pos);
+                    continue;
+                }
+            }
+        }
+#endif
         int c = -1;
         if (FS_UNI(pos) < n) {
             if (wide && (FS_UNI(pos) | 3u) < n) {
@@ -900,6 +934,9 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
                 c = (int)((cur >> (8u * (pos & 3u))) & 0xFFu);
             } else c = (int)fs_ld8(in + pos);
             pos++;
+#if FS_WIDE
+            hist = (hist >> 8) | ((uint32_t)c << 24);
+#endif
         }
         // everything carried from symbol to symbol is wave-uniform by construction; saying so here keeps one value the
         // compiler could not prove uniform from turning the whole loop body into exec-masked (divergent) code

@@ -28,6 +28,7 @@
     #define FS_DEV_NOINLINE __device__ __forceinline__
   #endif
   #define FS_WAVE 64
+  #define FS_WIDE 1                                  // the 64-lane code paths (this build and the lock-step test emulation)
   #define FS_LANE() ((int)(threadIdx.x & 63))
   // make a loaded value wave-uniform (it already is by construction; this moves it to an SGPR)
   #define FS_UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
@@ -37,6 +38,28 @@
   #define FS_UB(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
   // order this wave's cooperative memory phase against the uniform code that follows it
   #define FS_WAVE_SYNC() __syncthreads()
+  #define FS_EMU_MEET() ((void)0)
+#elif defined(FS_SIMT_EMU)
+  // TEST-ONLY: the 64-lane code paths on the host, 64 fibers in lock step (tests/emu/simt.h).  Never in the product.
+  #include "../../tests/emu/simt.h"
+  #define FS_GLOBAL
+  #define FS_LDS
+  #define FS_DEV static inline
+  #define FS_DEV_M inline
+  #define FS_DEV_NOINLINE static
+  #define FS_WAVE 64
+  #define FS_WIDE 1
+  #define FS_LANE() (simt::lane())
+  #if defined(FS_SIMT_CHECK_UNIFORM)
+    #define FS_UNI(x) (simt::readfirst((uint32_t)(x)))       // slow: every assertion is a meeting point, and is checked
+  #else
+    #define FS_UNI(x) ((uint32_t)(x))
+  #endif
+  #define FS_UB(c) (c)
+  #define FS_WAVE_SYNC() simt::barrier()
+  // a store whose lanes write different data is a meeting point here (on the device the lanes execute the instruction
+  // together, so a later load by any lane sees all of it)
+  #define FS_EMU_MEET() simt::barrier()
 #else
   #define FS_GLOBAL
   #define FS_LDS
@@ -44,10 +67,12 @@
   #define FS_DEV_M inline
   #define FS_DEV_NOINLINE static
   #define FS_WAVE 1
+  #define FS_WIDE 0
   #define FS_LANE() 0
   #define FS_UNI(x) ((uint32_t)(x))
   #define FS_UB(c) (c)
   #define FS_WAVE_SYNC() ((void)0)
+  #define FS_EMU_MEET() ((void)0)
 #endif
 
 // host-only event counters for design studies (tools/ppmd_paths.cpp); compiled out everywhere else
@@ -74,11 +99,22 @@ typedef const FS_GLOBAL uint32_t* fs_cgptr32;
 typedef FS_GLOBAL uint32_t* fs_gptr32;
 
 // ---- uniform little-endian accessors on a byte heap (2-byte aligned addresses) ----
-FS_DEV uint32_t fs_ld8(fs_cgptr p) { FS_CNT(g_ld[3]); return FS_UNI(*p); }
-FS_DEV uint32_t fs_ld16(fs_cgptr p) { FS_CNT(g_ld[4]); return FS_UNI(*(fs_cgptr16)p); }
+// (FS_EMU_MEET after a load: in the lock-step test emulation every lane has read before any lane goes on to write the
+// same place -- what the device gives by executing the load for all lanes at once; nothing on the device)
+FS_DEV uint32_t fs_ld8(fs_cgptr p) { FS_CNT(g_ld[3]); const uint32_t v = *p; FS_EMU_MEET(); return FS_UNI(v); }
+FS_DEV uint32_t fs_ld16(fs_cgptr p) { FS_CNT(g_ld[4]); const uint32_t v = *(fs_cgptr16)p; FS_EMU_MEET(); return FS_UNI(v); }
 FS_DEV uint32_t fs_ld32h(fs_cgptr p)   // 32-bit value at a 2-byte aligned address
-{ FS_CNT(g_ld[6]); return FS_UNI((uint32_t)((fs_cgptr16)p)[0] | ((uint32_t)((fs_cgptr16)p)[1] << 16)); }
-FS_DEV uint32_t fs_ld32(fs_cgptr p) { FS_CNT(g_ld[5]); return FS_UNI(*(fs_cgptr32)p); }
+{ FS_CNT(g_ld[6]); const uint32_t v = (uint32_t)((fs_cgptr16)p)[0] | ((uint32_t)((fs_cgptr16)p)[1] << 16); FS_EMU_MEET(); return FS_UNI(v); }
+FS_DEV uint32_t fs_ld32(fs_cgptr p) { FS_CNT(g_ld[5]); const uint32_t v = *(fs_cgptr32)p; FS_EMU_MEET(); return FS_UNI(v); }
+// wave-uniform read of a word of the wave's LDS state that the wave also rewrites (adaptive tables, counters)
+#define FS_LDS_RD(x) fs_lds_rd((uint32_t)(x))
+FS_DEV uint32_t fs_lds_rd(uint32_t v) { FS_EMU_MEET(); return FS_UNI(v); }
+// statistics counter in LDS: every lane stores the same sum on the device; one lane counts in the emulation
+#if defined(FS_SIMT_EMU)
+  #define FS_STAT_ADD(w, x) do { if (FS_LANE() == 0) (w) += (x); } while (0)
+#else
+  #define FS_STAT_ADD(w, x) do { (w) = FS_UNI(w) + (x); } while (0)
+#endif
 // Uniform stores are executed by all lanes (same address, same value).  Issuing them from one lane was
 // measured: the same number of L1->L2 write requests and the same run time, but a divergent `if` per store, which
 // makes the compiler structurize the surrounding uniform control flow with exec masks (+14 % code).
@@ -89,9 +125,10 @@ FS_DEV void fs_st32(fs_gptr p, uint32_t v) { FS_CNT(g_st); *(fs_gptr32)p = v; }
 FS_DEV void fs_st32h(fs_gptr p, uint32_t v)
 {
     FS_CNT(g_st);
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_ST48)
+#if FS_WIDE && !defined(FS_NO_ST48)
     const uint32_t l = (uint32_t)FS_LANE();
     if (l < 2u) ((fs_gptr16)p)[l] = (uint16_t)(l ? v >> 16 : v);
+    FS_EMU_MEET();
 #else
     ((fs_gptr16)p)[0] = (uint16_t)v; ((fs_gptr16)p)[1] = (uint16_t)(v >> 16);
 #endif
@@ -100,9 +137,10 @@ FS_DEV void fs_st32h(fs_gptr p, uint32_t v)
 FS_DEV void fs_st48(fs_gptr p, uint32_t w0, uint32_t w1, uint32_t w2)
 {
     FS_CNT(g_st);
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(FS_NO_ST48)
+#if FS_WIDE && !defined(FS_NO_ST48)
     const uint32_t l = (uint32_t)FS_LANE();
     if (l < 3u) ((fs_gptr16)p)[l] = (uint16_t)(l == 0u ? w0 : (l == 1u ? w1 : w2));
+    FS_EMU_MEET();
 #else
     ((fs_gptr16)p)[0] = (uint16_t)w0; ((fs_gptr16)p)[1] = (uint16_t)w1; ((fs_gptr16)p)[2] = (uint16_t)w2;
 #endif
@@ -114,11 +152,20 @@ FS_DEV uint64_t fs_ballot(bool p) { return __ballot(p); }
 FS_DEV uint32_t fs_popc64(uint64_t x) { return (uint32_t)__popcll(x); }
 FS_DEV uint32_t fs_ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
 FS_DEV uint32_t fs_readlane(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+// value of `v` in lane `src` (per-lane source, any lane): ds_bpermute_b32
+FS_DEV uint32_t fs_bperm(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v); }
+#elif defined(FS_SIMT_EMU)
+FS_DEV uint64_t fs_ballot(bool p) { return simt::ballot(p); }
+FS_DEV uint32_t fs_popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
+FS_DEV uint32_t fs_ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
+FS_DEV uint32_t fs_readlane(uint32_t v, uint32_t lane) { return simt::readlane(v, lane); }
+FS_DEV uint32_t fs_bperm(uint32_t v, uint32_t src) { return simt::bperm(v, src); }
 #else
 FS_DEV uint64_t fs_ballot(bool p) { return p ? 1u : 0u; }
 FS_DEV uint32_t fs_popc64(uint64_t x) { return (uint32_t)__builtin_popcountll(x); }
 FS_DEV uint32_t fs_ctz64(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
 FS_DEV uint32_t fs_readlane(uint32_t v, uint32_t) { return v; }
+FS_DEV uint32_t fs_bperm(uint32_t v, uint32_t) { return v; }
 #endif
 // sum over the lanes with `pred` of a small value per lane: the DPP wave scan (row_shr 1/2/4/8 inside each row of 16,
 // then row_bcast:15 and row_bcast:31 carry the row totals on), total read from lane 63 -- 6 adds instead of the 8
@@ -134,6 +181,8 @@ FS_DEV uint32_t fs_wave_sum8(uint32_t v, bool pred)
     x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
     return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+#elif defined(FS_SIMT_EMU)
+    return simt::sum(v, pred);
 #else
     return pred ? v : 0u;
 #endif

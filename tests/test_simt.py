@@ -1,0 +1,82 @@
+"""The 64-lane code paths of the PPMd core (the ones the device runs: lane-parallel scans and the windowed hit path of
+ppmd_window.h) on the lock-step wave emulation of tests/emu/simt.h, against the oracle's C restatement.  No GPU needed:
+the same source is compiled with -DFS_SIMT_EMU and runs as 64 cooperative fibers."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, VECTORS, oracle_ppmd
+
+
+@pytest.fixture(scope="module")
+def simt():
+    out = os.path.join(ROOT, "build", "libsimt_emu.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU", "-shared", "-fPIC", "-o", out,
+                           os.path.join(ROOT, "tests", "emu", "ppmd_simt.cpp"), os.path.join(ROOT, "tests", "emu", "simt.cpp")])
+    lib = ctypes.CDLL(out)
+    lib.simt_ppmd_encode.restype = ctypes.c_size_t
+    lib.simt_ppmd_encode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    return lib
+
+
+def encode(lib, data):
+    buf = ctypes.create_string_buffer(2 * len(data) + 4096)
+    st = (ctypes.c_uint64 * 8)()
+    # the device batch pads every stream to 16 bytes: the window reads whole aligned words around the last symbols
+    n = lib.simt_ppmd_encode(data + b"\0" * 32, len(data), buf, len(buf), None, st)
+    return buf.raw[:n], {"attempts": st[0], "windows": st[1], "covered": st[2], "rounds": st[3], "redone": st[4]}
+
+
+def quality(n, seed, read_len=150):
+    rng = np.random.default_rng(seed)
+    steps = np.array([-3, -1, 0, 0, 0, 0, 1, 1])[rng.integers(0, 8, n)]
+    out = np.empty(n, np.uint8); cur = 38
+    for i in range(n):
+        if i % read_len == 0:
+            cur = 38
+        cur = min(40, max(2, cur + steps[i])); out[i] = cur
+    return out.tobytes()
+
+
+def test_windowed_hit_path_reproduces_the_serial_walk_on_quality_streams(simt, oracle):
+    data = quality(300_000, 1)
+    got, st = encode(simt, data)
+    assert got == oracle_ppmd(oracle, data)
+    # the path under test really ran: most of the stream went through windows, with shared contexts and redone windows
+    assert st["covered"] > 0.7 * len(data) and st["rounds"] > st["windows"] and st["redone"] > 0, st
+
+
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 100, 4097, 20_001])
+def test_window_edges_short_and_ragged_streams(simt, oracle, n):
+    for data in (quality(n, n, read_len=37), bytes([30]) * n, bytes([7, 9]) * (n // 2) + bytes([7]) * (n % 2)):
+        got, _ = encode(simt, data)
+        assert got == oracle_ppmd(oracle, data)
+
+
+def test_other_stream_kinds_through_the_64_lane_paths(simt, oracle):
+    rng = np.random.default_rng(3)
+    streams = {
+        "bases": rng.choice(np.frombuffer(b"ACGTN.", dtype=np.uint8), 60_000).tobytes(),
+        "flags": rng.integers(0, 9, 40_000).astype(np.uint8).tobytes(),
+        "noise": rng.integers(0, 256, 12_000).astype(np.uint8).tobytes(),
+        "skewed": np.minimum(rng.geometric(0.4, 80_000) - 1, 255).astype(np.uint8).tobytes(),      # many states per context
+        "periodic": (bytes(range(40)) * 2000),                                                    # every context binary
+    }
+    for name, data in streams.items():
+        got, st = encode(simt, data)
+        assert got == oracle_ppmd(oracle, data), name
+
+
+def test_reference_vectors_through_the_64_lane_paths(simt):
+    names = sorted(f[:-3] for f in os.listdir(VECTORS) if f.startswith("ppmd_") and f.endswith(".in"))
+    assert names
+    for nme in names:
+        data = open(os.path.join(VECTORS, nme + ".in"), "rb").read()
+        if len(data) > 400_000:
+            continue
+        got, _ = encode(simt, data)
+        assert got == open(os.path.join(VECTORS, nme + ".out"), "rb").read(), nme
