@@ -34,7 +34,9 @@ class Stats(C.Structure):
                 ("rc_symbols", C.c_uint64), ("ppmd_restarts", C.c_uint64), ("h2d_bytes", C.c_uint64),
                 ("d2h_bytes", C.c_uint64), ("bins", C.c_uint64), ("records", C.c_uint64),
                 ("algorithmic_bytes", C.c_uint64), ("block0_records", C.c_uint64), ("block0_bytes", C.c_uint64),
-                ("cdata_bytes", C.c_uint64), ("host_coded_symbols", C.c_uint64), ("host_coded_streams", C.c_uint64)]
+                ("cdata_bytes", C.c_uint64), ("host_coded_symbols", C.c_uint64), ("host_coded_streams", C.c_uint64),
+                ("ppmd_window_attempts", C.c_uint64), ("ppmd_windows", C.c_uint64), ("ppmd_window_symbols", C.c_uint64),
+                ("ppmd_window_rounds", C.c_uint64), ("ppmd_windows_redone", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -81,6 +83,7 @@ def load_library(path=None):
     lib.fsgpu_pack_files.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     lib.fsgpu_reset_stats.argtypes = [C.c_void_p]
     lib.fsgpu_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    lib.fsgpu_get_window_profile.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 8)]
     lib.fsgpu_set_archive_params.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     pp = C.POINTER(C.c_char_p)
     lib.fsgpu_ppmd_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -237,6 +240,12 @@ class Packer:
         st = Stats()
         self._check(self.lib.fsgpu_get_stats(self.ctx, C.byref(st)))
         return st.as_dict()
+
+    def window_profile(self):
+        """phase clocks of the windowed PPMd path (units of 64 shader clocks; zero unless built with -DFS_WIN_PROFILE)"""
+        out = (C.c_uint64 * 8)()
+        self._check(self.lib.fsgpu_get_window_profile(self.ctx, C.byref(out)))
+        return dict(zip(("fetch", "states_chain", "ranks", "rounds", "writeback", "coder", "windows_total", "streams_total"), list(out)))
 
     def _encode(self, fn, streams, unit, extra=None):
         n = len(streams)

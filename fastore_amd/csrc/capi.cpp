@@ -448,7 +448,16 @@ int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out)
     *out = ctx->c.stats;
     out->encode_kernel_ms = ctx->c.timing.encode_ms; out->assemble_kernel_ms = ctx->c.timing.assemble_ms;
     out->kernel_launches = ctx->c.timing.launches; out->stream_items = ctx->c.timing.items; out->ppmd_symbols = ctx->c.timing.ppmd_symbols;
+    out->ppmd_window_attempts = ctx->c.timing.win[1]; out->ppmd_windows = ctx->c.timing.win[2]; out->ppmd_window_symbols = ctx->c.timing.win[3];
+    out->ppmd_window_rounds = ctx->c.timing.win[4]; out->ppmd_windows_redone = ctx->c.timing.win[5];
     out->rc_symbols = ctx->c.timing.rc_symbols; out->ppmd_restarts = ctx->c.timing.restarts; out->h2d_bytes = ctx->c.timing.h2d_bytes; out->d2h_bytes = ctx->c.timing.d2h_bytes;
+    return FSGPU_OK;
+}
+
+int fsgpu_get_window_profile(const fsgpu_ctx* ctx, uint64_t out[8])
+{
+    if (!ctx || !out) return FSGPU_ERR_ARG;
+    for (int i = 0; i < 8; ++i) out[i] = ctx->c.timing.win[8 + i];
     return FSGPU_OK;
 }
 

@@ -11,6 +11,7 @@ struct BatchTiming {
     double encode_ms = 0, assemble_ms = 0;      // HIP-event time of the two kernels (summed over launches)
     uint64_t launches = 0, items = 0, ppmd_symbols = 0, rc_symbols = 0, restarts = 0;
     uint64_t h2d_bytes = 0, d2h_bytes = 0;
+    uint64_t win[16] = {0};                     // windowed PPMd hit path, summed over the streams: [1] attempts [2] windows [3] symbols [4] rounds [5] redone; [8..15] phase clocks / 64
 };
 
 // What the lanes of one GPU share: the arena pool and its slot rings (see engine.hip).

@@ -111,6 +111,7 @@ __device__ __forceinline__ void encode_streams_body()
         fs_gptr dst = (fs_gptr)(k->out + item.out_off);
         fs_gptr ar = (fs_gptr)arena;
         uint32_t size = 0, rs = 0;
+        const uint64_t tStream = FS_PROF_NOW();
         if (kind == KIND_PPMD) {
             if (n > 0) size = fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs);
         } else if (kind == KIND_QVZ) {
@@ -118,7 +119,21 @@ __device__ __forceinline__ void encode_streams_body()
         } else {
             size = fsrc::encode_model(kind - KIND_RC_BASE, ar, src, n, dst, cap);
         }
-        if (threadIdx.x == 0) { KernArgs k2 = kernargs(); k2->outSizes[it] = size; k2->restarts[it] = rs; }
+        if (threadIdx.x < 16u) {
+            KernArgs k2 = kernargs();
+            if (threadIdx.x == 0) k2->outSizes[it] = size;
+            // per-stream telemetry: [0] model restarts, [1..5] windowed hit path (attempts, windows, symbols, rounds, redone
+            // windows), [8..14] phase clocks / 64 and [15] the stream's whole time / 64 (FS_WIN_PROFILE builds, else 0)
+            const uint32_t t = threadIdx.x;
+            uint32_t v = 0;
+            if (kind == KIND_PPMD && n > 0) {
+                if (t >= 1u && t <= 5u) v = sh.winStats[t - 1u];
+                else if (t >= 8u && t < 15u) v = sh.winStats[t];
+                else if (t == 15u) v = (uint32_t)((FS_PROF_NOW() - tStream) >> 6);
+            }
+            if (t == 0u) v = rs;
+            k2->restarts[16u * it + t] = v;
+        }
         __syncthreads();
     }
     if (useRings && threadIdx.x == 0) {
@@ -386,7 +401,7 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     if (ensure(dev, dev->dItems, dev->capItems, sizeof(StreamItem) * nItems)) return -1;
     if (ensure(dev, dev->dOrder, dev->capOrder, 4ull * nItems)) return -1;
     if (ensure(dev, dev->dSizes, dev->capSizes, 4ull * nItems)) return -1;
-    if (ensure(dev, dev->dRestarts, dev->capRestarts, 4ull * nItems)) return -1;
+    if (ensure(dev, dev->dRestarts, dev->capRestarts, 64ull * nItems)) return -1;
 
     uint64_t need = fsppmd::ARENA_BYTES;
     for (const auto& it : items) {
@@ -426,15 +441,15 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));
     if (getenv("FS_TRACE")) { HIP_TRY(wait_stream(dev, st)); }
     sizes.resize(nItems);
-    std::vector<uint32_t> restarts(nItems);
+    std::vector<uint32_t> restarts(16ull * nItems);
     HIP_TRY(hipMemcpyAsync(sizes.data(), dev->dSizes, 4ull * nItems, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(restarts.data(), dev->dRestarts, 4ull * nItems, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(restarts.data(), dev->dRestarts, 64ull * nItems, hipMemcpyDeviceToHost, st));
     HIP_TRY(wait_stream(dev, st));
     if (timing) {
         float a = 0;
         (void)hipEventElapsedTime(&a, (hipEvent_t)dev->ev[0], (hipEvent_t)dev->ev[1]);
         timing->encode_ms += a; timing->launches += 1; timing->items += nItems; timing->h2d_bytes += inputBytes;
-        for (uint32_t i = 0; i < nItems; ++i) { timing->restarts += restarts[i]; if (items[i].kind == KIND_PPMD) timing->ppmd_symbols += items[i].in_len; else timing->rc_symbols += items[i].in_len; }
+        for (uint32_t i = 0; i < nItems; ++i) { timing->restarts += restarts[16ull * i]; for (int k = 1; k < 16; ++k) timing->win[k] += restarts[16ull * i + k]; if (items[i].kind == KIND_PPMD) timing->ppmd_symbols += items[i].in_len; else timing->rc_symbols += items[i].in_len; }
     }
     return 0;
 }

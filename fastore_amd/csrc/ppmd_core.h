@@ -64,7 +64,9 @@ struct Shared {
     uint8_t CharMask[256];
     uint8_t QT[260];             // QTable, tabulated once per wave
     uint32_t GlueCount, GlueCount1, restarts;   // touched only by the allocator's rare paths / model restarts: kept out of the registers
-    uint32_t winStats[8];        // windowed hit path: attempts, windows, symbols covered, rounds, redone windows
+    uint32_t winA[64], winM[64], winCut;
+    uint32_t winTab[512], winMask[128];      // owner search: lowest lane per hash slot, per-owner position masks; then the successor words on their way back      // windowed hit path: per-position results, first position that must go back to the serial path
+    uint32_t winStats[16];       // windowed hit path: attempts, windows, symbols covered, rounds, redone windows; [8..15] phase clocks / 64 (FS_WIN_PROFILE builds)
 };
 
 // the three words of a context record as fetched (per-lane values, fetch still in flight): issue early, finish at first use
@@ -887,7 +889,7 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
     Coder m;
     m.hb = arena - 1; m.sh = sh; m.out = out; m.outCap = outCap; m.outPos = 0; sh->restarts = 0;
     m.NumMasked = 0; m.FoundState = 0; m.BSumm = 0; m.rLow = m.rHigh = m.rScale = 0; m.fsSym = m.fsFreq = m.fsSucc = 0;
-    for (uint32_t i = (uint32_t)FS_LANE(); i < 8u; i += FS_WAVE) sh->winStats[i] = 0u;
+    for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) sh->winStats[i] = 0u;
     for (uint32_t i = (uint32_t)FS_LANE(); i < 260u; i += FS_WAVE) sh->QT[i] = (uint8_t)QTable(i);
     // zero the 64-byte guard behind the heap: GlueFreeBlocks may read one stamp past the end
     for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) *(fs_gptr32)(arena + SA_SIZE + 4u * i) = 0u;
@@ -904,9 +906,7 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
     Ctx sufRec = mc; uint32_t sufCtx = 0;
     m.pfCtx = 0; m.pf.a = m.pf.b = m.pf.d = 0;
 #if FS_WIDE
-    // windowed hit path: `hist` = the four bytes in front of `pos`; after a short window the next attempts are put off
-    // (winSkip serial symbols, doubling up to 64 while the windows stay short) so that unpredictable streams and the
-    // learning phase of a model pay next to nothing for it
+    // windowed hit path: `hist` = the four bytes in front of `pos`; winSkip = serial symbols to code before the next attempt
     uint32_t hist = 0, winSkip = 0, winPenalty = 0;
     const bool windows = wide && n >= 64u;
 #endif
@@ -917,7 +917,10 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
             if (FS_UNI(winSkip) != 0u) --winSkip;
             else {
                 const uint32_t done = window_step(m, in, n, FS_UNI(pos), FS_UNI(MinContext), hist);
-                if (done >= 24u) winPenalty = 0; else { winPenalty = winPenalty >= 32u ? 64u : 2u * winPenalty + 1u; winSkip = winPenalty; }
+                // a window that stopped short did so in front of a symbol for the serial path: skip one attempt.  An attempt
+                // that codes nothing doubles the pause (learning phase of a model, unpredictable streams).
+                if (done != 0u) { winPenalty = 0; winSkip = done < 64u ? 1u : 0u; }
+                else { winPenalty = winPenalty >= 32u ? 64u : 2u * winPenalty + 1u; winSkip = winPenalty; }
                 if (done != 0u) {
                     pos += done; MinContext = m.MaxContext; m.pfCtx = 0; keep = 0; prevCtx = 0;
                     if ((pos & 3u) != 0u && (pos | 3u) < n) { cur = *(fs_cgptr32)(in + (pos & ~3u)); if ((pos & ~3u) + 8u <= n) nxt = *(fs_cgptr32)(in + (pos & ~3u) + 4u); }

@@ -54,32 +54,55 @@ FS_DEV uint32_t fs_mulhi(uint32_t a, uint32_t b)
 }
 FS_DEV uint32_t recip_div(uint32_t n, uint32_t mul, uint32_t l) { const uint32_t t = fs_mulhi(n, mul); return (t + ((n - t) >> 1)) >> (l - 1u); }
 
-// compare-exchange of two packed states, larger `hi` first
-#define FS_CE(a, b) do { const bool sw_ = hi[a] < hi[b]; const uint32_t h_ = sw_ ? hi[b] : hi[a], g_ = sw_ ? hi[a] : hi[b]; \
-                         const uint32_t l_ = sw_ ? lo[b] : lo[a], k_ = sw_ ? lo[a] : lo[b]; hi[a] = h_; hi[b] = g_; lo[a] = l_; lo[b] = k_; } while (0)
+// ---- packed state list of one context in a lane: eight states as bytes, no register arrays indexed at run time ----
+// S = symbols, F = frequencies (state j in byte j of the 64-bit value), P = nibble j names the original slot whose
+// successor field belongs to the state now at place j (the 32-bit successors themselves never move: they are gathered
+// through P when the list is written back).
+struct Packed { uint64_t S, F; uint32_t P; };
 
-// The reference's rescale of a context of at most eight states, in one lane, for OrderFall == 0 (Model.cpp:246-280):
-// found state to the front, frequencies halved, stable insertion sort by the halved frequencies, SummFreq rebuilt, the
-// found state's bonus.  Returns false -- and changes nothing -- when a state would drop out (frequency 1 -> 0): that path
-// frees units (ShrinkUnits / FreeUnits) and stays with the serial code.
-FS_DEV bool lane_rescale(uint32_t (&sf)[8], uint32_t (&sc)[8], uint32_t ns, uint32_t kf, uint32_t& summ, uint32_t& flags)
+FS_DEV uint32_t fs_sum_bytes(uint32_t x)
 {
-    uint32_t hi[8], lo[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sad_u8(x, 0u, 0u);                     // v_sad_u8: sum of the four bytes
+#else
+    return (x & 0xFFu) + ((x >> 8) & 0xFFu) + ((x >> 16) & 0xFFu) + (x >> 24);
+#endif
+}
+FS_DEV uint32_t fs_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+FS_DEV uint32_t fs_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+// place of `sym` among the states 0..ns (8 = absent)
+FS_DEV uint32_t packed_find(const Packed& c, uint32_t ns, uint32_t sym)
+{
+    const uint64_t x = c.S ^ (0x0101010101010101ull * sym);
+    // a byte of x is zero <=> that state has the symbol; the lowest flagged byte of the classic test is always exact
+    uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+    z &= ns >= 7u ? ~0ull : ((1ull << (8u * (ns + 1u))) - 1ull);
+    return z ? (uint32_t)__builtin_ctzll(z) >> 3 : 8u;
+}
+
+// The reference's rescale for OrderFall == 0 (Model.cpp:246-280) on a packed list: found state (place kf) to the front,
+// frequencies halved, stable insertion sort by the halved frequencies -- a 19-step min/max network on one word per
+// state --, SummFreq rebuilt, the found state's bonus.  Returns false and changes nothing when a state would drop out
+// (frequency 1 -> 0): that path frees units (ShrinkUnits / FreeUnits) and stays with the serial code.
+FS_DEV bool packed_rescale(Packed& c, uint32_t ns, uint32_t kf, uint32_t& summ, uint32_t& flags)
+{
+    uint32_t key[8];
     uint32_t sumOld = 0, sumNew = 0, f0 = 0; bool zeros = false, hiAny = false;
     #pragma unroll
     for (uint32_t j = 0; j < 8u; ++j) {
-        const uint32_t f = sf[j] >> 8, sy = sf[j] & 0xFFu, nf = f >> 1;
+        const uint32_t f = (uint32_t)(c.F >> (8u * j)) & 0xFFu, sy = (uint32_t)(c.S >> (8u * j)) & 0xFFu, pj = (c.P >> (4u * j)) & 0xFu, nf = f >> 1;
         const bool valid = j <= ns, isF = j == kf;
         const uint32_t r = isF ? 0u : (j < kf ? j + 1u : j);                 // place after the move-to-front
         if (valid) { sumOld += f; sumNew += nf; }
         if (valid && isF) f0 = f;
         if (valid && !isF && nf == 0u) zeros = true;
         if (valid && !isF && nf != 0u && sy >= 0x40u) hiAny = true;
-        const uint32_t key = !valid ? 0u : (isF ? 0xFFFFu : ((nf << 4) | (15u - r)));
-        hi[j] = (key << 16) | (nf << 8) | sy; lo[j] = sc[j];
+        // descending order of the keys = the reference's order: halved frequency, then the earlier place; found state on top
+        key[j] = !valid ? 0u : (((isF ? 0xFFu : nf) << 24) | ((15u - r) << 20) | (nf << 12) | (sy << 4) | pj);
     }
     if (zeros) return false;
-    // 19 compare-exchanges sort eight keys (keys are distinct: the place `r` is part of them)
+    #define FS_CE(a, b) do { const uint32_t hi_ = fs_umax(key[a], key[b]), lo_ = fs_umin(key[a], key[b]); key[a] = hi_; key[b] = lo_; } while (0)
     FS_CE(0, 1); FS_CE(2, 3); FS_CE(4, 5); FS_CE(6, 7);
     FS_CE(0, 2); FS_CE(1, 3); FS_CE(4, 6); FS_CE(5, 7);
     FS_CE(1, 2); FS_CE(5, 6); FS_CE(0, 4); FS_CE(3, 7);
@@ -87,8 +110,7 @@ FS_DEV bool lane_rescale(uint32_t (&sf)[8], uint32_t (&sc)[8], uint32_t ns, uint
     FS_CE(1, 4); FS_CE(3, 6);
     FS_CE(2, 4); FS_CE(3, 5);
     FS_CE(3, 4);
-    #pragma unroll
-    for (uint32_t j = 0; j < 8u; ++j) { sf[j] = hi[j] & 0xFFFFu; sc[j] = lo[j]; }
+    #undef FS_CE
     const uint32_t escFreq = summ - sumOld, nf0 = f0 >> 1;
     uint32_t s = sumNew + ((escFreq + 1u) >> 1), a;
     if ((flags & 0x04u) == 0u) {
@@ -98,7 +120,14 @@ FS_DEV bool lane_rescale(uint32_t (&sf)[8], uint32_t (&sc)[8], uint32_t ns, uint
         a = (f0 * s - sfm * nf0 + a - 1u) / a;
         a = a < 2u ? 2u : (a > (uint32_t)MAX_FREQ / 2u - 18u ? (uint32_t)MAX_FREQ / 2u - 18u : a);
     } else a = 2u;
-    sf[0] = (sf[0] & 0xFFu) | ((nf0 + a) << 8);
+    uint64_t S = 0, F = 0; uint32_t P = 0;
+    #pragma unroll
+    for (uint32_t j = 0; j < 8u; ++j) {
+        S |= (uint64_t)((key[j] >> 4) & 0xFFu) << (8u * j);
+        F |= (uint64_t)(j == 0u ? nf0 + a : ((key[j] >> 12) & 0xFFu)) << (8u * j);
+        P |= (key[j] & 0xFu) << (4u * j);
+    }
+    c.S = S; c.F = F; c.P = P;
     summ = s + a;
     flags = (flags & 0x14u) | (hiAny ? 0x08u : 0u) | 0x04u;
     return true;
@@ -107,9 +136,14 @@ FS_DEV bool lane_rescale(uint32_t (&sf)[8], uint32_t (&sc)[8], uint32_t ns, uint
 // One window at position `pos` (the serial state is at the top of its loop with OrderFall == 0 and MinContext ==
 // MaxContext).  Returns the number of symbols coded, 0 if the first position is not a plain hit.  On return > 0 the model
 // memory, the coder, PrevSuccess, MaxContext and `hist` are exactly what the serial walk would have left.
+//
+// Positions that share a context are taken by the lane of the FIRST of them (the owner): it keeps the context's states in
+// its registers and walks its positions in stream order, one per round, so the rounds of a window are as many as the
+// most popular context has positions; every position's result goes to its slot in LDS.
 FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uint32_t MinContext, uint32_t& hist)
 {
     const uint32_t lane = (uint32_t)FS_LANE();
+    uint64_t tp = FS_PROF_NOW(); const uint64_t tEnter = tp;
     const uint32_t W = n - pos < (uint32_t)FS_WAVE ? n - pos : (uint32_t)FS_WAVE;
     const uint32_t q = pos + (lane < W ? lane : W - 1u);
     // the four bytes in front of the position and the position's own byte, from two aligned words
@@ -135,24 +169,25 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
     FS_STAT_ADD(m.sh->winStats[0], 1u);
 
     uint32_t L = W;
+    FS_PROF_ACC(m.sh->winStats[8], tp);                                // input bytes, hint, record
     for (;;) {
-        uint32_t sf[8], sc[8];
+        Packed c; uint32_t sc[8];
         {   // eight states = 48 bytes = twelve words; state j lives at byte 6 j
             fs_cgptr32 p = (fs_cgptr32)HP(ls);
             uint32_t w[12];
             #pragma unroll
             for (int i = 0; i < 12; ++i) w[i] = p[i];
+            c.S = 0; c.F = 0; c.P = 0x76543210u;
             #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const uint32_t x = w[3 * t], y = w[3 * t + 1], z = w[3 * t + 2];
-                sf[2 * t] = x & 0xFFFFu; sc[2 * t] = (x >> 16) | (y << 16);
-                sf[2 * t + 1] = y >> 16; sc[2 * t + 1] = z;
+                c.S |= (uint64_t)((x & 0xFFu) | ((y >> 8) & 0xFF00u)) << (16 * t);
+                c.F |= (uint64_t)(((x >> 8) & 0xFFu) | ((y >> 16) & 0xFF00u)) << (16 * t);
+                sc[2 * t] = (x >> 16) | (y << 16); sc[2 * t + 1] = z;
             }
         }
         uint32_t summ = r0 >> 16, flags = (r0 >> 8) & 0xFFu;
-        uint32_t k = 8u;
-        #pragma unroll
-        for (int j = 7; j >= 0; --j) if ((uint32_t)j <= ns && (sf[j] & 0xFFu) == sym) k = (uint32_t)j;
+        const uint32_t k = packed_find(c, ns, sym);
         uint32_t succ = 0;
         #pragma unroll
         for (int j = 0; j < 8; ++j) if ((uint32_t)j == k) succ = sc[j];
@@ -163,93 +198,110 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
         const uint64_t good = fs_ballot(plain && link && lane < L);
         const uint32_t lead = ~good ? fs_ctz64(~good) : 64u;
         L = lead < L ? lead : L;
-        if (L == 0u) return 0u;
+        FS_PROF_ACC(m.sh->winStats[9], tp);                            // state lists, find, chain
+        if (L == 0u) { uint64_t te = tEnter; FS_PROF_ACC(m.sh->winStats[14], te); return 0u; }
 
-        // positions that share a context: rank among them, the lane before, and whether this is the last one
-        uint32_t rank = 0, prevLane = 0; bool last = true;
-        for (uint32_t j = 0; j < L; ++j) {
-            const uint32_t a = fs_readlane(addr, j);
-            const bool same = a == addr;
-            if (same && j < lane) { ++rank; prevLane = j; }
-            if (same && j > lane) last = false;
+        // The owner of a context = the first window position that has it.  A 512-slot table in LDS names, per hash
+        // slot, the lowest lane that wrote to it; a lane whose slot was won by a lane with ANOTHER context (a collision)
+        // is resolved by the loop below, one step per distinct context among the colliding lanes -- rare.  Then every
+        // position sets its bit in its owner's mask.
+        const bool inWin = lane < L;
+        uint32_t ownerLane = lane;
+        {
+            #pragma unroll
+            for (uint32_t i = 0; i < 8u; ++i) m.sh->winTab[64u * i + lane] = 0u;
+            m.sh->winMask[2u * lane] = 0u; m.sh->winMask[2u * lane + 1u] = 0u;
+            if (lane == 0u) m.sh->winCut = 64u;
+            FS_WAVE_SYNC();
+            const uint32_t h = (addr * 0x9E3779B1u) >> 23;
+            if (inWin) FS_LDS_MAX(m.sh->winTab[h], 64u - lane);
+            FS_WAVE_SYNC();
+            const uint32_t w = (64u - m.sh->winTab[h]) & 63u;
+            const uint32_t aw = fs_bperm(addr, w);
+            if (inWin && aw == addr) ownerLane = w;
+            for (uint64_t todo = fs_ballot(inWin && aw != addr); todo != 0ull;) {
+                const uint32_t j = fs_ctz64(todo), a = fs_readlane(addr, j);
+                const bool mine = inWin && aw != addr && addr == a;
+                if (mine) ownerLane = j;
+                todo &= ~fs_ballot(mine);
+            }
+            if (inWin) FS_LDS_OR(m.sh->winMask[2u * ownerLane + (lane >> 5)], 1u << (lane & 31u));
+            FS_WAVE_SYNC();
         }
-        uint32_t tA = 0, tM = 0, ps = 0;
-        uint64_t cutMask = 0;
+        const bool owner = inWin && ownerLane == lane;
+        uint32_t rlo = owner ? m.sh->winMask[2u * lane] : 0u, rhi = owner ? m.sh->winMask[2u * lane + 1u] : 0u;      // positions still to do
+        FS_PROF_ACC(m.sh->winStats[10], tp);                           // context sets
         uint32_t rounds = 0;
-        for (uint32_t r = 0;; ++r) {
-            const bool act = lane < L && rank == r;
+        for (;;) {
+            const bool act = (rlo | rhi) != 0u;
             if (fs_ballot(act) == 0ull) break;
             ++rounds;
-            if (r > 0u) {   // the state of the context as the previous position of the same context left it
-                #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t a = fs_bperm(sf[j], prevLane), b = fs_bperm(sc[j], prevLane);
-                    if (act) { sf[j] = a; sc[j] = b; }
-                }
-                const uint32_t a = fs_bperm(summ | (flags << 16), prevLane);
-                if (act) { summ = a & 0xFFFFu; flags = a >> 16; }
-            }
-            // encodeSymbol1 + update1 on the lane's copy (Model.cpp:447-481)
-            uint32_t kk = 8u;
-            #pragma unroll
-            for (int j = 7; j >= 0; --j) if ((uint32_t)j <= ns && (sf[j] & 0xFFu) == sym) kk = (uint32_t)j;
-            uint32_t loCnt = 0, f = 0, fPrev = 0;
-            #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t fj = sf[j] >> 8;
-                if ((uint32_t)j < kk) loCnt += fj;
-                if ((uint32_t)j == kk) f = fj;
-                if ((uint32_t)j + 1u == kk) fPrev = fj;
-            }
-            bool lost = act && kk >= 8u;                              // cannot happen while nothing drops out; never trust it
+            const uint32_t p = !act ? lane : (rlo ? (uint32_t)__builtin_ctz(rlo) : 32u + (uint32_t)__builtin_ctz(rhi));
+            if (rlo) rlo &= rlo - 1u; else rhi &= rhi - 1u;
+            const uint32_t sy = fs_bperm(sym, p);
+            // encodeSymbol1 + update1 on the owner's copy (Model.cpp:447-481)
+            const uint32_t kk = packed_find(c, ns, sy);
+            const bool lost = act && kk >= 8u;                        // cannot happen while nothing drops out; never trust it
+            const uint32_t k8 = 8u * (kk & 7u);
+            const uint32_t f = (uint32_t)(c.F >> k8) & 0xFFu, fPrev = kk ? (uint32_t)(c.F >> (k8 - 8u)) & 0xFFu : 0u;
+            const uint64_t below = c.F & ((1ull << k8) - 1ull);
+            const uint32_t loCnt = fs_sum_bytes((uint32_t)below) + fs_sum_bytes((uint32_t)(below >> 32));
             const uint32_t nf = f + 4u;
             const bool doSwap = kk != 0u && kk < 8u && nf > fPrev;
             const bool resc = act && !lost && nf > (uint32_t)MAX_FREQ && (kk == 0u || doSwap);
             if (act && !lost) {
-                const Recip rc = recip_make(summ);
-                tA = loCnt | (f << 16) | (rc.l << 24); tM = rc.mul;
-                ps = (kk == 0u && 2u * f > summ) ? 1u : 0u;
-                #pragma unroll
-                for (int j = 0; j < 8; ++j) if ((uint32_t)j == kk) sf[j] = (sf[j] & 0xFFu) | (nf << 8);
-                #pragma unroll
-                for (int j = 1; j < 8; ++j)
-                    if (doSwap && (uint32_t)j == kk) { const uint32_t a = sf[j], b = sc[j]; sf[j] = sf[j - 1]; sc[j] = sc[j - 1]; sf[j - 1] = a; sc[j - 1] = b; }
+                // slot of position p: cumulative frequency | frequency << 16 | PrevSuccess << 23 ; the total
+                m.sh->winA[p] = loCnt | (f << 16) | ((kk == 0u && 2u * f > summ) ? (1u << 23) : 0u);
+                m.sh->winM[p] = summ;
+                c.F += 4ull << k8;
+                if (doSwap) {                                      // states kk and kk-1 change places: symbol, frequency, successor tag
+                    const uint32_t j8 = k8 - 8u, j4 = 4u * kk - 4u;
+                    const uint64_t dS = ((c.S >> j8) ^ (c.S >> k8)) & 0xFFull, dF = ((c.F >> j8) ^ (c.F >> k8)) & 0xFFull;
+                    c.S ^= (dS << j8) | (dS << k8); c.F ^= (dF << j8) | (dF << k8);
+                    const uint32_t dP = ((c.P >> j4) ^ (c.P >> (j4 + 4u))) & 0xFu;
+                    c.P ^= (dP << j4) | (dP << (j4 + 4u));
+                }
                 summ += 4u;
             }
             bool cut = lost;
             if (fs_ballot(resc) != 0ull) {
-                uint32_t sf2[8], sc2[8], summ2 = summ, flags2 = flags;
-                #pragma unroll
-                for (int j = 0; j < 8; ++j) { sf2[j] = sf[j]; sc2[j] = sc[j]; }
-                const bool done = lane_rescale(sf2, sc2, ns, doSwap ? kk - 1u : kk, summ2, flags2);
-                if (resc && done) {
-                    #pragma unroll
-                    for (int j = 0; j < 8; ++j) { sf[j] = sf2[j]; sc[j] = sc2[j]; }
-                    summ = summ2; flags = flags2;
-                }
+                Packed c2 = c; uint32_t summ2 = summ, flags2 = flags;
+                const bool done = packed_rescale(c2, ns, doSwap ? kk - 1u : kk, summ2, flags2);
+                if (resc && done) { c = c2; summ = summ2; flags = flags2; }
                 if (resc && !done) cut = true;                     // a state drops out: the serial path takes this symbol
             }
-            cutMask |= fs_ballot(cut);
+            if (cut) { FS_LDS_MIN(m.sh->winCut, p); rlo = rhi = 0u; }
         }
+        FS_WAVE_SYNC();
         FS_STAT_ADD(m.sh->winStats[3], rounds);
-        if (cutMask != 0ull) {                                        // nothing has been stored yet: shorten the window and redo it
-            const uint32_t at = fs_ctz64(cutMask);
+        FS_PROF_ACC(m.sh->winStats[11], tp);                           // rounds
+        const uint32_t cutAt = FS_LDS_RD(m.sh->winCut);
+        if (cutAt < L) {                                              // nothing has been stored yet: shorten the window and redo it
             FS_STAT_ADD(m.sh->winStats[4], 1u);
-            L = at;                                                   // at < L: every redo is strictly shorter
-            if (L == 0u) return 0u;
+            L = cutAt;                                                // every redo is strictly shorter
+            if (L == 0u) { uint64_t te = tEnter; FS_PROF_ACC(m.sh->winStats[14], te); return 0u; }
             continue;
         }
 
-        // commit: the last position of each context writes the list and the record word back
-        if (lane < L && last) {
+        // commit: every owner writes its context's list and record word back.  The successors go through the lane's
+        // eight words of LDS (the hash table's space, free again) to be picked up in their final order.
+        #pragma unroll
+        for (int j = 0; j < 8; ++j) m.sh->winTab[8u * lane + (uint32_t)j] = sc[j];
+        FS_WAVE_SYNC();
+        if (owner) {
             fs_gptr32 p = (fs_gptr32)HP(stats);
             const uint32_t nst = ns + 1u, full = (3u * nst) >> 1;
-            uint32_t w[12];
+            uint32_t w[12], sf[8], so[8];
+            #pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sf[j] = ((uint32_t)(c.S >> (8 * j)) & 0xFFu) | (((uint32_t)(c.F >> (8 * j)) & 0xFFu) << 8);
+                so[j] = m.sh->winTab[8u * lane + ((c.P >> (4 * j)) & 7u)];
+            }
             #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                w[3 * t] = sf[2 * t] | (sc[2 * t] << 16);
-                w[3 * t + 1] = (sc[2 * t] >> 16) | (sf[2 * t + 1] << 16);
-                w[3 * t + 2] = sc[2 * t + 1];
+                w[3 * t] = sf[2 * t] | (so[2 * t] << 16);
+                w[3 * t + 1] = (so[2 * t] >> 16) | (sf[2 * t + 1] << 16);
+                w[3 * t + 2] = so[2 * t + 1];
             }
             #pragma unroll
             for (int i = 0; i < 12; ++i) if ((uint32_t)i < full) p[i] = w[i];
@@ -261,21 +313,39 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
             }
             *(fs_gptr32)HP(addr) = ns | (flags << 8) | (summ << 16);
         }
-        FS_WAVE_SYNC();
-
-        // the range coder, in stream order (Coder.hpp:13-17 + the normalisation of Model.cpp:580)
-        for (uint32_t i = 0; i < L; ++i) {
-            const uint32_t A = FS_UNI(fs_readlane(tA, i)), M = FS_UNI(fs_readlane(tM, i));
-            const uint32_t rr = recip_div(m.range, M, A >> 24);
-            m.low += (A & 0xFFFFu) * rr; m.range = rr * ((A >> 16) & 0xFFu);
-            rc_normalize(m);
+        // every position: its slot, and the reciprocal of its total (all lanes at once)
+        uint32_t tA = 0, tM = 0;
+        if (inWin) {
+            const Recip rc = recip_make(m.sh->winM[lane]);
+            tA = m.sh->winA[lane] | ((rc.l - 1u) << 24); tM = rc.mul;
         }
-        m.PrevSuccess = FS_UNI(fs_readlane(ps, L - 1u));
+        FS_WAVE_SYNC();
+        FS_PROF_ACC(m.sh->winStats[12], tp);                           // write-back, reciprocals
+
+        // the range coder, in stream order (Coder.hpp:13-17 + the normalisation of Model.cpp:580): scalar code
+        // (range >= 2^24 implies that low and low + range differ above bit 23: nothing to shift out -- the usual case is
+        // decided by one compare; the slots of four symbols are fetched ahead of their chains)
+        #define FS_CODE_ONE(A_, M_) do { \
+            const uint32_t t_ = fs_mulhi(m.range, M_), rr_ = (t_ + ((m.range - t_) >> 1)) >> (A_ >> 24); \
+            m.low += (A_ & 0xFFFFu) * rr_; m.range = rr_ * ((A_ >> 16) & 0x7Fu); \
+            if (__builtin_expect(m.range < TOP, 0)) rc_normalize(m); } while (0)
+        uint32_t i_ = 0;
+        while (i_ + 4u <= L) {
+            const uint32_t A0 = FS_UNI(fs_readlane(tA, i_)), M0 = FS_UNI(fs_readlane(tM, i_)), A1 = FS_UNI(fs_readlane(tA, i_ + 1u)), M1 = FS_UNI(fs_readlane(tM, i_ + 1u));
+            const uint32_t A2 = FS_UNI(fs_readlane(tA, i_ + 2u)), M2 = FS_UNI(fs_readlane(tM, i_ + 2u)), A3 = FS_UNI(fs_readlane(tA, i_ + 3u)), M3 = FS_UNI(fs_readlane(tM, i_ + 3u));
+            FS_CODE_ONE(A0, M0); FS_CODE_ONE(A1, M1); FS_CODE_ONE(A2, M2); FS_CODE_ONE(A3, M3);
+            i_ += 4u;
+        }
+        for (; i_ < L; ++i_) { const uint32_t A0 = FS_UNI(fs_readlane(tA, i_)), M0 = FS_UNI(fs_readlane(tM, i_)); FS_CODE_ONE(A0, M0); }
+        #undef FS_CODE_ONE
+        m.PrevSuccess = (FS_UNI(fs_readlane(tA, L - 1u)) >> 23) & 1u;
         m.MaxContext = FS_UNI(fs_readlane(succ, L - 1u));
         const uint32_t kl = FS_UNI(fs_readlane(key, L - 1u)), sl = FS_UNI(fs_readlane(sym, L - 1u));
         hist = (kl >> 8) | (sl << 24);
         FS_STAT_ADD(m.sh->winStats[1], 1u);
         FS_STAT_ADD(m.sh->winStats[2], L);
+        FS_PROF_ACC(m.sh->winStats[13], tp);                           // range coder
+        { uint64_t te = tEnter; FS_PROF_ACC(m.sh->winStats[14], te); }
         return L;
     }
 }

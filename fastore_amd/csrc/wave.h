@@ -109,6 +109,27 @@ FS_DEV uint32_t fs_ld32(fs_cgptr p) { FS_CNT(g_ld[5]); const uint32_t v = *(fs_c
 // wave-uniform read of a word of the wave's LDS state that the wave also rewrites (adaptive tables, counters)
 #define FS_LDS_RD(x) fs_lds_rd((uint32_t)(x))
 FS_DEV uint32_t fs_lds_rd(uint32_t v) { FS_EMU_MEET(); return FS_UNI(v); }
+// phase clocks of the windowed hit path (tools/ppmd_microbench.py with an -DFS_WIN_PROFILE build); nothing otherwise
+#if defined(FS_WIN_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+  #define FS_PROF_NOW() ((uint64_t)__builtin_amdgcn_s_memtime())
+  #define FS_PROF_ACC(w, t0) do { const uint64_t t1_ = FS_PROF_NOW(); (w) = FS_UNI(w) + (uint32_t)((t1_ - (t0)) >> 6); (t0) = t1_; } while (0)
+#else
+  #define FS_PROF_NOW() 0ull
+  #define FS_PROF_ACC(w, t0) ((void)(t0))
+#endif
+// minimum into a word of the wave's LDS state from the lanes that have something to report
+#if defined(__HIP_DEVICE_COMPILE__)
+  #define FS_LDS_MIN(w, v) ((void)__hip_atomic_fetch_min(&(w), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#else
+  #define FS_LDS_MIN(w, v) do { if ((uint32_t)(v) < (w)) (w) = (uint32_t)(v); } while (0)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+  #define FS_LDS_MAX(w, v) ((void)__hip_atomic_fetch_max(&(w), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+  #define FS_LDS_OR(w, v) ((void)__hip_atomic_fetch_or(&(w), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+#else
+  #define FS_LDS_MAX(w, v) do { if ((uint32_t)(v) > (w)) (w) = (uint32_t)(v); } while (0)
+  #define FS_LDS_OR(w, v) do { (w) |= (uint32_t)(v); } while (0)
+#endif
 // statistics counter in LDS: every lane stores the same sum on the device; one lane counts in the emulation
 #if defined(FS_SIMT_EMU)
   #define FS_STAT_ADD(w, x) do { if (FS_LANE() == 0) (w) += (x); } while (0)

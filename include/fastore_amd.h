@@ -100,6 +100,9 @@ typedef struct fsgpu_stats {
     /* standard-bin PPMd streams that the scheduler gave to idle host cores (same coder core, one lane -- what block 0
      * always does) because they were predicted to outlast the balanced device step; 0 unless host_residue is enabled */
     uint64_t host_coded_symbols, host_coded_streams;
+    /* windowed PPMd hit path (ppmd_window.h): window attempts, windows coded, symbols coded inside windows (of
+     * ppmd_symbols), rounds (positions sharing a context are processed one rank per round), windows redone shorter */
+    uint64_t ppmd_window_attempts, ppmd_windows, ppmd_window_symbols, ppmd_window_rounds, ppmd_windows_redone;
 } fsgpu_stats;
 
 void fsgpu_config_defaults(fsgpu_config* cfg);
@@ -176,6 +179,10 @@ int fsgpu_print_stream_sizes(const char* out_prefix, char* err, size_t err_len);
 
 int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out);   /* cumulative since fsgpu_reset_stats() */
 int fsgpu_reset_stats(fsgpu_ctx* ctx);
+/* Diagnostic: the per-phase clock sums of the windowed PPMd path since fsgpu_reset_stats(), in units of 64 shader clocks
+ * (all zero unless the library was built with -DFS_WIN_PROFILE): [0] input/hint/record fetch, [1] state lists + chain,
+ * [2] ranks, [3] rounds, [4] write-back, [5] range coder, [6] whole windows, [7] whole PPMd streams. */
+int fsgpu_get_window_profile(const fsgpu_ctx* ctx, uint64_t out[8]);
 const char* fsgpu_device_name(const fsgpu_ctx* ctx);
 
 #ifdef __cplusplus
