@@ -38,15 +38,18 @@ constexpr uint64_t kGuard = 64ull << 10;
 // launch ends with its longest stream -- so 3 waves/SIMD (3072 waves, no register spills) beats 6.
 constexpr uint32_t kWavesPerSimd = 3;
 
-// Arena slots.  The pool is cut into kXcc partitions of `slotsPerXcc` arenas; a wave takes a slot of the XCD it runs
-// on from that XCD's ring and returns it when its queue is empty.  Slots never migrate between XCDs: the per-XCD L2s
-// are not coherent with each other, so an arena reused from another XCD inside one cache epoch could be clobbered by
-// a late write-back of the previous owner's dead lines.  Ring entry = ticket << 32 | slot (Vyukov-style tickets):
-// pop k of a ring reads entry k % S once its ticket is k; push k writes entry k % S with ticket k + S.  A pop only
-// waits while more workgroups are resident on the XCD than it has slots (several launches in flight with a small
-// --max-waves); the holders do not depend on the waiters, so every wave reaches its exit.
+// Arena slots.  The pool is cut into kXcc partitions of `slotsPerXcc` arenas; a wave claims a slot of the XCD it runs
+// on and gives it back when its queue is empty.  Slots never migrate between XCDs: the per-XCD L2s are not coherent
+// with each other, so an arena reused from another XCD inside one cache epoch could be clobbered by a late write-back
+// of the previous owner's dead lines.  A partition is a bitmap (bit set = taken): claim = find a clear bit, atomicOr,
+// keep it if the bit was clear before; release = atomicAnd.  There is no queue and no ticket, so nothing can be lost or
+// overwritten (round 1's ticket ring could drop a ticket when a slot was returned before the waiter's next poll, which
+// left that wave spinning for ever: the "stall with more than four launches in flight").  A claim only has to retry
+// while more waves are resident on the XCD than it has slots (a small --max-waves): the holders do not depend on the
+// waiters, so every wave reaches its exit.
 constexpr uint32_t kXcc = 8;
-struct SlotRing { uint32_t head; uint32_t pad0[15]; uint32_t tail; uint32_t pad1[15]; };
+constexpr uint32_t kBitmapWords = 16;            // 64-bit words per XCD: up to 1024 slots
+struct SlotMap { unsigned long long w[kBitmapWords]; };
 
 __device__ __forceinline__ uint32_t xcc_id()
 { uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & (kXcc - 1u); }
@@ -56,7 +59,7 @@ __device__ __forceinline__ uint32_t xcc_id()
 // spill scalars to vector lanes.  `kernargs()` hides the pointer from the optimiser so that the loads are not hoisted.
 struct EncodeArgs {
     const StreamItem* items; const uint32_t* order; const uint8_t* in; uint8_t* out; uint32_t* outSizes; uint32_t* restarts;
-    uint8_t* arenas; uint64_t arenaStride; uint32_t* queueHead; SlotRing* rings; unsigned long long* ringEntries;
+    uint8_t* arenas; uint64_t arenaStride; uint32_t* queueHead; SlotMap* maps; unsigned long long* unused0;
     uint32_t nItems, longLen, slotsPerXcc, pad;
 };
 typedef const __attribute__((address_space(4))) EncodeArgs* KernArgs;
@@ -67,26 +70,49 @@ __device__ __forceinline__ KernArgs kernargs()
     return k;
 }
 
-__device__ __forceinline__ void encode_streams_body()
+// TWO: the two-wave form (128-thread workgroups): wave 0 walks the models and queues every PPMd coding step, wave 1 is
+// the coder wave (ppmd_core.h: coder_wave).  Range-coded and QVZ items are coded by wave 0 alone, as in the one-wave form.
+template <bool TWO> __device__ __forceinline__ void encode_streams_body()
 {
     __shared__ fsppmd::Shared sh;
-    // rings == nullptr: exclusive launch (no other kernel in flight), one arena per workgroup index
-    uint32_t slot = blockIdx.x, xcc = 0;
-    const bool useRings = kernargs()->rings != nullptr;
-    if (useRings) {
+    uint32_t qTail = 0;
+    if (TWO) {
+        if (threadIdx.x == 0) { sh.qTail = 0u; sh.qHead = 0u; }
+        __syncthreads();                               // the workgroup's only barrier: from here on the waves go separate ways
+        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) { fsppmd::coder_wave((FS_LDS fsppmd::Shared*)&sh); return; }
+    }
+    // maps == nullptr: exclusive launch (no other kernel in flight), one arena per workgroup index
+    uint32_t slot = blockIdx.x, xcc = 0, word = 0, bit = 0;
+    const bool useMaps = kernargs()->maps != nullptr;
+    if (useMaps) {
         KernArgs k = kernargs();
         xcc = xcc_id();
         uint32_t s = 0;
         if (threadIdx.x == 0) {
-            const uint32_t t = atomicAdd(&k->rings[xcc].head, 1u);
-            unsigned long long* e = k->ringEntries + (uint64_t)xcc * k->slotsPerXcc + t % k->slotsPerXcc;
+            SlotMap* mp = k->maps + xcc;
+            const uint32_t per = k->slotsPerXcc, words = (per + 63u) >> 6;
+            uint32_t w0 = blockIdx.x % words;                       // spread the first probes over the words
             for (;;) {
-                const unsigned long long v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((uint32_t)(v >> 32) == t) { s = (uint32_t)v; break; }
-                __builtin_amdgcn_s_sleep(32);
+                bool got = false;
+                for (uint32_t i = 0; i < words && !got; ++i) {
+                    const uint32_t wi = (w0 + i) % words;
+                    // bits past the partition's last slot are never offered
+                    const unsigned long long valid = (wi + 1u) * 64u <= per ? ~0ull : ((1ull << (per - wi * 64u)) - 1ull);
+                    unsigned long long cur = __hip_atomic_load(&mp->w[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while ((~cur & valid) != 0ull) {
+                        const uint32_t b = (uint32_t)__builtin_ctzll(~cur & valid);
+                        const unsigned long long old = __hip_atomic_fetch_or(&mp->w[wi], 1ull << b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (!(old & (1ull << b))) { s = 1u + wi * 64u + b; got = true; break; }
+                        cur = old | (1ull << b);
+                    }
+                }
+                if (got) break;
+                __builtin_amdgcn_s_sleep(64);
             }
         }
-        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
+        s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s) - 1u;
+        word = s >> 6; bit = s & 63u;
+        slot = xcc * kernargs()->slotsPerXcc + s;
     }
     uint8_t* arena;
     { KernArgs k = kernargs(); arena = k->arenas + (uint64_t)slot * k->arenaStride; }
@@ -113,7 +139,10 @@ __device__ __forceinline__ void encode_streams_body()
         uint32_t size = 0, rs = 0;
         const uint64_t tStream = FS_PROF_NOW();
         if (kind == KIND_PPMD) {
-            if (n > 0) size = fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs);
+            if (n > 0) {
+                if (TWO) { KernArgs k3 = kernargs(); (void)fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs, true, (FS_GLOBAL uint32_t*)(k3->outSizes + it), qTail, &qTail); }
+                else size = fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs);
+            }
         } else if (kind == KIND_QVZ) {
             size = fsqvz::encode_stream(ar, (fs_cgptr)(k->in + item.aux_off), src, n, dst, cap);
         } else {
@@ -121,7 +150,7 @@ __device__ __forceinline__ void encode_streams_body()
         }
         if (threadIdx.x < 16u) {
             KernArgs k2 = kernargs();
-            if (threadIdx.x == 0) k2->outSizes[it] = size;
+            if (threadIdx.x == 0 && !(TWO && kind == KIND_PPMD && n > 0)) k2->outSizes[it] = size;       // (two-wave form: a PPMd member's size comes from the coder wave)
             // per-stream telemetry: [0] model restarts, [1..5] windowed hit path (attempts, windows, symbols, rounds, redone
             // windows), [8..14] phase clocks / 64 and [15] the stream's whole time / 64 (FS_WIN_PROFILE builds, else 0)
             const uint32_t t = threadIdx.x;
@@ -134,17 +163,19 @@ __device__ __forceinline__ void encode_streams_body()
             if (t == 0u) v = rs;
             k2->restarts[16u * it + t] = v;
         }
-        __syncthreads();
+        FS_WAVE_SYNC();
     }
-    if (useRings && threadIdx.x == 0) {
+    if (TWO) fsppmd::cq_send_exit((FS_LDS fsppmd::Shared*)&sh, qTail);
+    if (useMaps && threadIdx.x == 0) {
         KernArgs k = kernargs();
-        const uint32_t t = atomicAdd(&k->rings[xcc].tail, 1u);
-        unsigned long long* e = k->ringEntries + (uint64_t)xcc * k->slotsPerXcc + t % k->slotsPerXcc;
-        __hip_atomic_store(e, ((unsigned long long)(t + k->slotsPerXcc) << 32) | slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the wave's stores have left for the XCD's L2 before the slot shows as free; its next owner runs on this XCD
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_and(&(k->maps + xcc)->w[word], ~(1ull << bit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-__global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(EncodeArgs /* read through kernargs() */) { encode_streams_body(); }
+__global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(EncodeArgs /* read through kernargs() */) { encode_streams_body<false>(); }
+__global__ __launch_bounds__(128, kWavesPerSimd) void fs_encode_streams2(EncodeArgs /* read through kernargs() */) { encode_streams_body<true>(); }
 
 __device__ __forceinline__ void put_be(uint8_t* p, uint64_t v, int nbytes)
 { for (int i = 0; i < nbytes; ++i) p[i] = (uint8_t)(v >> (8 * (nbytes - 1 - i))); }
@@ -228,13 +259,13 @@ int device_count()
 
 static double wallMs() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; }
 
-// Shared by the lanes of one GPU.  `gate`: launches that take their arenas from the rings hold it shared; a launch
+// Shared by the lanes of one GPU.  `gate`: launches that take their arenas from the slot maps hold it shared; a launch
 // whose coder table does not fit a slot (the sparse <256,1> read-id model of archives with > 16 header fields) runs
 // alone, with one arena per workgroup index carved at its own stride.
 struct Pool {
     uint8_t* arenas = nullptr; uint64_t bytes = 0, slotStride = 0;
     uint32_t slotsPerXcc = 0;
-    SlotRing* rings = nullptr; unsigned long long* entries = nullptr;
+    SlotMap* maps = nullptr;
     std::shared_mutex gate;
     std::mutex m; int lanes = 0;
 };
@@ -262,8 +293,7 @@ int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size
     auto fail = [&](const char* what, hipError_t e) {
         snprintf(err, errLen, "%s: %s", what, hipGetErrorString(e));
         if (pool->arenas) (void)hipFree(pool->arenas);
-        if (pool->rings) (void)hipFree(pool->rings);
-        if (pool->entries) (void)hipFree(pool->entries);
+        if (pool->maps) (void)hipFree(pool->maps);
         delete pool; delete dev; return -1;
     };
     hipError_t e;
@@ -279,22 +309,16 @@ int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size
     // at most 55 % of the free HBM.
     const uint32_t waves = maxWaves ? maxWaves : (uint32_t)dev->cus * 4u * kWavesPerSimd;
     const uint64_t stride = ((fsppmd::ARENA_BYTES + kGuard) + 4095ull) & ~4095ull;
-    uint32_t perXcc = (waves + kXcc - 1) / kXcc;
+    uint32_t perXcc = std::min<uint32_t>((waves + kXcc - 1) / kXcc, kBitmapWords * 64u);
     const uint64_t budget = (uint64_t)((double)freeB * 0.55);
     while (perXcc > 1 && (uint64_t)perXcc * kXcc * stride > budget) --perXcc;
     pool->slotStride = stride; pool->slotsPerXcc = perXcc; pool->bytes = (uint64_t)perXcc * kXcc * stride;
     if (pool->bytes > budget) { snprintf(err, errLen, "not enough device memory for the coder arenas"); delete pool; delete dev; return -1; }
     dev->nWaves = waves; dev->pool = pool;
     if ((e = hipMalloc((void**)&pool->arenas, pool->bytes)) != hipSuccess) return fail("hipMalloc(arenas)", e);
-    if ((e = hipMalloc((void**)&pool->rings, sizeof(SlotRing) * kXcc)) != hipSuccess) return fail("hipMalloc(rings)", e);
-    if ((e = hipMalloc((void**)&pool->entries, 8ull * kXcc * perXcc)) != hipSuccess) return fail("hipMalloc(ring entries)", e);
-    {   // every ring full: entry k holds ticket k and its own slot
-        std::vector<unsigned long long> init((size_t)kXcc * perXcc);
-        for (uint32_t x = 0; x < kXcc; ++x) for (uint32_t k = 0; k < perXcc; ++k) init[(size_t)x * perXcc + k] = ((unsigned long long)k << 32) | (x * perXcc + k);
-        if ((e = hipMemcpy(pool->entries, init.data(), init.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(ring entries)", e);
-        if ((e = hipMemset(pool->rings, 0, sizeof(SlotRing) * kXcc)) != hipSuccess) return fail("hipMemset(rings)", e);
-    }
-    if (lane_init(dev, err, errLen) != 0) { (void)hipFree(pool->arenas); (void)hipFree(pool->rings); (void)hipFree(pool->entries); delete pool; delete dev; return -1; }
+    if ((e = hipMalloc((void**)&pool->maps, sizeof(SlotMap) * kXcc)) != hipSuccess) return fail("hipMalloc(slot maps)", e);
+    if ((e = hipMemset(pool->maps, 0, sizeof(SlotMap) * kXcc)) != hipSuccess) return fail("hipMemset(slot maps)", e);
+    if (lane_init(dev, err, errLen) != 0) { (void)hipFree(pool->arenas); (void)hipFree(pool->maps); delete pool; delete dev; return -1; }
     pool->lanes = 1;
     *out = dev;
     if (getenv("FS_TRACE")) fprintf(stderr, "[trace] device_create: up to %u waves, %u slots per XCD, %.1f GB arena pool, %.1f ms\n", waves, perXcc, pool->bytes / 1e9, wallMs() - tc0);
@@ -328,7 +352,7 @@ void device_destroy(Device* dev)
     if (Pool* pool = dev->pool) {
         bool last;
         { std::lock_guard<std::mutex> g(pool->m); last = --pool->lanes == 0; }
-        if (last) { (void)hipFree(pool->arenas); (void)hipFree(pool->rings); (void)hipFree(pool->entries); delete pool; }
+        if (last) { (void)hipFree(pool->arenas); (void)hipFree(pool->maps); delete pool; }
     }
     delete dev;
 }
@@ -340,14 +364,14 @@ int lane_debug(Device* dev, char* out, size_t outLen)
     if (hipSetDevice(dev->deviceId) != hipSuccess) return -1;
     hipStream_t s = nullptr;
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return -1;
-    uint32_t head = 0; SlotRing rings[kXcc]; memset(rings, 0, sizeof rings);
+    uint32_t head = 0; SlotMap maps[kXcc]; memset(maps, 0, sizeof maps);
     bool ok = hipMemcpyAsync(&head, dev->queueHead, 4, hipMemcpyDeviceToHost, s) == hipSuccess;
-    ok = ok && hipMemcpyAsync(rings, dev->pool->rings, sizeof rings, hipMemcpyDeviceToHost, s) == hipSuccess;
+    ok = ok && hipMemcpyAsync(maps, dev->pool->maps, sizeof maps, hipMemcpyDeviceToHost, s) == hipSuccess;
     ok = ok && hipStreamSynchronize(s) == hipSuccess;
     (void)hipStreamDestroy(s);
     if (!ok) { snprintf(out, outLen, "device read failed"); return -1; }
-    int n = snprintf(out, outLen, "queue head %u, stream %s; rings (head-tail):", head, hipStreamQuery((hipStream_t)dev->stream) == hipSuccess ? "idle" : "busy");
-    for (uint32_t x = 0; x < kXcc && n > 0 && (size_t)n < outLen; ++x) n += snprintf(out + n, outLen - n, " %u-%u", rings[x].head, rings[x].tail);
+    int n = snprintf(out, outLen, "queue head %u, stream %s; arena slots taken per XCD:", head, hipStreamQuery((hipStream_t)dev->stream) == hipSuccess ? "idle" : "busy");
+    for (uint32_t x = 0; x < kXcc && n > 0 && (size_t)n < outLen; ++x) { int c = 0; for (uint32_t w = 0; w < kBitmapWords; ++w) c += __builtin_popcountll(maps[x].w[w]); n += snprintf(out + n, outLen - n, " %d", c); }
     return 0;
 }
 
@@ -432,10 +456,14 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         EncodeArgs ka;
         ka.items = (const StreamItem*)dev->dItems; ka.order = (const uint32_t*)dev->dOrder; ka.in = (const uint8_t*)dev->dIn; ka.out = (uint8_t*)dev->dScratch;
         ka.outSizes = (uint32_t*)dev->dSizes; ka.restarts = (uint32_t*)dev->dRestarts; ka.arenas = pool->arenas; ka.arenaStride = stride;
-        ka.queueHead = (uint32_t*)dev->queueHead; ka.rings = exclusive ? (SlotRing*)nullptr : pool->rings;
-        ka.ringEntries = exclusive ? (unsigned long long*)nullptr : pool->entries;
+        ka.queueHead = (uint32_t*)dev->queueHead; ka.maps = exclusive ? (SlotMap*)nullptr : pool->maps; ka.unused0 = nullptr;
         ka.nItems = nRest; ka.longLen = longLen; ka.slotsPerXcc = pool->slotsPerXcc; ka.pad = 0;
-        hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, ka);
+        // two-wave form where the step is bound by its longest PPMd stream (the coder runs beside the model walk: ~1.4x per
+        // stream, but a stream takes two wave slots); FS_TWO_WAVE=0/1 forces either form
+        bool two = maxLen >= (256u << 10);
+        if (const char* tw = getenv("FS_TWO_WAVE")) two = atoi(tw) != 0;
+        if (two) { const uint32_t g2 = std::max(1u, std::min(grid, dev->nWaves / 2u)); hipLaunchKernelGGL(fs_encode_streams2, dim3(g2), dim3(128), 0, st, ka); }
+        else hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, ka);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));

@@ -234,7 +234,7 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
 // into slices, and the moment the last bin of a slice is done its lane thread builds the slice's stream items, stages
 // them and runs the device call -- so the host front end of the later slices, the staging and the device work of the
 // earlier ones all overlap, and the kernels of consecutive slices overlap on the device (shared arena pool).
-enum : uint32_t { kMaxLanes = 4 };
+enum : uint32_t { kMaxLanes = 8 };
 
 void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, const std::vector<uint32_t>& binArch, const BinProducer& produce)
 {
@@ -253,21 +253,24 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     std::sort(byWork.begin(), byWork.end(), [&](uint32_t x, uint32_t y) { return weight[x] > weight[y]; });
     uint64_t totalW = 0;
     for (uint64_t w : weight) totalW += w;
-    // slice boundaries by cumulated weight
+    // Slices.  The device step ends with the longest stream of the batch (a PPMd stream is serial: one wavefront walks
+    // it from end to end), so the biggest bins must reach the device as early as possible: the first slice is what the
+    // host threads finish in their first round -- one bin each --, the rest of the weight is cut into equal parts that
+    // become ready one after the other while the earlier ones are coded.  Up to eight launches are in flight (one per
+    // lane); they take their arenas from the pool's slot maps.
     std::vector<uint32_t> cut{0};
-    // default: four slices of equal weight on four lanes.  Eight concurrent launches were 5-10 % faster when they
-    // worked, but on some MI355X boxes the device stopped making progress with more than four kernels in flight (all
-    // eight submitted, none finishing, even a fresh stream's 4-byte copy blocked; never with four: profiles/
-    // r01_stall_bisect.txt) -- the compute front end has four pipes, and a pipe whose kernel cannot place its remaining
-    // workgroups (the GPU is full of waves waiting for arena slots) holds up the queues that share it.
     const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? kMaxLanes : 1u);
     if (wantSlices > 1) {
-        // relative slice weights: equal, or FS_SLICE_WEIGHTS="1,2,2,3" (experiment: a light first slice starts the
-        // device -- and the longest streams -- earlier)
-        std::vector<double> share(wantSlices, 1.0);
+        // FS_SLICE_WEIGHTS="1,2,2,3" (experiment): relative weights of ALL slices instead of the rule above
+        std::vector<double> share;
         if (const char* sw = getenv("FS_SLICE_WEIGHTS")) {
-            uint32_t n = 0;
-            for (const char* q = sw; *q && n < wantSlices; ) { const double v = atof(q); if (v > 0) share[n] = v; ++n; while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+            for (const char* q = sw; *q && share.size() < wantSlices; ) { const double v = atof(q); share.push_back(v > 0 ? v : 1.0); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+            share.resize(wantSlices, 1.0);
+        } else {
+            uint64_t firstW = 0; const uint32_t firstBins = std::min<uint32_t>(std::max(1u, hostThreads), nBins / wantSlices);
+            for (uint32_t i = 0; i < firstBins; ++i) firstW += weight[byWork[i]];
+            const double f = std::min(0.5, (double)firstW / (double)std::max<uint64_t>(1, totalW));
+            share.assign(wantSlices, (1.0 - f) / (wantSlices - 1)); share[0] = f;
         }
         double shareSum = 0; for (double v : share) shareSum += v;
         uint64_t acc = 0; uint32_t k = 0; double upTo = share[0];

@@ -66,6 +66,10 @@ struct Shared {
     uint32_t GlueCount, GlueCount1, restarts;   // touched only by the allocator's rare paths / model restarts: kept out of the registers
     uint32_t winA[64], winM[64], winCut;
     uint32_t winTab[512], winMask[128];      // owner search: lowest lane per hash slot, per-owner position masks; then the successor words on their way back      // windowed hit path: per-position results, first position that must go back to the serial path
+    // coder queue (two-wave form: the model wave produces, the coder wave consumes; see the range-coder section)
+    uint32_t qA[256], qM[256];
+    uint32_t qTail, qHead;
+    uint32_t qOutLo, qOutHi, qOutCap, qSizeLo, qSizeHi;     // the running stream's output buffer, capacity, and where its size goes
     uint32_t winStats[16];       // windowed hit path: attempts, windows, symbols covered, rounds, redone windows; [8..15] phase clocks / 64 (FS_WIN_PROFILE builds)
 };
 
@@ -82,6 +86,7 @@ struct Coder {
     int32_t BSumm, OrderFall, RunLength;
     uint32_t low, range, rLow, rHigh, rScale;
     fs_gptr out; uint32_t outCap, outPos;
+    uint32_t queued, qTail, qHeadSeen;   // queued != 0: every coding step goes to the coder wave through sh->qA/qM (this wave never reads low/range)
     uint32_t pfCtx; CtxRaw pf;     // record of the next symbol's first context, requested ahead of this symbol's stores (0 = none)
 };
 
@@ -283,15 +288,84 @@ FS_DEV void FreeUnits(Coder& m, uint32_t ptr, uint32_t NU)
 { uint32_t indx = kUnits2Indx[NU - 1]; blk_insert(m, BL(indx), ptr, kIndx2Units[indx]); }
 
 // ---------------- range coder ----------------
+// The carry-less coder of Coder.hpp:7-28.  One-wave form: the walking wave codes as it goes.  Two-wave form
+// (m.queued): the model never needs low/range back -- an encoder is open loop -- so every coding step is written as one
+// entry into a ring in LDS and a second wavefront of the workgroup, the coder wave, works them off in order while the
+// model wave walks on (coder_wave below).  Entries, two words (A, M):
+//   A < 2^31           a plain hit of the windowed path: A = cumulative frequency | frequency << 16 (7 bits) |
+//                      PrevSuccess << 23 (model side only), M = the total; the coder wave turns the totals of a whole
+//                      batch into reciprocals at once, one per lane
+//   A = 2^31 | low     a step of the serial path: M = frequency | total << 16; a binary context's step is the same with
+//                      the total 2^14 (Model.cpp:415-432: range >>= TOT_BITS is the division by it)
+//   A = 0xFFFFFFFF     command M: stream start (header bytes), stream end (flush, size), exit
+enum : uint32_t { CQ_SIZE = 256u, CQ_SERIAL = 0x80000000u, CQ_CMD = 0xFFFFFFFFu, CQ_START = 1u, CQ_END = 2u, CQ_EXIT = 3u };
+
 FS_DEV void put_byte(Coder& m, uint32_t c) { if (m.outPos < m.outCap) fs_st8(m.out + m.outPos, c); m.outPos += (m.outPos < m.outCap); }
-FS_DEV void rc_normalize(Coder& m)
+FS_DEV void rc_shift_out(Coder& m)
 {
     while ((m.low ^ (m.low + m.range)) < TOP || (m.range < BOT && ((m.range = (0u - m.low) & (BOT - 1)), true))) {
         put_byte(m, m.low >> 24);
         m.range <<= 8; m.low <<= 8;
     }
 }
-FS_DEV void rc_encode(Coder& m) { m.low += m.rLow * (m.range /= m.rScale); m.range *= m.rHigh - m.rLow; }
+
+#if FS_WIDE
+// polls of a word the other wave of the workgroup writes
+#if defined(__HIP_DEVICE_COMPILE__)
+  #define FS_Q_LOAD(w) FS_UNI(__hip_atomic_load(&(w), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP))
+  #define FS_Q_STORE(w, v) do { if (FS_LANE() == 0) __hip_atomic_store(&(w), (uint32_t)(v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
+  #define FS_Q_IDLE() __builtin_amdgcn_s_sleep(8)
+#else
+  #define FS_Q_LOAD(w) fs_q_load(&(w))
+  FS_DEV uint32_t fs_q_load(const uint32_t* p) { FS_EMU_MEET(); const uint32_t v = *(const volatile uint32_t*)p; FS_EMU_MEET(); return v; }
+  #define FS_Q_STORE(w, v) do { FS_EMU_MEET(); if (FS_LANE() == 0) *(volatile uint32_t*)&(w) = (uint32_t)(v); FS_EMU_MEET(); } while (0)
+  #define FS_Q_IDLE() ((void)0)
+#endif
+// room for `need` more entries (the consumer frees a batch as soon as it has it in registers)
+FS_DEV void cq_room(Coder& m, uint32_t need)
+{
+    while (m.qTail + need - m.qHeadSeen > CQ_SIZE) { m.qHeadSeen = FS_Q_LOAD(m.sh->qHead); if (m.qTail + need - m.qHeadSeen > CQ_SIZE) FS_Q_IDLE(); }
+}
+FS_DEV void cq_push(Coder& m, uint32_t A, uint32_t M)
+{
+    cq_room(m, 1u);
+    if (FS_LANE() == 0) { m.sh->qA[m.qTail & (CQ_SIZE - 1u)] = A; m.sh->qM[m.qTail & (CQ_SIZE - 1u)] = M; }
+    m.qTail += 1u;
+    FS_Q_STORE(m.sh->qTail, m.qTail);
+}
+// L entries, one per lane
+FS_DEV void cq_push_lanes(Coder& m, uint32_t A, uint32_t M, uint32_t L)
+{
+    cq_room(m, L);
+    if ((uint32_t)FS_LANE() < L) { const uint32_t at = (m.qTail + (uint32_t)FS_LANE()) & (CQ_SIZE - 1u); m.sh->qA[at] = A; m.sh->qM[at] = M; }
+    m.qTail += L;
+    FS_Q_STORE(m.sh->qTail, m.qTail);
+}
+FS_DEV void cq_drain(Coder& m) { while (FS_Q_LOAD(m.sh->qHead) != m.qTail) FS_Q_IDLE(); m.qHeadSeen = m.qTail; }
+// the model wave's last word: the coder wave returns
+FS_DEV void cq_send_exit(FS_LDS Shared* sh, uint32_t qTail)
+{ Coder m; m.sh = sh; m.qTail = qTail; m.qHeadSeen = qTail - CQ_SIZE; cq_push(m, CQ_CMD, CQ_EXIT); }
+#else
+FS_DEV void cq_push(Coder&, uint32_t, uint32_t) {}
+FS_DEV void cq_send_exit(FS_LDS Shared*, uint32_t) {}
+FS_DEV void coder_wave(FS_LDS Shared*) {}
+#endif
+
+// after a coding step (Model.cpp:569, 580)
+FS_DEV void rc_normalize(Coder& m) { if (!m.queued) rc_shift_out(m); }
+// one step with (rLow, rHigh, rScale)
+FS_DEV void rc_encode(Coder& m)
+{
+    if (m.queued) { cq_push(m, CQ_SERIAL | m.rLow, (m.rHigh - m.rLow) | (m.rScale << 16)); return; }
+    m.low += m.rLow * (m.range /= m.rScale); m.range *= m.rHigh - m.rLow;
+}
+// a binary context's step (rcBinStart / rcBinCorrect0 / rcBinCorrect1): the symbol has probability bs / 2^14
+FS_DEV void rc_encode_bin(Coder& m, uint32_t bs, bool hit)
+{
+    if (m.queued) { cq_push(m, CQ_SERIAL | (hit ? 0u : bs), (hit ? bs : (uint32_t)BIN_SCALE - bs) | ((uint32_t)BIN_SCALE << 16)); return; }
+    const uint32_t tmp = bs * (m.range >>= TOT_BITS);
+    if (hit) m.range = tmp; else { m.low += tmp; m.range *= (uint32_t)BIN_SCALE - bs; }
+}
 
 // ---------------- model ----------------
 FS_DEV void clear_mask(Coder& m)
@@ -709,18 +783,17 @@ FS_DEV void encodeBinSymbol(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufR
     const uint32_t idx = FS_UNI(m.sh->QT[mc.oneFreq() - 1]) * 64u + NS2BSIndx(sufNs) + m.PrevSuccess + mc.flags() + (uint32_t)((m.RunLength >> 26) & 0x20);
     uint32_t bs = FS_LDS_RD(m.sh->BinSumm[idx]);
     m.BSumm = (int32_t)bs;
-    const uint32_t tmp = bs * (m.range >>= TOT_BITS);
+    rc_encode_bin(m, bs, (int)mc.oneSym() == symbol);
     bs -= (bs + ROUND) >> PERIOD_BITS;
     if ((int)mc.oneSym() == symbol) {
         prefetch_successor(m, c, mc.w1);
-        bs += INTERVAL; m.range = tmp;
+        bs += INTERVAL;
         const uint32_t nf = mc.oneFreq() + (mc.oneFreq() < 196);
         m.FoundState = rs; S_FREQ_SET(rs, nf);
         m.fsSym = mc.oneSym(); m.fsFreq = nf; m.fsSucc = mc.w1;
         mc.set_one_freq(nf);          // the caller's copy of the record follows the store
         m.RunLength++; m.PrevSuccess = 1;
     } else {
-        m.low += tmp; m.range *= (uint32_t)(BIN_SCALE - m.BSumm);
         m.sh->CharMask[mc.oneSym()] = (uint8_t)m.EscCount;
         m.NumMasked = m.PrevSuccess = 0; m.FoundState = 0;
     }
@@ -883,18 +956,31 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
 
 // Encode one member.  `arena` = ARENA_BYTES of 16-byte aligned scratch (content irrelevant),
 // returns the member size (clipped at outCap like the reference's ByteStream::Put).
+// queued (64-lane builds): the caller runs coder_wave() on a second wavefront of the workgroup; the member's size then
+// goes to *sizeOut from there and the return value is 0.
 FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uint32_t n, fs_gptr out, uint32_t outCap,
-                              uint32_t* restartsOut)
+                              uint32_t* restartsOut, bool queued = false, FS_GLOBAL uint32_t* sizeOut = nullptr, uint32_t qTail = 0, uint32_t* qTailOut = nullptr)
 {
     Coder m;
     m.hb = arena - 1; m.sh = sh; m.out = out; m.outCap = outCap; m.outPos = 0; sh->restarts = 0;
+    m.queued = queued ? 1u : 0u; m.qTail = qTail; m.qHeadSeen = qTail;
     m.NumMasked = 0; m.FoundState = 0; m.BSumm = 0; m.rLow = m.rHigh = m.rScale = 0; m.fsSym = m.fsFreq = m.fsSucc = 0;
     for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) sh->winStats[i] = 0u;
     for (uint32_t i = (uint32_t)FS_LANE(); i < 260u; i += FS_WAVE) sh->QT[i] = (uint8_t)QTable(i);
     // zero the 64-byte guard behind the heap: GlueFreeBlocks may read one stamp past the end
     for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) *(fs_gptr32)(arena + SA_SIZE + 4u * i) = 0u;
     FS_WAVE_SYNC();
-    put_byte(m, 0xCA); put_byte(m, MAX_ORDER);
+#if FS_WIDE
+    if (m.queued) {       // the coder wave has finished the previous stream: hand it this one's output buffer
+        cq_drain(m);
+        if (FS_LANE() == 0) {
+            const uint64_t o = (uint64_t)(uintptr_t)out, z = (uint64_t)(uintptr_t)sizeOut;
+            sh->qOutLo = (uint32_t)o; sh->qOutHi = (uint32_t)(o >> 32); sh->qOutCap = outCap; sh->qSizeLo = (uint32_t)z; sh->qSizeHi = (uint32_t)(z >> 32);
+        }
+        cq_push(m, CQ_CMD, CQ_START);
+    } else
+#endif
+    { put_byte(m, 0xCA); put_byte(m, MAX_ORDER); }
     m.low = 0; m.range = 0xFFFFFFFFu;
     StartModelRare(m);
     // input window: the next aligned dword is requested one step ahead of its first use
@@ -979,10 +1065,73 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
         else { UpdateModel(m, MinContext, mc, FS_UNI(sufCtx) != 0 && FS_UNI(sufCtx) == FS_UNI(mc.suff), sufRec); if (FS_UNI(m.EscCount) == 0) clear_mask(m); }
         rc_normalize(m); MinContext = m.MaxContext;
     }
-    for (int i = 0; i < 4; i++) { put_byte(m, m.low >> 24); m.low <<= 8; }
     if (restartsOut) *restartsOut = FS_UNI(m.sh->restarts);
+    if (m.queued) { cq_push(m, CQ_CMD, CQ_END); if (qTailOut) *qTailOut = m.qTail; return 0u; }
+    for (int i = 0; i < 4; i++) { put_byte(m, m.low >> 24); m.low <<= 8; }
     return m.outPos;
 }
+
+#if FS_WIDE
+// The coder wave of the two-wave form: works the entries of the ring off in order (see the range-coder section).  Runs
+// until the exit command; every wait is for the model wave, which never waits for anything but ring space.
+FS_DEV void coder_wave(FS_LDS Shared* sh)
+{
+    Coder m;                                                   // only the coder's own fields are used here
+    m.sh = sh; m.queued = 0; m.low = 0; m.range = 0xFFFFFFFFu; m.out = nullptr; m.outCap = 0; m.outPos = 0;
+    FS_GLOBAL uint32_t* sizeOut = nullptr;
+    const uint32_t lane = (uint32_t)FS_LANE();
+    uint32_t head = 0;
+    for (;;) {
+        uint32_t tail;
+        for (;;) { tail = FS_Q_LOAD(sh->qTail); if (tail != head) break; FS_Q_IDLE(); }
+        const uint32_t n = tail - head < (uint32_t)FS_WAVE ? tail - head : (uint32_t)FS_WAVE;
+        uint32_t eA = 0, eM = 0;
+        if (lane < n) { eA = sh->qA[(head + lane) & (CQ_SIZE - 1u)]; eM = sh->qM[(head + lane) & (CQ_SIZE - 1u)]; }
+        head += n;
+        FS_Q_STORE(sh->qHead, head);                            // the batch is in registers: its slots are free again
+        const bool special = lane < n && (eA >> 31) != 0u;
+        if (lane < n && !special) {                             // all the batch's reciprocals at once
+            const Recip rc = recip_make(eM);
+            eA = (eA & 0x00FFFFFFu) | ((rc.l - 1u) << 24); eM = rc.mul;
+        }
+        uint64_t todo = fs_ballot(special);
+        m.low = FS_UNI(m.low); m.range = FS_UNI(m.range); m.outPos = FS_UNI(m.outPos);
+        for (uint32_t i = 0; i < n;) {
+            const uint64_t ahead = todo >> i;
+            const uint32_t stop = ahead ? i + fs_ctz64(ahead) : n;
+            // plain hits [i, stop): Coder.hpp:13-17 with the division by multiplication, then Model.cpp:580
+            #define FS_CODE_ONE(A_, M_) do { \
+                const uint32_t t_ = fs_mulhi(m.range, M_), rr_ = (t_ + ((m.range - t_) >> 1)) >> (A_ >> 24); \
+                m.low += (A_ & 0xFFFFu) * rr_; m.range = rr_ * ((A_ >> 16) & 0x7Fu); \
+                if (__builtin_expect(m.range < TOP, 0)) rc_shift_out(m); } while (0)
+            while (i + 4u <= stop) {
+                const uint32_t A0 = FS_UNI(fs_readlane(eA, i)), M0 = FS_UNI(fs_readlane(eM, i)), A1 = FS_UNI(fs_readlane(eA, i + 1u)), M1 = FS_UNI(fs_readlane(eM, i + 1u));
+                const uint32_t A2 = FS_UNI(fs_readlane(eA, i + 2u)), M2 = FS_UNI(fs_readlane(eM, i + 2u)), A3 = FS_UNI(fs_readlane(eA, i + 3u)), M3 = FS_UNI(fs_readlane(eM, i + 3u));
+                FS_CODE_ONE(A0, M0); FS_CODE_ONE(A1, M1); FS_CODE_ONE(A2, M2); FS_CODE_ONE(A3, M3);
+                i += 4u;
+            }
+            for (; i < stop; ++i) { const uint32_t A0 = FS_UNI(fs_readlane(eA, i)), M0 = FS_UNI(fs_readlane(eM, i)); FS_CODE_ONE(A0, M0); }
+            #undef FS_CODE_ONE
+            if (i >= n) break;
+            const uint32_t A = FS_UNI(fs_readlane(eA, i)), M = FS_UNI(fs_readlane(eM, i));
+            ++i;
+            if (A != CQ_CMD) {                                  // a step of the serial path
+                const uint32_t rr = m.range / (M >> 16);
+                m.low += (A & 0xFFFFu) * rr; m.range = rr * (M & 0xFFFFu);
+                rc_shift_out(m);
+            } else if (M == CQ_START) {
+                const uint64_t o = (uint64_t)FS_LDS_RD(sh->qOutLo) | ((uint64_t)FS_LDS_RD(sh->qOutHi) << 32), z = (uint64_t)FS_LDS_RD(sh->qSizeLo) | ((uint64_t)FS_LDS_RD(sh->qSizeHi) << 32);
+                m.out = (fs_gptr)(uintptr_t)o; sizeOut = (FS_GLOBAL uint32_t*)(uintptr_t)z; m.outCap = FS_LDS_RD(sh->qOutCap); m.outPos = 0;
+                put_byte(m, 0xCA); put_byte(m, MAX_ORDER);
+                m.low = 0; m.range = 0xFFFFFFFFu;
+            } else if (M == CQ_END) {
+                for (int k = 0; k < 4; k++) { put_byte(m, m.low >> 24); m.low <<= 8; }
+                if (sizeOut) *sizeOut = m.outPos;
+            } else return;                                      // CQ_EXIT
+        }
+    }
+}
+#endif
 
 #undef HP
 #undef BL

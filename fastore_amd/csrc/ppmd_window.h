@@ -313,13 +313,17 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
             }
             *(fs_gptr32)HP(addr) = ns | (flags << 8) | (summ << 16);
         }
-        // every position: its slot, and the reciprocal of its total (all lanes at once)
-        uint32_t tA = 0, tM = 0;
-        if (inWin) {
-            const Recip rc = recip_make(m.sh->winM[lane]);
-            tA = m.sh->winA[lane] | ((rc.l - 1u) << 24); tM = rc.mul;
-        }
+        uint32_t tA = inWin ? m.sh->winA[lane] : 0u, tM = inWin ? m.sh->winM[lane] : 0u;
         FS_WAVE_SYNC();
+        if (m.queued) {                                            // two-wave form: the slots go to the coder wave as they are
+            cq_push_lanes(m, tA, tM, L);
+            FS_PROF_ACC(m.sh->winStats[12], tp);
+        } else {
+        // every position: its slot, and the reciprocal of its total (all lanes at once)
+        if (inWin) {
+            const Recip rc = recip_make(tM);
+            tA |= (rc.l - 1u) << 24; tM = rc.mul;
+        }
         FS_PROF_ACC(m.sh->winStats[12], tp);                           // write-back, reciprocals
 
         // the range coder, in stream order (Coder.hpp:13-17 + the normalisation of Model.cpp:580): scalar code
@@ -328,7 +332,7 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
         #define FS_CODE_ONE(A_, M_) do { \
             const uint32_t t_ = fs_mulhi(m.range, M_), rr_ = (t_ + ((m.range - t_) >> 1)) >> (A_ >> 24); \
             m.low += (A_ & 0xFFFFu) * rr_; m.range = rr_ * ((A_ >> 16) & 0x7Fu); \
-            if (__builtin_expect(m.range < TOP, 0)) rc_normalize(m); } while (0)
+            if (__builtin_expect(m.range < TOP, 0)) rc_shift_out(m); } while (0)
         uint32_t i_ = 0;
         while (i_ + 4u <= L) {
             const uint32_t A0 = FS_UNI(fs_readlane(tA, i_)), M0 = FS_UNI(fs_readlane(tM, i_)), A1 = FS_UNI(fs_readlane(tA, i_ + 1u)), M1 = FS_UNI(fs_readlane(tM, i_ + 1u));
@@ -338,6 +342,7 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
         }
         for (; i_ < L; ++i_) { const uint32_t A0 = FS_UNI(fs_readlane(tA, i_)), M0 = FS_UNI(fs_readlane(tM, i_)); FS_CODE_ONE(A0, M0); }
         #undef FS_CODE_ONE
+        }
         m.PrevSuccess = (FS_UNI(fs_readlane(tA, L - 1u)) >> 23) & 1u;
         m.MaxContext = FS_UNI(fs_readlane(succ, L - 1u));
         const uint32_t kl = FS_UNI(fs_readlane(key, L - 1u)), sl = FS_UNI(fs_readlane(sym, L - 1u));

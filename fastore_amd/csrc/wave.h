@@ -36,8 +36,10 @@
   // drags every value merged behind it into vector registers).  Via ballot: the result is a scalar mask compare, where
   // readfirstlane of the boolean would cost a round trip through a vector register.
   #define FS_UB(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
-  // order this wave's cooperative memory phase against the uniform code that follows it
-  #define FS_WAVE_SYNC() __syncthreads()
+  // order this wave's cooperative memory phase against the code that follows it.  The lanes of a wavefront execute in
+  // step and its LDS and vector-memory operations are processed in issue order, so this is a compiler-level fence; it must
+  // NOT be a workgroup barrier: in the two-wave form of the PPMd kernel the other wave of the workgroup never joins it
+  #define FS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
   #define FS_EMU_MEET() ((void)0)
 #elif defined(FS_SIMT_EMU)
   // TEST-ONLY: the 64-lane code paths on the host, 64 fibers in lock step (tests/emu/simt.h).  Never in the product.

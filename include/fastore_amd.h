@@ -49,11 +49,11 @@ typedef struct fsgpu_config {
     uint32_t min_consensus_size;        /* -c */
     int32_t device_id;                  /* HIP device ordinal */
     uint32_t host_threads;              /* worker threads of the host stages (0 = all cores) */
-    uint32_t max_waves;                 /* resident coder wavefronts (0 = 16 per CU, memory permitting) */
+    uint32_t max_waves;                 /* resident coder wavefronts (0 = 12 per CU = 3 per SIMD, memory permitting) */
     uint64_t batch_bases;               /* bases per device batch (0 = default) */
     uint32_t rank, world_size;          /* bin sharding: this context packs bins i with i % world_size == rank */
-    uint32_t pipeline_slices;           /* slices a batch is cut into so that host front end and device overlap (0 = default 4, 1 = off) */
-    uint32_t pipeline_lanes;            /* engine instances (HIP streams) whose kernels may overlap on the GPU (0 = one per slice, at most 4: more concurrent kernels stalled some GPUs) */
+    uint32_t pipeline_slices;           /* slices a batch is cut into so that host front end and device overlap (0 = default 8, 1 = off) */
+    uint32_t pipeline_lanes;            /* engine instances (HIP streams) whose kernels may overlap on the GPU (0 = one per slice, at most 8) */
     uint32_t reserved0, reserved1;
 } fsgpu_config;
 

@@ -4,6 +4,27 @@
 #include <stdlib.h>
 #include "../../fastore_amd/csrc/ppmd_core.h"
 
+// the two-wave form: wave 0 walks the model and queues the coding steps, wave 1 is the coder wave; several streams one
+// after the other through the same pair (the hand-over between streams is part of what is tested)
+extern "C" int simt_ppmd_encode_two_waves(int nStreams, const uint8_t* const* in, const size_t* n, uint8_t* const* out, const size_t* cap, uint32_t* sizes)
+{
+    uint8_t* arena = (uint8_t*)aligned_alloc(64, (fsppmd::ARENA_BYTES + 4096 + 63) & ~63ull);
+    fsppmd::Shared* sh = new fsppmd::Shared;
+    sh->qTail = sh->qHead = 0;
+    simt::run_waves(2, [&](int wave, int) {
+        if (wave == 1) { fsppmd::coder_wave(sh); return; }
+        uint32_t q = 0;
+        for (int s = 0; s < nStreams; ++s) {
+            uint32_t r0 = 0;
+            if (n[s] == 0) { if (simt::lane() == 0) sizes[s] = 0; continue; }
+            fsppmd::encode_member(arena, sh, in[s], (uint32_t)n[s], out[s], (uint32_t)cap[s], &r0, true, &sizes[s], q, &q);
+        }
+        fsppmd::cq_send_exit(sh, q);
+    });
+    delete sh; free(arena);
+    return 0;
+}
+
 extern "C" size_t simt_ppmd_encode(const uint8_t* in, size_t n, uint8_t* out, size_t cap, uint32_t* restarts, uint64_t* windowStats)
 {
     uint8_t* arena = (uint8_t*)aligned_alloc(64, (fsppmd::ARENA_BYTES + 4096 + 63) & ~63ull);
@@ -15,6 +36,7 @@ extern "C" size_t simt_ppmd_encode(const uint8_t* in, size_t n, uint8_t* out, si
         if (lane == 0) { result = r; rs = r0; }
     });
     if (restarts) *restarts = rs;
+    (void)0;
     if (windowStats) { for (int i = 0; i < 8; ++i) windowStats[i] = sh->winStats[i]; }
     delete sh; free(arena);
     return result;

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <vector>
 
 #if !defined(__x86_64__)
 #error "the SIMT emulation's context switch is written for x86-64"
@@ -36,81 +37,103 @@ simt_switch:
 namespace simt {
 
 namespace {
-struct State {
+struct Wave {
     void* sp[WAVE];
-    void* mainSp = nullptr;
-    uint8_t* stacks = nullptr;
-    const std::function<void(int)>* body = nullptr;
-    int cur = 0, live = 0;
+    bool alive[WAVE];
+    int live = WAVE;
+    int resume = 0;                 // lane that runs next when this wave gets its turn
     uint64_t slot[2][WAVE];
     uint32_t opCount[WAVE];
+};
+struct State {
+    std::vector<Wave> waves;
+    void* mainSp = nullptr;
+    uint8_t* stacks = nullptr;
+    const std::function<void(int, int)>* body = nullptr;
+    int curWave = 0, curLane = 0, liveWaves = 0;
 };
 thread_local State* g = nullptr;
 constexpr size_t kStack = 512 << 10;
 
-void next()
+// the running fiber gives way: to the next lane of its wave, or -- when every lane of the wave has arrived -- to the
+// next wave that still has lanes.  `dying`: the caller has finished and never comes back.
+void yield(bool dying)
 {
     State& s = *g;
-    const int me = s.cur;
-    if (s.live == 0) { simt_switch(&s.sp[me], s.mainSp); return; }
-    int n = me;
-    do { n = (n + 1) % WAVE; } while (s.sp[n] == nullptr && n != me);      // finished lanes have no context any more
-    if (n == me) return;
-    s.cur = n;
-    simt_switch(&s.sp[me], s.sp[n]);
+    const int w = s.curWave, me = s.curLane;
+    Wave& W = s.waves[w];
+    void* dead; void** save = dying ? &dead : &W.sp[me];
+    if (dying) { W.alive[me] = false; if (--W.live == 0) --s.liveWaves; }
+    if (s.liveWaves == 0) { simt_switch(save, s.mainSp); return; }
+    int nw = w, nl = -1;
+    if (W.live > 0) {
+        int n = me;
+        do { n = (n + 1) % WAVE; } while (!W.alive[n]);
+        const bool wrapped = n <= me;                 // every live lane of this wave has been through this point
+        if (!wrapped) nl = n;
+        else { W.resume = n; }
+    }
+    if (nl < 0) {                                     // hand over to the next wave with live lanes (possibly this one again)
+        do { nw = (nw + 1) % (int)s.waves.size(); } while (s.waves[nw].live == 0);
+        nl = s.waves[nw].resume;
+    }
+    if (nw == w && nl == me && !dying) return;
+    s.curWave = nw; s.curLane = nl;
+    simt_switch(save, s.waves[nw].sp[nl]);
 }
 
 void trampoline()
 {
     State& s = *g;
-    const int me = s.cur;
-    (*s.body)(me);
-    // uniform control flow: the lanes finish one after the other without meeting again
-    --s.live;
-    void* dead;
-    if (s.live == 0) { s.sp[me] = nullptr; simt_switch(&dead, s.mainSp); }
-    int n = me;
-    do { n = (n + 1) % WAVE; } while (n != me && (s.sp[n] == nullptr));
-    s.sp[me] = nullptr; s.cur = n;
-    simt_switch(&dead, s.sp[n]);
+    (*s.body)(s.curWave, s.curLane);
+    yield(true);
     abort();
 }
 }  // namespace
 
-void run(const std::function<void(int)>& body)
+void run_waves(int waves, const std::function<void(int, int)>& body)
 {
-    State st; memset(st.sp, 0, sizeof st.sp); memset(st.opCount, 0, sizeof st.opCount);
-    st.stacks = (uint8_t*)mmap(nullptr, kStack * WAVE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    State st; st.waves.resize(waves);
+    const size_t fibers = (size_t)waves * WAVE;
+    st.stacks = (uint8_t*)mmap(nullptr, kStack * fibers, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (st.stacks == (uint8_t*)MAP_FAILED) { perror("simt: mmap"); abort(); }
-    st.body = &body; st.live = WAVE;
-    for (int l = 0; l < WAVE; ++l) {
-        // initial frame: six callee-saved registers, then the return address; the stack is 16-byte aligned at the
-        // trampoline's first instruction as after a call (rsp % 16 == 8)
-        uint64_t* top = (uint64_t*)(st.stacks + kStack * (l + 1));
-        top -= 1;                                   // alignment slot
-        *--top = (uint64_t)(uintptr_t)&trampoline;  // ret target
-        for (int k = 0; k < 6; ++k) *--top = 0;
-        st.sp[l] = top;
+    st.body = &body; st.liveWaves = waves;
+    for (int w = 0; w < waves; ++w) {
+        Wave& W = st.waves[w];
+        memset(W.opCount, 0, sizeof W.opCount);
+        for (int l = 0; l < WAVE; ++l) {
+            // initial frame: six callee-saved registers, then the return address; the stack is 16-byte aligned at the
+            // trampoline's first instruction as after a call (rsp % 16 == 8)
+            uint64_t* top = (uint64_t*)(st.stacks + kStack * ((size_t)w * WAVE + l + 1));
+            top -= 1;                                   // alignment slot
+            *--top = (uint64_t)(uintptr_t)&trampoline;  // ret target
+            for (int k = 0; k < 6; ++k) *--top = 0;
+            W.sp[l] = top; W.alive[l] = true;
+        }
     }
     State* prev = g; g = &st;
-    st.cur = 0;
-    simt_switch(&st.mainSp, st.sp[0]);
+    st.curWave = 0; st.curLane = 0;
+    simt_switch(&st.mainSp, st.waves[0].sp[0]);
     g = prev;
-    munmap(st.stacks, kStack * WAVE);
+    munmap(st.stacks, kStack * fibers);
 }
 
-int lane() { return g->cur; }
-void barrier() { next(); }
+void run(const std::function<void(int)>& body) { run_waves(1, [&](int, int lane) { body(lane); }); }
+
+int lane() { return g->curLane; }
+int wave() { return g->curWave; }
+void barrier() { yield(false); }
 
 // every primitive: publish, meet, read.  The slots alternate between two sets so that a lane that runs ahead into the
 // next primitive cannot overwrite a value a slower lane has still to read.
 static inline uint64_t* publish(uint64_t v)
 {
     State& s = *g;
-    const int me = s.cur;
-    uint64_t* set = s.slot[s.opCount[me]++ & 1u];
+    Wave& W = s.waves[s.curWave];
+    const int me = s.curLane;
+    uint64_t* set = W.slot[W.opCount[me]++ & 1u];
     set[me] = v;
-    next();
+    yield(false);
     return set;
 }
 

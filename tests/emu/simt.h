@@ -18,6 +18,11 @@ namespace simt {
 enum { WAVE = 64 };
 // run `body(lane)` on WAVE fibers in lock step; returns when all have returned
 void run(const std::function<void(int)>& body);
+// several waves of one workgroup side by side (they share memory, e.g. an LDS image): `body(wave, lane)`.  Each wave is
+// in lock step with itself only; after every meeting point of a wave the other waves get their turn, so a wave that
+// polls for another one's progress (through a primitive or barrier() per poll) cannot starve it.
+void run_waves(int waves, const std::function<void(int, int)>& body);
+int wave();
 int lane();
 void barrier();                                 // all lanes meet here
 uint64_t ballot(bool p);

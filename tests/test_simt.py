@@ -20,6 +20,7 @@ def simt():
     lib = ctypes.CDLL(out)
     lib.simt_ppmd_encode.restype = ctypes.c_size_t
     lib.simt_ppmd_encode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    lib.simt_ppmd_encode_two_waves.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5
     return lib
 
 
@@ -80,3 +81,26 @@ def test_reference_vectors_through_the_64_lane_paths(simt):
             continue
         got, _ = encode(simt, data)
         assert got == open(os.path.join(VECTORS, nme + ".out"), "rb").read(), nme
+
+
+def encode_two_waves(lib, streams):
+    """the two-wave form: a model wave and a coder wave (64 fibers each) with the coding steps queued through LDS; the
+    streams go through the same pair of waves one after the other, as the items of a launch do"""
+    k = len(streams)
+    pads = [s + b"\0" * 32 for s in streams]
+    ins = (ctypes.c_char_p * k)(*pads); lens = (ctypes.c_size_t * k)(*[len(s) for s in streams])
+    bufs = [ctypes.create_string_buffer(2 * len(s) + 4096) for s in streams]
+    outs = (ctypes.c_void_p * k)(*[ctypes.addressof(b) for b in bufs]); caps = (ctypes.c_size_t * k)(*[len(b) for b in bufs])
+    sizes = (ctypes.c_uint32 * k)()
+    lib.simt_ppmd_encode_two_waves(k, ins, lens, outs, caps, sizes)
+    return [bufs[i].raw[:sizes[i]] for i in range(k)]
+
+
+def test_two_wave_form_model_wave_and_coder_wave(simt, oracle):
+    rng = np.random.default_rng(9)
+    streams = [quality(120_000, 2), b"", rng.choice(np.frombuffer(b"ACGTN.", dtype=np.uint8), 20_000).tobytes(), b"Q",
+               rng.integers(0, 256, 6_000).astype(np.uint8).tobytes(), rng.integers(0, 9, 15_000).astype(np.uint8).tobytes(),
+               quality(777, 5), bytes(range(40)) * 300, quality(64, 6), quality(65, 7)]
+    got = encode_two_waves(simt, streams)
+    for i, (s, g) in enumerate(zip(streams, got)):
+        assert g == (oracle_ppmd(oracle, s) if s else b""), i
