@@ -13,8 +13,8 @@ Workload (BASELINE.json configs[1]): ONE library of 10 M x 150 b
 `--paired` packs ONE library of --reads pairs instead (configs[2] scaled by the stated factor).
 
 --gpus N > 1: the N ranks pack disjoint shards (LPT over the .bmeta per-signature totals) of the SAME library
-into one archive; the only collective is an all-gather of the block sizes over RCCL, every rank writes its blocks
-at its own offsets ("scaling": "strong").  `--weak` makes every rank pack the whole library into its own archive.
+into one archive; the only collective is an all-reduce of the block-size table (one u64 per block) over RCCL, every
+rank writes its blocks at its own offsets ("scaling": "strong").  `--weak` makes every rank pack the whole library into its own archive.
 
 cpu_baseline = the real reference fastore_pack (oracle/_ref) on the same library at -t min(32, cores) (and at
 -t1 with --cpu-t1, ~4 min); parity = every block of the product's archive against the reference's block of the same
@@ -154,7 +154,7 @@ def main():
 
     def step():
         if sharded:
-            shard.pack_sharded(packer, binned, out, dist)
+            shard.pack_sharded(packer, binned, out, dist, device=torch.device("cuda", local))
         else:
             packer.pack_file(binned, out)
 
@@ -202,7 +202,7 @@ def main():
                                       "" if not args.paired else " (configs[2] scaled by %g)" % (args.reads / 100e6)),
                        "fastq_bytes": fastq_bytes, "pack_flags": " ".join(PACK_FLAGS),
                        "parallelism": ("1 GPU" if world == 1 else ("%d ranks, each the whole library (replicas)" % world if args.weak else
-                                       "%d ranks pack disjoint LPT shards of the library's bins; all-gather of block sizes over RCCL; no data-path collective" % world))},
+                                       "%d ranks pack disjoint LPT shards of the library's bins; one all-reduce of the block-size table over RCCL; no block bytes cross ranks" % world))},
             "roofline": {"bound": "hbm", "kernel": "fs_encode_streams", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic,
                          "traffic_unit": "bytes per launch (profiles/r02_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)",

@@ -101,6 +101,9 @@ def load_library(path=None):
         f.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
     lib.fsgpu_compress_bins.argtypes = [C.c_void_p, C.POINTER(BinBatch), C.POINTER(BlockBatch)]
     lib.fsgpu_merge_parts.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_size_t]
+    lib.fsgpu_shard_pack.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t)]
+    lib.fsgpu_shard_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.fsgpu_shard_write.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
     if path is None:
         _lib = lib
     return lib
@@ -215,6 +218,22 @@ class Packer:
         a = (C.c_char_p * n)(*[p.encode() for p in in_prefixes]); b = (C.c_char_p * n)(*[p.encode() for p in out_prefixes])
         self._check(self.lib.fsgpu_pack_files(self.ctx, n, a, b, int(verbose)))
         return self.stats()
+
+    def shard_pack(self, in_prefix):
+        """code this rank's LPT share of the library's bins and hold the blocks; returns (signatures, own sizes) of the whole
+        archive's block table in its final order (numpy uint32 / uint64 arrays; sizes are 0 for the other ranks' blocks)"""
+        import numpy as np
+        n = C.c_size_t(0)
+        self._check(self.lib.fsgpu_shard_pack(self.ctx, in_prefix.encode(), C.byref(n)))
+        sigs = np.zeros(n.value, dtype=np.uint32); sizes = np.zeros(n.value, dtype=np.uint64)
+        self._check(self.lib.fsgpu_shard_table(self.ctx, sigs.ctypes.data, sizes.ctypes.data, n.value))
+        return sigs, sizes
+
+    def shard_write(self, out_prefix, all_sizes):
+        """write the held blocks at their offsets (all_sizes = element-wise sum of every rank's size table)"""
+        import numpy as np
+        a = np.ascontiguousarray(all_sizes, dtype=np.uint64)
+        self._check(self.lib.fsgpu_shard_write(self.ctx, out_prefix.encode(), a.ctypes.data, len(a)))
 
     def set_archive_params(self, config, header_fields=b"", quality_codebook=b""):
         """Archive-level parameters for compress_bins(): raw BinModuleConfig, serialized read-id field table, QVZ section."""

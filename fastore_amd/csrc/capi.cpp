@@ -425,6 +425,30 @@ int fsgpu_pack_file(fsgpu_ctx* ctx, const char* inPrefix, const char* outPrefix,
     FS_GUARD(ctx, ctx->c.packFiles({std::string(inPrefix)}, {std::string(outPrefix)}, verbose));
 }
 
+int fsgpu_shard_pack(fsgpu_ctx* ctx, const char* inPrefix, size_t* nBlocks)
+{
+    if (!ctx || !inPrefix || !nBlocks) return FSGPU_ERR_ARG;
+    FS_GUARD(ctx, { ctx->c.shardPack(inPrefix); *nBlocks = ctx->c.shard.order.size(); });
+}
+
+int fsgpu_shard_table(const fsgpu_ctx* ctx, uint32_t* signatures, uint64_t* sizes, size_t nBlocks)
+{
+    if (!ctx || !signatures || !sizes) return FSGPU_ERR_ARG;
+    fsgpu_ctx* c = const_cast<fsgpu_ctx*>(ctx);
+    FS_GUARD(c, {
+        std::vector<uint32_t> sg; std::vector<uint64_t> sz;
+        ctx->c.shardTable(sg, sz);
+        if (sg.size() != nBlocks) throw std::runtime_error("block table size mismatch");
+        std::copy(sg.begin(), sg.end(), signatures); std::copy(sz.begin(), sz.end(), sizes);
+    });
+}
+
+int fsgpu_shard_write(fsgpu_ctx* ctx, const char* outPrefix, const uint64_t* allSizes, size_t nBlocks)
+{
+    if (!ctx || !outPrefix || !allSizes) return FSGPU_ERR_ARG;
+    FS_GUARD(ctx, ctx->c.shardWrite(outPrefix, std::vector<uint64_t>(allSizes, allSizes + nBlocks)));
+}
+
 int fsgpu_pack_files(fsgpu_ctx* ctx, size_t n, const char* const* inPrefixes, const char* const* outPrefixes, int verbose)
 {
     if (!ctx || !n || !inPrefixes || !outPrefixes) return FSGPU_ERR_ARG;

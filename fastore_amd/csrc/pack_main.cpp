@@ -6,7 +6,7 @@
 // one: a process that may have initialised the GPU -- e.g. under a preloaded profiler -- must not be replaced).
 // New flags: -g<device> (HIP device ordinal), -j<n> (host threads beyond the reference's -t limit of 64),
 // -R<rank>/-N<world> (bin sharding: this process packs its share into <out>.part<rank>), -G<n> (one process, n GPUs:
-// devices g .. g+n-1 each pack their share of the bins side by side, then the parts are merged in -t1 order).
+// devices g .. g+n-1 each pack their LPT share of the bins side by side and write their blocks into the one archive).
 #include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -102,18 +102,36 @@ int main(int argc, char** argv)
             ctxs[r] = fsgpu_create(&c);
             if (!ctxs[r]) { fprintf(stderr, "Error: %s\n", fsgpu_create_error()); for (fsgpu_ctx* x : ctxs) if (x) fsgpu_destroy(x); return 255; }
         }
-        std::vector<int> rcs(gpus, 0); std::vector<std::thread> th;
-        // -v: progress from the first context only; the StreamSizes statistics are taken from the merged archive below
-        for (int r = 0; r < gpus; ++r) th.emplace_back([&, r]() { rcs[r] = fsgpu_pack_file(ctxs[r], in.c_str(), out.c_str(), (r == 0 && verbose) ? 2 : 0); });
+        // every context codes its LPT share of the bins and holds the blocks; the size tables are summed here (between
+        // processes that sum is the one collective, fastore_amd/shard.py); then every context writes its blocks at their
+        // places in the one archive.  No part files, no block bytes between devices.
+        std::vector<int> rcs(gpus, 0); std::vector<std::thread> th; std::vector<size_t> nb(gpus, 0);
+        for (int r = 0; r < gpus; ++r) th.emplace_back([&, r]() { rcs[r] = fsgpu_shard_pack(ctxs[r], in.c_str(), &nb[r]); });
         for (auto& t : th) t.join();
+        th.clear();
         int bad = -1; for (int r = 0; r < gpus; ++r) if (rcs[r] != 0 && bad < 0) bad = r;
+        std::vector<uint64_t> all;
+        if (bad < 0) {
+            all.assign(nb[0], 0);
+            std::vector<uint32_t> sg(nb[0]); std::vector<uint64_t> sz(nb[0]);
+            for (int r = 0; r < gpus && bad < 0; ++r) {
+                if (nb[r] != nb[0] || fsgpu_shard_table(ctxs[r], sg.data(), sz.data(), nb[0]) != 0) { bad = r; break; }
+                for (size_t i = 0; i < nb[0]; ++i) all[i] += sz[i];
+            }
+        }
+        if (bad < 0) {
+            for (int r = 0; r < gpus; ++r) th.emplace_back([&, r]() { rcs[r] = fsgpu_shard_write(ctxs[r], out.c_str(), all.data(), all.size()); });
+            for (auto& t : th) t.join();
+            for (int r = 0; r < gpus; ++r) if (rcs[r] != 0 && bad < 0) bad = r;
+        }
         if (bad >= 0) fprintf(stderr, "Error: %s\n", fsgpu_last_error(ctxs[bad]));
         for (fsgpu_ctx* x : ctxs) fsgpu_destroy(x);
-        auto dropParts = [&]() { for (int r = 0; r < gpus; ++r) { const std::string b = out + ".part" + std::to_string(r); remove((b + ".cdata").c_str()); remove((b + ".cmeta").c_str()); } };
-        if (bad >= 0) { dropParts(); return 255; }
-        char err[256] = {0};
-        if (fsgpu_merge_parts(out.c_str(), (uint32_t)gpus, err, sizeof err) != 0) { fprintf(stderr, "Error: %s\n", err); dropParts(); return 255; }
-        if (verbose && fsgpu_print_stream_sizes(out.c_str(), err, sizeof err) != 0) { fprintf(stderr, "Error: %s\n", err); return 255; }
+        if (bad >= 0) { remove((out + ".cdata").c_str()); remove((out + ".cmeta").c_str()); return 255; }
+        if (verbose) {
+            char err[256] = {0};
+            fprintf(stderr, "\rParts processed: %zu (100%%) \n", all.size());
+            if (fsgpu_print_stream_sizes(out.c_str(), err, sizeof err) != 0) { fprintf(stderr, "Error: %s\n", err); return 255; }
+        }
         return 0;
     }
     fsgpu_ctx* ctx = fsgpu_create(&cfg);

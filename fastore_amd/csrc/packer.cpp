@@ -6,10 +6,12 @@
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <map>
 #include <memory>
 #include <chrono>
 #include <stdexcept>
 #include <thread>
+#include <fcntl.h>
 #include <unistd.h>
 #include "bitio.h"
 #include "hostcoders.h"
@@ -93,6 +95,10 @@ void serializeHeaderFields(const HeaderStats& head, bool pairedEnd, std::vector<
 
 // ------------------------------------------------------------------------------------------------
 ArchiveWriter::~ArchiveWriter() { if (meta_) fclose(meta_); if (data_) fclose(data_); }
+ArchiveWriter::ArchiveWriter(ArchiveWriter&& o)
+    : sizeStats_(o.sizeStats_), prefix_(std::move(o.prefix_)), meta_(o.meta_), data_(o.data_), inMemory_(o.inMemory_), mem_(std::move(o.mem_)), held_(std::move(o.held_)),
+      conf_(o.conf_), sizes_(std::move(o.sizes_)), sigs_(std::move(o.sigs_)), dataBytes_(o.dataBytes_)
+{ o.meta_ = nullptr; o.data_ = nullptr; }
 
 void StreamSizeStats::start(const ArchiveTypeRaw& type, const MinimizerParametersRaw& mp)
 {
@@ -148,17 +154,58 @@ void ArchiveWriter::start(const std::string& prefix, const BinModuleConfigRaw& c
     sizeStats_.start(cfg.archiveType, cfg.minimizer);
 }
 
+std::vector<uint32_t> shardOwners(const std::vector<uint64_t>& weights, uint32_t world)
+{
+    const uint32_t n = (uint32_t)weights.size();
+    std::vector<uint32_t> owner(n, 0), idx(n);
+    if (world <= 1) return owner;
+    for (uint32_t i = 0; i < n; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return weights[a] > weights[b]; });
+    std::vector<uint64_t> load(world, 0);
+    for (uint32_t i : idx) {
+        uint32_t best = 0;
+        for (uint32_t r = 1; r < world; ++r) if (load[r] < load[best]) best = r;
+        owner[i] = best; load[best] += weights[i] + 1;          // (+1: empty weights still spread)
+    }
+    return owner;
+}
+
+void ArchiveWriter::startInMemory(const BinModuleConfigRaw& cfg)
+{
+    inMemory_ = true; prefix_ = "(held)";
+    memset(&conf_, 0, sizeof conf_);
+    conf_.archType = cfg.archiveType; conf_.minParams = cfg.minimizer;
+    conf_.quaParams.method = cfg.quaParams.method; conf_.quaParams.binaryThreshold = cfg.quaParams.binaryThreshold;
+    conf_.quaParams.qvzOpts.verbose = cfg.quaParams.qvzOpts.verbose; conf_.quaParams.qvzOpts.stats = cfg.quaParams.qvzOpts.stats;
+    conf_.quaParams.qvzOpts.uncompressed = cfg.quaParams.qvzOpts.uncompressed; conf_.quaParams.qvzOpts.distortion = cfg.quaParams.qvzOpts.distortion;
+    conf_.quaParams.qvzOpts.D = cfg.quaParams.qvzOpts.D;
+    sizeStats_.start(cfg.archiveType, cfg.minimizer);
+}
+
 void ArchiveWriter::writeBlock(const uint8_t* data, uint64_t size, uint32_t signature)
 {
     sizes_.push_back(size); sigs_.push_back(signature);
     sizeStats_.addBlock(data, size, signature);
+    if (inMemory_) { held_.push_back(HeldBlock{signature, (uint64_t)mem_.size(), size}); mem_.insert(mem_.end(), data, data + size); dataBytes_ += size; return; }
     if (fwrite(data, 1, size, data_) != size) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
     dataBytes_ += size;
 }
 
 // every write is checked: a full disk must end in "Error: Cannot write ..." (FSGPU_ERR_IO), not in a truncated archive
+void ArchiveWriter::writeMeta(const std::string& prefix, const std::vector<uint64_t>& sizes, const std::vector<uint32_t>& sigs, const HeaderStats& head, const QvzModel& qvz)
+{
+    ArchiveWriter w;
+    w.prefix_ = prefix; w.conf_ = conf_; w.sizes_ = sizes; w.sigs_ = sigs;
+    w.meta_ = fopen((prefix + ".cmeta").c_str(), "wb");
+    if (!w.meta_) throw std::runtime_error("Cannot open file: " + prefix + ".cmeta");
+    static const uint8_t zeros[24] = {0};
+    if (fwrite(zeros, 1, 24, w.meta_) != 24) throw std::runtime_error("Cannot write " + prefix + ".cmeta");
+    w.finish(head, qvz);
+}
+
 void ArchiveWriter::finish(const HeaderStats& head, const QvzModel& qvz)
 {
+    if (inMemory_) return;                                 // held blocks: shardWrite places them
     const std::string what = "Cannot write " + prefix_ + ".cmeta";
     auto put = [&](const void* p, size_t n) { if (n && fwrite(p, 1, n, meta_) != n) throw std::runtime_error(what); };
     const uint64_t footerOffset = 24;
@@ -185,7 +232,7 @@ void ArchiveWriter::finish(const HeaderStats& head, const QvzModel& qvz)
     FILE* m = meta_; meta_ = nullptr;
     if (fclose(m) != 0) throw std::runtime_error(what);
     FILE* d = data_; data_ = nullptr;
-    if (fclose(d) != 0) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
+    if (d && fclose(d) != 0) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -517,7 +564,7 @@ void Context::compressRawBlock(Batch& batch, const ArchiveParams& arch, std::vec
 }
 
 // ------------------------------------------------------------------------------------------------
-void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::vector<std::string>& outPrefixes, int verbose)
+void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::vector<std::string>& outPrefixes, int verbose, bool hold)
 {
     const double tStart = nowMs();
     const size_t nLibs = inPrefixes.size();
@@ -540,11 +587,16 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         Lib& L = *libs[l];
         L.bf.open(inPrefixes[l], par.minBinSize);
         archives[l].cfg = L.bf.config(); archives[l].head = L.bf.headData(); archives[l].qvz = L.bf.qvz();
-        L.aw.start(world > 1 ? outPrefixes[l] + ".part" + std::to_string(rank) : outPrefixes[l], archives[l].cfg);
+        if (hold) L.aw.startInMemory(archives[l].cfg);
+        else L.aw.start(world > 1 ? outPrefixes[l] + ".part" + std::to_string(rank) : outPrefixes[l], archives[l].cfg);
     });
+    if (hold && nLibs != 1) throw std::runtime_error("a held (bin-sharded) pack takes one library");
     for (size_t l = 0; l < nLibs; ++l) {
         const auto& stdSigs = libs[l]->bf.stdSignatures();
-        for (uint32_t i = 0; i < stdSigs.size(); ++i) if (i % world == rank) work.push_back(Work{(uint32_t)l, stdSigs[i]});
+        std::vector<uint64_t> w(stdSigs.size());
+        for (uint32_t i = 0; i < stdSigs.size(); ++i) w[i] = libs[l]->bf.bins().at(stdSigs[i]).totalRecordsCount;
+        const std::vector<uint32_t> owner = shardOwners(w, world);
+        for (uint32_t i = 0; i < stdSigs.size(); ++i) if (owner[i] == rank) work.push_back(Work{(uint32_t)l, stdSigs[i]});
     }
     haveArchive = true;
     // block 0 of every library (rank 0): merged small bins + N bin, compressed on host cores.  Its threads start when the
@@ -705,6 +757,15 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
     { std::lock_guard<std::mutex> lk(gateMx); hostTasksDone = true; }          // no standard bins at all: block 0 starts here
     gateCv.notify_all();
     if (closer.joinable()) closer.join();
+    if (hold) {       // the blocks stay with the context; the archive's block table in its final order: block 0, then ascending signature
+        shard.order.clear();
+        Lib& L = *libs[0];
+        if (!L.bf.smallSignatures().empty() || L.bf.hasNBin()) shard.order.push_back(L.bf.nSignature());
+        for (uint32_t sg : L.bf.stdSignatures()) shard.order.push_back(sg);
+        shard.arch = archives[0];
+        shard.aw.reset(new ArchiveWriter(std::move(L.aw)));
+        shard.have = true;
+    }
     {   // whatever is still mapped (no standard bins on this rank): one task per library
         const double tc = nowMs();
         parallelFor((uint32_t)nLibs, std::min<uint32_t>((uint32_t)nLibs, hostThreads), [&](uint32_t l, uint32_t) { libs[l].reset(); });
@@ -712,6 +773,53 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
     }
     stats.total_ms += nowMs() - tStart;
     if (getenv("FS_TRACE")) fprintf(stderr, "[trace] packFiles total %.1f ms\n", nowMs() - tStart);
+}
+
+// ------------------------------------------------------------------------------------------------
+void Context::shardPack(const std::string& inPrefix)
+{
+    shard = Shard();
+    packFiles({inPrefix}, {std::string("(held)")}, 0, true);
+}
+
+void Context::shardTable(std::vector<uint32_t>& sigs, std::vector<uint64_t>& sizes) const
+{
+    if (!shard.have) throw std::runtime_error("no held pack: call the shard pack first");
+    sigs = shard.order; sizes.assign(sigs.size(), 0);
+    std::map<uint32_t, size_t> place;
+    for (size_t i = 0; i < sigs.size(); ++i) place[sigs[i]] = i;
+    for (const ArchiveWriter::HeldBlock& b : shard.aw->heldBlocks()) {
+        const auto it = place.find(b.signature);
+        if (it == place.end()) throw std::runtime_error("held block without a place in the archive");
+        sizes[it->second] = b.size;
+    }
+}
+
+void Context::shardWrite(const std::string& outPrefix, const std::vector<uint64_t>& allSizes)
+{
+    if (!shard.have) throw std::runtime_error("no held pack: call the shard pack first");
+    std::vector<uint32_t> sigs; std::vector<uint64_t> own;
+    shardTable(sigs, own);
+    if (allSizes.size() != sigs.size()) throw std::runtime_error("size table does not match the archive's block table");
+    std::vector<uint64_t> off(sigs.size() + 1, 0);
+    for (size_t i = 0; i < sigs.size(); ++i) { if (own[i] && own[i] != allSizes[i]) throw std::runtime_error("size table disagrees with the held blocks"); off[i + 1] = off[i] + allSizes[i]; }
+    // O_CREAT without O_TRUNC and positional writes: the ranks need no order among themselves (nobody cuts the file below
+    // its final size; rank 0 cuts a longer file of an earlier run down to it)
+    const std::string name = outPrefix + ".cdata";
+    const int fd = ::open(name.c_str(), O_CREAT | O_RDWR, 0644);
+    if (fd < 0) throw std::runtime_error("Cannot open file: " + name);
+    bool ok = true;
+    std::map<uint32_t, size_t> place;
+    for (size_t i = 0; i < sigs.size(); ++i) place[sigs[i]] = i;
+    for (const ArchiveWriter::HeldBlock& b : shard.aw->heldBlocks()) {
+        const uint8_t* p = shard.aw->heldData() + b.offset; uint64_t left = b.size, at = off[place.at(b.signature)];
+        while (ok && left) { const ssize_t w = ::pwrite(fd, p, left, (off_t)at); if (w <= 0) { ok = false; break; } p += w; left -= (uint64_t)w; at += (uint64_t)w; }
+    }
+    if (cfg.rank == 0) ok = ok && ::ftruncate(fd, (off_t)off[sigs.size()]) == 0;
+    if (::close(fd) != 0 || !ok) throw std::runtime_error("Cannot write " + name);
+    stats.cdata_bytes += shard.aw->dataBytes();
+    if (cfg.rank == 0) shard.aw->writeMeta(outPrefix, allSizes, sigs, shard.arch.head, shard.arch.qvz);
+    shard = Shard();
 }
 
 }  // namespace fs

@@ -29,10 +29,24 @@ private:
 };
 
 // .cmeta/.cdata writer: ArchiveFileWriter (fastore_pack/ArchiveFile.cpp:21-204)
+// Bins -> ranks for one library packed by several GPUs: longest-processing-time-first over the per-signature
+// record totals of the .bmeta footer (fastore_bin/BinFile.h:57-79) -- heaviest bin to the least loaded rank, ties to
+// the lower index / rank.  A pure function of the footer: every rank computes the same table, nothing is exchanged.
+std::vector<uint32_t> shardOwners(const std::vector<uint64_t>& weights, uint32_t world);
+
 class ArchiveWriter {
 public:
+    ArchiveWriter() = default;
+    ArchiveWriter(ArchiveWriter&& o);
     ~ArchiveWriter();
     void start(const std::string& prefix, const BinModuleConfigRaw& cfg);
+    // keep the blocks in memory instead (bin-sharded packs: the blocks' places in the archive depend on the other ranks' sizes)
+    void startInMemory(const BinModuleConfigRaw& cfg);
+    struct HeldBlock { uint32_t signature; uint64_t offset, size; };
+    const std::vector<HeldBlock>& heldBlocks() const { return held_; }
+    const uint8_t* heldData() const { return mem_.data(); }
+    // .cmeta of an archive whose blocks (sizes, signatures in archive order) were written by several ranks
+    void writeMeta(const std::string& prefix, const std::vector<uint64_t>& sizes, const std::vector<uint32_t>& sigs, const HeaderStats& head, const QvzModel& qvz);
     void writeBlock(const uint8_t* data, uint64_t size, uint32_t signature);
     void finish(const HeaderStats& head, const QvzModel& qvz);
     uint64_t dataBytes() const { return dataBytes_; }
@@ -41,6 +55,7 @@ private:
     StreamSizeStats sizeStats_;
     std::string prefix_;
     FILE *meta_ = nullptr, *data_ = nullptr;
+    bool inMemory_ = false; std::vector<uint8_t> mem_; std::vector<HeldBlock> held_;
     ArchiveConfigRaw conf_{};
     std::vector<uint64_t> sizes_;
     std::vector<uint32_t> sigs_;
@@ -83,7 +98,15 @@ struct Context {
     void compressRawBlock(Batch& batch, const ArchiveParams& arch, std::vector<uint8_t>& out) const;
     // `fastore_pack e` for one or several libraries; bins of all libraries share the device batches
     // verbose: 0 quiet, 1 = the reference's -v (progress on stderr, StreamSizes on stdout), 2 = progress only
-    void packFiles(const std::vector<std::string>& inPrefixes, const std::vector<std::string>& outPrefixes, int verbose);
+    void packFiles(const std::vector<std::string>& inPrefixes, const std::vector<std::string>& outPrefixes, int verbose, bool hold = false);
+    // bin-sharded pack of ONE library, in three steps (the middle one is the caller's: an all-gather / all-reduce of the
+    // size table over RCCL, or a sum over the contexts of one process): shardPack codes this rank's bins and holds the
+    // blocks; shardTable lists every block of the archive in its final (-t1) order with this rank's sizes (0 elsewhere);
+    // shardWrite puts the held blocks at their offsets in <out>.cdata (rank 0 also writes <out>.cmeta).
+    void shardPack(const std::string& inPrefix);
+    void shardTable(std::vector<uint32_t>& sigs, std::vector<uint64_t>& sizes) const;
+    void shardWrite(const std::string& outPrefix, const std::vector<uint64_t>& allSizes);
+    struct Shard { std::unique_ptr<ArchiveWriter> aw; std::vector<uint32_t> order; ArchiveParams arch; bool have = false; } shard;
 };
 
 void parseHeaderFields(const uint8_t* p, size_t n, bool pairedEnd, HeaderStats& out);

@@ -165,7 +165,22 @@ const void* fsgpu_library_config(const fsgpu_library* lib, size_t* bytes);      
 const uint8_t* fsgpu_library_header_fields(const fsgpu_library* lib, size_t* bytes);       /* NULL/0 without read ids */
 const uint8_t* fsgpu_library_quality_codebook(const fsgpu_library* lib, size_t* bytes);    /* NULL/0 unless --lossy */
 
-/* Bin-sharded packing of one library by `world_size` contexts (one per GPU; fsgpu_config.rank / world_size): every
+/* Bin-sharded packing of ONE library by `world_size` contexts (one per GPU; fsgpu_config.rank / world_size) WITHOUT part
+ * files.  Every context takes its share of the standard bins -- longest-processing-time-first over the per-signature
+ * record totals of the .bmeta footer (fastore_bin/BinFile.h:57-79), a pure function of the footer, so nothing is exchanged
+ * for it; the merged small-bins/N block goes to rank 0 -- in three steps:
+ *   fsgpu_shard_pack   codes the rank's bins and holds the blocks in memory; *n_blocks = blocks of the WHOLE archive
+ *   fsgpu_shard_table  the archive's block table in its final (-t1) order: signatures (the same on every rank) and this
+ *                      rank's block sizes, 0 for the blocks of other ranks
+ *   (caller)           element-wise sum of the size tables of all ranks: ONE all-reduce (or all-gather) of n_blocks u64
+ *                      over RCCL between processes (fastore_amd/shard.py), a plain sum inside one process (-G<n>)
+ *   fsgpu_shard_write  writes the held blocks at their offsets in <out_prefix>.cdata; rank 0 also writes the .cmeta
+ * No block bytes cross ranks; the archive equals the single-GPU (and the reference's -t1) archive byte for byte. */
+int fsgpu_shard_pack(fsgpu_ctx* ctx, const char* in_prefix, size_t* n_blocks);
+int fsgpu_shard_table(const fsgpu_ctx* ctx, uint32_t* signatures, uint64_t* sizes, size_t n_blocks);
+int fsgpu_shard_write(fsgpu_ctx* ctx, const char* out_prefix, const uint64_t* all_sizes, size_t n_blocks);
+
+/* The file-based form of the same: bin-sharded packing of one library by `world_size` contexts (one per GPU; fsgpu_config.rank / world_size): every
  * context writes <out_prefix>.part<rank>.{cdata,cmeta}; this call merges the parts into <out_prefix>.{cdata,cmeta} in
  * the reference's -t1 order (the merged small-bins/N block of rank 0 first, then ascending signature) and removes them.
  * Host only.  The multi-process form of the same exchange (all-gather of sizes over RCCL) is fastore_amd/shard.py.

@@ -271,6 +271,25 @@ def test_gpu_rank_sharded_pack_on_one_device(tmp_path):
         assert not [f for f in os.listdir(tmp_path) if ".part" in f]
 
 
+def test_gpu_shard_api_on_one_device(tmp_path):
+    # the multi-GPU path proper (fsgpu_shard_pack / _table / _write: LPT shares, summed size table, positional writes),
+    # three ranks on device 0 one after the other
+    import fastore_amd
+    name, paired, flags = manifest()[1]
+    out = str(tmp_path / "o")
+    world = 3
+    packers = [fastore_amd.Packer(device_id=0, rank=r, world_size=world, **knobs_from_flags(flags)) for r in range(world)]
+    try:
+        tables = [p.shard_pack(os.path.join(GOLDEN, name + ".in")) for p in packers]
+        total = np.stack([t[1] for t in tables]).sum(axis=0)
+        for p in packers:
+            p.shard_write(out, total)
+    finally:
+        for p in packers:
+            p.close()
+    assert_same_archive(out, os.path.join(GOLDEN, name + ".ref"))
+
+
 def test_gpu_cli_two_contexts_on_one_box(tmp_path):
     # `fastore_pack e -G2` needs two devices; on a one-GPU box the same code path is driven with -R/-N + merge
     import fastore_amd

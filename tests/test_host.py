@@ -310,6 +310,41 @@ def test_cli_packs_one_library_on_several_devices(tmp_path, gpus):
         assert not [f for f in os.listdir(str(tmp_path)) if ".part" in f]
 
 
+@pytest.mark.parametrize("world", [2, 5])
+def test_shard_api_lpt_split_and_positional_writes(emu_lib, tmp_path, world):
+    # fsgpu_shard_pack / _table / _write: every rank holds its LPT share, the size tables are summed (the one collective
+    # of the multi-GPU path), the ranks write their blocks in ANY order -- the archive is the single-writer archive
+    import fastore_amd, numpy as np
+    name, paired, flags = manifest()[0]
+    out = str(tmp_path / "o")
+    open(out + ".cdata", "wb").write(b"x" * (8 << 20))            # a longer file of an earlier run must not survive
+    packers = [fastore_amd.Packer(lib=emu_lib, host_threads=2, rank=r, world_size=world, **knobs_from_flags(flags)) for r in range(world)]
+    tables = [p.shard_pack(os.path.join(GOLDEN, name + ".in")) for p in packers]
+    sigs = tables[0][0]
+    assert all((t[0] == sigs).all() for t in tables)
+    assert sigs[0] == sigs.max() and (np.diff(sigs[1:].astype(np.int64)) > 0).all()         # block 0, then ascending signature
+    own = np.stack([t[1] for t in tables])
+    assert ((own > 0).sum(axis=0) == 1).all()                                               # every block has exactly one owner
+    records = [p.stats()["records"] for p in packers]
+    assert max(records) - min(records) <= 0.15 * sum(records) / world + 4000, records      # LPT: the shares are even
+    total = own.sum(axis=0)
+    for r in reversed(range(world)):                                                        # last rank first
+        packers[r].shard_write(out, total)
+    for p in packers:
+        p.close()
+    assert_same_archive(out, os.path.join(GOLDEN, name + ".ref"))
+
+
+def test_cli_several_devices_verbose_statistics(tmp_path):
+    # -G<n> -v: the StreamSizes statistics are those of the whole archive (taken from the merged blocks' headers)
+    cli = os.path.join(ROOT, "build", "fastore_pack_emu")
+    name, paired, flags = manifest()[0]
+    r = subprocess.run([cli, "e", "-i" + os.path.join(GOLDEN, name + ".in"), "-o" + str(tmp_path / "o"), "-t4", "-G3", "-v"] + flags, capture_output=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == open(os.path.join(GOLDEN, name + ".ref.vout"), "rb").read()
+    assert b"Parts processed" in r.stderr
+
+
 def test_merge_parts_of_rank_sharded_contexts(emu_lib, tmp_path):
     import fastore_amd
     name, paired, flags = manifest()[1]
