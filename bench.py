@@ -30,7 +30,7 @@ import time
 
 # the pack context runs one HIP stream per pipeline slice; they need their own hardware queues to overlap
 # (the runtime default is 4, shared round-robin) -- must be in the environment before HIP initialises
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

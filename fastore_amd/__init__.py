@@ -36,7 +36,7 @@ class Stats(C.Structure):
                 ("algorithmic_bytes", C.c_uint64), ("block0_records", C.c_uint64), ("block0_bytes", C.c_uint64),
                 ("cdata_bytes", C.c_uint64), ("host_coded_symbols", C.c_uint64), ("host_coded_streams", C.c_uint64),
                 ("ppmd_window_attempts", C.c_uint64), ("ppmd_windows", C.c_uint64), ("ppmd_window_symbols", C.c_uint64),
-                ("ppmd_window_rounds", C.c_uint64), ("ppmd_windows_redone", C.c_uint64)]
+                ("ppmd_window_rounds", C.c_uint64), ("ppmd_windows_redone", C.c_uint64), ("ppmd_window_light_rounds", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -57,7 +57,7 @@ class BlockBatch(C.Structure):
 _lib = None
 
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one hardware queue per pipeline lane (see engine.hip)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # one hardware queue per pipeline lane (see engine.hip)
 
 
 def load_library(path=None):

@@ -76,6 +76,7 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
     c.hostThreads = cfg->host_threads ? cfg->host_threads : std::max(localRanks > 1 ? 4u : 1u, std::min(24u, share));
     if (getenv("FS_HOST_THREADS")) c.hostThreads = std::max(1, atoi(getenv("FS_HOST_THREADS")));     // experiments
     if (getenv("FS_PIPELINE_SLICES") && atoi(getenv("FS_PIPELINE_SLICES")) > 0) c.cfg.pipeline_slices = (uint32_t)atoi(getenv("FS_PIPELINE_SLICES"));
+    if (getenv("FS_PIPELINE_LANES") && atoi(getenv("FS_PIPELINE_LANES")) > 0) c.cfg.pipeline_lanes = (uint32_t)atoi(getenv("FS_PIPELINE_LANES"));
     if (getenv("FS_MAX_WAVES") && atoi(getenv("FS_MAX_WAVES")) > 0) c.cfg.max_waves = (uint32_t)atoi(getenv("FS_MAX_WAVES"));
     if (c.par.mismatchCost <= 0 || c.par.shiftCost < 0 || c.par.maxLzWindowSize == 0 || c.par.maxPairLzWindowSize == 0) { g_createError = "invalid matcher parameters"; delete ctx; return nullptr; }
     if (fsengine::device_count() <= 0) {
@@ -473,7 +474,7 @@ int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out)
     out->encode_kernel_ms = ctx->c.timing.encode_ms; out->assemble_kernel_ms = ctx->c.timing.assemble_ms;
     out->kernel_launches = ctx->c.timing.launches; out->stream_items = ctx->c.timing.items; out->ppmd_symbols = ctx->c.timing.ppmd_symbols;
     out->ppmd_window_attempts = ctx->c.timing.win[1]; out->ppmd_windows = ctx->c.timing.win[2]; out->ppmd_window_symbols = ctx->c.timing.win[3];
-    out->ppmd_window_rounds = ctx->c.timing.win[4]; out->ppmd_windows_redone = ctx->c.timing.win[5];
+    out->ppmd_window_rounds = ctx->c.timing.win[4]; out->ppmd_windows_redone = ctx->c.timing.win[5]; out->ppmd_window_light_rounds = ctx->c.timing.win[6];
     out->rc_symbols = ctx->c.timing.rc_symbols; out->ppmd_restarts = ctx->c.timing.restarts; out->h2d_bytes = ctx->c.timing.h2d_bytes; out->d2h_bytes = ctx->c.timing.d2h_bytes;
     return FSGPU_OK;
 }

@@ -151,12 +151,12 @@ template <bool TWO> __device__ __forceinline__ void encode_streams_body()
         if (threadIdx.x < 16u) {
             KernArgs k2 = kernargs();
             if (threadIdx.x == 0 && !(TWO && kind == KIND_PPMD && n > 0)) k2->outSizes[it] = size;       // (two-wave form: a PPMd member's size comes from the coder wave)
-            // per-stream telemetry: [0] model restarts, [1..5] windowed hit path (attempts, windows, symbols, rounds, redone
-            // windows), [8..14] phase clocks / 64 and [15] the stream's whole time / 64 (FS_WIN_PROFILE builds, else 0)
+            // per-stream telemetry: [0] model restarts, [1..6] windowed hit path (attempts, windows, symbols, rounds, redone
+            // windows, light rounds), [8..14] phase clocks / 64 and [15] the stream's whole time / 64 (FS_WIN_PROFILE builds, else 0)
             const uint32_t t = threadIdx.x;
             uint32_t v = 0;
             if (kind == KIND_PPMD && n > 0) {
-                if (t >= 1u && t <= 5u) v = sh.winStats[t - 1u];
+                if (t >= 1u && t <= 6u) v = sh.winStats[t - 1u];
                 else if (t >= 8u && t < 15u) v = sh.winStats[t];
                 else if (t == 15u) v = (uint32_t)((FS_PROF_NOW() - tStream) >> 6);
             }
@@ -247,7 +247,7 @@ namespace fsengine {
 // streams onto 4 hardware queues by default, and streams sharing a queue run their kernels one after the other
 // (measured: 5 lanes on 4 queues lose 18 % of the step).  Takes effect only if HIP is not initialised yet; a process
 // that initialises HIP first (PyTorch) sets the variable itself (bench.py does).
-static void want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+static void want_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 int device_count()
 {

@@ -281,7 +281,7 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
 // into slices, and the moment the last bin of a slice is done its lane thread builds the slice's stream items, stages
 // them and runs the device call -- so the host front end of the later slices, the staging and the device work of the
 // earlier ones all overlap, and the kernels of consecutive slices overlap on the device (shared arena pool).
-enum : uint32_t { kMaxLanes = 8 };
+enum : uint32_t { kMaxLanes = 14 };      // one HIP stream each, on its own hardware queue (GPU_MAX_HW_QUEUES=16; measured: 24 queues make launches wait for each other again)
 
 void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, const std::vector<uint32_t>& binArch, const BinProducer& produce)
 {
@@ -306,24 +306,45 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     // become ready one after the other while the earlier ones are coded.  Up to eight launches are in flight (one per
     // lane); they take their arenas from the pool's slot maps.
     std::vector<uint32_t> cut{0};
-    const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? kMaxLanes : 1u);
+    const bool autoSlices = cfg.pipeline_slices == 0;
+    const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? 14u : 1u);
     if (wantSlices > 1) {
-        // FS_SLICE_WEIGHTS="1,2,2,3" (experiment): relative weights of ALL slices instead of the rule above
+        // FS_SLICE_WEIGHTS="1,2,2,3" (experiment): relative weights of ALL slices instead of the rule below
         std::vector<double> share;
-        if (const char* sw = getenv("FS_SLICE_WEIGHTS")) {
+        const char* sw = getenv("FS_SLICE_WEIGHTS");
+        if (sw) {
             for (const char* q = sw; *q && share.size() < wantSlices; ) { const double v = atof(q); share.push_back(v > 0 ? v : 1.0); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
             share.resize(wantSlices, 1.0);
-        } else {
+        } else if (!autoSlices) {
             uint64_t firstW = 0; const uint32_t firstBins = std::min<uint32_t>(std::max(1u, hostThreads), nBins / wantSlices);
             for (uint32_t i = 0; i < firstBins; ++i) firstW += weight[byWork[i]];
             const double f = std::min(0.5, (double)firstW / (double)std::max<uint64_t>(1, totalW));
             share.assign(wantSlices, (1.0 - f) / (wantSlices - 1)); share[0] = f;
         }
-        double shareSum = 0; for (double v : share) shareSum += v;
-        uint64_t acc = 0; uint32_t k = 0; double upTo = share[0];
-        for (uint32_t i = 0; i < nBins && k + 1 < wantSlices; ++i) {
-            acc += weight[byWork[i]];
-            if ((double)acc >= upTo / shareSum * (double)totalW && i + 1 < nBins) { cut.push_back(i + 1); ++k; upTo += share[k]; }
+        if (!share.empty()) {
+            double shareSum = 0; for (double v : share) shareSum += v;
+            uint64_t acc = 0; uint32_t k = 0; double upTo = share[0];
+            for (uint32_t i = 0; i < nBins && k + 1 < wantSlices; ++i) {
+                acc += weight[byWork[i]];
+                if ((double)acc >= upTo / shareSum * (double)totalW && i + 1 < nBins) { cut.push_back(i + 1); ++k; upTo += share[k]; }
+            }
+        } else {
+            // Default rule.  A slice is ready when the host has been through its last bin, and then needs the device for as
+            // long as its longest stream takes; the host works through the bins at a steady rate, heaviest first.  So the
+            // first slice is exactly the bins the host threads take in their first round (one each: ready when the
+            // heaviest bin is), the middle slices grow, and the last ones -- small bins only, short streams -- shrink
+            // again, so that little device work is left when the host is done.
+            const uint32_t firstBins = std::min<uint32_t>(std::max(1u, hostThreads), std::max(1u, nBins / wantSlices));
+            uint64_t firstW = 0;
+            for (uint32_t i = 0; i < firstBins; ++i) firstW += weight[byWork[i]];
+            static const double upToFrac[] = {0.0, 0.10, 0.20, 0.32, 0.45, 0.58, 0.70, 0.80, 0.88, 0.94, 0.975, 0.99, 0.997, 1.0};   // of the weight behind the first slice
+            cut.push_back(firstBins);
+            uint64_t acc = 0; uint32_t k = 1;
+            const double rest = (double)(totalW - firstW);
+            for (uint32_t i = firstBins; i < nBins && k + 1 < wantSlices; ++i) {
+                acc += weight[byWork[i]];
+                if ((double)acc >= upToFrac[k] * rest && i + 1 < nBins && i + 1 > cut.back()) { cut.push_back(i + 1); ++k; }
+            }
         }
     }
     cut.push_back(nBins);
@@ -337,8 +358,11 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     struct Slice {
         std::vector<StreamItem> items; std::vector<BlockPlan> plans; std::vector<uint64_t> sizes;
         fsengine::BatchTiming timing; std::string err; std::thread th; double tReady = 0, tSubmit = 0, tDone = 0;
-        std::mutex mx; std::condition_variable cv; uint32_t pending = 0; bool done = false;
+        std::mutex mx; std::condition_variable cv; uint32_t pending = 0; bool done = false; int lane = -1; uint64_t inBytes = 0;
     };
+    // a slice takes whichever lane is free when its bins are ready (the early slices hold theirs for the longest streams)
+    std::mutex laneMx; std::condition_variable laneCv; std::vector<uint32_t> freeLanes;
+    for (uint32_t l = nLanes; l-- > 0;) freeLanes.push_back(l);
     std::vector<Slice> slices(nSlices);
     std::vector<uint32_t> sliceOf(nBins);
     for (uint32_t si = 0; si < nSlices; ++si) { slices[si].pending = cut[si + 1] - cut[si]; for (uint32_t k = cut[si]; k < cut[si + 1]; ++k) sliceOf[k] = si; }
@@ -351,12 +375,12 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             std::unique_lock<std::mutex> lk(S.mx);
             S.cv.wait(lk, [&]() { return S.pending == 0 || abort.load(); });
         }
-        if (si >= nLanes) {   // the lane is still busy with an earlier slice
-            Slice& P = slices[si - nLanes];
-            std::unique_lock<std::mutex> lk(P.mx);
-            P.cv.wait(lk, [&]() { return P.done || abort.load(); });
-        }
         if (abort.load()) return;
+        {
+            std::unique_lock<std::mutex> lk(laneMx);
+            laneCv.wait(lk, [&]() { return !freeLanes.empty(); });
+            S.lane = (int)freeLanes.back(); freeLanes.pop_back();
+        }
         S.tReady = nowMs();
         try {
             const uint32_t first = cut[si], count = cut[si + 1] - cut[si];
@@ -402,7 +426,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                     inBytes += (bytes + 15) & ~15ull;
                 }
             }
-            fsengine::Device* L = lanes[si % nLanes];
+            fsengine::Device* L = lanes[(uint32_t)S.lane];
             uint8_t* input = fsengine::staging_buffer(L, inBytes + 16);        // pinned host memory owned by the lane
             if (!input) throw std::runtime_error(std::string("device: ") + L->err);
             for (size_t a = 0; a < archives.size(); ++a) if (qvzOff[a] != ~0ull) memcpy(input + qvzOff[a], archives[a].qvz.blob.data(), archives[a].qvz.blob.size());
@@ -414,10 +438,12 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                     if (!v.empty()) memcpy(input + S.items[pl.first_item + s].in_off, v.data(), v.size());
                 }
             });
-            S.tSubmit = nowMs();
+            S.tSubmit = nowMs(); S.inBytes = inBytes;
             if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, sliceBlocks[si], S.sizes, &S.timing) != 0) S.err = std::string("device: ") + L->err;
         } catch (const std::exception& e) { S.err = e.what(); }
         S.tDone = nowMs();
+        { std::lock_guard<std::mutex> lk(laneMx); freeLanes.push_back((uint32_t)S.lane); }
+        laneCv.notify_one();
         { std::lock_guard<std::mutex> lk(S.mx); S.done = true; }
         S.cv.notify_all();
     };
@@ -439,10 +465,10 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             for (uint32_t si = 0; si < nSlices; ++si) {
                 Slice& S = slices[si];
                 bool dn; { std::lock_guard<std::mutex> g(S.mx); dn = S.done; }
-                if (dn || S.tSubmit <= 0) continue;
+                if (dn || S.tSubmit <= 0 || S.lane < 0) continue;
                 fprintf(stderr, "[watchdog] slice %u device state: ", si); fflush(stderr);
                 char buf[512] = {0};
-                fsengine::lane_debug(lanes[si % nLanes], buf, sizeof buf);
+                fsengine::lane_debug(lanes[(uint32_t)S.lane], buf, sizeof buf);
                 fprintf(stderr, "%s\n", buf); fflush(stderr);
             }
             _exit(86);
@@ -479,6 +505,10 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     if (onHostTasksDone) onHostTasksDone();
     joinAll();
     for (Slice& S : slices) if (!S.err.empty()) throw std::runtime_error(S.err);
+    if (nSlices > 1) {   // any lane may get the largest slice of the next batch: size their pinned staging buffers alike, once
+        uint64_t mx = 0; for (Slice& S : slices) mx = std::max(mx, S.inBytes);
+        for (uint32_t l = 0; l < nLanes; ++l) (void)fsengine::staging_buffer(lanes[l], mx + 16);
+    }
     stats.frontend_ms += feMs;
     for (uint32_t si = 0; si < nSlices; ++si) {
         Slice& S = slices[si];

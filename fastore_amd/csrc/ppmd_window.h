@@ -232,6 +232,34 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
         uint32_t rlo = owner ? m.sh->winMask[2u * lane] : 0u, rhi = owner ? m.sh->winMask[2u * lane + 1u] : 0u;      // positions still to do
         FS_PROF_ACC(m.sh->winStats[10], tp);                           // context sets
         uint32_t rounds = 0;
+        // Light rounds.  Until a context needs a swap or a rescale its states stay where they were fetched: a position's
+        // place is the one it found for itself (k), so a round is a fetch of that place from the position's lane, two byte
+        // extractions and a masked byte sum.  The first position of a context that would swap or cross MAX_FREQ is left,
+        // with the rest of that context's positions, to the full rounds below (which start from the list as it is now:
+        // only frequencies have changed).
+        {
+            bool full = false;
+            for (;;) {
+                const bool act = !full && (rlo | rhi) != 0u;
+                if (fs_ballot(act) == 0ull) break;
+                ++rounds;
+                const uint32_t p = !act ? lane : (rlo ? (uint32_t)__builtin_ctz(rlo) : 32u + (uint32_t)__builtin_ctz(rhi));
+                const uint32_t kk = fs_bperm(k, p) & 7u, k8 = 8u * kk;
+                const uint32_t f = (uint32_t)(c.F >> k8) & 0xFFu, fPrev = kk ? (uint32_t)(c.F >> (k8 - 8u)) & 0xFFu : 0xFFFFu;
+                const uint32_t nf = f + 4u;
+                if (act && (nf > fPrev || nf > (uint32_t)MAX_FREQ)) full = true;
+                else if (act) {
+                    if (rlo) rlo &= rlo - 1u; else rhi &= rhi - 1u;
+                    const uint64_t below = c.F & ((1ull << k8) - 1ull);
+                    const uint32_t loCnt = fs_sum_bytes((uint32_t)below) + fs_sum_bytes((uint32_t)(below >> 32));
+                    m.sh->winA[p] = loCnt | (f << 16) | ((kk == 0u && 2u * f > summ) ? (1u << 23) : 0u);
+                    m.sh->winM[p] = summ;
+                    c.F += 4ull << k8;
+                    summ += 4u;
+                }
+            }
+        }
+        FS_STAT_ADD(m.sh->winStats[5], rounds);
         for (;;) {
             const bool act = (rlo | rhi) != 0u;
             if (fs_ballot(act) == 0ull) break;
@@ -303,14 +331,11 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
                 w[3 * t + 1] = (so[2 * t] >> 16) | (sf[2 * t + 1] << 16);
                 w[3 * t + 2] = so[2 * t + 1];
             }
+            // whole units (two states, three words) go back: the spare half of an odd list's last unit is never read
+            (void)full;
+            const uint32_t units = (nst + 1u) >> 1;
             #pragma unroll
-            for (int i = 0; i < 12; ++i) if ((uint32_t)i < full) p[i] = w[i];
-            if (nst & 1u) {
-                uint32_t tail = 0;
-                #pragma unroll
-                for (int i = 0; i < 12; ++i) if ((uint32_t)i == full) tail = w[i];
-                *(fs_gptr16)(HP(stats) + 4u * full) = (uint16_t)tail;
-            }
+            for (int u = 0; u < 4; ++u) if ((uint32_t)u < units) { p[3 * u] = w[3 * u]; p[3 * u + 1] = w[3 * u + 1]; p[3 * u + 2] = w[3 * u + 2]; }
             *(fs_gptr32)HP(addr) = ns | (flags << 8) | (summ << 16);
         }
         uint32_t tA = inWin ? m.sh->winA[lane] : 0u, tM = inWin ? m.sh->winM[lane] : 0u;

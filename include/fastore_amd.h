@@ -103,6 +103,7 @@ typedef struct fsgpu_stats {
     /* windowed PPMd hit path (ppmd_window.h): window attempts, windows coded, symbols coded inside windows (of
      * ppmd_symbols), rounds (positions sharing a context are processed one rank per round), windows redone shorter */
     uint64_t ppmd_window_attempts, ppmd_windows, ppmd_window_symbols, ppmd_window_rounds, ppmd_windows_redone;
+    uint64_t ppmd_window_light_rounds;   /* of ppmd_window_rounds: rounds that needed no swap and no rescale */
 } fsgpu_stats;
 
 void fsgpu_config_defaults(fsgpu_config* cfg);

@@ -1,0 +1,12 @@
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+T=${TAG:-r2j}
+( timeout 600 python -m pytest tests/test_gpu.py -m gpu -x -q -k "ppmd or reproduces or deterministic" ) > gpurun_out/${T}_tests.log 2>&1
+tail -3 gpurun_out/${T}_tests.log
+FS_TWO_WAVE=1 FS_LIB=build/libfastore_amd_prof.so COPIES=1 timeout 600 python3 tools/ppmd_microbench.py 3000000 > gpurun_out/${T}_prof_3M_two.txt 2>&1
+cat gpurun_out/${T}_prof_3M_two.txt
+FS_TWO_WAVE=1 COPIES=1,1536 timeout 600 python3 tools/ppmd_microbench.py 3000000 > gpurun_out/${T}_micro_3M_two.txt 2>&1
+cat gpurun_out/${T}_micro_3M_two.txt
+( time FS_TRACE=1 FS_WATCHDOG=120 timeout 1500 python3 bench.py --steps 3 --warmup 1 --no-cli --no-cpu-baseline ) > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
+cat gpurun_out/${T}_bench.json
+grep "slice\|batch:" gpurun_out/${T}_bench.err | tail -15
