@@ -36,7 +36,9 @@ class Stats(C.Structure):
                 ("algorithmic_bytes", C.c_uint64), ("block0_records", C.c_uint64), ("block0_bytes", C.c_uint64),
                 ("cdata_bytes", C.c_uint64), ("host_coded_symbols", C.c_uint64), ("host_coded_streams", C.c_uint64),
                 ("ppmd_window_attempts", C.c_uint64), ("ppmd_windows", C.c_uint64), ("ppmd_window_symbols", C.c_uint64),
-                ("ppmd_window_rounds", C.c_uint64), ("ppmd_windows_redone", C.c_uint64), ("ppmd_window_light_rounds", C.c_uint64)]
+                ("ppmd_window_rounds", C.c_uint64), ("ppmd_windows_redone", C.c_uint64), ("ppmd_window_light_rounds", C.c_uint64),
+                ("gather_kernel_ms", C.c_double), ("gather_symbols", C.c_uint64), ("gather_bytes", C.c_uint64),
+                ("matcher_reads", C.c_uint64), ("matcher_call_ms", C.c_double), ("matcher_kernel_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -87,6 +89,8 @@ def load_library(path=None):
     lib.fsgpu_set_archive_params.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     pp = C.POINTER(C.c_char_p)
     lib.fsgpu_ppmd_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fsgpu_matcher_check.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.fsgpu_gather_quality.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fsgpu_rc_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fsgpu_set_quality_codebook.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     lib.fsgpu_qvz_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -284,6 +288,24 @@ class Packer:
     def ppmd_encode(self, streams):
         """PPMd var.J order-4 members, one per input stream (device)."""
         return self._encode(self.lib.fsgpu_ppmd_encode, streams, 1)
+
+    def gather_quality(self, packed, strings):
+        """Quality stream of a lossless bin built by fs_gather_quality (device): packed = the stored scores (six bits each,
+        MSB first), strings = [(bit offset of the first score, length, emitted back to front?)] in emission order."""
+        import numpy as np
+        desc = np.zeros(len(strings), dtype=np.dtype([("src_bit", "<u8"), ("len", "<u4"), ("reverse", "<u4")]))
+        for i, (b, n, r) in enumerate(strings):
+            desc[i] = (b, n, 1 if r else 0)
+        total = int(desc["len"].sum())
+        out = C.create_string_buffer(total + 16); got = C.c_size_t(0)
+        self._check(self.lib.fsgpu_gather_quality(self.ctx, packed, len(packed), desc.ctypes.data, len(strings), out, total + 16, C.byref(got)))
+        return out.raw[:got.value]
+
+    def matcher_check(self, in_prefix):
+        """(reads searched, rows on which the device matcher and the host's window scan disagree) over the standard bins of a library."""
+        r = C.c_uint64(0); d = C.c_uint64(0)
+        self._check(self.lib.fsgpu_matcher_check(self.ctx, in_prefix.encode(), C.byref(r), C.byref(d)))
+        return r.value, d.value
 
     def rc_encode(self, models, pair_streams):
         """Range-coded streams; pair_streams[i] = interleaved (symbol, ctx0) bytes, models[i] in 0..5."""

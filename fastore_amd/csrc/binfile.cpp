@@ -47,9 +47,11 @@ struct Unpacker {
     void checkGroup(uint32_t groupSize, uint32_t recIdx, uint32_t slack) const { if ((uint64_t)groupSize > (uint64_t)(recEnd - recIdx) + slack) throw std::runtime_error("Corrupted bin: group larger than the bin"); }
     uint32_t dna4[256];      // byte of packed bases -> four characters
 
+    // packedQ: the qualities stay packed (Batch::quaPacked / quaBit): readQuality only notes where a string starts
+    bool packedQ = false; uint64_t quaStart = 0;
     Unpacker(const BinModuleConfigRaw& c, Batch& batch, Batch& graph, const std::vector<uint8_t>& m, uint64_t ms, const std::vector<uint8_t>& d, uint64_t ds,
-             const std::vector<uint8_t>& q, uint64_t qs, const std::vector<uint8_t>& h, uint64_t hs)
-        : cfg(c), b(batch), g(graph), meta(m.data(), ms), dna(d.data(), ds), qua(q.data(), qs), head(h.data(), hs), pe(c.archiveType.readType == READ_PE)
+             const uint8_t* q, uint64_t qs, const std::vector<uint8_t>& h, uint64_t hs)
+        : cfg(c), b(batch), g(graph), meta(m.data(), ms), dna(d.data(), ds), qua(q, qs), head(h.data(), hs), pe(c.archiveType.readType == READ_PE)
     {
         pairSettings.minLen = pairSettings.maxLen = 1; pairSettings.hasConstLen = true; pairSettings.usesHeaders = false;
         const char* o = c.minimizer.dnaSymbolOrder;
@@ -79,8 +81,10 @@ struct Unpacker {
             for (uint32_t i = minimPos + suffixLen; i < seqLen; ++i) seq[i] = base3();
         }
     }
-    void readQuality(uint8_t* q, uint32_t n)
+    void readQuality(uint64_t at, uint32_t n)
     {
+        if (packedQ) { quaStart = qua.bitPosition(); qua.skipBits(6ull * n); return; }
+        uint8_t* q = b.qua.data() + at;
         const uint32_t off = cfg.archiveType.qualityOffset;
         switch (cfg.quaParams.method) {
         case MET_BINARY: for (uint32_t i = 0; i < n; ++i) q[i] = (uint8_t)(off + (qua.getBit() ? 40 : 6)); break;
@@ -113,16 +117,26 @@ struct Unpacker {
         // before any base is stored: the position comes from 8 untrusted bits
         if (s.suffixLen != 0 && minimPos + s.suffixLen > len) throw std::runtime_error("Corrupted bin: signature position outside the read");
         readDna(b.seq.data() + seqOff, len, minimPos, s.suffixLen);
-        readQuality(b.qua.data() + seqOff, len);
+        readQuality(seqOff, len);
+        if (packedQ) noteQuality(r, len, isMate2);
         if (s.usesHeaders) readHeader(r);
         return true;
+    }
+    // the record's bit offset (first mate); a second mate's scores must follow the first's directly
+    void noteQuality(const Rec& r, uint32_t len, bool isMate2)
+    {
+        const size_t idx = (size_t)(&r - b.recs.data());
+        if (quaStart > 0xFFFFFFFFull) throw std::runtime_error("bin with more than 512 MiB of packed qualities");
+        if (!isMate2) b.quaBit[idx] = (uint32_t)quaStart;
+        else if (quaStart != (uint64_t)b.quaBit[idx] + 6ull * r.seqLen) throw std::runtime_error("Corrupted bin: mate qualities are not adjacent");
+        (void)len;
     }
     uint32_t allocSeq(uint32_t n)
     {
         if (placed) { if (seqCur + n > seqEnd) throw std::runtime_error("bin footer understates the bases"); const uint64_t o = seqCur; seqCur += n; return (uint32_t)o; }
         const uint64_t off = b.seq.size();
         if (off + n > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB of bases");
-        b.seq.resize(off + n); b.qua.resize(off + n);
+        b.seq.resize(off + n); if (!packedQ) b.qua.resize(off + n);
         return (uint32_t)off;
     }
     void readRecordData(const Settings& s, Rec& r)
@@ -151,7 +165,8 @@ struct Unpacker {
         r.seqOff = allocSeq((uint32_t)r.seqLen + r.auxLen);
         memcpy(b.seq.data() + r.seqOff, b.seq.data() + mainRec.seqOff, mainRec.seqLen);
         r.minimPos = mainRec.minimPos;
-        readQuality(b.qua.data() + r.seqOff, r.seqLen);
+        readQuality(r.seqOff, r.seqLen);
+        if (packedQ) noteQuality(r, r.seqLen, false);
         if (cfg.archiveType.readsHaveHeaders) readHeader(r);
         if (pe) readNextRecord(pairSettings, r, r.seqOff + r.seqLen, r.auxLen, true);
     }
@@ -334,11 +349,11 @@ void BinFile::readFooter(const std::vector<uint8_t>& buf)
     }
 }
 
-void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin) const { unpackImpl(signature, batch, batch, asNewBin, false, 0, 0, 0); }
-void BinFile::unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, uint64_t headBase, uint32_t recBase, Batch& graph) const
-{ unpackImpl(signature, data, graph, true, true, seqBase, headBase, recBase); }
+void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin) const { unpackImpl(signature, batch, batch, asNewBin, false, 0, 0, 0, -1); }
+void BinFile::unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, uint64_t headBase, uint32_t recBase, Batch& graph, int64_t quaBase) const
+{ unpackImpl(signature, data, graph, true, true, seqBase, headBase, recBase, quaBase); }
 
-void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase) const
+void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase, int64_t quaBase) const
 {
     // gather buffers of the calling thread, kept across bins: fresh vectors of this size are mmap'ed by malloc, and the
     // map/unmap/first-touch churn of thousands of them per second serialises the host threads in the kernel
@@ -349,13 +364,18 @@ void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asN
     // BinFileReader::ReadBlock: gather the signature's slices from the four streams
     if (bMeta_.size() < bi.totalMetaSize) bMeta_.resize(bi.totalMetaSize);
     if (bDna_.size() < bi.totalDnaSize) bDna_.resize(bi.totalDnaSize);
-    if (bQua_.size() < bi.totalQuaSize) bQua_.resize(bi.totalQuaSize);
+    const bool packedQ = quaBase >= 0;
+    if (packedQ) {
+        if (!placed || cfg_.quaParams.method != MET_NONE) throw std::runtime_error("packed qualities: placed unpack of a lossless archive only");
+        if ((uint64_t)quaBase + bi.totalQuaSize > data.quaPacked.size() || data.quaBit.size() != data.recs.size()) throw std::runtime_error("packed qualities: batch arrays not sized");
+    } else if (bQua_.size() < bi.totalQuaSize) bQua_.resize(bi.totalQuaSize);
+    uint8_t* const quaDst = packedQ ? data.quaPacked.data() + quaBase : bQua_.data();
     if (usesHeaderStream_ && bHead_.size() < bi.totalHeadSize) bHead_.resize(bi.totalHeadSize);
     uint64_t mo = 0, dO = 0, qo = 0, ho = 0, rawDna = 0, records = 0;
     for (const BlockMetaDataRaw& blk : bi.blocks) {
         copyAt(meta_, blk.metaFileOffset, bMeta_.data() + mo, blk.metaSize, ".bmeta"); mo += blk.metaSize;
         copyAt(dna_, blk.dnaFileOffset, bDna_.data() + dO, blk.dnaSize, ".bdna"); dO += blk.dnaSize;
-        copyAt(qua_, blk.quaFileOffset, bQua_.data() + qo, blk.quaSize, ".bqua"); qo += blk.quaSize;
+        copyAt(qua_, blk.quaFileOffset, quaDst + qo, blk.quaSize, ".bqua"); qo += blk.quaSize;
         if (usesHeaderStream_) { copyAt(headf_, blk.headFileOffset, bHead_.data() + ho, blk.headSize, ".bhead"); ho += blk.headSize; }
         rawDna += blk.rawDnaSize; records += blk.recordsCount;
     }
@@ -371,7 +391,8 @@ void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asN
     else { recIdx = (uint32_t)data.recs.size(); data.recs.resize(data.recs.size() + records, Rec{}); }
     const uint32_t recFirst = recIdx;
 
-    Unpacker u(cfg_, data, graph, bMeta_, mo, bDna_, dO, bQua_, qo, bHead_, ho);
+    Unpacker u(cfg_, data, graph, bMeta_, mo, bDna_, dO, quaDst, qo, bHead_, ho);
+    u.packedQ = packedQ;
     u.placed = placed; u.seqCur = seqBase; u.headCur = headBase;
     // a placed bin owns exactly the footer's totals of the shared arrays; a footer that understates them must not spill
     // into the neighbouring bin (another host thread is filling it)

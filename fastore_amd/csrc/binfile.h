@@ -36,11 +36,13 @@ public:
     void unpack(uint32_t signature, Batch& batch, bool asNewBin) const;
     // Placed form for parallel batch assembly: bases/quals/headers/records go to pre-sized arrays of `data` at the given
     // offsets (their sizes are known from the footer); the graph tables and the BinIn go to `graph` (node indices local to it).
-    void unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, uint64_t headBase, uint32_t recBase, Batch& graph) const;
+    // quaBase >= 0: the qualities are not unpacked; the bin's .bqua bytes go to data.quaPacked at quaBase and every record's
+    // bit offset into them to data.quaBit (lossless archives only; see Batch)
+    void unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, uint64_t headBase, uint32_t recBase, Batch& graph, int64_t quaBase = -1) const;
 
 private:
     void readFooter(const std::vector<uint8_t>& buf);
-    void unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase) const;
+    void unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase, int64_t quaBase) const;
     struct Map { const uint8_t* p = nullptr; uint64_t size = 0; };    // read-only mmap of one stream file
     static Map mapFile(const std::string& name);
     static void unmap(Map& m);

@@ -43,6 +43,16 @@ public:
     uint32_t get4Bytes() { return getBits(32); }
     uint64_t get8Bytes() { const uint64_t hi = getBits(32); return (hi << 32) | getBits(32); }
     void flushWord() { const uint32_t r = cnt_ & 7u; acc_ <<= r; cnt_ -= r; }
+    // bits consumed so far, and a skip over n bits that are read elsewhere (the device-side quality path)
+    uint64_t bitPosition() const { return pos_ * 8u - cnt_; }
+    void skipBits(uint64_t n)
+    {
+        if (n <= cnt_) { if (n >= 64) { acc_ = 0; cnt_ = 0; } else { acc_ <<= n; cnt_ -= (uint32_t)n; } return; }
+        n -= cnt_; cnt_ = 0; acc_ = 0;
+        if (n > (size_ - pos_) * 8u) throw std::runtime_error("bin stream truncated");
+        pos_ += n >> 3;
+        if (n & 7u) (void)getBits((uint32_t)(n & 7u));
+    }
     // n 6-bit fields -> bytes (+ add): eight fields per 48-bit bite of the window
     void unpack6(uint8_t* dst, uint32_t n, uint32_t add)
     {

@@ -77,6 +77,7 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
     if (getenv("FS_HOST_THREADS")) c.hostThreads = std::max(1, atoi(getenv("FS_HOST_THREADS")));     // experiments
     if (getenv("FS_PIPELINE_SLICES") && atoi(getenv("FS_PIPELINE_SLICES")) > 0) c.cfg.pipeline_slices = (uint32_t)atoi(getenv("FS_PIPELINE_SLICES"));
     if (getenv("FS_PIPELINE_LANES") && atoi(getenv("FS_PIPELINE_LANES")) > 0) c.cfg.pipeline_lanes = (uint32_t)atoi(getenv("FS_PIPELINE_LANES"));
+    if (getenv("FS_DEVICE_MATCHER") && atoi(getenv("FS_DEVICE_MATCHER")) == 0) c.deviceMatcher = false;       // A/B runs: the host window scan
     if (getenv("FS_MAX_WAVES") && atoi(getenv("FS_MAX_WAVES")) > 0) c.cfg.max_waves = (uint32_t)atoi(getenv("FS_MAX_WAVES"));
     if (c.par.mismatchCost <= 0 || c.par.shiftCost < 0 || c.par.maxLzWindowSize == 0 || c.par.maxPairLzWindowSize == 0) { g_createError = "invalid matcher parameters"; delete ctx; return nullptr; }
     if (fsengine::device_count() <= 0) {
@@ -91,6 +92,7 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
 void fsgpu_destroy(fsgpu_ctx* ctx)
 {
     if (!ctx) return;
+    for (fsengine::MatchLane* m : ctx->c.matchLanes) fsengine::match_lane_destroy(m);
     for (size_t i = 1; i < ctx->c.lanes.size(); ++i) fsengine::device_destroy(ctx->c.lanes[i]);      // lanes[0] == dev
     fsengine::device_destroy(ctx->c.dev);
     delete ctx;
@@ -420,6 +422,38 @@ int fsgpu_rc_encode(fsgpu_ctx* ctx, size_t n, const uint32_t* model, const uint8
     return encodeStreams(ctx, n, kinds.data(), pairs, nPairs, out, outCap, outLen);
 }
 
+int fsgpu_gather_quality(fsgpu_ctx* ctx, const uint8_t* packed, size_t packedBytes, const fsgpu_quality_string* strings, size_t n, uint8_t* out, size_t outCap, size_t* outLen)
+{
+    if (!ctx || !outLen || (n && (!packed || !strings || !out))) return FSGPU_ERR_ARG;
+    FS_GUARD(ctx, {
+        uint64_t total = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (strings[i].len > 0xFFFFu || strings[i].src_bit + 6ull * strings[i].len > 8ull * packedBytes) throw std::runtime_error("quality string outside the packed scores");
+            total += strings[i].len;
+        }
+        if (total > outCap || total > 0xF0000000ull || n > 0xFFFFFFF0ull) throw std::runtime_error("output buffer too small for the gathered quality stream");
+        *outLen = (size_t)total;
+        if (n == 0) return FSGPU_OK;
+        // the device input: packed scores (+ slack for the kernel's word reads), then the descriptors
+        const uint64_t descOff = ((uint64_t)packedBytes + 8u + 15u) & ~15ull;
+        std::vector<uint8_t> input(descOff + n * sizeof(fsdev::QuaString) + 16, 0);
+        memcpy(input.data(), packed, packedBytes);
+        fsdev::QuaString* qs = (fsdev::QuaString*)(input.data() + descOff);
+        uint64_t dst = 0;
+        for (size_t i = 0; i < n; ++i) { qs[i].src_bit = strings[i].src_bit; qs[i].dst_off = (uint32_t)dst; qs[i].len = (uint16_t)strings[i].len; qs[i].reverse = strings[i].reverse ? 1 : 0; dst += strings[i].len; }
+        fsdev::GatherPlan gp; gp.desc_off = descOff; gp.n_strings = (uint32_t)n; gp.out_bytes = (total + 15u) & ~15ull; gp.symbols = total;
+        std::vector<uint8_t> res;
+        if (fsengine::gather_quality_raw(ctx->c.dev, input.data(), descOff + n * sizeof(fsdev::QuaString), gp, res, &ctx->c.timing) != 0) throw std::runtime_error(std::string("device: ") + ctx->c.dev->err);
+        memcpy(out, res.data(), total);
+    });
+}
+
+int fsgpu_matcher_check(fsgpu_ctx* ctx, const char* inPrefix, uint64_t* reads, uint64_t* differing)
+{
+    if (!ctx || !inPrefix || !reads || !differing) return FSGPU_ERR_ARG;
+    FS_GUARD(ctx, ctx->c.matcherCheck(inPrefix, *reads, *differing));
+}
+
 int fsgpu_pack_file(fsgpu_ctx* ctx, const char* inPrefix, const char* outPrefix, int verbose)
 {
     if (!ctx || !inPrefix || !outPrefix) return FSGPU_ERR_ARG;
@@ -463,7 +497,7 @@ int fsgpu_pack_files(fsgpu_ctx* ctx, size_t n, const char* const* inPrefixes, co
 int fsgpu_reset_stats(fsgpu_ctx* ctx)
 {
     if (!ctx) return FSGPU_ERR_ARG;
-    ctx->c.stats = fsgpu_stats(); ctx->c.timing = fsengine::BatchTiming();
+    ctx->c.stats = fsgpu_stats(); ctx->c.timing = fsengine::BatchTiming(); ctx->c.matchedReads = 0; ctx->c.matchUs = 0; ctx->c.matchKernelUs = 0;
     return FSGPU_OK;
 }
 
@@ -475,6 +509,8 @@ int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out)
     out->kernel_launches = ctx->c.timing.launches; out->stream_items = ctx->c.timing.items; out->ppmd_symbols = ctx->c.timing.ppmd_symbols;
     out->ppmd_window_attempts = ctx->c.timing.win[1]; out->ppmd_windows = ctx->c.timing.win[2]; out->ppmd_window_symbols = ctx->c.timing.win[3];
     out->ppmd_window_rounds = ctx->c.timing.win[4]; out->ppmd_windows_redone = ctx->c.timing.win[5]; out->ppmd_window_light_rounds = ctx->c.timing.win[6];
+    out->matcher_reads = ctx->c.matchedReads.load(); out->matcher_call_ms = ctx->c.matchUs.load() / 1e3; out->matcher_kernel_ms = ctx->c.matchKernelUs.load() / 1e3;
+    out->gather_kernel_ms = ctx->c.timing.gather_ms; out->gather_symbols = ctx->c.timing.gather_symbols; out->gather_bytes = ctx->c.timing.gather_bytes;
     out->rc_symbols = ctx->c.timing.rc_symbols; out->ppmd_restarts = ctx->c.timing.restarts; out->h2d_bytes = ctx->c.timing.h2d_bytes; out->d2h_bytes = ctx->c.timing.d2h_bytes;
     return FSGPU_OK;
 }

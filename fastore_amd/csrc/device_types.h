@@ -17,6 +17,22 @@ struct StreamItem {
     uint64_t aux_off;     // KIND_QVZ: byte offset of the library's model blob in the batch input buffer (16-byte aligned)
 };
 
+// fs_gather_quality: one quality string of a slice, in emission order.  src_bit: bit offset of its first stored score in
+// the batch input buffer (six bits per score, MSB first); dst_off: byte offset of its first coded symbol in the gather
+// region behind the uploaded input; reverse: the string is emitted back to front
+struct QuaString { uint64_t src_bit; uint32_t dst_off; uint16_t len; uint16_t reverse; };
+// device-only part of a batch input buffer: quality streams gathered on the device instead of uploaded
+struct GatherPlan { uint64_t desc_off = 0; uint32_t n_strings = 0; uint64_t out_bytes = 0; uint64_t symbols = 0; };
+
+// Device-side read matcher (matcher.hip): the reads of a bin's match-tree constructions, each construction's reads in
+// processing order; a row of answers per read
+struct MatchRead { uint32_t seq_off; uint16_t len, min_pos; };            // bases (ASCII) at seq[seq_off .. +len); signature position
+struct MatchCall { uint32_t first, count; int32_t aux; uint32_t pad; };   // reads[first .. first+count); aux: read holding the sub-tree's root copy, or -1
+struct MatchParams { uint32_t window; int32_t shift_cost, mismatch_cost, encode_threshold; };   // -w, -s, -m, -e (0 = read length / 2)
+// match: read the best window slot holds (-1 none at or below the threshold, -2 a dummy slot); cost / shift / no_mismatches of
+// that match (cost = threshold + 1 when none); identical: exact duplicate of a slot that is not the root copy
+struct MatchRow { int32_t match; int16_t cost, shift; uint8_t no_mismatches, identical, dummy, pad; };
+
 enum : uint32_t { MAX_STREAMS = 23 };
 
 // per-bin block assembly plan (reference block layout: SURVEY §8 a13,

@@ -9,6 +9,7 @@ namespace fsengine {
 
 struct BatchTiming {
     double encode_ms = 0, assemble_ms = 0;      // HIP-event time of the two kernels (summed over launches)
+    double gather_ms = 0; uint64_t gather_symbols = 0, gather_bytes = 0;   // fs_gather_quality: time, scores, bytes read + written
     uint64_t launches = 0, items = 0, ppmd_symbols = 0, rc_symbols = 0, restarts = 0;
     uint64_t h2d_bytes = 0, d2h_bytes = 0;
     uint64_t win[16] = {0};                     // windowed PPMd hit path, summed over the streams: [1] attempts [2] windows [3] symbols [4] rounds [5] redone; [8..15] phase clocks / 64
@@ -24,7 +25,7 @@ struct Device {
     char name[64];
     char err[256];
     void* stream;
-    void* ev[4];
+    void* ev[6];
     void* evWait;                                          // blocking-sync event: a waiting lane thread sleeps instead of spinning
     Pool* pool; uint32_t* queueHead; uint32_t nWaves /* resident-wave cap */;
     uint8_t* dIn; size_t capIn;
@@ -47,8 +48,19 @@ int lane_debug(Device* dev, char* out, size_t outLen);
 uint8_t* staging_buffer(Device* dev, size_t bytes);     // grow-only pinned host buffer for the batch input
 int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,
                        std::vector<uint8_t>& raw, std::vector<uint32_t>& sizes, BatchTiming* timing);
+// Device-side read matcher (matcher.hip): a lane of its own (high-priority stream, own buffers) per caller; match_reads
+// answers every read of one bin's match-tree constructions and returns when the rows are in `rows`
+struct MatchLane;
+int match_lane_create(Device* dev, MatchLane** out);
+void match_lane_destroy(MatchLane* m);
+int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, const fsdev::MatchRead* reads, size_t nReads,
+                const fsdev::MatchCall* calls, size_t nCalls, const fsdev::MatchParams& par, fsdev::MatchRow* rows, double* kernelMs);
+// fs_gather_quality on its own: `input` = packed scores then the descriptors (plan.desc_off); returns the gathered bytes
+int gather_quality_raw(Device* dev, const uint8_t* input, size_t inputBytes, const fsdev::GatherPlan& plan, std::vector<uint8_t>& out, BatchTiming* timing);
+// gather (optional): quality streams that fs_gather_quality writes behind the uploaded input (at inputBytes rounded up to
+// 16) from the packed scores inside it; their items' in_off already point there
 int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,
                  std::vector<fsdev::BlockPlan>& plans, std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes,
-                 BatchTiming* timing);
+                 BatchTiming* timing, const fsdev::GatherPlan* gather = nullptr);
 
 }  // namespace fsengine

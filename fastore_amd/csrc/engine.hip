@@ -177,6 +177,41 @@ template <bool TWO> __device__ __forceinline__ void encode_streams_body()
 __global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(EncodeArgs /* read through kernargs() */) { encode_streams_body<false>(); }
 __global__ __launch_bounds__(128, kWavesPerSimd) void fs_encode_streams2(EncodeArgs /* read through kernargs() */) { encode_streams_body<true>(); }
 
+// fs_gather_quality -- the quality stream of a lossless bin, built on the device (SURVEY 8 a8 + f1): the stored scores
+// (.bqua: six bits each, MSB first, fastore_bin/FastqPacker.cpp:157-287) are unpacked, turned back to front where the read
+// is stored reverse-complemented (IQualityStoreBase::CompressReadQuality, MET_NONE: FastqCompressor.cpp:229-247 -- the coded
+// byte is the score minus the archive's offset, which is exactly the stored six bits) and written in the order in which
+// the tree walk emitted the reads, straight into the input place of the bin's PPMd stream.
+// One wavefront per string at a time; a lane takes four consecutive OUTPUT symbols: their 24 stored bits lie inside one
+// unaligned 32-bit word of the input, and go out as one 32-bit store (the strings follow each other without gaps, so
+// consecutive lanes and consecutive strings write consecutive bytes).  HBM-bound: 0.75 B read + 1 B written per score.
+__global__ __launch_bounds__(256) void fs_gather_quality(const QuaString* __restrict__ strings, uint32_t nStrings,
+                                                         const uint8_t* __restrict__ in, uint8_t* __restrict__ out)
+{
+    const uint32_t lane = threadIdx.x & 63u, nWaves = gridDim.x * 4u;
+    for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < nStrings; i += nWaves) {
+        const QuaString d = strings[i];
+        const uint32_t len = d.len;
+        for (uint32_t o = 4u * lane; o < len; o += 256u) {
+            const uint32_t cnt = len - o < 4u ? len - o : 4u;
+            const uint32_t lo = d.reverse ? len - o - cnt : o;            // lowest stored index among this lane's symbols
+            const uint64_t bit = d.src_bit + 6ull * lo;
+            uint32_t w; __builtin_memcpy(&w, in + (bit >> 3), 4);
+            w = __builtin_bswap32(w) << (uint32_t)(bit & 7u);               // first symbol in the top six bits
+            uint32_t s0 = w >> 26, s1 = (w >> 20) & 63u, s2 = (w >> 14) & 63u, s3 = (w >> 8) & 63u;
+            if (d.reverse) {                                                // stored order lo .. lo+cnt-1, emitted last first
+                const uint32_t a = cnt > 0 ? (cnt == 1 ? s0 : (cnt == 2 ? s1 : (cnt == 3 ? s2 : s3))) : 0u;
+                const uint32_t b = cnt == 2 ? s0 : (cnt == 3 ? s1 : s2);
+                const uint32_t c = cnt == 3 ? s0 : s1;
+                s3 = s0; s0 = a; s1 = b; s2 = c;
+            }
+            uint8_t* dst = out + d.dst_off + o;
+            if (cnt == 4u) { const uint32_t v = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24); __builtin_memcpy(dst, &v, 4); }
+            else { dst[0] = (uint8_t)s0; if (cnt > 1u) dst[1] = (uint8_t)s1; if (cnt > 2u) dst[2] = (uint8_t)s2; }
+        }
+    }
+}
+
 __device__ __forceinline__ void put_be(uint8_t* p, uint64_t v, int nbytes)
 { for (int i = 0; i < nbytes; ++i) p[i] = (uint8_t)(v >> (8 * (nbytes - 1 - i))); }
 
@@ -277,7 +312,7 @@ static int lane_init(Device* dev, char* err, size_t errLen)
     if ((e = hipSetDevice(dev->deviceId)) != hipSuccess) return fail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags((hipStream_t*)&dev->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipMalloc((void**)&dev->queueHead, 64)) != hipSuccess) return fail("hipMalloc(queue)", e);
-    for (int i = 0; i < 4; ++i) if ((e = hipEventCreate((hipEvent_t*)&dev->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
+    for (int i = 0; i < 6; ++i) if ((e = hipEventCreate((hipEvent_t*)&dev->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags((hipEvent_t*)&dev->evWait, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     return 0;
 }
@@ -347,7 +382,7 @@ void device_destroy(Device* dev)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (dev->evWait) (void)hipEventDestroy((hipEvent_t)dev->evWait);
     if (dev->hStage) (void)hipHostFree(dev->hStage);
-    for (int i = 0; i < 4; ++i) if (dev->ev[i]) (void)hipEventDestroy((hipEvent_t)dev->ev[i]);
+    for (int i = 0; i < 6; ++i) if (dev->ev[i]) (void)hipEventDestroy((hipEvent_t)dev->ev[i]);
     if (dev->stream) (void)hipStreamDestroy((hipStream_t)dev->stream);
     if (Pool* pool = dev->pool) {
         bool last;
@@ -389,7 +424,7 @@ uint8_t* staging_buffer(Device* dev, size_t bytes)
 
 // H2D + fs_encode_streams + D2H of the per-stream sizes.  Leaves the coded streams in dev->dScratch.
 static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items,
-                      std::vector<uint32_t>& sizes, uint64_t& scratchBytes, BatchTiming* timing)
+                      std::vector<uint32_t>& sizes, uint64_t& scratchBytes, BatchTiming* timing, const GatherPlan* gather = nullptr)
 {
     HIP_TRY(hipSetDevice(dev->deviceId));
     hipStream_t st = (hipStream_t)dev->stream;
@@ -420,7 +455,12 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     };
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
 
-    if (ensure(dev, dev->dIn, dev->capIn, inputBytes + 16)) return -1;
+    // the gathered quality streams live behind the uploaded bytes
+    const uint64_t gatherBase = ((uint64_t)inputBytes + 15u) & ~15ull, gatherBytes = gather ? gather->out_bytes : 0;
+    if (gather && (gather->desc_off & 15u || gather->desc_off + (uint64_t)gather->n_strings * sizeof(QuaString) > inputBytes || gatherBase + gatherBytes > 0xFFFFFF00ull)) {
+        snprintf(dev->err, sizeof dev->err, "quality gather plan outside the batch input"); return -1;
+    }
+    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + gatherBytes + 64)) return -1;
     if (ensure(dev, dev->dScratch, dev->capScratch, scratch + 16)) return -1;
     if (ensure(dev, dev->dItems, dev->capItems, sizeof(StreamItem) * nItems)) return -1;
     if (ensure(dev, dev->dOrder, dev->capOrder, 4ull * nItems)) return -1;
@@ -444,6 +484,20 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     HIP_TRY(hipMemcpyAsync(dev->dItems, items.data(), sizeof(StreamItem) * nItems, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dev->dOrder, order.data(), 4ull * nRest, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(dev->queueHead, 0, 64, st));
+    if (gather && gather->n_strings) {
+        // every string's source and destination inside the buffer, checked here: the kernel trusts its descriptors
+        const QuaString* qs = (const QuaString*)(input + gather->desc_off);
+        for (uint32_t i = 0; i < gather->n_strings; ++i)
+            if ((qs[i].src_bit >> 3) + (6ull * qs[i].len + 7u) / 8u + 4u > inputBytes || (uint64_t)qs[i].dst_off + qs[i].len > gatherBytes) {
+                snprintf(dev->err, sizeof dev->err, "quality string %u outside the batch input", i); return -1;
+            }
+        HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[4], st));
+        const uint32_t blocks = std::min<uint32_t>((gather->n_strings + 3u) / 4u, (uint32_t)dev->cus * 16u);
+        hipLaunchKernelGGL(fs_gather_quality, dim3(blocks), dim3(256), 0, st, (const QuaString*)(dev->dIn + gather->desc_off), gather->n_strings,
+                           (const uint8_t*)dev->dIn, (uint8_t*)(dev->dIn + gatherBase));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[5], st));
+    }
     const uint32_t grid = exclusive ? (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nItems, dev->nWaves), pool->bytes / stride)
                                     : std::min<uint32_t>(std::max(nRest, 1u), dev->nWaves);
     if (grid == 0) { snprintf(dev->err, sizeof dev->err, "arena pool too small for a %llu-byte coder table", (unsigned long long)need); return -1; }
@@ -477,8 +531,36 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         float a = 0;
         (void)hipEventElapsedTime(&a, (hipEvent_t)dev->ev[0], (hipEvent_t)dev->ev[1]);
         timing->encode_ms += a; timing->launches += 1; timing->items += nItems; timing->h2d_bytes += inputBytes;
+        if (gather && gather->n_strings) {
+            float g = 0; (void)hipEventElapsedTime(&g, (hipEvent_t)dev->ev[4], (hipEvent_t)dev->ev[5]);
+            timing->gather_ms += g; timing->gather_symbols += gather->symbols; timing->gather_bytes += gather->symbols + (gather->symbols * 3u + 3u) / 4u;
+        }
         for (uint32_t i = 0; i < nItems; ++i) { timing->restarts += restarts[16ull * i]; for (int k = 1; k < 16; ++k) timing->win[k] += restarts[16ull * i + k]; if (items[i].kind == KIND_PPMD) timing->ppmd_symbols += items[i].in_len; else timing->rc_symbols += items[i].in_len; }
     }
+    return 0;
+}
+
+int gather_quality_raw(Device* dev, const uint8_t* input, size_t inputBytes, const GatherPlan& plan, std::vector<uint8_t>& out, BatchTiming* timing)
+{
+    HIP_TRY(hipSetDevice(dev->deviceId));
+    hipStream_t st = (hipStream_t)dev->stream;
+    const uint64_t gatherBase = ((uint64_t)inputBytes + 15u) & ~15ull;
+    if (plan.desc_off & 15u || plan.desc_off + (uint64_t)plan.n_strings * sizeof(QuaString) > inputBytes) { snprintf(dev->err, sizeof dev->err, "quality gather plan outside the input"); return -1; }
+    const QuaString* qs = (const QuaString*)(input + plan.desc_off);
+    for (uint32_t i = 0; i < plan.n_strings; ++i)
+        if ((qs[i].src_bit >> 3) + (6ull * qs[i].len + 7u) / 8u + 4u > plan.desc_off || (uint64_t)qs[i].dst_off + qs[i].len > plan.out_bytes) { snprintf(dev->err, sizeof dev->err, "quality string %u outside the input", i); return -1; }
+    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + plan.out_bytes + 64)) return -1;
+    HIP_TRY(hipMemcpyAsync(dev->dIn, input, inputBytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[4], st));
+    const uint32_t blocks = std::max(1u, std::min<uint32_t>((plan.n_strings + 3u) / 4u, (uint32_t)dev->cus * 16u));
+    hipLaunchKernelGGL(fs_gather_quality, dim3(blocks), dim3(256), 0, st, (const QuaString*)(dev->dIn + plan.desc_off), plan.n_strings,
+                       (const uint8_t*)dev->dIn, (uint8_t*)(dev->dIn + gatherBase));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[5], st));
+    out.resize(plan.out_bytes);
+    HIP_TRY(hipMemcpyAsync(out.data(), dev->dIn + gatherBase, plan.out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(wait_stream(dev, st));
+    if (timing) { float g = 0; (void)hipEventElapsedTime(&g, (hipEvent_t)dev->ev[4], (hipEvent_t)dev->ev[5]); timing->gather_ms += g; timing->gather_symbols += plan.symbols; timing->gather_bytes += plan.symbols + (plan.symbols * 3u + 3u) / 4u; }
     return 0;
 }
 
@@ -500,13 +582,13 @@ int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std
 // bytes / (symbol, ctx) pairs.
 int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items,
                  std::vector<BlockPlan>& plans, std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes,
-                 BatchTiming* timing)
+                 BatchTiming* timing, const GatherPlan* gather)
 {
     const uint32_t nItems = (uint32_t)items.size(), nBins = (uint32_t)plans.size();
     blockSizes.assign(nBins, 0);                 // `blocks` keeps its size between calls: resize() below does not re-zero what is overwritten anyway
     if (nItems == 0) { blocks.clear(); return 0; }
     std::vector<uint32_t> sizes; uint64_t scratch = 0;
-    if (run_encode(dev, input, inputBytes, items, sizes, scratch, timing)) return -1;
+    if (run_encode(dev, input, inputBytes, items, sizes, scratch, timing, gather)) return -1;
     hipStream_t st = (hipStream_t)dev->stream;
     if (ensure(dev, dev->dPlans, dev->capPlans, sizeof(BlockPlan) * nBins)) return -1;
     // a stream that filled its scratch slot was clipped: refuse rather than emit a corrupt block

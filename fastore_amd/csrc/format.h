@@ -102,6 +102,13 @@ typedef std::vector<uint8_t, NoInitAlloc<uint8_t>> ByteVec;
 struct Batch {
     ByteVec seq, qua, head;
     std::vector<Rec, NoInitAlloc<Rec>> recs;
+    // Device-side quality path (lossless archives packed from .b* files): the quality strings stay as they are stored,
+    // six bits per score, MSB first (fastore_bin/FastqPacker.cpp:157-287): quaPacked = the bins' .bqua bytes back to back,
+    // quaBit[r] = bit offset of record r's first score from the start of ITS BIN's bytes (a PE record's second mate
+    // follows the first).  `qua` is left empty then: the scores are unpacked, oriented and put in emission order by
+    // the fs_gather_quality kernel.
+    ByteVec quaPacked;
+    std::vector<uint32_t, NoInitAlloc<uint32_t>> quaBit;
     std::vector<NodeIn> nodes;
     std::vector<uint32_t> topNodes;
     std::vector<uint32_t> emRecs;
@@ -109,7 +116,7 @@ struct Batch {
     std::vector<BinIn> bins;
     // append `o` (whole bins) behind this batch, re-basing every index
     void append(const Batch& o);
-    void clear() { seq.clear(); qua.clear(); head.clear(); recs.clear(); nodes.clear(); topNodes.clear(); emRecs.clear(); trees.clear(); bins.clear(); }
+    void clear() { seq.clear(); qua.clear(); head.clear(); recs.clear(); quaPacked.clear(); quaBit.clear(); nodes.clear(); topNodes.clear(); emRecs.clear(); trees.clear(); bins.clear(); }
 };
 
 }  // namespace fs

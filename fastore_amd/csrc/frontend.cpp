@@ -286,14 +286,64 @@ struct BinEncoder::Impl {
         void push_front(const WinEntry& e) { head = (head - 1) & mask; buf[head] = e; mp[head] = (int16_t)e.minPos; ++count; }
         void pop_back() { --count; }
     };
+    // ---- device-side window search (matcher.hip) ----
+    // Every match-tree construction of the bin is known once the bin is unpacked and its top-level reads are sorted: the
+    // top-level one, and one per stored sub-tree (its reads in stored order behind a copy of the record that holds the
+    // tree, FastqCompressor.cpp:1784-1818).  mReads/mCalls are that table; mRows the answers (from the device, or traced
+    // from the host scan for the parity check); callOfTree[t] = construction of sub-tree t (-1 top level = call 0).
+    std::vector<fsdev::MatchRead> mReads; std::vector<fsdev::MatchCall> mCalls; std::vector<fsdev::MatchRow> mRows;
+    std::vector<int32_t> callOfTree;
+    bool havePre = false;                      // mRows hold the device's answers: constructMatchTree does not scan
+    bool traceResize = false;
+    std::vector<fsdev::MatchRow>* matchTrace = nullptr;   // host scan: note every read's answer here (same indexing as mRows)
+    MatchFn matcher;
+    uint64_t matchSeqBase = 0, matchSeqBytes = 0;
+
+    void buildMatchTable(const std::vector<int32_t>& topOrder)
+    {
+        mReads.clear(); mCalls.clear(); callOfTree.assign(G->trees.size(), -1);
+        uint64_t lo = ~0ull, hi = 0;
+        auto add = [&](uint32_t rec, uint32_t minPos) {
+            const Rec& r = B->recs[rec];
+            lo = std::min<uint64_t>(lo, r.seqOff); hi = std::max<uint64_t>(hi, (uint64_t)r.seqOff + r.seqLen);
+            mReads.push_back(fsdev::MatchRead{r.seqOff, r.seqLen, (uint16_t)minPos});
+        };
+        fsdev::MatchCall top{0u, (uint32_t)topOrder.size(), -1, 0u};
+        for (int32_t n : topOrder) add(vrecs[nodes[n].vrec].rec, vrecs[nodes[n].vrec].minimPos);
+        mCalls.push_back(top);
+        for (size_t n = 0; n < nodes.size(); ++n) {
+            const NodeIn& ni = G->nodes[nodeBase + n];
+            for (uint32_t k = 0; k < ni.treeCount; ++k) {
+                const uint32_t t = ni.treeBegin + k; const TreeIn& tree = G->trees[t];
+                if (tree.nodeCount == 0 || (uint64_t)tree.nodeBegin - nodeBase + tree.nodeCount > nodes.size()) continue;
+                fsdev::MatchCall c{0u, tree.nodeCount, (int32_t)mReads.size(), 0u};
+                add(vrecs[nodes[n].vrec].rec, (uint32_t)tree.mainSignaturePos);        // the root copy, at the sub-tree's signature position
+                c.first = (uint32_t)mReads.size();
+                for (uint32_t j = 0; j < tree.nodeCount; ++j) { const Node& sn = nodes[tree.nodeBegin - nodeBase + j]; add(vrecs[sn.vrec].rec, vrecs[sn.vrec].minimPos); }
+                callOfTree[t] = (int32_t)mCalls.size();
+                mCalls.push_back(c);
+            }
+        }
+        matchSeqBase = lo == ~0ull ? 0 : lo; matchSeqBytes = lo == ~0ull ? 0 : hi - lo;
+        for (auto& r : mReads) r.seq_off -= (uint32_t)matchSeqBase;
+    }
+    fsdev::MatchParams matchParams() const { return fsdev::MatchParams{par.maxLzWindowSize, par.shiftCost, par.mismatchCost, par.encodeThreshold}; }
+
     std::vector<uint64_t> prefKey;            // per node: the packed start of its reversed prefix (see constructMatchTree)
     WinRing winRings[8];                      // one per nesting level of sub-trees (constructMatchTree re-enters itself)
     uint32_t winDepth = 0;
 
     // ReadsClassifierSE::ConstructMatchTree (fastore_pack/ReadsClassifier.cpp:95-442).
     // order: node ids in processing order; auxRoot: node id of the sub-tree root copy or -1.
-    void constructMatchTree(const std::vector<int32_t>& order, std::vector<int32_t>& roots, int32_t auxRoot)
+    // call: index of this construction in mCalls (answers / trace rows at mCalls[call].first + position), or -1
+    void constructMatchTree(const std::vector<int32_t>& order, std::vector<int32_t>& roots, int32_t auxRoot, int32_t call = -1)
     {
+        const bool pre = havePre && call >= 0;
+        const fsdev::MatchRow* preRows = pre ? mRows.data() + mCalls[call].first : nullptr;
+        fsdev::MatchRow* traceRows = (matchTrace && call >= 0) ? matchTrace->data() + mCalls[call].first : nullptr;
+        const int32_t tableFirst = call >= 0 ? (int32_t)mCalls[call].first : 0, tableAux = call >= 0 ? mCalls[call].aux : -1;
+        std::vector<int32_t> placeOf;              // trace: node -> its place in `order`
+        if (traceRows) { placeOf.assign(nodes.size(), -1); for (size_t k = 0; k < order.size(); ++k) placeOf[order[k]] = (int32_t)k; }
         struct Dummy { uint8_t b[256]; Dummy() { memset(b, 'N', sizeof b); } };
         static const Dummy dummyEntry;                        // (initialised once, thread-safe: the encoders run side by side)
         const uint8_t* dummy = dummyEntry.b;
@@ -331,18 +381,30 @@ struct BinEncoder::Impl {
         if (auxRoot >= 0) {
             popBack();
             const int32_t v = nodes[auxRoot].vrec;
-            win.push_front(WinEntry{seq(v), auxRoot, (uint16_t)seqLen(v), (uint16_t)minimPos(v)});
+            if (!pre) win.push_front(WinEntry{seq(v), auxRoot, (uint16_t)seqLen(v), (uint16_t)minimPos(v)});
             roots.push_back(auxRoot);
         }
-        for (int32_t cur : order) {
+        for (size_t place = 0; place < order.size(); ++place) {
+            const int32_t cur = order[place];
             Node& curNode = nodes[cur];
             const int32_t v = curNode.vrec;
             const uint8_t* rs = seq(v); const uint32_t rl = seqLen(v); const int32_t rm = (int32_t)minimPos(v);
-            popBack();
+            if (!pre) popBack();
             int32_t encodeThreshold = par.encodeThreshold == 0 ? (int32_t)(rl / 2) : par.encodeThreshold;
             // FindBestLzMatch (ReadsClassifier.cpp:55-83)
             MatchResult mr; mr.cost = encodeThreshold + 1;
             bool stop = false;
+            int32_t bestNode = -1; bool bestIsReal = false; uint32_t bestLen = 256u;
+            if (pre) {
+                // the device searched the window (matcher.hip): the cheapest slot, the first among equals
+                const fsdev::MatchRow& row = preRows[place];
+                mr.cost = row.cost; mr.shift = row.shift; mr.noMismatches = row.no_mismatches != 0;
+                if (row.match >= 0) {
+                    bestIsReal = true;
+                    bestNode = row.match == tableAux ? auxRoot : order.at((size_t)(row.match - tableFirst));
+                    bestLen = seqLen(nodes[bestNode].vrec);
+                }
+            } else {
 #if defined(__SSE2__)
             {
                 // Eight entries per step are tested for |minPos - rm| * shiftCost <= best cost so far (and <= 127): an entry
@@ -390,15 +452,26 @@ struct BinEncoder::Impl {
                 // threshold; all dummies are identical, so the first one decides
                 if (updateLzMatch(mr, rs, rl, rm, dummy, 256, 0)) mr.prevId = (int32_t)win.size();
             }
-            const bool bestIsReal = (uint32_t)mr.prevId < win.size();
-            const uint32_t bestLen = bestIsReal ? win[mr.prevId].seqLen : 256u;
+            bestIsReal = (uint32_t)mr.prevId < win.size();
+            bestLen = bestIsReal ? win[mr.prevId].seqLen : 256u;
+            // (a dummy that wins leaves the reference with a null node; the slot the ring holds there is kept as it was)
+            bestNode = bestIsReal || win.mask ? win[mr.prevId].node : -1;
+            }
             bool identical = (mr.cost == 0 && bestLen == rl);
             bool isHard = mr.cost > encodeThreshold;
-            if (identical) identical = bestIsReal && nodes[win[mr.prevId].node].type != TYPE_NONE;
+            if (identical) identical = bestIsReal && nodes[bestNode].type != TYPE_NONE;
+            if (traceRows) {
+                fsdev::MatchRow& row = traceRows[place];
+                const bool any = mr.cost <= encodeThreshold;
+                row.match = !any ? -1 : (!bestIsReal ? -2 : (bestNode == auxRoot ? tableAux : tableFirst + placeOf[bestNode]));
+                row.cost = (int16_t)mr.cost; row.shift = (int16_t)(any ? mr.shift : 0); row.no_mismatches = any && mr.noMismatches ? 1 : 0;
+                row.identical = identical ? 1 : 0; row.dummy = any && !bestIsReal ? 1 : 0; row.pad = 0;
+            }
+            if (pre && identical != (preRows[place].identical != 0)) throw std::runtime_error("device matcher: duplicate flags disagree with the tree builder");
             const WinEntry newLz{rs, cur, (uint16_t)rl, (uint16_t)rm};
             if (identical) {
                 curNode.type = TYPE_NONE; curNode.lzVrec = -1; curNode.parent = -1;
-                Node& parent = nodes[win[mr.prevId].node];
+                Node& parent = nodes[bestNode];
                 if (curNode.hasEm) {
                     if (!parent.hasEm) { parent.hasEm = true; parent.em = std::move(curNode.em); }
                     else parent.em.insert(parent.em.end(), curNode.em.begin(), curNode.em.end());
@@ -451,12 +524,12 @@ struct BinEncoder::Impl {
                     curNode.type = TYPE_HARD; curNode.lzVrec = -1; curNode.parent = -1;
                     roots.push_back(cur);
                 } else {
-                    if (parentNode < 0) parentNode = win[mr.prevId].node;
+                    if (parentNode < 0) parentNode = bestNode;
                     curNode.type = TYPE_LZ; curNode.parent = parentNode; curNode.lzVrec = nodes[parentNode].vrec;
                     curNode.shift = (int16_t)mr.shift; curNode.noMismatches = mr.noMismatches; curNode.cost = (int16_t)mr.cost;
                     nodes[parentNode].children.push_back(cur);
                 }
-                win.push_front(newLz);
+                if (!pre) win.push_front(newLz);
                 if (rpb) {                        // std::set::insert: skipped when an equivalent node is present
                     const auto it = lbPos != ~(size_t)0 ? rpb->begin() + (ptrdiff_t)lbPos : std::lower_bound(rpb->begin(), rpb->end(), cur, prefixLess);
                     if (it == rpb->end() || prefixLess(cur, *it)) rpb->insert(it, cur);
@@ -784,7 +857,13 @@ struct BinEncoder::Impl {
         compressReadId(*headp, B->head.data() + r.headOff, r.headLen, out->s[S_IdToken], out->s[S_IdValue]);
         out->rawIdSize += r.headLen;
     }
-    void compressQuality(int32_t v) { compressReadQuality(cfg, seq(v), qua(v), seqLen(v), isReverse(v), out->s[S_Quality], qvzp, &well); }
+    bool packedQuality() const { return !B->quaBit.empty(); }
+    void refQuality(uint32_t bit, uint32_t len, bool reverse) { out->quaRefs.push_back(QuaRef{bit, (uint16_t)len, (uint16_t)(reverse ? 1 : 0)}); out->quaSymbols += len; }
+    void compressQuality(int32_t v)
+    {
+        if (packedQuality()) { refQuality(B->quaBit[vrecs[v].rec], seqLen(v), isReverse(v)); return; }
+        compressReadQuality(cfg, seq(v), qua(v), seqLen(v), isReverse(v), out->s[S_Quality], qvzp, &well);
+    }
 
     void compressHardRead(int32_t v)
     {
@@ -972,7 +1051,7 @@ struct BinEncoder::Impl {
             std::vector<int32_t> order(tree.nodeCount);
             for (uint32_t k = 0; k < tree.nodeCount; ++k) order[k] = (int32_t)(tree.nodeBegin - nodeBase + k);
             std::vector<int32_t> roots;
-            constructMatchTree(order, roots, localRoot);
+            constructMatchTree(order, roots, localRoot, t < callOfTree.size() ? callOfTree[t] : -1);
             const size_t contigMark = contigs.size();
             bool isFirst = true;
             for (int32_t root : roots) {
@@ -1036,7 +1115,21 @@ struct BinEncoder::Impl {
         for (uint32_t k = 0; k < bin.topCount; ++k) order[k] = (int32_t)(G->topNodes[bin.topBegin + k] - nodeBase);
         introsort(order.data(), order.size(), [&](int32_t a, int32_t b) { return compareReads(nodes[a].vrec, nodes[b].vrec); });
         std::vector<int32_t> roots;
-        constructMatchTree(order, roots, -1);
+        // the window searches of all the bin's constructions, on the device (matcher.hip); a row that names a dummy slot
+        // (reads of mostly 'N', manual thresholds) sends the whole bin through the host scan, which keeps the
+        // reference's handling of that corner
+        havePre = false;
+        const bool wantTable = (bool)matcher || matchTrace != nullptr;
+        if (wantTable) buildMatchTable(order);
+        if (matchTrace && traceResize) { matchTrace->assign(mReads.size(), fsdev::MatchRow{-1, 0, 0, 0, 0, 0, 0}); }
+        if (matcher && !matchTrace && par.maxLzWindowSize >= 2 && par.maxLzWindowSize <= 1025 && bin.maxLen <= 256) {
+            mRows.resize(mReads.size());
+            if (matcher(B->seq.data() + matchSeqBase, matchSeqBytes, mReads.data(), mReads.size(), mCalls.data(), mCalls.size(), matchParams(), mRows.data())) {
+                havePre = true;
+                for (const fsdev::MatchCall& c : mCalls) for (uint32_t i = 0; i < c.count && havePre; ++i) if (mRows[c.first + i].dummy) havePre = false;
+            }
+        }
+        constructMatchTree(order, roots, -1, wantTable ? 0 : -1);
 #ifdef FS_DEBUG_DUMP
         if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == bin.signature) {
             auto H = [&](int32_t n) { if (n < 0) return std::string("-"); const Rec& r = R(nodes[n].vrec); return std::string((const char*)B->head.data() + r.headOff, r.headLen); };
@@ -1064,6 +1157,30 @@ struct BinEncoder::Impl {
 namespace fs {
 
 BinEncoder::BinEncoder(const PackParams& par) : impl_(new Impl(par)) {}
+void BinEncoder::setMatcher(MatchFn fn) { impl_->matcher = std::move(fn); }
+void BinEncoder::checkMatcher(const Batch& data, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, const MatchFn& fn, uint64_t& reads, uint64_t& differing)
+{
+    Impl& m = *impl_;
+    BinStreams tmp;
+    std::vector<fsdev::MatchRow> host;
+    const MatchFn keep = m.matcher; m.matcher = nullptr;
+    // pass 1: the host scan, tracing its answers (the table is built inside; size the trace when it is known)
+    m.matchTrace = &host;
+    m.traceResize = true;
+    m.encodeLz(data, graph, bin, arch, tmp);
+    m.matchTrace = nullptr; m.traceResize = false;
+    const std::vector<fsdev::MatchRead> tReads = m.mReads; const std::vector<fsdev::MatchCall> tCalls = m.mCalls;
+    std::vector<fsdev::MatchRow> dev(tReads.size());
+    memset(dev.data(), 0, dev.size() * sizeof(fsdev::MatchRow));
+    if (!fn(data.seq.data() + m.matchSeqBase, m.matchSeqBytes, tReads.data(), tReads.size(), tCalls.data(), tCalls.size(), m.matchParams(), dev.data())) throw std::runtime_error("device matcher did not run");
+    for (const fsdev::MatchCall& c : tCalls)
+        for (uint32_t i = 0; i < c.count; ++i) {
+            const fsdev::MatchRow &a = host[c.first + i], &b = dev[c.first + i];
+            ++reads;
+            if (a.match != b.match || a.cost != b.cost || a.shift != b.shift || a.no_mismatches != b.no_mismatches || a.identical != b.identical || a.dummy != b.dummy) ++differing;
+        }
+    m.matcher = keep;
+}
 BinEncoder::~BinEncoder() { if (impl_) impl_->dropPairState(); delete impl_; }
 void BinEncoder::encodeLz(const Batch& batch, const BinIn& bin, const ArchiveParams& arch, BinStreams& out) { impl_->encodeLz(batch, batch, bin, arch, out); }
 void BinEncoder::encodeLz(const Batch& data, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, BinStreams& out) { impl_->encodeLz(data, graph, bin, arch, out); }

@@ -9,8 +9,10 @@
 #include <stdint.h>
 #include <deque>
 #include <vector>
+#include <functional>
 #include "format.h"
 #include "qvz.h"
+#include "device_types.h"
 
 namespace fs {
 
@@ -39,11 +41,19 @@ enum Stream {
     S_FlagPE = S_SE_COUNT, S_LettersXPE, S_SwapPE, S_HardPE, S_LzIdPE, S_ShiftPE, S_MatchRlePE, S_MatchBinaryPE, S_PE_COUNT
 };
 
+// one quality string of the device-side quality path, in emission order: where its scores start in the bin's packed
+// .bqua bytes, how many there are, and whether the string is emitted back to front (IQualityStoreBase::CompressReadQuality,
+// FastqCompressor.cpp:236: a reverse-complemented record's scores are coded in the read's original orientation)
+struct QuaRef { uint32_t bit; uint16_t len; uint16_t reverse; };
+
 struct BinStreams {
     std::vector<uint8_t> s[S_PE_COUNT];   // P streams: raw bytes; R streams: (symbol, ctx0) byte pairs
     uint64_t rawIdSize = 0;
     uint32_t nStreams = S_SE_COUNT;
-    void reset(uint32_t n) { nStreams = n; rawIdSize = 0; for (auto& v : s) v.clear(); }
+    // device-side quality path: s[S_Quality] stays empty, the stream is these strings one after the other
+    std::vector<QuaRef> quaRefs; uint64_t quaSymbols = 0;
+    const uint8_t* quaPacked = nullptr; uint64_t quaPackedBytes = 0;      // the bin's .bqua bytes (owned by the batch)
+    void reset(uint32_t n) { nStreams = n; rawIdSize = 0; for (auto& v : s) v.clear(); quaRefs.clear(); quaSymbols = 0; quaPacked = nullptr; quaPackedBytes = 0; }
 };
 
 // which streams are range-coded in place (true) vs PPMd-compressed (false), and with which model
@@ -54,9 +64,19 @@ uint32_t streamModel(uint32_t stream, uint32_t qualityMethod);
 // archive-level parameters of one library (they travel inside .bmeta)
 struct ArchiveParams { BinModuleConfigRaw cfg{}; HeaderStats head; QvzModel qvz; };
 
+// The device-side window search (matcher.hip) as the front end sees it: the bin's bases, the table of its match-tree
+// constructions, one row of answers per read.  Returns false when the search could not be run (the host scan is used).
+typedef std::function<bool(const uint8_t* seq, size_t seqBytes, const fsdev::MatchRead* reads, size_t nReads, const fsdev::MatchCall* calls,
+                           size_t nCalls, const fsdev::MatchParams& par, fsdev::MatchRow* rows)> MatchFn;
+
 class BinEncoder {
 public:
     explicit BinEncoder(const PackParams& par);
+    // window searches of the following encodeLz calls go through `fn` (empty: the host scan)
+    void setMatcher(MatchFn fn);
+    // parity check of the device matcher: runs the bin through the host scan and through `fn`, returns the number of reads
+    // and of rows that differ (match, cost, shift, mismatch-free flag, duplicate flag)
+    void checkMatcher(const Batch& data, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, const MatchFn& fn, uint64_t& reads, uint64_t& differing);
     // standard bin: LzCompressorSE/PE::Compress up to (not including) CompressBuffers
     void encodeLz(const Batch& batch, const BinIn& bin, const ArchiveParams& arch, BinStreams& out);
     // the same with the bin's stored graph in a batch of its own (node indices local to `graph`, record indices into `data`)

@@ -1,0 +1,336 @@
+// Device-side read matcher: the LZ-window search of ReadsClassifierSE::ConstructMatchTree
+// (/root/reference/fastore/fastore_pack/ReadsClassifier.cpp:95-442: PrepareLzBuffer :38-52, FindBestLzMatch :55-83,
+// UpdateLzMatchResult ReadsClassifier.h:160-196) for every read of every match-tree construction of a bin -- the
+// top-level one over the sorted reads and one per stored sub-tree with its copied root.
+//
+// What the reference does per read, in processing order: drop the oldest of the W window slots, compare the read with
+// every slot front to back (cost = |shift| * shiftCost + mismatches * mismatchCost over the overlap, shift = difference of
+// the signature positions, |shift| <= 127), keep the cheapest slot at or below the threshold -- the first one among equal
+// costs --, then put the read at the front, or, if it is an exact duplicate of a slot that is not the sub-tree's root
+// copy, at the back, from where the next read drops it unseen.  So the window a read sees is the last W-1 non-duplicate
+// reads before it (root copy included), newest first, padded with dummy slots of 256 x 'N' while fewer exist.
+//
+// MI355X mapping: one workgroup per construction, ONE THREAD PER WINDOW SLOT.  A thread keeps its slot's read in
+// registers as three bit planes (two base bits and an 'N' flag per position); the current read's planes are wave-uniform
+// (scalar loads).  Every thread prices its slot -- a per-lane 256-bit funnel shift by the difference of the signature
+// positions, XOR, population count -- and the workgroup takes the minimum of (cost, slot age): a DPP min inside each
+// wave, one LDS exchange and one barrier across the waves.  The thread that owns the oldest slot then takes the read
+// over.  Duplicates, the root copy and the dummy slots follow the reference to the letter, so the table that comes back
+// -- matched read, cost, shift, exact-duplicate flag per read -- is what the host's serial scan computes (checked read by
+// read: fsgpu_matcher_check, tests/test_gpu.py).  The prefix-buffer search of -r/-l (ReadsClassifier.cpp:115-153,
+// 329-392), which needs the final decisions of all earlier reads, stays with the host tree builder that consumes the table.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "device_types.h"
+#include "engine.h"
+
+using namespace fsdev;
+
+namespace {
+
+enum : uint32_t { kNone = 0xFFFFFFFFu };
+
+// ASCII bases -> three bit planes of NW words each (bit p of word w = position 32 w + p): plane 0/1 = the two bits of
+// (c >> 1) & 3 (A 0, C 1, T 2, G 3), plane 2 = the base is none of ACGT ('N'); positions past the read are 0 / 0 / 0
+template <int NW> __global__ __launch_bounds__(256) void fs_pack_bases(const uint8_t* __restrict__ seq, const MatchRead* __restrict__ reads, uint32_t nReads,
+                                                                        uint32_t* __restrict__ planes)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t r = g / NW, w = g % NW;
+    if (r >= nReads) return;
+    const MatchRead rd = reads[r];
+    const uint8_t* s = seq + rd.seq_off;
+    uint32_t p0 = 0, p1 = 0, pn = 0;
+    for (uint32_t b = 0; b < 32u; ++b) {
+        const uint32_t pos = 32u * w + b;
+        if (pos >= rd.len) break;
+        const uint32_t c = s[pos];
+        const bool acgt = c == 'A' || c == 'C' || c == 'G' || c == 'T';
+        const uint32_t code = acgt ? (c >> 1) & 3u : 0u;
+        p0 |= (code & 1u) << b; p1 |= (code >> 1) << b; pn |= (acgt ? 0u : 1u) << b;
+    }
+    uint32_t* o = planes + (size_t)r * (3 * NW);
+    o[w] = p0; o[NW + w] = p1; o[2 * NW + w] = pn;
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
+{
+    // DPP min scan: row_shr 1/2/4/8 inside each row of 16, row_bcast 15 / 31 across the rows; the wave's minimum ends in lane 63
+    int v = (int)x;
+    #define FS_MIN_STEP(ctrl, rowmask) do { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp((int)kNone, v, ctrl, rowmask, 0xf, false); \
+                                            v = (int)(((uint32_t)v < o_) ? (uint32_t)v : o_); } while (0)
+    FS_MIN_STEP(0x111, 0xf); FS_MIN_STEP(0x112, 0xf); FS_MIN_STEP(0x114, 0xf); FS_MIN_STEP(0x118, 0xf);
+    FS_MIN_STEP(0x142, 0xa); FS_MIN_STEP(0x143, 0xc);
+    #undef FS_MIN_STEP
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+
+// right shift of an NW-word bit string by s < 128 bits
+template <int NW> __device__ __forceinline__ void shr_bits(uint32_t (&x)[NW], uint32_t s)
+{
+    const uint32_t ws = s >> 5, bs = s & 31u;
+    if (ws & 1u) { _Pragma("unroll") for (int i = 0; i < NW; ++i) x[i] = i + 1 < NW ? x[i + 1] : 0u; }
+    if (ws & 2u) { _Pragma("unroll") for (int i = 0; i < NW; ++i) x[i] = i + 2 < NW ? x[i + 2] : 0u; }
+    _Pragma("unroll") for (int i = 0; i < NW; ++i) x[i] = __builtin_amdgcn_alignbit(i + 1 < NW ? x[i + 1] : 0u, x[i], bs);
+}
+
+struct Shared {
+    uint32_t key[2][16], match[2][16], info[2][16];     // per wave: its best key, the matched read, len | shift << 16 | noMismatches << 31; two buffers by parity
+};
+
+// MULTI: more than one wavefront per construction (windows of more than 64 slots)
+template <int NW, bool MULTI> __global__ __launch_bounds__(MULTI ? 1024 : 64) void fs_match_reads(
+    const MatchCall* __restrict__ calls, const uint32_t* __restrict__ callIds, const MatchRead* __restrict__ reads, const uint32_t* __restrict__ planes,
+    MatchParams par, MatchRow* __restrict__ rows)
+{
+    __shared__ Shared sh;
+    const MatchCall call = calls[callIds[blockIdx.x]];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nWaves = blockDim.x >> 6;
+    const uint32_t cap = par.window - 1u;                 // real slots: the reference drops one slot before every search
+    // this thread's slot
+    uint32_t e0[NW], e1[NW], en[NW];
+    uint32_t eRead = kNone, eLen = 0, eMin = 0, ePush = 0; bool valid = false;
+    uint32_t pushed = 0, nextSlot = 0;                     // entries put at the front so far; entry k lives in slot k % cap = nextSlot
+    auto take = [&](uint32_t r, uint32_t minPos) {        // the owner of the next slot takes read r over
+        if (tid == nextSlot) {
+            const uint32_t* p = planes + (size_t)r * (3 * NW);
+            _Pragma("unroll") for (int i = 0; i < NW; ++i) { e0[i] = p[i]; e1[i] = p[NW + i]; en[i] = p[2 * NW + i]; }
+            eRead = r; eLen = reads[r].len; eMin = minPos; ePush = pushed; valid = true;
+        }
+        ++pushed; nextSlot = nextSlot + 1u == cap ? 0u : nextSlot + 1u;
+    };
+    if (call.aux >= 0) take((uint32_t)call.aux, reads[call.aux].min_pos);
+    for (uint32_t i = 0; i < call.count; ++i) {
+        const uint32_t r = call.first + i;
+        const MatchRead rd = reads[r];
+        const uint32_t rLen = rd.len, rMin = rd.min_pos;
+        const int32_t thr = par.encode_threshold ? par.encode_threshold : (int32_t)(rLen / 2u);
+        const uint32_t* rp = planes + (size_t)r * (3 * NW);          // wave-uniform address: scalar loads
+        uint32_t key = kNone, myInfo = 0;
+        if (valid) {
+            const int32_t shift = (int32_t)eMin - (int32_t)rMin;
+            const uint32_t ashift = (uint32_t)(shift < 0 ? -shift : shift);
+            const int32_t insertCost = (int32_t)ashift * par.shift_cost;
+            if (ashift <= 127u && insertCost <= thr + 1) {
+                // a: the string that is read from offset `ashift` on, b: the one read from its start
+                uint32_t a0[NW], a1[NW], an[NW], b0[NW], b1[NW], bn[NW];
+                const bool entryShifted = shift > 0;
+                _Pragma("unroll") for (int k = 0; k < NW; ++k) {
+                    const uint32_t r0 = rp[k], r1 = rp[NW + k], rn = rp[2 * NW + k];
+                    a0[k] = entryShifted ? e0[k] : r0; a1[k] = entryShifted ? e1[k] : r1; an[k] = entryShifted ? en[k] : rn;
+                    b0[k] = entryShifted ? r0 : e0[k]; b1[k] = entryShifted ? r1 : e1[k]; bn[k] = entryShifted ? rn : en[k];
+                }
+                shr_bits<NW>(a0, ashift); shr_bits<NW>(a1, ashift); shr_bits<NW>(an, ashift);
+                const uint32_t aLen = (entryShifted ? eLen : rLen) - ashift, bLen = entryShifted ? rLen : eLen;
+                const uint32_t minLen = aLen < bLen ? aLen : bLen;
+                uint32_t mism = 0;
+                _Pragma("unroll") for (int k = 0; k < NW; ++k) {
+                    const uint32_t lo = 32u * (uint32_t)k;
+                    const uint32_t m = minLen >= lo + 32u ? 0xFFFFFFFFu : (minLen > lo ? (1u << (minLen - lo)) - 1u : 0u);
+                    const uint32_t anyN = an[k] | bn[k];
+                    const uint32_t d = ((((a0[k] ^ b0[k]) | (a1[k] ^ b1[k])) & ~anyN) | (an[k] ^ bn[k])) & m;
+                    mism += (uint32_t)__builtin_popcount(d);
+                }
+                const int32_t cc = insertCost + (int32_t)mism * par.mismatch_cost;
+                if (cc <= thr) {
+                    key = ((uint32_t)cc << 16) | (pushed - 1u - ePush);       // age: 0 = newest
+                    myInfo = eLen | (((uint32_t)shift & 0x7FFFu) << 16) | (mism == 0u ? 0x80000000u : 0u);
+                }
+            }
+        }
+        uint32_t myMatch = eRead;
+        // the dummy slots (256 x 'N', signature position 0) are all alike and come behind the real ones: one thread prices them
+        if (pushed < cap && tid == nextSlot && rMin <= 127u) {
+            uint32_t nN = 0;                                                  // 'N' positions of the read from rMin on
+            _Pragma("unroll") for (int k = 0; k < NW; ++k) {
+                const uint32_t lo = 32u * (uint32_t)k;
+                const uint32_t from = rMin > lo ? (rMin - lo >= 32u ? 0u : 0xFFFFFFFFu << (rMin - lo)) : 0xFFFFFFFFu;
+                nN += (uint32_t)__builtin_popcount(rp[2 * NW + k] & from);
+            }
+            const uint32_t minLen = rLen - rMin < 256u ? rLen - rMin : 256u;
+            const int32_t cc = (int32_t)rMin * par.shift_cost + (int32_t)(minLen - nN) * par.mismatch_cost;
+            if (cc <= thr) {
+                key = ((uint32_t)cc << 16) | pushed;
+                myInfo = 256u | (((uint32_t)(-(int32_t)rMin) & 0x7FFFu) << 16) | (minLen == nN ? 0x80000000u : 0u);
+                myMatch = kNone - 1u;                                        // dummy
+            }
+        }
+        // minimum over the workgroup; the owner of the minimum publishes its slot
+        uint32_t best = wave_min_u32(key), bMatch, bInfo;
+        if (MULTI) {
+            const uint32_t par2 = i & 1u;
+            if (key == best && (best != kNone ? true : lane == 0u)) { sh.key[par2][wave] = best; sh.match[par2][wave] = myMatch; sh.info[par2][wave] = myInfo; }
+            __syncthreads();
+            uint32_t k2 = lane < nWaves ? sh.key[par2][lane] : kNone;
+            best = wave_min_u32(k2);
+            const uint64_t who = __ballot(lane < nWaves && k2 == best);
+            const uint32_t w = (uint32_t)__builtin_ctzll(who | (1ull << 63));
+            bMatch = sh.match[par2][w < nWaves ? w : 0u]; bInfo = sh.info[par2][w < nWaves ? w : 0u];
+        } else {
+            const uint64_t who = __ballot(key == best);
+            const uint32_t l = (uint32_t)__builtin_ctzll(who);
+            bMatch = (uint32_t)__builtin_amdgcn_readlane((int)myMatch, (int)l); bInfo = (uint32_t)__builtin_amdgcn_readlane((int)myInfo, (int)l);
+        }
+        MatchRow row; row.match = -1; row.cost = (int16_t)(thr + 1); row.shift = 0; row.no_mismatches = 0; row.identical = 0; row.dummy = 0; row.pad = 0;
+        bool identical = false;
+        if (best != kNone) {
+            const bool dummy = bMatch == kNone - 1u;
+            const uint32_t cost = best >> 16, bLen = bInfo & 0xFFFFu;
+            int32_t sh15 = (int32_t)((bInfo >> 16) & 0x7FFFu); if (sh15 & 0x4000) sh15 -= 0x8000;
+            row.match = dummy ? -2 : (int32_t)bMatch; row.cost = (int16_t)cost; row.shift = (int16_t)sh15;
+            row.no_mismatches = (uint8_t)(bInfo >> 31); row.dummy = dummy ? 1 : 0;
+            // an exact duplicate of a real slot that is not the sub-tree's root copy goes to the back of the window and is
+            // dropped by the next read (ReadsClassifier.cpp:184-186, 305)
+            identical = cost == 0u && bLen == rLen && !dummy && (int32_t)bMatch != call.aux;
+            row.identical = identical ? 1 : 0;
+        }
+        if (tid == 0u) rows[r] = row;
+        if (!identical) take(r, rMin);
+    }
+}
+
+template <class T> int ensureBuf(fsengine::Device* dev, T*& p, size_t& cap, size_t need)
+{
+    if (need <= cap && p) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = need + need / 4 + 4096;
+    hipError_t e = hipMalloc((void**)&p, want);
+    if (e != hipSuccess) { snprintf(dev->err, sizeof dev->err, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return -1; }
+    cap = want;
+    return 0;
+}
+
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(dev->err, sizeof dev->err, "%s failed: %s", #x, hipGetErrorString(e_)); return -1; } } while (0)
+
+}  // namespace
+
+namespace fsengine {
+
+struct MatchLane {
+    int deviceId = 0;
+    hipStream_t stream = nullptr; hipEvent_t evWait = nullptr, ev0 = nullptr, ev1 = nullptr;
+    uint8_t* dSeq = nullptr; size_t capSeq = 0;
+    MatchRead* dReads = nullptr; size_t capReads = 0;
+    MatchCall* dCalls = nullptr; size_t capCalls = 0;
+    uint32_t* dIds = nullptr; size_t capIds = 0;
+    uint32_t* dPlanes = nullptr; size_t capPlanes = 0;
+    MatchRow* dRows = nullptr; size_t capRows = 0;
+    uint8_t* hStage = nullptr; size_t capStage = 0;
+};
+
+int match_lane_create(Device* dev, MatchLane** out)
+{
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(dev->deviceId));
+    MatchLane* m = new MatchLane(); m->deviceId = dev->deviceId;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // (least, greatest): the searches are short and sit in front of host work
+    hipError_t e = hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, hi);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->evWait, hipEventBlockingSync | hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&m->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&m->ev1);
+    if (e != hipSuccess) { snprintf(dev->err, sizeof dev->err, "matcher lane: %s", hipGetErrorString(e)); delete m; return -1; }
+    *out = m;
+    return 0;
+}
+
+void match_lane_destroy(MatchLane* m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->deviceId);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    void* ptrs[] = {m->dSeq, m->dReads, m->dCalls, m->dIds, m->dPlanes, m->dRows};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (m->hStage) (void)hipHostFree(m->hStage);
+    if (m->evWait) (void)hipEventDestroy(m->evWait);
+    if (m->ev0) (void)hipEventDestroy(m->ev0);
+    if (m->ev1) (void)hipEventDestroy(m->ev1);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+// One bin's searches.  seq: the bin's bases (ASCII); reads: every read of every construction, each construction's reads in
+// processing order (a sub-tree's root copy is one more read, named by its call); rows[i] answers reads[i] (root copies: unset).
+int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, const MatchRead* reads, size_t nReads,
+                const MatchCall* calls, size_t nCalls, const MatchParams& par, MatchRow* rows, double* kernelMs)
+{
+    if (nReads == 0 || nCalls == 0) return 0;
+    if (par.window < 2u || par.window > 1025u) { snprintf(dev->err, sizeof dev->err, "device matcher: window of %u slots not supported (2..1025)", par.window); return -1; }
+    HIP_TRY(hipSetDevice(m->deviceId));
+    uint32_t maxLen = 0;
+    for (size_t i = 0; i < nReads; ++i) {
+        if ((uint64_t)reads[i].seq_off + reads[i].len > seqBytes || reads[i].min_pos > reads[i].len) { snprintf(dev->err, sizeof dev->err, "device matcher: read %zu outside the bases", i); return -1; }
+        maxLen = std::max<uint32_t>(maxLen, reads[i].len);
+    }
+    if (maxLen > 256u) { snprintf(dev->err, sizeof dev->err, "device matcher: reads longer than 256 bases"); return -1; }
+    const int NW = maxLen <= 160u ? 5 : 8;
+    // constructions by the number of window slots they can fill: one wavefront, or one thread per slot up to the window
+    std::vector<uint32_t> ids(nCalls), small, large[4];       // large: 128, 256, 512, 1024 threads
+    const uint32_t cap = par.window - 1u;
+    for (size_t c = 0; c < nCalls; ++c) {
+        const MatchCall& k = calls[c];
+        if ((uint64_t)k.first + k.count > nReads || (k.aux >= 0 && (size_t)k.aux >= nReads)) { snprintf(dev->err, sizeof dev->err, "device matcher: construction %zu outside the read table", c); return -1; }
+        if (k.count == 0) continue;
+        const uint32_t slots = std::min<uint32_t>(k.count + (k.aux >= 0 ? 1u : 0u), cap);
+        if (slots <= 64u) small.push_back((uint32_t)c);
+        else large[slots <= 128u ? 0 : (slots <= 256u ? 1 : (slots <= 512u ? 2 : 3))].push_back((uint32_t)c);
+    }
+    const size_t planeBytes = nReads * (size_t)(3 * NW) * 4u;
+    if (ensureBuf(dev, m->dSeq, m->capSeq, seqBytes + 64) || ensureBuf(dev, m->dReads, m->capReads, nReads * sizeof(MatchRead)) ||
+        ensureBuf(dev, m->dCalls, m->capCalls, nCalls * sizeof(MatchCall)) || ensureBuf(dev, m->dIds, m->capIds, nCalls * 4u) ||
+        ensureBuf(dev, m->dPlanes, m->capPlanes, planeBytes) || ensureBuf(dev, m->dRows, m->capRows, nReads * sizeof(MatchRow))) return -1;
+    // pinned staging for everything that goes up (the callers' arrays are pageable)
+    const size_t upBytes = ((seqBytes + 15) & ~(size_t)15) + ((nReads * sizeof(MatchRead) + 15) & ~(size_t)15) + ((nCalls * sizeof(MatchCall) + 15) & ~(size_t)15) + nCalls * 4u + 64;
+    if (upBytes > m->capStage) {
+        if (m->hStage) (void)hipHostFree(m->hStage);
+        m->hStage = nullptr; m->capStage = 0;
+        const size_t want = upBytes + upBytes / 4 + 65536;
+        HIP_TRY(hipHostMalloc((void**)&m->hStage, want, hipHostMallocDefault));
+        m->capStage = want;
+    }
+    uint8_t* h = m->hStage; size_t o = 0;
+    memcpy(h + o, seq, seqBytes); const size_t oSeq = o; o += (seqBytes + 15) & ~(size_t)15;
+    memcpy(h + o, reads, nReads * sizeof(MatchRead)); const size_t oReads = o; o += (nReads * sizeof(MatchRead) + 15) & ~(size_t)15;
+    memcpy(h + o, calls, nCalls * sizeof(MatchCall)); const size_t oCalls = o; o += (nCalls * sizeof(MatchCall) + 15) & ~(size_t)15;
+    uint32_t* hid = (uint32_t*)(h + o); const size_t oIds = o; size_t nid = 0;
+    const size_t smallAt = nid; for (uint32_t c : small) hid[nid++] = c;
+    size_t largeAt[4]; for (int g = 0; g < 4; ++g) { largeAt[g] = nid; for (uint32_t c : large[g]) hid[nid++] = c; }
+    hipStream_t st = m->stream;
+    HIP_TRY(hipMemcpyAsync(m->dSeq, h + oSeq, seqBytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->dReads, h + oReads, nReads * sizeof(MatchRead), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->dCalls, h + oCalls, nCalls * sizeof(MatchCall), hipMemcpyHostToDevice, st));
+    if (nid) HIP_TRY(hipMemcpyAsync(m->dIds, h + oIds, nid * 4u, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(m->ev0, st));
+    const uint32_t packBlocks = (uint32_t)((nReads * (size_t)NW + 255) / 256);
+    if (NW == 5) hipLaunchKernelGGL(fs_pack_bases<5>, dim3(packBlocks), dim3(256), 0, st, (const uint8_t*)m->dSeq, (const MatchRead*)m->dReads, (uint32_t)nReads, m->dPlanes);
+    else hipLaunchKernelGGL(fs_pack_bases<8>, dim3(packBlocks), dim3(256), 0, st, (const uint8_t*)m->dSeq, (const MatchRead*)m->dReads, (uint32_t)nReads, m->dPlanes);
+    HIP_TRY(hipGetLastError());
+    auto launch = [&](size_t at, size_t n, uint32_t threads) {
+        if (!n) return;
+        const uint32_t* idp = m->dIds + at;
+        if (threads == 64u) {
+            if (NW == 5) hipLaunchKernelGGL((fs_match_reads<5, false>), dim3((uint32_t)n), dim3(64), 0, st, (const MatchCall*)m->dCalls, idp, (const MatchRead*)m->dReads, (const uint32_t*)m->dPlanes, par, m->dRows);
+            else hipLaunchKernelGGL((fs_match_reads<8, false>), dim3((uint32_t)n), dim3(64), 0, st, (const MatchCall*)m->dCalls, idp, (const MatchRead*)m->dReads, (const uint32_t*)m->dPlanes, par, m->dRows);
+        } else {
+            if (NW == 5) hipLaunchKernelGGL((fs_match_reads<5, true>), dim3((uint32_t)n), dim3(threads), 0, st, (const MatchCall*)m->dCalls, idp, (const MatchRead*)m->dReads, (const uint32_t*)m->dPlanes, par, m->dRows);
+            else hipLaunchKernelGGL((fs_match_reads<8, true>), dim3((uint32_t)n), dim3(threads), 0, st, (const MatchCall*)m->dCalls, idp, (const MatchRead*)m->dReads, (const uint32_t*)m->dPlanes, par, m->dRows);
+        }
+    };
+    // the largest constructions first: they run the longest
+    for (int g = 3; g >= 0; --g) launch(largeAt[g], large[g].size(), 128u << g);
+    launch(smallAt, small.size(), 64u);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(m->ev1, st));
+    HIP_TRY(hipMemcpyAsync(rows, m->dRows, nReads * sizeof(MatchRow), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(m->evWait, st));
+    HIP_TRY(hipEventSynchronize(m->evWait));
+    if (kernelMs) { float a = 0; (void)hipEventElapsedTime(&a, m->ev0, m->ev1); *kernelMs += a; }
+    return 0;
+}
+
+}  // namespace fsengine

@@ -253,6 +253,41 @@ fsengine::Device* Context::lane(uint32_t i)
     return lanes[i];
 }
 
+// The window searches of host thread `tid`: its own matcher lane (stream + buffers), created on the first bin
+MatchFn Context::matcherFor(uint32_t tid)
+{
+    if (!deviceMatcher) return MatchFn();
+    if (matchLanes.size() <= tid) throw std::runtime_error("matcher lanes not sized");       // (sized by the callers before their threads start)
+    return [this, tid](const uint8_t* seq, size_t seqBytes, const fsdev::MatchRead* reads, size_t nReads, const fsdev::MatchCall* calls, size_t nCalls,
+                       const fsdev::MatchParams& mp, fsdev::MatchRow* rows) -> bool {
+        if (!matchLanes[tid] && fsengine::match_lane_create(dev, &matchLanes[tid]) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+        const double t0 = nowMs(); double kms = 0;
+        if (fsengine::match_reads(dev, matchLanes[tid], seq, seqBytes, reads, nReads, calls, nCalls, mp, rows, &kms) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+        matchedReads += nReads; matchUs += (uint64_t)((nowMs() - t0) * 1e3); matchKernelUs += (uint64_t)(kms * 1e3);
+        return true;
+    };
+}
+
+// Parity check of the device matcher on every standard bin of a library: host scan vs device, row by row
+void Context::matcherCheck(const std::string& inPrefix, uint64_t& reads, uint64_t& differing)
+{
+    reads = differing = 0;
+    BinFile bf; bf.open(inPrefix, par.minBinSize);
+    ArchiveParams arch; arch.cfg = bf.config(); arch.head = bf.headData(); arch.qvz = bf.qvz();
+    const std::vector<uint32_t>& sigs = bf.stdSignatures();
+    std::mutex mx;
+    const bool keep = deviceMatcher; deviceMatcher = true;
+    if (matchLanes.size() < hostThreads) matchLanes.resize(hostThreads, nullptr);
+    parallelFor((uint32_t)sigs.size(), std::min<uint32_t>(hostThreads, 8u), [&](uint32_t k, uint32_t tid) {
+        Batch b; bf.unpack(sigs[k], b, true);
+        BinEncoder enc(par);
+        uint64_t r = 0, d = 0;
+        enc.checkMatcher(b, b, b.bins.at(0), arch, matcherFor(tid), r, d);
+        std::lock_guard<std::mutex> g(mx); reads += r; differing += d;
+    });
+    deviceMatcher = keep;
+}
+
 void Context::gatherBlocks()
 {
     const uint32_t nBins = (uint32_t)blockSizes.size();
@@ -387,6 +422,8 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             S.plans.resize(count);
             S.items.reserve((size_t)count * S_PE_COUNT);
             uint64_t inBytes = 0;
+            // device-side quality path: per bin the place of its packed scores in the input; the gathered streams' places
+            std::vector<uint64_t> packedOff(count, 0); std::vector<uint32_t> gatherItems; uint64_t gatherBytes = 0, nStrings = 0, gatherSymbols = 0;
             // --lossy libraries: one read-only model blob per library in front of the streams
             std::vector<uint64_t> qvzOff(archives.size(), ~0ull);
             for (uint32_t k = 0; k < count; ++k) {
@@ -409,6 +446,20 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 for (uint32_t s = 0; s < bs.nStreams; ++s) if (!streamIsRangeCoded(s, qm)) pl.copy_order[c++] = s;
                 for (uint32_t s = 0; s < bs.nStreams; ++s) {
                     const bool rc = streamIsRangeCoded(s, qm);
+                    if (s == S_Quality && !bs.quaRefs.empty()) {       // device-side quality path: the stream is gathered on the device
+                        if (rc || !bs.quaPacked) throw std::runtime_error("quality references without packed scores");
+                        StreamItem it; memset(&it, 0, sizeof it);
+                        it.bin = k; it.kind = KIND_PPMD; it.in_len = (uint32_t)bs.quaSymbols; it.out_cap = (uint32_t)(bs.quaSymbols + bs.quaSymbols / 8 + 64);
+                        if (bs.quaSymbols > 0xF0000000ull) throw std::runtime_error("stream larger than 4 GiB");
+                        it.in_off = gatherBytes;                         // relative to the gather region for now (its base is known after the layout)
+                        gatherBytes += (bs.quaSymbols + 15u + 16u) & ~15ull;
+                        gatherItems.push_back((uint32_t)S.items.size());
+                        pl.work_size[s] = bs.quaSymbols;
+                        S.items.push_back(it);
+                        packedOff[k] = inBytes; inBytes += (bs.quaPackedBytes + 8u + 15u) & ~15ull;
+                        nStrings += bs.quaRefs.size(); gatherSymbols += bs.quaSymbols;
+                        continue;
+                    }
                     const uint64_t bytes = bs.s[s].size();
                     if (bytes > 0xF0000000ull) throw std::runtime_error("stream larger than 4 GiB");
                     StreamItem it; memset(&it, 0, sizeof it);
@@ -426,20 +477,46 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                     inBytes += (bytes + 15) & ~15ull;
                 }
             }
+            fsdev::GatherPlan gp;
+            if (nStrings) {
+                if (nStrings > 0xFFFFFFF0ull || gatherBytes > 0xF0000000ull) throw std::runtime_error("quality gather larger than 4 GiB");
+                gp.desc_off = inBytes; gp.n_strings = (uint32_t)nStrings; gp.out_bytes = gatherBytes; gp.symbols = gatherSymbols;
+                inBytes += (nStrings * sizeof(fsdev::QuaString) + 15u) & ~15ull;
+                const uint64_t gatherBase = (inBytes + 15u) & ~15ull;
+                for (uint32_t gi : gatherItems) S.items[gi].in_off += gatherBase;
+            }
             fsengine::Device* L = lanes[(uint32_t)S.lane];
             uint8_t* input = fsengine::staging_buffer(L, inBytes + 16);        // pinned host memory owned by the lane
             if (!input) throw std::runtime_error(std::string("device: ") + L->err);
             for (size_t a = 0; a < archives.size(); ++a) if (qvzOff[a] != ~0ull) memcpy(input + qvzOff[a], archives[a].qvz.blob.data(), archives[a].qvz.blob.size());
             // staging copy on a few helper threads of its own (the host threads are busy with the next slices' front end)
+            std::vector<uint64_t> stringBase(count + 1, 0);          // first descriptor of every bin
+            if (nStrings) for (uint32_t k = 0; k < count; ++k) stringBase[k + 1] = stringBase[k] + st[byWork[first + k]].quaRefs.size();
             parallelFor(count, 4, [&](uint32_t k, uint32_t) {
                 const BlockPlan& pl = S.plans[k]; const uint32_t b = byWork[first + k];
+                const bool gathered = !st[b].quaRefs.empty();
                 for (uint32_t s = 0; s < pl.n_streams; ++s) {
+                    if (gathered && s == S_Quality) continue;
                     const auto& v = st[b].s[s];
                     if (!v.empty()) memcpy(input + S.items[pl.first_item + s].in_off, v.data(), v.size());
                 }
+                if (gathered) {
+                    memcpy(input + packedOff[k], st[b].quaPacked, st[b].quaPackedBytes);
+                    memset(input + packedOff[k] + st[b].quaPackedBytes, 0, 8);
+                    fsdev::QuaString* qs = (fsdev::QuaString*)(input + gp.desc_off) + stringBase[k];
+                    // the stream's place in the gather region, relative to its base (in_off is absolute: the base is the
+                    // input size rounded up to 16, see encode_batch)
+                    uint64_t dst = S.items[pl.first_item + S_Quality].in_off - ((inBytes + 15u) & ~15ull);
+                    const uint64_t srcBase = 8ull * packedOff[k], maxBit = 8ull * st[b].quaPackedBytes;
+                    for (const QuaRef& r : st[b].quaRefs) {
+                        if ((uint64_t)r.bit + 6ull * r.len > maxBit) throw std::runtime_error("Corrupted bin: quality string outside the bin's quality bytes");
+                        qs->src_bit = srcBase + r.bit; qs->dst_off = (uint32_t)dst; qs->len = r.len; qs->reverse = r.reverse; ++qs;
+                        dst += r.len;
+                    }
+                }
             });
             S.tSubmit = nowMs(); S.inBytes = inBytes;
-            if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, sliceBlocks[si], S.sizes, &S.timing) != 0) S.err = std::string("device: ") + L->err;
+            if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, sliceBlocks[si], S.sizes, &S.timing, nStrings ? &gp : nullptr) != 0) S.err = std::string("device: ") + L->err;
         } catch (const std::exception& e) { S.err = e.what(); }
         S.tDone = nowMs();
         { std::lock_guard<std::mutex> lk(laneMx); freeLanes.push_back((uint32_t)S.lane); }
@@ -482,11 +559,12 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     std::vector<double> busyMs(hostThreads, 0.0);
     std::vector<std::unique_ptr<BinEncoder>>& encs = encoders;        // kept across calls: their work buffers stay mapped
     if (encs.size() < hostThreads) encs.resize(hostThreads);
+    if (matchLanes.size() < hostThreads) matchLanes.resize(hostThreads, nullptr);
     const double tf = nowMs();
     try {
         parallelFor(nBins, hostThreads, [&](uint32_t k, uint32_t tid) {
             const uint32_t b = byWork[k];
-            if (!encs[tid]) encs[tid].reset(new BinEncoder(par));
+            if (!encs[tid]) { encs[tid].reset(new BinEncoder(par)); encs[tid]->setMatcher(matcherFor(tid)); }
             const double ta = trace ? nowMs() : 0.0;
             produce(b, *encs[tid], st[b], info[b], recBytes[b]);
             if (trace) busyMs[tid] += nowMs() - ta;
@@ -520,6 +598,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         timing.encode_ms += S.timing.encode_ms; timing.assemble_ms += S.timing.assemble_ms; timing.launches += S.timing.launches; timing.items += S.timing.items;
         timing.ppmd_symbols += S.timing.ppmd_symbols; timing.rc_symbols += S.timing.rc_symbols; timing.restarts += S.timing.restarts; for (int w = 0; w < 16; ++w) timing.win[w] += S.timing.win[w];
         timing.h2d_bytes += S.timing.h2d_bytes; timing.d2h_bytes += S.timing.d2h_bytes;
+        timing.gather_ms += S.timing.gather_ms; timing.gather_symbols += S.timing.gather_symbols; timing.gather_bytes += S.timing.gather_bytes;
         if (trace) fprintf(stderr, "[trace] slice %u/%u: %u bins, front end done at %.1f ms, staged+submitted at %.1f ms, device done at %.1f ms (kernel %.1f ms)\n",
                            si + 1, nSlices, cut[si + 1] - cut[si], S.tReady - t0, S.tSubmit - t0, S.tDone - t0, S.timing.encode_ms);
     }
@@ -695,14 +774,21 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             const uint32_t nb = (uint32_t)(next - first);
             // record arrays are placed: their sizes are in the .bmeta footer, so every bin knows its offsets up front and
             // is unpacked by the same host task that runs its front end (no barrier between the two stages)
-            std::vector<uint64_t> seqBase(nb + 1, 0), headBase(nb + 1, 0), recBase(nb + 1, 0), weight(nb);
+            std::vector<uint64_t> seqBase(nb + 1, 0), headBase(nb + 1, 0), recBase(nb + 1, 0), quaBase(nb + 1, 0), weight(nb);
+            // device-side quality path: lossless archives keep their scores packed (fs_gather_quality unpacks, orients and
+            // orders them on the device); FS_DEVICE_QUALITY=0 keeps the host symbolisation (A/B runs)
+            bool packedQ = !(getenv("FS_DEVICE_QUALITY") && atoi(getenv("FS_DEVICE_QUALITY")) == 0);
+            for (uint32_t k = 0; k < nb; ++k) if (archives[work[first + k].lib].cfg.quaParams.method != MET_NONE) packedQ = false;
             for (uint32_t k = 0; k < nb; ++k) {
                 const BinInfo& bi = libs[work[first + k].lib]->bf.bins().at(work[first + k].sig);
                 seqBase[k + 1] = seqBase[k] + bi.totalRawDnaSize; headBase[k + 1] = headBase[k] + bi.totalRawHeadSize; recBase[k + 1] = recBase[k] + bi.totalRecordsCount;
+                quaBase[k + 1] = quaBase[k] + ((bi.totalQuaSize + 15u) & ~15ull);
                 weight[k] = bi.totalRecordsCount;
             }
             if (seqBase[nb] > 0xFFFFFFF0ull || headBase[nb] > 0xFFFFFFF0ull || recBase[nb] > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB");
-            batch.seq.resize(seqBase[nb]); batch.qua.resize(seqBase[nb]); batch.head.resize(headBase[nb]); batch.recs.resize(recBase[nb]);
+            batch.seq.resize(seqBase[nb]); batch.head.resize(headBase[nb]); batch.recs.resize(recBase[nb]);
+            if (packedQ) { batch.qua.clear(); batch.quaPacked.resize(quaBase[nb]); batch.quaBit.resize(recBase[nb]); }
+            else { batch.qua.resize(seqBase[nb]); batch.quaPacked.clear(); batch.quaBit.clear(); }
             std::vector<Batch> graph(nb);                              // per bin: its stored graph (node indices local to it)
             for (size_t k = first; k < next; ++k) binArch.push_back(work[k].lib);
             stats.io_ms += nowMs() - tio;
@@ -718,9 +804,10 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             };
             compressBins(nb, weight, binArch, [&](uint32_t k, BinEncoder& enc, BinStreams& out, BinIn& info, uint64_t& recBytes) {
                 const Work& w = work[first + k];
-                libs[w.lib]->bf.unpackPlaced(w.sig, batch, seqBase[k], headBase[k], (uint32_t)recBase[k], graph[k]);
+                libs[w.lib]->bf.unpackPlaced(w.sig, batch, seqBase[k], headBase[k], (uint32_t)recBase[k], graph[k], packedQ ? (int64_t)quaBase[k] : -1);
                 info = graph[k].bins.at(0);
                 enc.encodeLz(batch, graph[k], info, archives[w.lib], out);
+                if (packedQ) { out.quaPacked = batch.quaPacked.data() + quaBase[k]; out.quaPackedBytes = libs[w.lib]->bf.bins().at(w.sig).totalQuaSize; }
                 recBytes = 2ull * (seqBase[k + 1] - seqBase[k]) + (headBase[k + 1] - headBase[k]);
                 graph[k] = Batch();
             });

@@ -2,6 +2,7 @@
 // blocks; plus the merged small-bins/N block and the archive writer (drop-in boundary).
 #pragma once
 #include <stdint.h>
+#include <atomic>
 #include <functional>
 #include <memory>
 #include <string>
@@ -94,6 +95,12 @@ struct Context {
     std::vector<BinIn> binInfo;                   // per bin of the last compressBins call
     std::function<void()> onHostTasksDone;        // called by compressBins when its host tasks are done (the device may still run)
     std::vector<std::unique_ptr<BinEncoder>> encoders;   // one per host thread
+    // device-side window search (matcher.hip): a matcher lane per host thread, made on first use; deviceMatcher off = host scan
+    std::vector<fsengine::MatchLane*> matchLanes;
+    bool deviceMatcher = true;
+    std::atomic<uint64_t> matchedReads{0}, matchUs{0}, matchKernelUs{0};
+    MatchFn matcherFor(uint32_t tid);
+    void matcherCheck(const std::string& inPrefix, uint64_t& reads, uint64_t& differing);
     // merged small bins + N bin (batch with ONE bin, records already in stored order): RawCompressorSE/PE
     void compressRawBlock(Batch& batch, const ArchiveParams& arch, std::vector<uint8_t>& out) const;
     // `fastore_pack e` for one or several libraries; bins of all libraries share the device batches

@@ -64,7 +64,7 @@ struct Shared {
     uint8_t CharMask[256];
     uint8_t QT[260];             // QTable, tabulated once per wave
     uint32_t GlueCount, GlueCount1, restarts;   // touched only by the allocator's rare paths / model restarts: kept out of the registers
-    uint32_t winA[64], winM[64], winCut;
+    uint32_t winA[128], winM[128], winCut;      // [64..127]: spare slots for lanes that have nothing to store in a round
     uint32_t winTab[512], winMask[128];      // owner search: lowest lane per hash slot, per-owner position masks; then the successor words on their way back      // windowed hit path: per-position results, first position that must go back to the serial path
     // coder queue (two-wave form: the model wave produces, the coder wave consumes; see the range-coder section)
     uint32_t qA[256], qM[256];

@@ -238,58 +238,66 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
         // with the rest of that context's positions, to the full rounds below (which start from the list as it is now:
         // only frequencies have changed).
         {
+            // (branch-free inside a round: every lane computes, the lanes with nothing to do write to a spare slot -- a
+            // taken branch or an exec-mask change costs a lone wavefront as much as four or five vector instructions)
             bool full = false;
             for (;;) {
                 const bool act = !full && (rlo | rhi) != 0u;
                 if (fs_ballot(act) == 0ull) break;
                 ++rounds;
-                const uint32_t p = !act ? lane : (rlo ? (uint32_t)__builtin_ctz(rlo) : 32u + (uint32_t)__builtin_ctz(rhi));
+                const uint32_t pLo = (uint32_t)__builtin_ctz(rlo | 0x80000000u), pHi = 32u + (uint32_t)__builtin_ctz(rhi | 0x80000000u);
+                const uint32_t p = !act ? lane : (rlo ? pLo : pHi);
                 const uint32_t kk = fs_bperm(k, p) & 7u, k8 = 8u * kk;
-                const uint32_t f = (uint32_t)(c.F >> k8) & 0xFFu, fPrev = kk ? (uint32_t)(c.F >> (k8 - 8u)) & 0xFFu : 0xFFFFu;
+                const uint32_t f = (uint32_t)(c.F >> k8) & 0xFFu, fPrev = kk ? (uint32_t)(c.F >> ((k8 - 8u) & 63u)) & 0xFFu : 0xFFFFu;
                 const uint32_t nf = f + 4u;
-                if (act && (nf > fPrev || nf > (uint32_t)MAX_FREQ)) full = true;
-                else if (act) {
-                    if (rlo) rlo &= rlo - 1u; else rhi &= rhi - 1u;
-                    const uint64_t below = c.F & ((1ull << k8) - 1ull);
-                    const uint32_t loCnt = fs_sum_bytes((uint32_t)below) + fs_sum_bytes((uint32_t)(below >> 32));
-                    m.sh->winA[p] = loCnt | (f << 16) | ((kk == 0u && 2u * f > summ) ? (1u << 23) : 0u);
-                    m.sh->winM[p] = summ;
-                    c.F += 4ull << k8;
-                    summ += 4u;
-                }
+                const bool ok = act && !(nf > fPrev || nf > (uint32_t)MAX_FREQ);
+                full = full || (act && !ok);
+                const uint32_t nlo = rlo & (rlo - 1u), nhi = rhi & (rhi - 1u);
+                rhi = (ok && rlo == 0u) ? nhi : rhi; rlo = ok ? nlo : rlo;     // (rlo & (rlo - 1) is 0 for rlo == 0)
+                const uint64_t below = c.F & ((1ull << k8) - 1ull);
+                const uint32_t loCnt = fs_sum_bytes((uint32_t)below) + fs_sum_bytes((uint32_t)(below >> 32));
+                const uint32_t at = ok ? p : 64u + lane;
+                m.sh->winA[at] = loCnt | (f << 16) | ((kk == 0u && 2u * f > summ) ? (1u << 23) : 0u);
+                m.sh->winM[at] = summ;
+                c.F += ok ? 4ull << k8 : 0ull;
+                summ += ok ? 4u : 0u;
             }
         }
         FS_STAT_ADD(m.sh->winStats[5], rounds);
+        // Full rounds: the contexts that swap or rescale (again without branches inside a round, except for the rare
+        // rescale).  A lane that must hand a position to the serial path remembers it; the minimum is taken after the loop.
+        uint32_t myCut = 64u;
         for (;;) {
             const bool act = (rlo | rhi) != 0u;
             if (fs_ballot(act) == 0ull) break;
             ++rounds;
-            const uint32_t p = !act ? lane : (rlo ? (uint32_t)__builtin_ctz(rlo) : 32u + (uint32_t)__builtin_ctz(rhi));
-            if (rlo) rlo &= rlo - 1u; else rhi &= rhi - 1u;
+            const uint32_t pLo = (uint32_t)__builtin_ctz(rlo | 0x80000000u), pHi = 32u + (uint32_t)__builtin_ctz(rhi | 0x80000000u);
+            const uint32_t p = !act ? lane : (rlo ? pLo : pHi);
+            { const uint32_t nlo = rlo & (rlo - 1u), nhi = rhi & (rhi - 1u); rhi = rlo == 0u ? nhi : rhi; rlo = nlo; }
             const uint32_t sy = fs_bperm(sym, p);
             // encodeSymbol1 + update1 on the owner's copy (Model.cpp:447-481)
             const uint32_t kk = packed_find(c, ns, sy);
             const bool lost = act && kk >= 8u;                        // cannot happen while nothing drops out; never trust it
+            const bool go = act && !lost;
             const uint32_t k8 = 8u * (kk & 7u);
-            const uint32_t f = (uint32_t)(c.F >> k8) & 0xFFu, fPrev = kk ? (uint32_t)(c.F >> (k8 - 8u)) & 0xFFu : 0u;
+            const uint32_t f = (uint32_t)(c.F >> k8) & 0xFFu, fPrev = (kk & 7u) ? (uint32_t)(c.F >> ((k8 - 8u) & 63u)) & 0xFFu : 0u;
             const uint64_t below = c.F & ((1ull << k8) - 1ull);
             const uint32_t loCnt = fs_sum_bytes((uint32_t)below) + fs_sum_bytes((uint32_t)(below >> 32));
             const uint32_t nf = f + 4u;
-            const bool doSwap = kk != 0u && kk < 8u && nf > fPrev;
-            const bool resc = act && !lost && nf > (uint32_t)MAX_FREQ && (kk == 0u || doSwap);
-            if (act && !lost) {
-                // slot of position p: cumulative frequency | frequency << 16 | PrevSuccess << 23 ; the total
-                m.sh->winA[p] = loCnt | (f << 16) | ((kk == 0u && 2u * f > summ) ? (1u << 23) : 0u);
-                m.sh->winM[p] = summ;
-                c.F += 4ull << k8;
-                if (doSwap) {                                      // states kk and kk-1 change places: symbol, frequency, successor tag
-                    const uint32_t j8 = k8 - 8u, j4 = 4u * kk - 4u;
-                    const uint64_t dS = ((c.S >> j8) ^ (c.S >> k8)) & 0xFFull, dF = ((c.F >> j8) ^ (c.F >> k8)) & 0xFFull;
-                    c.S ^= (dS << j8) | (dS << k8); c.F ^= (dF << j8) | (dF << k8);
-                    const uint32_t dP = ((c.P >> j4) ^ (c.P >> (j4 + 4u))) & 0xFu;
-                    c.P ^= (dP << j4) | (dP << (j4 + 4u));
-                }
-                summ += 4u;
+            const bool doSwap = go && kk != 0u && nf > fPrev;
+            const bool resc = go && nf > (uint32_t)MAX_FREQ && (kk == 0u || doSwap);
+            // slot of position p: cumulative frequency | frequency << 16 | PrevSuccess << 23 ; the total
+            const uint32_t at = go ? p : 64u + lane;
+            m.sh->winA[at] = loCnt | (f << 16) | ((kk == 0u && 2u * f > summ) ? (1u << 23) : 0u);
+            m.sh->winM[at] = summ;
+            c.F += go ? 4ull << k8 : 0ull;
+            summ += go ? 4u : 0u;
+            {   // states kk and kk-1 change places: symbol, frequency, successor tag (the differences are zero without a swap)
+                const uint32_t j8 = (k8 - 8u) & 63u, j4 = (4u * kk - 4u) & 31u;
+                const uint64_t dS = doSwap ? ((c.S >> j8) ^ (c.S >> k8)) & 0xFFull : 0ull, dF = doSwap ? ((c.F >> j8) ^ (c.F >> k8)) & 0xFFull : 0ull;
+                c.S ^= (dS << j8) | (dS << k8); c.F ^= (dF << j8) | (dF << k8);
+                const uint32_t dP = doSwap ? ((c.P >> j4) ^ (c.P >> ((j4 + 4u) & 31u))) & 0xFu : 0u;
+                c.P ^= (dP << j4) | (dP << ((j4 + 4u) & 31u));
             }
             bool cut = lost;
             if (fs_ballot(resc) != 0ull) {
@@ -298,8 +306,10 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
                 if (resc && done) { c = c2; summ = summ2; flags = flags2; }
                 if (resc && !done) cut = true;                     // a state drops out: the serial path takes this symbol
             }
-            if (cut) { FS_LDS_MIN(m.sh->winCut, p); rlo = rhi = 0u; }
+            myCut = cut && p < myCut ? p : myCut;
+            rlo = cut ? 0u : rlo; rhi = cut ? 0u : rhi;
         }
+        if (fs_ballot(myCut < 64u) != 0ull) FS_LDS_MIN(m.sh->winCut, myCut);
         FS_WAVE_SYNC();
         FS_STAT_ADD(m.sh->winStats[3], rounds);
         FS_PROF_ACC(m.sh->winStats[11], tp);                           // rounds

@@ -104,6 +104,11 @@ typedef struct fsgpu_stats {
      * ppmd_symbols), rounds (positions sharing a context are processed one rank per round), windows redone shorter */
     uint64_t ppmd_window_attempts, ppmd_windows, ppmd_window_symbols, ppmd_window_rounds, ppmd_windows_redone;
     uint64_t ppmd_window_light_rounds;   /* of ppmd_window_rounds: rounds that needed no swap and no rescale */
+    /* fs_gather_quality (device-side quality path of lossless archives): HIP-event time, scores gathered, bytes read + written */
+    double gather_kernel_ms; uint64_t gather_symbols, gather_bytes;
+    /* device-side read matcher (matcher.hip): reads searched, time the host threads spent in its calls (summed over the
+     * threads: upload, kernels, download, waiting), HIP-event time of its kernels (summed over the calls) */
+    uint64_t matcher_reads; double matcher_call_ms, matcher_kernel_ms;
 } fsgpu_stats;
 
 void fsgpu_config_defaults(fsgpu_config* cfg);
@@ -143,6 +148,22 @@ int fsgpu_rc_encode(fsgpu_ctx* ctx, size_t n_streams, const uint32_t* model, con
 int fsgpu_qvz_encode(fsgpu_ctx* ctx, const uint8_t* qvz_footer, size_t qvz_footer_bytes, size_t n_streams,
                      const uint8_t* const* quals, const uint32_t* const* read_lens, const size_t* n_reads,
                      uint8_t* const* out, const size_t* out_cap, size_t* out_len);
+
+/* Quality stream of a lossless bin, built on the device (fs_gather_quality): what FastqPacker's six-bit unpack
+ * (fastore_bin/FastqPacker.cpp:290-411, scores stored MSB first) followed by IQualityStoreBase::CompressReadQuality for
+ * MET_NONE (fastore_pack/FastqCompressor.cpp:229-247: score minus the archive's offset, back to front for a record stored
+ * reverse-complemented) leave in the PPMd input buffer.  strings[i]: bit offset of the i-th emitted read's first stored
+ * score in `packed`, its length, and whether it is emitted back to front; out receives the strings one after the other.
+ * Timing of the last call: fsgpu_stats.gather_kernel_ms / gather_symbols / gather_bytes. */
+typedef struct fsgpu_quality_string { uint64_t src_bit; uint32_t len; uint32_t reverse; } fsgpu_quality_string;
+int fsgpu_gather_quality(fsgpu_ctx* ctx, const uint8_t* packed, size_t packed_bytes, const fsgpu_quality_string* strings,
+                         size_t n_strings, uint8_t* out, size_t out_cap, size_t* out_len);
+
+/* Parity check of the device-side read matcher (matcher.hip; ReadsClassifierSE::ConstructMatchTree's window search,
+ * fastore_pack/ReadsClassifier.cpp:55-83, 95-442): every standard bin of the library <in_prefix> goes through the host's
+ * serial window scan and through the device; *reads = reads searched, *differing = rows (matched read, cost, shift,
+ * mismatch-free flag, exact-duplicate flag) on which the two disagree. */
+int fsgpu_matcher_check(fsgpu_ctx* ctx, const char* in_prefix, uint64_t* reads, uint64_t* differing);
 
 /* Whole `fastore_pack e -i<in_prefix> -o<out_prefix>`: reads .bmeta/.bdna/.bqua/.bhead, writes
  * .cmeta/.cdata in the reference's -t1 block order. */

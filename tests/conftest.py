@@ -142,3 +142,32 @@ def check_compress_bins_seam(fastore_amd, packer, name, flags, lib=None):
     for sg, blk in zip(sigs, blocks):
         assert blk == want[sg], "block of signature %d differs" % sg
     assert len(want) == len(sigs) + 1          # + block 0 (small bins and the N bin), which is not part of this seam
+
+
+def quality_gather_case(seed, n_strings=400, max_len=310):
+    """Random packed quality scores and emitted strings for fs_gather_quality, with the expected stream.
+    Restates, in numpy, what the reference leaves in the PPMd input of a lossless bin: FastqPacker stores a score as six
+    bits, MSB first (fastore_bin/FastqPacker.cpp:157-287, read back :290-411), and IQualityStoreBase::CompressReadQuality
+    (MET_NONE, fastore_pack/FastqCompressor.cpp:229-247) emits score - offset -- the stored six bits -- back to front when the
+    record is flagged reverse-complemented."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    lens = [0, 1, 2, 3, 4, 5, 63, 64, 65, 150, 151, 255, 256, 257, max_len] + [int(x) for x in rng.integers(0, max_len + 1, n_strings)]
+    total = sum(lens) + 3 * len(lens) + 16
+    vals = rng.integers(0, 64, total, dtype=np.uint8)
+    bits = np.unpackbits(vals[:, None], axis=1)[:, 2:]            # six low bits of every score, MSB first
+    packed = np.packbits(bits.reshape(-1)).tobytes()
+    strings, expect, pos = [], bytearray(), 0
+    for n in lens:
+        rev = bool(rng.integers(0, 2))
+        strings.append((6 * pos, n, rev))
+        seg = vals[pos:pos + n]
+        expect += bytes(seg[::-1] if rev else seg)
+        pos += n + int(rng.integers(0, 3))                        # strings need not be adjacent in the packed scores
+    order = rng.permutation(len(strings))                         # nor emitted in stored order
+    out = bytearray()
+    chunks = []
+    p2 = 0
+    for (b, n, r) in strings:
+        chunks.append(bytes(expect[p2:p2 + n])); p2 += n
+    return packed, [strings[i] for i in order], b"".join(chunks[i] for i in order)

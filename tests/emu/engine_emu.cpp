@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <thread>
+#include <algorithm>
+#include <vector>
 #include <atomic>
 #include "../../fastore_amd/csrc/engine.h"
 #include "../../fastore_amd/csrc/ppmd_core.h"
@@ -54,10 +56,86 @@ int encode_streams_raw(Device*, const uint8_t* input, size_t, std::vector<Stream
 
 static void putBe(uint8_t*& h, uint64_t v, int n) { for (int i = 0; i < n; ++i) *h++ = (uint8_t)(v >> (8 * (n - 1 - i))); }
 
-int encode_batch(Device* dev, const uint8_t* input, size_t, std::vector<StreamItem>& items, std::vector<BlockPlan>& plans,
-                 std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes, BatchTiming* t)
+// what fs_gather_quality does, one string after the other (the staging buffer has room behind the uploaded bytes)
+static void gatherQuality(uint8_t* buf, size_t inputBytes, const GatherPlan& g)
+{
+    const QuaString* qs = (const QuaString*)(buf + g.desc_off);
+    uint8_t* out = buf + ((inputBytes + 15u) & ~(size_t)15u);
+    for (uint32_t i = 0; i < g.n_strings; ++i)
+        for (uint32_t j = 0; j < qs[i].len; ++j) {
+            const uint64_t bit = qs[i].src_bit + 6ull * (qs[i].reverse ? qs[i].len - 1u - j : j);
+            const uint32_t w = ((uint32_t)buf[bit >> 3] << 8) | buf[(bit >> 3) + 1];
+            out[qs[i].dst_off + j] = (uint8_t)((w >> (10u - (uint32_t)(bit & 7u))) & 63u);
+        }
+}
+
+// what matcher.hip computes, as a plain scalar loop over a window kept newest first (test-only stand-in)
+struct MatchLane { int unused; };
+int match_lane_create(Device*, MatchLane** out) { *out = new MatchLane(); return 0; }
+void match_lane_destroy(MatchLane* m) { delete m; }
+int match_reads(Device*, MatchLane*, const uint8_t* seq, size_t, const MatchRead* reads, size_t, const MatchCall* calls, size_t nCalls,
+                const MatchParams& par, MatchRow* rows, double*)
+{
+    const uint32_t cap = par.window - 1u;
+    for (size_t c = 0; c < nCalls; ++c) {
+        const MatchCall& call = calls[c];
+        std::vector<uint32_t> win;                                     // newest first
+        if (call.aux >= 0) win.push_back((uint32_t)call.aux);
+        for (uint32_t i = 0; i < call.count; ++i) {
+            const uint32_t r = call.first + i; const MatchRead& rd = reads[r];
+            const int32_t thr = par.encode_threshold ? par.encode_threshold : (int32_t)(rd.len / 2u);
+            int32_t best = thr + 1, bestShift = 0; int64_t bestSlot = -1; bool bestNoMism = false; uint32_t bestLen = 0;
+            auto price = [&](const uint8_t* e, uint32_t eLen, int32_t eMin, int64_t slot) {
+                const int32_t shift = eMin - (int32_t)rd.min_pos, ashift = shift < 0 ? -shift : shift;
+                if (ashift > 127) return;
+                const uint32_t recOff = shift < 0 ? (uint32_t)ashift : 0u, lzOff = shift > 0 ? (uint32_t)ashift : 0u;
+                const uint32_t n = std::min(rd.len - recOff, eLen - lzOff);
+                int32_t mism = 0;
+                for (uint32_t k = 0; k < n; ++k) mism += seq[rd.seq_off + recOff + k] != e[lzOff + k];
+                const int32_t cc = ashift * par.shift_cost + mism * par.mismatch_cost;
+                if (cc < best) { best = cc; bestShift = shift; bestSlot = slot; bestNoMism = mism == 0; bestLen = eLen; }
+            };
+            for (size_t j = 0; j < win.size(); ++j) price(seq + reads[win[j]].seq_off, reads[win[j]].len, reads[win[j]].min_pos, (int64_t)j);
+            uint8_t dummy[256]; memset(dummy, 'N', sizeof dummy);
+            if (win.size() < cap) price(dummy, 256u, 0, (int64_t)win.size());
+            MatchRow row{-1, (int16_t)(thr + 1), 0, 0, 0, 0, 0};
+            bool identical = false;
+            if (bestSlot >= 0) {
+                const bool isDummy = (size_t)bestSlot >= win.size();
+                row.match = isDummy ? -2 : (int32_t)win[(size_t)bestSlot]; row.cost = (int16_t)best; row.shift = (int16_t)bestShift;
+                row.no_mismatches = bestNoMism; row.dummy = isDummy;
+                identical = best == 0 && bestLen == rd.len && !isDummy && row.match != call.aux;
+                row.identical = identical;
+            }
+            rows[r] = row;
+            if (!identical) { win.insert(win.begin(), r); if (win.size() > cap) win.pop_back(); }
+        }
+    }
+    return 0;
+}
+
+int gather_quality_raw(Device*, const uint8_t* input, size_t inputBytes, const GatherPlan& plan, std::vector<uint8_t>& out, BatchTiming* t)
+{
+    std::vector<uint8_t> work(((inputBytes + 15u) & ~(size_t)15u) + plan.out_bytes + 64);
+    memcpy(work.data(), input, inputBytes);
+    gatherQuality(work.data(), inputBytes, plan);
+    out.assign(work.begin() + ((inputBytes + 15u) & ~(size_t)15u), work.begin() + ((inputBytes + 15u) & ~(size_t)15u) + plan.out_bytes);
+    if (t) t->gather_symbols += plan.symbols;
+    return 0;
+}
+
+int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items, std::vector<BlockPlan>& plans,
+                 std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes, BatchTiming* t, const GatherPlan* gather)
 {
     std::vector<uint8_t> scratch; std::vector<uint32_t> sizes;
+    std::vector<uint8_t> work;                          // the device's input buffer: uploaded bytes + gather region
+    if (gather && gather->n_strings) {
+        work.resize(((inputBytes + 15u) & ~(size_t)15u) + gather->out_bytes + 64);
+        memcpy(work.data(), input, inputBytes);
+        gatherQuality(work.data(), inputBytes, *gather);
+        input = work.data();
+        if (t) { t->gather_symbols += gather->symbols; }
+    }
     runItems(input, items, scratch, sizes, t);
     for (size_t i = 0; i < items.size(); ++i) {
         if (sizes[i] == 0xFFFFFFFFu) { snprintf(dev->err, sizeof dev->err, "stream item %zu: symbol or context outside its coder's alphabet (corrupted input)", i); return -2; }

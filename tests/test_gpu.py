@@ -306,3 +306,73 @@ def test_gpu_cli_two_contexts_on_one_box(tmp_path):
             assert subprocess.run([cli, "e", "-i" + os.path.join(GOLDEN, name + ".in"), "-o" + out, "-R%d" % r, "-N2"] + flags).returncode == 0
         fastore_amd.merge_parts(out, 2)
     assert_same_archive(out, os.path.join(GOLDEN, name + ".ref"))
+
+
+def test_gather_quality_device_matches_the_restated_unpack(packer):
+    # fs_gather_quality through the C ABI: ragged strings (0 .. 310 scores), unaligned bit offsets, both orientations,
+    # emitted in a shuffled order -- against the numpy restatement of the reference's unpack + CompressReadQuality
+    from conftest import quality_gather_case
+    for seed in (1, 2, 3, 4):
+        packed, strings, expect = quality_gather_case(seed, n_strings=3000)
+        assert packer.gather_quality(packed, strings) == expect
+    st = packer.stats()
+    assert st["gather_symbols"] > 0 and st["gather_kernel_ms"] > 0
+
+
+def test_gpu_quality_streams_come_from_the_device_gather(tmp_path, monkeypatch):
+    # a lossless library packed from .b* files: the scores go to the device packed (six bits each) and the quality
+    # streams are built there; the host symbolisation (FS_DEVICE_QUALITY=0) gives the same archive with more H2D bytes
+    import fastore_amd
+    name, paired, flags = manifest()[0]
+    ref = open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
+    h2d = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FS_DEVICE_QUALITY", mode)
+        with fastore_amd.Packer(device_id=0, **knobs_from_flags(flags)) as p:
+            st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o" + mode)))
+        assert open(str(tmp_path / ("o" + mode)) + ".cdata", "rb").read() == ref
+        h2d[mode] = st["h2d_bytes"]
+        assert (st["gather_symbols"] > 0) == (mode == "1")
+    assert h2d["1"] < h2d["0"]
+
+
+@pytest.mark.parametrize("name,paired,flags", manifest())
+def test_device_matcher_agrees_with_the_host_window_scan(name, paired, flags):
+    # matcher.hip against the host's serial restatement of ReadsClassifierSE::ConstructMatchTree's window search, read
+    # by read over every match-tree construction (top level + stored sub-trees) of every golden bin: matched read,
+    # cost, shift, mismatch-free flag, exact-duplicate flag
+    import fastore_amd
+    with fastore_amd.Packer(device_id=0, **knobs_from_flags(flags)) as p:
+        reads, differing = p.matcher_check(os.path.join(GOLDEN, name + ".in"))
+    assert reads > 1000 and differing == 0, (reads, differing)
+
+
+@pytest.mark.parametrize("window", [2, 3, 5, 64, 65, 66, 129, 300, 1025])
+def test_device_matcher_window_sizes(window):
+    # windows of one slot up to the largest the kernel takes (one thread per slot, 1 .. 16 wavefronts): ring wrap-around,
+    # dummy slots while the window fills, duplicates that stay out of it
+    import fastore_amd
+    name, paired, flags = manifest()[0]
+    kn = knobs_from_flags(flags); kn["max_lz_window"] = window
+    with fastore_amd.Packer(device_id=0, **kn) as p:
+        reads, differing = p.matcher_check(os.path.join(GOLDEN, name + ".in"))
+    assert reads > 1000 and differing == 0, (window, reads, differing)
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)), reason="reference binaries (oracle/_ref) not shipped")
+@pytest.mark.parametrize("paired,reads", [(False, 400_000), (True, 150_000)])
+def test_device_matcher_on_fresh_libraries_and_same_archive_either_way(tmp_path, monkeypatch, paired, reads):
+    # C1-profile libraries (bins of thousands of reads: full 1023-slot windows, sub-trees): the device's rows equal the host
+    # scan's, and the archive is the same bytes with the device matcher and with the host scan (FS_DEVICE_MATCHER=0)
+    import fastore_amd
+    t = str(tmp_path)
+    binned, pe = ref_pipeline(t, "m", reads, 150, (2 if paired else 1) * reads * 150 // 50, 11, paired, 0, threads=min(16, len(os.sched_getaffinity(0))))
+    kn = dict(min_bin_size=256, max_lz_window=1024, max_pair_lz_window=1024, extra_reduce_hard_reads=1, min_consensus_size=10, max_hamming_distance=8)
+    with fastore_amd.Packer(device_id=0, **kn) as p:
+        n, differing = p.matcher_check(binned)
+        assert n > reads // 2 and differing == 0, (n, differing)
+        p.pack_file(binned, os.path.join(t, "dev"))
+    monkeypatch.setenv("FS_DEVICE_MATCHER", "0")
+    with fastore_amd.Packer(device_id=0, **kn) as p:
+        p.pack_file(binned, os.path.join(t, "host"))
+    assert open(os.path.join(t, "dev.cdata"), "rb").read() == open(os.path.join(t, "host.cdata"), "rb").read()

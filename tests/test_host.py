@@ -40,7 +40,7 @@ def test_c_abi_exports_every_declared_symbol(product_lib):
 def test_structs_match_header_layout(product_lib):
     import fastore_amd
     assert ctypes.sizeof(fastore_amd.Config) == 96
-    assert ctypes.sizeof(fastore_amd.Stats) == 216
+    assert ctypes.sizeof(fastore_amd.Stats) == 264
     cfg = fastore_amd.Config()
     product_lib.fsgpu_config_defaults(ctypes.byref(cfg))
     # reference defaults: fastore_pack/Params.h:18-147, fastore_bin/Globals.h:61-62
@@ -367,3 +367,48 @@ def test_cli_verbose_statistics_match_the_reference(tmp_path, name, paired):
     assert r.returncode == 0, r.stderr
     assert r.stdout == open(os.path.join(GOLDEN, name + ".ref.vout"), "rb").read()
     assert b"Parts processed" in r.stderr
+
+
+def test_quality_gather_emulation_matches_the_restated_unpack(emu_lib):
+    # the test-only host form of fs_gather_quality (tests/emu/engine_emu.cpp) against the numpy restatement: pins the
+    # expectation the GPU test uses, and the descriptor plumbing of fsgpu_gather_quality
+    import fastore_amd
+    from conftest import quality_gather_case
+    with fastore_amd.Packer(lib=emu_lib, device_id=0) as p:
+        for seed in (1, 2, 3):
+            packed, strings, expect = quality_gather_case(seed)
+            assert p.gather_quality(packed, strings) == expect
+        assert p.gather_quality(b"", []) == b""
+        with pytest.raises(fastore_amd.FastoreError, match="outside the packed scores"):
+            p.gather_quality(b"\0" * 8, [(40, 5, False)])
+
+
+@pytest.mark.parametrize("name,paired,flags", [m for m in manifest() if m[0] in ("se_lossless", "pe_lossless", "se_noheader", "se_c0")])
+def test_device_quality_path_is_taken_and_changes_no_byte(emu_lib, tmp_path, monkeypatch, name, paired, flags):
+    # lossless archives packed from .b* files keep their scores packed: the quality streams are gathered by the engine
+    # (fs_gather_quality on the device), not symbolised by the host front end -- same archive either way
+    import fastore_amd
+    ref = open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
+    seen = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FS_DEVICE_QUALITY", mode)
+        with fastore_amd.Packer(lib=emu_lib, device_id=0, **knobs_from_flags(flags)) as p:
+            st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o" + mode)))
+        assert open(str(tmp_path / ("o" + mode)) + ".cdata", "rb").read() == ref
+        seen[mode] = st["gather_symbols"]
+    assert seen["0"] == 0 and seen["1"] > 0
+
+
+@pytest.mark.parametrize("name,paired,flags", manifest())
+def test_matcher_table_and_trace_against_the_scalar_restatement(emu_lib, name, paired, flags):
+    # the table of match-tree constructions the front end hands to the device matcher, and the rows the host scan traces
+    # for the parity check, against the test-only scalar window search (tests/emu/engine_emu.cpp): no GPU needed to pin
+    # the window model (last W-1 non-duplicate reads, root copy, dummy slots) that matcher.hip implements
+    import fastore_amd
+    for window in (None, 3, 17):
+        kn = knobs_from_flags(flags)
+        if window:
+            kn["max_lz_window"] = window
+        with fastore_amd.Packer(lib=emu_lib, device_id=0, **kn) as p:
+            reads, differing = p.matcher_check(os.path.join(GOLDEN, name + ".in"))
+        assert reads > 1000 and differing == 0, (window, reads, differing)
