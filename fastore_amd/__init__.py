@@ -86,6 +86,7 @@ def load_library(path=None):
     lib.fsgpu_reset_stats.argtypes = [C.c_void_p]
     lib.fsgpu_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     lib.fsgpu_get_window_profile.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 8)]
+    lib.fsgpu_get_serial_profile.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 2)]
     lib.fsgpu_set_archive_params.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     pp = C.POINTER(C.c_char_p)
     lib.fsgpu_ppmd_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -268,7 +269,11 @@ class Packer:
         """phase clocks of the windowed PPMd path (units of 64 shader clocks; zero unless built with -DFS_WIN_PROFILE)"""
         out = (C.c_uint64 * 8)()
         self._check(self.lib.fsgpu_get_window_profile(self.ctx, C.byref(out)))
-        return dict(zip(("fetch", "states_chain", "ranks", "rounds", "writeback", "coder", "windows_total", "streams_total"), list(out)))
+        d = dict(zip(("fetch", "states_chain", "ranks", "rounds", "writeback", "coder", "windows_total", "streams_total"), list(out)))
+        ser = (C.c_uint64 * 2)()
+        self._check(self.lib.fsgpu_get_serial_profile(self.ctx, C.byref(ser)))
+        d["serial_escapes"], d["serial_update_model"] = ser[0], ser[1]
+        return d
 
     def _encode(self, fn, streams, unit, extra=None):
         n = len(streams)

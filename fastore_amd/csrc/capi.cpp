@@ -522,4 +522,11 @@ int fsgpu_get_window_profile(const fsgpu_ctx* ctx, uint64_t out[8])
     return FSGPU_OK;
 }
 
+int fsgpu_get_serial_profile(const fsgpu_ctx* ctx, uint64_t out[2])
+{
+    if (!ctx || !out) return FSGPU_ERR_ARG;
+    out[0] = ctx->c.timing.win[6]; out[1] = ctx->c.timing.win[7];
+    return FSGPU_OK;
+}
+
 }  // extern "C"

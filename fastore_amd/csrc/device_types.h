@@ -27,7 +27,10 @@ struct GatherPlan { uint64_t desc_off = 0; uint32_t n_strings = 0; uint64_t out_
 // Device-side read matcher (matcher.hip): the reads of a bin's match-tree constructions, each construction's reads in
 // processing order; a row of answers per read
 struct MatchRead { uint32_t seq_off; uint16_t len, min_pos; };            // bases (ASCII) at seq[seq_off .. +len); signature position
-struct MatchCall { uint32_t first, count; int32_t aux; uint32_t pad; };   // reads[first .. first+count); aux: read holding the sub-tree's root copy, or -1
+// reads[first .. first+count) in processing order; aux: read holding the sub-tree's root copy, or -1; warm: the window as it
+// stands in front of reads[first] when this is a later piece of a long construction -- warm_count reads, oldest first, named
+// in the warm-up list from warm_first on (a piece's answers do not depend on how the construction was cut)
+struct MatchCall { uint32_t first, count; int32_t aux; uint32_t warm_first, warm_count, pad; };
 struct MatchParams { uint32_t window; int32_t shift_cost, mismatch_cost, encode_threshold; };   // -w, -s, -m, -e (0 = read length / 2)
 // match: read the best window slot holds (-1 none at or below the threshold, -2 a dummy slot); cost / shift / no_mismatches of
 // that match (cost = threshold + 1 when none); identical: exact duplicate of a slot that is not the root copy

@@ -53,8 +53,10 @@ int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std
 struct MatchLane;
 int match_lane_create(Device* dev, MatchLane** out);
 void match_lane_destroy(MatchLane* m);
+int match_lane_reserve(Device* dev, MatchLane* m, size_t maxReads, size_t maxSeqBytes, size_t maxCalls, size_t maxWarm);
 int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, const fsdev::MatchRead* reads, size_t nReads,
-                const fsdev::MatchCall* calls, size_t nCalls, const fsdev::MatchParams& par, fsdev::MatchRow* rows, double* kernelMs);
+                const fsdev::MatchCall* calls, size_t nCalls, const uint32_t* warm, size_t nWarm, const fsdev::MatchParams& par,
+                fsdev::MatchRow* rows, double* kernelMs);
 // fs_gather_quality on its own: `input` = packed scores then the descriptors (plan.desc_off); returns the gathered bytes
 int gather_quality_raw(Device* dev, const uint8_t* input, size_t inputBytes, const fsdev::GatherPlan& plan, std::vector<uint8_t>& out, BatchTiming* timing);
 // gather (optional): quality streams that fs_gather_quality writes behind the uploaded input (at inputBytes rounded up to

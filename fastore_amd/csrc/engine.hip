@@ -156,7 +156,12 @@ template <bool TWO> __device__ __forceinline__ void encode_streams_body()
             const uint32_t t = threadIdx.x;
             uint32_t v = 0;
             if (kind == KIND_PPMD && n > 0) {
+#if defined(FS_WIN_PROFILE)
+                if (t >= 1u && t <= 5u) v = sh.winStats[t - 1u];
+                else if (t == 6u || t == 7u) v = sh.winStats[t];          // serial-path clocks: escapes, UpdateModel
+#else
                 if (t >= 1u && t <= 6u) v = sh.winStats[t - 1u];
+#endif
                 else if (t >= 8u && t < 15u) v = sh.winStats[t];
                 else if (t == 15u) v = (uint32_t)((FS_PROF_NOW() - tStream) >> 6);
             }

@@ -292,7 +292,11 @@ struct BinEncoder::Impl {
     // tree, FastqCompressor.cpp:1784-1818).  mReads/mCalls are that table; mRows the answers (from the device, or traced
     // from the host scan for the parity check); callOfTree[t] = construction of sub-tree t (-1 top level = call 0).
     std::vector<fsdev::MatchRead> mReads; std::vector<fsdev::MatchCall> mCalls; std::vector<fsdev::MatchRow> mRows;
+    std::vector<uint32_t> mWarm;              // warm-up lists of the pieces of the top-level construction
+    struct Slot3 { uint64_t hash; uint32_t read, push; };
+    std::vector<Slot3> dupTable;
     std::vector<int32_t> callOfTree;
+    uint32_t topCalls = 0;                     // the first topCalls entries of mCalls are the pieces of the top-level construction
     bool havePre = false;                      // mRows hold the device's answers: constructMatchTree does not scan
     bool traceResize = false;
     std::vector<fsdev::MatchRow>* matchTrace = nullptr;   // host scan: note every read's answer here (same indexing as mRows)
@@ -308,15 +312,61 @@ struct BinEncoder::Impl {
             lo = std::min<uint64_t>(lo, r.seqOff); hi = std::max<uint64_t>(hi, (uint64_t)r.seqOff + r.seqLen);
             mReads.push_back(fsdev::MatchRead{r.seqOff, r.seqLen, (uint16_t)minPos});
         };
-        fsdev::MatchCall top{0u, (uint32_t)topOrder.size(), -1, 0u};
+        // The top-level construction is long (most of a bin's reads).  Which of its reads are exact duplicates -- and stay
+        // out of the window -- can be told without searching: a read is one exactly when an equal read (same bases, same
+        // signature position) is still in the window, and equal reads never share the window, so one table look-up per
+        // read (its class's latest non-duplicate, and how many non-duplicates came since) decides it.  That makes the
+        // window in front of ANY read known (the last W-1 non-duplicates before it), so the construction is cut into
+        // pieces that the device searches side by side, each starting from its warm-up list.
+        mWarm.clear();
         for (int32_t n : topOrder) add(vrecs[nodes[n].vrec].rec, vrecs[nodes[n].vrec].minimPos);
-        mCalls.push_back(top);
+        {
+            const uint32_t n = (uint32_t)topOrder.size(), cap = par.maxLzWindowSize > 1 ? par.maxLzWindowSize - 1u : 1u;
+            const uint32_t piece = 512u;
+            std::vector<uint8_t> dup(n, 0);
+            {
+                struct Slot { uint64_t hash; uint32_t read, push; };                  // read + 1 (0 = empty); push number of the class's latest non-duplicate
+                uint32_t tsz = 64; while (tsz < 2u * n) tsz <<= 1;
+                dupTable.assign(tsz, Slot3{0, 0, 0});
+                uint32_t pushed = 0;
+                for (uint32_t i = 0; i < n; ++i) {
+                    const int32_t a = nodes[topOrder[i]].vrec;
+                    const uint8_t* sa = seq(a); const uint32_t la = seqLen(a), ma = minimPos(a);
+                    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)la << 32 | ma);
+                    uint32_t k = 0;
+                    for (; k + 8 <= la; k += 8) { uint64_t w; memcpy(&w, sa + k, 8); h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32; }
+                    { uint64_t w = 0; memcpy(&w, sa + k, la - k); h = (h ^ w) * 0xc4ceb9fe1a85ec53ull; h ^= h >> 29; }
+                    uint32_t at = (uint32_t)h & (tsz - 1u);
+                    for (;; at = (at + 1u) & (tsz - 1u)) {
+                        Slot3& s = dupTable[at];
+                        if (s.read == 0) { s.hash = h; s.read = i + 1u; s.push = pushed++; break; }        // a new class
+                        if (s.hash != h) continue;
+                        const int32_t b = nodes[topOrder[s.read - 1u]].vrec;
+                        if (seqLen(b) != la || minimPos(b) != ma || memcmp(seq(b), sa, la) != 0) continue;
+                        if (pushed - 1u - s.push < cap) dup[i] = 1;                                         // its class's non-duplicate is still in the window
+                        else { s.read = i + 1u; s.push = pushed++; }                                        // it has left: this read takes its place
+                        break;
+                    }
+                }
+                (void)sizeof(Slot);
+            }
+            for (uint32_t c0 = 0; c0 < n || c0 == 0; c0 += piece) {
+                fsdev::MatchCall c{c0, std::min(piece, n - c0), -1, (uint32_t)mWarm.size(), 0u, 0u};
+                std::vector<uint32_t> w;
+                for (uint32_t j = c0; j > 0 && w.size() < cap; --j) if (!dup[j - 1]) w.push_back(j - 1);
+                c.warm_count = (uint32_t)w.size();
+                mWarm.insert(mWarm.end(), w.rbegin(), w.rend());          // oldest first
+                mCalls.push_back(c);
+                if (n == 0) break;
+            }
+        }
+        topCalls = (uint32_t)mCalls.size();
         for (size_t n = 0; n < nodes.size(); ++n) {
             const NodeIn& ni = G->nodes[nodeBase + n];
             for (uint32_t k = 0; k < ni.treeCount; ++k) {
                 const uint32_t t = ni.treeBegin + k; const TreeIn& tree = G->trees[t];
                 if (tree.nodeCount == 0 || (uint64_t)tree.nodeBegin - nodeBase + tree.nodeCount > nodes.size()) continue;
-                fsdev::MatchCall c{0u, tree.nodeCount, (int32_t)mReads.size(), 0u};
+                fsdev::MatchCall c{0u, tree.nodeCount, (int32_t)mReads.size(), 0u, 0u, 0u};
                 add(vrecs[nodes[n].vrec].rec, (uint32_t)tree.mainSignaturePos);        // the root copy, at the sub-tree's signature position
                 c.first = (uint32_t)mReads.size();
                 for (uint32_t j = 0; j < tree.nodeCount; ++j) { const Node& sn = nodes[tree.nodeBegin - nodeBase + j]; add(vrecs[sn.vrec].rec, vrecs[sn.vrec].minimPos); }
@@ -335,7 +385,8 @@ struct BinEncoder::Impl {
 
     // ReadsClassifierSE::ConstructMatchTree (fastore_pack/ReadsClassifier.cpp:95-442).
     // order: node ids in processing order; auxRoot: node id of the sub-tree root copy or -1.
-    // call: index of this construction in mCalls (answers / trace rows at mCalls[call].first + position), or -1
+    // call: index of this construction in mCalls (answers / trace rows at mCalls[call].first + position; the top-level
+    // construction is call 0 and its pieces follow each other in the table), or -1
     void constructMatchTree(const std::vector<int32_t>& order, std::vector<int32_t>& roots, int32_t auxRoot, int32_t call = -1)
     {
         const bool pre = havePre && call >= 0;
@@ -1124,7 +1175,7 @@ struct BinEncoder::Impl {
         if (matchTrace && traceResize) { matchTrace->assign(mReads.size(), fsdev::MatchRow{-1, 0, 0, 0, 0, 0, 0}); }
         if (matcher && !matchTrace && par.maxLzWindowSize >= 2 && par.maxLzWindowSize <= 1025 && bin.maxLen <= 256) {
             mRows.resize(mReads.size());
-            if (matcher(B->seq.data() + matchSeqBase, matchSeqBytes, mReads.data(), mReads.size(), mCalls.data(), mCalls.size(), matchParams(), mRows.data())) {
+            if (matcher(B->seq.data() + matchSeqBase, matchSeqBytes, mReads.data(), mReads.size(), mCalls.data(), mCalls.size(), mWarm.data(), mWarm.size(), matchParams(), mRows.data())) {
                 havePre = true;
                 for (const fsdev::MatchCall& c : mCalls) for (uint32_t i = 0; i < c.count && havePre; ++i) if (mRows[c.first + i].dummy) havePre = false;
             }
@@ -1169,10 +1220,10 @@ void BinEncoder::checkMatcher(const Batch& data, const Batch& graph, const BinIn
     m.traceResize = true;
     m.encodeLz(data, graph, bin, arch, tmp);
     m.matchTrace = nullptr; m.traceResize = false;
-    const std::vector<fsdev::MatchRead> tReads = m.mReads; const std::vector<fsdev::MatchCall> tCalls = m.mCalls;
+    const std::vector<fsdev::MatchRead> tReads = m.mReads; const std::vector<fsdev::MatchCall> tCalls = m.mCalls; const std::vector<uint32_t> tWarm = m.mWarm;
     std::vector<fsdev::MatchRow> dev(tReads.size());
     memset(dev.data(), 0, dev.size() * sizeof(fsdev::MatchRow));
-    if (!fn(data.seq.data() + m.matchSeqBase, m.matchSeqBytes, tReads.data(), tReads.size(), tCalls.data(), tCalls.size(), m.matchParams(), dev.data())) throw std::runtime_error("device matcher did not run");
+    if (!fn(data.seq.data() + m.matchSeqBase, m.matchSeqBytes, tReads.data(), tReads.size(), tCalls.data(), tCalls.size(), tWarm.data(), tWarm.size(), m.matchParams(), dev.data())) throw std::runtime_error("device matcher did not run");
     for (const fsdev::MatchCall& c : tCalls)
         for (uint32_t i = 0; i < c.count; ++i) {
             const fsdev::MatchRow &a = host[c.first + i], &b = dev[c.first + i];

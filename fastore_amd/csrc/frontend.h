@@ -67,7 +67,7 @@ struct ArchiveParams { BinModuleConfigRaw cfg{}; HeaderStats head; QvzModel qvz;
 // The device-side window search (matcher.hip) as the front end sees it: the bin's bases, the table of its match-tree
 // constructions, one row of answers per read.  Returns false when the search could not be run (the host scan is used).
 typedef std::function<bool(const uint8_t* seq, size_t seqBytes, const fsdev::MatchRead* reads, size_t nReads, const fsdev::MatchCall* calls,
-                           size_t nCalls, const fsdev::MatchParams& par, fsdev::MatchRow* rows)> MatchFn;
+                           size_t nCalls, const uint32_t* warm, size_t nWarm, const fsdev::MatchParams& par, fsdev::MatchRow* rows)> MatchFn;
 
 class BinEncoder {
 public:

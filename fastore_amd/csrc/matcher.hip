@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 #include "device_types.h"
@@ -34,27 +35,30 @@ namespace {
 
 enum : uint32_t { kNone = 0xFFFFFFFFu };
 
-// ASCII bases -> three bit planes of NW words each (bit p of word w = position 32 w + p): plane 0/1 = the two bits of
-// (c >> 1) & 3 (A 0, C 1, T 2, G 3), plane 2 = the base is none of ACGT ('N'); positions past the read are 0 / 0 / 0
-template <int NW> __global__ __launch_bounds__(256) void fs_pack_bases(const uint8_t* __restrict__ seq, const MatchRead* __restrict__ reads, uint32_t nReads,
+// ASCII bases -> four bit planes of FW words each in a frame ALIGNED AT THE SIGNATURE: bit OFF + p - minPos stands for
+// base p, so two reads of a bin line up bit for bit whatever their shift (OFF = 32 * (FW / 2): 160 for reads of up to 160
+// bases, 256 up to 256).  Planes: the two bits of (c >> 1) & 3 (A 0, C 1, T 2, G 3; 0 for 'N'), the 'N' flag, and
+// "a base is here".  Two bases differ where both are present and any of the first three planes differs.
+template <int FW> __global__ __launch_bounds__(256) void fs_pack_bases(const uint8_t* __restrict__ seq, const MatchRead* __restrict__ reads, uint32_t nReads,
                                                                         uint32_t* __restrict__ planes)
 {
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t r = g / NW, w = g % NW;
+    const uint32_t r = g / FW, w = g % FW;
     if (r >= nReads) return;
     const MatchRead rd = reads[r];
     const uint8_t* s = seq + rd.seq_off;
-    uint32_t p0 = 0, p1 = 0, pn = 0;
+    const int32_t OFF = 32 * (FW / 2);
+    uint32_t p0 = 0, p1 = 0, pn = 0, pv = 0;
     for (uint32_t b = 0; b < 32u; ++b) {
-        const uint32_t pos = 32u * w + b;
-        if (pos >= rd.len) break;
+        const int32_t pos = (int32_t)(32u * w + b) - OFF + (int32_t)rd.min_pos;
+        if (pos < 0 || pos >= (int32_t)rd.len) continue;
         const uint32_t c = s[pos];
         const bool acgt = c == 'A' || c == 'C' || c == 'G' || c == 'T';
         const uint32_t code = acgt ? (c >> 1) & 3u : 0u;
-        p0 |= (code & 1u) << b; p1 |= (code >> 1) << b; pn |= (acgt ? 0u : 1u) << b;
+        p0 |= (code & 1u) << b; p1 |= (code >> 1) << b; pn |= (acgt ? 0u : 1u) << b; pv |= 1u << b;
     }
-    uint32_t* o = planes + (size_t)r * (3 * NW);
-    o[w] = p0; o[NW + w] = p1; o[2 * NW + w] = pn;
+    uint32_t* o = planes + (size_t)r * (4 * FW);
+    o[w] = p0; o[FW + w] = p1; o[2 * FW + w] = pn; o[3 * FW + w] = pv;
 }
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
@@ -69,74 +73,65 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
     return (uint32_t)__builtin_amdgcn_readlane(v, 63);
 }
 
-// right shift of an NW-word bit string by s < 128 bits
-template <int NW> __device__ __forceinline__ void shr_bits(uint32_t (&x)[NW], uint32_t s)
-{
-    const uint32_t ws = s >> 5, bs = s & 31u;
-    if (ws & 1u) { _Pragma("unroll") for (int i = 0; i < NW; ++i) x[i] = i + 1 < NW ? x[i + 1] : 0u; }
-    if (ws & 2u) { _Pragma("unroll") for (int i = 0; i < NW; ++i) x[i] = i + 2 < NW ? x[i + 2] : 0u; }
-    _Pragma("unroll") for (int i = 0; i < NW; ++i) x[i] = __builtin_amdgcn_alignbit(i + 1 < NW ? x[i + 1] : 0u, x[i], bs);
-}
-
 struct Shared {
     uint32_t key[2][16], match[2][16], info[2][16];     // per wave: its best key, the matched read, len | shift << 16 | noMismatches << 31; two buffers by parity
 };
 
 // MULTI: more than one wavefront per construction (windows of more than 64 slots)
-template <int NW, bool MULTI> __global__ __launch_bounds__(MULTI ? 1024 : 64) void fs_match_reads(
+template <int FW, bool MULTI> __global__ __launch_bounds__(MULTI ? 1024 : 64) void fs_match_reads(
     const MatchCall* __restrict__ calls, const uint32_t* __restrict__ callIds, const MatchRead* __restrict__ reads, const uint32_t* __restrict__ planes,
-    MatchParams par, MatchRow* __restrict__ rows)
+    const uint32_t* __restrict__ warm, MatchParams par, MatchRow* __restrict__ rows)
 {
     __shared__ Shared sh;
     const MatchCall call = calls[callIds[blockIdx.x]];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nWaves = blockDim.x >> 6;
     const uint32_t cap = par.window - 1u;                 // real slots: the reference drops one slot before every search
+    constexpr int C0 = FW / 2 - 2, C1 = FW / 2 + 2;       // the four words around the signature (64 bases either side of its start): compared first
     // this thread's slot
-    uint32_t e0[NW], e1[NW], en[NW];
+    uint32_t e0[FW], e1[FW], en[FW], ev[FW];
     uint32_t eRead = kNone, eLen = 0, eMin = 0, ePush = 0; bool valid = false;
     uint32_t pushed = 0, nextSlot = 0;                     // entries put at the front so far; entry k lives in slot k % cap = nextSlot
-    auto take = [&](uint32_t r, uint32_t minPos) {        // the owner of the next slot takes read r over
-        if (tid == nextSlot) {
-            const uint32_t* p = planes + (size_t)r * (3 * NW);
-            _Pragma("unroll") for (int i = 0; i < NW; ++i) { e0[i] = p[i]; e1[i] = p[NW + i]; en[i] = p[2 * NW + i]; }
-            eRead = r; eLen = reads[r].len; eMin = minPos; ePush = pushed; valid = true;
-        }
+    auto load = [&](uint32_t r) {
+        const uint32_t* p = planes + (size_t)r * (4 * FW);
+        _Pragma("unroll") for (int i = 0; i < FW; ++i) { e0[i] = p[i]; e1[i] = p[FW + i]; en[i] = p[2 * FW + i]; ev[i] = p[3 * FW + i]; }
+        eRead = r; eLen = reads[r].len; eMin = reads[r].min_pos; valid = true;
+    };
+    auto take = [&](uint32_t r) {                          // the owner of the next slot takes read r over
+        if (tid == nextSlot) { load(r); ePush = pushed; }
         ++pushed; nextSlot = nextSlot + 1u == cap ? 0u : nextSlot + 1u;
     };
-    if (call.aux >= 0) take((uint32_t)call.aux, reads[call.aux].min_pos);
+    if (call.aux >= 0) take((uint32_t)call.aux);
+    if (call.warm_count) {                                 // a later piece of a long construction: the window as it stands, one slot per thread
+        if (tid < call.warm_count) { load(warm[call.warm_first + tid]); ePush = tid; }
+        pushed = call.warm_count; nextSlot = call.warm_count == cap ? 0u : call.warm_count;
+    }
     for (uint32_t i = 0; i < call.count; ++i) {
         const uint32_t r = call.first + i;
         const MatchRead rd = reads[r];
         const uint32_t rLen = rd.len, rMin = rd.min_pos;
         const int32_t thr = par.encode_threshold ? par.encode_threshold : (int32_t)(rLen / 2u);
-        const uint32_t* rp = planes + (size_t)r * (3 * NW);          // wave-uniform address: scalar loads
+        const uint32_t* rp = planes + (size_t)r * (4 * FW);          // wave-uniform address: scalar loads
         uint32_t key = kNone, myInfo = 0;
-        if (valid) {
+        {
             const int32_t shift = (int32_t)eMin - (int32_t)rMin;
             const uint32_t ashift = (uint32_t)(shift < 0 ? -shift : shift);
             const int32_t insertCost = (int32_t)ashift * par.shift_cost;
-            if (ashift <= 127u && insertCost <= thr + 1) {
-                // a: the string that is read from offset `ashift` on, b: the one read from its start
-                uint32_t a0[NW], a1[NW], an[NW], b0[NW], b1[NW], bn[NW];
-                const bool entryShifted = shift > 0;
-                _Pragma("unroll") for (int k = 0; k < NW; ++k) {
-                    const uint32_t r0 = rp[k], r1 = rp[NW + k], rn = rp[2 * NW + k];
-                    a0[k] = entryShifted ? e0[k] : r0; a1[k] = entryShifted ? e1[k] : r1; an[k] = entryShifted ? en[k] : rn;
-                    b0[k] = entryShifted ? r0 : e0[k]; b1[k] = entryShifted ? r1 : e1[k]; bn[k] = entryShifted ? rn : en[k];
-                }
-                shr_bits<NW>(a0, ashift); shr_bits<NW>(a1, ashift); shr_bits<NW>(an, ashift);
-                const uint32_t aLen = (entryShifted ? eLen : rLen) - ashift, bLen = entryShifted ? rLen : eLen;
-                const uint32_t minLen = aLen < bLen ? aLen : bLen;
-                uint32_t mism = 0;
-                _Pragma("unroll") for (int k = 0; k < NW; ++k) {
-                    const uint32_t lo = 32u * (uint32_t)k;
-                    const uint32_t m = minLen >= lo + 32u ? 0xFFFFFFFFu : (minLen > lo ? (1u << (minLen - lo)) - 1u : 0u);
-                    const uint32_t anyN = an[k] | bn[k];
-                    const uint32_t d = ((((a0[k] ^ b0[k]) | (a1[k] ^ b1[k])) & ~anyN) | (an[k] ^ bn[k])) & m;
+            bool live = valid && ashift <= 127u && insertCost <= thr;
+            // stage 1: the words around the signature; a wave none of whose slots can still get to the threshold stops here
+            uint32_t mism = 0;
+            _Pragma("unroll") for (int k = C0; k < C1; ++k) {
+                const uint32_t d = ((e0[k] ^ rp[k]) | (e1[k] ^ rp[FW + k]) | (en[k] ^ rp[2 * FW + k])) & ev[k] & rp[3 * FW + k];
+                mism += (uint32_t)__builtin_popcount(d);
+            }
+            live = live && insertCost + (int32_t)mism * par.mismatch_cost <= thr;
+            if (__ballot(live) != 0ull) {
+                _Pragma("unroll") for (int k = 0; k < FW; ++k) {
+                    if (k >= C0 && k < C1) continue;
+                    const uint32_t d = ((e0[k] ^ rp[k]) | (e1[k] ^ rp[FW + k]) | (en[k] ^ rp[2 * FW + k])) & ev[k] & rp[3 * FW + k];
                     mism += (uint32_t)__builtin_popcount(d);
                 }
                 const int32_t cc = insertCost + (int32_t)mism * par.mismatch_cost;
-                if (cc <= thr) {
+                if (live && cc <= thr) {
                     key = ((uint32_t)cc << 16) | (pushed - 1u - ePush);       // age: 0 = newest
                     myInfo = eLen | (((uint32_t)shift & 0x7FFFu) << 16) | (mism == 0u ? 0x80000000u : 0u);
                 }
@@ -145,18 +140,15 @@ template <int NW, bool MULTI> __global__ __launch_bounds__(MULTI ? 1024 : 64) vo
         uint32_t myMatch = eRead;
         // the dummy slots (256 x 'N', signature position 0) are all alike and come behind the real ones: one thread prices them
         if (pushed < cap && tid == nextSlot && rMin <= 127u) {
-            uint32_t nN = 0;                                                  // 'N' positions of the read from rMin on
-            _Pragma("unroll") for (int k = 0; k < NW; ++k) {
-                const uint32_t lo = 32u * (uint32_t)k;
-                const uint32_t from = rMin > lo ? (rMin - lo >= 32u ? 0u : 0xFFFFFFFFu << (rMin - lo)) : 0xFFFFFFFFu;
-                nN += (uint32_t)__builtin_popcount(rp[2 * NW + k] & from);
-            }
+            uint32_t real = 0;                                                // bases of the read from its signature position on that are not 'N'
+            _Pragma("unroll") for (int k = FW / 2; k < FW; ++k) real += (uint32_t)__builtin_popcount(rp[3 * FW + k] & ~rp[2 * FW + k]);
             const uint32_t minLen = rLen - rMin < 256u ? rLen - rMin : 256u;
-            const int32_t cc = (int32_t)rMin * par.shift_cost + (int32_t)(minLen - nN) * par.mismatch_cost;
+            const int32_t cc = (int32_t)rMin * par.shift_cost + (int32_t)real * par.mismatch_cost;
             if (cc <= thr) {
                 key = ((uint32_t)cc << 16) | pushed;
-                myInfo = 256u | (((uint32_t)(-(int32_t)rMin) & 0x7FFFu) << 16) | (minLen == nN ? 0x80000000u : 0u);
+                myInfo = 256u | (((uint32_t)(-(int32_t)rMin) & 0x7FFFu) << 16) | (real == 0u ? 0x80000000u : 0u);
                 myMatch = kNone - 1u;                                        // dummy
+                (void)minLen;
             }
         }
         // minimum over the workgroup; the owner of the minimum publishes its slot
@@ -189,7 +181,7 @@ template <int NW, bool MULTI> __global__ __launch_bounds__(MULTI ? 1024 : 64) vo
             row.identical = identical ? 1 : 0;
         }
         if (tid == 0u) rows[r] = row;
-        if (!identical) take(r, rMin);
+        if (!identical) take(r);
     }
 }
 
@@ -211,6 +203,12 @@ template <class T> int ensureBuf(fsengine::Device* dev, T*& p, size_t& cap, size
 
 namespace fsengine {
 
+// The searches of all host threads go through TWO streams per GPU (each thread has its own buffers; a thread's copies and
+// kernels keep their order on the stream they share with others).  The coder lanes hold 14 of the 16 hardware queues for
+// kernels that run for a second: a stream that had to share one of THOSE queues would wait behind such a kernel.
+struct StreamPool { hipStream_t s[2] = {nullptr, nullptr}; int users = 0; unsigned next = 0; };
+static std::mutex g_poolMx; static StreamPool g_pool[16];
+
 struct MatchLane {
     int deviceId = 0;
     hipStream_t stream = nullptr; hipEvent_t evWait = nullptr, ev0 = nullptr, ev1 = nullptr;
@@ -218,6 +216,7 @@ struct MatchLane {
     MatchRead* dReads = nullptr; size_t capReads = 0;
     MatchCall* dCalls = nullptr; size_t capCalls = 0;
     uint32_t* dIds = nullptr; size_t capIds = 0;
+    uint32_t* dWarm = nullptr; size_t capWarm = 0;
     uint32_t* dPlanes = nullptr; size_t capPlanes = 0;
     MatchRow* dRows = nullptr; size_t capRows = 0;
     uint8_t* hStage = nullptr; size_t capStage = 0;
@@ -228,9 +227,15 @@ int match_lane_create(Device* dev, MatchLane** out)
     *out = nullptr;
     HIP_TRY(hipSetDevice(dev->deviceId));
     MatchLane* m = new MatchLane(); m->deviceId = dev->deviceId;
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // (least, greatest): the searches are short and sit in front of host work
-    hipError_t e = hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, hi);
+    // (streams of normal priority: a high-priority queue makes the scheduler save and restore the resident coder waves
+    // around every search -- measured: the coder kernels ran twice as long)
+    hipError_t e = hipSuccess;
+    {
+        std::lock_guard<std::mutex> g(g_poolMx);
+        StreamPool& p = g_pool[dev->deviceId & 15];
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) if (!p.s[i]) e = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
+        if (e == hipSuccess) { m->stream = p.s[p.next++ & 1u]; ++p.users; }
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->evWait, hipEventBlockingSync | hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&m->ev0);
     if (e == hipSuccess) e = hipEventCreate(&m->ev1);
@@ -243,21 +248,45 @@ void match_lane_destroy(MatchLane* m)
 {
     if (!m) return;
     (void)hipSetDevice(m->deviceId);
-    if (m->stream) (void)hipStreamSynchronize(m->stream);
-    void* ptrs[] = {m->dSeq, m->dReads, m->dCalls, m->dIds, m->dPlanes, m->dRows};
+    if (m->stream) {
+        (void)hipStreamSynchronize(m->stream);
+        std::lock_guard<std::mutex> g(g_poolMx);
+        StreamPool& p = g_pool[m->deviceId & 15];
+        if (--p.users == 0) { for (int i = 0; i < 2; ++i) if (p.s[i]) { (void)hipStreamDestroy(p.s[i]); p.s[i] = nullptr; } }
+        m->stream = nullptr;
+    }
+    void* ptrs[] = {m->dSeq, m->dReads, m->dCalls, m->dIds, m->dWarm, m->dPlanes, m->dRows};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->hStage) (void)hipHostFree(m->hStage);
     if (m->evWait) (void)hipEventDestroy(m->evWait);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
-    if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
+}
+
+// Room for bins of up to maxReads table entries / maxSeqBytes bases / maxCalls constructions / maxWarm warm-up entries, made
+// BEFORE the coder kernels of a batch are in flight: growing a buffer later would hipFree, which waits for every running kernel
+int match_lane_reserve(Device* dev, MatchLane* m, size_t maxReads, size_t maxSeqBytes, size_t maxCalls, size_t maxWarm)
+{
+    HIP_TRY(hipSetDevice(m->deviceId));
+    const size_t planeBytes = maxReads * (size_t)(4 * 16) * 4u;
+    if (ensureBuf(dev, m->dSeq, m->capSeq, maxSeqBytes + 64) || ensureBuf(dev, m->dReads, m->capReads, maxReads * sizeof(MatchRead)) ||
+        ensureBuf(dev, m->dCalls, m->capCalls, maxCalls * sizeof(MatchCall)) || ensureBuf(dev, m->dIds, m->capIds, maxCalls * 4u) || ensureBuf(dev, m->dWarm, m->capWarm, maxWarm * 4u + 16) ||
+        ensureBuf(dev, m->dPlanes, m->capPlanes, planeBytes) || ensureBuf(dev, m->dRows, m->capRows, maxReads * sizeof(MatchRow))) return -1;
+    const size_t upBytes = ((maxSeqBytes + 15) & ~(size_t)15) + ((maxReads * sizeof(MatchRead) + 15) & ~(size_t)15) + ((maxCalls * sizeof(MatchCall) + 15) & ~(size_t)15) + ((maxCalls * 4u + 15) & ~(size_t)15) + maxWarm * 4u + 64;
+    if (upBytes > m->capStage) {
+        if (m->hStage) (void)hipHostFree(m->hStage);
+        m->hStage = nullptr; m->capStage = 0;
+        HIP_TRY(hipHostMalloc((void**)&m->hStage, upBytes + 65536, hipHostMallocDefault));
+        m->capStage = upBytes + 65536;
+    }
+    return 0;
 }
 
 // One bin's searches.  seq: the bin's bases (ASCII); reads: every read of every construction, each construction's reads in
 // processing order (a sub-tree's root copy is one more read, named by its call); rows[i] answers reads[i] (root copies: unset).
 int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, const MatchRead* reads, size_t nReads,
-                const MatchCall* calls, size_t nCalls, const MatchParams& par, MatchRow* rows, double* kernelMs)
+                const MatchCall* calls, size_t nCalls, const uint32_t* warm, size_t nWarm, const MatchParams& par, MatchRow* rows, double* kernelMs)
 {
     if (nReads == 0 || nCalls == 0) return 0;
     if (par.window < 2u || par.window > 1025u) { snprintf(dev->err, sizeof dev->err, "device matcher: window of %u slots not supported (2..1025)", par.window); return -1; }
@@ -268,24 +297,26 @@ int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
         maxLen = std::max<uint32_t>(maxLen, reads[i].len);
     }
     if (maxLen > 256u) { snprintf(dev->err, sizeof dev->err, "device matcher: reads longer than 256 bases"); return -1; }
-    const int NW = maxLen <= 160u ? 5 : 8;
+    const int FW = maxLen <= 160u ? 10 : 16;
     // constructions by the number of window slots they can fill: one wavefront, or one thread per slot up to the window
     std::vector<uint32_t> ids(nCalls), small, large[4];       // large: 128, 256, 512, 1024 threads
     const uint32_t cap = par.window - 1u;
+    for (size_t i = 0; i < nWarm; ++i) if (warm[i] >= nReads) { snprintf(dev->err, sizeof dev->err, "device matcher: warm-up list outside the read table"); return -1; }
     for (size_t c = 0; c < nCalls; ++c) {
         const MatchCall& k = calls[c];
         if ((uint64_t)k.first + k.count > nReads || (k.aux >= 0 && (size_t)k.aux >= nReads)) { snprintf(dev->err, sizeof dev->err, "device matcher: construction %zu outside the read table", c); return -1; }
+        if ((uint64_t)k.warm_first + k.warm_count > nWarm || k.warm_count > cap || (k.warm_count && k.aux >= 0)) { snprintf(dev->err, sizeof dev->err, "device matcher: warm-up list of construction %zu", c); return -1; }
         if (k.count == 0) continue;
-        const uint32_t slots = std::min<uint32_t>(k.count + (k.aux >= 0 ? 1u : 0u), cap);
+        const uint32_t slots = std::min<uint32_t>(k.count + (k.aux >= 0 ? 1u : 0u) + k.warm_count, cap);
         if (slots <= 64u) small.push_back((uint32_t)c);
         else large[slots <= 128u ? 0 : (slots <= 256u ? 1 : (slots <= 512u ? 2 : 3))].push_back((uint32_t)c);
     }
-    const size_t planeBytes = nReads * (size_t)(3 * NW) * 4u;
+    const size_t planeBytes = nReads * (size_t)(4 * FW) * 4u;
     if (ensureBuf(dev, m->dSeq, m->capSeq, seqBytes + 64) || ensureBuf(dev, m->dReads, m->capReads, nReads * sizeof(MatchRead)) ||
-        ensureBuf(dev, m->dCalls, m->capCalls, nCalls * sizeof(MatchCall)) || ensureBuf(dev, m->dIds, m->capIds, nCalls * 4u) ||
+        ensureBuf(dev, m->dCalls, m->capCalls, nCalls * sizeof(MatchCall)) || ensureBuf(dev, m->dIds, m->capIds, nCalls * 4u) || ensureBuf(dev, m->dWarm, m->capWarm, nWarm * 4u + 16) ||
         ensureBuf(dev, m->dPlanes, m->capPlanes, planeBytes) || ensureBuf(dev, m->dRows, m->capRows, nReads * sizeof(MatchRow))) return -1;
     // pinned staging for everything that goes up (the callers' arrays are pageable)
-    const size_t upBytes = ((seqBytes + 15) & ~(size_t)15) + ((nReads * sizeof(MatchRead) + 15) & ~(size_t)15) + ((nCalls * sizeof(MatchCall) + 15) & ~(size_t)15) + nCalls * 4u + 64;
+    const size_t upBytes = ((seqBytes + 15) & ~(size_t)15) + ((nReads * sizeof(MatchRead) + 15) & ~(size_t)15) + ((nCalls * sizeof(MatchCall) + 15) & ~(size_t)15) + ((nCalls * 4u + 15) & ~(size_t)15) + nWarm * 4u + 64;
     if (upBytes > m->capStage) {
         if (m->hStage) (void)hipHostFree(m->hStage);
         m->hStage = nullptr; m->capStage = 0;
@@ -300,25 +331,29 @@ int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
     uint32_t* hid = (uint32_t*)(h + o); const size_t oIds = o; size_t nid = 0;
     const size_t smallAt = nid; for (uint32_t c : small) hid[nid++] = c;
     size_t largeAt[4]; for (int g = 0; g < 4; ++g) { largeAt[g] = nid; for (uint32_t c : large[g]) hid[nid++] = c; }
+    o += (nCalls * 4u + 15) & ~(size_t)15;
+    const size_t oWarm = o;
+    if (nWarm) memcpy(h + o, warm, nWarm * 4u);
     hipStream_t st = m->stream;
     HIP_TRY(hipMemcpyAsync(m->dSeq, h + oSeq, seqBytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->dReads, h + oReads, nReads * sizeof(MatchRead), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->dCalls, h + oCalls, nCalls * sizeof(MatchCall), hipMemcpyHostToDevice, st));
     if (nid) HIP_TRY(hipMemcpyAsync(m->dIds, h + oIds, nid * 4u, hipMemcpyHostToDevice, st));
+    if (nWarm) HIP_TRY(hipMemcpyAsync(m->dWarm, h + oWarm, nWarm * 4u, hipMemcpyHostToDevice, st));
     HIP_TRY(hipEventRecord(m->ev0, st));
-    const uint32_t packBlocks = (uint32_t)((nReads * (size_t)NW + 255) / 256);
-    if (NW == 5) hipLaunchKernelGGL(fs_pack_bases<5>, dim3(packBlocks), dim3(256), 0, st, (const uint8_t*)m->dSeq, (const MatchRead*)m->dReads, (uint32_t)nReads, m->dPlanes);
-    else hipLaunchKernelGGL(fs_pack_bases<8>, dim3(packBlocks), dim3(256), 0, st, (const uint8_t*)m->dSeq, (const MatchRead*)m->dReads, (uint32_t)nReads, m->dPlanes);
+    const uint32_t packBlocks = (uint32_t)((nReads * (size_t)FW + 255) / 256);
+    if (FW == 10) hipLaunchKernelGGL(fs_pack_bases<10>, dim3(packBlocks), dim3(256), 0, st, (const uint8_t*)m->dSeq, (const MatchRead*)m->dReads, (uint32_t)nReads, m->dPlanes);
+    else hipLaunchKernelGGL(fs_pack_bases<16>, dim3(packBlocks), dim3(256), 0, st, (const uint8_t*)m->dSeq, (const MatchRead*)m->dReads, (uint32_t)nReads, m->dPlanes);
     HIP_TRY(hipGetLastError());
     auto launch = [&](size_t at, size_t n, uint32_t threads) {
         if (!n) return;
         const uint32_t* idp = m->dIds + at;
         if (threads == 64u) {
-            if (NW == 5) hipLaunchKernelGGL((fs_match_reads<5, false>), dim3((uint32_t)n), dim3(64), 0, st, (const MatchCall*)m->dCalls, idp, (const MatchRead*)m->dReads, (const uint32_t*)m->dPlanes, par, m->dRows);
-            else hipLaunchKernelGGL((fs_match_reads<8, false>), dim3((uint32_t)n), dim3(64), 0, st, (const MatchCall*)m->dCalls, idp, (const MatchRead*)m->dReads, (const uint32_t*)m->dPlanes, par, m->dRows);
+            if (FW == 10) hipLaunchKernelGGL((fs_match_reads<10, false>), dim3((uint32_t)n), dim3(64), 0, st, (const MatchCall*)m->dCalls, idp, (const MatchRead*)m->dReads, (const uint32_t*)m->dPlanes, (const uint32_t*)m->dWarm, par, m->dRows);
+            else hipLaunchKernelGGL((fs_match_reads<16, false>), dim3((uint32_t)n), dim3(64), 0, st, (const MatchCall*)m->dCalls, idp, (const MatchRead*)m->dReads, (const uint32_t*)m->dPlanes, (const uint32_t*)m->dWarm, par, m->dRows);
         } else {
-            if (NW == 5) hipLaunchKernelGGL((fs_match_reads<5, true>), dim3((uint32_t)n), dim3(threads), 0, st, (const MatchCall*)m->dCalls, idp, (const MatchRead*)m->dReads, (const uint32_t*)m->dPlanes, par, m->dRows);
-            else hipLaunchKernelGGL((fs_match_reads<8, true>), dim3((uint32_t)n), dim3(threads), 0, st, (const MatchCall*)m->dCalls, idp, (const MatchRead*)m->dReads, (const uint32_t*)m->dPlanes, par, m->dRows);
+            if (FW == 10) hipLaunchKernelGGL((fs_match_reads<10, true>), dim3((uint32_t)n), dim3(threads), 0, st, (const MatchCall*)m->dCalls, idp, (const MatchRead*)m->dReads, (const uint32_t*)m->dPlanes, (const uint32_t*)m->dWarm, par, m->dRows);
+            else hipLaunchKernelGGL((fs_match_reads<16, true>), dim3((uint32_t)n), dim3(threads), 0, st, (const MatchCall*)m->dCalls, idp, (const MatchRead*)m->dReads, (const uint32_t*)m->dPlanes, (const uint32_t*)m->dWarm, par, m->dRows);
         }
     };
     // the largest constructions first: they run the longest

@@ -259,10 +259,10 @@ MatchFn Context::matcherFor(uint32_t tid)
     if (!deviceMatcher) return MatchFn();
     if (matchLanes.size() <= tid) throw std::runtime_error("matcher lanes not sized");       // (sized by the callers before their threads start)
     return [this, tid](const uint8_t* seq, size_t seqBytes, const fsdev::MatchRead* reads, size_t nReads, const fsdev::MatchCall* calls, size_t nCalls,
-                       const fsdev::MatchParams& mp, fsdev::MatchRow* rows) -> bool {
+                       const uint32_t* warm, size_t nWarm, const fsdev::MatchParams& mp, fsdev::MatchRow* rows) -> bool {
         if (!matchLanes[tid] && fsengine::match_lane_create(dev, &matchLanes[tid]) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
         const double t0 = nowMs(); double kms = 0;
-        if (fsengine::match_reads(dev, matchLanes[tid], seq, seqBytes, reads, nReads, calls, nCalls, mp, rows, &kms) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+        if (fsengine::match_reads(dev, matchLanes[tid], seq, seqBytes, reads, nReads, calls, nCalls, warm, nWarm, mp, rows, &kms) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
         matchedReads += nReads; matchUs += (uint64_t)((nowMs() - t0) * 1e3); matchKernelUs += (uint64_t)(kms * 1e3);
         return true;
     };
@@ -560,11 +560,25 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     std::vector<std::unique_ptr<BinEncoder>>& encs = encoders;        // kept across calls: their work buffers stay mapped
     if (encs.size() < hostThreads) encs.resize(hostThreads);
     if (matchLanes.size() < hostThreads) matchLanes.resize(hostThreads, nullptr);
+    uint32_t matcherBins = deviceMatcher ? 3u * hostThreads : 0u;
+    if (const char* mb = getenv("FS_MATCHER_BINS")) matcherBins = (uint32_t)std::max(0, atoi(mb));
+    if (deviceMatcher && matchReserve.reads && matcherBins) {
+        // every host thread's matcher lane gets room for the largest bin now, while no coder kernel is in flight
+        for (uint32_t t = 0; t < hostThreads; ++t) {
+            if (!matchLanes[t] && fsengine::match_lane_create(dev, &matchLanes[t]) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+            if (fsengine::match_lane_reserve(dev, matchLanes[t], matchReserve.reads, matchReserve.seqBytes, matchReserve.calls, matchReserve.warm) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+        }
+    }
     const double tf = nowMs();
     try {
         parallelFor(nBins, hostThreads, [&](uint32_t k, uint32_t tid) {
             const uint32_t b = byWork[k];
-            if (!encs[tid]) { encs[tid].reset(new BinEncoder(par)); encs[tid]->setMatcher(matcherFor(tid)); }
+            if (!encs[tid]) encs[tid].reset(new BinEncoder(par));
+            // The heaviest bins -- the first few rounds of the host threads -- have their window searches done by the device:
+            // they sit on the critical path (their quality streams are the longest) and the device is still nearly empty.
+            // Later the coder kernels hold every register of the chip (3 waves x 168 VGPRs per SIMD): a search would wait
+            // for coder waves to leave, longer than the host scan takes, so the lighter bins keep the host scan.
+            encs[tid]->setMatcher(k < matcherBins ? matcherFor(tid) : MatchFn());
             const double ta = trace ? nowMs() : 0.0;
             produce(b, *encs[tid], st[b], info[b], recBytes[b]);
             if (trace) busyMs[tid] += nowMs() - ta;
@@ -606,6 +620,8 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         double sum = 0, mx = 0; for (double v : busyMs) { sum += v; mx = std::max(mx, v); }
         fprintf(stderr, "[trace] batch: %u bins in %u slices on %u lanes, host tasks %.1f ms (%u threads: busy sum %.0f ms, busiest %.0f ms), total %.1f ms\n",
                 nBins, nSlices, nLanes, feMs, hostThreads, sum, mx, nowMs() - t0);
+        fprintf(stderr, "[trace] device matcher so far: %llu reads, %.0f ms in its calls (summed over the host threads), %.0f ms of kernels\n",
+                (unsigned long long)matchedReads.load(), matchUs.load() / 1e3, matchKernelUs.load() / 1e3);
     }
     stats.bins += nBins;
     binInfo.swap(info);
@@ -787,6 +803,13 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             }
             if (seqBase[nb] > 0xFFFFFFF0ull || headBase[nb] > 0xFFFFFFF0ull || recBase[nb] > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB");
             batch.seq.resize(seqBase[nb]); batch.head.resize(headBase[nb]); batch.recs.resize(recBase[nb]);
+            {   // the largest bin's matcher tables: a read and at most one root copy per record, a construction per sub-tree
+                // (fewer than records) + the pieces of the top-level one, a full window of warm-up entries per piece
+                uint64_t mr = 0, ms = 0;
+                for (uint32_t k = 0; k < nb; ++k) { mr = std::max<uint64_t>(mr, recBase[k + 1] - recBase[k]); ms = std::max<uint64_t>(ms, seqBase[k + 1] - seqBase[k]); }
+                matchReserve.reads = 2 * mr + 16; matchReserve.seqBytes = ms; matchReserve.calls = mr + mr / 512 + 16;
+                matchReserve.warm = (mr / 512 + 2) * (uint64_t)std::max(1u, par.maxLzWindowSize);
+            }
             if (packedQ) { batch.qua.clear(); batch.quaPacked.resize(quaBase[nb]); batch.quaBit.resize(recBase[nb]); }
             else { batch.qua.resize(seqBase[nb]); batch.quaPacked.clear(); batch.quaBit.clear(); }
             std::vector<Batch> graph(nb);                              // per bin: its stored graph (node indices local to it)

@@ -98,6 +98,7 @@ struct Context {
     // device-side window search (matcher.hip): a matcher lane per host thread, made on first use; deviceMatcher off = host scan
     std::vector<fsengine::MatchLane*> matchLanes;
     bool deviceMatcher = true;
+    struct { size_t reads = 0, seqBytes = 0, calls = 0, warm = 0; } matchReserve;     // bounds of the largest bin of the coming batch (0: grow on demand)
     std::atomic<uint64_t> matchedReads{0}, matchUs{0}, matchKernelUs{0};
     MatchFn matcherFor(uint32_t tid);
     void matcherCheck(const std::string& inPrefix, uint64_t& reads, uint64_t& differing);

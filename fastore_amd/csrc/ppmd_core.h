@@ -1005,8 +1005,10 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
                 const uint32_t done = window_step(m, in, n, FS_UNI(pos), FS_UNI(MinContext), hist);
                 // a window that stopped short did so in front of a symbol for the serial path: skip one attempt.  An attempt
                 // that codes nothing doubles the pause (learning phase of a model, unpredictable streams).
+                // (a failed attempt costs less than half a serial symbol, and the symbols behind a read boundary are plain hits
+                // again after two or three: the pause only starts to grow with the fourth failure in a row)
                 if (done != 0u) { winPenalty = 0; winSkip = done < 64u ? 1u : 0u; }
-                else { winPenalty = winPenalty >= 32u ? 64u : 2u * winPenalty + 1u; winSkip = winPenalty; }
+                else { ++winPenalty; winSkip = winPenalty <= 3u ? 1u : (winPenalty >= 9u ? 64u : 1u << (winPenalty - 3u)); }
                 if (done != 0u) {
                     pos += done; MinContext = m.MaxContext; m.pfCtx = 0; keep = 0; prevCtx = 0;
                     if ((pos & 3u) != 0u && (pos | 3u) < n) { cur = *(fs_cgptr32)(in + (pos & ~3u)); if ((pos & ~3u) + 8u <= n) nxt = *(fs_cgptr32)(in + (pos & ~3u) + 4u); }
@@ -1045,6 +1047,7 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
         if (mc.ns() != 0) { FS_PATH(g_path[2]); encodeSymbol1(m, MinContext, mc, c); rc_encode(m); if (m.FoundState) { if (m.rLow == 0) FS_PATH(g_path[3]); else FS_PATH(g_path[4]); } }
         else { FS_PATH(g_path[1]); encodeBinSymbol(m, MinContext, mc, c, sufRec, sufCtx); }
         uint32_t stop = 0;
+        uint64_t tSer = FS_PROF_NOW();
         while (FS_UNI(m.FoundState) == 0) {
             rc_normalize(m);
             do {
@@ -1059,10 +1062,11 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
             if (m.FoundState) FS_PATH(g_path[6]);
         }
         if (FS_UNI(stop)) break;
+        FS_PROF_ACC(m.sh->winStats[6], tSer);                          // escapes: suffix walk + encodeSymbol2 rounds
         const uint32_t succ = FS_UNI(m.fsSucc);
         FS_SYMHOOK(prevCtx, MinContext, mc, m, succ);
         if (FS_UNI((uint32_t)m.OrderFall) == 0 && succ >= FS_UNI(m.UnitsStart)) { FS_PATH(g_path[7]); m.MaxContext = succ; keep = (succ == MinContext) ? 1u : 0u; }
-        else { UpdateModel(m, MinContext, mc, FS_UNI(sufCtx) != 0 && FS_UNI(sufCtx) == FS_UNI(mc.suff), sufRec); if (FS_UNI(m.EscCount) == 0) clear_mask(m); }
+        else { UpdateModel(m, MinContext, mc, FS_UNI(sufCtx) != 0 && FS_UNI(sufCtx) == FS_UNI(mc.suff), sufRec); if (FS_UNI(m.EscCount) == 0) clear_mask(m); FS_PROF_ACC(m.sh->winStats[7], tSer); }
         rc_normalize(m); MinContext = m.MaxContext;
     }
     if (restartsOut) *restartsOut = FS_UNI(m.sh->restarts);

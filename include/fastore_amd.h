@@ -220,6 +220,8 @@ int fsgpu_reset_stats(fsgpu_ctx* ctx);
  * (all zero unless the library was built with -DFS_WIN_PROFILE): [0] input/hint/record fetch, [1] state lists + chain,
  * [2] ranks, [3] rounds, [4] write-back, [5] range coder, [6] whole windows, [7] whole PPMd streams. */
 int fsgpu_get_window_profile(const fsgpu_ctx* ctx, uint64_t out[8]);
+/* -DFS_WIN_PROFILE builds: clocks / 64 of the serial path spent in escapes (suffix walk + masked contexts) and in UpdateModel */
+int fsgpu_get_serial_profile(const fsgpu_ctx* ctx, uint64_t out[2]);
 const char* fsgpu_device_name(const fsgpu_ctx* ctx);
 
 #ifdef __cplusplus

@@ -73,14 +73,16 @@ static void gatherQuality(uint8_t* buf, size_t inputBytes, const GatherPlan& g)
 struct MatchLane { int unused; };
 int match_lane_create(Device*, MatchLane** out) { *out = new MatchLane(); return 0; }
 void match_lane_destroy(MatchLane* m) { delete m; }
+int match_lane_reserve(Device*, MatchLane*, size_t, size_t, size_t, size_t) { return 0; }
 int match_reads(Device*, MatchLane*, const uint8_t* seq, size_t, const MatchRead* reads, size_t, const MatchCall* calls, size_t nCalls,
-                const MatchParams& par, MatchRow* rows, double*)
+                const uint32_t* warm, size_t, const MatchParams& par, MatchRow* rows, double*)
 {
     const uint32_t cap = par.window - 1u;
     for (size_t c = 0; c < nCalls; ++c) {
         const MatchCall& call = calls[c];
         std::vector<uint32_t> win;                                     // newest first
         if (call.aux >= 0) win.push_back((uint32_t)call.aux);
+        for (uint32_t k = 0; k < call.warm_count; ++k) win.insert(win.begin(), warm[call.warm_first + k]);     // listed oldest first
         for (uint32_t i = 0; i < call.count; ++i) {
             const uint32_t r = call.first + i; const MatchRead& rd = reads[r];
             const int32_t thr = par.encode_threshold ? par.encode_threshold : (int32_t)(rd.len / 2u);

@@ -370,7 +370,7 @@ def test_device_matcher_on_fresh_libraries_and_same_archive_either_way(tmp_path,
     kn = dict(min_bin_size=256, max_lz_window=1024, max_pair_lz_window=1024, extra_reduce_hard_reads=1, min_consensus_size=10, max_hamming_distance=8)
     with fastore_amd.Packer(device_id=0, **kn) as p:
         n, differing = p.matcher_check(binned)
-        assert n > reads // 2 and differing == 0, (n, differing)
+        assert n > reads // 4 and differing == 0, (n, differing)
         p.pack_file(binned, os.path.join(t, "dev"))
     monkeypatch.setenv("FS_DEVICE_MATCHER", "0")
     with fastore_amd.Packer(device_id=0, **kn) as p:

@@ -13,7 +13,7 @@ run() { # name, env...
   python3 -c "
 import json,sys
 d=json.loads(open('gpurun_out/${T}_bench_$name.json').read()); print('$name', d['value'], 'MB/s', d['ms_per_step'], 'ms', d['stages_ms_per_step_rank0'])"
-  grep "slice\|batch:" gpurun_out/${T}_bench_$name.err | tail -15 | cut -c1-170 | grep -v "slice [4-9]/\|slice 1[0-2]/"
+  grep "slice\|batch:\|matcher" gpurun_out/${T}_bench_$name.err | tail -15 | cut -c1-170 | grep -v "slice [4-9]/\|slice 1[0-2]/"
 }
 run devm
 run hostm FS_DEVICE_MATCHER=0
