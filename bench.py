@@ -213,6 +213,16 @@ def main():
                          "overlapping_launches_per_step": launches // args.steps,
                          "ppmd_symbols_per_s_whole_job": round(tot["ppmd_symbols"] / dt, 1)},
             "host_coded_symbol_fraction": round(float(tot.get("host_coded_symbols", 0)) / sym, 4),
+            # the other kernels of the path (rank 0's context): fs_gather_quality builds the quality streams on the device
+            # (HBM-bound: 0.75 B read + 1 B written per score, launch durations from HIP events on the lanes' streams);
+            # fs_match_reads does the LZ-window searches of the heaviest bins (duration summed over its launches)
+            "other_kernels": {
+                "fs_gather_quality": {"ms_per_step": round(st["gather_kernel_ms"] / args.steps, 3), "scores_per_step": st["gather_symbols"] // args.steps,
+                                      "achieved_GBps": round(st["gather_bytes"] / max(1e-9, st["gather_kernel_ms"] / 1e3) / 1e9, 1) if st["gather_kernel_ms"] > 0 else None,
+                                      "frac_of_hbm_peak": round(st["gather_bytes"] / max(1e-9, st["gather_kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if st["gather_kernel_ms"] > 0 else None},
+                "fs_match_reads": {"reads_per_step": st["matcher_reads"] // args.steps, "kernel_ms_per_step": round(st["matcher_kernel_ms"] / args.steps, 1),
+                                   "host_wait_ms_per_step_summed_over_threads": round(st["matcher_call_ms"] / args.steps, 1)}},
+            "h2d_bytes_per_step": int(st["h2d_bytes"]) // args.steps,
             "stages_ms_per_step_rank0": {k: round(st[k] / args.steps, 1) for k in ("encode_kernel_ms", "assemble_kernel_ms", "frontend_ms", "io_ms", "block0_ms", "total_ms")},
             "archive": {"cdata_bytes": int(tot["cdata_bytes"]) // args.steps, "bins": int(tot["bins"]) // args.steps, "records": int(tot["records"]) // args.steps,
                         "block0_records": st["block0_records"] // args.steps},

@@ -46,6 +46,7 @@ void device_destroy(Device* dev);                                            // 
 // diagnostic: progress of the lane's current launch (work-queue head) and the pool's slot rings, read on a stream of its own
 int lane_debug(Device* dev, char* out, size_t outLen);
 uint8_t* staging_buffer(Device* dev, size_t bytes);     // grow-only pinned host buffer for the batch input
+int lanes_equalize(Device* const* lanes, size_t n);     // between batches: every lane gets the device buffers of the best-equipped one
 int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,
                        std::vector<uint8_t>& raw, std::vector<uint32_t>& sizes, BatchTiming* timing);
 // Device-side read matcher (matcher.hip): a lane of its own (high-priority stream, own buffers) per caller; match_reads

@@ -545,6 +545,34 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     return 0;
 }
 
+// Give every lane the device buffers of the best-equipped one.  Which slice a lane gets changes from batch to batch; a
+// lane that had to grow a buffer in the middle of a batch would hipFree -- which waits for every kernel in flight, a
+// second or more while the long streams are being coded.  Called between batches (nothing in flight).
+int lanes_equalize(Device* const* lanes, size_t n)
+{
+    if (n < 2) return 0;
+    size_t mIn = 0, mScratch = 0, mItems = 0, mOrder = 0, mSizes = 0, mRestarts = 0, mPlans = 0, mBlocks = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const Device* d = lanes[i];
+        mIn = std::max(mIn, d->capIn); mScratch = std::max(mScratch, d->capScratch); mItems = std::max(mItems, d->capItems); mOrder = std::max(mOrder, d->capOrder);
+        mSizes = std::max(mSizes, d->capSizes); mRestarts = std::max(mRestarts, d->capRestarts); mPlans = std::max(mPlans, d->capPlans); mBlocks = std::max(mBlocks, d->capBlocks);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        Device* dev = lanes[i];
+        HIP_TRY(hipSetDevice(dev->deviceId));
+        auto grow = [&](auto*& p, size_t& cap, size_t want) -> int {
+            if (cap >= want && p) return 0;
+            if (p) (void)hipFree(p);
+            p = nullptr; cap = 0;
+            HIP_TRY(hipMalloc((void**)&p, want));
+            cap = want; return 0;
+        };
+        if (grow(dev->dIn, dev->capIn, mIn) || grow(dev->dScratch, dev->capScratch, mScratch) || grow(dev->dItems, dev->capItems, mItems) || grow(dev->dOrder, dev->capOrder, mOrder) ||
+            grow(dev->dSizes, dev->capSizes, mSizes) || grow(dev->dRestarts, dev->capRestarts, mRestarts) || grow(dev->dPlans, dev->capPlans, mPlans) || grow(dev->dBlocks, dev->capBlocks, mBlocks)) return -1;
+    }
+    return 0;
+}
+
 int gather_quality_raw(Device* dev, const uint8_t* input, size_t inputBytes, const GatherPlan& plan, std::vector<uint8_t>& out, BatchTiming* timing)
 {
     HIP_TRY(hipSetDevice(dev->deviceId));

@@ -560,7 +560,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     std::vector<std::unique_ptr<BinEncoder>>& encs = encoders;        // kept across calls: their work buffers stay mapped
     if (encs.size() < hostThreads) encs.resize(hostThreads);
     if (matchLanes.size() < hostThreads) matchLanes.resize(hostThreads, nullptr);
-    uint32_t matcherBins = deviceMatcher ? 3u * hostThreads : 0u;
+    uint32_t matcherBins = deviceMatcher ? 6u * hostThreads : 0u;      // measured on the BASELINE library: 72 bins 1841, 144 bins 1923, 250+ bins below 1750 MB/s (the searches start to wait for registers)
     if (const char* mb = getenv("FS_MATCHER_BINS")) matcherBins = (uint32_t)std::max(0, atoi(mb));
     if (deviceMatcher && matchReserve.reads && matcherBins) {
         // every host thread's matcher lane gets room for the largest bin now, while no coder kernel is in flight
@@ -600,6 +600,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     if (nSlices > 1) {   // any lane may get the largest slice of the next batch: size their pinned staging buffers alike, once
         uint64_t mx = 0; for (Slice& S : slices) mx = std::max(mx, S.inBytes);
         for (uint32_t l = 0; l < nLanes; ++l) (void)fsengine::staging_buffer(lanes[l], mx + 16);
+        if (fsengine::lanes_equalize(lanes.data(), nLanes) != 0) throw std::runtime_error(std::string("device: ") + lanes[0]->err);
     }
     stats.frontend_ms += feMs;
     for (uint32_t si = 0; si < nSlices; ++si) {

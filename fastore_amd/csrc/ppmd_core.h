@@ -88,6 +88,7 @@ struct Coder {
     fs_gptr out; uint32_t outCap, outPos;
     uint32_t queued, qTail, qHeadSeen;   // queued != 0: every coding step goes to the coder wave through sh->qA/qM (this wave never reads low/range)
     uint32_t pfCtx; CtxRaw pf;     // record of the next symbol's first context, requested ahead of this symbol's stores (0 = none)
+    uint32_t inAhead;              // windowed path: the input has been pulled into the cache up to here
 };
 
 #define HP(ix) (m.hb + (ix))
@@ -964,6 +965,7 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
     Coder m;
     m.hb = arena - 1; m.sh = sh; m.out = out; m.outCap = outCap; m.outPos = 0; sh->restarts = 0;
     m.queued = queued ? 1u : 0u; m.qTail = qTail; m.qHeadSeen = qTail;
+    m.inAhead = 0;
     m.NumMasked = 0; m.FoundState = 0; m.BSumm = 0; m.rLow = m.rHigh = m.rScale = 0; m.fsSym = m.fsFreq = m.fsSucc = 0;
     for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) sh->winStats[i] = 0u;
     for (uint32_t i = (uint32_t)FS_LANE(); i < 260u; i += FS_WAVE) sh->QT[i] = (uint8_t)QTable(i);

@@ -231,6 +231,17 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
         const bool owner = inWin && ownerLane == lane;
         uint32_t rlo = owner ? m.sh->winMask[2u * lane] : 0u, rhi = owner ? m.sh->winMask[2u * lane + 1u] : 0u;      // positions still to do
         FS_PROF_ACC(m.sh->winStats[10], tp);                           // context sets
+        // Input read-ahead.  The stream is read once, so every new cache line of it is a trip to HBM (~900 clocks against
+        // ~200 for an L2 hit) -- paid by the first loads of a window and by the serial path's byte fetches.  A kilobyte
+        // ahead of the window, sixteen lines at a time, is requested HERE: the rounds that follow use no global memory,
+        // so the trip is over before the next load of this wave has to wait for it (loads complete in issue order).
+        uint32_t ahead = 0;
+        const bool pull = FS_UNI((uint32_t)(pos + 1024u >= m.inAhead));
+        if (pull) {
+            const uint32_t want = pos + 1024u + 16u * lane, last = (n - 4u) & ~3u;
+            ahead = *(fs_cgptr32)(in + (want < last ? want & ~3u : last));
+            m.inAhead = pos + 2048u;
+        }
         uint32_t rounds = 0;
         // Light rounds.  Until a context needs a swap or a rescale its states stay where they were fetched: a position's
         // place is the one it found for itself (k), so a round is a fetch of that place from the position's lane, two byte
@@ -310,6 +321,7 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
             rlo = cut ? 0u : rlo; rhi = cut ? 0u : rhi;
         }
         if (fs_ballot(myCut < 64u) != 0ull) FS_LDS_MIN(m.sh->winCut, myCut);
+        FS_KEEP(ahead);
         FS_WAVE_SYNC();
         FS_STAT_ADD(m.sh->winStats[3], rounds);
         FS_PROF_ACC(m.sh->winStats[11], tp);                           // rounds

@@ -119,6 +119,12 @@ FS_DEV uint32_t fs_lds_rd(uint32_t v) { FS_EMU_MEET(); return FS_UNI(v); }
   #define FS_PROF_NOW() 0ull
   #define FS_PROF_ACC(w, t0) ((void)(t0))
 #endif
+// keep a loaded value alive up to this point without using it (input read-ahead of the windowed PPMd path)
+#if defined(__HIP_DEVICE_COMPILE__)
+  #define FS_KEEP(v) asm volatile("" :: "v"(v))
+#else
+  #define FS_KEEP(v) ((void)(v))
+#endif
 // minimum into a word of the wave's LDS state from the lanes that have something to report
 #if defined(__HIP_DEVICE_COMPILE__)
   #define FS_LDS_MIN(w, v) ((void)__hip_atomic_fetch_min(&(w), (uint32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))

@@ -22,6 +22,7 @@ int device_create(Device** out, int, uint32_t, char*, size_t)
 { Device* d = new Device(); memset(d, 0, sizeof *d); snprintf(d->name, sizeof d->name, "host-emulation"); d->nWaves = 1; *out = d; return 0; }
 int lane_create(Device*, Device** out, char* e, size_t n) { return device_create(out, 0, 0, e, n); }
 void device_destroy(Device* d) { if (d) free(d->hStage); delete d; }
+int lanes_equalize(Device* const*, size_t) { return 0; }
 int lane_debug(Device*, char* out, size_t outLen) { if (out && outLen) snprintf(out, outLen, "host emulation"); return 0; }
 
 uint8_t* staging_buffer(Device* d, size_t bytes)
