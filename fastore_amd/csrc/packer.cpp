@@ -191,6 +191,34 @@ void ArchiveWriter::writeBlock(const uint8_t* data, uint64_t size, uint32_t sign
     dataBytes_ += size;
 }
 
+void ArchiveWriter::writeBlocks(const std::vector<const uint8_t*>& data, const std::vector<uint64_t>& sizes, const std::vector<uint32_t>& signatures, uint32_t threads)
+{
+    const size_t n = data.size();
+    if (inMemory_ || n < 8 || threads < 2) { for (size_t i = 0; i < n; ++i) writeBlock(data[i], sizes[i], signatures[i]); return; }
+    if (fflush(data_) != 0) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
+    const off_t base = ftello(data_);
+    if (base < 0) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
+    std::vector<uint64_t> off(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) { off[i + 1] = off[i] + sizes[i]; sizes_.push_back(sizes[i]); sigs_.push_back(signatures[i]); sizeStats_.addBlock(data[i], sizes[i], signatures[i]); }
+    const int fd = fileno(data_);
+    // pieces of about equal bytes, one thread each
+    const uint32_t t = (uint32_t)std::min<size_t>(threads, n);
+    std::vector<size_t> cut(t + 1, n); cut[0] = 0;
+    for (uint32_t k = 1; k < t; ++k) { const uint64_t want = off[n] / t * k; cut[k] = (size_t)(std::lower_bound(off.begin(), off.end(), want) - off.begin()); if (cut[k] > n) cut[k] = n; }
+    parallelFor(t, t, [&](uint32_t k, uint32_t) {
+        for (size_t i = cut[k]; i < cut[k + 1]; ++i) {
+            uint64_t done = 0;
+            while (done < sizes[i]) {
+                const ssize_t w = pwrite(fd, data[i] + done, sizes[i] - done, base + (off_t)(off[i] + done));
+                if (w <= 0) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
+                done += (uint64_t)w;
+            }
+        }
+    });
+    if (fseeko(data_, base + (off_t)off[n], SEEK_SET) != 0) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
+    dataBytes_ += off[n];
+}
+
 // every write is checked: a full disk must end in "Error: Cannot write ..." (FSGPU_ERR_IO), not in a truncated archive
 void ArchiveWriter::writeMeta(const std::string& prefix, const std::vector<uint64_t>& sizes, const std::vector<uint32_t>& sigs, const HeaderStats& head, const QvzModel& qvz)
 {
@@ -867,7 +895,11 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                     }
                     for (auto& p : L.pending) { uint64_t off = 0; for (size_t k = 0; k < p.sizes.size(); ++k) { L.aw.writeBlock(p.data.data() + off, p.sizes[k], p.sigs[k]); off += p.sizes[k]; } }
                     L.pending.clear();
-                    for (size_t k = runOf[l].first; k < runOf[l].second; ++k) L.aw.writeBlock(blockData((uint32_t)k), blockSizes[k], binInfo[k].signature);
+                    {
+                        std::vector<const uint8_t*> ptrs; std::vector<uint64_t> szs; std::vector<uint32_t> sgs;
+                        for (size_t k = runOf[l].first; k < runOf[l].second; ++k) { ptrs.push_back(blockData((uint32_t)k)); szs.push_back(blockSizes[k]); sgs.push_back(binInfo[k].signature); }
+                        L.aw.writeBlocks(ptrs, szs, sgs, std::max(1u, hostThreads / (uint32_t)std::max<size_t>(1, nLibs)));
+                    }
                     L.aw.finish(archives[l].head, archives[l].qvz);
                     L.finished = true;
                 });

@@ -49,6 +49,9 @@ public:
     // .cmeta of an archive whose blocks (sizes, signatures in archive order) were written by several ranks
     void writeMeta(const std::string& prefix, const std::vector<uint64_t>& sizes, const std::vector<uint32_t>& sigs, const HeaderStats& head, const QvzModel& qvz);
     void writeBlock(const uint8_t* data, uint64_t size, uint32_t signature);
+    // the same for a run of blocks that follow each other in the archive: their places are known, so several threads put
+    // them there with positional writes (one buffered writer moves ~4 GB/s: 0.1 s of a 0.45 GB archive at the very end of a step)
+    void writeBlocks(const std::vector<const uint8_t*>& data, const std::vector<uint64_t>& sizes, const std::vector<uint32_t>& signatures, uint32_t threads);
     void finish(const HeaderStats& head, const QvzModel& qvz);
     uint64_t dataBytes() const { return dataBytes_; }
     void printStreamSizes(FILE* to) const { sizeStats_.print(to); }

@@ -243,38 +243,51 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
             m.inAhead = pos + 2048u;
         }
         uint32_t rounds = 0;
-        // Light rounds.  Until a context needs a swap or a rescale its states stay where they were fetched: a position's
-        // place is the one it found for itself (k), so a round is a fetch of that place from the position's lane, two byte
-        // extractions and a masked byte sum.  The first position of a context that would swap or cross MAX_FREQ is left,
-        // with the rest of that context's positions, to the full rounds below (which start from the list as it is now:
-        // only frequencies have changed).
+        // Closed form.  While a context neither swaps two states nor crosses MAX_FREQ, its states stay where they were
+        // fetched and every hit just adds 4 to one frequency and to the total -- so a position can price ITSELF from the
+        // list it fetched and three counts over the earlier positions of its context (all of them / those on its own
+        // state / those on states in front of it), taken from bit masks: the context's positions (its owner's mask) and
+        // the bit-sliced places of all 64 positions.  The first position of a context whose step would swap or rescale,
+        // and everything of that context behind it, is left to the rounds below; the owner accounts for what went
+        // before (frequencies and total) and keeps the rest of its mask.
+        uint32_t cfA = 0, cfM = 0; bool cfDone = false;
         {
-            // (branch-free inside a round: every lane computes, the lanes with nothing to do write to a spare slot -- a
-            // taken branch or an exec-mask change costs a lone wavefront as much as four or five vector instructions)
-            bool full = false;
-            for (;;) {
-                const bool act = !full && (rlo | rhi) != 0u;
-                if (fs_ballot(act) == 0ull) break;
-                ++rounds;
-                const uint32_t pLo = (uint32_t)__builtin_ctz(rlo | 0x80000000u), pHi = 32u + (uint32_t)__builtin_ctz(rhi | 0x80000000u);
-                const uint32_t p = !act ? lane : (rlo ? pLo : pHi);
-                const uint32_t kk = fs_bperm(k, p) & 7u, k8 = 8u * kk;
-                const uint32_t f = (uint32_t)(c.F >> k8) & 0xFFu, fPrev = kk ? (uint32_t)(c.F >> ((k8 - 8u) & 63u)) & 0xFFu : 0xFFFFu;
-                const uint32_t nf = f + 4u;
-                const bool ok = act && !(nf > fPrev || nf > (uint32_t)MAX_FREQ);
-                full = full || (act && !ok);
-                const uint32_t nlo = rlo & (rlo - 1u), nhi = rhi & (rhi - 1u);
-                rhi = (ok && rlo == 0u) ? nhi : rhi; rlo = ok ? nlo : rlo;     // (rlo & (rlo - 1) is 0 for rlo == 0)
-                const uint64_t below = c.F & ((1ull << k8) - 1ull);
-                const uint32_t loCnt = fs_sum_bytes((uint32_t)below) + fs_sum_bytes((uint32_t)(below >> 32));
-                const uint32_t at = ok ? p : 64u + lane;
-                m.sh->winA[at] = loCnt | (f << 16) | ((kk == 0u && 2u * f > summ) ? (1u << 23) : 0u);
-                m.sh->winM[at] = summ;
-                c.F += ok ? 4ull << k8 : 0ull;
-                summ += ok ? 4u : 0u;
+            const uint32_t smLo = m.sh->winMask[2u * ownerLane], smHi = m.sh->winMask[2u * ownerLane + 1u];
+            const uint64_t sm = inWin ? ((uint64_t)smHi << 32) | smLo : 0ull;
+            const uint64_t kb0 = fs_ballot(inWin && (k & 1u) != 0u), kb1 = fs_ballot(inWin && (k & 2u) != 0u), kb2 = fs_ballot(inWin && (k & 4u) != 0u);
+            const uint64_t earlier = sm & ((1ull << lane) - 1ull);
+            const uint32_t kq = k & 7u, kp = (kq - 1u) & 7u;
+            const uint64_t e0 = (kq & 1u) ? kb0 : ~kb0, e1 = (kq & 2u) ? kb1 : ~kb1, e2 = (kq & 4u) ? kb2 : ~kb2;
+            const uint64_t eqK = e0 & e1 & e2;
+            const uint64_t eqP = ((kp & 1u) ? kb0 : ~kb0) & ((kp & 2u) ? kb1 : ~kb1) & ((kp & 4u) ? kb2 : ~kb2);
+            const uint64_t ltK = ((kq & 4u) ? ~kb2 : 0ull) | (e2 & (((kq & 2u) ? ~kb1 : 0ull) | (e1 & ((kq & 1u) ? ~kb0 : 0ull))));
+            const uint32_t cAll = fs_popc64(earlier), cSame = fs_popc64(earlier & eqK), cPrev = fs_popc64(earlier & eqP), cBelow = fs_popc64(earlier & ltK);
+            const uint32_t k8 = 8u * kq;
+            const uint32_t f = ((uint32_t)(c.F >> k8) & 0xFFu) + 4u * cSame;
+            const uint32_t fPrev = kq ? ((uint32_t)(c.F >> ((k8 - 8u) & 63u)) & 0xFFu) + 4u * cPrev : 0xFFFFu;
+            const bool bad = inWin && (f + 4u > fPrev || f + 4u > (uint32_t)MAX_FREQ);
+            const uint64_t badSet = fs_ballot(bad) & sm;               // of my context
+            const uint32_t firstBad = badSet ? fs_ctz64(badSet) : 64u;
+            cfDone = inWin && lane < firstBad;
+            const uint64_t below = c.F & ((1ull << k8) - 1ull);
+            const uint32_t tot = summ + 4u * cAll;
+            cfA = (fs_sum_bytes((uint32_t)below) + fs_sum_bytes((uint32_t)(below >> 32)) + 4u * cBelow) | (f << 16) | ((kq == 0u && 2u * f > tot) ? (1u << 23) : 0u);
+            cfM = tot;
+            // the owner: what its context's finished positions added, and what is left for the rounds
+            const uint64_t doneSet = firstBad < 64u ? sm & ((1ull << firstBad) - 1ull) : sm;
+            if (owner) {
+                uint64_t add = 0;
+                #pragma unroll
+                for (uint32_t j = 0; j < 8u; ++j) {
+                    const uint64_t ej = ((j & 1u) ? kb0 : ~kb0) & ((j & 2u) ? kb1 : ~kb1) & ((j & 4u) ? kb2 : ~kb2);
+                    add |= (uint64_t)(4u * fs_popc64(doneSet & ej)) << (8u * j);      // no byte overflows: every frequency stays <= MAX_FREQ
+                }
+                c.F += add; summ += 4u * fs_popc64(doneSet);
+                const uint64_t rest = sm & ~doneSet;
+                rlo = (uint32_t)rest; rhi = (uint32_t)(rest >> 32);
             }
         }
-        FS_STAT_ADD(m.sh->winStats[5], rounds);
+        if (fs_ballot(inWin && !cfDone) == 0ull) FS_STAT_ADD(m.sh->winStats[5], 1u);     // a window without a single round
         // Full rounds: the contexts that swap or rescale (again without branches inside a round, except for the rare
         // rescale).  A lane that must hand a position to the serial path remembers it; the minimum is taken after the loop.
         uint32_t myCut = 64u;
@@ -360,7 +373,7 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
             for (int u = 0; u < 4; ++u) if ((uint32_t)u < units) { p[3 * u] = w[3 * u]; p[3 * u + 1] = w[3 * u + 1]; p[3 * u + 2] = w[3 * u + 2]; }
             *(fs_gptr32)HP(addr) = ns | (flags << 8) | (summ << 16);
         }
-        uint32_t tA = inWin ? m.sh->winA[lane] : 0u, tM = inWin ? m.sh->winM[lane] : 0u;
+        uint32_t tA = inWin ? (cfDone ? cfA : m.sh->winA[lane]) : 0u, tM = inWin ? (cfDone ? cfM : m.sh->winM[lane]) : 0u;
         FS_WAVE_SYNC();
         if (m.queued) {                                            // two-wave form: the slots go to the coder wave as they are
             cq_push_lanes(m, tA, tM, L);

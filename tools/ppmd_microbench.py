@@ -23,7 +23,7 @@ with fastore_amd.Packer(lib=_lib, device_id=0, max_waves=int(sys.argv[2]) if len
         print("copies %5d  len %d -> %d  kernel %.1f ms  per-symbol(one stream) %.2f us  aggregate %.1f Msym/s  wall %.2f s" % (
             copies, len(base), len(out[0]), st["encode_kernel_ms"], st["encode_kernel_ms"] * 1e3 / len(base), copies * len(base) / st["encode_kernel_ms"] / 1e3, dt), flush=True)
         w = max(1, st["ppmd_windows"])
-        print("   windows: %.1f %% of the symbols in %d windows (%.1f symbols, %.2f rounds per window of which %.2f light; %d attempts, %d redone)" % (
+        print("   windows: %.1f %% of the symbols in %d windows (%.1f symbols, %.2f rounds per window, %.2f of the windows without a round; %d attempts, %d redone)" % (
             100.0 * st["ppmd_window_symbols"] / max(1, st["ppmd_symbols"]), st["ppmd_windows"], st["ppmd_window_symbols"] / w, st["ppmd_window_rounds"] / w, st["ppmd_window_light_rounds"] / w,
             st["ppmd_window_attempts"], st["ppmd_windows_redone"]), flush=True)
         pr = p.window_profile()
