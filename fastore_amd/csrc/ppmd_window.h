@@ -85,12 +85,14 @@ FS_DEV uint32_t packed_find(const Packed& c, uint32_t ns, uint32_t sym)
 // frequencies halved, stable insertion sort by the halved frequencies -- a 19-step min/max network on one word per
 // state --, SummFreq rebuilt, the found state's bonus.  Returns false and changes nothing when a state would drop out
 // (frequency 1 -> 0): that path frees units (ShrinkUnits / FreeUnits) and stays with the serial code.
-FS_DEV bool packed_rescale(Packed& c, uint32_t ns, uint32_t kf, uint32_t& summ, uint32_t& flags)
+// N = 4: every context that rescales has at most four states (the caller checks, wave-wide): a five-step network and half
+// the packing -- the usual case on quality data, where a context rarely has more successors than that
+template <int N> FS_DEV bool packed_rescale(Packed& c, uint32_t ns, uint32_t kf, uint32_t& summ, uint32_t& flags)
 {
-    uint32_t key[8];
+    uint32_t key[N];
     uint32_t sumOld = 0, sumNew = 0, f0 = 0; bool zeros = false, hiAny = false;
     #pragma unroll
-    for (uint32_t j = 0; j < 8u; ++j) {
+    for (uint32_t j = 0; j < (uint32_t)N; ++j) {
         const uint32_t f = (uint32_t)(c.F >> (8u * j)) & 0xFFu, sy = (uint32_t)(c.S >> (8u * j)) & 0xFFu, pj = (c.P >> (4u * j)) & 0xFu, nf = f >> 1;
         const bool valid = j <= ns, isF = j == kf;
         const uint32_t r = isF ? 0u : (j < kf ? j + 1u : j);                 // place after the move-to-front
@@ -103,13 +105,17 @@ FS_DEV bool packed_rescale(Packed& c, uint32_t ns, uint32_t kf, uint32_t& summ, 
     }
     if (zeros) return false;
     #define FS_CE(a, b) do { const uint32_t hi_ = fs_umax(key[a], key[b]), lo_ = fs_umin(key[a], key[b]); key[a] = hi_; key[b] = lo_; } while (0)
-    FS_CE(0, 1); FS_CE(2, 3); FS_CE(4, 5); FS_CE(6, 7);
-    FS_CE(0, 2); FS_CE(1, 3); FS_CE(4, 6); FS_CE(5, 7);
-    FS_CE(1, 2); FS_CE(5, 6); FS_CE(0, 4); FS_CE(3, 7);
-    FS_CE(1, 5); FS_CE(2, 6);
-    FS_CE(1, 4); FS_CE(3, 6);
-    FS_CE(2, 4); FS_CE(3, 5);
-    FS_CE(3, 4);
+    if (N == 8) {
+        FS_CE(0, 1); FS_CE(2, 3); FS_CE(4 % N, 5 % N); FS_CE(6 % N, 7 % N);
+        FS_CE(0, 2); FS_CE(1, 3); FS_CE(4 % N, 6 % N); FS_CE(5 % N, 7 % N);
+        FS_CE(1, 2); FS_CE(5 % N, 6 % N); FS_CE(0, 4 % N); FS_CE(3, 7 % N);
+        FS_CE(1, 5 % N); FS_CE(2, 6 % N);
+        FS_CE(1, 4 % N); FS_CE(3, 6 % N);
+        FS_CE(2, 4 % N); FS_CE(3, 5 % N);
+        FS_CE(3, 4 % N);
+    } else {
+        FS_CE(0, 1); FS_CE(2, 3); FS_CE(0, 2); FS_CE(1, 3); FS_CE(1, 2);
+    }
     #undef FS_CE
     const uint32_t escFreq = summ - sumOld, nf0 = f0 >> 1;
     uint32_t s = sumNew + ((escFreq + 1u) >> 1), a;
@@ -122,7 +128,7 @@ FS_DEV bool packed_rescale(Packed& c, uint32_t ns, uint32_t kf, uint32_t& summ, 
     } else a = 2u;
     uint64_t S = 0, F = 0; uint32_t P = 0;
     #pragma unroll
-    for (uint32_t j = 0; j < 8u; ++j) {
+    for (uint32_t j = 0; j < (uint32_t)N; ++j) {
         S |= (uint64_t)((key[j] >> 4) & 0xFFu) << (8u * j);
         F |= (uint64_t)(j == 0u ? nf0 + a : ((key[j] >> 12) & 0xFFu)) << (8u * j);
         P |= (key[j] & 0xFu) << (4u * j);
@@ -326,7 +332,8 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
             bool cut = lost;
             if (fs_ballot(resc) != 0ull) {
                 Packed c2 = c; uint32_t summ2 = summ, flags2 = flags;
-                const bool done = packed_rescale(c2, ns, doSwap ? kk - 1u : kk, summ2, flags2);
+                const bool done = fs_ballot(resc && ns > 3u) == 0ull ? packed_rescale<4>(c2, ns, doSwap ? kk - 1u : kk, summ2, flags2)
+                                                                      : packed_rescale<8>(c2, ns, doSwap ? kk - 1u : kk, summ2, flags2);
                 if (resc && done) { c = c2; summ = summ2; flags = flags2; }
                 if (resc && !done) cut = true;                     // a state drops out: the serial path takes this symbol
             }
