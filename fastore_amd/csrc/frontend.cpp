@@ -3,6 +3,8 @@
 #include <emmintrin.h>
 #endif
 #include <string.h>
+#include <time.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <map>
 #include <stdexcept>
@@ -1152,6 +1154,9 @@ struct BinEncoder::Impl {
 
     void encodeLz(const Batch& batch, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, BinStreams& o)
     {
+        const bool stageTrace = getenv("FS_BIN_TRACE") && bin.recCount >= 40000;      // stage clock of the heaviest bins (design studies)
+        auto clk = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; };
+        const double t0 = stageTrace ? clk() : 0; double t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         setArchive(arch);
         B = &batch; G = &graph; out = &o; curSig = bin.signature;
         o.reset(pe ? S_PE_COUNT : S_SE_COUNT);
@@ -1166,6 +1171,7 @@ struct BinEncoder::Impl {
         for (uint32_t k = 0; k < bin.topCount; ++k) order[k] = (int32_t)(G->topNodes[bin.topBegin + k] - nodeBase);
         introsort(order.data(), order.size(), [&](int32_t a, int32_t b) { return compareReads(nodes[a].vrec, nodes[b].vrec); });
         std::vector<int32_t> roots;
+        if (stageTrace) t1 = clk();
         // the window searches of all the bin's constructions, on the device (matcher.hip); a row that names a dummy slot
         // (reads of mostly 'N', manual thresholds) sends the whole bin through the host scan, which keeps the
         // reference's handling of that corner
@@ -1180,7 +1186,9 @@ struct BinEncoder::Impl {
                 for (const fsdev::MatchCall& c : mCalls) for (uint32_t i = 0; i < c.count && havePre; ++i) if (mRows[c.first + i].dummy) havePre = false;
             }
         }
+        if (stageTrace) t2 = clk();
         constructMatchTree(order, roots, -1, wantTable ? 0 : -1);
+        if (stageTrace) t3 = clk();
 #ifdef FS_DEBUG_DUMP
         if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == bin.signature) {
             auto H = [&](int32_t n) { if (n < 0) return std::string("-"); const Rec& r = R(nodes[n].vrec); return std::string((const char*)B->head.data() + r.headOff, r.headLen); };
@@ -1198,6 +1206,7 @@ struct BinEncoder::Impl {
         }
         matchRle.end(); consMatchRle.end(); lzRle0.end();
         if (pe) matchRlePE.end();
+        if (stageTrace) { t4 = clk(); fprintf(stderr, "[bin] %u records: nodes + sort %.1f ms, match table + device search %.1f ms (pre %d), top-level tree %.1f ms, contigs + sub-trees + emission %.1f ms\n", bin.recCount, t1 - t0, t2 - t1, (int)havePre, t3 - t2, t4 - t3); }
     }
 };
 

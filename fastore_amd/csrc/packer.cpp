@@ -856,7 +856,9 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             };
             compressBins(nb, weight, binArch, [&](uint32_t k, BinEncoder& enc, BinStreams& out, BinIn& info, uint64_t& recBytes) {
                 const Work& w = work[first + k];
+                const double tu = getenv("FS_BIN_TRACE") ? nowMs() : 0;
                 libs[w.lib]->bf.unpackPlaced(w.sig, batch, seqBase[k], headBase[k], (uint32_t)recBase[k], graph[k], packedQ ? (int64_t)quaBase[k] : -1);
+                if (tu > 0 && recBase[k + 1] - recBase[k] >= 40000) fprintf(stderr, "[bin] %llu records: unpack %.1f ms\n", (unsigned long long)(recBase[k + 1] - recBase[k]), nowMs() - tu);
                 info = graph[k].bins.at(0);
                 enc.encodeLz(batch, graph[k], info, archives[w.lib], out);
                 if (packedQ) { out.quaPacked = batch.quaPacked.data() + quaBase[k]; out.quaPackedBytes = libs[w.lib]->bf.bins().at(w.sig).totalQuaSize; }

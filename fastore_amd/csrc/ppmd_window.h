@@ -211,7 +211,7 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
         // slot, the lowest lane that wrote to it; a lane whose slot was won by a lane with ANOTHER context (a collision)
         // is resolved by the loop below, one step per distinct context among the colliding lanes -- rare.  Then every
         // position sets its bit in its owner's mask.
-        const bool inWin = lane < L;
+        bool inWin = lane < L;
         uint32_t ownerLane = lane;
         {
             #pragma unroll
@@ -234,8 +234,8 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
             if (inWin) FS_LDS_OR(m.sh->winMask[2u * ownerLane + (lane >> 5)], 1u << (lane & 31u));
             FS_WAVE_SYNC();
         }
-        const bool owner = inWin && ownerLane == lane;
-        uint32_t rlo = owner ? m.sh->winMask[2u * lane] : 0u, rhi = owner ? m.sh->winMask[2u * lane + 1u] : 0u;      // positions still to do
+        bool owner = inWin && ownerLane == lane;
+        uint32_t rlo = 0u, rhi = 0u;                                   // an owner's positions still to do
         FS_PROF_ACC(m.sh->winStats[10], tp);                           // context sets
         // Input read-ahead.  The stream is read once, so every new cache line of it is a trip to HBM (~900 clocks against
         // ~200 for an L2 hit) -- paid by the first loads of a window and by the serial path's byte fetches.  A kilobyte
@@ -257,6 +257,7 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
         // and everything of that context behind it, is left to the rounds below; the owner accounts for what went
         // before (frequencies and total) and keeps the rest of its mask.
         uint32_t cfA = 0, cfM = 0; bool cfDone = false;
+        uint64_t cfSm = 0, cfKb0 = 0, cfKb1 = 0, cfKb2 = 0; uint32_t cfFirstBad = 64u;
         {
             const uint32_t smLo = m.sh->winMask[2u * ownerLane], smHi = m.sh->winMask[2u * ownerLane + 1u];
             const uint64_t sm = inWin ? ((uint64_t)smHi << 32) | smLo : 0ull;
@@ -279,21 +280,34 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
             const uint32_t tot = summ + 4u * cAll;
             cfA = (fs_sum_bytes((uint32_t)below) + fs_sum_bytes((uint32_t)(below >> 32)) + 4u * cBelow) | (f << 16) | ((kq == 0u && 2u * f > tot) ? (1u << 23) : 0u);
             cfM = tot;
-            // the owner: what its context's finished positions added, and what is left for the rounds
-            const uint64_t doneSet = firstBad < 64u ? sm & ((1ull << firstBad) - 1ull) : sm;
+            cfSm = sm; cfFirstBad = firstBad; cfKb0 = kb0; cfKb1 = kb1; cfKb2 = kb2;
+        }
+        if (fs_ballot(inWin && !cfDone) == 0ull) FS_STAT_ADD(m.sh->winStats[5], 1u);     // a window without a single round
+        // The owners' part, and the rounds.  When a round finds that a position must go to the serial path (a rescale that
+        // drops a state), the window ends in front of it -- and only THIS part is done again for the shorter window: the
+        // lists, the chain, the context sets and the closed-form prices of the positions that stay do not depend on
+        // the positions that go.
+        const Packed c0 = c; const uint32_t summ0 = summ, flags0 = flags;
+        for (;;) {
+        inWin = lane < L; owner = inWin && ownerLane == lane;
+        c = c0; summ = summ0; flags = flags0; rlo = rhi = 0u; rounds = 0;
+        {   // the owner: what its context's finished positions added, and what is left for the rounds
+            const uint64_t lim = L >= 64u ? ~0ull : (1ull << L) - 1ull;
+            const uint64_t doneSet = (cfFirstBad < 64u ? cfSm & ((1ull << cfFirstBad) - 1ull) : cfSm) & lim;
             if (owner) {
                 uint64_t add = 0;
                 #pragma unroll
                 for (uint32_t j = 0; j < 8u; ++j) {
-                    const uint64_t ej = ((j & 1u) ? kb0 : ~kb0) & ((j & 2u) ? kb1 : ~kb1) & ((j & 4u) ? kb2 : ~kb2);
+                    const uint64_t ej = ((j & 1u) ? cfKb0 : ~cfKb0) & ((j & 2u) ? cfKb1 : ~cfKb1) & ((j & 4u) ? cfKb2 : ~cfKb2);
                     add |= (uint64_t)(4u * fs_popc64(doneSet & ej)) << (8u * j);      // no byte overflows: every frequency stays <= MAX_FREQ
                 }
                 c.F += add; summ += 4u * fs_popc64(doneSet);
-                const uint64_t rest = sm & ~doneSet;
+                const uint64_t rest = cfSm & lim & ~doneSet;
                 rlo = (uint32_t)rest; rhi = (uint32_t)(rest >> 32);
             }
+            if (lane == 0u) m.sh->winCut = 64u;
+            FS_WAVE_SYNC();
         }
-        if (fs_ballot(inWin && !cfDone) == 0ull) FS_STAT_ADD(m.sh->winStats[5], 1u);     // a window without a single round
         // Full rounds: the contexts that swap or rescale (again without branches inside a round, except for the rare
         // rescale).  A lane that must hand a position to the serial path remembers it; the minimum is taken after the loop.
         uint32_t myCut = 64u;
@@ -346,11 +360,13 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
         FS_STAT_ADD(m.sh->winStats[3], rounds);
         FS_PROF_ACC(m.sh->winStats[11], tp);                           // rounds
         const uint32_t cutAt = FS_LDS_RD(m.sh->winCut);
-        if (cutAt < L) {                                              // nothing has been stored yet: shorten the window and redo it
+        if (cutAt < L) {                                              // nothing has been stored yet: shorten the window and do the owners' part again
             FS_STAT_ADD(m.sh->winStats[4], 1u);
             L = cutAt;                                                // every redo is strictly shorter
             if (L == 0u) { uint64_t te = tEnter; FS_PROF_ACC(m.sh->winStats[14], te); return 0u; }
             continue;
+        }
+        break;
         }
 
         // commit: every owner writes its context's list and record word back.  The successors go through the lane's
