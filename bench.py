@@ -150,9 +150,17 @@ def main():
     threads = max(2, cores // world) if world > 1 else 0
     packer = fastore_amd.Packer(device_id=local if world > 1 else 0, lib=lib, host_threads=threads,
                                 rank=rank if sharded else 0, world_size=world if sharded else 1)
-    out = os.path.join(args.work, "out" if sharded else "out_r%d" % rank)
+    out_base = os.path.join(args.work, "out" if sharded else "out_r%d" % rank)
+    out = out_base
+
+    # every step writes a NEW archive, as every run of fastore_pack does (overwriting the previous step's 0.45 GB file makes
+    # the open wait for its write-back: ~50 ms per step that no real run pays); the extra archives are removed after the timing
+    made = []
 
     def step():
+        nonlocal out
+        out = out_base + "_%d" % len(made)
+        made.append(out)
         if sharded:
             shard.pack_sharded(packer, binned, out, dist, device=torch.device("cuda", local))
         else:
@@ -172,6 +180,11 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     st = packer.stats()
+    if rank == 0 or not sharded:
+        for o in made[:-1]:
+            for e in (".cdata", ".cmeta"):
+                if os.path.exists(o + e):
+                    os.remove(o + e)
     if world > 1:
         t = torch.tensor([dt], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
         keys = ["algorithmic_bytes", "ppmd_symbols", "host_coded_symbols", "kernel_launches", "encode_kernel_ms", "cdata_bytes", "bins", "records"]

@@ -13,6 +13,8 @@
 #include <thread>
 #include <fcntl.h>
 #include <unistd.h>
+#include <sys/mman.h>
+#include <fcntl.h>
 #include "bitio.h"
 #include "hostcoders.h"
 
@@ -205,6 +207,24 @@ void ArchiveWriter::writeBlocks(const std::vector<const uint8_t*>& data, const s
     const uint32_t t = (uint32_t)std::min<size_t>(threads, n);
     std::vector<size_t> cut(t + 1, n); cut[0] = 0;
     for (uint32_t k = 1; k < t; ++k) { const uint64_t want = off[n] / t * k; cut[k] = (size_t)(std::lower_bound(off.begin(), off.end(), want) - off.begin()); if (cut[k] > n) cut[k] = n; }
+    // Through a shared mapping of the file's new extent when the file system allows it: write() calls on ONE file take
+    // its lock in turn (~4 GB/s whatever the thread count), page-cache pages of a mapping are filled side by side.
+    {
+        const long pg = sysconf(_SC_PAGESIZE);
+        const off_t mapFrom = base - (base % pg); const size_t mapLen = (size_t)(base - mapFrom) + off[n];
+        // (the extent is reserved first: a full disk then ends in an error here, not in a bus error inside the mapping)
+        if (off[n] > 0 && fallocate(fd, 0, base, (off_t)off[n]) == 0) {
+            void* mp = mmap(nullptr, mapLen, PROT_READ | PROT_WRITE, MAP_SHARED, fd, mapFrom);
+            if (mp != MAP_FAILED) {
+                uint8_t* dst = (uint8_t*)mp + (base - mapFrom);
+                parallelFor(t, t, [&](uint32_t k, uint32_t) { for (size_t i = cut[k]; i < cut[k + 1]; ++i) memcpy(dst + off[i], data[i], sizes[i]); });
+                if (munmap(mp, mapLen) != 0) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
+                if (fseeko(data_, base + (off_t)off[n], SEEK_SET) != 0) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
+                dataBytes_ += off[n];
+                return;
+            }
+        }
+    }
     parallelFor(t, t, [&](uint32_t k, uint32_t) {
         for (size_t i = cut[k]; i < cut[k + 1]; ++i) {
             uint64_t done = 0;
