@@ -38,7 +38,7 @@ class Stats(C.Structure):
                 ("ppmd_window_attempts", C.c_uint64), ("ppmd_windows", C.c_uint64), ("ppmd_window_symbols", C.c_uint64),
                 ("ppmd_window_rounds", C.c_uint64), ("ppmd_windows_redone", C.c_uint64), ("ppmd_window_light_rounds", C.c_uint64),
                 ("gather_kernel_ms", C.c_double), ("gather_symbols", C.c_uint64), ("gather_bytes", C.c_uint64),
-                ("matcher_reads", C.c_uint64), ("matcher_call_ms", C.c_double), ("matcher_kernel_ms", C.c_double)]
+                ("matcher_reads", C.c_uint64), ("matcher_call_ms", C.c_double), ("matcher_kernel_ms", C.c_double), ("tokenised_ids", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -90,6 +90,8 @@ def load_library(path=None):
     lib.fsgpu_set_archive_params.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
     pp = C.POINTER(C.c_char_p)
     lib.fsgpu_ppmd_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fsgpu_gather_quality_binned.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.fsgpu_tokeniser_check.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.fsgpu_matcher_check.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.fsgpu_gather_quality.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fsgpu_rc_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -305,6 +307,27 @@ class Packer:
         out = C.create_string_buffer(total + 16); got = C.c_size_t(0)
         self._check(self.lib.fsgpu_gather_quality(self.ctx, packed, len(packed), desc.ctypes.data, len(strings), out, total + 16, C.byref(got)))
         return out.raw[:got.value]
+
+    def gather_quality_binned(self, packed, bits, binary_threshold, strings):
+        """(symbol, context) pairs of an 8-bin (bits=3) / binary (bits=1) quality stream built by fs_gather_quality_pairs (device):
+        strings = [(bit offset, length, back to front?, bytes of 'N' positions)] in emission order."""
+        import numpy as np
+        class S(C.Structure):
+            _fields_ = [("src_bit", C.c_uint64), ("len", C.c_uint32), ("reverse", C.c_uint32), ("n_positions", C.c_void_p), ("n_count", C.c_uint32)]
+        arr = (S * len(strings))(); keep = []
+        total = 0
+        for i, (b, n, r, npos) in enumerate(strings):
+            buf = C.create_string_buffer(bytes(npos), max(1, len(npos))); keep.append(buf)
+            arr[i] = S(b, n, 1 if r else 0, C.cast(buf, C.c_void_p) if len(npos) else None, len(npos)); total += n - len(npos)
+        out = C.create_string_buffer(2 * total + 16); got = C.c_size_t(0)
+        self._check(self.lib.fsgpu_gather_quality_binned(self.ctx, packed, len(packed), bits, binary_threshold, arr, len(strings), out, total, C.byref(got)))
+        return out.raw[:2 * got.value]
+
+    def tokeniser_check(self, in_prefix):
+        """(read ids tokenised, bins whose IdToken / IdValue streams differ between the device tokeniser and the host's) over a library."""
+        r = C.c_uint64(0); d = C.c_uint64(0)
+        self._check(self.lib.fsgpu_tokeniser_check(self.ctx, in_prefix.encode(), C.byref(r), C.byref(d)))
+        return r.value, d.value
 
     def matcher_check(self, in_prefix):
         """(reads searched, rows on which the device matcher and the host's window scan disagree) over the standard bins of a library."""

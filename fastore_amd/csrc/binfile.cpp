@@ -48,10 +48,10 @@ struct Unpacker {
     uint32_t dna4[256];      // byte of packed bases -> four characters
 
     // packedQ: the qualities stay packed (Batch::quaPacked / quaBit): readQuality only notes where a string starts
-    bool packedQ = false; uint64_t quaStart = 0;
+    bool packedQ = false; uint64_t quaStart = 0; uint32_t quaBits = 6;      // bits per stored score: 6 (lossless), 3 (8-bin), 1 (binary)
     Unpacker(const BinModuleConfigRaw& c, Batch& batch, Batch& graph, const std::vector<uint8_t>& m, uint64_t ms, const std::vector<uint8_t>& d, uint64_t ds,
-             const uint8_t* q, uint64_t qs, const std::vector<uint8_t>& h, uint64_t hs)
-        : cfg(c), b(batch), g(graph), meta(m.data(), ms), dna(d.data(), ds), qua(q, qs), head(h.data(), hs), pe(c.archiveType.readType == READ_PE)
+             const uint8_t* q, uint64_t qs, const uint8_t* h, uint64_t hs)
+        : cfg(c), b(batch), g(graph), meta(m.data(), ms), dna(d.data(), ds), qua(q, qs), head(h, hs), pe(c.archiveType.readType == READ_PE)
     {
         pairSettings.minLen = pairSettings.maxLen = 1; pairSettings.hasConstLen = true; pairSettings.usesHeaders = false;
         const char* o = c.minimizer.dnaSymbolOrder;
@@ -83,7 +83,7 @@ struct Unpacker {
     }
     void readQuality(uint64_t at, uint32_t n)
     {
-        if (packedQ) { quaStart = qua.bitPosition(); qua.skipBits(6ull * n); return; }
+        if (packedQ) { quaStart = qua.bitPosition(); qua.skipBits((uint64_t)quaBits * n); return; }
         uint8_t* q = b.qua.data() + at;
         const uint32_t off = cfg.archiveType.qualityOffset;
         switch (cfg.quaParams.method) {
@@ -92,9 +92,17 @@ struct Unpacker {
         default: qua.unpack6(q, n, off); break;
         }
     }
+    bool packedH = false;      // the read ids stay packed (Batch::headPacked / headBit): readHeader only notes where the characters start
     void readHeader(Rec& r)
     {
         r.headLen = (uint8_t)head.getBits(8);
+        if (packedH) {
+            const uint64_t at = head.bitPosition();
+            if (at > 0xFFFFFFFFull) throw std::runtime_error("bin with more than 512 MiB of packed read ids");
+            b.headBit[(size_t)(&r - b.recs.data())] = (uint32_t)at; r.headOff = 0;
+            if (r.headLen > 1) head.skipBits(7ull * (r.headLen - 1u));
+            return;
+        }
         if (placed) { if (headCur + r.headLen > headEnd) throw std::runtime_error("bin footer understates the header bytes"); r.headOff = (uint32_t)headCur; headCur += r.headLen; }
         else { r.headOff = (uint32_t)b.head.size(); b.head.resize(b.head.size() + r.headLen); }
         uint8_t* h = b.head.data() + r.headOff;
@@ -128,7 +136,7 @@ struct Unpacker {
         const size_t idx = (size_t)(&r - b.recs.data());
         if (quaStart > 0xFFFFFFFFull) throw std::runtime_error("bin with more than 512 MiB of packed qualities");
         if (!isMate2) b.quaBit[idx] = (uint32_t)quaStart;
-        else if (quaStart != (uint64_t)b.quaBit[idx] + 6ull * r.seqLen) throw std::runtime_error("Corrupted bin: mate qualities are not adjacent");
+        else if (quaStart != (uint64_t)b.quaBit[idx] + (uint64_t)quaBits * r.seqLen) throw std::runtime_error("Corrupted bin: mate qualities are not adjacent");
         (void)len;
     }
     uint32_t allocSeq(uint32_t n)
@@ -349,11 +357,11 @@ void BinFile::readFooter(const std::vector<uint8_t>& buf)
     }
 }
 
-void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin) const { unpackImpl(signature, batch, batch, asNewBin, false, 0, 0, 0, -1); }
-void BinFile::unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, uint64_t headBase, uint32_t recBase, Batch& graph, int64_t quaBase) const
-{ unpackImpl(signature, data, graph, true, true, seqBase, headBase, recBase, quaBase); }
+void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin) const { unpackImpl(signature, batch, batch, asNewBin, false, 0, 0, 0, -1, -1); }
+void BinFile::unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, uint64_t headBase, uint32_t recBase, Batch& graph, int64_t quaBase, int64_t headPackedBase) const
+{ unpackImpl(signature, data, graph, true, true, seqBase, headBase, recBase, quaBase, headPackedBase); }
 
-void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase, int64_t quaBase) const
+void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase, int64_t quaBase, int64_t headPackedBase) const
 {
     // gather buffers of the calling thread, kept across bins: fresh vectors of this size are mmap'ed by malloc, and the
     // map/unmap/first-touch churn of thousands of them per second serialises the host threads in the kernel
@@ -366,17 +374,21 @@ void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asN
     if (bDna_.size() < bi.totalDnaSize) bDna_.resize(bi.totalDnaSize);
     const bool packedQ = quaBase >= 0;
     if (packedQ) {
-        if (!placed || cfg_.quaParams.method != MET_NONE) throw std::runtime_error("packed qualities: placed unpack of a lossless archive only");
+        if (!placed || cfg_.quaParams.method == MET_QVZ) throw std::runtime_error("packed qualities: placed unpack of a lossless, 8-bin or binary archive only");
         if ((uint64_t)quaBase + bi.totalQuaSize > data.quaPacked.size() || data.quaBit.size() != data.recs.size()) throw std::runtime_error("packed qualities: batch arrays not sized");
     } else if (bQua_.size() < bi.totalQuaSize) bQua_.resize(bi.totalQuaSize);
     uint8_t* const quaDst = packedQ ? data.quaPacked.data() + quaBase : bQua_.data();
-    if (usesHeaderStream_ && bHead_.size() < bi.totalHeadSize) bHead_.resize(bi.totalHeadSize);
+    const bool packedH = headPackedBase >= 0 && usesHeaderStream_;
+    if (packedH) {
+        if (!placed || (uint64_t)headPackedBase + bi.totalHeadSize > data.headPacked.size() || data.headBit.size() != data.recs.size()) throw std::runtime_error("packed read ids: batch arrays not sized");
+    } else if (usesHeaderStream_ && bHead_.size() < bi.totalHeadSize) bHead_.resize(bi.totalHeadSize);
+    uint8_t* const headDst = packedH ? data.headPacked.data() + headPackedBase : bHead_.data();
     uint64_t mo = 0, dO = 0, qo = 0, ho = 0, rawDna = 0, records = 0;
     for (const BlockMetaDataRaw& blk : bi.blocks) {
         copyAt(meta_, blk.metaFileOffset, bMeta_.data() + mo, blk.metaSize, ".bmeta"); mo += blk.metaSize;
         copyAt(dna_, blk.dnaFileOffset, bDna_.data() + dO, blk.dnaSize, ".bdna"); dO += blk.dnaSize;
         copyAt(qua_, blk.quaFileOffset, quaDst + qo, blk.quaSize, ".bqua"); qo += blk.quaSize;
-        if (usesHeaderStream_) { copyAt(headf_, blk.headFileOffset, bHead_.data() + ho, blk.headSize, ".bhead"); ho += blk.headSize; }
+        if (usesHeaderStream_) { copyAt(headf_, blk.headFileOffset, headDst + ho, blk.headSize, ".bhead"); ho += blk.headSize; }
         rawDna += blk.rawDnaSize; records += blk.recordsCount;
     }
     if (asNewBin || graph.bins.empty()) {
@@ -391,8 +403,9 @@ void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asN
     else { recIdx = (uint32_t)data.recs.size(); data.recs.resize(data.recs.size() + records, Rec{}); }
     const uint32_t recFirst = recIdx;
 
-    Unpacker u(cfg_, data, graph, bMeta_, mo, bDna_, dO, quaDst, qo, bHead_, ho);
-    u.packedQ = packedQ;
+    Unpacker u(cfg_, data, graph, bMeta_, mo, bDna_, dO, quaDst, qo, headDst, ho);
+    u.packedH = packedH;
+    u.packedQ = packedQ; u.quaBits = cfg_.quaParams.method == MET_BINARY ? 1u : (cfg_.quaParams.method == MET_8BIN ? 3u : 6u);
     u.placed = placed; u.seqCur = seqBase; u.headCur = headBase;
     // a placed bin owns exactly the footer's totals of the shared arrays; a footer that understates them must not spill
     // into the neighbouring bin (another host thread is filling it)

@@ -38,11 +38,12 @@ public:
     // offsets (their sizes are known from the footer); the graph tables and the BinIn go to `graph` (node indices local to it).
     // quaBase >= 0: the qualities are not unpacked; the bin's .bqua bytes go to data.quaPacked at quaBase and every record's
     // bit offset into them to data.quaBit (lossless archives only; see Batch)
-    void unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, uint64_t headBase, uint32_t recBase, Batch& graph, int64_t quaBase = -1) const;
+    // headPackedBase >= 0: the same for the read ids (data.headPacked / data.headBit)
+    void unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, uint64_t headBase, uint32_t recBase, Batch& graph, int64_t quaBase = -1, int64_t headPackedBase = -1) const;
 
 private:
     void readFooter(const std::vector<uint8_t>& buf);
-    void unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase, int64_t quaBase) const;
+    void unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase, int64_t quaBase, int64_t headPackedBase) const;
     struct Map { const uint8_t* p = nullptr; uint64_t size = 0; };    // read-only mmap of one stream file
     static Map mapFile(const std::string& name);
     static void unmap(Map& m);

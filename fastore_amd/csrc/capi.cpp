@@ -448,6 +448,44 @@ int fsgpu_gather_quality(fsgpu_ctx* ctx, const uint8_t* packed, size_t packedByt
     });
 }
 
+int fsgpu_gather_quality_binned(fsgpu_ctx* ctx, const uint8_t* packed, size_t packedBytes, uint32_t bits, uint32_t binaryThreshold,
+                                const fsgpu_quality_string_n* strings, size_t n, uint8_t* out, size_t outCapPairs, size_t* outPairs)
+{
+    if (!ctx || !outPairs || (bits != 3u && bits != 1u) || (n && (!packed || !strings || !out))) return FSGPU_ERR_ARG;
+    FS_GUARD(ctx, {
+        uint64_t total = 0, nBytes = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (strings[i].len > 255u || strings[i].n_count > strings[i].len || strings[i].src_bit + (uint64_t)bits * strings[i].len > 8ull * packedBytes || (strings[i].n_count && !strings[i].n_positions))
+                throw std::runtime_error("quality string outside the packed scores");
+            total += strings[i].len - strings[i].n_count; nBytes += strings[i].n_count;
+        }
+        if (total > outCapPairs || total > 0x70000000ull || n > 0xFFFFFFF0ull) throw std::runtime_error("output buffer too small for the gathered quality stream");
+        *outPairs = (size_t)total;
+        if (n == 0) return FSGPU_OK;
+        const uint64_t descOff = ((uint64_t)packedBytes + 8u + 15u) & ~15ull, nOff = descOff + ((n * sizeof(fsdev::QuaPairString) + 15u) & ~15ull);
+        std::vector<uint8_t> input(nOff + nBytes + 32, 0);
+        memcpy(input.data(), packed, packedBytes);
+        fsdev::QuaPairString* qs = (fsdev::QuaPairString*)(input.data() + descOff);
+        uint64_t dst = 0, np = 0;
+        for (size_t i = 0; i < n; ++i) {
+            qs[i].src_bit = strings[i].src_bit; qs[i].dst_off = (uint32_t)dst; qs[i].n_off = (uint32_t)np; qs[i].len = (uint16_t)strings[i].len; qs[i].reverse = strings[i].reverse ? 1 : 0; qs[i].n_count = (uint8_t)strings[i].n_count;
+            if (strings[i].n_count) memcpy(input.data() + nOff + np, strings[i].n_positions, strings[i].n_count);
+            dst += strings[i].len - strings[i].n_count; np += strings[i].n_count;
+        }
+        fsdev::GatherPlan gp; gp.desc_off = descOff; gp.n_strings = (uint32_t)n; gp.out_bytes = (2 * total + 15u) & ~15ull; gp.symbols = total; gp.bits = bits;
+        gp.n_list_off = nOff; gp.n_list_bytes = nBytes; gp.sym_of_bit[0] = 6u >= binaryThreshold ? 1u : 0u; gp.sym_of_bit[1] = 40u >= binaryThreshold ? 1u : 0u;
+        std::vector<uint8_t> res;
+        if (fsengine::gather_quality_raw(ctx->c.dev, input.data(), nOff + nBytes + 16, gp, res, &ctx->c.timing) != 0) throw std::runtime_error(std::string("device: ") + ctx->c.dev->err);
+        memcpy(out, res.data(), 2 * total);
+    });
+}
+
+int fsgpu_tokeniser_check(fsgpu_ctx* ctx, const char* inPrefix, uint64_t* ids, uint64_t* differingBins)
+{
+    if (!ctx || !inPrefix || !ids || !differingBins) return FSGPU_ERR_ARG;
+    FS_GUARD(ctx, ctx->c.tokeniserCheck(inPrefix, *ids, *differingBins));
+}
+
 int fsgpu_matcher_check(fsgpu_ctx* ctx, const char* inPrefix, uint64_t* reads, uint64_t* differing)
 {
     if (!ctx || !inPrefix || !reads || !differing) return FSGPU_ERR_ARG;
@@ -509,7 +547,7 @@ int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out)
     out->kernel_launches = ctx->c.timing.launches; out->stream_items = ctx->c.timing.items; out->ppmd_symbols = ctx->c.timing.ppmd_symbols;
     out->ppmd_window_attempts = ctx->c.timing.win[1]; out->ppmd_windows = ctx->c.timing.win[2]; out->ppmd_window_symbols = ctx->c.timing.win[3];
     out->ppmd_window_rounds = ctx->c.timing.win[4]; out->ppmd_windows_redone = ctx->c.timing.win[5]; out->ppmd_window_light_rounds = ctx->c.timing.win[6];
-    out->matcher_reads = ctx->c.matchedReads.load(); out->matcher_call_ms = ctx->c.matchUs.load() / 1e3; out->matcher_kernel_ms = ctx->c.matchKernelUs.load() / 1e3;
+    out->tokenised_ids = ctx->c.timing.id_strings; out->matcher_reads = ctx->c.matchedReads.load(); out->matcher_call_ms = ctx->c.matchUs.load() / 1e3; out->matcher_kernel_ms = ctx->c.matchKernelUs.load() / 1e3;
     out->gather_kernel_ms = ctx->c.timing.gather_ms; out->gather_symbols = ctx->c.timing.gather_symbols; out->gather_bytes = ctx->c.timing.gather_bytes;
     out->rc_symbols = ctx->c.timing.rc_symbols; out->ppmd_restarts = ctx->c.timing.restarts; out->h2d_bytes = ctx->c.timing.h2d_bytes; out->d2h_bytes = ctx->c.timing.d2h_bytes;
     return FSGPU_OK;

@@ -22,7 +22,13 @@ struct StreamItem {
 // region behind the uploaded input; reverse: the string is emitted back to front
 struct QuaString { uint64_t src_bit; uint32_t dst_off; uint16_t len; uint16_t reverse; };
 // device-only part of a batch input buffer: quality streams gathered on the device instead of uploaded
-struct GatherPlan { uint64_t desc_off = 0; uint32_t n_strings = 0; uint64_t out_bytes = 0; uint64_t symbols = 0; };
+// 8-bin / binary archives: the stream is (symbol, context) byte pairs, symbol = the stored 3- or 1-bit score, context =
+// (emitted index * 8 or 2) / length; the n_count positions listed (stored indices, n_off into the slice's list) lie under
+// an 'N' base and are left out.  dst_off counts PAIRS.
+struct QuaPairString { uint64_t src_bit; uint32_t dst_off, n_off; uint16_t len; uint8_t reverse, n_count; };
+// bits: 6 = QuaString descriptors and byte output; 3 / 1 = QuaPairString descriptors, pair output, n_list_off = the 'N' positions
+struct GatherPlan { uint64_t desc_off = 0; uint32_t n_strings = 0; uint64_t out_bytes = 0; uint64_t symbols = 0; uint32_t bits = 6; uint64_t n_list_off = 0, n_list_bytes = 0;
+                    uint32_t sym_of_bit[2] = {0, 1}; };      // binary archives: the coded symbol of a stored 0 / 1 (score 6 / 40 against the archive's threshold)
 
 // Device-side read matcher (matcher.hip): the reads of a bin's match-tree constructions, each construction's reads in
 // processing order; a row of answers per read
@@ -35,6 +41,14 @@ struct MatchParams { uint32_t window; int32_t shift_cost, mismatch_cost, encode_
 // match: read the best window slot holds (-1 none at or below the threshold, -2 a dummy slot); cost / shift / no_mismatches of
 // that match (cost = threshold + 1 when none); identical: exact duplicate of a slot that is not the root copy
 struct MatchRow { int32_t match; int16_t cost, shift; uint8_t no_mismatches, identical, dummy, pad; };
+
+// Device-side read-id tokeniser (fs_tokenise_ids).  Field table of a library, as the kernel reads it: n_fields, then per
+// field an IdField, then the token fields' value lists (per value: u32 offset from the blob start, u32 length), then bytes
+struct IdField { uint8_t separator, is_const, is_numeric, plog; uint32_t n_values, values_off; uint64_t min_value; };
+struct IdString { uint64_t src_bit; uint32_t len, pad; };      // first stored character (7 bits each, after the implied '@'); length incl. the '@'
+// one bin: its strings, where its two streams go (byte offsets in the gather region), the items whose in_len the kernel sets
+struct IdJob { uint32_t first, count, tok_item, val_item; uint64_t tok_out, val_out, table_off; };
+struct IdPlan { uint64_t jobs_off = 0, strings_off = 0; uint32_t n_jobs = 0, n_strings = 0; uint64_t out_bytes = 0; };
 
 enum : uint32_t { MAX_STREAMS = 23 };
 

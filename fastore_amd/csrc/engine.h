@@ -10,6 +10,7 @@ namespace fsengine {
 struct BatchTiming {
     double encode_ms = 0, assemble_ms = 0;      // HIP-event time of the two kernels (summed over launches)
     double gather_ms = 0; uint64_t gather_symbols = 0, gather_bytes = 0;   // fs_gather_quality: time, scores, bytes read + written
+    uint64_t id_strings = 0;                                                 // fs_tokenise_ids: read ids tokenised on the device
     uint64_t launches = 0, items = 0, ppmd_symbols = 0, rc_symbols = 0, restarts = 0;
     uint64_t h2d_bytes = 0, d2h_bytes = 0;
     uint64_t win[16] = {0};                     // windowed PPMd hit path, summed over the streams: [1] attempts [2] windows [3] symbols [4] rounds [5] redone; [8..15] phase clocks / 64
@@ -60,10 +61,12 @@ int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
                 fsdev::MatchRow* rows, double* kernelMs);
 // fs_gather_quality on its own: `input` = packed scores then the descriptors (plan.desc_off); returns the gathered bytes
 int gather_quality_raw(Device* dev, const uint8_t* input, size_t inputBytes, const fsdev::GatherPlan& plan, std::vector<uint8_t>& out, BatchTiming* timing);
+// fs_tokenise_ids on its own (parity checks): tok[j] / val[j] = the (symbol, context) pair streams of job j (its items: 2 j, 2 j + 1)
+int tokenise_ids_raw(Device* dev, const uint8_t* input, size_t inputBytes, const fsdev::IdPlan& plan, std::vector<std::vector<uint8_t>>& tok, std::vector<std::vector<uint8_t>>& val);
 // gather (optional): quality streams that fs_gather_quality writes behind the uploaded input (at inputBytes rounded up to
 // 16) from the packed scores inside it; their items' in_off already point there
 int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,
                  std::vector<fsdev::BlockPlan>& plans, std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes,
-                 BatchTiming* timing, const fsdev::GatherPlan* gather = nullptr);
+                 BatchTiming* timing, const fsdev::GatherPlan* gather = nullptr, const fsdev::IdPlan* ids = nullptr);
 
 }  // namespace fsengine

@@ -217,6 +217,123 @@ __global__ __launch_bounds__(256) void fs_gather_quality(const QuaString* __rest
     }
 }
 
+// The same for 8-bin / binary archives (IQualityStoreBase::CompressReadQuality, MET_8BIN / MET_BINARY: FastqCompressor.cpp:
+// 249-316): the stream is (symbol, context) pairs for the order-k range coder -- symbol = the stored 3-bit bin (1 bit:
+// mapped through the archive's threshold), context = emitted index * 8 (2) / length -- and positions under an 'N' base are
+// left out, so a lane's pair lands behind the pairs of the earlier positions that stay: its index minus the listed 'N'
+// positions in front of it.  One wavefront per string, one position per lane and step, one 16-bit store.
+__global__ __launch_bounds__(256) void fs_gather_quality_pairs(const QuaPairString* __restrict__ strings, uint32_t nStrings, const uint8_t* __restrict__ in,
+                                                               const uint8_t* __restrict__ nList, uint8_t* __restrict__ out, uint32_t bits, uint32_t sym0, uint32_t sym1)
+{
+    const uint32_t lane = threadIdx.x & 63u, nWaves = gridDim.x * 4u, ctxMul = bits == 3u ? 8u : 2u;
+    for (uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6); s < nStrings; s += nWaves) {
+        const QuaPairString d = strings[s];
+        const uint32_t len = d.len;
+        for (uint32_t i = lane; i < len; i += 64u) {
+            const uint32_t ii = d.reverse ? len - 1u - i : i;
+            bool isN = false; uint32_t before = 0;
+            for (uint32_t t = 0; t < d.n_count; ++t) {
+                const uint32_t p = nList[d.n_off + t];
+                isN = isN || p == ii;
+                before += d.reverse ? (p > ii ? 1u : 0u) : (p < ii ? 1u : 0u);
+            }
+            if (isN) continue;
+            const uint64_t bit = d.src_bit + (uint64_t)bits * ii;
+            const uint32_t w = ((uint32_t)in[bit >> 3] << 8) | in[(bit >> 3) + 1];
+            uint32_t sym = (w >> (16u - bits - (uint32_t)(bit & 7u))) & ((1u << bits) - 1u);
+            if (bits == 1u) sym = sym ? sym1 : sym0;
+            const uint32_t ctx = i * ctxMul / len;
+            const uint16_t v = (uint16_t)(sym | (ctx << 8));
+            __builtin_memcpy(out + 2ull * (d.dst_off + i - before), &v, 2);
+        }
+    }
+}
+
+// fs_tokenise_ids -- the read-id streams of a bin, built on the device (SURVEY 8 a10 + f1): the stored headers (.bhead: 7 bits per
+// character behind an implied '@', fastore_bin/FastqPacker.cpp:157-287) are split at each field's own separator, constant
+// fields skipped, token fields looked up in the field's value list (their index, context = field), numeric fields written
+// as the big-endian bytes of (value - minimum) with context = field * 4 + byte (IHeaderStoreBase::CompressReadId,
+// fastore_pack/FastqCompressor.cpp:504-583).  One workgroup per bin, one read per thread and step; a read's pairs land behind
+// those of the reads before it: counted first, placed by a prefix sum over the workgroup, then written.  The two streams'
+// lengths go to their stream items, which the coder kernel reads behind this one.
+template <bool WRITE> __device__ __forceinline__ void id_parse(const IdString& s, const uint8_t* __restrict__ in, const uint8_t* __restrict__ tab, uint32_t& nt, uint32_t& nv,
+                                                               uint8_t* tokDst, uint8_t* valDst)
+{
+    const uint32_t nf = *(const uint32_t*)tab;
+    const IdField* F = (const IdField*)(tab + 8);
+    auto ch = [&](uint32_t j) -> uint32_t {
+        if (j == 0u) return (uint32_t)'@';
+        const uint64_t bit = s.src_bit + 7ull * (j - 1u);
+        const uint32_t w = ((uint32_t)in[bit >> 3] << 8) | in[(bit >> 3) + 1];
+        return (w >> (9u - (uint32_t)(bit & 7u))) & 127u;
+    };
+    uint32_t fieldStart = 0, fi = 0;
+    for (uint32_t i = 0; i <= s.len; ++i) {
+        if (fi >= nf) break;
+        const IdField f = F[fi];
+        if (i != s.len && ch(i) != (uint32_t)f.separator) continue;
+        if (!f.is_const) {
+            const uint32_t fieldLen = i - fieldStart;
+            if (!f.is_numeric) {
+                uint32_t id = f.n_values;                                  // std::find's end() when the value is not listed
+                const uint32_t* vl = (const uint32_t*)(tab + f.values_off);
+                for (uint32_t v = 0; v < f.n_values && id == f.n_values; ++v) {
+                    if (vl[2 * v + 1] != fieldLen) continue;
+                    const uint8_t* vb = tab + vl[2 * v];
+                    bool same = true;
+                    for (uint32_t k = 0; k < fieldLen && same; ++k) same = vb[k] == ch(fieldStart + k);
+                    if (same) id = v;
+                }
+                if (WRITE) { tokDst[2 * nt] = (uint8_t)id; tokDst[2 * nt + 1] = (uint8_t)fi; }
+                ++nt;
+            } else {
+                uint64_t v = 0;
+                for (uint32_t k = 0; k < fieldLen; ++k) { const uint32_t c = ch(fieldStart + k); if (c < '0' || c > '9') break; v = v * 10u + (c - '0'); }
+                const int64_t diff = (int64_t)(v - f.min_value);
+                uint32_t ctx = fi << 2;
+                for (int32_t p = (int32_t)f.plog; p >= 0; --p) {
+                    if (WRITE) { valDst[2 * nv] = (uint8_t)((diff >> (8 * p)) & 0xFF); valDst[2 * nv + 1] = (uint8_t)ctx; }
+                    ++ctx; ++nv;
+                }
+            }
+        }
+        fieldStart = i + 1u; ++fi;
+    }
+}
+
+__global__ __launch_bounds__(256) void fs_tokenise_ids(const IdJob* __restrict__ jobs, const IdString* __restrict__ strings, const uint8_t* __restrict__ in,
+                                                       uint8_t* __restrict__ out, StreamItem* items)
+{
+    __shared__ uint32_t sT[256], sV[256];
+    const IdJob job = jobs[blockIdx.x];
+    const uint8_t* tab = in + job.table_off;
+    const uint32_t tid = threadIdx.x;
+    uint32_t tokBase = 0, valBase = 0;                             // pairs written so far
+    for (uint32_t c0 = 0; c0 < job.count; c0 += 256u) {
+        const bool active = c0 + tid < job.count;
+        IdString s; s.src_bit = 0; s.len = 0; s.pad = 0;
+        uint32_t nt = 0, nv = 0;
+        if (active) { s = strings[job.first + c0 + tid]; id_parse<false>(s, in, tab, nt, nv, nullptr, nullptr); }
+        // inclusive prefix sums over the workgroup (Hillis-Steele in LDS)
+        sT[tid] = nt; sV[tid] = nv;
+        __syncthreads();
+        for (uint32_t d = 1; d < 256u; d <<= 1) {
+            const uint32_t a = tid >= d ? sT[tid - d] : 0u, b = tid >= d ? sV[tid - d] : 0u;
+            __syncthreads();
+            sT[tid] += a; sV[tid] += b;
+            __syncthreads();
+        }
+        const uint32_t offT = sT[tid] - nt, offV = sV[tid] - nv, totT = sT[255], totV = sV[255];
+        if (active) {
+            uint32_t wt = 0, wv = 0;
+            id_parse<true>(s, in, tab, wt, wv, out + job.tok_out + 2ull * (tokBase + offT), out + job.val_out + 2ull * (valBase + offV));
+        }
+        tokBase += totT; valBase += totV;
+        __syncthreads();
+    }
+    if (tid == 0u) { items[job.tok_item].in_len = tokBase; items[job.val_item].in_len = valBase; }
+}
+
 __device__ __forceinline__ void put_be(uint8_t* p, uint64_t v, int nbytes)
 { for (int i = 0; i < nbytes; ++i) p[i] = (uint8_t)(v >> (8 * (nbytes - 1 - i))); }
 
@@ -429,7 +546,7 @@ uint8_t* staging_buffer(Device* dev, size_t bytes)
 
 // H2D + fs_encode_streams + D2H of the per-stream sizes.  Leaves the coded streams in dev->dScratch.
 static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items,
-                      std::vector<uint32_t>& sizes, uint64_t& scratchBytes, BatchTiming* timing, const GatherPlan* gather = nullptr)
+                      std::vector<uint32_t>& sizes, uint64_t& scratchBytes, BatchTiming* timing, const GatherPlan* gather = nullptr, const IdPlan* ids = nullptr)
 {
     HIP_TRY(hipSetDevice(dev->deviceId));
     hipStream_t st = (hipStream_t)dev->stream;
@@ -461,8 +578,14 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost(a) > cost(b); });
 
     // the gathered quality streams live behind the uploaded bytes
-    const uint64_t gatherBase = ((uint64_t)inputBytes + 15u) & ~15ull, gatherBytes = gather ? gather->out_bytes : 0;
-    if (gather && (gather->desc_off & 15u || gather->desc_off + (uint64_t)gather->n_strings * sizeof(QuaString) > inputBytes || gatherBase + gatherBytes > 0xFFFFFF00ull)) {
+    // (quality streams first, then the read-id streams)
+    const uint64_t gatherBase = ((uint64_t)inputBytes + 15u) & ~15ull, gatherBytes = (gather ? gather->out_bytes : 0) + (ids ? ids->out_bytes : 0);
+    if (ids && (ids->jobs_off & 7u || ids->strings_off & 7u || ids->jobs_off + (uint64_t)ids->n_jobs * sizeof(IdJob) > inputBytes || ids->strings_off + (uint64_t)ids->n_strings * sizeof(IdString) > inputBytes)) {
+        snprintf(dev->err, sizeof dev->err, "read-id plan outside the batch input"); return -1;
+    }
+    const size_t descBytes = gather ? (gather->bits == 6u ? sizeof(QuaString) : sizeof(QuaPairString)) : 0;
+    if (gather && (gather->desc_off & 15u || gather->desc_off + (uint64_t)gather->n_strings * descBytes > inputBytes || gatherBase + gatherBytes > 0xFFFFFF00ull ||
+                   (gather->bits != 6u && gather->bits != 3u && gather->bits != 1u) || (gather->bits != 6u && gather->n_list_off + gather->n_list_bytes > inputBytes))) {
         snprintf(dev->err, sizeof dev->err, "quality gather plan outside the batch input"); return -1;
     }
     if (ensure(dev, dev->dIn, dev->capIn, gatherBase + gatherBytes + 64)) return -1;
@@ -491,15 +614,28 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     HIP_TRY(hipMemsetAsync(dev->queueHead, 0, 64, st));
     if (gather && gather->n_strings) {
         // every string's source and destination inside the buffer, checked here: the kernel trusts its descriptors
-        const QuaString* qs = (const QuaString*)(input + gather->desc_off);
-        for (uint32_t i = 0; i < gather->n_strings; ++i)
-            if ((qs[i].src_bit >> 3) + (6ull * qs[i].len + 7u) / 8u + 4u > inputBytes || (uint64_t)qs[i].dst_off + qs[i].len > gatherBytes) {
-                snprintf(dev->err, sizeof dev->err, "quality string %u outside the batch input", i); return -1;
-            }
+        if (gather->bits == 6u) {
+            const QuaString* qs = (const QuaString*)(input + gather->desc_off);
+            for (uint32_t i = 0; i < gather->n_strings; ++i)
+                if ((qs[i].src_bit >> 3) + (6ull * qs[i].len + 7u) / 8u + 4u > inputBytes || (uint64_t)qs[i].dst_off + qs[i].len > gatherBytes) {
+                    snprintf(dev->err, sizeof dev->err, "quality string %u outside the batch input", i); return -1;
+                }
+        } else {
+            const QuaPairString* qs = (const QuaPairString*)(input + gather->desc_off);
+            for (uint32_t i = 0; i < gather->n_strings; ++i)
+                if ((qs[i].src_bit >> 3) + ((uint64_t)gather->bits * qs[i].len + 7u) / 8u + 2u > inputBytes || qs[i].n_count > qs[i].len ||
+                    2ull * ((uint64_t)qs[i].dst_off + qs[i].len - qs[i].n_count) > gatherBytes || (uint64_t)qs[i].n_off + qs[i].n_count > gather->n_list_bytes) {
+                    snprintf(dev->err, sizeof dev->err, "quality string %u outside the batch input", i); return -1;
+                }
+        }
         HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[4], st));
         const uint32_t blocks = std::min<uint32_t>((gather->n_strings + 3u) / 4u, (uint32_t)dev->cus * 16u);
-        hipLaunchKernelGGL(fs_gather_quality, dim3(blocks), dim3(256), 0, st, (const QuaString*)(dev->dIn + gather->desc_off), gather->n_strings,
-                           (const uint8_t*)dev->dIn, (uint8_t*)(dev->dIn + gatherBase));
+        if (gather->bits == 6u)
+            hipLaunchKernelGGL(fs_gather_quality, dim3(blocks), dim3(256), 0, st, (const QuaString*)(dev->dIn + gather->desc_off), gather->n_strings,
+                               (const uint8_t*)dev->dIn, (uint8_t*)(dev->dIn + gatherBase));
+        else
+            hipLaunchKernelGGL(fs_gather_quality_pairs, dim3(blocks), dim3(256), 0, st, (const QuaPairString*)(dev->dIn + gather->desc_off), gather->n_strings,
+                               (const uint8_t*)dev->dIn, (const uint8_t*)(dev->dIn + gather->n_list_off), (uint8_t*)(dev->dIn + gatherBase), gather->bits, gather->sym_of_bit[0], gather->sym_of_bit[1]);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[5], st));
     }
@@ -510,6 +646,19 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     std::shared_lock<std::shared_mutex> shared(pool->gate, std::defer_lock);
     std::unique_lock<std::shared_mutex> alone(pool->gate, std::defer_lock);
     if (exclusive) alone.lock(); else shared.lock();
+    if (ids && ids->n_jobs) {
+        // every job's strings, table and output inside the buffers, checked here: the kernel trusts its descriptors
+        const IdJob* jb = (const IdJob*)(input + ids->jobs_off); const IdString* ss = (const IdString*)(input + ids->strings_off);
+        for (uint32_t j = 0; j < ids->n_jobs; ++j) {
+            bool ok = (uint64_t)jb[j].first + jb[j].count <= ids->n_strings && jb[j].tok_item < nItems && jb[j].val_item < nItems && jb[j].table_off + 8u <= inputBytes && (jb[j].table_off & 7u) == 0 &&
+                      jb[j].tok_out + 2ull * items[jb[j].tok_item].in_len <= gatherBytes && jb[j].val_out + 2ull * items[jb[j].val_item].in_len <= gatherBytes;
+            for (uint32_t k = 0; ok && k < jb[j].count; ++k) { const IdString& s = ss[jb[j].first + k]; ok = s.len <= 255u && (s.src_bit >> 3) + (7ull * s.len + 7u) / 8u + 2u <= inputBytes; }
+            if (!ok) { snprintf(dev->err, sizeof dev->err, "read-id job %u outside the batch input", j); return -1; }
+        }
+        hipLaunchKernelGGL(fs_tokenise_ids, dim3(ids->n_jobs), dim3(256), 0, st, (const IdJob*)(dev->dIn + ids->jobs_off), (const IdString*)(dev->dIn + ids->strings_off),
+                           (const uint8_t*)dev->dIn, (uint8_t*)(dev->dIn + gatherBase), (StreamItem*)dev->dItems);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[0], st));
     {
         EncodeArgs ka;
@@ -536,9 +685,11 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         float a = 0;
         (void)hipEventElapsedTime(&a, (hipEvent_t)dev->ev[0], (hipEvent_t)dev->ev[1]);
         timing->encode_ms += a; timing->launches += 1; timing->items += nItems; timing->h2d_bytes += inputBytes;
+        if (ids) timing->id_strings += ids->n_strings;
         if (gather && gather->n_strings) {
             float g = 0; (void)hipEventElapsedTime(&g, (hipEvent_t)dev->ev[4], (hipEvent_t)dev->ev[5]);
-            timing->gather_ms += g; timing->gather_symbols += gather->symbols; timing->gather_bytes += gather->symbols + (gather->symbols * 3u + 3u) / 4u;
+            timing->gather_ms += g; timing->gather_symbols += gather->symbols;
+            timing->gather_bytes += gather->bits == 6u ? gather->symbols + (gather->symbols * 3u + 3u) / 4u : 2u * gather->symbols + (gather->symbols * gather->bits + 7u) / 8u;
         }
         for (uint32_t i = 0; i < nItems; ++i) { timing->restarts += restarts[16ull * i]; for (int k = 1; k < 16; ++k) timing->win[k] += restarts[16ull * i + k]; if (items[i].kind == KIND_PPMD) timing->ppmd_symbols += items[i].in_len; else timing->rc_symbols += items[i].in_len; }
     }
@@ -578,22 +729,73 @@ int gather_quality_raw(Device* dev, const uint8_t* input, size_t inputBytes, con
     HIP_TRY(hipSetDevice(dev->deviceId));
     hipStream_t st = (hipStream_t)dev->stream;
     const uint64_t gatherBase = ((uint64_t)inputBytes + 15u) & ~15ull;
-    if (plan.desc_off & 15u || plan.desc_off + (uint64_t)plan.n_strings * sizeof(QuaString) > inputBytes) { snprintf(dev->err, sizeof dev->err, "quality gather plan outside the input"); return -1; }
-    const QuaString* qs = (const QuaString*)(input + plan.desc_off);
-    for (uint32_t i = 0; i < plan.n_strings; ++i)
-        if ((qs[i].src_bit >> 3) + (6ull * qs[i].len + 7u) / 8u + 4u > plan.desc_off || (uint64_t)qs[i].dst_off + qs[i].len > plan.out_bytes) { snprintf(dev->err, sizeof dev->err, "quality string %u outside the input", i); return -1; }
+    const size_t descBytes = plan.bits == 6u ? sizeof(QuaString) : sizeof(QuaPairString);
+    if (plan.desc_off & 15u || plan.desc_off + (uint64_t)plan.n_strings * descBytes > inputBytes || (plan.bits != 6u && plan.bits != 3u && plan.bits != 1u) ||
+        (plan.bits != 6u && plan.n_list_off + plan.n_list_bytes > inputBytes)) { snprintf(dev->err, sizeof dev->err, "quality gather plan outside the input"); return -1; }
+    if (plan.bits == 6u) {
+        const QuaString* qs = (const QuaString*)(input + plan.desc_off);
+        for (uint32_t i = 0; i < plan.n_strings; ++i)
+            if ((qs[i].src_bit >> 3) + (6ull * qs[i].len + 7u) / 8u + 4u > plan.desc_off || (uint64_t)qs[i].dst_off + qs[i].len > plan.out_bytes) { snprintf(dev->err, sizeof dev->err, "quality string %u outside the input", i); return -1; }
+    } else {
+        const QuaPairString* qs = (const QuaPairString*)(input + plan.desc_off);
+        for (uint32_t i = 0; i < plan.n_strings; ++i)
+            if ((qs[i].src_bit >> 3) + ((uint64_t)plan.bits * qs[i].len + 7u) / 8u + 2u > plan.desc_off || qs[i].n_count > qs[i].len || 2ull * ((uint64_t)qs[i].dst_off + qs[i].len - qs[i].n_count) > plan.out_bytes ||
+                (uint64_t)qs[i].n_off + qs[i].n_count > plan.n_list_bytes) { snprintf(dev->err, sizeof dev->err, "quality string %u outside the input", i); return -1; }
+    }
     if (ensure(dev, dev->dIn, dev->capIn, gatherBase + plan.out_bytes + 64)) return -1;
     HIP_TRY(hipMemcpyAsync(dev->dIn, input, inputBytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[4], st));
     const uint32_t blocks = std::max(1u, std::min<uint32_t>((plan.n_strings + 3u) / 4u, (uint32_t)dev->cus * 16u));
-    hipLaunchKernelGGL(fs_gather_quality, dim3(blocks), dim3(256), 0, st, (const QuaString*)(dev->dIn + plan.desc_off), plan.n_strings,
-                       (const uint8_t*)dev->dIn, (uint8_t*)(dev->dIn + gatherBase));
+    if (plan.bits == 6u)
+        hipLaunchKernelGGL(fs_gather_quality, dim3(blocks), dim3(256), 0, st, (const QuaString*)(dev->dIn + plan.desc_off), plan.n_strings,
+                           (const uint8_t*)dev->dIn, (uint8_t*)(dev->dIn + gatherBase));
+    else
+        hipLaunchKernelGGL(fs_gather_quality_pairs, dim3(blocks), dim3(256), 0, st, (const QuaPairString*)(dev->dIn + plan.desc_off), plan.n_strings,
+                           (const uint8_t*)dev->dIn, (const uint8_t*)(dev->dIn + plan.n_list_off), (uint8_t*)(dev->dIn + gatherBase), plan.bits, plan.sym_of_bit[0], plan.sym_of_bit[1]);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[5], st));
     out.resize(plan.out_bytes);
     HIP_TRY(hipMemcpyAsync(out.data(), dev->dIn + gatherBase, plan.out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(wait_stream(dev, st));
     if (timing) { float g = 0; (void)hipEventElapsedTime(&g, (hipEvent_t)dev->ev[4], (hipEvent_t)dev->ev[5]); timing->gather_ms += g; timing->gather_symbols += plan.symbols; timing->gather_bytes += plan.symbols + (plan.symbols * 3u + 3u) / 4u; }
+    return 0;
+}
+
+// fs_tokenise_ids on its own (parity checks): `input` holds the packed headers, field tables, jobs and strings of `plan`; the
+// two streams of job j come back in tok[j] / val[j]
+int tokenise_ids_raw(Device* dev, const uint8_t* input, size_t inputBytes, const IdPlan& plan, std::vector<std::vector<uint8_t>>& tok, std::vector<std::vector<uint8_t>>& val)
+{
+    HIP_TRY(hipSetDevice(dev->deviceId));
+    hipStream_t st = (hipStream_t)dev->stream;
+    const uint64_t gatherBase = ((uint64_t)inputBytes + 15u) & ~15ull;
+    if (plan.jobs_off & 7u || plan.strings_off & 7u || plan.jobs_off + (uint64_t)plan.n_jobs * sizeof(IdJob) > inputBytes || plan.strings_off + (uint64_t)plan.n_strings * sizeof(IdString) > inputBytes) {
+        snprintf(dev->err, sizeof dev->err, "read-id plan outside the input"); return -1;
+    }
+    const IdJob* jb = (const IdJob*)(input + plan.jobs_off); const IdString* ss = (const IdString*)(input + plan.strings_off);
+    std::vector<StreamItem> items(2 * (size_t)plan.n_jobs); memset(items.data(), 0, items.size() * sizeof(StreamItem));
+    for (uint32_t j = 0; j < plan.n_jobs; ++j) {
+        bool ok = (uint64_t)jb[j].first + jb[j].count <= plan.n_strings && jb[j].tok_item == 2 * j && jb[j].val_item == 2 * j + 1 && jb[j].table_off + 8u <= inputBytes && (jb[j].table_off & 7u) == 0 &&
+                  jb[j].tok_out <= plan.out_bytes && jb[j].val_out <= plan.out_bytes;
+        for (uint32_t k = 0; ok && k < jb[j].count; ++k) { const IdString& s = ss[jb[j].first + k]; ok = s.len <= 255u && (s.src_bit >> 3) + (7ull * s.len + 7u) / 8u + 2u <= inputBytes; }
+        if (!ok) { snprintf(dev->err, sizeof dev->err, "read-id job %u outside the input", j); return -1; }
+    }
+    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + plan.out_bytes + 64)) return -1;
+    if (ensure(dev, dev->dItems, dev->capItems, sizeof(StreamItem) * items.size() + 64)) return -1;
+    HIP_TRY(hipMemcpyAsync(dev->dIn, input, inputBytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dev->dItems, items.data(), sizeof(StreamItem) * items.size(), hipMemcpyHostToDevice, st));
+    if (plan.n_jobs) hipLaunchKernelGGL(fs_tokenise_ids, dim3(plan.n_jobs), dim3(256), 0, st, (const IdJob*)(dev->dIn + plan.jobs_off), (const IdString*)(dev->dIn + plan.strings_off),
+                                        (const uint8_t*)dev->dIn, (uint8_t*)(dev->dIn + gatherBase), (StreamItem*)dev->dItems);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint8_t> out(plan.out_bytes + 16);
+    HIP_TRY(hipMemcpyAsync(out.data(), dev->dIn + gatherBase, plan.out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(items.data(), dev->dItems, sizeof(StreamItem) * items.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(wait_stream(dev, st));
+    tok.assign(plan.n_jobs, {}); val.assign(plan.n_jobs, {});
+    for (uint32_t j = 0; j < plan.n_jobs; ++j) {
+        const uint64_t nt = 2ull * items[2 * j].in_len, nv = 2ull * items[2 * j + 1].in_len;
+        if (jb[j].tok_out + nt > plan.out_bytes || jb[j].val_out + nv > plan.out_bytes) { snprintf(dev->err, sizeof dev->err, "read-id job %u wrote outside its streams", j); return -1; }
+        tok[j].assign(out.begin() + jb[j].tok_out, out.begin() + jb[j].tok_out + nt); val[j].assign(out.begin() + jb[j].val_out, out.begin() + jb[j].val_out + nv);
+    }
     return 0;
 }
 
@@ -615,13 +817,13 @@ int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std
 // bytes / (symbol, ctx) pairs.
 int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items,
                  std::vector<BlockPlan>& plans, std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes,
-                 BatchTiming* timing, const GatherPlan* gather)
+                 BatchTiming* timing, const GatherPlan* gather, const IdPlan* ids)
 {
     const uint32_t nItems = (uint32_t)items.size(), nBins = (uint32_t)plans.size();
     blockSizes.assign(nBins, 0);                 // `blocks` keeps its size between calls: resize() below does not re-zero what is overwritten anyway
     if (nItems == 0) { blocks.clear(); return 0; }
     std::vector<uint32_t> sizes; uint64_t scratch = 0;
-    if (run_encode(dev, input, inputBytes, items, sizes, scratch, timing, gather)) return -1;
+    if (run_encode(dev, input, inputBytes, items, sizes, scratch, timing, gather, ids)) return -1;
     hipStream_t st = (hipStream_t)dev->stream;
     if (ensure(dev, dev->dPlans, dev->capPlans, sizeof(BlockPlan) * nBins)) return -1;
     // a stream that filled its scratch slot was clipped: refuse rather than emit a corrupt block

@@ -109,6 +109,11 @@ struct Batch {
     // the fs_gather_quality kernel.
     ByteVec quaPacked;
     std::vector<uint32_t, NoInitAlloc<uint32_t>> quaBit;
+    // Device-side read-id tokeniser: the headers stay as stored too (.bhead: a length byte, then 7 bits per character behind
+    // an implied '@', fastore_bin/FastqPacker.cpp:157-287): headPacked = the bins' .bhead bytes, headBit[r] = bit offset of
+    // record r's first stored character in its bin's bytes (Rec::headLen is set, `head` stays empty)
+    ByteVec headPacked;
+    std::vector<uint32_t, NoInitAlloc<uint32_t>> headBit;
     std::vector<NodeIn> nodes;
     std::vector<uint32_t> topNodes;
     std::vector<uint32_t> emRecs;
@@ -116,7 +121,7 @@ struct Batch {
     std::vector<BinIn> bins;
     // append `o` (whole bins) behind this batch, re-basing every index
     void append(const Batch& o);
-    void clear() { seq.clear(); qua.clear(); head.clear(); recs.clear(); quaPacked.clear(); quaBit.clear(); nodes.clear(); topNodes.clear(); emRecs.clear(); trees.clear(); bins.clear(); }
+    void clear() { seq.clear(); qua.clear(); head.clear(); recs.clear(); quaPacked.clear(); quaBit.clear(); headPacked.clear(); headBit.clear(); nodes.clear(); topNodes.clear(); emRecs.clear(); trees.clear(); bins.clear(); }
 };
 
 }  // namespace fs

@@ -76,6 +76,8 @@ struct Rle0 {                        // rle/RleEncoder.h:140-212
     void end() { if (prev == 1) w->push_back(1); }
 };
 
+}  // namespace
+
 uint32_t intLog(uint64_t x, uint64_t base)
 {
     uint32_t r = 0;
@@ -84,8 +86,6 @@ uint32_t intLog(uint64_t x, uint64_t base)
     for (uint64_t t = base; t <= x; t *= base) ++r;
     return r;
 }
-
-}  // namespace
 
 bool streamIsRangeCoded(uint32_t s, uint32_t qm)
 {
@@ -907,14 +907,25 @@ struct BinEncoder::Impl {
     {
         if (!hasHeaders) return;
         const Rec& r = R(v);
-        compressReadId(*headp, B->head.data() + r.headOff, r.headLen, out->s[S_IdToken], out->s[S_IdValue]);
+        if (!B->headBit.empty()) out->idRefs.push_back(IdRef{B->headBit[vrecs[v].rec], r.headLen});      // tokenised on the device
+        else compressReadId(*headp, B->head.data() + r.headOff, r.headLen, out->s[S_IdToken], out->s[S_IdValue]);
         out->rawIdSize += r.headLen;
     }
     bool packedQuality() const { return !B->quaBit.empty(); }
-    void refQuality(uint32_t bit, uint32_t len, bool reverse) { out->quaRefs.push_back(QuaRef{bit, (uint16_t)len, (uint16_t)(reverse ? 1 : 0)}); out->quaSymbols += len; }
+    uint32_t quaBits() const { return cfg.quaParams.method == MET_BINARY ? 1u : (cfg.quaParams.method == MET_8BIN ? 3u : 6u); }
+    void refQuality(const uint8_t* s, uint32_t bit, uint32_t len, bool reverse)
+    {
+        QuaRef r{bit, (uint16_t)len, (uint8_t)(reverse ? 1 : 0), 0, (uint32_t)out->quaN.size()};
+        if (cfg.quaParams.method != MET_NONE) {                      // the scores under an 'N' are left out
+            uint32_t cnt = 0;
+            for (const uint8_t* q = (const uint8_t*)memchr(s, 'N', len); q; q = (const uint8_t*)memchr(q + 1, 'N', (size_t)(s + len - q - 1))) { out->quaN.push_back((uint8_t)(q - s)); ++cnt; }
+            r.nCount = (uint8_t)cnt;                                 // len <= 255, and a read of nothing but 'N' has no signature
+        }
+        out->quaRefs.push_back(r); out->quaSymbols += len - r.nCount;
+    }
     void compressQuality(int32_t v)
     {
-        if (packedQuality()) { refQuality(B->quaBit[vrecs[v].rec], seqLen(v), isReverse(v)); return; }
+        if (packedQuality()) { refQuality(seq(v), B->quaBit[vrecs[v].rec], seqLen(v), isReverse(v)); return; }
         compressReadQuality(cfg, seq(v), qua(v), seqLen(v), isReverse(v), out->s[S_Quality], qvzp, &well);
     }
 

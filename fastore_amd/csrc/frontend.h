@@ -44,16 +44,24 @@ enum Stream {
 // one quality string of the device-side quality path, in emission order: where its scores start in the bin's packed
 // .bqua bytes, how many there are, and whether the string is emitted back to front (IQualityStoreBase::CompressReadQuality,
 // FastqCompressor.cpp:236: a reverse-complemented record's scores are coded in the read's original orientation)
-struct QuaRef { uint32_t bit; uint16_t len; uint16_t reverse; };
+// (8-bin / binary archives: positions under an 'N' base are not coded, FastqCompressor.cpp:277, 307 -- nCount of them,
+// as stored indices, from quaN[nFirst] on)
+struct QuaRef { uint32_t bit; uint16_t len; uint8_t reverse, nCount; uint32_t nFirst; };
+
+// one read id of the device-side tokeniser, in emission order: where its stored characters start in the bin's packed
+// .bhead bytes, and its length (the leading '@' is implied)
+struct IdRef { uint32_t bit; uint32_t len; };
 
 struct BinStreams {
     std::vector<uint8_t> s[S_PE_COUNT];   // P streams: raw bytes; R streams: (symbol, ctx0) byte pairs
     uint64_t rawIdSize = 0;
     uint32_t nStreams = S_SE_COUNT;
     // device-side quality path: s[S_Quality] stays empty, the stream is these strings one after the other
-    std::vector<QuaRef> quaRefs; uint64_t quaSymbols = 0;
+    std::vector<QuaRef> quaRefs; uint64_t quaSymbols = 0; std::vector<uint8_t> quaN;
     const uint8_t* quaPacked = nullptr; uint64_t quaPackedBytes = 0;      // the bin's .bqua bytes (owned by the batch)
-    void reset(uint32_t n) { nStreams = n; rawIdSize = 0; for (auto& v : s) v.clear(); quaRefs.clear(); quaSymbols = 0; quaPacked = nullptr; quaPackedBytes = 0; }
+    // device-side read-id tokeniser: s[S_IdToken] / s[S_IdValue] stay empty, the device writes them from these
+    std::vector<IdRef> idRefs; const uint8_t* headPacked = nullptr; uint64_t headPackedBytes = 0;
+    void reset(uint32_t n) { nStreams = n; rawIdSize = 0; for (auto& v : s) v.clear(); quaRefs.clear(); quaSymbols = 0; quaN.clear(); quaPacked = nullptr; quaPackedBytes = 0; idRefs.clear(); headPacked = nullptr; headPackedBytes = 0; }
 };
 
 // which streams are range-coded in place (true) vs PPMd-compressed (false), and with which model
@@ -96,6 +104,7 @@ public:
 struct FieldSpec { uint8_t method; };     // 0 const, 1 token, 2 raw numeric
 void compressReadId(const HeaderStats& head, const uint8_t* h, uint32_t headLen, std::vector<uint8_t>& tokenPairs,
                     std::vector<uint8_t>& valuePairs);
+uint32_t intLog(uint64_t x, uint64_t base);       // int_log of fastore_bin/Utils.h as CompressReadId uses it (bytes of a numeric field)
 // IQualityStoreBase::CompressReadQuality (FastqCompressor.cpp:221-364); MET_QVZ needs the library's model and the
 // block's running WELL generator (reset at every block start, FastqCompressor.cpp:906-915)
 void compressReadQuality(const BinModuleConfigRaw& cfg, const uint8_t* seq, const uint8_t* qua, uint32_t len, bool reverse,

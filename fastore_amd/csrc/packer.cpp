@@ -301,6 +301,44 @@ fsengine::Device* Context::lane(uint32_t i)
     return lanes[i];
 }
 
+// The read-id field table of a library as fs_tokenise_ids reads it (device_types.h: IdField); also the numbers of
+// (symbol, context) pairs a read id gives at most: token pairs, value pairs
+static void idFieldBlob(const HeaderStats& head, std::vector<uint8_t>& blob, uint32_t& tokPerRead, uint32_t& valPerRead)
+{
+    const uint32_t nf = (uint32_t)head.fields.size();
+    tokPerRead = valPerRead = 0;
+    std::vector<fsdev::IdField> F(nf);
+    size_t at = 8 + nf * sizeof(fsdev::IdField);
+    std::vector<uint8_t> lists;                                   // value lists, then the value bytes
+    for (uint32_t i = 0; i < nf; ++i) {
+        const HeaderField& f = head.fields[i];
+        fsdev::IdField& d = F[i]; memset(&d, 0, sizeof d);
+        d.separator = (uint8_t)f.separator; d.is_const = f.isConst ? 1 : 0; d.is_numeric = f.isNumeric ? 1 : 0; d.min_value = f.minValue;
+        if (f.isConst) continue;
+        if (f.isNumeric) {
+            const int32_t valueRange = (int32_t)(f.maxValue - f.minValue);      // as IHeaderStoreBase::CompressReadId computes it
+            d.plog = (uint8_t)intLog((uint64_t)(int64_t)valueRange, 256);
+            valPerRead += d.plog + 1u;
+        } else { d.n_values = (uint32_t)f.possibleValues.size(); ++tokPerRead; }
+    }
+    for (uint32_t i = 0; i < nf; ++i) {
+        const HeaderField& f = head.fields[i];
+        if (f.isConst || f.isNumeric) continue;
+        F[i].values_off = (uint32_t)(at + lists.size());
+        const size_t listAt = lists.size(); lists.resize(listAt + 8 * f.possibleValues.size());
+        for (size_t v = 0; v < f.possibleValues.size(); ++v) {
+            const uint32_t off = (uint32_t)(at + lists.size()), len = (uint32_t)f.possibleValues[v].size();
+            memcpy(lists.data() + listAt + 8 * v, &off, 4); memcpy(lists.data() + listAt + 8 * v + 4, &len, 4);
+            lists.insert(lists.end(), f.possibleValues[v].begin(), f.possibleValues[v].end());
+        }
+        while (lists.size() & 7u) lists.push_back(0);
+    }
+    blob.assign(at + lists.size() + 8, 0);
+    memcpy(blob.data(), &nf, 4);
+    if (nf) memcpy(blob.data() + 8, F.data(), nf * sizeof(fsdev::IdField));
+    if (!lists.empty()) memcpy(blob.data() + at, lists.data(), lists.size());
+}
+
 // The window searches of host thread `tid`: its own matcher lane (stream + buffers), created on the first bin
 MatchFn Context::matcherFor(uint32_t tid)
 {
@@ -334,6 +372,49 @@ void Context::matcherCheck(const std::string& inPrefix, uint64_t& reads, uint64_
         std::lock_guard<std::mutex> g(mx); reads += r; differing += d;
     });
     deviceMatcher = keep;
+}
+
+void Context::tokeniserCheck(const std::string& inPrefix, uint64_t& ids, uint64_t& differingBins)
+{
+    ids = differingBins = 0;
+    BinFile bf; bf.open(inPrefix, par.minBinSize);
+    if (!bf.usesHeaders()) return;
+    const HeaderStats head = bf.headData();
+    std::vector<uint8_t> table; uint32_t tokPer = 0, valPer = 0;
+    idFieldBlob(head, table, tokPer, valPer);
+    for (uint32_t sig : bf.stdSignatures()) {
+        const BinInfo& bi = bf.bins().at(sig);
+        // host: unpacked headers in stored order through IHeaderStoreBase::CompressReadId's restatement
+        Batch hb; bf.unpack(sig, hb, true);
+        std::vector<uint8_t> tokH, valH;
+        for (const Rec& r : hb.recs) compressReadId(head, hb.head.data() + r.headOff, r.headLen, tokH, valH);
+        // device: the same records from the packed headers
+        Batch pb, pg;
+        pb.seq.resize(bi.totalRawDnaSize); pb.qua.resize(bi.totalRawDnaSize); pb.recs.resize(bi.totalRecordsCount);
+        pb.headPacked.resize(bi.totalHeadSize + 16); pb.headBit.resize(bi.totalRecordsCount);
+        bf.unpackPlaced(sig, pb, 0, 0, 0, pg, -1, 0);
+        const size_t n = pb.recs.size();
+        uint64_t off = 0;
+        const uint64_t tabOff = off; off += (table.size() + 15) & ~15ull;
+        const uint64_t headOff = off; off += (bi.totalHeadSize + 8 + 15) & ~15ull;
+        const uint64_t jobsOff = off; off += (sizeof(fsdev::IdJob) + 15) & ~15ull;
+        const uint64_t strOff = off; off += (n * sizeof(fsdev::IdString) + 15) & ~15ull;
+        std::vector<uint8_t> input(off + 16, 0);
+        memcpy(input.data() + tabOff, table.data(), table.size());
+        memcpy(input.data() + headOff, pb.headPacked.data(), bi.totalHeadSize);
+        fsdev::IdJob job; memset(&job, 0, sizeof job);
+        job.first = 0; job.count = (uint32_t)n; job.tok_item = 0; job.val_item = 1; job.table_off = tabOff;
+        job.tok_out = 0; job.val_out = (2ull * n * tokPer + 31u) & ~15ull;
+        memcpy(input.data() + jobsOff, &job, sizeof job);
+        fsdev::IdString* ss = (fsdev::IdString*)(input.data() + strOff);
+        for (size_t i = 0; i < n; ++i) { ss[i].src_bit = 8ull * headOff + pb.headBit[i]; ss[i].len = pb.recs[i].headLen; ss[i].pad = 0; }
+        fsdev::IdPlan plan; plan.jobs_off = jobsOff; plan.strings_off = strOff; plan.n_jobs = 1; plan.n_strings = (uint32_t)n;
+        plan.out_bytes = job.val_out + ((2ull * n * valPer + 31u) & ~15ull);
+        std::vector<std::vector<uint8_t>> tok, val;
+        if (fsengine::tokenise_ids_raw(dev, input.data(), off, plan, tok, val) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+        ids += n;
+        if (tok[0] != tokH || val[0] != valH) ++differingBins;
+    }
 }
 
 void Context::gatherBlocks()
@@ -471,9 +552,21 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             S.items.reserve((size_t)count * S_PE_COUNT);
             uint64_t inBytes = 0;
             // device-side quality path: per bin the place of its packed scores in the input; the gathered streams' places
-            std::vector<uint64_t> packedOff(count, 0); std::vector<uint32_t> gatherItems; uint64_t gatherBytes = 0, nStrings = 0, gatherSymbols = 0;
+            std::vector<uint64_t> packedOff(count, 0), nFirst(count, 0); std::vector<uint32_t> gatherItems; uint64_t gatherBytes = 0, nStrings = 0, gatherSymbols = 0, nListBytes = 0;
+            uint32_t gatherBits = 0;
+            std::vector<uint32_t> idItems;
             // --lossy libraries: one read-only model blob per library in front of the streams
             std::vector<uint64_t> qvzOff(archives.size(), ~0ull);
+            // device-side read-id tokeniser: one field table per library in the input, per bin its packed headers, its job
+            std::vector<uint64_t> idTabOff(archives.size(), ~0ull); std::vector<std::vector<uint8_t>> idTab(archives.size());
+            std::vector<uint32_t> idTok(archives.size(), 0), idVal(archives.size(), 0);
+            std::vector<uint64_t> headOff(count, 0); std::vector<fsdev::IdJob> idJobs; std::vector<uint32_t> idJobBin; uint64_t idBytes = 0, nIdStrings = 0;
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t b = byWork[first + k], a = binArch[b];
+                if (st[b].idRefs.empty() || idTabOff[a] != ~0ull) continue;
+                idFieldBlob(archives[a].head, idTab[a], idTok[a], idVal[a]);
+                idTabOff[a] = inBytes; inBytes += (idTab[a].size() + 15) & ~15ull;
+            }
             for (uint32_t k = 0; k < count; ++k) {
                 const uint32_t a = binArch[byWork[first + k]];
                 if (archives[a].cfg.quaParams.method != MET_QVZ || qvzOff[a] != ~0ull) continue;
@@ -495,21 +588,47 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 for (uint32_t s = 0; s < bs.nStreams; ++s) {
                     const bool rc = streamIsRangeCoded(s, qm);
                     if (s == S_Quality && !bs.quaRefs.empty()) {       // device-side quality path: the stream is gathered on the device
-                        if (rc || !bs.quaPacked) throw std::runtime_error("quality references without packed scores");
+                        if (!bs.quaPacked || qm == MET_QVZ) throw std::runtime_error("quality references without packed scores");
+                        const uint32_t bits = qm == MET_NONE ? 6u : (qm == MET_8BIN ? 3u : 1u);
+                        if (gatherBits && gatherBits != bits) throw std::runtime_error("libraries of different quality modes in one device batch");
+                        gatherBits = bits;
+                        if (bs.quaSymbols > 0x70000000ull) throw std::runtime_error("stream larger than 4 GiB");
                         StreamItem it; memset(&it, 0, sizeof it);
-                        it.bin = k; it.kind = KIND_PPMD; it.in_len = (uint32_t)bs.quaSymbols; it.out_cap = (uint32_t)(bs.quaSymbols + bs.quaSymbols / 8 + 64);
-                        if (bs.quaSymbols > 0xF0000000ull) throw std::runtime_error("stream larger than 4 GiB");
+                        it.bin = k;
+                        const uint64_t outBytes = rc ? 2ull * bs.quaSymbols : bs.quaSymbols;      // (symbol, context) pairs for the range coder, bytes for PPMd
+                        if (rc) { it.kind = KIND_RC_BASE + streamModel(s, qm); it.in_len = (uint32_t)bs.quaSymbols; it.out_cap = 2 * it.in_len + 32; pl.work_size[s] = ~0ull; }
+                        else { it.kind = KIND_PPMD; it.in_len = (uint32_t)bs.quaSymbols; it.out_cap = (uint32_t)(bs.quaSymbols + bs.quaSymbols / 8 + 64); pl.work_size[s] = bs.quaSymbols; }
                         it.in_off = gatherBytes;                         // relative to the gather region for now (its base is known after the layout)
-                        gatherBytes += (bs.quaSymbols + 15u + 16u) & ~15ull;
+                        gatherBytes += (outBytes + 15u + 16u) & ~15ull;
                         gatherItems.push_back((uint32_t)S.items.size());
-                        pl.work_size[s] = bs.quaSymbols;
                         S.items.push_back(it);
                         packedOff[k] = inBytes; inBytes += (bs.quaPackedBytes + 8u + 15u) & ~15ull;
+                        nFirst[k] = nListBytes; nListBytes += bs.quaN.size();
                         nStrings += bs.quaRefs.size(); gatherSymbols += bs.quaSymbols;
                         continue;
                     }
                     const uint64_t bytes = bs.s[s].size();
                     if (bytes > 0xF0000000ull) throw std::runtime_error("stream larger than 4 GiB");
+                    if ((s == S_IdToken || s == S_IdValue) && !bs.idRefs.empty()) {      // tokenised on the device: in_len is set there (here: its bound)
+                        const uint32_t a = binArch[b];
+                        uint32_t model = streamModel(s, qm); if (model == 5 && archives[a].head.fields.size() <= 16) model = 6;
+                        StreamItem it; memset(&it, 0, sizeof it);
+                        const uint64_t pairs = (uint64_t)bs.idRefs.size() * (s == S_IdToken ? idTok[a] : idVal[a]);
+                        if (pairs > 0x70000000ull) throw std::runtime_error("stream larger than 4 GiB");
+                        it.bin = k; it.kind = KIND_RC_BASE + model; it.in_len = (uint32_t)pairs; it.out_cap = 2 * it.in_len + 32; pl.work_size[s] = ~0ull;
+                        it.in_off = idBytes;                             // relative to the read-id part of the device-only region for now
+                        if (s == S_IdToken) {
+                            fsdev::IdJob j; memset(&j, 0, sizeof j);
+                            j.first = (uint32_t)nIdStrings; j.count = (uint32_t)bs.idRefs.size(); j.tok_item = (uint32_t)S.items.size(); j.tok_out = idBytes; j.table_off = idTabOff[a];
+                            idJobs.push_back(j); idJobBin.push_back(k);
+                            nIdStrings += bs.idRefs.size();
+                            headOff[k] = inBytes; inBytes += (bs.headPackedBytes + 8u + 15u) & ~15ull;
+                        } else { idJobs.back().val_item = (uint32_t)S.items.size(); idJobs.back().val_out = idBytes; }
+                        idBytes += (2 * pairs + 15u + 16u) & ~15ull;
+                        idItems.push_back((uint32_t)S.items.size());
+                        S.items.push_back(it);
+                        continue;
+                    }
                     StreamItem it; memset(&it, 0, sizeof it);
                     it.bin = k; it.in_off = inBytes;
                     // header-less archives never create the read-id coders: their streams stay empty (FastqCompressor.cpp:923-930)
@@ -525,18 +644,52 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                     inBytes += (bytes + 15) & ~15ull;
                 }
             }
-            fsdev::GatherPlan gp;
+            fsdev::GatherPlan gp; uint64_t gatherBaseQ = 0;
             if (nStrings) {
                 if (nStrings > 0xFFFFFFF0ull || gatherBytes > 0xF0000000ull) throw std::runtime_error("quality gather larger than 4 GiB");
-                gp.desc_off = inBytes; gp.n_strings = (uint32_t)nStrings; gp.out_bytes = gatherBytes; gp.symbols = gatherSymbols;
-                inBytes += (nStrings * sizeof(fsdev::QuaString) + 15u) & ~15ull;
+                gp.desc_off = inBytes; gp.n_strings = (uint32_t)nStrings; gp.out_bytes = gatherBytes; gp.symbols = gatherSymbols; gp.bits = gatherBits;
+                inBytes += (nStrings * (gatherBits == 6u ? sizeof(fsdev::QuaString) : sizeof(fsdev::QuaPairString)) + 15u) & ~15ull;
+                if (gatherBits != 6u) {
+                    if (nListBytes > 0xFFFFFFF0ull) throw std::runtime_error("quality gather larger than 4 GiB");
+                    gp.n_list_off = inBytes; gp.n_list_bytes = nListBytes; inBytes += (nListBytes + 15u) & ~15ull;
+                    // a stored 0 / 1 stands for the scores 6 / 40 (FastqPacker); the coded symbol is the score against the archive's threshold
+                    const uint32_t thr = archives[binArch[byWork[first]]].cfg.quaParams.binaryThreshold;
+                    gp.sym_of_bit[0] = 6u >= thr ? 1u : 0u; gp.sym_of_bit[1] = 40u >= thr ? 1u : 0u;
+                }
+                gatherBaseQ = (inBytes + 15u) & ~15ull;
+                for (uint32_t gi : gatherItems) S.items[gi].in_off += gatherBaseQ;
+            }
+            fsdev::IdPlan ip;
+            if (!idJobs.empty()) {
+                if (nIdStrings > 0xFFFFFFF0ull || gatherBytes + idBytes > 0xF0000000ull) throw std::runtime_error("read-id streams larger than 4 GiB");
+                ip.n_jobs = (uint32_t)idJobs.size(); ip.n_strings = (uint32_t)nIdStrings; ip.out_bytes = idBytes;
+                ip.jobs_off = inBytes; inBytes += (idJobs.size() * sizeof(fsdev::IdJob) + 15u) & ~15ull;
+                ip.strings_off = inBytes; inBytes += (nIdStrings * sizeof(fsdev::IdString) + 15u) & ~15ull;
                 const uint64_t gatherBase = (inBytes + 15u) & ~15ull;
-                for (uint32_t gi : gatherItems) S.items[gi].in_off += gatherBase;
+                // (the quality part's items were based on an input that has grown since: base them again)
+                if (nStrings) for (uint32_t gi : gatherItems) S.items[gi].in_off += gatherBase - gatherBaseQ;
+                for (uint32_t gi : idItems) S.items[gi].in_off += gatherBase + gatherBytes;
+                for (fsdev::IdJob& j : idJobs) { j.tok_out += gatherBytes; j.val_out += gatherBytes; }
             }
             fsengine::Device* L = lanes[(uint32_t)S.lane];
             uint8_t* input = fsengine::staging_buffer(L, inBytes + 16);        // pinned host memory owned by the lane
             if (!input) throw std::runtime_error(std::string("device: ") + L->err);
             for (size_t a = 0; a < archives.size(); ++a) if (qvzOff[a] != ~0ull) memcpy(input + qvzOff[a], archives[a].qvz.blob.data(), archives[a].qvz.blob.size());
+            for (size_t a = 0; a < archives.size(); ++a) if (idTabOff[a] != ~0ull) memcpy(input + idTabOff[a], idTab[a].data(), idTab[a].size());
+            if (!idJobs.empty()) {
+                memcpy(input + ip.jobs_off, idJobs.data(), idJobs.size() * sizeof(fsdev::IdJob));
+                parallelFor((uint32_t)idJobs.size(), 4, [&](uint32_t j, uint32_t) {
+                    const uint32_t k = idJobBin[j], b = byWork[first + k];
+                    memcpy(input + headOff[k], st[b].headPacked, st[b].headPackedBytes);
+                    memset(input + headOff[k] + st[b].headPackedBytes, 0, 8);
+                    fsdev::IdString* ss = (fsdev::IdString*)(input + ip.strings_off) + idJobs[j].first;
+                    const uint64_t maxBit = 8ull * st[b].headPackedBytes;
+                    for (const IdRef& r : st[b].idRefs) {
+                        if (r.len > 1u && (uint64_t)r.bit + 7ull * (r.len - 1u) > maxBit) throw std::runtime_error("Corrupted bin: read id outside the bin's header bytes");
+                        ss->src_bit = 8ull * headOff[k] + r.bit; ss->len = r.len; ss->pad = 0; ++ss;
+                    }
+                });
+            }
             // staging copy on a few helper threads of its own (the host threads are busy with the next slices' front end)
             std::vector<uint64_t> stringBase(count + 1, 0);          // first descriptor of every bin
             if (nStrings) for (uint32_t k = 0; k < count; ++k) stringBase[k + 1] = stringBase[k] + st[byWork[first + k]].quaRefs.size();
@@ -551,20 +704,31 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 if (gathered) {
                     memcpy(input + packedOff[k], st[b].quaPacked, st[b].quaPackedBytes);
                     memset(input + packedOff[k] + st[b].quaPackedBytes, 0, 8);
-                    fsdev::QuaString* qs = (fsdev::QuaString*)(input + gp.desc_off) + stringBase[k];
                     // the stream's place in the gather region, relative to its base (in_off is absolute: the base is the
                     // input size rounded up to 16, see encode_batch)
                     uint64_t dst = S.items[pl.first_item + S_Quality].in_off - ((inBytes + 15u) & ~15ull);
                     const uint64_t srcBase = 8ull * packedOff[k], maxBit = 8ull * st[b].quaPackedBytes;
-                    for (const QuaRef& r : st[b].quaRefs) {
-                        if ((uint64_t)r.bit + 6ull * r.len > maxBit) throw std::runtime_error("Corrupted bin: quality string outside the bin's quality bytes");
-                        qs->src_bit = srcBase + r.bit; qs->dst_off = (uint32_t)dst; qs->len = r.len; qs->reverse = r.reverse; ++qs;
-                        dst += r.len;
+                    if (gp.bits == 6u) {
+                        fsdev::QuaString* qs = (fsdev::QuaString*)(input + gp.desc_off) + stringBase[k];
+                        for (const QuaRef& r : st[b].quaRefs) {
+                            if ((uint64_t)r.bit + 6ull * r.len > maxBit) throw std::runtime_error("Corrupted bin: quality string outside the bin's quality bytes");
+                            qs->src_bit = srcBase + r.bit; qs->dst_off = (uint32_t)dst; qs->len = r.len; qs->reverse = r.reverse; ++qs;
+                            dst += r.len;
+                        }
+                    } else {
+                        fsdev::QuaPairString* qs = (fsdev::QuaPairString*)(input + gp.desc_off) + stringBase[k];
+                        if (!st[b].quaN.empty()) memcpy(input + gp.n_list_off + nFirst[k], st[b].quaN.data(), st[b].quaN.size());
+                        dst /= 2;                                       // pairs
+                        for (const QuaRef& r : st[b].quaRefs) {
+                            if ((uint64_t)r.bit + (uint64_t)gp.bits * r.len > maxBit) throw std::runtime_error("Corrupted bin: quality string outside the bin's quality bytes");
+                            qs->src_bit = srcBase + r.bit; qs->dst_off = (uint32_t)dst; qs->n_off = (uint32_t)(nFirst[k] + r.nFirst); qs->len = r.len; qs->reverse = r.reverse; qs->n_count = r.nCount; ++qs;
+                            dst += r.len - r.nCount;
+                        }
                     }
                 }
             });
             S.tSubmit = nowMs(); S.inBytes = inBytes;
-            if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, sliceBlocks[si], S.sizes, &S.timing, nStrings ? &gp : nullptr) != 0) S.err = std::string("device: ") + L->err;
+            if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, sliceBlocks[si], S.sizes, &S.timing, nStrings ? &gp : nullptr, idJobs.empty() ? nullptr : &ip) != 0) S.err = std::string("device: ") + L->err;
         } catch (const std::exception& e) { S.err = e.what(); }
         S.tDone = nowMs();
         { std::lock_guard<std::mutex> lk(laneMx); freeLanes.push_back((uint32_t)S.lane); }
@@ -661,7 +825,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         timing.encode_ms += S.timing.encode_ms; timing.assemble_ms += S.timing.assemble_ms; timing.launches += S.timing.launches; timing.items += S.timing.items;
         timing.ppmd_symbols += S.timing.ppmd_symbols; timing.rc_symbols += S.timing.rc_symbols; timing.restarts += S.timing.restarts; for (int w = 0; w < 16; ++w) timing.win[w] += S.timing.win[w];
         timing.h2d_bytes += S.timing.h2d_bytes; timing.d2h_bytes += S.timing.d2h_bytes;
-        timing.gather_ms += S.timing.gather_ms; timing.gather_symbols += S.timing.gather_symbols; timing.gather_bytes += S.timing.gather_bytes;
+        timing.gather_ms += S.timing.gather_ms; timing.gather_symbols += S.timing.gather_symbols; timing.gather_bytes += S.timing.gather_bytes; timing.id_strings += S.timing.id_strings;
         if (trace) fprintf(stderr, "[trace] slice %u/%u: %u bins, front end done at %.1f ms, staged+submitted at %.1f ms, device done at %.1f ms (kernel %.1f ms)\n",
                            si + 1, nSlices, cut[si + 1] - cut[si], S.tReady - t0, S.tSubmit - t0, S.tDone - t0, S.timing.encode_ms);
     }
@@ -839,19 +1003,26 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             const uint32_t nb = (uint32_t)(next - first);
             // record arrays are placed: their sizes are in the .bmeta footer, so every bin knows its offsets up front and
             // is unpacked by the same host task that runs its front end (no barrier between the two stages)
-            std::vector<uint64_t> seqBase(nb + 1, 0), headBase(nb + 1, 0), recBase(nb + 1, 0), quaBase(nb + 1, 0), weight(nb);
+            std::vector<uint64_t> seqBase(nb + 1, 0), headBase(nb + 1, 0), recBase(nb + 1, 0), quaBase(nb + 1, 0), hpBase(nb + 1, 0), weight(nb);
+            // device-side read-id tokeniser: the headers stay packed too (FS_DEVICE_IDS=0: host tokeniser)
+            bool packedH = !(getenv("FS_DEVICE_IDS") && atoi(getenv("FS_DEVICE_IDS")) == 0);
+            for (uint32_t k = 0; k < nb; ++k) if (!libs[work[first + k].lib]->bf.usesHeaders()) packedH = false;
             // device-side quality path: lossless archives keep their scores packed (fs_gather_quality unpacks, orients and
             // orders them on the device); FS_DEVICE_QUALITY=0 keeps the host symbolisation (A/B runs)
             bool packedQ = !(getenv("FS_DEVICE_QUALITY") && atoi(getenv("FS_DEVICE_QUALITY")) == 0);
-            for (uint32_t k = 0; k < nb; ++k) if (archives[work[first + k].lib].cfg.quaParams.method != MET_NONE) packedQ = false;
+            // (all libraries of the batch must share one mode: lossless bytes, or the (symbol, context) pairs of 8-bin / binary)
+            for (uint32_t k = 0; k < nb; ++k) { const uint32_t qmk = archives[work[first + k].lib].cfg.quaParams.method; if (qmk == MET_QVZ || qmk != archives[work[first].lib].cfg.quaParams.method) packedQ = false; }
             for (uint32_t k = 0; k < nb; ++k) {
                 const BinInfo& bi = libs[work[first + k].lib]->bf.bins().at(work[first + k].sig);
                 seqBase[k + 1] = seqBase[k] + bi.totalRawDnaSize; headBase[k + 1] = headBase[k] + bi.totalRawHeadSize; recBase[k + 1] = recBase[k] + bi.totalRecordsCount;
                 quaBase[k + 1] = quaBase[k] + ((bi.totalQuaSize + 15u) & ~15ull);
+                hpBase[k + 1] = hpBase[k] + ((bi.totalHeadSize + 15u) & ~15ull);
                 weight[k] = bi.totalRecordsCount;
             }
             if (seqBase[nb] > 0xFFFFFFF0ull || headBase[nb] > 0xFFFFFFF0ull || recBase[nb] > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB");
-            batch.seq.resize(seqBase[nb]); batch.head.resize(headBase[nb]); batch.recs.resize(recBase[nb]);
+            batch.seq.resize(seqBase[nb]); batch.recs.resize(recBase[nb]);
+            if (packedH) { batch.head.clear(); batch.headPacked.resize(hpBase[nb]); batch.headBit.resize(recBase[nb]); }
+            else { batch.head.resize(headBase[nb]); batch.headPacked.clear(); batch.headBit.clear(); }
             {   // the largest bin's matcher tables: a read and at most one root copy per record, a construction per sub-tree
                 // (fewer than records) + the pieces of the top-level one, a full window of warm-up entries per piece
                 uint64_t mr = 0, ms = 0;
@@ -877,11 +1048,12 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             compressBins(nb, weight, binArch, [&](uint32_t k, BinEncoder& enc, BinStreams& out, BinIn& info, uint64_t& recBytes) {
                 const Work& w = work[first + k];
                 const double tu = getenv("FS_BIN_TRACE") ? nowMs() : 0;
-                libs[w.lib]->bf.unpackPlaced(w.sig, batch, seqBase[k], headBase[k], (uint32_t)recBase[k], graph[k], packedQ ? (int64_t)quaBase[k] : -1);
+                libs[w.lib]->bf.unpackPlaced(w.sig, batch, seqBase[k], headBase[k], (uint32_t)recBase[k], graph[k], packedQ ? (int64_t)quaBase[k] : -1, packedH ? (int64_t)hpBase[k] : -1);
                 if (tu > 0 && recBase[k + 1] - recBase[k] >= 40000) fprintf(stderr, "[bin] %llu records: unpack %.1f ms\n", (unsigned long long)(recBase[k + 1] - recBase[k]), nowMs() - tu);
                 info = graph[k].bins.at(0);
                 enc.encodeLz(batch, graph[k], info, archives[w.lib], out);
                 if (packedQ) { out.quaPacked = batch.quaPacked.data() + quaBase[k]; out.quaPackedBytes = libs[w.lib]->bf.bins().at(w.sig).totalQuaSize; }
+                if (packedH) { out.headPacked = batch.headPacked.data() + hpBase[k]; out.headPackedBytes = libs[w.lib]->bf.bins().at(w.sig).totalHeadSize; }
                 recBytes = 2ull * (seqBase[k + 1] - seqBase[k]) + (headBase[k + 1] - headBase[k]);
                 graph[k] = Batch();
             });

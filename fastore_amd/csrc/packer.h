@@ -105,6 +105,8 @@ struct Context {
     std::atomic<uint64_t> matchedReads{0}, matchUs{0}, matchKernelUs{0};
     MatchFn matcherFor(uint32_t tid);
     void matcherCheck(const std::string& inPrefix, uint64_t& reads, uint64_t& differing);
+    // parity check of the device tokeniser: every standard bin's read ids through the host tokeniser and through fs_tokenise_ids
+    void tokeniserCheck(const std::string& inPrefix, uint64_t& ids, uint64_t& differingBins);
     // merged small bins + N bin (batch with ONE bin, records already in stored order): RawCompressorSE/PE
     void compressRawBlock(Batch& batch, const ArchiveParams& arch, std::vector<uint8_t>& out) const;
     // `fastore_pack e` for one or several libraries; bins of all libraries share the device batches

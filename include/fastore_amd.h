@@ -109,6 +109,7 @@ typedef struct fsgpu_stats {
     /* device-side read matcher (matcher.hip): reads searched, time the host threads spent in its calls (summed over the
      * threads: upload, kernels, download, waiting), HIP-event time of its kernels (summed over the calls) */
     uint64_t matcher_reads; double matcher_call_ms, matcher_kernel_ms;
+    uint64_t tokenised_ids;              /* read ids split into the IdToken / IdValue streams by fs_tokenise_ids (device) */
 } fsgpu_stats;
 
 void fsgpu_config_defaults(fsgpu_config* cfg);
@@ -159,11 +160,25 @@ typedef struct fsgpu_quality_string { uint64_t src_bit; uint32_t len; uint32_t r
 int fsgpu_gather_quality(fsgpu_ctx* ctx, const uint8_t* packed, size_t packed_bytes, const fsgpu_quality_string* strings,
                          size_t n_strings, uint8_t* out, size_t out_cap, size_t* out_len);
 
+/* The same for 8-bin (`bits` = 3) and binary (`bits` = 1) archives (MET_8BIN / MET_BINARY, FastqCompressor.cpp:249-316): the
+ * stream is (symbol, context) byte pairs for the order-k range coder, positions under an 'N' base (n_positions: stored
+ * indices inside the string) are left out; binary_threshold maps a stored bit (score 6 / 40) to the coded symbol.
+ * out receives the pairs (2 bytes each), *out_pairs their number. */
+typedef struct fsgpu_quality_string_n { uint64_t src_bit; uint32_t len; uint32_t reverse; const uint8_t* n_positions; uint32_t n_count; } fsgpu_quality_string_n;
+int fsgpu_gather_quality_binned(fsgpu_ctx* ctx, const uint8_t* packed, size_t packed_bytes, uint32_t bits, uint32_t binary_threshold,
+                                const fsgpu_quality_string_n* strings, size_t n_strings, uint8_t* out, size_t out_cap_pairs, size_t* out_pairs);
+
 /* Parity check of the device-side read matcher (matcher.hip; ReadsClassifierSE::ConstructMatchTree's window search,
  * fastore_pack/ReadsClassifier.cpp:55-83, 95-442): every standard bin of the library <in_prefix> goes through the host's
  * serial window scan and through the device; *reads = reads searched, *differing = rows (matched read, cost, shift,
  * mismatch-free flag, exact-duplicate flag) on which the two disagree. */
 int fsgpu_matcher_check(fsgpu_ctx* ctx, const char* in_prefix, uint64_t* reads, uint64_t* differing);
+
+/* Parity check of the device-side read-id tokeniser (fs_tokenise_ids; IHeaderStoreBase::CompressReadId, fastore_pack/
+ * FastqCompressor.cpp:504-583): every standard bin's read ids, in stored order, through the host's restatement (unpacked
+ * headers) and through the kernel (packed .bhead bytes); *ids = read ids tokenised, *differing_bins = bins whose IdToken or
+ * IdValue pair stream differs. */
+int fsgpu_tokeniser_check(fsgpu_ctx* ctx, const char* in_prefix, uint64_t* ids, uint64_t* differing_bins);
 
 /* Whole `fastore_pack e -i<in_prefix> -o<out_prefix>`: reads .bmeta/.bdna/.bqua/.bhead, writes
  * .cmeta/.cdata in the reference's -t1 block order. */

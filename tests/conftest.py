@@ -171,3 +171,37 @@ def quality_gather_case(seed, n_strings=400, max_len=310):
     for (b, n, r) in strings:
         chunks.append(bytes(expect[p2:p2 + n])); p2 += n
     return packed, [strings[i] for i in order], b"".join(chunks[i] for i in order)
+
+
+def quality_gather_binned_case(seed, bits, threshold=20, n_strings=300, max_len=255):
+    """Random packed 8-bin (3-bit) / binary (1-bit) scores, emitted strings with 'N' positions, and the expected (symbol, context)
+    pairs -- numpy restatement of IQualityStoreBase::CompressReadQuality for MET_8BIN / MET_BINARY (fastore_pack/
+    FastqCompressor.cpp:249-316): positions under an 'N' are skipped, context = emitted index * 8 (2) / length; a stored bit
+    stands for the scores 6 / 40 (FastqPacker) and is coded as score >= threshold; the stored 3-bit value is the bin index."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    lens = [1, 2, 3, 7, 8, 9, 63, 64, 65, 150, 151, max_len] + [int(x) for x in rng.integers(1, max_len + 1, n_strings)]
+    total = sum(lens) + 3 * len(lens) + 16
+    vals = rng.integers(0, 1 << bits, total, dtype=np.uint8)
+    b = np.unpackbits(vals[:, None], axis=1)[:, 8 - bits:]
+    packed = np.packbits(b.reshape(-1)).tobytes() + b"\0" * 4
+    strings, chunks, pos = [], [], 0
+    for n in lens:
+        rev = bool(rng.integers(0, 2))
+        k = int(rng.integers(0, 4)) if n > 4 else 0
+        npos = sorted(set(int(x) for x in rng.integers(0, n, k)))
+        if len(npos) >= n:
+            npos = []
+        strings.append((bits * pos, n, rev, bytes(npos)))
+        out = bytearray()
+        for i in range(n):
+            ii = n - 1 - i if rev else i
+            if ii in npos:
+                continue
+            v = int(vals[pos + ii])
+            sym = v if bits == 3 else (1 if (40 if v else 6) >= threshold else 0)
+            out += bytes([sym, i * (8 if bits == 3 else 2) // n])
+        chunks.append(bytes(out))
+        pos += n + int(rng.integers(0, 3))
+    order = rng.permutation(len(strings))
+    return packed, [strings[i] for i in order], b"".join(chunks[i] for i in order)

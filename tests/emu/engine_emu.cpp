@@ -60,6 +60,26 @@ static void putBe(uint8_t*& h, uint64_t v, int n) { for (int i = 0; i < n; ++i) 
 // what fs_gather_quality does, one string after the other (the staging buffer has room behind the uploaded bytes)
 static void gatherQuality(uint8_t* buf, size_t inputBytes, const GatherPlan& g)
 {
+    if (g.bits != 6u) {                                            // 8-bin / binary: (symbol, context) pairs, positions under 'N' left out
+        const QuaPairString* qs = (const QuaPairString*)(buf + g.desc_off);
+        uint8_t* out = buf + ((inputBytes + 15u) & ~(size_t)15u);
+        const uint8_t* nl = buf + g.n_list_off;
+        for (uint32_t i = 0; i < g.n_strings; ++i) {
+            uint32_t at = qs[i].dst_off;
+            for (uint32_t j = 0; j < qs[i].len; ++j) {
+                const uint32_t ii = qs[i].reverse ? qs[i].len - 1u - j : j;
+                bool isN = false;
+                for (uint32_t t = 0; t < qs[i].n_count; ++t) isN = isN || nl[qs[i].n_off + t] == ii;
+                if (isN) continue;
+                const uint64_t bit = qs[i].src_bit + (uint64_t)g.bits * ii;
+                const uint32_t w = ((uint32_t)buf[bit >> 3] << 8) | buf[(bit >> 3) + 1];
+                uint32_t sym = (w >> (16u - g.bits - (uint32_t)(bit & 7u))) & ((1u << g.bits) - 1u);
+                if (g.bits == 1u) sym = g.sym_of_bit[sym];
+                out[2 * at] = (uint8_t)sym; out[2 * at + 1] = (uint8_t)(j * (g.bits == 3u ? 8u : 2u) / qs[i].len); ++at;
+            }
+        }
+        return;
+    }
     const QuaString* qs = (const QuaString*)(buf + g.desc_off);
     uint8_t* out = buf + ((inputBytes + 15u) & ~(size_t)15u);
     for (uint32_t i = 0; i < g.n_strings; ++i)
@@ -117,6 +137,65 @@ int match_reads(Device*, MatchLane*, const uint8_t* seq, size_t, const MatchRead
     return 0;
 }
 
+// what fs_tokenise_ids does, one read id after the other (work = the device's input buffer with room behind the input)
+static void tokeniseIds(uint8_t* buf, size_t inputBytes, const IdPlan& p, std::vector<StreamItem>& items)
+{
+    const IdJob* jobs = (const IdJob*)(buf + p.jobs_off); const IdString* ss = (const IdString*)(buf + p.strings_off);
+    uint8_t* out = buf + ((inputBytes + 15u) & ~(size_t)15u);
+    for (uint32_t j = 0; j < p.n_jobs; ++j) {
+        const IdJob& job = jobs[j];
+        const uint8_t* tab = buf + job.table_off;
+        const uint32_t nf = *(const uint32_t*)tab; const IdField* F = (const IdField*)(tab + 8);
+        uint32_t nt = 0, nv = 0;
+        for (uint32_t r = 0; r < job.count; ++r) {
+            const IdString& s = ss[job.first + r];
+            std::vector<uint8_t> h(s.len);
+            for (uint32_t k = 0; k < s.len; ++k) {
+                if (k == 0) { h[0] = '@'; continue; }
+                const uint64_t bit = s.src_bit + 7ull * (k - 1);
+                h[k] = (uint8_t)(((((uint32_t)buf[bit >> 3] << 8) | buf[(bit >> 3) + 1]) >> (9u - (uint32_t)(bit & 7u))) & 127u);
+            }
+            uint32_t fieldStart = 0, fi = 0;
+            for (uint32_t i = 0; i <= s.len; ++i) {
+                if (fi >= nf) break;
+                const IdField& f = F[fi];
+                if (i != s.len && h[i] != f.separator) continue;
+                if (!f.is_const) {
+                    const uint32_t fl = i - fieldStart;
+                    if (!f.is_numeric) {
+                        uint32_t id = f.n_values; const uint32_t* vl = (const uint32_t*)(tab + f.values_off);
+                        for (uint32_t v = 0; v < f.n_values && id == f.n_values; ++v) if (vl[2 * v + 1] == fl && memcmp(tab + vl[2 * v], h.data() + fieldStart, fl) == 0) id = v;
+                        out[job.tok_out + 2ull * nt] = (uint8_t)id; out[job.tok_out + 2ull * nt + 1] = (uint8_t)fi; ++nt;
+                    } else {
+                        uint64_t v = 0;
+                        for (uint32_t k = 0; k < fl; ++k) { const uint8_t c = h[fieldStart + k]; if (c < '0' || c > '9') break; v = v * 10 + (c - '0'); }
+                        const int64_t diff = (int64_t)(v - f.min_value); uint32_t ctx = fi << 2;
+                        for (int32_t q = (int32_t)f.plog; q >= 0; --q) { out[job.val_out + 2ull * nv] = (uint8_t)((diff >> (8 * q)) & 0xFF); out[job.val_out + 2ull * nv + 1] = (uint8_t)ctx; ++ctx; ++nv; }
+                    }
+                }
+                fieldStart = i + 1; ++fi;
+            }
+        }
+        items[job.tok_item].in_len = nt; items[job.val_item].in_len = nv;
+    }
+}
+
+int tokenise_ids_raw(Device*, const uint8_t* input, size_t inputBytes, const IdPlan& plan, std::vector<std::vector<uint8_t>>& tok, std::vector<std::vector<uint8_t>>& val)
+{
+    std::vector<uint8_t> work(((inputBytes + 15u) & ~(size_t)15u) + plan.out_bytes + 64);
+    memcpy(work.data(), input, inputBytes);
+    std::vector<StreamItem> items(2 * (size_t)plan.n_jobs); memset(items.data(), 0, items.size() * sizeof(StreamItem));
+    tokeniseIds(work.data(), inputBytes, plan, items);
+    const IdJob* jb = (const IdJob*)(input + plan.jobs_off);
+    const uint8_t* out = work.data() + ((inputBytes + 15u) & ~(size_t)15u);
+    tok.assign(plan.n_jobs, {}); val.assign(plan.n_jobs, {});
+    for (uint32_t j = 0; j < plan.n_jobs; ++j) {
+        tok[j].assign(out + jb[j].tok_out, out + jb[j].tok_out + 2ull * items[2 * j].in_len);
+        val[j].assign(out + jb[j].val_out, out + jb[j].val_out + 2ull * items[2 * j + 1].in_len);
+    }
+    return 0;
+}
+
 int gather_quality_raw(Device*, const uint8_t* input, size_t inputBytes, const GatherPlan& plan, std::vector<uint8_t>& out, BatchTiming* t)
 {
     std::vector<uint8_t> work(((inputBytes + 15u) & ~(size_t)15u) + plan.out_bytes + 64);
@@ -128,16 +207,18 @@ int gather_quality_raw(Device*, const uint8_t* input, size_t inputBytes, const G
 }
 
 int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items, std::vector<BlockPlan>& plans,
-                 std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes, BatchTiming* t, const GatherPlan* gather)
+                 std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes, BatchTiming* t, const GatherPlan* gather, const IdPlan* ids)
 {
     std::vector<uint8_t> scratch; std::vector<uint32_t> sizes;
     std::vector<uint8_t> work;                          // the device's input buffer: uploaded bytes + gather region
-    if (gather && gather->n_strings) {
-        work.resize(((inputBytes + 15u) & ~(size_t)15u) + gather->out_bytes + 64);
+    if ((gather && gather->n_strings) || (ids && ids->n_jobs)) {
+        work.resize(((inputBytes + 15u) & ~(size_t)15u) + (gather ? gather->out_bytes : 0) + (ids ? ids->out_bytes : 0) + 64);
         memcpy(work.data(), input, inputBytes);
-        gatherQuality(work.data(), inputBytes, *gather);
+        if (gather && gather->n_strings) gatherQuality(work.data(), inputBytes, *gather);
+        if (ids && ids->n_jobs) tokeniseIds(work.data(), inputBytes, *ids, items);
         input = work.data();
-        if (t) { t->gather_symbols += gather->symbols; }
+        if (t && gather) { t->gather_symbols += gather->symbols; }
+        if (t && ids) t->id_strings += ids->n_strings;
     }
     runItems(input, items, scratch, sizes, t);
     for (size_t i = 0; i < items.size(); ++i) {

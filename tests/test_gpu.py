@@ -319,11 +319,21 @@ def test_gather_quality_device_matches_the_restated_unpack(packer):
     assert st["gather_symbols"] > 0 and st["gather_kernel_ms"] > 0
 
 
-def test_gpu_quality_streams_come_from_the_device_gather(tmp_path, monkeypatch):
+def test_gather_quality_pairs_device_matches_the_restated_symbolisation(packer):
+    # fs_gather_quality_pairs (8-bin and binary archives): 3- and 1-bit scores, 'N' positions left out, contexts by emitted
+    # index, thresholds that map the stored bit either way -- against the numpy restatement
+    from conftest import quality_gather_binned_case
+    for bits, thr in ((3, 20), (1, 20), (1, 5), (1, 41)):
+        packed, strings, expect = quality_gather_binned_case(100 + bits + thr, bits, thr, n_strings=2000)
+        assert packer.gather_quality_binned(packed, bits, thr, strings) == expect, (bits, thr)
+
+
+@pytest.mark.parametrize("which", [0, 2, 4])
+def test_gpu_quality_streams_come_from_the_device_gather(tmp_path, monkeypatch, which):
     # a lossless library packed from .b* files: the scores go to the device packed (six bits each) and the quality
     # streams are built there; the host symbolisation (FS_DEVICE_QUALITY=0) gives the same archive with more H2D bytes
     import fastore_amd
-    name, paired, flags = manifest()[0]
+    name, paired, flags = manifest()[which]              # lossless, 8-bin, binary
     ref = open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
     h2d = {}
     for mode in ("1", "0"):
@@ -371,8 +381,38 @@ def test_device_matcher_on_fresh_libraries_and_same_archive_either_way(tmp_path,
     with fastore_amd.Packer(device_id=0, **kn) as p:
         n, differing = p.matcher_check(binned)
         assert n > reads // 4 and differing == 0, (n, differing)
+        ids, bad_bins = p.tokeniser_check(binned)              # the same libraries through the device tokeniser
+        assert ids > reads // 4 and bad_bins == 0, (ids, bad_bins)
         p.pack_file(binned, os.path.join(t, "dev"))
-    monkeypatch.setenv("FS_DEVICE_MATCHER", "0")
+    monkeypatch.setenv("FS_DEVICE_MATCHER", "0"); monkeypatch.setenv("FS_DEVICE_IDS", "0"); monkeypatch.setenv("FS_DEVICE_QUALITY", "0")
     with fastore_amd.Packer(device_id=0, **kn) as p:
         p.pack_file(binned, os.path.join(t, "host"))
     assert open(os.path.join(t, "dev.cdata"), "rb").read() == open(os.path.join(t, "host.cdata"), "rb").read()
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_gpu_read_id_streams_come_from_the_device_tokeniser(tmp_path, monkeypatch, which):
+    # fs_tokenise_ids: the IdToken / IdValue streams written on the device from the packed headers (SE and PE golden
+    # libraries: a constant token, numeric fields, the pair field) -- the archive is the reference's either way
+    import fastore_amd
+    name, paired, flags = manifest()[which]
+    ref = open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FS_DEVICE_IDS", mode)
+        with fastore_amd.Packer(device_id=0, **knobs_from_flags(flags)) as p:
+            st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o" + mode)))
+        assert open(str(tmp_path / ("o" + mode)) + ".cdata", "rb").read() == ref
+        assert st["tokenised_ids"] == (st["records"] if mode == "1" else 0)
+
+
+def test_device_tokeniser_agrees_with_the_host_tokeniser():
+    # fs_tokenise_ids against the host restatement of IHeaderStoreBase::CompressReadId, bin by bin, on every golden library with
+    # read ids (SE, PE with the pair field, 8-bin, QVZ, bin-stage flavour)
+    import fastore_amd
+    total = 0
+    for name, paired, flags in manifest():
+        with fastore_amd.Packer(device_id=0, **knobs_from_flags(flags)) as p:
+            ids, differing = p.tokeniser_check(os.path.join(GOLDEN, name + ".in"))
+        assert differing == 0, (name, ids, differing)
+        total += ids
+    assert total > 10000

@@ -40,7 +40,7 @@ def test_c_abi_exports_every_declared_symbol(product_lib):
 def test_structs_match_header_layout(product_lib):
     import fastore_amd
     assert ctypes.sizeof(fastore_amd.Config) == 96
-    assert ctypes.sizeof(fastore_amd.Stats) == 264
+    assert ctypes.sizeof(fastore_amd.Stats) == 272
     cfg = fastore_amd.Config()
     product_lib.fsgpu_config_defaults(ctypes.byref(cfg))
     # reference defaults: fastore_pack/Params.h:18-147, fastore_bin/Globals.h:61-62
@@ -383,7 +383,16 @@ def test_quality_gather_emulation_matches_the_restated_unpack(emu_lib):
             p.gather_quality(b"\0" * 8, [(40, 5, False)])
 
 
-@pytest.mark.parametrize("name,paired,flags", [m for m in manifest() if m[0] in ("se_lossless", "pe_lossless", "se_noheader", "se_c0")])
+def test_binned_quality_gather_emulation_matches_the_restated_symbolisation(emu_lib):
+    import fastore_amd
+    from conftest import quality_gather_binned_case
+    with fastore_amd.Packer(lib=emu_lib, device_id=0) as p:
+        for bits, thr in ((3, 20), (1, 20), (1, 5), (1, 41)):
+            packed, strings, expect = quality_gather_binned_case(bits + thr, bits, thr)
+            assert p.gather_quality_binned(packed, bits, thr, strings) == expect, (bits, thr)
+
+
+@pytest.mark.parametrize("name,paired,flags", [m for m in manifest() if m[0] in ("se_lossless", "pe_lossless", "se_noheader", "se_c0", "se_reduced", "se_binary")])
 def test_device_quality_path_is_taken_and_changes_no_byte(emu_lib, tmp_path, monkeypatch, name, paired, flags):
     # lossless archives packed from .b* files keep their scores packed: the quality streams are gathered by the engine
     # (fs_gather_quality on the device), not symbolised by the host front end -- same archive either way
@@ -412,3 +421,33 @@ def test_matcher_table_and_trace_against_the_scalar_restatement(emu_lib, name, p
         with fastore_amd.Packer(lib=emu_lib, device_id=0, **kn) as p:
             reads, differing = p.matcher_check(os.path.join(GOLDEN, name + ".in"))
         assert reads > 1000 and differing == 0, (window, reads, differing)
+
+
+@pytest.mark.parametrize("name,paired,flags", [m for m in manifest() if m[0] != "se_noheader"])
+def test_device_tokeniser_is_taken_and_changes_no_byte(emu_lib, tmp_path, monkeypatch, name, paired, flags):
+    # archives with read ids packed from .b* files keep their headers packed: the IdToken / IdValue streams are written by the
+    # engine (fs_tokenise_ids on the device), not by the host front end -- same archive either way
+    import fastore_amd
+    ref = open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
+    seen = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FS_DEVICE_IDS", mode)
+        with fastore_amd.Packer(lib=emu_lib, device_id=0, **knobs_from_flags(flags)) as p:
+            st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o" + mode)))
+        assert open(str(tmp_path / ("o" + mode)) + ".cdata", "rb").read() == ref
+        seen[mode] = st["tokenised_ids"]
+    has_ids = open(os.path.join(GOLDEN, name + ".in.bmeta"), "rb").read(33)[32] != 0       # usesHeaderStream of the .bmeta header
+    assert seen["0"] == 0 and seen["1"] == (st["records"] if has_ids else 0), seen
+
+
+def test_tokeniser_checker_against_the_scalar_restatement(emu_lib):
+    # the packed-header descriptors, the field-table blob and the parity harness of fs_tokenise_ids, with the test-only scalar
+    # stand-in of the kernel: every standard bin of the golden libraries that carry read ids
+    import fastore_amd
+    total = 0
+    for name, paired, flags in manifest():
+        with fastore_amd.Packer(lib=emu_lib, device_id=0, **knobs_from_flags(flags)) as p:
+            ids, differing = p.tokeniser_check(os.path.join(GOLDEN, name + ".in"))
+        assert differing == 0, (name, ids, differing)
+        total += ids
+    assert total > 10000
