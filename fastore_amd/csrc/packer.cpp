@@ -519,6 +519,15 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     while (nLanes < wantLanes && lane(nLanes)) ++nLanes;
     (void)lane(0);
 
+    // Lanes of the previous batch get the buffers of its best-equipped one now (not at its end: a one-shot run -- the CLI --
+    // would pay for pinned and device memory it never uses): whichever slice a lane gets, nothing has to grow -- and so to
+    // be freed, which waits for every kernel in flight -- while the long streams are being coded.
+    if (equalizeLanes > 1) {
+        const uint32_t n = std::min<uint32_t>(equalizeLanes, (uint32_t)lanes.size());
+        for (uint32_t l = 0; l < n; ++l) (void)fsengine::staging_buffer(lanes[l], equalizeStage);
+        if (fsengine::lanes_equalize(lanes.data(), n) != 0) throw std::runtime_error(std::string("device: ") + lanes[0]->err);
+        equalizeLanes = 0;
+    }
     struct Slice {
         std::vector<StreamItem> items; std::vector<BlockPlan> plans; std::vector<uint64_t> sizes;
         fsengine::BatchTiming timing; std::string err; std::thread th; double tReady = 0, tSubmit = 0, tDone = 0;
@@ -809,10 +818,9 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     if (onHostTasksDone) onHostTasksDone();
     joinAll();
     for (Slice& S : slices) if (!S.err.empty()) throw std::runtime_error(S.err);
-    if (nSlices > 1) {   // any lane may get the largest slice of the next batch: size their pinned staging buffers alike, once
+    if (nSlices > 1) {   // any lane may get the largest slice of the next batch: their buffers are made alike in front of it (see above)
         uint64_t mx = 0; for (Slice& S : slices) mx = std::max(mx, S.inBytes);
-        for (uint32_t l = 0; l < nLanes; ++l) (void)fsengine::staging_buffer(lanes[l], mx + 16);
-        if (fsengine::lanes_equalize(lanes.data(), nLanes) != 0) throw std::runtime_error(std::string("device: ") + lanes[0]->err);
+        equalizeStage = std::max(equalizeStage, mx + 16); equalizeLanes = nLanes;
     }
     stats.frontend_ms += feMs;
     for (uint32_t si = 0; si < nSlices; ++si) {

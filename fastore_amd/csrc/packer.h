@@ -81,6 +81,7 @@ struct Context {
     const uint8_t* blockData(uint32_t b) const { return sliceBlocks[blockSlice[b]].data() + blockOff[b]; }
     void gatherBlocks();
     std::vector<fsengine::Device*> lanes;         // lanes[0] == dev; further engine instances for the pipelined batches
+    uint64_t equalizeStage = 0; uint32_t equalizeLanes = 0;     // pending: make the lanes' buffers alike in front of the next batch
     fsengine::Device* lane(uint32_t i);
     fsgpu_stats stats{};
     fsengine::BatchTiming timing;
