@@ -12,9 +12,12 @@ Workload (BASELINE.json configs[1]): ONE library of 10 M x 150 b
 47 660 reads, so its quality streams run up to 7.15 M PPMd symbols: the shape that decides the device step.
 `--paired` packs ONE library of --reads pairs instead (configs[2] scaled by the stated factor).
 
---gpus N > 1: the N ranks pack disjoint shards (LPT over the .bmeta per-signature totals) of the SAME library
-into one archive; the only collective is an all-reduce of the block-size table (one u64 per block) over RCCL, every
-rank writes its blocks at its own offsets ("scaling": "strong").  `--weak` makes every rank pack the whole library into its own archive.
+--gpus N > 1 (default, "scaling": "weak" -- per-GPU work fixed): the job is a SET of N such libraries (seeds 8 .. 8+N-1,
+prepared side by side, one per rank); every rank codes its LPT share (over the .bmeta per-signature totals) of EVERY
+library's bins in one device pipeline, the only collective is ONE all-reduce of the concatenated block-size tables (one
+u64 per block) over RCCL, every rank writes its blocks at their offsets in the N archives.  `--strong` shards the ONE
+library of the N = 1 run instead (its step is bound by single streams, which more GPUs do not shorten: expect a flat
+curve); `--replicas` makes every rank pack the whole library into its own archive.
 
 cpu_baseline = the real reference fastore_pack (oracle/_ref) on the same library at -t min(32, cores) (and at
 -t1 with --cpu-t1, ~4 min); parity = every block of the product's archive against the reference's block of the same
@@ -112,7 +115,9 @@ def main():
     ap.add_argument("--cpu-t1", action="store_true", help="also time the reference at -t1 on the same library (~4 min)")
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end run of the fastore_pack CLI (process start -> exit)")
     ap.add_argument("--paired", action="store_true", help="ONE paired-end library of --reads pairs: configs[2] scaled, not the default line")
-    ap.add_argument("--weak", action="store_true", help="--gpus N: every rank packs the whole library (replicas) instead of sharding one job")
+    ap.add_argument("--rehearse", action="store_true", help="N ranks on ONE device over gloo (no RCCL): a dry run of the N > 1 code path on a one-GPU box")
+    ap.add_argument("--strong", action="store_true", help="--gpus N: shard the ONE library of the N = 1 run over the ranks (total work fixed)")
+    ap.add_argument("--replicas", "--weak", dest="replicas", action="store_true", help="--gpus N: every rank packs the whole library into its own archive")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -120,8 +125,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.rehearse:
+            local = 0; torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     os.makedirs(args.work, exist_ok=True)
     if rank == 0 and not os.path.exists(GEN):
         subprocess.check_call(["g++", "-O2", "-o", GEN, os.path.join(ROOT, "tools", "gen_fastq.cpp")])
@@ -133,20 +142,33 @@ def main():
     name = ("pe%dk" if args.paired else "se%dk") % (args.reads // 1000)
     cov = 2 if args.paired else 1            # bases per record: the genome is sized for ~50x coverage either way
     prep_s = 0.0
-    if rank == 0:
+    lib_set = world > 1 and not args.strong and not args.replicas       # the default N > 1 job: N libraries, bin-sharded
+    genome = cov * args.reads * L // 50
+    if lib_set:
+        # rank r prepares library r (seed 8 + r) while the others prepare theirs
+        names = [name if r == 0 else "%s_s%d" % (name, 8 + r) for r in range(world)]
         t0 = time.time()
-        binned, fastq_bytes = prepare_library(args.work, name, args.reads, L, cov * args.reads * L // 50, 8, min(cores, 32), args.paired)
+        prepare_library(args.work, names[rank], args.reads, L, genome, 8 + rank, max(2, min(cores // world, 32)), args.paired)
         prep_s = time.time() - t0
-    if world > 1:
         dist.barrier()
-    binned = os.path.join(args.work, name + ".b8"); fastq_bytes = int(open(os.path.join(args.work, name + ".done")).read())
+        binned_set = [os.path.join(args.work, n + ".b8") for n in names]
+        fastq_bytes = sum(int(open(os.path.join(args.work, n + ".done")).read()) for n in names)
+        binned = binned_set[0]
+    else:
+        if rank == 0:
+            t0 = time.time()
+            binned, fastq_bytes = prepare_library(args.work, name, args.reads, L, genome, 8, min(cores, 32), args.paired)
+            prep_s = time.time() - t0
+        if world > 1:
+            dist.barrier()
+        binned = os.path.join(args.work, name + ".b8"); fastq_bytes = int(open(os.path.join(args.work, name + ".done")).read())
 
     import fastore_amd
     from fastore_amd import shard
     # FASTORE_AMD_LIB: A/B runs of alternative builds of the library (kernel experiments); default = the in-tree build
     alt = os.environ.get("FASTORE_AMD_LIB")
     lib = fastore_amd.load_library(alt) if alt else None
-    sharded = world > 1 and not args.weak
+    sharded = world > 1 and not args.replicas
     threads = max(2, cores // world) if world > 1 else 0
     packer = fastore_amd.Packer(device_id=local if world > 1 else 0, lib=lib, host_threads=threads,
                                 rank=rank if sharded else 0, world_size=world if sharded else 1)
@@ -161,8 +183,10 @@ def main():
         nonlocal out
         out = out_base + "_%d" % len(made)
         made.append(out)
-        if sharded:
-            shard.pack_sharded(packer, binned, out, dist, device=torch.device("cuda", local))
+        if lib_set:
+            shard.pack_sharded_set(packer, binned_set, ["%s_l%d" % (out, i) for i in range(world)], dist, device=None if args.rehearse else torch.device("cuda", local))
+        elif sharded:
+            shard.pack_sharded(packer, binned, out, dist, device=None if args.rehearse else torch.device("cuda", local))
         else:
             packer.pack_file(binned, out)
 
@@ -182,19 +206,20 @@ def main():
     st = packer.stats()
     if rank == 0 or not sharded:
         for o in made[:-1]:
-            for e in (".cdata", ".cmeta"):
-                if os.path.exists(o + e):
-                    os.remove(o + e)
+            for oo in ([o] if not lib_set else ["%s_l%d" % (o, i) for i in range(world)]):
+                for e in (".cdata", ".cmeta"):
+                    if os.path.exists(oo + e):
+                        os.remove(oo + e)
     if world > 1:
-        t = torch.tensor([dt], device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+        t = torch.tensor([dt], device="cpu" if args.rehearse else "cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
         keys = ["algorithmic_bytes", "ppmd_symbols", "host_coded_symbols", "kernel_launches", "encode_kernel_ms", "cdata_bytes", "bins", "records"]
-        v = torch.tensor([float(st[k]) for k in keys], device="cuda", dtype=torch.float64); dist.all_reduce(v)
+        v = torch.tensor([float(st[k]) for k in keys], device="cpu" if args.rehearse else "cuda", dtype=torch.float64); dist.all_reduce(v)
         tot = dict(zip(keys, v.tolist()))
     else:
         tot = st
 
     if rank == 0:
-        jobs = world if (world > 1 and args.weak) else 1
+        jobs = world if (world > 1 and args.replicas) else 1
         value = fastq_bytes * jobs * args.steps / dt / 1e6
         launches = max(1, int(tot["kernel_launches"]))
         avg_launch_s = tot["encode_kernel_ms"] / 1e3 / launches
@@ -209,13 +234,15 @@ def main():
         res = {
             "metric": "fastore_pack compressed MB/s (input FASTQ)", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak" if (world > 1 and args.weak) else "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "ONE library of %.1f M x %d bp %s synthetic FASTQ (gen_fastq genome %d bp, seed 8), --lossless, C1 profile%s"
-                                   % (args.reads / 1e6, L, "PE pairs" if args.paired else "SE reads", cov * args.reads * L // 50,
+            "scaling": "weak" if (world > 1 and not args.strong) else "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s of %.1f M x %d bp %s synthetic FASTQ (gen_fastq genome %d bp, seed%s), --lossless, C1 profile%s"
+                                   % ("ONE library" if not lib_set else "a SET of %d libraries, each" % world, args.reads / 1e6, L, "PE pairs" if args.paired else "SE reads", genome,
+                                      " 8" if not lib_set else "s 8..%d" % (7 + world),
                                       "" if not args.paired else " (configs[2] scaled by %g)" % (args.reads / 100e6)),
                        "fastq_bytes": fastq_bytes, "pack_flags": " ".join(PACK_FLAGS),
-                       "parallelism": ("1 GPU" if world == 1 else ("%d ranks, each the whole library (replicas)" % world if args.weak else
-                                       "%d ranks pack disjoint LPT shards of the library's bins; one all-reduce of the block-size table over RCCL; no block bytes cross ranks" % world))},
+                       "parallelism": ("1 GPU" if world == 1 else ("%d ranks, each the whole library (replicas)" % world if args.replicas else
+                                       ("%d ranks pack disjoint LPT shards of the library's bins; one all-reduce of the block-size table over RCCL; no block bytes cross ranks" % world if args.strong else
+                                        "%d ranks, each its LPT share of the bins of all %d libraries in one device pipeline; one all-reduce of the concatenated block-size tables over RCCL; no block bytes cross ranks" % (world, world))))},
             "roofline": {"bound": "hbm", "kernel": "fs_encode_streams", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic,
                          "traffic_unit": "bytes per launch (profiles/r02_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)",
@@ -242,14 +269,14 @@ def main():
             "device": packer.device_name, "host_cores": cores, "prep_s": round(prep_s, 1),
         }
         pe = ["-z"] if args.paired else []
-        if not args.no_cli:
+        if not args.no_cli and not lib_set:
             # wall time of the `fastore_pack e` PROCESS (start -> exit: HIP init, arena allocation, reading .b*,
             # writing .c*), page cache warm -- beside the warm in-process number above
             cli = [fastore_amd.PACK_CLI, "e", "-i" + binned, "-o" + os.path.join(args.work, "cli")] + PACK_FLAGS + pe + (["-G%d" % world] if world > 1 else [])
             t = time.perf_counter(); rc = subprocess.call(cli, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); tc = time.perf_counter() - t
             res["cli_end_to_end"] = {"value": round(fastq_bytes / tc / 1e6, 2) if rc == 0 else None, "unit": "MB/s", "seconds": round(tc, 2), "exit": rc,
                                      "command": "fastore_pack e " + " ".join(PACK_FLAGS + pe)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not lib_set:
             # the reference's multi-threaded pack dead-locks at -t64 (observed here and in the build container), so the
             # all-cores leg uses at most 32 workers, under a timeout, stepping down if it still hangs
             refp = os.path.join(args.work, "ref")

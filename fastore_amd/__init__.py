@@ -24,7 +24,7 @@ class Config(C.Structure):
                 ("max_new_variants_per_read", C.c_uint32), ("max_hamming_distance", C.c_uint32),
                 ("min_consensus_size", C.c_uint32), ("device_id", C.c_int32), ("host_threads", C.c_uint32),
                 ("max_waves", C.c_uint32), ("batch_bases", C.c_uint64), ("rank", C.c_uint32), ("world_size", C.c_uint32),
-                ("pipeline_slices", C.c_uint32), ("pipeline_lanes", C.c_uint32), ("reserved0", C.c_uint32), ("reserved1", C.c_uint32)]
+                ("pipeline_slices", C.c_uint32), ("pipeline_lanes", C.c_uint32), ("one_shot", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -111,6 +111,9 @@ def load_library(path=None):
     lib.fsgpu_shard_pack.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_size_t)]
     lib.fsgpu_shard_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.fsgpu_shard_write.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]
+    lib.fsgpu_shard_pack_set.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.fsgpu_shard_table_of.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.fsgpu_shard_write_of.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_void_p, C.c_size_t]
     if path is None:
         _lib = lib
     return lib
@@ -241,6 +244,24 @@ class Packer:
         import numpy as np
         a = np.ascontiguousarray(all_sizes, dtype=np.uint64)
         self._check(self.lib.fsgpu_shard_write(self.ctx, out_prefix.encode(), a.ctypes.data, len(a)))
+
+    def shard_pack_set(self, in_prefixes):
+        """the same for a set of libraries in ONE device pipeline; returns [(signatures, own sizes)] per library"""
+        import numpy as np
+        n = len(in_prefixes)
+        arr = (C.c_char_p * n)(*[p.encode() for p in in_prefixes]); nb = (C.c_size_t * n)()
+        self._check(self.lib.fsgpu_shard_pack_set(self.ctx, n, arr, nb))
+        out = []
+        for i in range(n):
+            sigs = np.zeros(nb[i], dtype=np.uint32); sizes = np.zeros(nb[i], dtype=np.uint64)
+            self._check(self.lib.fsgpu_shard_table_of(self.ctx, i, sigs.ctypes.data, sizes.ctypes.data, nb[i]))
+            out.append((sigs, sizes))
+        return out
+
+    def shard_write_of(self, lib, out_prefix, all_sizes):
+        import numpy as np
+        a = np.ascontiguousarray(all_sizes, dtype=np.uint64)
+        self._check(self.lib.fsgpu_shard_write_of(self.ctx, lib, out_prefix.encode(), a.ctypes.data, len(a)))
 
     def set_archive_params(self, config, header_fields=b"", quality_codebook=b""):
         """Archive-level parameters for compress_bins(): raw BinModuleConfig, serialized read-id field table, QVZ section."""

@@ -501,7 +501,7 @@ int fsgpu_pack_file(fsgpu_ctx* ctx, const char* inPrefix, const char* outPrefix,
 int fsgpu_shard_pack(fsgpu_ctx* ctx, const char* inPrefix, size_t* nBlocks)
 {
     if (!ctx || !inPrefix || !nBlocks) return FSGPU_ERR_ARG;
-    FS_GUARD(ctx, { ctx->c.shardPack(inPrefix); *nBlocks = ctx->c.shard.order.size(); });
+    FS_GUARD(ctx, { ctx->c.shardPack({std::string(inPrefix)}); *nBlocks = ctx->c.shards.at(0).order.size(); });
 }
 
 int fsgpu_shard_table(const fsgpu_ctx* ctx, uint32_t* signatures, uint64_t* sizes, size_t nBlocks)
@@ -510,7 +510,7 @@ int fsgpu_shard_table(const fsgpu_ctx* ctx, uint32_t* signatures, uint64_t* size
     fsgpu_ctx* c = const_cast<fsgpu_ctx*>(ctx);
     FS_GUARD(c, {
         std::vector<uint32_t> sg; std::vector<uint64_t> sz;
-        ctx->c.shardTable(sg, sz);
+        ctx->c.shardTable(0, sg, sz);
         if (sg.size() != nBlocks) throw std::runtime_error("block table size mismatch");
         std::copy(sg.begin(), sg.end(), signatures); std::copy(sz.begin(), sz.end(), sizes);
     });
@@ -519,7 +519,36 @@ int fsgpu_shard_table(const fsgpu_ctx* ctx, uint32_t* signatures, uint64_t* size
 int fsgpu_shard_write(fsgpu_ctx* ctx, const char* outPrefix, const uint64_t* allSizes, size_t nBlocks)
 {
     if (!ctx || !outPrefix || !allSizes) return FSGPU_ERR_ARG;
-    FS_GUARD(ctx, ctx->c.shardWrite(outPrefix, std::vector<uint64_t>(allSizes, allSizes + nBlocks)));
+    FS_GUARD(ctx, ctx->c.shardWrite(0, outPrefix, std::vector<uint64_t>(allSizes, allSizes + nBlocks)));
+}
+
+// the same three steps for a SET of libraries packed in one device pipeline (lib = index into in_prefixes)
+int fsgpu_shard_pack_set(fsgpu_ctx* ctx, size_t n, const char* const* inPrefixes, size_t* nBlocks)
+{
+    if (!ctx || !n || !inPrefixes || !nBlocks) return FSGPU_ERR_ARG;
+    FS_GUARD(ctx, {
+        std::vector<std::string> in; for (size_t i = 0; i < n; ++i) { if (!inPrefixes[i]) throw std::runtime_error("null prefix"); in.emplace_back(inPrefixes[i]); }
+        ctx->c.shardPack(in);
+        for (size_t i = 0; i < n; ++i) nBlocks[i] = ctx->c.shards.at(i).order.size();
+    });
+}
+
+int fsgpu_shard_table_of(const fsgpu_ctx* ctx, size_t lib, uint32_t* signatures, uint64_t* sizes, size_t nBlocks)
+{
+    if (!ctx || !signatures || !sizes) return FSGPU_ERR_ARG;
+    fsgpu_ctx* c = const_cast<fsgpu_ctx*>(ctx);
+    FS_GUARD(c, {
+        std::vector<uint32_t> sg; std::vector<uint64_t> sz;
+        ctx->c.shardTable(lib, sg, sz);
+        if (sg.size() != nBlocks) throw std::runtime_error("block table size mismatch");
+        std::copy(sg.begin(), sg.end(), signatures); std::copy(sz.begin(), sz.end(), sizes);
+    });
+}
+
+int fsgpu_shard_write_of(fsgpu_ctx* ctx, size_t lib, const char* outPrefix, const uint64_t* allSizes, size_t nBlocks)
+{
+    if (!ctx || !outPrefix || !allSizes) return FSGPU_ERR_ARG;
+    FS_GUARD(ctx, ctx->c.shardWrite(lib, outPrefix, std::vector<uint64_t>(allSizes, allSizes + nBlocks)));
 }
 
 int fsgpu_pack_files(fsgpu_ctx* ctx, size_t n, const char* const* inPrefixes, const char* const* outPrefixes, int verbose)

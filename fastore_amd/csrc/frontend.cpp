@@ -83,8 +83,10 @@ uint32_t intLog(uint64_t x, uint64_t base)
     uint32_t r = 0;
     if (base == 0) return 1;
     if (base == 1) base++;
-    for (uint64_t t = base; t <= x; t *= base) ++r;
-    return r;
+    // (a range with bit 31 set reaches here sign-extended: the reference's loop would then wrap its power to zero and never
+    // end; seven is the last exponent whose power of 256 fits, and the byte count it stands for is the most a u64 has)
+    for (uint64_t t = base; t <= x; t *= base) { ++r; if (t > ~0ull / base) break; }
+    return r > 7 && base == 256 ? 7 : r;
 }
 
 bool streamIsRangeCoded(uint32_t s, uint32_t qm)

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 #include <spawn.h>
 #include <sys/wait.h>
@@ -47,6 +48,7 @@ int main(int argc, char** argv)
         return WIFEXITED(status) ? WEXITSTATUS(status) : 255;
     }
     fsgpu_config cfg; fsgpu_config_defaults(&cfg);
+    cfg.one_shot = 1;
     std::string in, out; int verbose = 0; int threads = 0, hostThreads = -1, gpus = 1; bool pe = false, threadsGiven = false;
     for (int i = 2; i < argc; ++i) {
         const char* p = argv[i];
@@ -134,9 +136,14 @@ int main(int argc, char** argv)
         }
         return 0;
     }
+    const bool trace = getenv("FS_TRACE") != nullptr;
+    auto clk = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; };
+    const double tm0 = clk();
     fsgpu_ctx* ctx = fsgpu_create(&cfg);
     if (!ctx) { fprintf(stderr, "Error: %s\n", fsgpu_create_error()); return 255; }
+    const double tm1 = clk();
     const int rc = fsgpu_pack_file(ctx, in.c_str(), out.c_str(), verbose);
+    const double tm2 = clk();
     if (rc != 0) { fprintf(stderr, "Error: %s\n", fsgpu_last_error(ctx)); fsgpu_destroy(ctx); return 255; }
     if (verbose) {
         fsgpu_stats st; fsgpu_get_stats(ctx, &st);
@@ -145,5 +152,6 @@ int main(int argc, char** argv)
                 st.frontend_ms, st.block0_ms, st.io_ms, st.total_ms);
     }
     fsgpu_destroy(ctx);
+    if (trace) fprintf(stderr, "[trace] main: context %.0f ms (HIP start-up, arena pool), pack %.0f ms, teardown %.0f ms\n", tm1 - tm0, tm2 - tm1, clk() - tm2);
     return 0;
 }

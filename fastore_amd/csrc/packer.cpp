@@ -417,6 +417,15 @@ void Context::tokeniserCheck(const std::string& inPrefix, uint64_t& ids, uint64_
     }
 }
 
+void Context::equalizeNow()
+{
+    if (equalizeLanes < 2) return;
+    const uint32_t n = std::min<uint32_t>(equalizeLanes, (uint32_t)lanes.size());
+    for (uint32_t l = 0; l < n; ++l) (void)fsengine::staging_buffer(lanes[l], equalizeStage);
+    if (fsengine::lanes_equalize(lanes.data(), n) != 0) throw std::runtime_error(std::string("device: ") + lanes[0]->err);
+    equalizeLanes = 0;
+}
+
 void Context::gatherBlocks()
 {
     const uint32_t nBins = (uint32_t)blockSizes.size();
@@ -522,12 +531,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     // Lanes of the previous batch get the buffers of its best-equipped one now (not at its end: a one-shot run -- the CLI --
     // would pay for pinned and device memory it never uses): whichever slice a lane gets, nothing has to grow -- and so to
     // be freed, which waits for every kernel in flight -- while the long streams are being coded.
-    if (equalizeLanes > 1) {
-        const uint32_t n = std::min<uint32_t>(equalizeLanes, (uint32_t)lanes.size());
-        for (uint32_t l = 0; l < n; ++l) (void)fsengine::staging_buffer(lanes[l], equalizeStage);
-        if (fsengine::lanes_equalize(lanes.data(), n) != 0) throw std::runtime_error(std::string("device: ") + lanes[0]->err);
-        equalizeLanes = 0;
-    }
+    equalizeNow();
     struct Slice {
         std::vector<StreamItem> items; std::vector<BlockPlan> plans; std::vector<uint64_t> sizes;
         fsengine::BatchTiming timing; std::string err; std::thread th; double tReady = 0, tSubmit = 0, tDone = 0;
@@ -818,9 +822,14 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     if (onHostTasksDone) onHostTasksDone();
     joinAll();
     for (Slice& S : slices) if (!S.err.empty()) throw std::runtime_error(S.err);
-    if (nSlices > 1) {   // any lane may get the largest slice of the next batch: their buffers are made alike in front of it (see above)
+    if (nSlices > 1) {
+        // Any lane may get the largest slice of the next batch: the lanes get the buffers of the best-equipped one NOW, behind
+        // the batch (nothing in flight) -- a lane that had to grow a buffer in the middle of the next batch would hipFree, which
+        // waits for every kernel in flight.  A one-shot context (the CLI) only notes it: it would pay for pinned and device
+        // memory it never uses; should it pack again, the lanes are made alike in front of that batch.
         uint64_t mx = 0; for (Slice& S : slices) mx = std::max(mx, S.inBytes);
         equalizeStage = std::max(equalizeStage, mx + 16); equalizeLanes = nLanes;
+        if (!cfg.one_shot) equalizeNow();
     }
     stats.frontend_ms += feMs;
     for (uint32_t si = 0; si < nSlices; ++si) {
@@ -936,7 +945,6 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         if (hold) L.aw.startInMemory(archives[l].cfg);
         else L.aw.start(world > 1 ? outPrefixes[l] + ".part" + std::to_string(rank) : outPrefixes[l], archives[l].cfg);
     });
-    if (hold && nLibs != 1) throw std::runtime_error("a held (bin-sharded) pack takes one library");
     for (size_t l = 0; l < nLibs; ++l) {
         const auto& stdSigs = libs[l]->bf.stdSignatures();
         std::vector<uint64_t> w(stdSigs.size());
@@ -1132,14 +1140,16 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
     { std::lock_guard<std::mutex> lk(gateMx); hostTasksDone = true; }          // no standard bins at all: block 0 starts here
     gateCv.notify_all();
     if (closer.joinable()) closer.join();
-    if (hold) {       // the blocks stay with the context; the archive's block table in its final order: block 0, then ascending signature
-        shard.order.clear();
-        Lib& L = *libs[0];
-        if (!L.bf.smallSignatures().empty() || L.bf.hasNBin()) shard.order.push_back(L.bf.nSignature());
-        for (uint32_t sg : L.bf.stdSignatures()) shard.order.push_back(sg);
-        shard.arch = archives[0];
-        shard.aw.reset(new ArchiveWriter(std::move(L.aw)));
-        shard.have = true;
+    if (hold) {       // the blocks stay with the context; every archive's block table in its final order: block 0, then ascending signature
+        shards.clear(); shards.resize(nLibs);
+        for (size_t l = 0; l < nLibs; ++l) {
+            Lib& L = *libs[l]; Shard& sh = shards[l];
+            if (!L.bf.smallSignatures().empty() || L.bf.hasNBin()) sh.order.push_back(L.bf.nSignature());
+            for (uint32_t sg : L.bf.stdSignatures()) sh.order.push_back(sg);
+            sh.arch = archives[l];
+            sh.aw.reset(new ArchiveWriter(std::move(L.aw)));
+            sh.have = true;
+        }
     }
     {   // whatever is still mapped (no standard bins on this rank): one task per library
         const double tc = nowMs();
@@ -1151,15 +1161,16 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
 }
 
 // ------------------------------------------------------------------------------------------------
-void Context::shardPack(const std::string& inPrefix)
+void Context::shardPack(const std::vector<std::string>& inPrefixes)
 {
-    shard = Shard();
-    packFiles({inPrefix}, {std::string("(held)")}, 0, true);
+    shards.clear();
+    packFiles(inPrefixes, std::vector<std::string>(inPrefixes.size(), std::string("(held)")), 0, true);
 }
 
-void Context::shardTable(std::vector<uint32_t>& sigs, std::vector<uint64_t>& sizes) const
+void Context::shardTable(size_t lib, std::vector<uint32_t>& sigs, std::vector<uint64_t>& sizes) const
 {
-    if (!shard.have) throw std::runtime_error("no held pack: call the shard pack first");
+    if (lib >= shards.size() || !shards[lib].have) throw std::runtime_error("no held pack: call the shard pack first");
+    const Shard& shard = shards[lib];
     sigs = shard.order; sizes.assign(sigs.size(), 0);
     std::map<uint32_t, size_t> place;
     for (size_t i = 0; i < sigs.size(); ++i) place[sigs[i]] = i;
@@ -1170,11 +1181,12 @@ void Context::shardTable(std::vector<uint32_t>& sigs, std::vector<uint64_t>& siz
     }
 }
 
-void Context::shardWrite(const std::string& outPrefix, const std::vector<uint64_t>& allSizes)
+void Context::shardWrite(size_t lib, const std::string& outPrefix, const std::vector<uint64_t>& allSizes)
 {
-    if (!shard.have) throw std::runtime_error("no held pack: call the shard pack first");
+    if (lib >= shards.size() || !shards[lib].have) throw std::runtime_error("no held pack: call the shard pack first");
+    Shard& shard = shards[lib];
     std::vector<uint32_t> sigs; std::vector<uint64_t> own;
-    shardTable(sigs, own);
+    shardTable(lib, sigs, own);
     if (allSizes.size() != sigs.size()) throw std::runtime_error("size table does not match the archive's block table");
     std::vector<uint64_t> off(sigs.size() + 1, 0);
     for (size_t i = 0; i < sigs.size(); ++i) { if (own[i] && own[i] != allSizes[i]) throw std::runtime_error("size table disagrees with the held blocks"); off[i + 1] = off[i] + allSizes[i]; }

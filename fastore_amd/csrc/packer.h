@@ -81,7 +81,8 @@ struct Context {
     const uint8_t* blockData(uint32_t b) const { return sliceBlocks[blockSlice[b]].data() + blockOff[b]; }
     void gatherBlocks();
     std::vector<fsengine::Device*> lanes;         // lanes[0] == dev; further engine instances for the pipelined batches
-    uint64_t equalizeStage = 0; uint32_t equalizeLanes = 0;     // pending: make the lanes' buffers alike in front of the next batch
+    uint64_t equalizeStage = 0; uint32_t equalizeLanes = 0;     // pending: make the lanes' buffers alike
+    void equalizeNow();
     fsengine::Device* lane(uint32_t i);
     fsgpu_stats stats{};
     fsengine::BatchTiming timing;
@@ -117,10 +118,12 @@ struct Context {
     // size table over RCCL, or a sum over the contexts of one process): shardPack codes this rank's bins and holds the
     // blocks; shardTable lists every block of the archive in its final (-t1) order with this rank's sizes (0 elsewhere);
     // shardWrite puts the held blocks at their offsets in <out>.cdata (rank 0 also writes <out>.cmeta).
-    void shardPack(const std::string& inPrefix);
-    void shardTable(std::vector<uint32_t>& sigs, std::vector<uint64_t>& sizes) const;
-    void shardWrite(const std::string& outPrefix, const std::vector<uint64_t>& allSizes);
-    struct Shard { std::unique_ptr<ArchiveWriter> aw; std::vector<uint32_t> order; ArchiveParams arch; bool have = false; } shard;
+    // (a SET of libraries goes through the same three steps in one device pipeline: lib = index into the prefixes of shardPack)
+    void shardPack(const std::vector<std::string>& inPrefixes);
+    void shardTable(size_t lib, std::vector<uint32_t>& sigs, std::vector<uint64_t>& sizes) const;
+    void shardWrite(size_t lib, const std::string& outPrefix, const std::vector<uint64_t>& allSizes);
+    struct Shard { std::unique_ptr<ArchiveWriter> aw; std::vector<uint32_t> order; ArchiveParams arch; bool have = false; };
+    std::vector<Shard> shards;
 };
 
 void parseHeaderFields(const uint8_t* p, size_t n, bool pairedEnd, HeaderStats& out);

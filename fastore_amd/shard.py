@@ -23,3 +23,23 @@ def pack_sharded(packer, in_prefix, out_prefix, dist, device=None):
     packer.shard_write(out_prefix, all_sizes)                   # positional writes: no order needed among the ranks
     dist.barrier()                                              # the archive is complete when any rank returns
     return int(all_sizes.sum())
+
+
+def pack_sharded_set(packer, in_prefixes, out_prefixes, dist, device=None):
+    """A SET of libraries as one bin-sharded job: every rank codes its LPT share of EVERY library's bins in one device
+    pipeline (so a rank's long streams of all libraries overlap), then the same exchange: ONE all-reduce over the
+    concatenated block-size tables, positional writes per library.  Returns the total .cdata bytes."""
+    import torch
+    tables = packer.shard_pack_set(list(in_prefixes))
+    cat = np.concatenate([t[1].astype(np.int64) for t in tables]) if tables else np.zeros(0, dtype=np.int64)
+    t = torch.from_numpy(cat)
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)                    # still the one collective of the path
+    all_sizes = t.cpu().numpy().astype(np.uint64)
+    at = 0
+    for i, (sigs, _) in enumerate(tables):
+        packer.shard_write_of(i, out_prefixes[i], all_sizes[at:at + len(sigs)])
+        at += len(sigs)
+    dist.barrier()
+    return int(all_sizes.sum())

@@ -54,7 +54,8 @@ typedef struct fsgpu_config {
     uint32_t rank, world_size;          /* bin sharding: this context packs bins i with i % world_size == rank */
     uint32_t pipeline_slices;           /* slices a batch is cut into so that host front end and device overlap (0 = default 8, 1 = off) */
     uint32_t pipeline_lanes;            /* engine instances (HIP streams) whose kernels may overlap on the GPU (0 = one per slice, at most 8) */
-    uint32_t reserved0, reserved1;
+    uint32_t one_shot;       /* 1: the context packs once and is destroyed (the CLI): buffers are not pre-sized for a next batch */
+    uint32_t reserved1;
 } fsgpu_config;
 
 /* Unpacked reads of a batch of bins, structure-of-arrays (what the reference hands to Compress() as
@@ -216,6 +217,11 @@ const uint8_t* fsgpu_library_quality_codebook(const fsgpu_library* lib, size_t* 
 int fsgpu_shard_pack(fsgpu_ctx* ctx, const char* in_prefix, size_t* n_blocks);
 int fsgpu_shard_table(const fsgpu_ctx* ctx, uint32_t* signatures, uint64_t* sizes, size_t n_blocks);
 int fsgpu_shard_write(fsgpu_ctx* ctx, const char* out_prefix, const uint64_t* all_sizes, size_t n_blocks);
+/* The same for a SET of libraries whose bins share one device pipeline (a rank's share of every library is coded side by
+ * side: the unit of sharding stays the bin): n_blocks[i] / lib index the libraries in the order of in_prefixes. */
+int fsgpu_shard_pack_set(fsgpu_ctx* ctx, size_t n, const char* const* in_prefixes, size_t* n_blocks);
+int fsgpu_shard_table_of(const fsgpu_ctx* ctx, size_t lib, uint32_t* signatures, uint64_t* sizes, size_t n_blocks);
+int fsgpu_shard_write_of(fsgpu_ctx* ctx, size_t lib, const char* out_prefix, const uint64_t* all_sizes, size_t n_blocks);
 
 /* The file-based form of the same: bin-sharded packing of one library by `world_size` contexts (one per GPU; fsgpu_config.rank / world_size): every
  * context writes <out_prefix>.part<rank>.{cdata,cmeta}; this call merges the parts into <out_prefix>.{cdata,cmeta} in

@@ -416,3 +416,26 @@ def test_device_tokeniser_agrees_with_the_host_tokeniser():
         assert differing == 0, (name, ids, differing)
         total += ids
     assert total > 10000
+
+
+def test_gpu_shard_set_api_on_one_device(tmp_path):
+    # the N > 1 bench path (fsgpu_shard_pack_set / _table_of / _write_of): a SET of libraries -- SE lossless, SE bin-stage
+    # flavour, SE lossless again -- bin-sharded over three ranks that share device 0, every rank's share of all three in one
+    # device pipeline; summed size tables, positional writes; every archive must be the single-writer archive
+    import fastore_amd
+    names = ["se_lossless", "se_c0", "se_lossless"]
+    flags = [m for m in manifest() if m[0] == "se_lossless"][0][2]
+    ins = [os.path.join(GOLDEN, n + ".in") for n in names]; outs = [str(tmp_path / ("o%d" % i)) for i in range(len(names))]
+    world = 3
+    packers = [fastore_amd.Packer(device_id=0, rank=r, world_size=world, **knobs_from_flags(flags)) for r in range(world)]
+    try:
+        tables = [p.shard_pack_set(ins) for p in packers]
+        for i in range(len(names)):
+            total = np.stack([t[i][1] for t in tables]).sum(axis=0)
+            for p in packers:
+                p.shard_write_of(i, outs[i], total)
+    finally:
+        for p in packers:
+            p.close()
+    for i, n in enumerate(names):
+        assert_same_archive(outs[i], os.path.join(GOLDEN, n + ".ref"))
