@@ -273,8 +273,18 @@ def main():
             # wall time of the `fastore_pack e` PROCESS (start -> exit: HIP init, arena allocation, reading .b*,
             # writing .c*), page cache warm -- beside the warm in-process number above
             cli = [fastore_amd.PACK_CLI, "e", "-i" + binned, "-o" + os.path.join(args.work, "cli")] + PACK_FLAGS + pe + (["-G%d" % world] if world > 1 else [])
-            t = time.perf_counter(); rc = subprocess.call(cli, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); tc = time.perf_counter() - t
-            res["cli_end_to_end"] = {"value": round(fastq_bytes / tc / 1e6, 2) if rc == 0 else None, "unit": "MB/s", "seconds": round(tc, 2), "exit": rc,
+            if world == 1:
+                packer.close()             # the process is measured on a device that is otherwise idle, as a user would run it
+            runs = []
+            for _ in range(3):
+                t = time.perf_counter(); rc = subprocess.call(cli, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); tc = time.perf_counter() - t
+                runs.append(round(tc, 2))
+                if rc != 0:
+                    break
+            tc = sorted(runs)[len(runs) // 2]
+            # (the first processes on a fresh box can wait 1-4 s in their first large device allocation -- the driver clears
+            # memory it has not handed out before, profiles/r02_mm_alloc_sizes.txt -- hence three runs and their median)
+            res["cli_end_to_end"] = {"value": round(fastq_bytes / tc / 1e6, 2) if rc == 0 else None, "unit": "MB/s", "seconds": tc, "runs_seconds": runs, "exit": rc,
                                      "command": "fastore_pack e " + " ".join(PACK_FLAGS + pe)}
         if not args.no_cpu_baseline and not lib_set:
             # the reference's multi-threaded pack dead-locks at -t64 (observed here and in the build container), so the

@@ -92,10 +92,17 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
 void fsgpu_destroy(fsgpu_ctx* ctx)
 {
     if (!ctx) return;
+    const bool trace = getenv("FS_TRACE") != nullptr;
+    auto clk = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; };
+    const double t0 = clk();
     for (fsengine::MatchLane* m : ctx->c.matchLanes) fsengine::match_lane_destroy(m);
+    const double t1 = clk();
     for (size_t i = 1; i < ctx->c.lanes.size(); ++i) fsengine::device_destroy(ctx->c.lanes[i]);      // lanes[0] == dev
+    const double t2 = clk();
     fsengine::device_destroy(ctx->c.dev);
+    const double t3 = clk();
     delete ctx;
+    if (trace) fprintf(stderr, "[trace] destroy: matcher lanes %.1f ms, lanes %.1f ms, first lane + pool %.1f ms, host buffers %.1f ms\n", t1 - t0, t2 - t1, t3 - t2, clk() - t3);
 }
 const char* fsgpu_last_error(const fsgpu_ctx* ctx) { return ctx ? ctx->c.err.c_str() : "null context"; }
 const char* fsgpu_device_name(const fsgpu_ctx* ctx) { return (ctx && ctx->c.dev) ? ctx->c.dev->name : ""; }

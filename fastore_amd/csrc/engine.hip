@@ -36,7 +36,10 @@ constexpr uint64_t kGuard = 64ull << 10;
 // Resident coder waves per SIMD.  Measured on MI355X (tools/ppmd_microbench.py): aggregate PPMd throughput saturates
 // at ~0.8 G symbols/s from ~3000 waves on (L2 share per wave shrinks), while per-stream latency keeps growing, and a
 // launch ends with its longest stream -- so 3 waves/SIMD (3072 waves, no register spills) beats 6.
-constexpr uint32_t kWavesPerSimd = 3;
+#ifndef FS_WAVES_PER_SIMD
+#define FS_WAVES_PER_SIMD 3
+#endif
+constexpr uint32_t kWavesPerSimd = FS_WAVES_PER_SIMD;
 
 // Arena slots.  The pool is cut into kXcc partitions of `slotsPerXcc` arenas; a wave claims a slot of the XCD it runs
 // on and gives it back when its queue is empty.  Slots never migrate between XCDs: the per-XCD L2s are not coherent
@@ -180,7 +183,10 @@ template <bool TWO> __device__ __forceinline__ void encode_streams_body()
 }
 
 __global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(EncodeArgs /* read through kernargs() */) { encode_streams_body<false>(); }
-__global__ __launch_bounds__(128, kWavesPerSimd) void fs_encode_streams2(EncodeArgs /* read through kernargs() */) { encode_streams_body<true>(); }
+// (the two-wave form is used where single streams decide the step: two workgroup-waves per SIMD leave each 256 VGPRs -- 3.5 %
+// off the time of a lone long stream against the 170 of three per SIMD, profiles/r02_qq_two_waves_per_simd.txt; the one-wave
+// form codes the slices of short streams, where the number of resident waves counts)
+__global__ __launch_bounds__(128, 2) void fs_encode_streams2(EncodeArgs /* read through kernargs() */) { encode_streams_body<true>(); }
 
 // fs_gather_quality -- the quality stream of a lossless bin, built on the device (SURVEY 8 a8 + f1): the stored scores
 // (.bqua: six bits each, MSB first, fastore_bin/FastqPacker.cpp:157-287) are unpacked, turned back to front where the read
@@ -454,7 +460,11 @@ int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size
         delete pool; delete dev; return -1;
     };
     hipError_t e;
+    const bool trace = getenv("FS_TRACE") != nullptr;
+    double tc1 = tc0;
+    auto lap = [&](const char* what) { if (trace) { const double t = wallMs(); fprintf(stderr, "[trace] device_create: %s %.1f ms\n", what, t - tc1); tc1 = t; } };
     if ((e = hipSetDevice(deviceId)) != hipSuccess) return fail("hipSetDevice", e);
+    lap("runtime start-up (hipSetDevice)");
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, deviceId)) != hipSuccess) return fail("hipGetDeviceProperties", e);
     dev->deviceId = deviceId;
@@ -472,13 +482,17 @@ int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size
     pool->slotStride = stride; pool->slotsPerXcc = perXcc; pool->bytes = (uint64_t)perXcc * kXcc * stride;
     if (pool->bytes > budget) { snprintf(err, errLen, "not enough device memory for the coder arenas"); delete pool; delete dev; return -1; }
     dev->nWaves = waves; dev->pool = pool;
+    lap("properties, memory info");
     if ((e = hipMalloc((void**)&pool->arenas, pool->bytes)) != hipSuccess) return fail("hipMalloc(arenas)", e);
+    lap("hipMalloc of the arena pool");
     if ((e = hipMalloc((void**)&pool->maps, sizeof(SlotMap) * kXcc)) != hipSuccess) return fail("hipMalloc(slot maps)", e);
     if ((e = hipMemset(pool->maps, 0, sizeof(SlotMap) * kXcc)) != hipSuccess) return fail("hipMemset(slot maps)", e);
+    lap("slot maps (first memset: code objects)");
     if (lane_init(dev, err, errLen) != 0) { (void)hipFree(pool->arenas); (void)hipFree(pool->maps); delete pool; delete dev; return -1; }
     pool->lanes = 1;
     *out = dev;
-    if (getenv("FS_TRACE")) fprintf(stderr, "[trace] device_create: up to %u waves, %u slots per XCD, %.1f GB arena pool, %.1f ms\n", waves, perXcc, pool->bytes / 1e9, wallMs() - tc0);
+    lap("first lane (stream, events)");
+    if (trace) fprintf(stderr, "[trace] device_create: up to %u waves, %u slots per XCD, %.1f GB arena pool, %.1f ms\n", waves, perXcc, pool->bytes / 1e9, wallMs() - tc0);
     return 0;
 }
 
@@ -509,7 +523,11 @@ void device_destroy(Device* dev)
     if (Pool* pool = dev->pool) {
         bool last;
         { std::lock_guard<std::mutex> g(pool->m); last = --pool->lanes == 0; }
-        if (last) { (void)hipFree(pool->arenas); (void)hipFree(pool->maps); delete pool; }
+        if (last) {
+            const double t0 = wallMs();
+            (void)hipFree(pool->arenas); (void)hipFree(pool->maps); delete pool;
+            if (getenv("FS_TRACE")) fprintf(stderr, "[trace] device_destroy: hipFree of the arena pool %.1f ms\n", wallMs() - t0);
+        }
     }
     delete dev;
 }

@@ -151,6 +151,14 @@ int main(int argc, char** argv)
                 fsgpu_device_name(ctx), (unsigned long long)st.bins, (unsigned long long)st.records, st.encode_kernel_ms, st.assemble_kernel_ms,
                 st.frontend_ms, st.block0_ms, st.io_ms, st.total_ms);
     }
+    // The archive is on disk and closed.  A one-shot process does not hand its device and pinned memory back piece by
+    // piece (0.75 s for a 10 M-read library: 53 GB of arenas, the lanes' pinned staging buffers): the kernel reclaims
+    // them with the process.  FS_ORDERLY_EXIT=1 keeps the orderly teardown (leak checkers, the sanitizer builds).
+    if (!getenv("FS_ORDERLY_EXIT")) {
+        if (trace) fprintf(stderr, "[trace] main: context %.0f ms (HIP start-up, arena pool), pack %.0f ms, no teardown\n", tm1 - tm0, tm2 - tm1);
+        fflush(stdout); fflush(stderr);
+        _exit(0);
+    }
     fsgpu_destroy(ctx);
     if (trace) fprintf(stderr, "[trace] main: context %.0f ms (HIP start-up, arena pool), pack %.0f ms, teardown %.0f ms\n", tm1 - tm0, tm2 - tm1, clk() - tm2);
     return 0;

@@ -14,6 +14,7 @@
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <fcntl.h>
 #include "bitio.h"
 #include "hostcoders.h"
@@ -96,11 +97,35 @@ void serializeHeaderFields(const HeaderStats& head, bool pairedEnd, std::vector<
 }
 
 // ------------------------------------------------------------------------------------------------
-ArchiveWriter::~ArchiveWriter() { if (meta_) fclose(meta_); if (data_) fclose(data_); }
+ArchiveWriter::~ArchiveWriter() { dropAhead(); if (meta_) fclose(meta_); if (data_) fclose(data_); }
 ArchiveWriter::ArchiveWriter(ArchiveWriter&& o)
     : sizeStats_(o.sizeStats_), prefix_(std::move(o.prefix_)), meta_(o.meta_), data_(o.data_), inMemory_(o.inMemory_), mem_(std::move(o.mem_)), held_(std::move(o.held_)),
       conf_(o.conf_), sizes_(std::move(o.sizes_)), sigs_(std::move(o.sigs_)), dataBytes_(o.dataBytes_)
-{ o.meta_ = nullptr; o.data_ = nullptr; }
+{ o.dropAhead(); o.meta_ = nullptr; o.data_ = nullptr; }
+
+void ArchiveWriter::reserveAhead(uint64_t bytes)
+{
+    if (inMemory_ || !data_ || pre_ || bytes < (8u << 20)) return;
+    const int fd = fileno(data_);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || (uint64_t)sb.st_size >= bytes) return;
+    if (fallocate(fd, 0, 0, (off_t)bytes) != 0) return;           // (file systems without it: the blocks go the usual way)
+    void* mp = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (mp == MAP_FAILED) { (void)!ftruncate(fd, sb.st_size); return; }
+    if (getenv("FS_TRACE")) fprintf(stderr, "[trace] archive: %llu bytes reserved ahead\n", (unsigned long long)bytes);
+    pre_ = (uint8_t*)mp; preLen_ = bytes;
+    preTh_ = std::thread([p = pre_, n = preLen_]() {
+        // a write access that changes nothing (an atomic OR of 0): block 0 may be going into the same pages through write()
+        const long pg = sysconf(_SC_PAGESIZE);
+        for (size_t o = 0; o < n; o += (size_t)pg) __atomic_fetch_or(p + o, (uint8_t)0, __ATOMIC_RELAXED);
+    });
+}
+
+void ArchiveWriter::dropAhead()
+{
+    if (preTh_.joinable()) preTh_.join();
+    if (pre_) { munmap(pre_, preLen_); pre_ = nullptr; preLen_ = 0; }
+}
 
 void StreamSizeStats::start(const ArchiveTypeRaw& type, const MinimizerParametersRaw& mp)
 {
@@ -143,7 +168,7 @@ void ArchiveWriter::start(const std::string& prefix, const BinModuleConfigRaw& c
 {
     prefix_ = prefix;
     meta_ = fopen((prefix + ".cmeta").c_str(), "wb");
-    data_ = fopen((prefix + ".cdata").c_str(), "wb");
+    data_ = fopen((prefix + ".cdata").c_str(), "w+b");      // (read access too: the blocks go in through a shared mapping)
     if (!meta_ || !data_) throw std::runtime_error("Cannot open file: " + prefix + ".cmeta/.cdata");
     memset(&conf_, 0, sizeof conf_);                       // padding bytes are zero here (stack garbage in the reference)
     conf_.archType = cfg.archiveType; conf_.minParams = cfg.minimizer;
@@ -209,6 +234,13 @@ void ArchiveWriter::writeBlocks(const std::vector<const uint8_t*>& data, const s
     for (uint32_t k = 1; k < t; ++k) { const uint64_t want = off[n] / t * k; cut[k] = (size_t)(std::lower_bound(off.begin(), off.end(), want) - off.begin()); if (cut[k] > n) cut[k] = n; }
     // Through a shared mapping of the file's new extent when the file system allows it: write() calls on ONE file take
     // its lock in turn (~4 GB/s whatever the thread count), page-cache pages of a mapping are filled side by side.
+    if (pre_ && (uint64_t)base + off[n] <= preLen_) {
+        uint8_t* dst = pre_ + base;
+        parallelFor(t, t, [&](uint32_t k, uint32_t) { for (size_t i = cut[k]; i < cut[k + 1]; ++i) memcpy(dst + off[i], data[i], sizes[i]); });
+        if (fseeko(data_, base + (off_t)off[n], SEEK_SET) != 0) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
+        dataBytes_ += off[n];
+        return;
+    }
     {
         const long pg = sysconf(_SC_PAGESIZE);
         const off_t mapFrom = base - (base % pg); const size_t mapLen = (size_t)(base - mapFrom) + off[n];
@@ -279,6 +311,11 @@ void ArchiveWriter::finish(const HeaderStats& head, const QvzModel& qvz)
     put(&footerOffset, 8); put(&footerSize, 8);
     FILE* m = meta_; meta_ = nullptr;
     if (fclose(m) != 0) throw std::runtime_error(what);
+    if (data_ && pre_) {
+        // the reserved extent was an estimate: the archive ends where its last block ends
+        const bool had = true; dropAhead();
+        if (had && (fflush(data_) != 0 || ftello(data_) < 0 || ftruncate(fileno(data_), ftello(data_)) != 0)) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
+    }
     FILE* d = data_; data_ = nullptr;
     if (d && fclose(d) != 0) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
 }
@@ -346,7 +383,13 @@ MatchFn Context::matcherFor(uint32_t tid)
     if (matchLanes.size() <= tid) throw std::runtime_error("matcher lanes not sized");       // (sized by the callers before their threads start)
     return [this, tid](const uint8_t* seq, size_t seqBytes, const fsdev::MatchRead* reads, size_t nReads, const fsdev::MatchCall* calls, size_t nCalls,
                        const uint32_t* warm, size_t nWarm, const fsdev::MatchParams& mp, fsdev::MatchRow* rows) -> bool {
-        if (!matchLanes[tid] && fsengine::match_lane_create(dev, &matchLanes[tid]) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+        if (!matchLanes[tid]) {
+            // a thread's first search: its lane, with room for the batch's largest bin at once (from nothing: no buffer
+            // is freed here, so no wait for running kernels) -- the host threads do this side by side, in their first bins
+            if (fsengine::match_lane_create(dev, &matchLanes[tid]) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+            if (matchReserve.reads && fsengine::match_lane_reserve(dev, matchLanes[tid], matchReserve.reads, matchReserve.seqBytes, matchReserve.calls, matchReserve.warm) != 0)
+                throw std::runtime_error(std::string("device: ") + dev->err);
+        }
         const double t0 = nowMs(); double kms = 0;
         if (fsengine::match_reads(dev, matchLanes[tid], seq, seqBytes, reads, nReads, calls, nCalls, warm, nWarm, mp, rows, &kms) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
         matchedReads += nReads; matchUs += (uint64_t)((nowMs() - t0) * 1e3); matchKernelUs += (uint64_t)(kms * 1e3);
@@ -524,9 +567,12 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     const uint32_t nSlices = (uint32_t)cut.size() - 1;
     // never more than kMaxLanes kernels in flight unless the caller insists (pipeline_lanes); extra slices queue behind
     const uint32_t wantLanes = nSlices > 1 ? std::min<uint32_t>(nSlices, cfg.pipeline_lanes ? cfg.pipeline_lanes : kMaxLanes) : 1;
-    uint32_t nLanes = 1;
-    while (nLanes < wantLanes && lane(nLanes)) ++nLanes;
+    // lanes of an earlier batch are there; a fresh context (the CLI) makes lane 0 here and the others beside the front end
+    // (a stream, events: 10-20 ms each), handing each to the slices as it comes
     (void)lane(0);
+    lanes.reserve(std::max<size_t>(lanes.capacity(), 64));          // (slice threads read lanes[] while the maker appends)
+    const uint32_t haveLanes = std::min<uint32_t>(wantLanes, (uint32_t)lanes.size());
+    uint32_t nLanes = haveLanes;
 
     // Lanes of the previous batch get the buffers of its best-equipped one now (not at its end: a one-shot run -- the CLI --
     // would pay for pinned and device memory it never uses): whichever slice a lane gets, nothing has to grow -- and so to
@@ -534,12 +580,37 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     equalizeNow();
     struct Slice {
         std::vector<StreamItem> items; std::vector<BlockPlan> plans; std::vector<uint64_t> sizes;
-        fsengine::BatchTiming timing; std::string err; std::thread th; double tReady = 0, tSubmit = 0, tDone = 0;
+        fsengine::BatchTiming timing; std::string err; std::thread th; double tReady = 0, tSubmit = 0, tDone = 0, bufMs = 0;
         std::mutex mx; std::condition_variable cv; uint32_t pending = 0; bool done = false; int lane = -1; uint64_t inBytes = 0;
     };
     // a slice takes whichever lane is free when its bins are ready (the early slices hold theirs for the longest streams)
     std::mutex laneMx; std::condition_variable laneCv; std::vector<uint32_t> freeLanes;
-    for (uint32_t l = nLanes; l-- > 0;) freeLanes.push_back(l);
+    // (a fresh context: the maker also gives every lane its pinned staging buffer, sized for the slice that will most likely
+    // take it -- slice i becomes ready i-th and takes the i-th lane --, before a slice can have it: 40-70 ms of hipHostMalloc
+    // per lane that would otherwise sit between a slice's front end and its upload)
+    std::vector<uint64_t> sliceEst(nSlices, 0);
+    if (stageEstimate.size() == nBins) for (uint32_t si = 0; si < nSlices; ++si) for (uint32_t k = cut[si]; k < cut[si + 1]; ++k) sliceEst[si] += stageEstimate[byWork[k]];
+    stageEstimate.clear();                                          // (it describes this call's bins only)
+    const bool makeLanes = haveLanes < wantLanes;
+    const bool fresh0 = makeLanes && haveLanes == 1 && lanes[0]->hStage == nullptr && sliceEst[0] != 0;
+    for (uint32_t l = nLanes; l-- > 0;) if (!(fresh0 && l == 0)) freeLanes.push_back(l);
+    std::thread laneMaker;
+    std::atomic<uint32_t> madeLanes(haveLanes);
+    if (makeLanes) laneMaker = std::thread([&]() {
+        auto prep = [&](fsengine::Device* d, uint32_t l) { if (l < nSlices && sliceEst[l]) (void)fsengine::staging_buffer(d, sliceEst[l] + (1u << 20)); };
+        if (fresh0) {
+            prep(lanes[0], 0);
+            { std::lock_guard<std::mutex> lk(laneMx); freeLanes.push_back(0); }
+            laneCv.notify_one();
+        }
+        for (uint32_t l = haveLanes; l < wantLanes; ++l) {
+            fsengine::Device* d = nullptr; char e[256] = {0};
+            if (fsengine::lane_create(dev, &d, e, sizeof e) != 0) { if (trace) fprintf(stderr, "[trace] no further engine lane: %s\n", e); break; }
+            prep(d, l);
+            { std::lock_guard<std::mutex> lk(laneMx); lanes.push_back(d); freeLanes.insert(freeLanes.begin(), l); }
+            laneCv.notify_one(); madeLanes = l + 1;
+        }
+    });
     std::vector<Slice> slices(nSlices);
     std::vector<uint32_t> sliceOf(nBins);
     for (uint32_t si = 0; si < nSlices; ++si) { slices[si].pending = cut[si + 1] - cut[si]; for (uint32_t k = cut[si]; k < cut[si + 1]; ++k) sliceOf[k] = si; }
@@ -684,8 +755,11 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 for (uint32_t gi : idItems) S.items[gi].in_off += gatherBase + gatherBytes;
                 for (fsdev::IdJob& j : idJobs) { j.tok_out += gatherBytes; j.val_out += gatherBytes; }
             }
-            fsengine::Device* L = lanes[(uint32_t)S.lane];
+            fsengine::Device* L;
+            { std::lock_guard<std::mutex> lk(laneMx); L = lanes[(uint32_t)S.lane]; }
+            const double tb = nowMs();
             uint8_t* input = fsengine::staging_buffer(L, inBytes + 16);        // pinned host memory owned by the lane
+            S.bufMs = nowMs() - tb;
             if (!input) throw std::runtime_error(std::string("device: ") + L->err);
             for (size_t a = 0; a < archives.size(); ++a) if (qvzOff[a] != ~0ull) memcpy(input + qvzOff[a], archives[a].qvz.blob.data(), archives[a].qvz.blob.size());
             for (size_t a = 0; a < archives.size(); ++a) if (idTabOff[a] != ~0ull) memcpy(input + idTabOff[a], idTab[a].data(), idTab[a].size());
@@ -777,7 +851,9 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         });
     }
     auto joinAll = [&]() {
+        if (laneMaker.joinable()) laneMaker.join();
         for (Slice& s : slices) if (s.th.joinable()) s.th.join();
+        nLanes = madeLanes.load();
         if (watchdog.joinable()) { { std::lock_guard<std::mutex> g(wdMx); wdStop = true; } wdCv.notify_all(); watchdog.join(); }
     };
 
@@ -788,13 +864,14 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     uint32_t matcherBins = deviceMatcher ? 6u * hostThreads : 0u;      // measured on the BASELINE library: 72 bins 1841, 144 bins 1923, 250+ bins below 1750 MB/s (the searches start to wait for registers)
     if (const char* mb = getenv("FS_MATCHER_BINS")) matcherBins = (uint32_t)std::max(0, atoi(mb));
     if (deviceMatcher && matchReserve.reads && matcherBins) {
-        // every host thread's matcher lane gets room for the largest bin now, while no coder kernel is in flight
-        for (uint32_t t = 0; t < hostThreads; ++t) {
-            if (!matchLanes[t] && fsengine::match_lane_create(dev, &matchLanes[t]) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
-            if (fsengine::match_lane_reserve(dev, matchLanes[t], matchReserve.reads, matchReserve.seqBytes, matchReserve.calls, matchReserve.warm) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
-        }
+        // the matcher lanes of an earlier batch get room for this batch's largest bin now, while no coder kernel is in
+        // flight (growing frees, and a free waits for every running kernel); lanes that do not exist yet are made by
+        // their threads (matcherFor)
+        for (uint32_t t = 0; t < hostThreads; ++t)
+            if (matchLanes[t] && fsengine::match_lane_reserve(dev, matchLanes[t], matchReserve.reads, matchReserve.seqBytes, matchReserve.calls, matchReserve.warm) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
     }
     const double tf = nowMs();
+    if (trace) fprintf(stderr, "[trace] batch set-up (slices, %u lanes, matcher lanes) %.1f ms\n", nLanes, tf - t0);
     try {
         parallelFor(nBins, hostThreads, [&](uint32_t k, uint32_t tid) {
             const uint32_t b = byWork[k];
@@ -843,8 +920,8 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         timing.ppmd_symbols += S.timing.ppmd_symbols; timing.rc_symbols += S.timing.rc_symbols; timing.restarts += S.timing.restarts; for (int w = 0; w < 16; ++w) timing.win[w] += S.timing.win[w];
         timing.h2d_bytes += S.timing.h2d_bytes; timing.d2h_bytes += S.timing.d2h_bytes;
         timing.gather_ms += S.timing.gather_ms; timing.gather_symbols += S.timing.gather_symbols; timing.gather_bytes += S.timing.gather_bytes; timing.id_strings += S.timing.id_strings;
-        if (trace) fprintf(stderr, "[trace] slice %u/%u: %u bins, front end done at %.1f ms, staged+submitted at %.1f ms, device done at %.1f ms (kernel %.1f ms)\n",
-                           si + 1, nSlices, cut[si + 1] - cut[si], S.tReady - t0, S.tSubmit - t0, S.tDone - t0, S.timing.encode_ms);
+        if (trace) fprintf(stderr, "[trace] slice %u/%u: %u bins, front end done at %.1f ms, staged+submitted at %.1f ms (%.0f MB; staging buffer %.1f ms), device done at %.1f ms (kernel %.1f ms)\n",
+                           si + 1, nSlices, cut[si + 1] - cut[si], S.tReady - t0, S.tSubmit - t0, S.inBytes / 1e6, S.bufMs, S.tDone - t0, S.timing.encode_ms);
     }
     if (trace) {
         double sum = 0, mx = 0; for (double v : busyMs) { sum += v; mx = std::max(mx, v); }
@@ -1035,6 +1112,15 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                 hpBase[k + 1] = hpBase[k] + ((bi.totalHeadSize + 15u) & ~15ull);
                 weight[k] = bi.totalRecordsCount;
             }
+            // what a bin brings into a lane's staging buffer, roughly: its quality scores (packed, or a byte / a pair each), its
+            // read ids, the descriptors and the small streams -- a fresh context sizes its lanes' pinned buffers by it up front
+            stageEstimate.assign(nb, 0);
+            for (uint32_t k = 0; k < nb; ++k) {
+                const BinInfo& bi = libs[work[first + k].lib]->bf.bins().at(work[first + k].sig);
+                const uint32_t qmk = archives[work[first + k].lib].cfg.quaParams.method;
+                const uint64_t q = packedQ ? bi.totalQuaSize : (qmk == MET_NONE ? bi.totalRawDnaSize : (qmk == MET_QVZ ? 4ull : 2ull) * bi.totalRawDnaSize);
+                stageEstimate[k] = q + (packedH ? bi.totalHeadSize : 2ull * bi.totalRawHeadSize) + 80ull * bi.totalRecordsCount;
+            }
             if (seqBase[nb] > 0xFFFFFFF0ull || headBase[nb] > 0xFFFFFFF0ull || recBase[nb] > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB");
             batch.seq.resize(seqBase[nb]); batch.recs.resize(recBase[nb]);
             if (packedH) { batch.head.clear(); batch.headPacked.resize(hpBase[nb]); batch.headBit.resize(recBase[nb]); }
@@ -1052,8 +1138,21 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             for (size_t k = first; k < next; ++k) binArch.push_back(work[k].lib);
             stats.io_ms += nowMs() - tio;
             const bool lastBatchNow = next >= work.size();
+            // what the archives will hold at the end, roughly: what they hold, what is pending, block 0 and three tenths of this
+            // batch's staged bytes (PPMd on quality scores) -- their page-cache pages are made while the device works
+            std::vector<uint64_t> aheadBytes(nLibs, 0);
+            if (lastBatchNow) {
+                for (uint32_t k = 0; k < nb; ++k) aheadBytes[work[first + k].lib] += stageEstimate[k] * 3 / 10;
+                for (size_t l = 0; l < nLibs; ++l) {
+                    Lib& L = *libs[l];
+                    uint64_t have = L.aw.dataBytes() + (64u << 20);             // (+ block 0 and slack)
+                    for (const Lib::Pending& pd : L.pending) have += pd.data.size();
+                    aheadBytes[l] += have;
+                }
+            }
             onHostTasksDone = [&, lastBatchNow]() {
                 if (!lastBatchNow) return;
+                for (size_t l = 0; l < nLibs; ++l) libs[l]->aw.reserveAhead(aheadBytes[l]);
                 { std::lock_guard<std::mutex> lk(gateMx); hostTasksDone = true; }
                 gateCv.notify_all();
                 closer = std::thread([&]() {                       // the mapped inputs have been read for the last time

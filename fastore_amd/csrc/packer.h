@@ -6,6 +6,7 @@
 #include <functional>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/fastore_amd.h"
 #include "binfile.h"
@@ -53,6 +54,10 @@ public:
     // them there with positional writes (one buffered writer moves ~4 GB/s: 0.1 s of a 0.45 GB archive at the very end of a step)
     void writeBlocks(const std::vector<const uint8_t*>& data, const std::vector<uint64_t>& sizes, const std::vector<uint32_t>& signatures, uint32_t threads);
     void finish(const HeaderStats& head, const QvzModel& qvz);
+    // The archive's first `bytes` bytes are given their page-cache pages NOW, by a thread of the writer's own (the host is
+    // idle while the device walks the long streams; the final copy of the blocks then finds its pages mapped instead of
+    // faulting 10^5 of them in at the very end of the step).  An estimate: finish() cuts the file to what was written.
+    void reserveAhead(uint64_t bytes);
     uint64_t dataBytes() const { return dataBytes_; }
     void printStreamSizes(FILE* to) const { sizeStats_.print(to); }
 private:
@@ -64,6 +69,8 @@ private:
     std::vector<uint64_t> sizes_;
     std::vector<uint32_t> sigs_;
     uint64_t dataBytes_ = 0;
+    uint8_t* pre_ = nullptr; size_t preLen_ = 0; std::thread preTh_;
+    void dropAhead();
 };
 
 struct Context {
@@ -97,6 +104,7 @@ struct Context {
     // (after unpacking it, for the file path) on one of the host threads
     typedef std::function<void(uint32_t, BinEncoder&, BinStreams&, BinIn&, uint64_t&)> BinProducer;
     void compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, const std::vector<uint32_t>& binArch, const BinProducer& produce);
+    std::vector<uint64_t> stageEstimate;          // optional, per bin of the coming compressBins call: bytes it will bring into a lane's staging buffer
     std::vector<BinIn> binInfo;                   // per bin of the last compressBins call
     std::function<void()> onHostTasksDone;        // called by compressBins when its host tasks are done (the device may still run)
     std::vector<std::unique_ptr<BinEncoder>> encoders;   // one per host thread

@@ -15,7 +15,8 @@ from conftest import ROOT, VECTORS, oracle_ppmd
 def simt():
     out = os.path.join(ROOT, "build", "libsimt_emu.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU", "-shared", "-fPIC", "-o", out,
+    # FS_EMU_DEFS: extra -D flags (kernel experiments, e.g. -DFS_WIN_PREFETCH=1) for the same tests
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU"] + os.environ.get("FS_EMU_DEFS", "").split() + ["-shared", "-fPIC", "-o", out,
                            os.path.join(ROOT, "tests", "emu", "ppmd_simt.cpp"), os.path.join(ROOT, "tests", "emu", "simt.cpp")])
     lib = ctypes.CDLL(out)
     lib.simt_ppmd_encode.restype = ctypes.c_size_t
