@@ -10,6 +10,9 @@
 
 namespace fs {
 
+void fs_advise_huge(void* p, size_t bytes) { (void)madvise(p, bytes, MADV_HUGEPAGE); }
+
+
 namespace {
 
 struct FileHeader { uint64_t footerOffset, recordsCount, blockCount, footerSize; uint8_t usesHeaderStream; uint8_t reserved[7]; };

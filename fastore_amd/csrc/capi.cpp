@@ -85,6 +85,11 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
         delete ctx; return nullptr;
     }
     char err[256] = {0};
+    {   // one-shot contexts stage through pageable memory (FS_PAGEABLE_STAGING=0/1 forces either way: A/B runs)
+        bool pageable = cfg->one_shot != 0;
+        if (const char* ps = getenv("FS_PAGEABLE_STAGING")) pageable = atoi(ps) != 0;
+        fsengine::set_pageable_staging(pageable);
+    }
     if (fsengine::device_create(&c.dev, cfg->device_id, c.cfg.max_waves, err, sizeof err) != 0) { g_createError = err; delete ctx; return nullptr; }
     return ctx;
 }

@@ -38,6 +38,10 @@ struct Device {
     void* dPlans; size_t capPlans;
     uint8_t* dBlocks; size_t capBlocks;
     uint8_t* hStage; size_t capStage;
+    // staging buffers outgrown in the middle of a batch: un-registering pinned memory waits for every running kernel (as a
+    // hipFree does), so they are kept until the lane is between batches (lanes_equalize) or goes
+    void* oldStage[4]; size_t oldStageCap[4]; uint32_t nOldStage;
+    uint32_t stagePageable;                                // the staging buffers of this lane are not registered with the runtime
 };
 
 int device_count();
@@ -46,6 +50,15 @@ int lane_create(Device* first, Device** out, char* err, size_t errLen);      // 
 void device_destroy(Device* dev);                                            // a lane; the pool goes with its last lane
 // diagnostic: progress of the lane's current launch (work-queue head) and the pool's slot rings, read on a stream of its own
 int lane_debug(Device* dev, char* out, size_t outLen);
+// Pinned host memory whose pages are made by the CALLING thread (anonymous mapping, touched here) and then registered with
+// the runtime: hipHostMalloc does both inside the runtime (~5 GB/s, and other threads' HIP calls queue behind it); the
+// registration alone is 4-8 x shorter (tools/probes/hip_startup_probe.cpp).  `bytes` is rounded up; pinned_free wants the same value.
+void* pinned_alloc(size_t* bytes, bool pin = true);      // pin = false: the pages only (pageable memory, the runtime stages the copies)
+void pinned_free(void* p, size_t bytes, bool pinned = true);
+// A context that packs once and goes (the CLI) keeps its lanes' staging buffers pageable: registering 2.6 GB of them and
+// handing them back at exit costs more (~0.5 s of process time) than the runtime's own staged copies do (call before device_create).
+void set_pageable_staging(bool on);
+bool pageable_staging();
 uint8_t* staging_buffer(Device* dev, size_t bytes);     // grow-only pinned host buffer for the batch input
 int lanes_equalize(Device* const* lanes, size_t n);     // between batches: every lane gets the device buffers of the best-equipped one
 int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,

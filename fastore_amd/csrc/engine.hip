@@ -13,6 +13,8 @@
 //   (/root/reference/fastore/fastore_pack/FastqCompressor.cpp:1055-1126, 684-699, 1199-1210) and
 //   the TEncoder<...>/PpmdEncoder calls behind them.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
@@ -433,11 +435,14 @@ struct Pool {
     std::mutex m; int lanes = 0;
 };
 
+static bool g_pageableStaging = false;
+
 static int lane_init(Device* dev, char* err, size_t errLen)
 {
     hipError_t e;
     auto fail = [&](const char* what, hipError_t c) { snprintf(err, errLen, "%s: %s", what, hipGetErrorString(c)); return -1; };
     if ((e = hipSetDevice(dev->deviceId)) != hipSuccess) return fail("hipSetDevice", e);
+    dev->stagePageable = g_pageableStaging ? 1u : 0u;
     if ((e = hipStreamCreateWithFlags((hipStream_t*)&dev->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipMalloc((void**)&dev->queueHead, 64)) != hipSuccess) return fail("hipMalloc(queue)", e);
     for (int i = 0; i < 6; ++i) if ((e = hipEventCreate((hipEvent_t*)&dev->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
@@ -517,7 +522,8 @@ void device_destroy(Device* dev)
     void* ptrs[] = {dev->queueHead, dev->dIn, dev->dScratch, dev->dItems, dev->dOrder, dev->dSizes, dev->dRestarts, dev->dPlans, dev->dBlocks};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (dev->evWait) (void)hipEventDestroy((hipEvent_t)dev->evWait);
-    if (dev->hStage) (void)hipHostFree(dev->hStage);
+    if (dev->hStage) pinned_free(dev->hStage, dev->capStage, !dev->stagePageable);
+    for (uint32_t i = 0; i < dev->nOldStage; ++i) pinned_free(dev->oldStage[i], dev->oldStageCap[i], !dev->stagePageable);
     for (int i = 0; i < 6; ++i) if (dev->ev[i]) (void)hipEventDestroy((hipEvent_t)dev->ev[i]);
     if (dev->stream) (void)hipStreamDestroy((hipStream_t)dev->stream);
     if (Pool* pool = dev->pool) {
@@ -550,14 +556,41 @@ int lane_debug(Device* dev, char* out, size_t outLen)
     return 0;
 }
 
+void set_pageable_staging(bool on) { g_pageableStaging = on; }
+bool pageable_staging() { return g_pageableStaging; }
+
+void* pinned_alloc(size_t* bytes, bool pin)
+{
+    const size_t len = (*bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    void* p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) return nullptr;
+    (void)madvise(p, len, MADV_HUGEPAGE);
+    const long pg = sysconf(_SC_PAGESIZE);
+    for (size_t o = 0; o < len; o += (size_t)pg) ((volatile uint8_t*)p)[o] = 0;
+    if (pin && hipHostRegister(p, len, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); munmap(p, len); return nullptr; }
+    *bytes = len;
+    return p;
+}
+
+void pinned_free(void* p, size_t bytes, bool pinned)
+{
+    if (!p) return;
+    if (pinned) (void)hipHostUnregister(p);
+    munmap(p, bytes);
+}
+
 uint8_t* staging_buffer(Device* dev, size_t bytes)
 {
     if (bytes <= dev->capStage && dev->hStage) return dev->hStage;
     (void)hipSetDevice(dev->deviceId);                   // lane threads start on device 0
-    if (dev->hStage) (void)hipHostFree(dev->hStage);
+    if (dev->hStage) {
+        if (dev->nOldStage < 4u) { dev->oldStage[dev->nOldStage] = dev->hStage; dev->oldStageCap[dev->nOldStage] = dev->capStage; ++dev->nOldStage; }
+        else pinned_free(dev->hStage, dev->capStage, !dev->stagePageable);
+    }
     dev->hStage = nullptr; dev->capStage = 0;
-    const size_t want = bytes + bytes / 4 + 4096;
-    if (hipHostMalloc((void**)&dev->hStage, want, hipHostMallocDefault) != hipSuccess) { snprintf(dev->err, sizeof dev->err, "hipHostMalloc(%zu) failed", want); return nullptr; }
+    size_t want = bytes + bytes / 4 + 4096;
+    dev->hStage = (uint8_t*)pinned_alloc(&want, !dev->stagePageable);
+    if (!dev->hStage) { snprintf(dev->err, sizeof dev->err, "pinned staging buffer of %zu bytes failed", want); return nullptr; }
     dev->capStage = want;
     return dev->hStage;
 }
@@ -729,6 +762,8 @@ int lanes_equalize(Device* const* lanes, size_t n)
     for (size_t i = 0; i < n; ++i) {
         Device* dev = lanes[i];
         HIP_TRY(hipSetDevice(dev->deviceId));
+        for (uint32_t k = 0; k < dev->nOldStage; ++k) pinned_free(dev->oldStage[k], dev->oldStageCap[k], !dev->stagePageable);      // nothing is in flight here
+        dev->nOldStage = 0;
         auto grow = [&](auto*& p, size_t& cap, size_t want) -> int {
             if (cap >= want && p) return 0;
             if (p) (void)hipFree(p);

@@ -219,7 +219,7 @@ struct MatchLane {
     uint32_t* dWarm = nullptr; size_t capWarm = 0;
     uint32_t* dPlanes = nullptr; size_t capPlanes = 0;
     MatchRow* dRows = nullptr; size_t capRows = 0;
-    uint8_t* hStage = nullptr; size_t capStage = 0;
+    uint8_t* hStage = nullptr; size_t capStage = 0; bool stagePageable = false;
 };
 
 int match_lane_create(Device* dev, MatchLane** out)
@@ -257,7 +257,7 @@ void match_lane_destroy(MatchLane* m)
     }
     void* ptrs[] = {m->dSeq, m->dReads, m->dCalls, m->dIds, m->dWarm, m->dPlanes, m->dRows};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    if (m->hStage) (void)hipHostFree(m->hStage);
+    if (m->hStage) pinned_free(m->hStage, m->capStage, !m->stagePageable);
     if (m->evWait) (void)hipEventDestroy(m->evWait);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
@@ -275,10 +275,12 @@ int match_lane_reserve(Device* dev, MatchLane* m, size_t maxReads, size_t maxSeq
         ensureBuf(dev, m->dPlanes, m->capPlanes, planeBytes) || ensureBuf(dev, m->dRows, m->capRows, maxReads * sizeof(MatchRow))) return -1;
     const size_t upBytes = ((maxSeqBytes + 15) & ~(size_t)15) + ((maxReads * sizeof(MatchRead) + 15) & ~(size_t)15) + ((maxCalls * sizeof(MatchCall) + 15) & ~(size_t)15) + ((maxCalls * 4u + 15) & ~(size_t)15) + maxWarm * 4u + 64;
     if (upBytes > m->capStage) {
-        if (m->hStage) (void)hipHostFree(m->hStage);
+        if (m->hStage) pinned_free(m->hStage, m->capStage, !m->stagePageable);
         m->hStage = nullptr; m->capStage = 0;
-        HIP_TRY(hipHostMalloc((void**)&m->hStage, upBytes + 65536, hipHostMallocDefault));
-        m->capStage = upBytes + 65536;
+        size_t want = upBytes + 65536;
+        m->stagePageable = pageable_staging(); m->hStage = (uint8_t*)pinned_alloc(&want, !m->stagePageable);
+        if (!m->hStage) { snprintf(dev->err, sizeof dev->err, "device matcher: pinned staging buffer of %zu bytes failed", want); return -1; }
+        m->capStage = want;
     }
     return 0;
 }
@@ -318,10 +320,11 @@ int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
     // pinned staging for everything that goes up (the callers' arrays are pageable)
     const size_t upBytes = ((seqBytes + 15) & ~(size_t)15) + ((nReads * sizeof(MatchRead) + 15) & ~(size_t)15) + ((nCalls * sizeof(MatchCall) + 15) & ~(size_t)15) + ((nCalls * 4u + 15) & ~(size_t)15) + nWarm * 4u + 64;
     if (upBytes > m->capStage) {
-        if (m->hStage) (void)hipHostFree(m->hStage);
+        if (m->hStage) pinned_free(m->hStage, m->capStage, !m->stagePageable);
         m->hStage = nullptr; m->capStage = 0;
-        const size_t want = upBytes + upBytes / 4 + 65536;
-        HIP_TRY(hipHostMalloc((void**)&m->hStage, want, hipHostMallocDefault));
+        size_t want = upBytes + upBytes / 4 + 65536;
+        m->stagePageable = pageable_staging(); m->hStage = (uint8_t*)pinned_alloc(&want, !m->stagePageable);
+        if (!m->hStage) { snprintf(dev->err, sizeof dev->err, "device matcher: pinned staging buffer of %zu bytes failed", want); return -1; }
         m->capStage = want;
     }
     uint8_t* h = m->hStage; size_t o = 0;

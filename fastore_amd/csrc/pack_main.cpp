@@ -139,6 +139,8 @@ int main(int argc, char** argv)
     const bool trace = getenv("FS_TRACE") != nullptr;
     auto clk = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; };
     const double tm0 = clk();
+    auto wallNow = []() { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return (long long)ts.tv_sec * 1000 + ts.tv_nsec / 1000000; };
+    if (trace) fprintf(stderr, "[trace] main: entered at %lld ms (epoch)\n", wallNow());
     fsgpu_ctx* ctx = fsgpu_create(&cfg);
     if (!ctx) { fprintf(stderr, "Error: %s\n", fsgpu_create_error()); return 255; }
     const double tm1 = clk();
@@ -155,7 +157,7 @@ int main(int argc, char** argv)
     // piece (0.75 s for a 10 M-read library: 53 GB of arenas, the lanes' pinned staging buffers): the kernel reclaims
     // them with the process.  FS_ORDERLY_EXIT=1 keeps the orderly teardown (leak checkers, the sanitizer builds).
     if (!getenv("FS_ORDERLY_EXIT")) {
-        if (trace) fprintf(stderr, "[trace] main: context %.0f ms (HIP start-up, arena pool), pack %.0f ms, no teardown\n", tm1 - tm0, tm2 - tm1);
+        if (trace) fprintf(stderr, "[trace] main: context %.0f ms (HIP start-up, arena pool), pack %.0f ms, no teardown; leaving at %lld ms (epoch)\n", tm1 - tm0, tm2 - tm1, wallNow());
         fflush(stdout); fflush(stderr);
         _exit(0);
     }

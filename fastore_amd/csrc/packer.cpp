@@ -597,7 +597,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     std::thread laneMaker;
     std::atomic<uint32_t> madeLanes(haveLanes);
     if (makeLanes) laneMaker = std::thread([&]() {
-        auto prep = [&](fsengine::Device* d, uint32_t l) { if (l < nSlices && sliceEst[l]) (void)fsengine::staging_buffer(d, sliceEst[l] + (1u << 20)); };
+        auto prep = [&](fsengine::Device* d, uint32_t l) { if (l < nSlices && sliceEst[l]) (void)fsengine::staging_buffer(d, sliceEst[l] - sliceEst[l] / 8 /* the estimate runs ~8 % high and the buffer adds a quarter */); };
         if (fresh0) {
             prep(lanes[0], 0);
             { std::lock_guard<std::mutex> lk(laneMx); freeLanes.push_back(0); }
@@ -627,7 +627,18 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         {
             std::unique_lock<std::mutex> lk(laneMx);
             laneCv.wait(lk, [&]() { return !freeLanes.empty(); });
-            S.lane = (int)freeLanes.back(); freeLanes.pop_back();
+            // the free lane whose staging buffer fits best (the smallest that is large enough, else the largest): a buffer that
+            // must grow in the middle of a batch costs a pinned allocation between the slice's front end and its upload
+            size_t pick = freeLanes.size() - 1;
+            if (sliceEst[si]) {
+                const uint64_t need = sliceEst[si] - sliceEst[si] / 16;
+                bool fits = lanes[freeLanes[pick]]->capStage >= need;
+                for (size_t i = freeLanes.size(); i-- > 0;) {
+                    const size_t cap = lanes[freeLanes[i]]->capStage, best = lanes[freeLanes[pick]]->capStage;
+                    if (cap >= need ? (!fits || cap < best) : (!fits && cap > best)) { pick = i; fits = cap >= need; }
+                }
+            }
+            S.lane = (int)freeLanes[pick]; freeLanes.erase(freeLanes.begin() + (ptrdiff_t)pick);
         }
         S.tReady = nowMs();
         try {

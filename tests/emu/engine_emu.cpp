@@ -23,6 +23,8 @@ int device_create(Device** out, int, uint32_t, char*, size_t)
 int lane_create(Device*, Device** out, char* e, size_t n) { return device_create(out, 0, 0, e, n); }
 void device_destroy(Device* d) { if (d) free(d->hStage); delete d; }
 int lanes_equalize(Device* const*, size_t) { return 0; }
+void set_pageable_staging(bool) {}
+bool pageable_staging() { return false; }
 int lane_debug(Device*, char* out, size_t outLen) { if (out && outLen) snprintf(out, outLen, "host emulation"); return 0; }
 
 uint8_t* staging_buffer(Device* d, size_t bytes)
