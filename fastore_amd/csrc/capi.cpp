@@ -73,6 +73,7 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
     unsigned localRanks = 1;
     if (const char* lw = getenv("LOCAL_WORLD_SIZE")) localRanks = (unsigned)std::max(1, atoi(lw));
     const unsigned share = usableCores() * 3u / 2u / localRanks;
+    c.hostCores = std::max(1u, usableCores() / localRanks);
     c.hostThreads = cfg->host_threads ? cfg->host_threads : std::max(localRanks > 1 ? 4u : 1u, std::min(24u, share));
     if (getenv("FS_HOST_THREADS")) c.hostThreads = std::max(1, atoi(getenv("FS_HOST_THREADS")));     // experiments
     if (getenv("FS_PIPELINE_SLICES") && atoi(getenv("FS_PIPELINE_SLICES")) > 0) c.cfg.pipeline_slices = (uint32_t)atoi(getenv("FS_PIPELINE_SLICES"));

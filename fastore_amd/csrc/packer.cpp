@@ -523,6 +523,10 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     // lane); they take their arenas from the pool's slot maps.
     std::vector<uint32_t> cut{0};
     const bool autoSlices = cfg.pipeline_slices == 0;
+    // (one bin per CORE in the first round -- the threads beyond the cores joining as bins finish -- was tried: the first slice
+    // goes up 25 ms earlier, the second one, whose streams are nearly as long, later: no gain, profiles/r02_yy_first_round.txt)
+    uint32_t firstRound = hostThreads;
+    if (const char* fr = getenv("FS_FIRST_ROUND")) firstRound = std::max(1u, std::min<uint32_t>(hostThreads, (uint32_t)atoi(fr)));     // A/B runs
     const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? 14u : 1u);
     if (wantSlices > 1) {
         // FS_SLICE_WEIGHTS="1,2,2,3" (experiment): relative weights of ALL slices instead of the rule below
@@ -550,7 +554,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             // first slice is exactly the bins the host threads take in their first round (one each: ready when the
             // heaviest bin is), the middle slices grow, and the last ones -- small bins only, short streams -- shrink
             // again, so that little device work is left when the host is done.
-            const uint32_t firstBins = std::min<uint32_t>(std::max(1u, hostThreads), std::max(1u, nBins / wantSlices));
+            const uint32_t firstBins = std::min<uint32_t>(std::max(1u, firstRound), std::max(1u, nBins / wantSlices));
             uint64_t firstW = 0;
             for (uint32_t i = 0; i < firstBins; ++i) firstW += weight[byWork[i]];
             static const double upToFrac[] = {0.0, 0.10, 0.20, 0.32, 0.45, 0.58, 0.70, 0.80, 0.88, 0.94, 0.975, 0.99, 0.997, 1.0};   // of the weight behind the first slice
@@ -884,8 +888,14 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     const double tf = nowMs();
     if (trace) fprintf(stderr, "[trace] batch set-up (slices, %u lanes, matcher lanes) %.1f ms\n", nLanes, tf - t0);
     try {
+        std::mutex roundMx; std::condition_variable roundCv; uint32_t binsDone = 0;
         parallelFor(nBins, hostThreads, [&](uint32_t k, uint32_t tid) {
             const uint32_t b = byWork[k];
+            if (k >= firstRound && k < hostThreads) {            // a thread beyond the cores: its first bin starts when a core is free
+                std::unique_lock<std::mutex> lk(roundMx);
+                roundCv.wait(lk, [&]() { return binsDone > k - firstRound || abort.load(); });
+            }
+            struct Done { std::mutex& m; std::condition_variable& cv; uint32_t& n; ~Done() { { std::lock_guard<std::mutex> g(m); ++n; } cv.notify_all(); } } done{roundMx, roundCv, binsDone};     // (also when the bin throws)
             if (!encs[tid]) encs[tid].reset(new BinEncoder(par));
             // The heaviest bins -- the first few rounds of the host threads -- have their window searches done by the device:
             // they sit on the critical path (their quality streams are the longest) and the device is still nearly empty.

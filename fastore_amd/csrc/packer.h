@@ -94,6 +94,7 @@ struct Context {
     fsgpu_stats stats{};
     fsengine::BatchTiming timing;
     uint32_t hostThreads = 1;
+    uint32_t hostCores = 0;                       // cores this process may really use (0: unknown); hostThreads is 1.5 x that by default
     // buffers kept across calls (their pages stay mapped: no first-touch faults or munmap churn per batch)
     Batch workBatch;
     std::vector<BinStreams> streamPool;
