@@ -161,7 +161,13 @@ template <bool TWO> __device__ __forceinline__ void encode_streams_body()
             const uint32_t t = threadIdx.x;
             uint32_t v = 0;
             if (kind == KIND_PPMD && n > 0) {
-#if defined(FS_WIN_PROFILE)
+#if defined(FS_SER_PROFILE)
+                if (t >= 1u && t <= 5u) v = sh.serStats[t - 1u];       // (design study: the serial path's clocks in place of the window counters)
+                else if (t == 6u || t == 7u) v = sh.winStats[t];
+                if (t == 3u) v = sh.serStats[5];                        // rescales inside rounds
+                if (t == 1u) v = sh.serStats[6];                        // swaps inside rounds
+                if (t == 2u) v = sh.serStats[7];                        // positions walked in rounds
+#elif defined(FS_WIN_PROFILE)
                 if (t >= 1u && t <= 5u) v = sh.winStats[t - 1u];
                 else if (t == 6u || t == 7u) v = sh.winStats[t];          // serial-path clocks: escapes, UpdateModel
 #else

@@ -70,7 +70,10 @@ struct Shared {
     uint32_t qA[256], qM[256];
     uint32_t qTail, qHead;
     uint32_t qOutLo, qOutHi, qOutCap, qSizeLo, qSizeHi;     // the running stream's output buffer, capacity, and where its size goes
-    uint32_t winStats[16];       // windowed hit path: attempts, windows, symbols covered, rounds, redone windows; [8..15] phase clocks / 64 (FS_WIN_PROFILE builds)
+    uint32_t winStats[16];
+#if defined(FS_SER_PROFILE)
+    uint32_t serStats[8];        // design study: [0] symbol start -> first context ready, [1] first-context coding + coder hand-off, [2] tail of the loop, [3] serial symbols, [4] failed window attempts (clocks / 64)
+#endif       // windowed hit path: attempts, windows, symbols covered, rounds, redone windows; [8..15] phase clocks / 64 (FS_WIN_PROFILE builds)
 };
 
 // the three words of a context record as fetched (per-lane values, fetch still in flight): issue early, finish at first use
@@ -968,6 +971,9 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
     m.inAhead = 0;
     m.NumMasked = 0; m.FoundState = 0; m.BSumm = 0; m.rLow = m.rHigh = m.rScale = 0; m.fsSym = m.fsFreq = m.fsSucc = 0;
     for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) sh->winStats[i] = 0u;
+#if defined(FS_SER_PROFILE)
+    for (uint32_t i = (uint32_t)FS_LANE(); i < 8u; i += FS_WAVE) sh->serStats[i] = 0u;
+#endif
     for (uint32_t i = (uint32_t)FS_LANE(); i < 260u; i += FS_WAVE) sh->QT[i] = (uint8_t)QTable(i);
     // zero the 64-byte guard behind the heap: GlueFreeBlocks may read one stamp past the end
     for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) *(fs_gptr32)(arena + SA_SIZE + 4u * i) = 0u;
@@ -1004,7 +1010,13 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
             hint_learn(m, FS_UNI(hist), FS_UNI(MinContext));
             if (FS_UNI(winSkip) != 0u) --winSkip;
             else {
+#if defined(FS_SER_PROFILE)
+                uint64_t tW = FS_PROF_NOW();
+#endif
                 const uint32_t done = window_step(m, in, n, FS_UNI(pos), FS_UNI(MinContext), hist);
+#if defined(FS_SER_PROFILE)
+                if (done == 0u) FS_PROF_ACC(m.sh->serStats[4], tW);
+#endif
                 // a window that stopped short did so in front of a symbol for the serial path: skip one attempt.  An attempt
                 // that codes nothing doubles the pause (learning phase of a model, unpredictable streams).
                 // (a failed attempt costs less than half a serial symbol, and the symbols behind a read boundary are plain hits
@@ -1019,6 +1031,10 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
                 }
             }
         }
+#endif
+#if defined(FS_SER_PROFILE)
+        uint64_t tS = FS_PROF_NOW();
+        FS_STAT_ADD(m.sh->serStats[3], 1u);
 #endif
         int c = -1;
         if (FS_UNI(pos) < n) {
@@ -1046,8 +1062,14 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
         m.pfCtx = 0; keep = 0; prevCtx = MinContext; sufCtx = 0;
         mc.a = FS_UNI(mc.a); mc.w1 = FS_UNI(mc.w1); mc.suff = FS_UNI(mc.suff);
         FS_PATH(g_path[0]);
+#if defined(FS_SER_PROFILE)
+        FS_PROF_ACC(m.sh->serStats[0], tS);
+#endif
         if (mc.ns() != 0) { FS_PATH(g_path[2]); encodeSymbol1(m, MinContext, mc, c); rc_encode(m); if (m.FoundState) { if (m.rLow == 0) FS_PATH(g_path[3]); else FS_PATH(g_path[4]); } }
         else { FS_PATH(g_path[1]); encodeBinSymbol(m, MinContext, mc, c, sufRec, sufCtx); }
+#if defined(FS_SER_PROFILE)
+        FS_PROF_ACC(m.sh->serStats[1], tS);
+#endif
         uint32_t stop = 0;
         uint64_t tSer = FS_PROF_NOW();
         while (FS_UNI(m.FoundState) == 0) {
@@ -1069,7 +1091,13 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
         FS_SYMHOOK(prevCtx, MinContext, mc, m, succ);
         if (FS_UNI((uint32_t)m.OrderFall) == 0 && succ >= FS_UNI(m.UnitsStart)) { FS_PATH(g_path[7]); m.MaxContext = succ; keep = (succ == MinContext) ? 1u : 0u; }
         else { UpdateModel(m, MinContext, mc, FS_UNI(sufCtx) != 0 && FS_UNI(sufCtx) == FS_UNI(mc.suff), sufRec); if (FS_UNI(m.EscCount) == 0) clear_mask(m); FS_PROF_ACC(m.sh->winStats[7], tSer); }
+#if defined(FS_SER_PROFILE)
+        uint64_t tE = FS_PROF_NOW();
+#endif
         rc_normalize(m); MinContext = m.MaxContext;
+#if defined(FS_SER_PROFILE)
+        FS_PROF_ACC(m.sh->serStats[2], tE);
+#endif
     }
     if (restartsOut) *restartsOut = FS_UNI(m.sh->restarts);
     if (m.queued) { cq_push(m, CQ_CMD, CQ_END); if (qTailOut) *qTailOut = m.qTail; return 0u; }

@@ -139,6 +139,53 @@ template <int N> FS_DEV bool packed_rescale(Packed& c, uint32_t ns, uint32_t kf,
     return true;
 }
 
+// The usual rescale needs no sorting at all: the state that reaches MAX_FREQ is the one at the front (the found state stays
+// there), and halving keeps the order of the others unless two of them were out of order before (a single +4 may lift a
+// state over TWO predecessors, and only one swap is made).  ok(): found state at place 0, halved frequencies of the places
+// 1 .. ns not increasing -- then the network would leave every state where it is, and the rest is byte arithmetic on the
+// packed words.  Same results as packed_rescale<N> on that domain (checked against it on the lock-step emulation).
+FS_DEV bool packed_rescale_quick_ok(const Packed& c, uint32_t ns, uint32_t kf)
+{
+    const uint64_t vm = ns >= 7u ? ~0ull : ((1ull << (8u * (ns + 1u))) - 1ull);           // the bytes of the valid states
+    const uint64_t nf = (c.F >> 1) & 0x7F7F7F7F7F7F7F7Full & vm;
+    const uint64_t ge = ((nf | 0x8080808080808080ull) - (nf >> 8)) & 0x8080808080808080ull;   // byte j: nf[j] >= nf[j+1] (both below 128: no borrow crosses a byte)
+    const uint64_t need = (vm >> 8) & ~0xFFull & 0x8080808080808080ull;                   // places 1 .. ns-1
+    return kf == 0u && (ge & need) == need;
+}
+
+FS_DEV bool packed_rescale_quick(Packed& c, uint32_t ns, uint32_t& summ, uint32_t& flags, bool live)
+{
+    const uint64_t vm = ns >= 7u ? ~0ull : ((1ull << (8u * (ns + 1u))) - 1ull);
+    const uint64_t nf = (c.F >> 1) & 0x7F7F7F7F7F7F7F7Full & vm;
+    // a state other than the found one that would drop to zero: the serial path's business (no early return: every lane
+    // takes part in the vote below)
+    const uint64_t zx = nf | 0xFFull | ~vm;
+    const bool zeros = ((zx - 0x0101010101010101ull) & ~zx & 0x8080808080808080ull) != 0ull;
+    const uint64_t fv = c.F & vm;
+    const uint32_t sumOld = fs_sum_bytes((uint32_t)fv) + fs_sum_bytes((uint32_t)(fv >> 32)), sumNew = fs_sum_bytes((uint32_t)nf) + fs_sum_bytes((uint32_t)(nf >> 32));
+    const uint32_t f0 = (uint32_t)c.F & 0xFFu, nf0 = f0 >> 1;
+    const bool hiAny = (c.S & vm & ~0xFFull & 0xC0C0C0C0C0C0C0C0ull) != 0ull;
+    const uint32_t escFreq = summ - sumOld;
+    uint32_t s = sumNew + ((escFreq + 1u) >> 1), a = 2u;
+    // (a context's FIRST rescale sets the found state's bonus by a division -- forty instructions the wave only walks
+    // through when a lane that really rescales needs them; lanes that ride along keep whatever they compute)
+    if (fs_ballot(live && !zeros && (flags & 0x04u) == 0u) != 0ull) {
+        const uint32_t sfm = summ - escFreq;
+        uint32_t d = sfm - f0;
+        d |= (uint32_t)(d == 0u);
+        d = (f0 * s - sfm * nf0 + d - 1u) / d;
+        d = d < 2u ? 2u : (d > (uint32_t)MAX_FREQ / 2u - 18u ? (uint32_t)MAX_FREQ / 2u - 18u : d);
+        if ((flags & 0x04u) == 0u) a = d;
+    }
+    if (zeros) return false;
+    c.F = (nf & ~0xFFull) | (uint64_t)(nf0 + a);
+    c.S &= vm;
+    c.P &= ns >= 7u ? ~0u : ((1u << (4u * (ns + 1u))) - 1u);
+    summ = s + a;
+    flags = (flags & 0x14u) | (hiAny ? 0x08u : 0u) | 0x04u;
+    return true;
+}
+
 // One window at position `pos` (the serial state is at the top of its loop with OrderFall == 0 and MinContext ==
 // MaxContext).  Returns the number of symbols coded, 0 if the first position is not a plain hit.  On return > 0 the model
 // memory, the coder, PrevSuccess, MaxContext and `hist` are exactly what the serial walk would have left.
@@ -343,11 +390,29 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
                 const uint32_t dP = doSwap ? ((c.P >> j4) ^ (c.P >> ((j4 + 4u) & 31u))) & 0xFu : 0u;
                 c.P ^= (dP << j4) | (dP << ((j4 + 4u) & 31u));
             }
+#if defined(FS_SER_PROFILE)
+            FS_STAT_ADD(m.sh->serStats[5], fs_popc64(fs_ballot(resc)));
+            FS_STAT_ADD(m.sh->serStats[6], fs_popc64(fs_ballot(doSwap)));
+            FS_STAT_ADD(m.sh->serStats[7], fs_popc64(fs_ballot(act)));
+#endif
             bool cut = lost;
             if (fs_ballot(resc) != 0ull) {
                 Packed c2 = c; uint32_t summ2 = summ, flags2 = flags;
-                const bool done = fs_ballot(resc && ns > 3u) == 0ull ? packed_rescale<4>(c2, ns, doSwap ? kk - 1u : kk, summ2, flags2)
-                                                                      : packed_rescale<8>(c2, ns, doSwap ? kk - 1u : kk, summ2, flags2);
+                const uint32_t kf = doSwap ? kk - 1u : kk;
+                bool done;
+                if (fs_ballot(resc && !packed_rescale_quick_ok(c, ns, kf)) == 0ull) {
+                    done = packed_rescale_quick(c2, ns, summ2, flags2, resc);
+#if defined(FS_SIMT_EMU)
+                    {   // the lock-step emulation holds the short form against the network, lane by lane
+                        Packed c3 = c; uint32_t summ3 = summ, flags3 = flags;
+                        const bool done3 = packed_rescale<8>(c3, ns, kf, summ3, flags3);
+                        if (resc && (done3 != done || (done && (c3.S != c2.S || c3.F != c2.F || c3.P != c2.P || summ3 != summ2 || flags3 != flags2)))) {
+                            fprintf(stderr, "packed_rescale_quick differs from the network (ns %u)\n", ns); abort();
+                        }
+                        if (resc) simt_count_quick_rescale();
+                    }
+#endif
+                } else done = fs_ballot(resc && ns > 3u) == 0ull ? packed_rescale<4>(c2, ns, kf, summ2, flags2) : packed_rescale<8>(c2, ns, kf, summ2, flags2);
                 if (resc && done) { c = c2; summ = summ2; flags = flags2; }
                 if (resc && !done) cut = true;                     // a state drops out: the serial path takes this symbol
             }

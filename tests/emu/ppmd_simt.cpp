@@ -2,6 +2,12 @@
 // emulation of tests/emu/simt.h.  build: g++ -O2 -std=c++17 -DFS_SIMT_EMU -shared -fPIC -o build/libsimt_emu.so
 //        tests/emu/ppmd_simt.cpp tests/emu/simt.cpp
 #include <stdlib.h>
+#include <stdio.h>
+#include <atomic>
+// rescales the short form (packed_rescale_quick) took, each held against the sorting network inside ppmd_window.h
+static std::atomic<unsigned long long> g_quickRescales{0};
+static inline void simt_count_quick_rescale() { g_quickRescales++; }
+extern "C" unsigned long long simt_quick_rescales() { return g_quickRescales.load(); }
 #include "../../fastore_amd/csrc/ppmd_core.h"
 
 // the two-wave form: wave 0 walks the model and queues the coding steps, wave 1 is the coder wave; several streams one

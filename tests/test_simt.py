@@ -22,6 +22,7 @@ def simt():
     lib.simt_ppmd_encode.restype = ctypes.c_size_t
     lib.simt_ppmd_encode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
     lib.simt_ppmd_encode_two_waves.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5
+    lib.simt_quick_rescales.restype = ctypes.c_ulonglong
     return lib
 
 
@@ -50,6 +51,9 @@ def test_windowed_hit_path_reproduces_the_serial_walk_on_quality_streams(simt, o
     assert got == oracle_ppmd(oracle, data)
     # the path under test really ran: most of the stream went through windows, with shared contexts and redone windows
     assert st["covered"] > 0.7 * len(data) and st["rounds"] > st["windows"] and st["redone"] > 0, st
+    # most rescales inside the rounds take the short form (no sorting network); the emulation build holds every one of them
+    # against the network and aborts on a difference
+    assert simt.simt_quick_rescales() > 1000
 
 
 @pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 100, 4097, 20_001])
