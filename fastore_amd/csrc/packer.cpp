@@ -557,9 +557,15 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             const uint32_t firstBins = std::min<uint32_t>(std::max(1u, firstRound), std::max(1u, nBins / wantSlices));
             uint64_t firstW = 0;
             for (uint32_t i = 0; i < firstBins; ++i) firstW += weight[byWork[i]];
-            static const double upToFrac[] = {0.0, 0.10, 0.20, 0.32, 0.45, 0.58, 0.70, 0.80, 0.88, 0.94, 0.975, 0.99, 0.997, 1.0};   // of the weight behind the first slice
+            // (measured on the BASELINE library, profiles/r02_ae_slice_weights.txt: the first round goes up as TWO slices -- the
+            // heavier half does not wait for the other's last bin --, and the slices right behind it stay small: the second-round
+            // bins reach the device as they finish instead of waiting for 20 others, whose streams are nearly as long as the
+            // first round's.  With one 24-bin first slice and 21 / 24 / 34 behind it the step ended with the SECOND slice.)
+            static const double upToFrac[] = {0.0, 0.0, 0.05, 0.10, 0.167, 0.257, 0.369, 0.504, 0.639, 0.762, 0.863, 0.942, 0.981, 1.0};   // of the weight behind the first round
+            const uint32_t half = firstBins >= 2u && wantSlices >= 4u ? (firstBins + 1u) / 2u : 0u;
+            if (half) cut.push_back(half);
             cut.push_back(firstBins);
-            uint64_t acc = 0; uint32_t k = 1;
+            uint64_t acc = 0; uint32_t k = half ? 2u : 1u;
             const double rest = (double)(totalW - firstW);
             for (uint32_t i = firstBins; i < nBins && k + 1 < wantSlices; ++i) {
                 acc += weight[byWork[i]];
