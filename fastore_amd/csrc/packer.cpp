@@ -105,7 +105,7 @@ ArchiveWriter::ArchiveWriter(ArchiveWriter&& o)
 
 void ArchiveWriter::reserveAhead(uint64_t bytes)
 {
-    if (inMemory_ || !data_ || pre_ || bytes < (8u << 20)) return;
+    if (inMemory_ || !data_ || pre_ || (bytes < (8u << 20) && !getenv("FS_AHEAD_BYTES"))) return;
     const int fd = fileno(data_);
     struct stat sb;
     if (fstat(fd, &sb) != 0 || (uint64_t)sb.st_size >= bytes) return;
@@ -234,9 +234,21 @@ void ArchiveWriter::writeBlocks(const std::vector<const uint8_t*>& data, const s
     for (uint32_t k = 1; k < t; ++k) { const uint64_t want = off[n] / t * k; cut[k] = (size_t)(std::lower_bound(off.begin(), off.end(), want) - off.begin()); if (cut[k] > n) cut[k] = n; }
     // Through a shared mapping of the file's new extent when the file system allows it: write() calls on ONE file take
     // its lock in turn (~4 GB/s whatever the thread count), page-cache pages of a mapping are filled side by side.
-    if (pre_ && (uint64_t)base + off[n] <= preLen_) {
+    if (pre_ && (uint64_t)base < preLen_) {
+        // blocks that end inside the reserved extent go into its (already present) pages; what lies behind it -- the estimate
+        // was short -- is written at its place
         uint8_t* dst = pre_ + base;
-        parallelFor(t, t, [&](uint32_t k, uint32_t) { for (size_t i = cut[k]; i < cut[k + 1]; ++i) memcpy(dst + off[i], data[i], sizes[i]); });
+        parallelFor(t, t, [&](uint32_t k, uint32_t) {
+            for (size_t i = cut[k]; i < cut[k + 1]; ++i) {
+                if ((uint64_t)base + off[i + 1] <= preLen_) { memcpy(dst + off[i], data[i], sizes[i]); continue; }
+                uint64_t done = 0;
+                while (done < sizes[i]) {
+                    const ssize_t w = pwrite(fd, data[i] + done, sizes[i] - done, base + (off_t)(off[i] + done));
+                    if (w <= 0) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
+                    done += (uint64_t)w;
+                }
+            }
+        });
         if (fseeko(data_, base + (off_t)off[n], SEEK_SET) != 0) throw std::runtime_error("Cannot write " + prefix_ + ".cdata");
         dataBytes_ += off[n];
         return;
@@ -1165,21 +1177,21 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             for (size_t k = first; k < next; ++k) binArch.push_back(work[k].lib);
             stats.io_ms += nowMs() - tio;
             const bool lastBatchNow = next >= work.size();
-            // what the archives will hold at the end, roughly: what they hold, what is pending, block 0 and three tenths of this
+            // what the archives will hold at the end, roughly: what they hold, what is pending, block 0 and a quarter of this
             // batch's staged bytes (PPMd on quality scores) -- their page-cache pages are made while the device works
             std::vector<uint64_t> aheadBytes(nLibs, 0);
             if (lastBatchNow) {
-                for (uint32_t k = 0; k < nb; ++k) aheadBytes[work[first + k].lib] += stageEstimate[k] * 3 / 10;
+                for (uint32_t k = 0; k < nb; ++k) aheadBytes[work[first + k].lib] += stageEstimate[k] / 4;
                 for (size_t l = 0; l < nLibs; ++l) {
                     Lib& L = *libs[l];
-                    uint64_t have = L.aw.dataBytes() + (64u << 20);             // (+ block 0 and slack)
+                    uint64_t have = L.aw.dataBytes() + (24u << 20);             // (+ block 0 and slack; what does not fit is written behind the extent)
                     for (const Lib::Pending& pd : L.pending) have += pd.data.size();
                     aheadBytes[l] += have;
                 }
             }
             onHostTasksDone = [&, lastBatchNow]() {
                 if (!lastBatchNow) return;
-                for (size_t l = 0; l < nLibs; ++l) libs[l]->aw.reserveAhead(aheadBytes[l]);
+                for (size_t l = 0; l < nLibs; ++l) libs[l]->aw.reserveAhead(getenv("FS_AHEAD_BYTES") ? (uint64_t)atoll(getenv("FS_AHEAD_BYTES")) : aheadBytes[l]);      // (the variable: tests of a short estimate)
                 { std::lock_guard<std::mutex> lk(gateMx); hostTasksDone = true; }
                 gateCv.notify_all();
                 closer = std::thread([&]() {                       // the mapped inputs have been read for the last time

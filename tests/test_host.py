@@ -109,6 +109,18 @@ def test_host_pipeline_reproduces_reference_archives(emu_lib, tmp_path, name, pa
     assert st["bins"] > 20 and st["block0_records"] > 0      # both the LZ path and block 0 are exercised
 
 
+@pytest.mark.parametrize("ahead", [65536, 200000, 1 << 20])
+def test_archive_extent_reserved_ahead_too_short_or_too_long(emu_lib, tmp_path, monkeypatch, ahead):
+    # the archive's pages are reserved from an ESTIMATE while the device works: blocks that end inside the extent are copied
+    # into it, the others are written behind it, and the file is cut to its real length -- whatever the estimate was
+    import fastore_amd
+    monkeypatch.setenv("FS_AHEAD_BYTES", str(ahead))
+    name, paired, flags = manifest()[0]
+    with fastore_amd.Packer(lib=emu_lib, host_threads=4, **knobs_from_flags(flags)) as p:
+        p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / "o"))
+    assert_same_archive(str(tmp_path / "o"), os.path.join(GOLDEN, name + ".ref"))
+
+
 @pytest.mark.parametrize("slices,lanes", [(4, 2), (7, 3), (2, 1)])
 def test_sliced_pipeline_does_not_change_the_archive(emu_lib, tmp_path, slices, lanes):
     # a batch cut into slices (front end of slice k+1 overlapping the device work of slice k) yields the same blocks
