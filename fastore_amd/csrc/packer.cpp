@@ -235,6 +235,7 @@ void ArchiveWriter::writeBlocks(const std::vector<const uint8_t*>& data, const s
     // Through a shared mapping of the file's new extent when the file system allows it: write() calls on ONE file take
     // its lock in turn (~4 GB/s whatever the thread count), page-cache pages of a mapping are filled side by side.
     if (pre_ && (uint64_t)base < preLen_) {
+        if (preTh_.joinable()) preTh_.join();                     // (long done: its pages were made while the device worked)
         // blocks that end inside the reserved extent go into its (already present) pages; what lies behind it -- the estimate
         // was short -- is written at its place
         uint8_t* dst = pre_ + base;
