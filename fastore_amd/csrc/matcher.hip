@@ -206,7 +206,10 @@ namespace fsengine {
 // The searches of all host threads go through TWO streams per GPU (each thread has its own buffers; a thread's copies and
 // kernels keep their order on the stream they share with others).  The coder lanes hold 14 of the 16 hardware queues for
 // kernels that run for a second: a stream that had to share one of THOSE queues would wait behind such a kernel.
-struct StreamPool { hipStream_t s[2] = {nullptr, nullptr}; int users = 0; unsigned next = 0; };
+enum { kMatchStreamsMax = 6 };
+struct StreamPool { hipStream_t s[kMatchStreamsMax] = {}; int users = 0; unsigned next = 0; };
+// streams the matcher lanes of a device share (FS_MATCHER_STREAMS: A/B runs; the coder lanes need a hardware queue each)
+static int matchStreams() { static const int n = []() { const char* e = getenv("FS_MATCHER_STREAMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > kMatchStreamsMax ? (int)kMatchStreamsMax : v); }(); return n; }
 static std::mutex g_poolMx; static StreamPool g_pool[16];
 
 struct MatchLane {
@@ -233,8 +236,8 @@ int match_lane_create(Device* dev, MatchLane** out)
     {
         std::lock_guard<std::mutex> g(g_poolMx);
         StreamPool& p = g_pool[dev->deviceId & 15];
-        for (int i = 0; i < 2 && e == hipSuccess; ++i) if (!p.s[i]) e = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
-        if (e == hipSuccess) { m->stream = p.s[p.next++ & 1u]; ++p.users; }
+        for (int i = 0; i < matchStreams() && e == hipSuccess; ++i) if (!p.s[i]) e = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
+        if (e == hipSuccess) { m->stream = p.s[p.next++ % (unsigned)matchStreams()]; ++p.users; }
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->evWait, hipEventBlockingSync | hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&m->ev0);
@@ -252,7 +255,7 @@ void match_lane_destroy(MatchLane* m)
         (void)hipStreamSynchronize(m->stream);
         std::lock_guard<std::mutex> g(g_poolMx);
         StreamPool& p = g_pool[m->deviceId & 15];
-        if (--p.users == 0) { for (int i = 0; i < 2; ++i) if (p.s[i]) { (void)hipStreamDestroy(p.s[i]); p.s[i] = nullptr; } }
+        if (--p.users == 0) { for (int i = 0; i < kMatchStreamsMax; ++i) if (p.s[i]) { (void)hipStreamDestroy(p.s[i]); p.s[i] = nullptr; } }
         m->stream = nullptr;
     }
     void* ptrs[] = {m->dSeq, m->dReads, m->dCalls, m->dIds, m->dWarm, m->dPlanes, m->dRows};
