@@ -1046,6 +1046,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         BinFile bf; ArchiveWriter aw;
         Batch b0; std::vector<uint8_t> block0; std::thread t0; std::string t0err; double t0ms = 0;
         bool haveBlock0 = false, block0Written = true, finished = false;
+        bool block0InFile = false;               // its own thread has put block 0 at the head of the (still empty) archive
         std::atomic<bool> t0done{false};        // the block-0 thread has finished (its block can be written without waiting)
         struct Pending { std::vector<uint8_t> data; std::vector<uint64_t> sizes; std::vector<uint32_t> sigs; };
         std::vector<Pending> pending;
@@ -1100,6 +1101,9 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                     { std::lock_guard<std::mutex> lk(gateMx); ++block0Unpacked; }
                     gateCv.notify_all();
                     compressRawBlock(lp->b0, *ap, lp->block0);
+                    // Block 0 heads the archive and nothing is written in front of it: this thread puts it there itself, while
+                    // the device still walks the long streams (the writer belongs to this thread until it is joined).
+                    if (lp->aw.dataBytes() == 0 && lp->pending.empty()) { lp->aw.writeBlock(lp->block0.data(), lp->block0.size(), lp->bf.nSignature()); lp->block0InFile = true; }
                 } catch (const std::exception& e) {
                     lp->t0err = e.what();
                     { std::lock_guard<std::mutex> lk(gateMx); ++block0Unpacked; }       // never leave the closer waiting
@@ -1115,7 +1119,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             if (!wait && !L.t0done.load()) return;
             L.t0.join(); if (!L.t0err.empty()) throw std::runtime_error(L.t0err);
             stats.block0_ms = std::max(stats.block0_ms, L.t0ms); stats.block0_bytes += L.block0.size(); stats.block0_records += L.b0.recs.size();
-            L.aw.writeBlock(L.block0.data(), L.block0.size(), L.bf.nSignature());
+            if (!L.block0InFile) L.aw.writeBlock(L.block0.data(), L.block0.size(), L.bf.nSignature());
             L.block0Written = true; L.b0.clear(); L.block0.clear(); L.block0.shrink_to_fit();
         }
         for (auto& p : L.pending) { uint64_t off = 0; for (size_t k = 0; k < p.sizes.size(); ++k) { L.aw.writeBlock(p.data.data() + off, p.sizes[k], p.sigs[k]); off += p.sizes[k]; } }
@@ -1239,7 +1243,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                     if (!L.block0Written) {
                         L.t0.join(); if (!L.t0err.empty()) throw std::runtime_error(L.t0err);
                         { std::lock_guard<std::mutex> g(statMx); stats.block0_ms = std::max(stats.block0_ms, L.t0ms); stats.block0_bytes += L.block0.size(); stats.block0_records += L.b0.recs.size(); }
-                        L.aw.writeBlock(L.block0.data(), L.block0.size(), L.bf.nSignature());
+                        if (!L.block0InFile) L.aw.writeBlock(L.block0.data(), L.block0.size(), L.bf.nSignature());
                         L.block0Written = true; L.b0.clear(); L.block0.clear(); L.block0.shrink_to_fit();
                     }
                     for (auto& p : L.pending) { uint64_t off = 0; for (size_t k = 0; k < p.sizes.size(); ++k) { L.aw.writeBlock(p.data.data() + off, p.sizes[k], p.sigs[k]); off += p.sizes[k]; } }
