@@ -287,6 +287,7 @@ def main():
             # program's time --, hence three runs; the best one is quoted, all three and their median are listed)
             res["cli_end_to_end"] = {"value": round(fastq_bytes / tc / 1e6, 2) if rc == 0 else None, "unit": "MB/s", "seconds": tc, "runs_seconds": runs,
                                      "median_seconds": sorted(runs)[len(runs) // 2], "quoted": "best of the runs", "exit": rc,
+                                     "archive_identical_to_the_in_process_one": bool(rc == 0 and world == 1 and all(open(os.path.join(args.work, "cli") + e, "rb").read() == open(out + e, "rb").read() for e in (".cdata", ".cmeta"))),
                                      "command": "fastore_pack e " + " ".join(PACK_FLAGS + pe)}
         if not args.no_cpu_baseline and not lib_set:
             # the reference's multi-threaded pack dead-locks at -t64 (observed here and in the build container), so the
