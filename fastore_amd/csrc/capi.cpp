@@ -4,6 +4,7 @@
 #include <string.h>
 #include <stdexcept>
 #include <string>
+#include <future>
 #include <thread>
 #include "../../include/fastore_amd.h"
 #include "packer.h"
@@ -81,23 +82,36 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
     if (getenv("FS_DEVICE_MATCHER") && atoi(getenv("FS_DEVICE_MATCHER")) == 0) c.deviceMatcher = false;       // A/B runs: the host window scan
     if (getenv("FS_MAX_WAVES") && atoi(getenv("FS_MAX_WAVES")) > 0) c.cfg.max_waves = (uint32_t)atoi(getenv("FS_MAX_WAVES"));
     if (c.par.mismatchCost <= 0 || c.par.shiftCost < 0 || c.par.maxLzWindowSize == 0 || c.par.maxPairLzWindowSize == 0) { g_createError = "invalid matcher parameters"; delete ctx; return nullptr; }
-    if (fsengine::device_count() <= 0) {
-        g_createError = "no HIP device available: the fastore_pack hot path has no CPU fallback";
-        delete ctx; return nullptr;
-    }
-    char err[256] = {0};
     {   // one-shot contexts stage through pageable memory (FS_PAGEABLE_STAGING=0/1 forces either way: A/B runs)
         bool pageable = cfg->one_shot != 0;
         if (const char* ps = getenv("FS_PAGEABLE_STAGING")) pageable = atoi(ps) != 0;
         fsengine::set_pageable_staging(pageable);
     }
-    if (fsengine::device_create(&c.dev, cfg->device_id, c.cfg.max_waves, err, sizeof err) != 0) { g_createError = err; delete ctx; return nullptr; }
+    // the device: at once -- or, for a context that packs once, on a thread of its own while the caller goes on to the
+    // pack call and the front end of the first bins (fs::Context::device() waits for it; a failure is reported there, as
+    // loudly: "no HIP device available ..." becomes the pack call's error).  FS_SYNC_DEVICE=1 keeps the order of old.
+    fs::Context* cp = &c;
+    const int deviceId = cfg->device_id; const uint32_t maxWaves = c.cfg.max_waves;
+    auto make = [cp, deviceId, maxWaves]() -> std::string {
+        if (fsengine::device_count() <= 0) return "no HIP device available: the fastore_pack hot path has no CPU fallback";
+        char err[256] = {0};
+        if (fsengine::device_create(&cp->dev, deviceId, maxWaves, err, sizeof err) != 0) return err[0] ? std::string(err) : std::string("device creation failed");
+        return std::string();
+    };
+    if (cfg->one_shot && !getenv("FS_SYNC_DEVICE")) {
+        c.devPending = std::async(std::launch::async, make).share();
+        c.devAsync.store(true);
+        return ctx;
+    }
+    const std::string e = make();
+    if (!e.empty()) { g_createError = e; delete ctx; return nullptr; }
     return ctx;
 }
 
 void fsgpu_destroy(fsgpu_ctx* ctx)
 {
     if (!ctx) return;
+    if (ctx->c.devAsync.load()) { try { (void)ctx->c.device(); } catch (...) {} }       // (a device still on its way is waited for, then released)
     const bool trace = getenv("FS_TRACE") != nullptr;
     auto clk = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; };
     const double t0 = clk();
@@ -111,7 +125,11 @@ void fsgpu_destroy(fsgpu_ctx* ctx)
     if (trace) fprintf(stderr, "[trace] destroy: matcher lanes %.1f ms, lanes %.1f ms, first lane + pool %.1f ms, host buffers %.1f ms\n", t1 - t0, t2 - t1, t3 - t2, clk() - t3);
 }
 const char* fsgpu_last_error(const fsgpu_ctx* ctx) { return ctx ? ctx->c.err.c_str() : "null context"; }
-const char* fsgpu_device_name(const fsgpu_ctx* ctx) { return (ctx && ctx->c.dev) ? ctx->c.dev->name : ""; }
+const char* fsgpu_device_name(const fsgpu_ctx* ctx)
+{
+    if (!ctx) return "";
+    try { return const_cast<fsgpu_ctx*>(ctx)->c.device()->name; } catch (...) { return ""; }
+}
 
 int fsgpu_set_archive_params(fsgpu_ctx* ctx, const void* cfgRaw, size_t cfgBytes, const uint8_t* fields, size_t fieldBytes)
 {
@@ -161,7 +179,7 @@ int fsgpu_qvz_encode(fsgpu_ctx* ctx, const uint8_t* footer, size_t footerBytes, 
         memcpy(input.data(), model.blob.data(), model.blob.size());
         for (size_t i = 0; i < n; ++i) if (!sym[i].empty()) memcpy(input.data() + items[i].in_off, sym[i].data(), sym[i].size());
         std::vector<uint8_t> raw; std::vector<uint32_t> rawSizes;
-        if (fsengine::encode_streams_raw(ctx->c.dev, input.data(), inBytes, items, raw, rawSizes, &ctx->c.timing) != 0) throw std::runtime_error(std::string("device: ") + ctx->c.dev->err);
+        if (fsengine::encode_streams_raw(ctx->c.device(), input.data(), inBytes, items, raw, rawSizes, &ctx->c.timing) != 0) throw std::runtime_error(std::string("device: ") + ctx->c.dev->err);
         for (size_t i = 0; i < n; ++i) {
             if (rawSizes[i] == 0xFFFFFFFFu) throw std::runtime_error("QVZ stream: malformed symbol or output overflow");
             outLen[i] = rawSizes[i];
@@ -409,7 +427,7 @@ static int encodeStreams(fsgpu_ctx* ctx, size_t n, const uint32_t* kinds, const 
         // one pseudo-bin per stream so that the assemble step hands every stream back separately
         std::vector<fsdev::BlockPlan> plans; std::vector<uint8_t> blocks; std::vector<uint64_t> sizes;
         std::vector<uint8_t> raw; std::vector<uint32_t> rawSizes;
-        if (fsengine::encode_streams_raw(ctx->c.dev, input.data(), inBytes, items, raw, rawSizes, &ctx->c.timing) != 0) throw std::runtime_error(std::string("device: ") + ctx->c.dev->err);
+        if (fsengine::encode_streams_raw(ctx->c.device(), input.data(), inBytes, items, raw, rawSizes, &ctx->c.timing) != 0) throw std::runtime_error(std::string("device: ") + ctx->c.dev->err);
         for (size_t i = 0; i < n; ++i) {
             if (rawSizes[i] == 0xFFFFFFFFu) throw std::runtime_error("stream " + std::to_string(i) + ": symbol or context outside its coder's alphabet");
             outLen[i] = rawSizes[i];
@@ -456,7 +474,7 @@ int fsgpu_gather_quality(fsgpu_ctx* ctx, const uint8_t* packed, size_t packedByt
         for (size_t i = 0; i < n; ++i) { qs[i].src_bit = strings[i].src_bit; qs[i].dst_off = (uint32_t)dst; qs[i].len = (uint16_t)strings[i].len; qs[i].reverse = strings[i].reverse ? 1 : 0; dst += strings[i].len; }
         fsdev::GatherPlan gp; gp.desc_off = descOff; gp.n_strings = (uint32_t)n; gp.out_bytes = (total + 15u) & ~15ull; gp.symbols = total;
         std::vector<uint8_t> res;
-        if (fsengine::gather_quality_raw(ctx->c.dev, input.data(), descOff + n * sizeof(fsdev::QuaString), gp, res, &ctx->c.timing) != 0) throw std::runtime_error(std::string("device: ") + ctx->c.dev->err);
+        if (fsengine::gather_quality_raw(ctx->c.device(), input.data(), descOff + n * sizeof(fsdev::QuaString), gp, res, &ctx->c.timing) != 0) throw std::runtime_error(std::string("device: ") + ctx->c.dev->err);
         memcpy(out, res.data(), total);
     });
 }
@@ -488,7 +506,7 @@ int fsgpu_gather_quality_binned(fsgpu_ctx* ctx, const uint8_t* packed, size_t pa
         fsdev::GatherPlan gp; gp.desc_off = descOff; gp.n_strings = (uint32_t)n; gp.out_bytes = (2 * total + 15u) & ~15ull; gp.symbols = total; gp.bits = bits;
         gp.n_list_off = nOff; gp.n_list_bytes = nBytes; gp.sym_of_bit[0] = 6u >= binaryThreshold ? 1u : 0u; gp.sym_of_bit[1] = 40u >= binaryThreshold ? 1u : 0u;
         std::vector<uint8_t> res;
-        if (fsengine::gather_quality_raw(ctx->c.dev, input.data(), nOff + nBytes + 16, gp, res, &ctx->c.timing) != 0) throw std::runtime_error(std::string("device: ") + ctx->c.dev->err);
+        if (fsengine::gather_quality_raw(ctx->c.device(), input.data(), nOff + nBytes + 16, gp, res, &ctx->c.timing) != 0) throw std::runtime_error(std::string("device: ") + ctx->c.dev->err);
         memcpy(out, res.data(), 2 * total);
     });
 }

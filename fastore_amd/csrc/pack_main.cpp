@@ -146,7 +146,11 @@ int main(int argc, char** argv)
     const double tm1 = clk();
     const int rc = fsgpu_pack_file(ctx, in.c_str(), out.c_str(), verbose);
     const double tm2 = clk();
-    if (rc != 0) { fprintf(stderr, "Error: %s\n", fsgpu_last_error(ctx)); fsgpu_destroy(ctx); return 255; }
+    if (rc != 0) {
+        fprintf(stderr, "Error: %s\n", fsgpu_last_error(ctx)); fsgpu_destroy(ctx);
+        remove((out + ".cdata").c_str()); remove((out + ".cmeta").c_str());       // (no half-written archive is left behind)
+        return 255;
+    }
     if (verbose) {
         fsgpu_stats st; fsgpu_get_stats(ctx, &st);
         fprintf(stderr, "device %s: %llu bins, %llu records, encode kernel %.1f ms, assemble %.1f ms, front end %.1f ms, block0 %.1f ms, io %.1f ms, total %.1f ms\n",

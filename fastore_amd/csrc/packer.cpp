@@ -337,12 +337,22 @@ void ArchiveWriter::finish(const HeaderStats& head, const QvzModel& qvz)
 // Lanes: independent engine instances on the same GPU (own HIP stream, arena pool, buffers).  A batch is cut into
 // slices; while the device codes slice k on one lane, the host threads run the front end of slice k+1, and the kernels
 // of consecutive slices overlap on the device (the waves a draining kernel frees are taken by the next one).
+fsengine::Device* Context::device()
+{
+    if (devAsync.load()) {
+        std::lock_guard<std::mutex> g(devMx);
+        if (devAsync.load()) { devError = devPending.get(); devAsync.store(false); }
+    }
+    if (!dev) throw std::runtime_error(devError.empty() ? std::string("no device") : devError);
+    return dev;
+}
+
 fsengine::Device* Context::lane(uint32_t i)
 {
-    if (lanes.empty()) lanes.push_back(dev);
+    if (lanes.empty()) lanes.push_back(device());
     while (lanes.size() <= i) {
         fsengine::Device* d = nullptr; char e[256] = {0};
-        if (fsengine::lane_create(dev, &d, e, sizeof e) != 0) {
+        if (fsengine::lane_create(device(), &d, e, sizeof e) != 0) {
             if (getenv("FS_TRACE")) fprintf(stderr, "[trace] no further engine lane: %s\n", e);
             return nullptr;
         }
@@ -396,6 +406,10 @@ MatchFn Context::matcherFor(uint32_t tid)
     if (matchLanes.size() <= tid) throw std::runtime_error("matcher lanes not sized");       // (sized by the callers before their threads start)
     return [this, tid](const uint8_t* seq, size_t seqBytes, const fsdev::MatchRead* reads, size_t nReads, const fsdev::MatchCall* calls, size_t nCalls,
                        const uint32_t* warm, size_t nWarm, const fsdev::MatchParams& mp, fsdev::MatchRow* rows) -> bool {
+        // (a device still on its way -- one-shot contexts -- is waited for a little: the heaviest bins, searched first, gain
+        // most from it; should it take longer -- a driver clearing memory -- the host scan gives the same rows)
+        if (!deviceReadyWithin(300)) return false;
+        fsengine::Device* dev = device();
         if (!matchLanes[tid]) {
             // a thread's first search: its lane, with room for the batch's largest bin at once (from nothing: no buffer
             // is freed here, so no wait for running kernels) -- the host threads do this side by side, in their first bins
@@ -467,7 +481,7 @@ void Context::tokeniserCheck(const std::string& inPrefix, uint64_t& ids, uint64_
         fsdev::IdPlan plan; plan.jobs_off = jobsOff; plan.strings_off = strOff; plan.n_jobs = 1; plan.n_strings = (uint32_t)n;
         plan.out_bytes = job.val_out + ((2ull * n * valPer + 31u) & ~15ull);
         std::vector<std::vector<uint8_t>> tok, val;
-        if (fsengine::tokenise_ids_raw(dev, input.data(), off, plan, tok, val) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+        if (fsengine::tokenise_ids_raw(device(), input.data(), off, plan, tok, val) != 0) throw std::runtime_error(std::string("device: ") + device()->err);
         ids += n;
         if (tok[0] != tokH || val[0] != valH) ++differingBins;
     }
@@ -592,7 +606,8 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     const uint32_t wantLanes = nSlices > 1 ? std::min<uint32_t>(nSlices, cfg.pipeline_lanes ? cfg.pipeline_lanes : kMaxLanes) : 1;
     // lanes of an earlier batch are there; a fresh context (the CLI) makes lane 0 here and the others beside the front end
     // (a stream, events: 10-20 ms each), handing each to the slices as it comes
-    (void)lane(0);
+    const bool devPendingNow = !deviceReadyWithin(0);               // (one-shot context whose device is still being made: the lane maker waits for it)
+    if (!devPendingNow) (void)lane(0);
     lanes.reserve(std::max<size_t>(lanes.capacity(), 64));          // (slice threads read lanes[] while the maker appends)
     const uint32_t haveLanes = std::min<uint32_t>(wantLanes, (uint32_t)lanes.size());
     uint32_t nLanes = haveLanes;
@@ -600,7 +615,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     // Lanes of the previous batch get the buffers of its best-equipped one now (not at its end: a one-shot run -- the CLI --
     // would pay for pinned and device memory it never uses): whichever slice a lane gets, nothing has to grow -- and so to
     // be freed, which waits for every kernel in flight -- while the long streams are being coded.
-    equalizeNow();
+    if (!devPendingNow) equalizeNow();
     struct Slice {
         std::vector<StreamItem> items; std::vector<BlockPlan> plans; std::vector<uint64_t> sizes;
         fsengine::BatchTiming timing; std::string err; std::thread th; double tReady = 0, tSubmit = 0, tDone = 0, bufMs = 0;
@@ -615,30 +630,41 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     if (stageEstimate.size() == nBins) for (uint32_t si = 0; si < nSlices; ++si) for (uint32_t k = cut[si]; k < cut[si + 1]; ++k) sliceEst[si] += stageEstimate[byWork[k]];
     stageEstimate.clear();                                          // (it describes this call's bins only)
     const bool makeLanes = haveLanes < wantLanes;
-    const bool fresh0 = makeLanes && haveLanes == 1 && lanes[0]->hStage == nullptr && sliceEst[0] != 0;
+    const bool fresh0 = makeLanes && (haveLanes == 0 || (haveLanes == 1 && lanes[0]->hStage == nullptr && sliceEst[0] != 0));
     for (uint32_t l = nLanes; l-- > 0;) if (!(fresh0 && l == 0)) freeLanes.push_back(l);
-    std::thread laneMaker;
-    std::atomic<uint32_t> madeLanes(haveLanes);
-    if (makeLanes) laneMaker = std::thread([&]() {
-        auto prep = [&](fsengine::Device* d, uint32_t l) { if (l < nSlices && sliceEst[l]) (void)fsengine::staging_buffer(d, sliceEst[l] - sliceEst[l] / 8 /* the estimate runs ~8 % high and the buffer adds a quarter */); };
-        if (fresh0) {
-            prep(lanes[0], 0);
-            { std::lock_guard<std::mutex> lk(laneMx); freeLanes.push_back(0); }
-            laneCv.notify_one();
-        }
-        for (uint32_t l = haveLanes; l < wantLanes; ++l) {
-            fsengine::Device* d = nullptr; char e[256] = {0};
-            if (fsengine::lane_create(dev, &d, e, sizeof e) != 0) { if (trace) fprintf(stderr, "[trace] no further engine lane: %s\n", e); break; }
-            prep(d, l);
-            { std::lock_guard<std::mutex> lk(laneMx); lanes.push_back(d); freeLanes.insert(freeLanes.begin(), l); }
-            laneCv.notify_one(); madeLanes = l + 1;
-        }
-    });
     std::vector<Slice> slices(nSlices);
     std::vector<uint32_t> sliceOf(nBins);
     for (uint32_t si = 0; si < nSlices; ++si) { slices[si].pending = cut[si + 1] - cut[si]; for (uint32_t k = cut[si]; k < cut[si + 1]; ++k) sliceOf[k] = si; }
     sliceBlocks.resize(std::max<size_t>(sliceBlocks.size(), nSlices));
     std::atomic<bool> abort(false);
+    std::thread laneMaker;
+    std::atomic<uint32_t> madeLanes(haveLanes);
+    std::string makerErr;
+    if (makeLanes) laneMaker = std::thread([&]() {
+        auto prep = [&](fsengine::Device* d, uint32_t l) { if (l < nSlices && sliceEst[l]) (void)fsengine::staging_buffer(d, sliceEst[l] - sliceEst[l] / 8 /* the estimate runs ~8 % high and the buffer adds a quarter */); };
+        fsengine::Device* first = nullptr;
+        try {
+            first = device();                                       // waits for a device that is still being made
+            if (haveLanes == 0) { std::lock_guard<std::mutex> lk(laneMx); (void)lane(0); }
+        } catch (const std::exception& e) {
+            makerErr = e.what(); abort.store(true);
+            for (Slice& sl : slices) { std::lock_guard<std::mutex> lk(sl.mx); sl.cv.notify_all(); }
+            laneCv.notify_all();
+            return;
+        }
+        if (fresh0) {
+            prep(lanes[0], 0);
+            { std::lock_guard<std::mutex> lk(laneMx); freeLanes.push_back(0); }
+            laneCv.notify_one(); madeLanes = std::max<uint32_t>(madeLanes.load(), 1u);
+        }
+        for (uint32_t l = std::max<uint32_t>(haveLanes, 1u); l < wantLanes; ++l) {
+            fsengine::Device* d = nullptr; char e[256] = {0};
+            if (fsengine::lane_create(first, &d, e, sizeof e) != 0) { if (trace) fprintf(stderr, "[trace] no further engine lane: %s\n", e); break; }
+            prep(d, l);
+            { std::lock_guard<std::mutex> lk(laneMx); lanes.push_back(d); freeLanes.insert(freeLanes.begin(), l); }
+            laneCv.notify_one(); madeLanes = l + 1;
+        }
+    });
 
     auto runSlice = [&](uint32_t si) {
         Slice& S = slices[si];
@@ -649,7 +675,8 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         if (abort.load()) return;
         {
             std::unique_lock<std::mutex> lk(laneMx);
-            laneCv.wait(lk, [&]() { return !freeLanes.empty(); });
+            laneCv.wait(lk, [&]() { return !freeLanes.empty() || abort.load(); });
+            if (freeLanes.empty()) return;                           // (the device could not be made: the batch is given up)
             // the free lane whose staging buffer fits best (the smallest that is large enough, else the largest): a buffer that
             // must grow in the middle of a batch costs a pinned allocation between the slice's front end and its upload
             size_t pick = freeLanes.size() - 1;
@@ -902,7 +929,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         // flight (growing frees, and a free waits for every running kernel); lanes that do not exist yet are made by
         // their threads (matcherFor)
         for (uint32_t t = 0; t < hostThreads; ++t)
-            if (matchLanes[t] && fsengine::match_lane_reserve(dev, matchLanes[t], matchReserve.reads, matchReserve.seqBytes, matchReserve.calls, matchReserve.warm) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+            if (matchLanes[t] && fsengine::match_lane_reserve(device(), matchLanes[t], matchReserve.reads, matchReserve.seqBytes, matchReserve.calls, matchReserve.warm) != 0) throw std::runtime_error(std::string("device: ") + device()->err);
     }
     const double tf = nowMs();
     if (trace) fprintf(stderr, "[trace] batch set-up (slices, %u lanes, matcher lanes) %.1f ms\n", nLanes, tf - t0);
@@ -910,6 +937,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         std::mutex roundMx; std::condition_variable roundCv; uint32_t binsDone = 0;
         parallelFor(nBins, hostThreads, [&](uint32_t k, uint32_t tid) {
             const uint32_t b = byWork[k];
+            if (abort.load()) return;                                // (the device could not be made: nothing left to do for the bins)
             if (k >= firstRound && k < hostThreads) {            // a thread beyond the cores: its first bin starts when a core is free
                 std::unique_lock<std::mutex> lk(roundMx);
                 roundCv.wait(lk, [&]() { return binsDone > k - firstRound || abort.load(); });
@@ -938,6 +966,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     const double feMs = nowMs() - tf;
     if (onHostTasksDone) onHostTasksDone();
     joinAll();
+    if (!makerErr.empty()) throw std::runtime_error(makerErr);
     for (Slice& S : slices) if (!S.err.empty()) throw std::runtime_error(S.err);
     if (nSlices > 1) {
         // Any lane may get the largest slice of the next batch: the lanes get the buffers of the best-equipped one NOW, behind

@@ -6,6 +6,8 @@
 #include <functional>
 #include <memory>
 #include <string>
+#include <future>
+#include <chrono>
 #include <thread>
 #include <vector>
 #include "../../include/fastore_amd.h"
@@ -77,6 +79,12 @@ struct Context {
     fsgpu_config cfg{};
     PackParams par;
     fsengine::Device* dev = nullptr;
+    // A one-shot context starts its device (HIP runtime, code objects, arena pool, first lane: 0.2 s, seconds on a box whose
+    // driver is clearing memory) on a thread of its own while the front end of the first bins runs: device() waits for it
+    // and throws what went wrong, deviceReadyWithin() asks.
+    std::shared_future<std::string> devPending; std::atomic<bool> devAsync{false}; std::mutex devMx; std::string devError;
+    fsengine::Device* device();
+    bool deviceReadyWithin(int ms) { return !devAsync.load() || devPending.wait_for(std::chrono::milliseconds(ms)) == std::future_status::ready; }
     std::vector<ArchiveParams> archives;          // one per library being packed (index 0 for the single-library calls)
     bool haveArchive = false;
     std::string err;

@@ -109,6 +109,21 @@ def test_host_pipeline_reproduces_reference_archives(emu_lib, tmp_path, name, pa
     assert st["bins"] > 20 and st["block0_records"] > 0      # both the LZ path and block 0 are exercised
 
 
+def test_cli_without_a_device_fails_loudly_and_leaves_no_archive(tmp_path):
+    # the CLI's context starts its device on a thread of its own (the front end of the first bins does not wait for it): a
+    # machine without a GPU must still end in the reference's error convention -- and not in a half-written archive
+    import fastore_amd
+    if not os.path.exists(fastore_amd.PACK_CLI):
+        pytest.skip("CLI not built")
+    out = str(tmp_path / "o")
+    r = subprocess.run([fastore_amd.PACK_CLI, "e", "-i" + os.path.join(GOLDEN, "se_lossless.in"), "-o" + out, "-r", "-f24", "-c10", "-d8", "-w1024", "-W1024"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if r.returncode == 0:
+        pytest.skip("a HIP device is present")
+    assert r.returncode == 255 and b"Error: no HIP device available" in r.stderr
+    assert not os.path.exists(out + ".cdata") and not os.path.exists(out + ".cmeta")
+
+
 @pytest.mark.parametrize("ahead", [65536, 200000, 1 << 20])
 def test_archive_extent_reserved_ahead_too_short_or_too_long(emu_lib, tmp_path, monkeypatch, ahead):
     # the archive's pages are reserved from an ESTIMATE while the device works: blocks that end inside the extent are copied
