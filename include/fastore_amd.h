@@ -54,7 +54,8 @@ typedef struct fsgpu_config {
     uint32_t rank, world_size;          /* bin sharding: this context packs bins i with i % world_size == rank */
     uint32_t pipeline_slices;           /* slices a batch is cut into so that host front end and device overlap (0 = default 8, 1 = off) */
     uint32_t pipeline_lanes;            /* engine instances (HIP streams) whose kernels may overlap on the GPU (0 = one per slice, at most 8) */
-    uint32_t one_shot;       /* 1: the context packs once and is destroyed (the CLI): buffers are not pre-sized for a next batch */
+    uint32_t one_shot;       /* 1: the context packs once and is destroyed (the CLI): its device is made on a thread of its own (a missing
+                                device is reported by the first call that needs it), buffers are not pre-sized for a next batch */
     uint32_t reserved1;
 } fsgpu_config;
 
