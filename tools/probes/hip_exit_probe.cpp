@@ -19,7 +19,12 @@ int main(int argc, char** argv)
     for (int i = 0; i < nStreams; ++i) (void)hipStreamSynchronize(s[i]);
     if (gb) { void* p; (void)hipMalloc(&p, gb << 30); (void)hipMemset(p, 1, gb << 30); (void)hipDeviceSynchronize(); }
     if (hostGb) { char* h = (char*)malloc(hostGb << 30); for (size_t o = 0; o < (hostGb << 30); o += 4096) h[o] = 1; }
-    printf("streams %d, device %zu GB, host %zu GB: leaving at %lld\n", nStreams, gb, hostGb, wallMs());
+    const int nAlloc = argc > 4 ? atoi(argv[4]) : 0;        // separate device allocations of 32 MB each, written
+    for (int i = 0; i < nAlloc; ++i) { void* p; (void)hipMalloc(&p, 32 << 20); (void)hipMemsetAsync(p, 1, 32 << 20, s[0]); }
+    const int nPinned = argc > 5 ? atoi(argv[5]) : 0;       // separate pinned host allocations of 8 MB each
+    for (int i = 0; i < nPinned; ++i) { void* p; (void)hipHostMalloc(&p, 8 << 20); }
+    (void)hipDeviceSynchronize();
+    printf("streams %d, device %zu GB, host %zu GB, %d device allocations, %d pinned allocations: leaving at %lld\n", nStreams, gb, hostGb, nAlloc, nPinned, wallMs());
     fflush(stdout);
     _exit(0);
 }
