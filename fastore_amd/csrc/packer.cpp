@@ -428,6 +428,7 @@ MatchFn Context::matcherFor(uint32_t tid)
 void Context::matcherCheck(const std::string& inPrefix, uint64_t& reads, uint64_t& differing)
 {
     reads = differing = 0;
+    (void)device();                                                  // (a device still on its way is waited for: this call is about it)
     BinFile bf; bf.open(inPrefix, par.minBinSize);
     ArchiveParams arch; arch.cfg = bf.config(); arch.head = bf.headData(); arch.qvz = bf.qvz();
     const std::vector<uint32_t>& sigs = bf.stdSignatures();
