@@ -136,6 +136,17 @@ int main(int argc, char** argv)
         }
         return 0;
     }
+    // A library of millions of reads has bins of tens of thousands: its pack is bound by single long streams, which a
+    // thousand resident coder waves serve as well as three thousand (profiles/r02_oo_max_waves_sweep.txt) -- while every
+    // gigabyte of arena costs a process that packs once set-up time (53 GB: 0.2 s more, profiles/r02_aj_back_to_back.txt).
+    // The record count is in the first 40 bytes of .bmeta (fastore_bin/BinFile.h:106-118).
+    if (cfg.max_waves == 0) {
+        if (FILE* f = fopen((in + ".bmeta").c_str(), "rb")) {
+            uint64_t h[2] = {0, 0};
+            if (fread(h, 8, 2, f) == 2 && h[1] >= 3000000ull) cfg.max_waves = 1024;
+            fclose(f);
+        }
+    }
     const bool trace = getenv("FS_TRACE") != nullptr;
     auto clk = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; };
     const double tm0 = clk();
