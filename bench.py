@@ -179,8 +179,26 @@ def main():
     # the open wait for its write-back: ~50 ms per step that no real run pays); the extra archives are removed after the timing
     made = []
 
+    # (a long run -- many steps -- must not fill the work directory with 0.45 GB archives: those more than four steps old are
+    # removed by a thread of their own while the next step runs; the last one stays for the parity check)
+    import threading
+    removed = set()
+
+    def drop(prefix):
+        for oo in ([prefix] if not lib_set else ["%s_l%d" % (prefix, i) for i in range(world)]):
+            for e in (".cdata", ".cmeta"):
+                try:
+                    os.remove(oo + e)
+                except OSError:
+                    pass
+
     def step():
         nonlocal out
+        if len(made) > 4 and (rank == 0 or not sharded):
+            old = made[len(made) - 5]
+            if old not in removed:
+                removed.add(old)
+                threading.Thread(target=drop, args=(old,), daemon=True).start()
         out = out_base + "_%d" % len(made)
         made.append(out)
         if lib_set:
@@ -206,10 +224,7 @@ def main():
     st = packer.stats()
     if rank == 0 or not sharded:
         for o in made[:-1]:
-            for oo in ([o] if not lib_set else ["%s_l%d" % (o, i) for i in range(world)]):
-                for e in (".cdata", ".cmeta"):
-                    if os.path.exists(oo + e):
-                        os.remove(oo + e)
+            drop(o)
     if world > 1:
         t = torch.tensor([dt], device="cpu" if args.rehearse else "cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
         keys = ["algorithmic_bytes", "ppmd_symbols", "host_coded_symbols", "kernel_launches", "encode_kernel_ms", "cdata_bytes", "bins", "records"]
