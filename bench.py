@@ -29,6 +29,7 @@ import os
 import struct
 import subprocess
 import sys
+import threading
 import time
 
 # the pack context runs one HIP stream per pipeline slice; they need their own hardware queues to overlap
@@ -104,6 +105,176 @@ def same_blocks(ours, ref):
     return True
 
 
+def roofline_of(tot, steps, traffic=None):
+    """algorithmic bytes per launch of the dominant kernel / its average launch duration (HIP events on the
+    lanes' own streams, summed by the library) against the HBM peak."""
+    launches = max(1, int(tot["kernel_launches"]))
+    avg_launch_s = tot["encode_kernel_ms"] / 1e3 / launches
+    achieved = tot["algorithmic_bytes"] / launches / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+    return {"bound": "hbm", "kernel": "fs_encode_streams", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic,
+            "traffic_unit": "bytes per launch (profiles/*hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)",
+            "avg_launch_ms": round(avg_launch_s * 1e3, 3), "launches": launches,
+            "algorithmic_bytes_per_launch": int(tot["algorithmic_bytes"]) // launches,
+            # the launches of a step overlap (one per pipeline slice, each on its own HIP stream), so a launch's
+            # duration includes the time it shares the GPU; the whole-GPU symbol rate is quoted per step wall time
+            "overlapping_launches_per_step": launches // max(1, steps)}
+
+
+def reference_pack(binned, refp, cores, pe, sweep=False):
+    """the real reference fastore_pack on the same library.  Its multi-threaded pack dead-locks at -t64 (observed here and
+    in the build container), so the all-cores leg uses at most 32 workers, under a timeout, stepping down if it still hangs.
+    sweep: also time 16 and 48 workers once (is -t32 the reference's best on this host?)."""
+    nt, tn = None, None
+    for cand in (32, 16, 8, 4):
+        if cand > max(4, cores):
+            continue
+        try:
+            t = time.perf_counter()
+            subprocess.run([REF, "pack", "-i" + binned, "-o" + refp, "-t%d" % cand] + PACK_FLAGS + pe, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=1500, check=True)
+            nt, tn = cand, time.perf_counter() - t
+            break
+        except (subprocess.TimeoutExpired, subprocess.CalledProcessError):
+            continue
+    others = {}
+    if sweep and nt is not None:
+        for cand in (16, 48):
+            if cand == nt or cand > cores:
+                continue
+            try:
+                t = time.perf_counter()
+                subprocess.run([REF, "pack", "-i" + binned, "-o" + refp + "_sweep", "-t%d" % cand] + PACK_FLAGS + pe, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=600, check=True)
+                others["t%d_seconds" % cand] = round(time.perf_counter() - t, 2)
+            except (subprocess.TimeoutExpired, subprocess.CalledProcessError):
+                others["t%d_seconds" % cand] = None
+        for e in (".cdata", ".cmeta"):
+            try:
+                os.remove(refp + "_sweep" + e)
+            except OSError:
+                pass
+    return nt, tn, others
+
+
+def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome, steps, warmup, cores, lib, cli_runs, traffic_file=None, sweep=False):
+    """ONE library on ONE GPU: K timed pack steps (file to file), then the CLI process, the reference on the same library,
+    and the block-for-block comparison.  Returns the leg's result dict."""
+    L = 150
+    t0 = time.time()
+    binned, fastq_bytes = prepare_library(work, name, reads, L, genome, 8, min(cores, 32), paired)
+    prep_s = time.time() - t0
+    packer = fastore_amd.Packer(device_id=0, lib=lib, host_threads=0)
+    out_base = os.path.join(work, "out_" + name)
+    made, removed = [], set()
+
+    def drop(prefix):
+        for e in (".cdata", ".cmeta"):
+            try:
+                os.remove(prefix + e)
+            except OSError:
+                pass
+
+    def step():
+        # every step writes a NEW archive, as every run of fastore_pack does (overwriting the previous step's file makes the
+        # open wait for its write-back: ~50 ms per step that no real run pays); archives more than four steps old are
+        # removed by a thread of their own while the next step runs; the last one stays for the parity check
+        if len(made) > 4:
+            old = made[len(made) - 5]
+            if old not in removed:
+                removed.add(old)
+                threading.Thread(target=drop, args=(old,), daemon=True).start()
+        o = out_base + "_%d" % len(made)
+        made.append(o)
+        packer.pack_file(binned, o)
+
+    for _ in range(warmup):
+        step()
+    packer.reset_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = packer.stats()
+    out = made[-1]
+    for o in made[:-1]:
+        drop(o)
+    traffic = None
+    if traffic_file and os.path.exists(traffic_file):
+        traffic = json.load(open(traffic_file))["hbm_bytes_per_step"] / max(1.0, int(st["kernel_launches"]) / steps)
+    sym = max(1.0, float(st["ppmd_symbols"]))
+    rf = roofline_of(st, steps, traffic)
+    rf["ppmd_symbols_per_s_whole_job"] = round(st["ppmd_symbols"] / dt, 1)
+    res = {
+        "value": round(fastq_bytes * steps / dt / 1e6, 2), "unit": "MB/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
+        "config": {"workload": "ONE library of %.1f M x %d bp %s synthetic FASTQ (gen_fastq genome %d bp, seed 8), --lossless, C1 profile%s"
+                               % (reads / 1e6, L, "PE pairs" if paired else "SE reads", genome, "" if not paired else " (configs[2] scaled by %g)" % (reads / 100e6)),
+                   "fastq_bytes": fastq_bytes, "pack_flags": " ".join(PACK_FLAGS + (["-z"] if paired else [])), "parallelism": "1 GPU"},
+        "roofline": rf,
+        "host_coded_symbol_fraction": round(float(st.get("host_coded_symbols", 0)) / sym, 4),
+        # the other kernels of the path: fs_gather_quality builds the quality streams on the device (HBM-bound: 0.75 B
+        # read + 1 B written per score, launch durations from HIP events on the lanes' streams); fs_match_reads does the
+        # LZ-window searches (duration summed over its launches)
+        "other_kernels": {
+            "fs_gather_quality": {"ms_per_step": round(st["gather_kernel_ms"] / steps, 3), "scores_per_step": st["gather_symbols"] // steps,
+                                  "achieved_GBps": round(st["gather_bytes"] / max(1e-9, st["gather_kernel_ms"] / 1e3) / 1e9, 1) if st["gather_kernel_ms"] > 0 else None,
+                                  "frac_of_hbm_peak": round(st["gather_bytes"] / max(1e-9, st["gather_kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if st["gather_kernel_ms"] > 0 else None},
+            "fs_match_reads": {"reads_per_step": st["matcher_reads"] // steps, "kernel_ms_per_step": round(st["matcher_kernel_ms"] / steps, 1),
+                               "host_wait_ms_per_step_summed_over_threads": round(st["matcher_call_ms"] / steps, 1)}},
+        "h2d_bytes_per_step": int(st["h2d_bytes"]) // steps,
+        "stages_ms_per_step": dict({k: round(st[k] / steps, 1) for k in ("encode_kernel_ms", "assemble_kernel_ms", "frontend_ms", "io_ms", "total_ms")},
+                                   block0_ms=round(st["block0_ms"], 1)),      # block0_ms is the longest single step's (a max in the library), not a sum
+        "archive": {"cdata_bytes": int(st["cdata_bytes"]) // steps, "bins": int(st["bins"]) // steps, "records": int(st["records"]) // steps,
+                    "block0_records": st["block0_records"] // steps},
+        "prep_s": round(prep_s, 1),
+    }
+    device_name = packer.device_name
+    pe = ["-z"] if paired else []
+    packer.close()                 # the CLI process is measured on a device that is otherwise idle, as a user would run it
+    if cli_runs > 0:
+        # SURVEY 8(d): wall time of the `fastore_pack e` PROCESS (start -> exit: HIP init, arena allocation, reading .b*,
+        # writing .c*), page cache warm -- beside the warm in-process number above
+        cli_out = os.path.join(work, "cli_" + name)
+        cli = [fastore_amd.PACK_CLI, "e", "-i" + binned, "-o" + cli_out] + PACK_FLAGS + pe
+        runs, rc = [], 0
+        for _ in range(cli_runs):
+            t = time.perf_counter(); rc = subprocess.call(cli, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); tc = time.perf_counter() - t
+            runs.append(round(tc, 2))
+            if rc != 0:
+                break
+        med = sorted(runs)[len(runs) // 2]
+        # (the first processes on a fresh box wait 1-4 s in their first large device allocation while the driver clears
+        # memory it has not handed out before -- profiles/r02_mm_alloc_sizes.txt: not the program's time --, hence
+        # several runs; the MEDIAN is quoted, all runs are listed)
+        res["cli_end_to_end"] = {"value": round(fastq_bytes / med / 1e6, 2) if rc == 0 else None, "unit": "MB/s", "seconds": med, "runs_seconds": runs,
+                                 "best_seconds": min(runs), "quoted": "median of the runs", "exit": rc,
+                                 "archive_identical_to_the_in_process_one": bool(rc == 0 and all(open(cli_out + e, "rb").read() == open(out + e, "rb").read() for e in (".cdata", ".cmeta"))),
+                                 "command": "fastore_pack e " + " ".join(PACK_FLAGS + pe)}
+        drop(cli_out)
+    if not args.no_cpu_baseline:
+        refp = os.path.join(work, "ref_" + name)
+        nt, tn, others = reference_pack(binned, refp, cores, pe, sweep)
+        if nt is not None:
+            res["cpu_baseline"] = {"value": round(fastq_bytes / tn / 1e6, 2), "unit": "MB/s", "cores": min(nt, cores), "kind": "reference",
+                                   "sample": "reference fastore_pack e -t%d on the SAME library (whole workload, %.1f MB FASTQ), %d host cores" % (nt, fastq_bytes / 1e6, cores),
+                                   "threads": nt, "seconds": round(tn, 2)}
+            if others:
+                res["cpu_baseline"]["thread_sweep"] = others
+            res["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 2)
+            res["parity"] = {"every_block_bit_identical_to_reference": bool(same_blocks(out, refp)), "block_order": "-t1 (block 0, ascending signature)",
+                             "on": "the whole workload archive (%d blocks)" % len(read_archive(out)[0])}
+        if args.cpu_t1:
+            t = time.perf_counter(); sh([REF, "pack", "-i" + binned, "-o" + refp + "1", "-t1"] + PACK_FLAGS + pe); t1 = time.perf_counter() - t
+            res.setdefault("cpu_baseline", {"unit": "MB/s", "kind": "reference"}).update({"t1_value": round(fastq_bytes / t1 / 1e6, 2), "t1_seconds": round(t1, 2)})
+            res.setdefault("parity", {})["cdata_bit_identical_to_reference_t1"] = open(out + ".cdata", "rb").read() == open(refp + "1.cdata", "rb").read()
+            drop(refp + "1")
+        drop(refp)
+    drop(out)
+    return res, device_name
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,10 +284,13 @@ def main():
     ap.add_argument("--work", default=os.environ.get("FASTORE_BENCH_DIR", "/tmp/fastore_bench"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-t1", action="store_true", help="also time the reference at -t1 on the same library (~4 min)")
+    ap.add_argument("--cpu-sweep", action="store_true", help="also time the reference at -t16 and -t48 once")
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end run of the fastore_pack CLI (process start -> exit)")
-    ap.add_argument("--paired", action="store_true", help="ONE paired-end library of --reads pairs: configs[2] scaled, not the default line")
+    ap.add_argument("--paired", action="store_true", help="the headline leg packs ONE paired-end library of --reads pairs (configs[2] scaled)")
+    ap.add_argument("--pe-reads", type=int, default=6_000_000, help="pairs of the paired-end leg of the N = 1 line (configs[2] scaled to what the run's window holds)")
+    ap.add_argument("--no-pe", action="store_true", help="N = 1: skip the paired-end leg")
     ap.add_argument("--rehearse", action="store_true", help="N ranks on ONE device over gloo (no RCCL): a dry run of the N > 1 code path on a one-GPU box")
-    ap.add_argument("--strong", action="store_true", help="--gpus N: shard the ONE library of the N = 1 run over the ranks (total work fixed)")
+    ap.add_argument("--strong", action="store_true", help="--gpus N: ONLY the strong line (the ONE library of the N = 1 run sharded over the ranks)")
     ap.add_argument("--replicas", "--weak", dest="replicas", action="store_true", help="--gpus N: every rank packs the whole library into its own archive")
     args = ap.parse_args()
 
@@ -141,200 +315,167 @@ def main():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
     name = ("pe%dk" if args.paired else "se%dk") % (args.reads // 1000)
     cov = 2 if args.paired else 1            # bases per record: the genome is sized for ~50x coverage either way
-    prep_s = 0.0
-    lib_set = world > 1 and not args.strong and not args.replicas       # the default N > 1 job: N libraries, bin-sharded
     genome = cov * args.reads * L // 50
-    if lib_set:
-        # rank r prepares library r (seed 8 + r) while the others prepare theirs
-        names = [name if r == 0 else "%s_s%d" % (name, 8 + r) for r in range(world)]
-        t0 = time.time()
-        prepare_library(args.work, names[rank], args.reads, L, genome, 8 + rank, max(2, min(cores // world, 32)), args.paired)
-        prep_s = time.time() - t0
-        dist.barrier()
-        binned_set = [os.path.join(args.work, n + ".b8") for n in names]
-        fastq_bytes = sum(int(open(os.path.join(args.work, n + ".done")).read()) for n in names)
-        binned = binned_set[0]
-    else:
-        if rank == 0:
-            t0 = time.time()
-            binned, fastq_bytes = prepare_library(args.work, name, args.reads, L, genome, 8, min(cores, 32), args.paired)
-            prep_s = time.time() - t0
-        if world > 1:
-            dist.barrier()
-        binned = os.path.join(args.work, name + ".b8"); fastq_bytes = int(open(os.path.join(args.work, name + ".done")).read())
 
     import fastore_amd
     from fastore_amd import shard
     # FASTORE_AMD_LIB: A/B runs of alternative builds of the library (kernel experiments); default = the in-tree build
     alt = os.environ.get("FASTORE_AMD_LIB")
     lib = fastore_amd.load_library(alt) if alt else None
-    sharded = world > 1 and not args.replicas
-    threads = max(2, cores // world) if world > 1 else 0
-    packer = fastore_amd.Packer(device_id=local if world > 1 else 0, lib=lib, host_threads=threads,
-                                rank=rank if sharded else 0, world_size=world if sharded else 1)
-    out_base = os.path.join(args.work, "out" if sharded else "out_r%d" % rank)
-    out = out_base
 
-    # every step writes a NEW archive, as every run of fastore_pack does (overwriting the previous step's 0.45 GB file makes
-    # the open wait for its write-back: ~50 ms per step that no real run pays); the extra archives are removed after the timing
-    made = []
+    if world == 1:
+        # ---- the N = 1 line: the headline leg (configs[1], or --paired) and, beside it, the paired-end leg ----
+        traffic_file = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json") if (args.reads == 10_000_000 and not args.paired) else None
+        leg, dev = one_library_leg(fastore_amd, torch, args, args.work, name, args.reads, args.paired, genome, args.steps, args.warmup, cores, lib,
+                                   0 if args.no_cli else 3, traffic_file, args.cpu_sweep)
+        res = {"metric": "fastore_pack compressed MB/s (input FASTQ)", "value": leg["value"], "unit": "MB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic"}
+        for k, v in leg.items():
+            if k not in res:
+                res[k] = v
+        res["stages_ms_per_step_rank0"] = res.pop("stages_ms_per_step")
+        res["device"] = dev; res["host_cores"] = cores
+        if not args.paired and not args.no_pe:
+            # configs[2] is 100 M pairs x 150 bp PE; what fits this run's window is a library of --pe-reads pairs from the same
+            # generator (genome scaled for the same 50x coverage): its own value, reference baseline, parity and roofline
+            pk, ps, pw = args.pe_reads, max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
+            pleg, _ = one_library_leg(fastore_amd, torch, args, args.work, "pe%dk" % (pk // 1000), pk, True, 2 * pk * L // 50, ps, pw, cores, lib, 0 if args.no_cli else 3)
+            res["pe"] = pleg
+        print(json.dumps(res), flush=True)
+        return
 
-    # (a long run -- many steps -- must not fill the work directory with 0.45 GB archives: those more than four steps old are
-    # removed by a thread of their own while the next step runs; the last one stays for the parity check)
-    import threading
-    removed = set()
+    # ---- N > 1 ----
+    prep_s = 0.0
+    lib_set = not args.strong and not args.replicas       # the default N > 1 job: N libraries, bin-sharded -- and the strong line beside it
+    names = [name if r == 0 else "%s_s%d" % (name, 8 + r) for r in range(world)]
+    if lib_set:
+        # rank r prepares library r (seed 8 + r) while the others prepare theirs
+        t0 = time.time()
+        prepare_library(args.work, names[rank], args.reads, L, genome, 8 + rank, max(2, min(cores // world, 32)), args.paired)
+        prep_s = time.time() - t0
+    elif rank == 0:
+        t0 = time.time()
+        prepare_library(args.work, name, args.reads, L, genome, 8, min(cores, 32), args.paired)
+        prep_s = time.time() - t0
+    dist.barrier()
+    binned_set = [os.path.join(args.work, n + ".b8") for n in names]
+    binned = binned_set[0]
+    fastq_one = int(open(os.path.join(args.work, name + ".done")).read())
+    fastq_set = sum(int(open(os.path.join(args.work, n + ".done")).read()) for n in names) if lib_set else fastq_one
 
-    def drop(prefix):
-        for oo in ([prefix] if not lib_set else ["%s_l%d" % (prefix, i) for i in range(world)]):
+    sharded = not args.replicas
+    threads = max(2, cores // world)
+    packer = fastore_amd.Packer(device_id=local, lib=lib, host_threads=threads, rank=rank if sharded else 0, world_size=world if sharded else 1)
+    coll_dev = None if args.rehearse else torch.device("cuda", local)
+    keys = ["algorithmic_bytes", "ppmd_symbols", "host_coded_symbols", "kernel_launches", "encode_kernel_ms", "cdata_bytes", "bins", "records"]
+
+    def drop(prefixes):
+        for oo in prefixes:
             for e in (".cdata", ".cmeta"):
                 try:
                     os.remove(oo + e)
                 except OSError:
                     pass
 
-    def step():
-        nonlocal out
-        if len(made) > 4 and (rank == 0 or not sharded):
-            old = made[len(made) - 5]
-            if old not in removed:
-                removed.add(old)
-                threading.Thread(target=drop, args=(old,), daemon=True).start()
-        out = out_base + "_%d" % len(made)
-        made.append(out)
-        if lib_set:
-            shard.pack_sharded_set(packer, binned_set, ["%s_l%d" % (out, i) for i in range(world)], dist, device=None if args.rehearse else torch.device("cuda", local))
-        elif sharded:
-            shard.pack_sharded(packer, binned, out, dist, device=None if args.rehearse else torch.device("cuda", local))
-        else:
-            packer.pack_file(binned, out)
+    def timed(kind, steps, warmup):
+        """W untimed + K timed steps of one job kind, bracketed by barrier + synchronize, MAX over the ranks"""
+        made, removed = [], set()
+        out_base = os.path.join(args.work, ("out_%s" % kind) if sharded else "out_r%d" % rank)
 
-    for _ in range(args.warmup):
-        step()
-    packer.reset_stats()
-    if world > 1:
+        def outs(o):
+            return ["%s_l%d" % (o, i) for i in range(world)] if kind == "set" else [o]
+
+        def step():
+            if len(made) > 4 and (rank == 0 or not sharded):
+                old = made[len(made) - 5]
+                if old not in removed:
+                    removed.add(old)
+                    threading.Thread(target=drop, args=(outs(old),), daemon=True).start()
+            o = out_base + "_%d" % len(made)
+            made.append(o)
+            if kind == "set":
+                shard.pack_sharded_set(packer, binned_set, outs(o), dist, device=coll_dev)
+            elif kind == "one":
+                shard.pack_sharded(packer, binned, o, dist, device=coll_dev)
+            else:
+                packer.pack_file(binned, o)
+
+        for _ in range(warmup):
+            step()
+        packer.reset_stats()
         dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
         dist.barrier()
-    dt = time.perf_counter() - t0
-    st = packer.stats()
-    if rank == 0 or not sharded:
-        for o in made[:-1]:
-            drop(o)
-    if world > 1:
+        dt = time.perf_counter() - t0
+        st = packer.stats()
         t = torch.tensor([dt], device="cpu" if args.rehearse else "cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
-        keys = ["algorithmic_bytes", "ppmd_symbols", "host_coded_symbols", "kernel_launches", "encode_kernel_ms", "cdata_bytes", "bins", "records"]
         v = torch.tensor([float(st[k]) for k in keys], device="cpu" if args.rehearse else "cuda", dtype=torch.float64); dist.all_reduce(v)
-        tot = dict(zip(keys, v.tolist()))
-    else:
-        tot = st
+        if rank == 0 or not sharded:
+            for o in made[:-1]:
+                drop(outs(o))
+        dist.barrier()
+        return dt, dict(zip(keys, v.tolist())), st, outs(made[-1])
+
+    main_kind = "set" if lib_set else ("one" if sharded else "replica")
+    dt, tot, st, last = timed(main_kind, args.steps, args.warmup)
+    strong = None
+    if lib_set:
+        # the strong line beside the weak one: ONE library (library 0 of the set) sharded over the same ranks -- its step is
+        # bound by single streams, which more GPUs do not shorten; reported as measured
+        ks, kw = max(1, min(args.steps, 3)), 1
+        sdt, stot, _, slast = timed("one", ks, kw)
+        strong = {"scaling": "strong", "value": round(fastq_one * ks / sdt / 1e6, 2), "unit": "MB/s", "steps": ks, "warmup": kw, "ms_per_step": round(sdt / ks * 1e3, 2),
+                  "workload": "ONE library (library 0 of the set, %.1f MB FASTQ) bin-sharded over the %d ranks" % (fastq_one / 1e6, world),
+                  "roofline": roofline_of(stot, ks)}
 
     if rank == 0:
-        jobs = world if (world > 1 and args.replicas) else 1
+        jobs = world if args.replicas else 1
+        fastq_bytes = fastq_set if lib_set else fastq_one
         value = fastq_bytes * jobs * args.steps / dt / 1e6
-        launches = max(1, int(tot["kernel_launches"]))
-        avg_launch_s = tot["encode_kernel_ms"] / 1e3 / launches
-        achieved = tot["algorithmic_bytes"] / launches / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        # HBM traffic of the dominant kernel: PMC passes cannot run inside this process; the committed summary of the
-        # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command is reported per launch
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-        if os.path.exists(tf) and args.reads == 10_000_000 and not args.paired and world == 1:
-            traffic = json.load(open(tf))["hbm_bytes_per_step"] / max(1.0, launches / args.steps)
+        rf = roofline_of(tot, args.steps); rf["ppmd_symbols_per_s_whole_job"] = round(tot["ppmd_symbols"] / dt, 1)
         sym = max(1.0, float(tot["ppmd_symbols"]))
         res = {
             "metric": "fastore_pack compressed MB/s (input FASTQ)", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak" if (world > 1 and not args.strong) else "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s of %.1f M x %d bp %s synthetic FASTQ (gen_fastq genome %d bp, seed%s), --lossless, C1 profile%s"
                                    % ("ONE library" if not lib_set else "a SET of %d libraries, each" % world, args.reads / 1e6, L, "PE pairs" if args.paired else "SE reads", genome,
                                       " 8" if not lib_set else "s 8..%d" % (7 + world),
                                       "" if not args.paired else " (configs[2] scaled by %g)" % (args.reads / 100e6)),
                        "fastq_bytes": fastq_bytes, "pack_flags": " ".join(PACK_FLAGS),
-                       "parallelism": ("1 GPU" if world == 1 else ("%d ranks, each the whole library (replicas)" % world if args.replicas else
+                       "parallelism": ("%d ranks, each the whole library (replicas)" % world if args.replicas else
                                        ("%d ranks pack disjoint LPT shards of the library's bins; one all-reduce of the block-size table over RCCL; no block bytes cross ranks" % world if args.strong else
-                                        "%d ranks, each its LPT share of the bins of all %d libraries in one device pipeline; one all-reduce of the concatenated block-size tables over RCCL; no block bytes cross ranks" % (world, world))))},
-            "roofline": {"bound": "hbm", "kernel": "fs_encode_streams", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic,
-                         "traffic_unit": "bytes per launch (profiles/r02_hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes)",
-                         "avg_launch_ms": round(avg_launch_s * 1e3, 3), "launches": launches,
-                         "algorithmic_bytes_per_launch": int(tot["algorithmic_bytes"]) // launches,
-                         # the launches of a step overlap (one per pipeline slice, each on its own HIP stream), so a launch's
-                         # duration includes the time it shares the GPU; the whole-GPU symbol rate is quoted per step wall time
-                         "overlapping_launches_per_step": launches // args.steps,
-                         "ppmd_symbols_per_s_whole_job": round(tot["ppmd_symbols"] / dt, 1)},
+                                        "%d ranks, each its LPT share of the bins of all %d libraries in one device pipeline; one all-reduce of the concatenated block-size tables over RCCL; no block bytes cross ranks" % (world, world)))},
+            "roofline": rf,
             "host_coded_symbol_fraction": round(float(tot.get("host_coded_symbols", 0)) / sym, 4),
-            # the other kernels of the path (rank 0's context): fs_gather_quality builds the quality streams on the device
-            # (HBM-bound: 0.75 B read + 1 B written per score, launch durations from HIP events on the lanes' streams);
-            # fs_match_reads does the LZ-window searches of the heaviest bins (duration summed over its launches)
-            "other_kernels": {
-                "fs_gather_quality": {"ms_per_step": round(st["gather_kernel_ms"] / args.steps, 3), "scores_per_step": st["gather_symbols"] // args.steps,
-                                      "achieved_GBps": round(st["gather_bytes"] / max(1e-9, st["gather_kernel_ms"] / 1e3) / 1e9, 1) if st["gather_kernel_ms"] > 0 else None,
-                                      "frac_of_hbm_peak": round(st["gather_bytes"] / max(1e-9, st["gather_kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if st["gather_kernel_ms"] > 0 else None},
-                "fs_match_reads": {"reads_per_step": st["matcher_reads"] // args.steps, "kernel_ms_per_step": round(st["matcher_kernel_ms"] / args.steps, 1),
-                                   "host_wait_ms_per_step_summed_over_threads": round(st["matcher_call_ms"] / args.steps, 1)}},
-            "h2d_bytes_per_step": int(st["h2d_bytes"]) // args.steps,
-            "stages_ms_per_step_rank0": {k: round(st[k] / args.steps, 1) for k in ("encode_kernel_ms", "assemble_kernel_ms", "frontend_ms", "io_ms", "block0_ms", "total_ms")},
-            "archive": {"cdata_bytes": int(tot["cdata_bytes"]) // args.steps, "bins": int(tot["bins"]) // args.steps, "records": int(tot["records"]) // args.steps,
-                        "block0_records": st["block0_records"] // args.steps},
+            "stages_ms_per_step_rank0": dict({k: round(st[k] / args.steps, 1) for k in ("encode_kernel_ms", "assemble_kernel_ms", "frontend_ms", "io_ms", "total_ms")}, block0_ms=round(st["block0_ms"], 1)),
+            "archive": {"cdata_bytes": int(tot["cdata_bytes"]) // args.steps, "bins": int(tot["bins"]) // args.steps, "records": int(tot["records"]) // args.steps},
             "device": packer.device_name, "host_cores": cores, "prep_s": round(prep_s, 1),
         }
-        pe = ["-z"] if args.paired else []
-        if not args.no_cli and not lib_set:
-            # wall time of the `fastore_pack e` PROCESS (start -> exit: HIP init, arena allocation, reading .b*,
-            # writing .c*), page cache warm -- beside the warm in-process number above
-            cli = [fastore_amd.PACK_CLI, "e", "-i" + binned, "-o" + os.path.join(args.work, "cli")] + PACK_FLAGS + pe + (["-G%d" % world] if world > 1 else [])
-            if world == 1:
-                packer.close()             # the process is measured on a device that is otherwise idle, as a user would run it
-            runs = []
-            for _ in range(3):
-                t = time.perf_counter(); rc = subprocess.call(cli, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); tc = time.perf_counter() - t
-                runs.append(round(tc, 2))
-                if rc != 0:
-                    break
-            tc = min(runs)
-            # (the first processes on a fresh box wait 1-4 s in their first large device allocation while the driver clears
-            # memory it has not handed out before -- profiles/r02_mm_alloc_sizes.txt, r02_ll_pool_probe.txt: not the
-            # program's time --, hence three runs; the best one is quoted, all three and their median are listed)
-            res["cli_end_to_end"] = {"value": round(fastq_bytes / tc / 1e6, 2) if rc == 0 else None, "unit": "MB/s", "seconds": tc, "runs_seconds": runs,
-                                     "median_seconds": sorted(runs)[len(runs) // 2], "quoted": "best of the runs", "exit": rc,
-                                     "archive_identical_to_the_in_process_one": bool(rc == 0 and world == 1 and all(open(os.path.join(args.work, "cli") + e, "rb").read() == open(out + e, "rb").read() for e in (".cdata", ".cmeta"))),
-                                     "command": "fastore_pack e " + " ".join(PACK_FLAGS + pe)}
-        if not args.no_cpu_baseline and not lib_set:
-            # the reference's multi-threaded pack dead-locks at -t64 (observed here and in the build container), so the
-            # all-cores leg uses at most 32 workers, under a timeout, stepping down if it still hangs
-            refp = os.path.join(args.work, "ref")
-            nt, tn = None, None
-            for cand in (32, 16, 8, 4):
-                if cand > max(4, cores):
-                    continue
-                try:
-                    t = time.perf_counter()
-                    subprocess.run([REF, "pack", "-i" + binned, "-o" + refp, "-t%d" % cand] + PACK_FLAGS + pe, stdout=subprocess.DEVNULL,
-                                   stderr=subprocess.DEVNULL, timeout=900, check=True)
-                    nt, tn = cand, time.perf_counter() - t
-                    break
-                except (subprocess.TimeoutExpired, subprocess.CalledProcessError):
-                    continue
+        if strong is not None:
+            res["strong"] = strong
+        if not args.no_cpu_baseline and sharded:
+            # parity of the N > 1 job: library 0's archive (the set's, and the strong line's) against the reference's pack of
+            # that library; the reference is timed on rank 0's host cores while the other ranks wait
+            pe = ["-z"] if args.paired else []
+            refp = os.path.join(args.work, "ref_" + name)
+            nt, tn, _ = reference_pack(binned, refp, cores, pe)
             if nt is not None:
-                res["cpu_baseline"] = {"value": round(fastq_bytes / tn / 1e6, 2), "unit": "MB/s", "cores": min(nt, cores), "kind": "reference",
-                                       "sample": "reference fastore_pack e -t%d on the SAME library (whole workload, %.1f MB FASTQ), %d host cores" % (nt, fastq_bytes / 1e6, cores),
-                                       "threads": nt, "seconds": round(tn, 2)}
-                res["parity"] = {"every_block_bit_identical_to_reference": bool(same_blocks(out, refp)), "block_order": "-t1 (block 0, ascending signature)",
-                                 "on": "the whole workload archive (%d blocks)" % len(read_archive(out)[0])}
-            if args.cpu_t1:
-                t = time.perf_counter(); sh([REF, "pack", "-i" + binned, "-o" + refp + "1", "-t1"] + PACK_FLAGS + pe); t1 = time.perf_counter() - t
-                res.setdefault("cpu_baseline", {"unit": "MB/s", "kind": "reference"}).update({"t1_value": round(fastq_bytes / t1 / 1e6, 2), "t1_seconds": round(t1, 2)})
-                res.setdefault("parity", {})["cdata_bit_identical_to_reference_t1"] = open(out + ".cdata", "rb").read() == open(refp + "1.cdata", "rb").read()
+                res["cpu_baseline"] = {"value": round(fastq_one / tn / 1e6, 2), "unit": "MB/s", "cores": min(nt, cores), "kind": "reference",
+                                       "sample": "reference fastore_pack e -t%d on library 0 (%.1f MB FASTQ), %d host cores" % (nt, fastq_one / 1e6, cores), "threads": nt, "seconds": round(tn, 2)}
+                res["parity"] = {"library_0_every_block_bit_identical_to_reference": bool(same_blocks(last[0], refp)),
+                                 "on": "library 0 of the job as the %d ranks wrote it (%d blocks)" % (world, len(read_archive(last[0])[0]))}
+                if strong is not None:
+                    res["parity"]["strong_line_archive_identical_to_reference"] = bool(same_blocks(slast[0], refp))
+            drop([refp])
         print(json.dumps(res), flush=True)
     packer.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

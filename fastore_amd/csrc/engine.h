@@ -11,7 +11,7 @@ struct BatchTiming {
     double encode_ms = 0, assemble_ms = 0;      // HIP-event time of the two kernels (summed over launches)
     double gather_ms = 0; uint64_t gather_symbols = 0, gather_bytes = 0;   // fs_gather_quality: time, scores, bytes read + written
     uint64_t id_strings = 0;                                                 // fs_tokenise_ids: read ids tokenised on the device
-    uint64_t launches = 0, items = 0, ppmd_symbols = 0, rc_symbols = 0, restarts = 0;
+    uint64_t launches = 0, items = 0, ppmd_symbols = 0, rc_symbols = 0, restarts = 0, max_restarts = 0;
     uint64_t h2d_bytes = 0, d2h_bytes = 0;
     uint64_t win[16] = {0};                     // windowed PPMd hit path, summed over the streams: [1] attempts [2] windows [3] symbols [4] rounds [5] redone; [8..15] phase clocks / 64
 };

@@ -82,7 +82,7 @@ template <bool TWO> __device__ __forceinline__ void encode_streams_body()
     __shared__ fsppmd::Shared sh;
     uint32_t qTail = 0;
     if (TWO) {
-        if (threadIdx.x == 0) { sh.qTail = 0u; sh.qHead = 0u; }
+        if (threadIdx.x == 0) { sh.qTail = 0u; sh.qHead = 0u; sh.qStarts = 0u; sh.qOpened = 0u; }
         __syncthreads();                               // the workgroup's only barrier: from here on the waves go separate ways
         if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) { fsppmd::coder_wave((FS_LDS fsppmd::Shared*)&sh); return; }
     }
@@ -669,6 +669,7 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     HIP_TRY(hipMemcpyAsync(dev->dItems, items.data(), sizeof(StreamItem) * nItems, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dev->dOrder, order.data(), 4ull * nRest, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(dev->queueHead, 0, 64, st));
+    HIP_TRY(hipMemsetAsync(dev->dSizes, 0xFF, 4ull * nItems, st));          // a size no wave writes reads as 0xFFFFFFFF: the callers' error path, not last launch's value
     if (gather && gather->n_strings) {
         // every string's source and destination inside the buffer, checked here: the kernel trusts its descriptors
         if (gather->bits == 6u) {
@@ -748,7 +749,7 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
             timing->gather_ms += g; timing->gather_symbols += gather->symbols;
             timing->gather_bytes += gather->bits == 6u ? gather->symbols + (gather->symbols * 3u + 3u) / 4u : 2u * gather->symbols + (gather->symbols * gather->bits + 7u) / 8u;
         }
-        for (uint32_t i = 0; i < nItems; ++i) { timing->restarts += restarts[16ull * i]; for (int k = 1; k < 16; ++k) timing->win[k] += restarts[16ull * i + k]; if (items[i].kind == KIND_PPMD) timing->ppmd_symbols += items[i].in_len; else timing->rc_symbols += items[i].in_len; }
+        for (uint32_t i = 0; i < nItems; ++i) { timing->restarts += restarts[16ull * i]; if (items[i].kind == KIND_PPMD) timing->max_restarts = std::max<uint64_t>(timing->max_restarts, restarts[16ull * i]); for (int k = 1; k < 16; ++k) timing->win[k] += restarts[16ull * i + k]; if (items[i].kind == KIND_PPMD) timing->ppmd_symbols += items[i].in_len; else timing->rc_symbols += items[i].in_len; }
     }
     return 0;
 }

@@ -94,7 +94,8 @@ int main(int argc, char** argv)
     cfg.host_threads = hostThreads >= 0 ? (uint32_t)hostThreads : (uint32_t)threads;   // -j overrides -t (which keeps the reference's 1..64 range)
     if (gpus < 1 || gpus > 64) { fprintf(stderr, "Error: invalid number of devices specified\n"); return 255; }
     if (gpus > 1) {
-        // one context (and one set of host threads) per device; bins are sharded round-robin, no data crosses devices
+        // one context (and one set of host threads) per device; every device takes its LPT share of the bins (longest first over
+        // the .bmeta record totals, packer.cpp: shardOwners), no block bytes cross devices
         std::vector<fsgpu_ctx*> ctxs(gpus, nullptr);
         for (int r = 0; r < gpus; ++r) {
             fsgpu_config c = cfg; c.device_id = cfg.device_id + r; c.rank = (uint32_t)r; c.world_size = (uint32_t)gpus;
@@ -171,7 +172,8 @@ int main(int argc, char** argv)
     // The archive is on disk and closed.  A one-shot process does not hand its device and pinned memory back piece by
     // piece (0.75 s for a 10 M-read library: 53 GB of arenas, the lanes' pinned staging buffers): the kernel reclaims
     // them with the process.  FS_ORDERLY_EXIT=1 keeps the orderly teardown (leak checkers, the sanitizer builds).
-    if (!getenv("FS_ORDERLY_EXIT")) {
+    // A preloaded tool (rocprofv3, a coverage or leak checker) writes its output from exit handlers: take the orderly way then.
+    if (!getenv("FS_ORDERLY_EXIT") && !getenv("LD_PRELOAD") && !getenv("ROCP_TOOL_LIBRARIES") && !getenv("ROCPROFILER_REGISTER_FORCE_LOAD")) {
         if (trace) fprintf(stderr, "[trace] main: context %.0f ms (HIP start-up, arena pool), pack %.0f ms, no teardown; leaving at %lld ms (epoch)\n", tm1 - tm0, tm2 - tm1, wallNow());
         fflush(stdout); fflush(stderr);
         _exit(0);

@@ -987,7 +987,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             blockSizes[b] = S.sizes[k]; blockSlice[b] = si; blockOff[b] = off; off += S.sizes[k];
         }
         timing.encode_ms += S.timing.encode_ms; timing.assemble_ms += S.timing.assemble_ms; timing.launches += S.timing.launches; timing.items += S.timing.items;
-        timing.ppmd_symbols += S.timing.ppmd_symbols; timing.rc_symbols += S.timing.rc_symbols; timing.restarts += S.timing.restarts; for (int w = 0; w < 16; ++w) timing.win[w] += S.timing.win[w];
+        timing.ppmd_symbols += S.timing.ppmd_symbols; timing.rc_symbols += S.timing.rc_symbols; timing.restarts += S.timing.restarts; timing.max_restarts = std::max(timing.max_restarts, S.timing.max_restarts); for (int w = 0; w < 16; ++w) timing.win[w] += S.timing.win[w];
         timing.h2d_bytes += S.timing.h2d_bytes; timing.d2h_bytes += S.timing.d2h_bytes;
         timing.gather_ms += S.timing.gather_ms; timing.gather_symbols += S.timing.gather_symbols; timing.gather_bytes += S.timing.gather_bytes; timing.id_strings += S.timing.id_strings;
         if (trace) fprintf(stderr, "[trace] slice %u/%u: %u bins, front end done at %.1f ms, staged+submitted at %.1f ms (%.0f MB; staging buffer %.1f ms), device done at %.1f ms (kernel %.1f ms)\n",
@@ -1168,6 +1168,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                 bases += add; ++next;
             }
             const uint32_t nb = (uint32_t)(next - first);
+            ++stats.device_batches;
             // record arrays are placed: their sizes are in the .bmeta footer, so every bin knows its offsets up front and
             // is unpacked by the same host task that runs its front end (no barrier between the two stages)
             std::vector<uint64_t> seqBase(nb + 1, 0), headBase(nb + 1, 0), recBase(nb + 1, 0), quaBase(nb + 1, 0), hpBase(nb + 1, 0), weight(nb);

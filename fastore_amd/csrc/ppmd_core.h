@@ -69,7 +69,13 @@ struct Shared {
     // coder queue (two-wave form: the model wave produces, the coder wave consumes; see the range-coder section)
     uint32_t qA[256], qM[256];
     uint32_t qTail, qHead;
-    uint32_t qOutLo, qOutHi, qOutCap, qSizeLo, qSizeHi;     // the running stream's output buffer, capacity, and where its size goes
+    // Stream mailboxes: output buffer, capacity and where the size goes, for the stream whose CQ_START is in the ring.  Two
+    // of them, used alternately: the model wave may only rewrite box (s & 1) for its stream number s once the coder wave has
+    // READ that box for stream s - 2, which qStarts (streams the coder wave has opened) tells it -- qHead alone does not:
+    // the coder wave frees a batch's ring slots when the batch is in its registers, before it has worked the batch off.
+    uint32_t qBox[2][5];          // qOutLo, qOutHi, qOutCap, qSizeLo, qSizeHi
+    uint32_t qStarts;             // written by the coder wave
+    uint32_t qOpened;             // model wave only: streams it has started in this workgroup
     uint32_t winStats[16];
 #if defined(FS_SER_PROFILE)
     uint32_t serStats[8];        // design study: [0] symbol start -> first context ready, [1] first-context coding + coder hand-off, [2] tail of the loop, [3] serial symbols, [4] failed window attempts (clocks / 64)
@@ -345,7 +351,8 @@ FS_DEV void cq_push_lanes(Coder& m, uint32_t A, uint32_t M, uint32_t L)
     m.qTail += L;
     FS_Q_STORE(m.sh->qTail, m.qTail);
 }
-FS_DEV void cq_drain(Coder& m) { while (FS_Q_LOAD(m.sh->qHead) != m.qTail) FS_Q_IDLE(); m.qHeadSeen = m.qTail; }
+// the coder wave has opened every stream up to number `upTo` - 1 (their mailboxes are read)
+FS_DEV void cq_wait_starts(Coder& m, uint32_t upTo) { while ((int32_t)(FS_Q_LOAD(m.sh->qStarts) - upTo) < 0) FS_Q_IDLE(); }
 // the model wave's last word: the coder wave returns
 FS_DEV void cq_send_exit(FS_LDS Shared* sh, uint32_t qTail)
 { Coder m; m.sh = sh; m.qTail = qTail; m.qHeadSeen = qTail - CQ_SIZE; cq_push(m, CQ_CMD, CQ_EXIT); }
@@ -979,13 +986,17 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
     for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) *(fs_gptr32)(arena + SA_SIZE + 4u * i) = 0u;
     FS_WAVE_SYNC();
 #if FS_WIDE
-    if (m.queued) {       // the coder wave has finished the previous stream: hand it this one's output buffer
-        cq_drain(m);
+    if (m.queued) {       // hand the coder wave this stream's output buffer: box (s & 1), free once stream s - 2 has been opened
+        const uint32_t s = FS_UNI(FS_LDS_RD(sh->qOpened));
+        if (s >= 2u) cq_wait_starts(m, s - 1u);
         if (FS_LANE() == 0) {
             const uint64_t o = (uint64_t)(uintptr_t)out, z = (uint64_t)(uintptr_t)sizeOut;
-            sh->qOutLo = (uint32_t)o; sh->qOutHi = (uint32_t)(o >> 32); sh->qOutCap = outCap; sh->qSizeLo = (uint32_t)z; sh->qSizeHi = (uint32_t)(z >> 32);
+            FS_LDS uint32_t* box = sh->qBox[s & 1u];
+            box[0] = (uint32_t)o; box[1] = (uint32_t)(o >> 32); box[2] = outCap; box[3] = (uint32_t)z; box[4] = (uint32_t)(z >> 32);
+            sh->qOpened = s + 1u;
         }
-        cq_push(m, CQ_CMD, CQ_START);
+        FS_WAVE_SYNC();
+        cq_push(m, CQ_CMD, CQ_START);          // (the release store of the tail publishes the box with the command)
     } else
 #endif
     { put_byte(m, 0xCA); put_byte(m, MAX_ORDER); }
@@ -1114,7 +1125,7 @@ FS_DEV void coder_wave(FS_LDS Shared* sh)
     m.sh = sh; m.queued = 0; m.low = 0; m.range = 0xFFFFFFFFu; m.out = nullptr; m.outCap = 0; m.outPos = 0;
     FS_GLOBAL uint32_t* sizeOut = nullptr;
     const uint32_t lane = (uint32_t)FS_LANE();
-    uint32_t head = 0;
+    uint32_t head = 0, starts = 0;
     for (;;) {
         uint32_t tail;
         for (;;) { tail = FS_Q_LOAD(sh->qTail); if (tail != head) break; FS_Q_IDLE(); }
@@ -1154,8 +1165,10 @@ FS_DEV void coder_wave(FS_LDS Shared* sh)
                 m.low += (A & 0xFFFFu) * rr; m.range = rr * (M & 0xFFFFu);
                 rc_shift_out(m);
             } else if (M == CQ_START) {
-                const uint64_t o = (uint64_t)FS_LDS_RD(sh->qOutLo) | ((uint64_t)FS_LDS_RD(sh->qOutHi) << 32), z = (uint64_t)FS_LDS_RD(sh->qSizeLo) | ((uint64_t)FS_LDS_RD(sh->qSizeHi) << 32);
-                m.out = (fs_gptr)(uintptr_t)o; sizeOut = (FS_GLOBAL uint32_t*)(uintptr_t)z; m.outCap = FS_LDS_RD(sh->qOutCap); m.outPos = 0;
+                FS_LDS uint32_t* box = sh->qBox[starts & 1u];
+                const uint64_t o = (uint64_t)FS_LDS_RD(box[0]) | ((uint64_t)FS_LDS_RD(box[1]) << 32), z = (uint64_t)FS_LDS_RD(box[3]) | ((uint64_t)FS_LDS_RD(box[4]) << 32);
+                m.out = (fs_gptr)(uintptr_t)o; sizeOut = (FS_GLOBAL uint32_t*)(uintptr_t)z; m.outCap = FS_LDS_RD(box[2]); m.outPos = 0;
+                ++starts; FS_Q_STORE(sh->qStarts, starts);            // the box is read: the model wave may use it for the stream after next
                 put_byte(m, 0xCA); put_byte(m, MAX_ORDER);
                 m.low = 0; m.range = 0xFFFFFFFFu;
             } else if (M == CQ_END) {

@@ -112,6 +112,8 @@ typedef struct fsgpu_stats {
      * threads: upload, kernels, download, waiting), HIP-event time of its kernels (summed over the calls) */
     uint64_t matcher_reads; double matcher_call_ms, matcher_kernel_ms;
     uint64_t tokenised_ids;              /* read ids split into the IdToken / IdValue streams by fs_tokenise_ids (device) */
+    uint64_t device_batches;             /* device batches the standard bins were cut into (fsgpu_config.batch_bases each at most) */
+    uint64_t ppmd_max_restarts;          /* most model restarts (sub-allocator exhausted, Model.cpp:109-140 again) inside ONE PPMd stream */
 } fsgpu_stats;
 
 void fsgpu_config_defaults(fsgpu_config* cfg);

@@ -97,13 +97,13 @@ def flag_variants():
     return out
 
 
-def ref_pipeline(tmp, name, reads, length, genome, seed, paired, q, threads=8):
+def ref_pipeline(tmp, name, reads, length, genome, seed, paired, q, threads=8, gen_flags=()):
     """synthetic FASTQ -> fastore_bin -> 3 x fastore_rebin with the REAL reference (C1 profile); returns (binned prefix, pe flags)"""
     gen = os.path.join(ROOT, "build", "gen_fastq")
     if not os.path.exists(gen):
         subprocess.check_call(["g++", "-O2", "-o", gen, os.path.join(ROOT, "tools", "gen_fastq.cpp")])
     base = os.path.join(tmp, name)
-    subprocess.check_call([gen, "--reads", str(reads), "--len", str(length), "--genome", str(genome), "--seed", str(seed), "--out", base] + (["--paired"] if paired else []))
+    subprocess.check_call([gen, "--reads", str(reads), "--len", str(length), "--genome", str(genome), "--seed", str(seed), "--out", base] + (["--paired"] if paired else []) + list(gen_flags))
     pe = ["-z"] if paired else []
     inp = base + "_1.fastq" + ((" " + base + "_2.fastq") if paired else "")
     subprocess.check_call([REF_DRIVER_GCC, "bin", "-i" + inp, "-o" + base + ".b0", "-t%d" % threads, "-H", "-q%d" % q, "-p8", "-s0", "-b256"] + pe)

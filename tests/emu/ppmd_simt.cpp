@@ -16,7 +16,7 @@ extern "C" int simt_ppmd_encode_two_waves(int nStreams, const uint8_t* const* in
 {
     uint8_t* arena = (uint8_t*)aligned_alloc(64, (fsppmd::ARENA_BYTES + 4096 + 63) & ~63ull);
     fsppmd::Shared* sh = new fsppmd::Shared;
-    sh->qTail = sh->qHead = 0;
+    sh->qTail = sh->qHead = 0; sh->qStarts = sh->qOpened = 0;
     simt::run_waves(2, [&](int wave, int) {
         if (wave == 1) { fsppmd::coder_wave(sh); return; }
         uint32_t q = 0;

@@ -259,6 +259,40 @@ def test_gpu_pack_equals_live_reference_on_a_library_with_long_streams(tmp_path,
         assert open(os.path.join(t, "cli" + e), "rb").read() == open(os.path.join(t, "gpu" + e), "rb").read(), e
 
 
+@pytest.mark.skipif(not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)), reason="reference binaries (oracle/_ref) not shipped")
+def test_gpu_pack_many_batches_and_model_restarts_inside_standard_bins(tmp_path):
+    # What a library of BASELINE configs[2]'s size does to the pipeline, at a size a test can afford: 3.5 M pairs with
+    # bins of > 15 000 pairs, a device batch budget that cuts the standard bins into >= 3 batches (blocks of the earlier
+    # batches wait behind block 0), and quality scores without structure (gen_fastq --noisy-quality), so that the PPMd
+    # model of a standard bin's quality stream outgrows its heap and restarts >= 3 times inside ONE stream
+    # (ppmd/Model.cpp:109-140 + the sub-allocator's exhaustion paths, SubAlloc.hpp:98-163).  Every block against the
+    # live reference's block of the same signature.
+    import fastore_amd
+    from conftest import reference_blocks
+    t = str(tmp_path)
+    cores = len(os.sched_getaffinity(0))
+    pairs = 3_500_000
+    binned, pe = ref_pipeline(t, "many", pairs, 150, 2 * pairs * 150 // 50, 11, True, 0, threads=min(16, cores), gen_flags=["--noisy-quality"])
+    for f in os.listdir(t):
+        if f.endswith(".fastq") or ".b0." in f or ".b2." in f or ".b4." in f:
+            os.remove(os.path.join(t, f))
+    flags = ["-r", "-f256", "-c10", "-d8", "-w1024", "-W1024"]
+    subprocess.check_call([REF_DRIVER, "pack", "-i" + binned, "-o" + os.path.join(t, "ref"), "-t%d" % min(16, cores)] + flags + pe)
+    with fastore_amd.Packer(device_id=0, batch_bases=250_000_000) as p:
+        st = p.pack_file(binned, os.path.join(t, "gpu"))
+    want = reference_blocks(os.path.join(t, "ref")); got = reference_blocks(os.path.join(t, "gpu"))
+    assert sorted(want) == sorted(got)
+    for sg in want:
+        assert got[sg] == want[sg], "block of signature %d differs" % sg
+    assert st["device_batches"] >= 3, st["device_batches"]
+    assert st["ppmd_max_restarts"] >= 3, st["ppmd_max_restarts"]
+    assert st["host_coded_symbols"] == 0
+    import struct
+    m = open(os.path.join(t, "gpu.cmeta"), "rb").read(); foff, _ = struct.unpack_from("<QQ", m, 0); n, = struct.unpack_from("<I", m, foff)
+    sigs = list(struct.unpack_from("<%dI" % n, m, foff + 4 + 8 * n))
+    assert sigs[0] == max(sigs) and sigs[1:] == sorted(sigs[1:])          # -t1 order although the batches finished one after the other
+
+
 def test_gpu_rank_sharded_pack_on_one_device(tmp_path):
     # the multi-GPU path (fsgpu_config.rank/world_size + fsgpu_merge_parts), both ranks on device 0 one after the other:
     # the merged archive must be the single-writer archive, for SE and PE and an odd world size

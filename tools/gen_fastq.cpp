@@ -7,6 +7,8 @@
 // 50/50; PE fragment length uniform in [2L, 3L], mate 2 = reverse complement of the fragment
 // end.  Per base: substitution 0.5 %, N 0.05 %.  Quality: bounded random walk on [2, 40] from
 // 38 with steps {-3,-1,0,0,0,0,+1,+1}, Phred+33.  Header "@SYN.<i> <i>/1" (and "/2").
+// --noisy-quality (tests only): every score uniform on [2, 40] instead -- a PPMd model of such a stream outgrows its
+// 16 MiB heap about every 1.4 M symbols and restarts (ppmd/Model.cpp:109-140), which the random walk never does.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +35,7 @@ static void seed_rng(uint64_t x)
 }
 static inline uint64_t bounded(uint64_t n) { return (uint64_t)(((__uint128_t)next_u64() * n) >> 64); }
 
+static bool g_noisyQuality = false;
 static const char ACGT[4] = {'A', 'C', 'G', 'T'};
 static inline char comp(char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; } return 'N'; }
 
@@ -51,8 +54,8 @@ static void emit(FILE* f, uint64_t idx, int mate, const char* frag, int L, bool 
     *p++ = '\n'; *p++ = '+'; *p++ = '\n';
     int q = 38;
     for (int i = 0; i < L; ++i) {
-        q += steps[next_u64() >> 61];
-        if (q < 2) q = 2; if (q > 40) q = 40;
+        if (g_noisyQuality) q = 2 + (int)bounded(39);
+        else { q += steps[next_u64() >> 61]; if (q < 2) q = 2; if (q > 40) q = 40; }
         *p++ = (char)(33 + q);
     }
     *p++ = '\n';
@@ -71,10 +74,11 @@ int main(int argc, char** argv)
         else if (a == "--seed") S = strtoull(val(), 0, 10);
         else if (a == "--out") out = val();
         else if (a == "--paired") paired = true;
+        else if (a == "--noisy-quality") g_noisyQuality = true;
         else { fprintf(stderr, "unknown arg %s\n", a.c_str()); return 2; }
     }
     if (!N || !G || out.empty() || L < 20 || L > 250 || G < (uint64_t)(3 * L + 1)) {
-        fprintf(stderr, "usage: gen_fastq --reads N --len L [--paired] --genome G --seed S --out PREFIX\n");
+        fprintf(stderr, "usage: gen_fastq --reads N --len L [--paired] [--noisy-quality] --genome G --seed S --out PREFIX\n");
         return 2;
     }
     seed_rng(S);
