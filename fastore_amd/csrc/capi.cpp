@@ -609,7 +609,8 @@ int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out)
     out->ppmd_window_rounds = ctx->c.timing.win[4]; out->ppmd_windows_redone = ctx->c.timing.win[5]; out->ppmd_window_light_rounds = ctx->c.timing.win[6];
     out->tokenised_ids = ctx->c.timing.id_strings; out->matcher_reads = ctx->c.matchedReads.load(); out->matcher_call_ms = ctx->c.matchUs.load() / 1e3; out->matcher_kernel_ms = ctx->c.matchKernelUs.load() / 1e3;
     out->gather_kernel_ms = ctx->c.timing.gather_ms; out->gather_symbols = ctx->c.timing.gather_symbols; out->gather_bytes = ctx->c.timing.gather_bytes;
-    out->rc_symbols = ctx->c.timing.rc_symbols; out->ppmd_restarts = ctx->c.timing.restarts; out->ppmd_max_restarts = ctx->c.timing.max_restarts; out->h2d_bytes = ctx->c.timing.h2d_bytes; out->d2h_bytes = ctx->c.timing.d2h_bytes;
+    out->rc_symbols = ctx->c.timing.rc_symbols; out->ppmd_restarts = ctx->c.timing.restarts; out->ppmd_max_restarts = ctx->c.timing.max_restarts;
+    out->ppmd_windows_ahead = ctx->c.timing.win[8]; out->ppmd_windows_ahead_in_vain = ctx->c.timing.win[9];       // (-DFS_WIN_PROFILE builds of the kernels keep phase clocks in these two slots instead) out->h2d_bytes = ctx->c.timing.h2d_bytes; out->d2h_bytes = ctx->c.timing.d2h_bytes;
     return FSGPU_OK;
 }
 

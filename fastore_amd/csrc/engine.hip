@@ -77,14 +77,19 @@ __device__ __forceinline__ KernArgs kernargs()
 
 // TWO: the two-wave form (128-thread workgroups): wave 0 walks the models and queues every PPMd coding step, wave 1 is
 // the coder wave (ppmd_core.h: coder_wave).  Range-coded and QVZ items are coded by wave 0 alone, as in the one-wave form.
-template <bool TWO> __device__ __forceinline__ void encode_streams_body()
+// WAVES = 3: the three-wave form (192-thread workgroups): wave 2 is the window wave, which prepares the windows of the hit path
+// ahead of wave 0's serial walk (ppmd_scout.h).
+template <int WAVES> __device__ __forceinline__ void encode_streams_body()
 {
+    constexpr bool TWO = WAVES >= 2, THREE = WAVES == 3;
     __shared__ fsppmd::Shared sh;
     uint32_t qTail = 0;
     if (TWO) {
-        if (threadIdx.x == 0) { sh.qTail = 0u; sh.qHead = 0u; sh.qStarts = 0u; sh.qOpened = 0u; }
+        if (threadIdx.x == 0) { sh.qTail = 0u; sh.qHead = 0u; sh.qStarts = 0u; sh.qOpened = 0u; if (THREE) fsppmd::scout_init((FS_LDS fsppmd::Shared*)&sh); }
         __syncthreads();                               // the workgroup's only barrier: from here on the waves go separate ways
-        if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0) { fsppmd::coder_wave((FS_LDS fsppmd::Shared*)&sh); return; }
+        const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        if (wv == 1u) { fsppmd::coder_wave((FS_LDS fsppmd::Shared*)&sh); return; }
+        if (THREE && wv == 2u) { __builtin_amdgcn_s_setprio(2); fsppmd::window_wave((FS_LDS fsppmd::Shared*)&sh); return; }
     }
     // maps == nullptr: exclusive launch (no other kernel in flight), one arena per workgroup index
     uint32_t slot = blockIdx.x, xcc = 0, word = 0, bit = 0;
@@ -145,7 +150,7 @@ template <bool TWO> __device__ __forceinline__ void encode_streams_body()
         const uint64_t tStream = FS_PROF_NOW();
         if (kind == KIND_PPMD) {
             if (n > 0) {
-                if (TWO) { KernArgs k3 = kernargs(); (void)fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs, true, (FS_GLOBAL uint32_t*)(k3->outSizes + it), qTail, &qTail); }
+                if (TWO) { KernArgs k3 = kernargs(); (void)fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs, true, (FS_GLOBAL uint32_t*)(k3->outSizes + it), qTail, &qTail, THREE); }
                 else size = fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs);
             }
         } else if (kind == KIND_QVZ) {
@@ -175,12 +180,17 @@ template <bool TWO> __device__ __forceinline__ void encode_streams_body()
 #endif
                 else if (t >= 8u && t < 15u) v = sh.winStats[t];
                 else if (t == 15u) v = (uint32_t)((FS_PROF_NOW() - tStream) >> 6);
+#if !defined(FS_WIN_PROFILE) && !defined(FS_SER_PROFILE)
+                if (THREE && t == 8u) v = sh.wxStats[0] - sh.wxBase[0];                  // windows prepared ahead of the serial walk and used
+                if (THREE && t == 9u) v = sh.wxStats[1] + sh.wxStats[2] - sh.wxBase[1] - sh.wxBase[2];    // prepared in vain (start lane unusable, or the check failed)
+#endif
             }
             if (t == 0u) v = rs;
             k2->restarts[16u * it + t] = v;
         }
         FS_WAVE_SYNC();
     }
+    if (THREE) fsppmd::scout_send_exit((FS_LDS fsppmd::Shared*)&sh);
     if (TWO) fsppmd::cq_send_exit((FS_LDS fsppmd::Shared*)&sh, qTail);
     if (useMaps && threadIdx.x == 0) {
         KernArgs k = kernargs();
@@ -190,11 +200,13 @@ template <bool TWO> __device__ __forceinline__ void encode_streams_body()
     }
 }
 
-__global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(EncodeArgs /* read through kernargs() */) { encode_streams_body<false>(); }
+__global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(EncodeArgs /* read through kernargs() */) { encode_streams_body<1>(); }
 // (the two-wave form is used where single streams decide the step: two workgroup-waves per SIMD leave each 256 VGPRs -- 3.5 %
 // off the time of a lone long stream against the 170 of three per SIMD, profiles/r02_qq_two_waves_per_simd.txt; the one-wave
 // form codes the slices of short streams, where the number of resident waves counts)
-__global__ __launch_bounds__(128, 2) void fs_encode_streams2(EncodeArgs /* read through kernargs() */) { encode_streams_body<true>(); }
+__global__ __launch_bounds__(128, 2) void fs_encode_streams2(EncodeArgs /* read through kernargs() */) { encode_streams_body<2>(); }
+// (the three-wave form: serial wave, coder wave, window wave -- for launches whose longest stream decides the step)
+__global__ __launch_bounds__(192, 2) void fs_encode_streams3(EncodeArgs /* read through kernargs() */) { encode_streams_body<3>(); }
 
 // fs_gather_quality -- the quality stream of a lossless bin, built on the device (SURVEY 8 a8 + f1): the stored scores
 // (.bqua: six bits each, MSB first, fastore_bin/FastqPacker.cpp:157-287) are unpacked, turned back to front where the read
@@ -270,22 +282,37 @@ __global__ __launch_bounds__(256) void fs_gather_quality_pairs(const QuaPairStri
 // fastore_pack/FastqCompressor.cpp:504-583).  One workgroup per bin, one read per thread and step; a read's pairs land behind
 // those of the reads before it: counted first, placed by a prefix sum over the workgroup, then written.  The two streams'
 // lengths go to their stream items, which the coder kernel reads behind this one.
+// (Round 3: a bin is cut into chunks of 256 reads, one workgroup each -- a 47 000-read bin used to be 186 rounds of ONE workgroup
+// on ONE compute unit, 50-330 ms in front of the slice's coder launch on the same stream.  fs_id_count parses every read once
+// and leaves its pair counts and the chunk's totals; fs_id_write places a chunk behind the totals of the bin's earlier chunks
+// and parses again to write.  Characters come eight at a time: 56 stored bits from one unaligned 64-bit load.)
+struct IdChunk { uint32_t job, c0, first_chunk, pad; };          // reads [c0, c0 + 256) of the job; the job's first chunk
+struct IdChars {
+    const uint8_t* in; uint64_t src_bit; uint64_t buf; uint32_t first;      // stored characters [first, first + 8) sit in the top 56 bits of buf
+    __device__ __forceinline__ uint32_t get(uint32_t j)
+    {
+        if (j == 0u) return (uint32_t)'@';
+        const uint32_t i = j - 1u;
+        if (i - first >= 8u) {
+            const uint64_t bit = src_bit + 7ull * i;
+            uint64_t w; __builtin_memcpy(&w, in + (bit >> 3), 8);
+            buf = __builtin_bswap64(w) << (uint32_t)(bit & 7u);
+            first = i;
+        }
+        return (uint32_t)(buf >> (57u - 7u * (i - first))) & 127u;
+    }
+};
 template <bool WRITE> __device__ __forceinline__ void id_parse(const IdString& s, const uint8_t* __restrict__ in, const uint8_t* __restrict__ tab, uint32_t& nt, uint32_t& nv,
                                                                uint8_t* tokDst, uint8_t* valDst)
 {
     const uint32_t nf = *(const uint32_t*)tab;
     const IdField* F = (const IdField*)(tab + 8);
-    auto ch = [&](uint32_t j) -> uint32_t {
-        if (j == 0u) return (uint32_t)'@';
-        const uint64_t bit = s.src_bit + 7ull * (j - 1u);
-        const uint32_t w = ((uint32_t)in[bit >> 3] << 8) | in[(bit >> 3) + 1];
-        return (w >> (9u - (uint32_t)(bit & 7u))) & 127u;
-    };
+    IdChars scan{in, s.src_bit, 0ull, 0xFFFFFF00u}, look{in, s.src_bit, 0ull, 0xFFFFFF00u};      // the separator scan, and the look back into a field
     uint32_t fieldStart = 0, fi = 0;
     for (uint32_t i = 0; i <= s.len; ++i) {
         if (fi >= nf) break;
         const IdField f = F[fi];
-        if (i != s.len && ch(i) != (uint32_t)f.separator) continue;
+        if (i != s.len && scan.get(i) != (uint32_t)f.separator) continue;
         if (!f.is_const) {
             const uint32_t fieldLen = i - fieldStart;
             if (!f.is_numeric) {
@@ -295,14 +322,14 @@ template <bool WRITE> __device__ __forceinline__ void id_parse(const IdString& s
                     if (vl[2 * v + 1] != fieldLen) continue;
                     const uint8_t* vb = tab + vl[2 * v];
                     bool same = true;
-                    for (uint32_t k = 0; k < fieldLen && same; ++k) same = vb[k] == ch(fieldStart + k);
+                    for (uint32_t k = 0; k < fieldLen && same; ++k) same = vb[k] == look.get(fieldStart + k);
                     if (same) id = v;
                 }
                 if (WRITE) { tokDst[2 * nt] = (uint8_t)id; tokDst[2 * nt + 1] = (uint8_t)fi; }
                 ++nt;
             } else {
                 uint64_t v = 0;
-                for (uint32_t k = 0; k < fieldLen; ++k) { const uint32_t c = ch(fieldStart + k); if (c < '0' || c > '9') break; v = v * 10u + (c - '0'); }
+                for (uint32_t k = 0; k < fieldLen; ++k) { const uint32_t c = look.get(fieldStart + k); if (c < '0' || c > '9') break; v = v * 10u + (c - '0'); }
                 const int64_t diff = (int64_t)(v - f.min_value);
                 uint32_t ctx = fi << 2;
                 for (int32_t p = (int32_t)f.plog; p >= 0; --p) {
@@ -315,37 +342,68 @@ template <bool WRITE> __device__ __forceinline__ void id_parse(const IdString& s
     }
 }
 
-__global__ __launch_bounds__(256) void fs_tokenise_ids(const IdJob* __restrict__ jobs, const IdString* __restrict__ strings, const uint8_t* __restrict__ in,
-                                                       uint8_t* __restrict__ out, StreamItem* items)
+// sums of (a, b) over the 256 threads of the workgroup (every thread gets both)
+__device__ __forceinline__ void id_block_sum(uint32_t& a, uint32_t& b, uint32_t* sA, uint32_t* sB)
 {
-    __shared__ uint32_t sT[256], sV[256];
-    const IdJob job = jobs[blockIdx.x];
-    const uint8_t* tab = in + job.table_off;
     const uint32_t tid = threadIdx.x;
-    uint32_t tokBase = 0, valBase = 0;                             // pairs written so far
-    for (uint32_t c0 = 0; c0 < job.count; c0 += 256u) {
-        const bool active = c0 + tid < job.count;
-        IdString s; s.src_bit = 0; s.len = 0; s.pad = 0;
-        uint32_t nt = 0, nv = 0;
-        if (active) { s = strings[job.first + c0 + tid]; id_parse<false>(s, in, tab, nt, nv, nullptr, nullptr); }
-        // inclusive prefix sums over the workgroup (Hillis-Steele in LDS)
-        sT[tid] = nt; sV[tid] = nv;
-        __syncthreads();
-        for (uint32_t d = 1; d < 256u; d <<= 1) {
-            const uint32_t a = tid >= d ? sT[tid - d] : 0u, b = tid >= d ? sV[tid - d] : 0u;
-            __syncthreads();
-            sT[tid] += a; sV[tid] += b;
-            __syncthreads();
-        }
-        const uint32_t offT = sT[tid] - nt, offV = sV[tid] - nv, totT = sT[255], totV = sV[255];
-        if (active) {
-            uint32_t wt = 0, wv = 0;
-            id_parse<true>(s, in, tab, wt, wv, out + job.tok_out + 2ull * (tokBase + offT), out + job.val_out + 2ull * (valBase + offV));
-        }
-        tokBase += totT; valBase += totV;
+    sA[tid] = a; sB[tid] = b;
+    __syncthreads();
+    for (uint32_t d = 128u; d > 0u; d >>= 1) {
+        if (tid < d) { sA[tid] += sA[tid + d]; sB[tid] += sB[tid + d]; }
         __syncthreads();
     }
-    if (tid == 0u) { items[job.tok_item].in_len = tokBase; items[job.val_item].in_len = valBase; }
+    a = sA[0]; b = sB[0];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void fs_id_count(const IdChunk* __restrict__ chunks, const IdJob* __restrict__ jobs, const IdString* __restrict__ strings, const uint8_t* __restrict__ in,
+                                                   uint32_t* __restrict__ counts, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t sT[256], sV[256];
+    const IdChunk ck = chunks[blockIdx.x];
+    const IdJob job = jobs[ck.job];
+    const uint32_t tid = threadIdx.x;
+    uint32_t nt = 0, nv = 0;
+    if (ck.c0 + tid < job.count) {
+        const IdString s = strings[job.first + ck.c0 + tid];
+        id_parse<false>(s, in, in + job.table_off, nt, nv, nullptr, nullptr);
+        counts[job.first + ck.c0 + tid] = nt | (nv << 16);          // (a read id has at most 255 characters: both counts stay far below 65 536)
+    }
+    id_block_sum(nt, nv, sT, sV);
+    if (tid == 0u) { totals[2u * blockIdx.x] = nt; totals[2u * blockIdx.x + 1u] = nv; }
+}
+
+__global__ __launch_bounds__(256) void fs_id_write(const IdChunk* __restrict__ chunks, const IdJob* __restrict__ jobs, const IdString* __restrict__ strings, const uint8_t* __restrict__ in,
+                                                   const uint32_t* __restrict__ counts, const uint32_t* __restrict__ totals, uint8_t* __restrict__ out, StreamItem* items)
+{
+    __shared__ uint32_t sT[256], sV[256];
+    const IdChunk ck = chunks[blockIdx.x];
+    const IdJob job = jobs[ck.job];
+    const uint32_t tid = threadIdx.x;
+    // pairs of the bin's earlier chunks
+    uint32_t tokBase = 0, valBase = 0;
+    for (uint32_t c = ck.first_chunk + tid; c < blockIdx.x; c += 256u) { tokBase += totals[2u * c]; valBase += totals[2u * c + 1u]; }
+    id_block_sum(tokBase, valBase, sT, sV);
+    const bool active = ck.c0 + tid < job.count;
+    uint32_t nt = 0, nv = 0;
+    if (active) { const uint32_t c = counts[job.first + ck.c0 + tid]; nt = c & 0xFFFFu; nv = c >> 16; }
+    // inclusive prefix sums over the workgroup (Hillis-Steele in LDS)
+    sT[tid] = nt; sV[tid] = nv;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256u; d <<= 1) {
+        const uint32_t a = tid >= d ? sT[tid - d] : 0u, b = tid >= d ? sV[tid - d] : 0u;
+        __syncthreads();
+        sT[tid] += a; sV[tid] += b;
+        __syncthreads();
+    }
+    const uint32_t offT = sT[tid] - nt, offV = sV[tid] - nv, totT = sT[255], totV = sV[255];
+    if (active) {
+        const IdString s = strings[job.first + ck.c0 + tid];
+        uint32_t wt = 0, wv = 0;
+        id_parse<true>(s, in, in + job.table_off, wt, wv, out + job.tok_out + 2ull * (tokBase + offT), out + job.val_out + 2ull * (valBase + offV));
+    }
+    // the bin's last chunk knows the streams' lengths: they go to their stream items, which the coder kernel reads behind this one
+    if (tid == 0u && ck.c0 + 256u >= job.count) { items[job.tok_item].in_len = tokBase + totT; items[job.val_item].in_len = valBase + totV; }
 }
 
 __device__ __forceinline__ void put_be(uint8_t* p, uint64_t v, int nbytes)
@@ -602,6 +660,37 @@ uint8_t* staging_buffer(Device* dev, size_t bytes)
 }
 
 // H2D + fs_encode_streams + D2H of the per-stream sizes.  Leaves the coded streams in dev->dScratch.
+// host side of the two kernels: the chunk table of the plan's jobs (kept by the caller until the stream has been waited for), the
+// scratch behind `scratchBase` in the lane's input buffer (chunk table, chunk totals, per-read counts), the two launches
+struct IdLaunch { std::vector<IdChunk> chunks; uint64_t tableOff = 0, totalsOff = 0, countsOff = 0, bytes = 0; };
+static void id_launch_plan(const IdJob* jb, uint32_t nJobs, uint32_t nStrings, uint64_t scratchBase, IdLaunch& L)
+{
+    L.chunks.clear();
+    for (uint32_t j = 0; j < nJobs; ++j) {
+        const uint32_t first = (uint32_t)L.chunks.size();
+        uint32_t c0 = 0;
+        do { L.chunks.push_back(IdChunk{j, c0, first, 0u}); c0 += 256u; } while (c0 < jb[j].count);      // (an empty bin keeps one chunk: it sets the lengths to zero)
+    }
+    L.tableOff = (scratchBase + 15u) & ~15ull;
+    L.totalsOff = L.tableOff + sizeof(IdChunk) * L.chunks.size();
+    L.countsOff = L.totalsOff + 8ull * L.chunks.size();
+    L.bytes = L.countsOff + 4ull * nStrings + 16u - scratchBase;
+}
+static int id_launch(Device* dev, hipStream_t st, const IdPlan& plan, uint64_t gatherBase, const IdLaunch& L)
+{
+    if (L.chunks.empty()) return 0;
+    HIP_TRY(hipMemcpyAsync(dev->dIn + L.tableOff, L.chunks.data(), sizeof(IdChunk) * L.chunks.size(), hipMemcpyHostToDevice, st));
+    const IdChunk* ck = (const IdChunk*)(dev->dIn + L.tableOff);
+    const IdJob* jobs = (const IdJob*)(dev->dIn + plan.jobs_off); const IdString* strs = (const IdString*)(dev->dIn + plan.strings_off);
+    uint32_t* counts = (uint32_t*)(dev->dIn + L.countsOff); uint32_t* totals = (uint32_t*)(dev->dIn + L.totalsOff);
+    hipLaunchKernelGGL(fs_id_count, dim3((uint32_t)L.chunks.size()), dim3(256), 0, st, ck, jobs, strs, (const uint8_t*)dev->dIn, counts, totals);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(fs_id_write, dim3((uint32_t)L.chunks.size()), dim3(256), 0, st, ck, jobs, strs, (const uint8_t*)dev->dIn, (const uint32_t*)counts, (const uint32_t*)totals,
+                       (uint8_t*)(dev->dIn + gatherBase), (StreamItem*)dev->dItems);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items,
                       std::vector<uint32_t>& sizes, uint64_t& scratchBytes, BatchTiming* timing, const GatherPlan* gather = nullptr, const IdPlan* ids = nullptr)
 {
@@ -645,7 +734,9 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
                    (gather->bits != 6u && gather->bits != 3u && gather->bits != 1u) || (gather->bits != 6u && gather->n_list_off + gather->n_list_bytes > inputBytes))) {
         snprintf(dev->err, sizeof dev->err, "quality gather plan outside the batch input"); return -1;
     }
-    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + gatherBytes + 64)) return -1;
+    IdLaunch idl;
+    if (ids && ids->n_jobs) id_launch_plan((const IdJob*)(input + ids->jobs_off), ids->n_jobs, ids->n_strings, gatherBase + gatherBytes, idl);
+    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + gatherBytes + idl.bytes + 64)) return -1;
     if (ensure(dev, dev->dScratch, dev->capScratch, scratch + 16)) return -1;
     if (ensure(dev, dev->dItems, dev->capItems, sizeof(StreamItem) * nItems)) return -1;
     if (ensure(dev, dev->dOrder, dev->capOrder, 4ull * nItems)) return -1;
@@ -713,9 +804,7 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
             for (uint32_t k = 0; ok && k < jb[j].count; ++k) { const IdString& s = ss[jb[j].first + k]; ok = s.len <= 255u && (s.src_bit >> 3) + (7ull * s.len + 7u) / 8u + 2u <= inputBytes; }
             if (!ok) { snprintf(dev->err, sizeof dev->err, "read-id job %u outside the batch input", j); return -1; }
         }
-        hipLaunchKernelGGL(fs_tokenise_ids, dim3(ids->n_jobs), dim3(256), 0, st, (const IdJob*)(dev->dIn + ids->jobs_off), (const IdString*)(dev->dIn + ids->strings_off),
-                           (const uint8_t*)dev->dIn, (uint8_t*)(dev->dIn + gatherBase), (StreamItem*)dev->dItems);
-        HIP_TRY(hipGetLastError());
+        if (id_launch(dev, st, *ids, gatherBase, idl)) return -1;
     }
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[0], st));
     {
@@ -726,9 +815,16 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         ka.nItems = nRest; ka.longLen = longLen; ka.slotsPerXcc = pool->slotsPerXcc; ka.pad = 0;
         // two-wave form where the step is bound by its longest PPMd stream (the coder runs beside the model walk: ~1.4x per
         // stream, but a stream takes two wave slots); FS_TWO_WAVE=0/1 forces either form
-        bool two = maxLen >= (256u << 10);
-        if (const char* tw = getenv("FS_TWO_WAVE")) two = atoi(tw) != 0;
-        if (two) { const uint32_t g2 = std::max(1u, std::min(grid, dev->nWaves / 2u)); hipLaunchKernelGGL(fs_encode_streams2, dim3(g2), dim3(128), 0, st, ka); }
+        // (FS_WAVES=1/2/3 forces a form; FS_TWO_WAVE=0/1 is the older switch between the first two.  The three-wave form --
+        // windows prepared by a wave of their own ahead of the serial walk, ppmd_scout.h -- is bit-exact and tested, but as
+        // measured in round 3 it does not yet beat the two-wave form on a lone 7 M-symbol stream (1.10 s against 0.97 s:
+        // 44 % of the windows prepared ahead cannot be used and are prepared again while the serial wave waits,
+        // profiles/r03_three_wave_*.txt), so it stays opt-in.)
+        uint32_t waves = maxLen >= (256u << 10) ? 2u : 1u;
+        if (const char* tw = getenv("FS_TWO_WAVE")) waves = atoi(tw) != 0 ? 2u : 1u;
+        if (const char* tw = getenv("FS_WAVES")) waves = (uint32_t)std::max(1, std::min(3, atoi(tw)));
+        if (waves == 3u) { const uint32_t g3 = std::max(1u, std::min(grid, dev->nWaves / 3u)); hipLaunchKernelGGL(fs_encode_streams3, dim3(g3), dim3(192), 0, st, ka); }
+        else if (waves == 2u) { const uint32_t g2 = std::max(1u, std::min(grid, dev->nWaves / 2u)); hipLaunchKernelGGL(fs_encode_streams2, dim3(g2), dim3(128), 0, st, ka); }
         else hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, ka);
         HIP_TRY(hipGetLastError());
     }
@@ -839,13 +935,13 @@ int tokenise_ids_raw(Device* dev, const uint8_t* input, size_t inputBytes, const
         for (uint32_t k = 0; ok && k < jb[j].count; ++k) { const IdString& s = ss[jb[j].first + k]; ok = s.len <= 255u && (s.src_bit >> 3) + (7ull * s.len + 7u) / 8u + 2u <= inputBytes; }
         if (!ok) { snprintf(dev->err, sizeof dev->err, "read-id job %u outside the input", j); return -1; }
     }
-    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + plan.out_bytes + 64)) return -1;
+    IdLaunch idl;
+    id_launch_plan(jb, plan.n_jobs, plan.n_strings, gatherBase + plan.out_bytes, idl);
+    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + plan.out_bytes + idl.bytes + 64)) return -1;
     if (ensure(dev, dev->dItems, dev->capItems, sizeof(StreamItem) * items.size() + 64)) return -1;
     HIP_TRY(hipMemcpyAsync(dev->dIn, input, inputBytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dev->dItems, items.data(), sizeof(StreamItem) * items.size(), hipMemcpyHostToDevice, st));
-    if (plan.n_jobs) hipLaunchKernelGGL(fs_tokenise_ids, dim3(plan.n_jobs), dim3(256), 0, st, (const IdJob*)(dev->dIn + plan.jobs_off), (const IdString*)(dev->dIn + plan.strings_off),
-                                        (const uint8_t*)dev->dIn, (uint8_t*)(dev->dIn + gatherBase), (StreamItem*)dev->dItems);
-    HIP_TRY(hipGetLastError());
+    if (plan.n_jobs && id_launch(dev, st, plan, gatherBase, idl)) return -1;
     std::vector<uint8_t> out(plan.out_bytes + 16);
     HIP_TRY(hipMemcpyAsync(out.data(), dev->dIn + gatherBase, plan.out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(items.data(), dev->dItems, sizeof(StreamItem) * items.size(), hipMemcpyDeviceToHost, st));

@@ -181,6 +181,12 @@ void ArchiveWriter::start(const std::string& prefix, const BinModuleConfigRaw& c
     sizeStats_.start(cfg.archiveType, cfg.minimizer);
 }
 
+// Longest-processing-time-first over the bins' record totals, aware of what a rank's step is made of: a rank is done when its
+// LONGEST stream is (one wavefront walks a PPMd stream from end to end: kLoneFactor records' worth of throughput work per
+// record of its largest bin -- a lone stream runs at ~6 M symbols/s, the chip at ~5 G symbols/s when full) or when the SUM of
+// its work is, whichever comes later.  Every bin goes where the job's makespan under that model ends up smallest; among
+// equals, to the rank with the least sum.  (With the heaviest bins going first this differs from the plain rule only when a
+// rank's sum outgrows its longest stream -- libraries far larger than 10 M reads -- but then it counts.)
 std::vector<uint32_t> shardOwners(const std::vector<uint64_t>& weights, uint32_t world)
 {
     const uint32_t n = (uint32_t)weights.size();
@@ -188,11 +194,18 @@ std::vector<uint32_t> shardOwners(const std::vector<uint64_t>& weights, uint32_t
     if (world <= 1) return owner;
     for (uint32_t i = 0; i < n; ++i) idx[i] = i;
     std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return weights[a] > weights[b]; });
-    std::vector<uint64_t> load(world, 0);
+    constexpr uint64_t kLoneFactor = 256;
+    std::vector<uint64_t> load(world, 0), longest(world, 0);
+    auto cost = [&](uint32_t r, uint64_t extra) { return std::max(kLoneFactor * std::max(longest[r], extra), load[r] + extra); };
     for (uint32_t i : idx) {
-        uint32_t best = 0;
-        for (uint32_t r = 1; r < world; ++r) if (load[r] < load[best]) best = r;
-        owner[i] = best; load[best] += weights[i] + 1;          // (+1: empty weights still spread)
+        const uint64_t w = weights[i] + 1;                         // (+1: empty weights still spread)
+        uint32_t best = 0; uint64_t bestSpan = ~0ull;
+        for (uint32_t r = 0; r < world; ++r) {
+            uint64_t span = cost(r, w);
+            for (uint32_t q = 0; q < world; ++q) if (q != r) span = std::max(span, cost(q, 0));
+            if (span < bestSpan || (span == bestSpan && load[r] < load[best])) { best = r; bestSpan = span; }
+        }
+        owner[i] = best; load[best] += w; longest[best] = std::max(longest[best], w);
     }
     return owner;
 }
@@ -1080,6 +1093,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         std::atomic<bool> t0done{false};        // the block-0 thread has finished (its block can be written without waiting)
         struct Pending { std::vector<uint8_t> data; std::vector<uint64_t> sizes; std::vector<uint32_t> sigs; };
         std::vector<Pending> pending;
+        std::mutex awMx;                        // block 0's thread decides under it whether it may head the archive itself; the main thread queues blocks under it
     };
     std::vector<std::unique_ptr<Lib>> libs;
     archives.clear(); archives.resize(nLibs);
@@ -1110,7 +1124,12 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
     const uint64_t budget = cfg.batch_bases ? cfg.batch_bases : (3072ull << 20);
     uint64_t stdBases = 0;
     for (const Work& w : work) stdBases += libs[w.lib]->bf.bins().at(w.sig).totalRawDnaSize;
-    std::mutex gateMx; std::condition_variable gateCv; bool hostTasksDone = work.empty() || stdBases > budget; size_t block0Unpacked = 0, block0Threads = 0;
+    // (Round 3: with eight cores or more the block-0 threads start at once all the same -- a paired-end library's block 0 is
+    // 0.8 s of one serial PPMd stream per 6 M pairs; behind a 1.3 s front end it WAS the end of the step (2.57 s), beside it
+    // it costs the front end a sixteenth of its cores for that time.  FS_BLOCK0_EARLY=0/1 forces either order.)
+    bool block0Early = hostCores >= 8;
+    if (const char* be = getenv("FS_BLOCK0_EARLY")) block0Early = atoi(be) != 0;
+    std::mutex gateMx; std::condition_variable gateCv; bool hostTasksDone = work.empty() || stdBases > budget || block0Early; size_t block0Unpacked = 0, block0Threads = 0;
     std::thread closer;
     if (rank == 0) {
         for (size_t l = 0; l < nLibs; ++l) {
@@ -1133,7 +1152,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                     compressRawBlock(lp->b0, *ap, lp->block0);
                     // Block 0 heads the archive and nothing is written in front of it: this thread puts it there itself, while
                     // the device still walks the long streams (the writer belongs to this thread until it is joined).
-                    if (lp->aw.dataBytes() == 0 && lp->pending.empty()) { lp->aw.writeBlock(lp->block0.data(), lp->block0.size(), lp->bf.nSignature()); lp->block0InFile = true; }
+                    { std::lock_guard<std::mutex> lk(lp->awMx); if (lp->aw.dataBytes() == 0 && lp->pending.empty()) { lp->aw.writeBlock(lp->block0.data(), lp->block0.size(), lp->bf.nSignature()); lp->block0InFile = true; } }
                 } catch (const std::exception& e) {
                     lp->t0err = e.what();
                     { std::lock_guard<std::mutex> lk(gateMx); ++block0Unpacked; }       // never leave the closer waiting
@@ -1257,7 +1276,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                     p.data.resize(bytes);
                     uint64_t off = 0;
                     for (size_t k = b; k < e; ++k) { memcpy(p.data.data() + off, blockData((uint32_t)k), blockSizes[k]); off += blockSizes[k]; }
-                    libs[l]->pending.push_back(std::move(p)); b = e;
+                    { std::lock_guard<std::mutex> lk(libs[l]->awMx); libs[l]->pending.push_back(std::move(p)); } b = e;
                 }
                 tio = nowMs();
                 for (auto& L : libs) flush(*L, false);

@@ -186,160 +186,198 @@ FS_DEV bool packed_rescale_quick(Packed& c, uint32_t ns, uint32_t& summ, uint32_
     return true;
 }
 
-// One window at position `pos` (the serial state is at the top of its loop with OrderFall == 0 and MinContext ==
-// MaxContext).  Returns the number of symbols coded, 0 if the first position is not a plain hit.  On return > 0 the model
-// memory, the coder, PrevSuccess, MaxContext and `hist` are exactly what the serial walk would have left.
+// ---- a window in three steps: fetch (per position, independent of where the window starts), solve (which positions form
+// the window, who owns which context, every position's price), commit (lists and records back, the prices to the coder).
+// One wave can do all three in a row (window_step below: the one- and two-wave forms), or a wave of its own can fetch and
+// solve AHEAD of the serial walk and commit once the walk has caught up (ppmd_scout.h: the three-wave form).
 //
-// Positions that share a context are taken by the lane of the FIRST of them (the owner): it keeps the context's states in
-// its registers and walks its positions in stream order, one per round, so the rounds of a window are as many as the
-// most popular context has positions; every position's result goes to its slot in LDS.
-FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uint32_t MinContext, uint32_t& hist)
+// Window = the lanes [s, E): lane i holds position base + i.  Positions that share a context are taken by the lane of the
+// FIRST of them (the owner): it keeps the context's states in its registers and walks its positions in stream order, one
+// per round, so the rounds of a window are as many as the most popular context has positions.
+// (-DFS_SCOUT_PROFILE builds use the phase slots for the window wave's own timeline: ppmd_scout.h)
+#if defined(FS_SCOUT_PROFILE)
+  #define FS_PROF_ACC_W(w, t0) ((void)(t0))
+#else
+  #define FS_PROF_ACC_W(w, t0) FS_PROF_ACC(w, t0)
+#endif
+struct WinFetch {                  // per lane, as fetched
+    uint32_t key, sym, addr, r0, stats, ns; bool ok;
+    Packed c; uint32_t sc[8];       // the state list as fetched: symbols, frequencies, successors
+    uint32_t k, succ; bool plain;   // place of the position's symbol in the list, its successor; a plain hit if the context is the right one
+    bool link;                      // this lane's context is the successor the lane before found (lane 0: by definition)
+    uint32_t W;                     // positions left in the stream from `base` on, at most 64
+};
+struct WinSolved {                 // per lane, after the rounds
+    uint32_t ownerLane; bool owner;
+    Packed c; uint32_t summ, flags; // an owner's context after all its positions
+    uint32_t tA, tM;                // the position's price: cumulative frequency | frequency << 16 | PrevSuccess << 23 ; the total
+};
+
+// lane0ctx != 0: the context of position `base` is known (the serial walk is there); otherwise every lane asks the hint table
+FS_DEV void win_fetch(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, uint32_t lane0ctx, WinFetch& f)
 {
     const uint32_t lane = (uint32_t)FS_LANE();
-    uint64_t tp = FS_PROF_NOW(); const uint64_t tEnter = tp;
-    const uint32_t W = n - pos < (uint32_t)FS_WAVE ? n - pos : (uint32_t)FS_WAVE;
-    const uint32_t q = pos + (lane < W ? lane : W - 1u);
+    f.W = n - base < (uint32_t)FS_WAVE ? n - base : (uint32_t)FS_WAVE;
+    const uint32_t q = base + (lane < f.W ? lane : f.W - 1u);
     // the four bytes in front of the position and the position's own byte, from two aligned words
     const uint32_t a0 = (q - 4u) & ~3u, sh8 = 8u * ((q - 4u) & 3u);
     const uint32_t d0 = *(fs_cgptr32)(in + a0), d1 = *(fs_cgptr32)(in + a0 + 4u);
-    const uint32_t key = sh8 ? ((d0 >> sh8) | (d1 << (32u - sh8))) : d0;
-    const uint32_t sym = (d1 >> sh8) & 0xFFu;
+    f.key = sh8 ? ((d0 >> sh8) | (d1 << (32u - sh8))) : d0;
+    f.sym = (d1 >> sh8) & 0xFFu;
     uint32_t addr;
     {
-        fs_cgptr32 e = (fs_cgptr32)(m.hb + 1u + HINT_OFF + 8u * hint_slot(key));
+        fs_cgptr32 e = (fs_cgptr32)(m.hb + 1u + HINT_OFF + 8u * hint_slot(f.key));
         const uint32_t k0 = e[0], c0 = e[1];
-        addr = k0 == key ? c0 : 0u;
+        addr = k0 == f.key ? c0 : 0u;
     }
-    if (lane == 0u) addr = MinContext;
+    if (lane == 0u && lane0ctx != 0u) addr = lane0ctx;
+    f.addr = addr;
     const uint32_t unitsStart = m.UnitsStart;
-    bool ok = lane < W && addr >= unitsStart && addr <= SA_SIZE - 11u && ((addr - 1u) & 3u) == 0u;
-    const uint32_t la = ok ? addr : MinContext;                   // lanes without a usable hint fetch somewhere harmless
+    bool ok = lane < f.W && addr >= unitsStart && addr <= SA_SIZE - 11u && ((addr - 1u) & 3u) == 0u;
+    const uint32_t safe = lane0ctx != 0u ? lane0ctx : unitsStart;     // lanes without a usable hint fetch somewhere harmless
+    const uint32_t la = ok ? addr : safe;
     uint32_t r0, r1;
     { fs_cgptr32 p = (fs_cgptr32)HP(la); r0 = p[0]; r1 = p[1]; }
     const uint32_t ns = r0 & 0xFFu, stats = r1;
     ok = ok && ns >= 1u && ns <= WIN_MAX_NS && stats >= unitsStart && stats <= SA_SIZE - 47u && ((stats - 1u) & 3u) == 0u;
     const uint32_t ls = ok ? stats : la;
-    FS_STAT_ADD(m.sh->winStats[0], 1u);
-
-    uint32_t L = W;
-    FS_PROF_ACC(m.sh->winStats[8], tp);                                // input bytes, hint, record
-    for (;;) {
-        Packed c; uint32_t sc[8];
-        {   // eight states = 48 bytes = twelve words; state j lives at byte 6 j
-            fs_cgptr32 p = (fs_cgptr32)HP(ls);
-            uint32_t w[12];
-            #pragma unroll
-            for (int i = 0; i < 12; ++i) w[i] = p[i];
-            c.S = 0; c.F = 0; c.P = 0x76543210u;
-            #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint32_t x = w[3 * t], y = w[3 * t + 1], z = w[3 * t + 2];
-                c.S |= (uint64_t)((x & 0xFFu) | ((y >> 8) & 0xFF00u)) << (16 * t);
-                c.F |= (uint64_t)(((x >> 8) & 0xFFu) | ((y >> 16) & 0xFF00u)) << (16 * t);
-                sc[2 * t] = (x >> 16) | (y << 16); sc[2 * t + 1] = z;
-            }
-        }
-        uint32_t summ = r0 >> 16, flags = (r0 >> 8) & 0xFFu;
-        const uint32_t k = packed_find(c, ns, sym);
-        uint32_t succ = 0;
+    f.r0 = r0; f.ns = ns; f.stats = stats; f.ok = ok;
+    {   // eight states = 48 bytes = twelve words; state j lives at byte 6 j
+        fs_cgptr32 p = (fs_cgptr32)HP(ls);
+        uint32_t w[12];
         #pragma unroll
-        for (int j = 0; j < 8; ++j) if ((uint32_t)j == k) succ = sc[j];
-        // plain hit, given that the context is the right one; the chain proves the contexts
-        const bool plain = ok && k < 8u && succ >= unitsStart;
-        const uint32_t prevSucc = fs_bperm(succ, (lane + 63u) & 63u);
-        const bool link = lane == 0u || addr == prevSucc;
-        const uint64_t good = fs_ballot(plain && link && lane < L);
-        const uint32_t lead = ~good ? fs_ctz64(~good) : 64u;
-        L = lead < L ? lead : L;
-        FS_PROF_ACC(m.sh->winStats[9], tp);                            // state lists, find, chain
-        if (L == 0u) { uint64_t te = tEnter; FS_PROF_ACC(m.sh->winStats[14], te); return 0u; }
+        for (int i = 0; i < 12; ++i) w[i] = p[i];
+        f.c.S = 0; f.c.F = 0; f.c.P = 0x76543210u;
+        #pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t x = w[3 * t], y = w[3 * t + 1], z = w[3 * t + 2];
+            f.c.S |= (uint64_t)((x & 0xFFu) | ((y >> 8) & 0xFF00u)) << (16 * t);
+            f.c.F |= (uint64_t)(((x >> 8) & 0xFFu) | ((y >> 16) & 0xFF00u)) << (16 * t);
+            f.sc[2 * t] = (x >> 16) | (y << 16); f.sc[2 * t + 1] = z;
+        }
+    }
+    f.k = packed_find(f.c, ns, f.sym);
+    uint32_t succ = 0;
+    #pragma unroll
+    for (int j = 0; j < 8; ++j) if ((uint32_t)j == f.k) succ = f.sc[j];
+    f.succ = succ;
+    // plain hit, given that the context is the right one; the chain proves the contexts
+    f.plain = ok && f.k < 8u && succ >= unitsStart;
+    const uint32_t prevSucc = fs_bperm(succ, (lane + 63u) & 63u);
+    f.link = lane == 0u || addr == prevSucc;
+}
 
-        // The owner of a context = the first window position that has it.  A 512-slot table in LDS names, per hash
-        // slot, the lowest lane that wrote to it; a lane whose slot was won by a lane with ANOTHER context (a collision)
-        // is resolved by the loop below, one step per distinct context among the colliding lanes -- rare.  Then every
-        // position sets its bit in its owner's mask.
-        bool inWin = lane < L;
-        uint32_t ownerLane = lane;
-        {
-            #pragma unroll
-            for (uint32_t i = 0; i < 8u; ++i) m.sh->winTab[64u * i + lane] = 0u;
-            m.sh->winMask[2u * lane] = 0u; m.sh->winMask[2u * lane + 1u] = 0u;
-            if (lane == 0u) m.sh->winCut = 64u;
-            FS_WAVE_SYNC();
-            const uint32_t h = (addr * 0x9E3779B1u) >> 23;
-            if (inWin) FS_LDS_MAX(m.sh->winTab[h], 64u - lane);
-            FS_WAVE_SYNC();
-            const uint32_t w = (64u - m.sh->winTab[h]) & 63u;
-            const uint32_t aw = fs_bperm(addr, w);
-            if (inWin && aw == addr) ownerLane = w;
-            for (uint64_t todo = fs_ballot(inWin && aw != addr); todo != 0ull;) {
-                const uint32_t j = fs_ctz64(todo), a = fs_readlane(addr, j);
-                const bool mine = inWin && aw != addr && addr == a;
-                if (mine) ownerLane = j;
-                todo &= ~fs_ballot(mine);
-            }
-            if (inWin) FS_LDS_OR(m.sh->winMask[2u * ownerLane + (lane >> 5)], 1u << (lane & 31u));
-            FS_WAVE_SYNC();
+// The window [s, E) of a fetch: E = the first lane from s on that is not a plain hit linked to the lane before it (lane s
+// itself needs no link: its context is known, or is checked by the caller), further shortened where a round finds a
+// position for the serial path (a rescale that drops a state).  Returns E; E <= s: no window.
+// watchSeq != 0 (three-wave form, start lane guessed): should the serial wave's forecast or request number watchSeq turn up
+// meanwhile and name another start lane, the solve is given up (WIN_ABORT) before its expensive part -- the caller solves again.
+enum : uint32_t { WIN_ABORT = 0xFFFFFFFFu };
+FS_DEV uint32_t win_watch(Coder& m, uint32_t watchSeq, uint32_t at);
+FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, const WinFetch& f, uint32_t s, WinSolved& o, uint64_t& tp, uint32_t watchSeq = 0u)
+{
+    const uint32_t lane = (uint32_t)FS_LANE();
+    const uint32_t ns = f.ns, sym = f.sym, addr = f.addr, k = f.k;
+    uint32_t E;
+    {
+        const uint64_t from = s >= 64u ? 0ull : ~0ull << s;
+        const uint64_t good = fs_ballot(f.plain && (f.link || lane == s) && lane < f.W);
+        const uint64_t bad = ~good & from;
+        E = bad ? fs_ctz64(bad) : 64u;
+        if (s >= 64u) E = s;
+    }
+    o.ownerLane = lane; o.owner = false; o.c = f.c; o.summ = f.r0 >> 16; o.flags = (f.r0 >> 8) & 0xFFu; o.tA = 0; o.tM = 0;
+    FS_PROF_ACC_W(m.sh->winStats[9], tp);                            // state lists, find, chain
+    if (E <= s) return E;
+
+    // The owner of a context = the first window position that has it.  A 512-slot table in LDS names, per hash
+    // slot, the lowest lane that wrote to it; a lane whose slot was won by a lane with ANOTHER context (a collision)
+    // is resolved by the loop below, one step per distinct context among the colliding lanes -- rare.  Then every
+    // position sets its bit in its owner's mask.
+    bool inWin = lane >= s && lane < E;
+    uint32_t ownerLane = lane;
+    {
+        #pragma unroll
+        for (uint32_t i = 0; i < 8u; ++i) m.sh->winTab[64u * i + lane] = 0u;
+        m.sh->winMask[2u * lane] = 0u; m.sh->winMask[2u * lane + 1u] = 0u;
+        if (lane == 0u) m.sh->winCut = 64u;
+        FS_WAVE_SYNC();
+        const uint32_t h = (addr * 0x9E3779B1u) >> 23;
+        if (inWin) FS_LDS_MAX(m.sh->winTab[h], 64u - lane);
+        FS_WAVE_SYNC();
+        const uint32_t w = (64u - m.sh->winTab[h]) & 63u;
+        const uint32_t aw = fs_bperm(addr, w);
+        if (inWin && aw == addr) ownerLane = w;
+        for (uint64_t todo = fs_ballot(inWin && aw != addr); todo != 0ull;) {
+            const uint32_t j = fs_ctz64(todo), a = fs_readlane(addr, j);
+            const bool mine = inWin && aw != addr && addr == a;
+            if (mine) ownerLane = j;
+            todo &= ~fs_ballot(mine);
         }
-        bool owner = inWin && ownerLane == lane;
-        uint32_t rlo = 0u, rhi = 0u;                                   // an owner's positions still to do
-        FS_PROF_ACC(m.sh->winStats[10], tp);                           // context sets
-        // Input read-ahead.  The stream is read once, so every new cache line of it is a trip to HBM (~900 clocks against
-        // ~200 for an L2 hit) -- paid by the first loads of a window and by the serial path's byte fetches.  A kilobyte
-        // ahead of the window, sixteen lines at a time, is requested HERE: the rounds that follow use no global memory,
-        // so the trip is over before the next load of this wave has to wait for it (loads complete in issue order).
-        uint32_t ahead = 0;
-        const bool pull = FS_UNI((uint32_t)(pos + 1024u >= m.inAhead));
-        if (pull) {
-            const uint32_t want = pos + 1024u + 16u * lane, last = (n - 4u) & ~3u;
-            ahead = *(fs_cgptr32)(in + (want < last ? want & ~3u : last));
-            m.inAhead = pos + 2048u;
-        }
-        uint32_t rounds = 0;
-        // Closed form.  While a context neither swaps two states nor crosses MAX_FREQ, its states stay where they were
-        // fetched and every hit just adds 4 to one frequency and to the total -- so a position can price ITSELF from the
-        // list it fetched and three counts over the earlier positions of its context (all of them / those on its own
-        // state / those on states in front of it), taken from bit masks: the context's positions (its owner's mask) and
-        // the bit-sliced places of all 64 positions.  The first position of a context whose step would swap or rescale,
-        // and everything of that context behind it, is left to the rounds below; the owner accounts for what went
-        // before (frequencies and total) and keeps the rest of its mask.
-        uint32_t cfA = 0, cfM = 0; bool cfDone = false;
-        uint64_t cfSm = 0, cfKb0 = 0, cfKb1 = 0, cfKb2 = 0; uint32_t cfFirstBad = 64u;
-        {
-            const uint32_t smLo = m.sh->winMask[2u * ownerLane], smHi = m.sh->winMask[2u * ownerLane + 1u];
-            const uint64_t sm = inWin ? ((uint64_t)smHi << 32) | smLo : 0ull;
-            const uint64_t kb0 = fs_ballot(inWin && (k & 1u) != 0u), kb1 = fs_ballot(inWin && (k & 2u) != 0u), kb2 = fs_ballot(inWin && (k & 4u) != 0u);
-            const uint64_t earlier = sm & ((1ull << lane) - 1ull);
-            const uint32_t kq = k & 7u, kp = (kq - 1u) & 7u;
-            const uint64_t e0 = (kq & 1u) ? kb0 : ~kb0, e1 = (kq & 2u) ? kb1 : ~kb1, e2 = (kq & 4u) ? kb2 : ~kb2;
-            const uint64_t eqK = e0 & e1 & e2;
-            const uint64_t eqP = ((kp & 1u) ? kb0 : ~kb0) & ((kp & 2u) ? kb1 : ~kb1) & ((kp & 4u) ? kb2 : ~kb2);
-            const uint64_t ltK = ((kq & 4u) ? ~kb2 : 0ull) | (e2 & (((kq & 2u) ? ~kb1 : 0ull) | (e1 & ((kq & 1u) ? ~kb0 : 0ull))));
-            const uint32_t cAll = fs_popc64(earlier), cSame = fs_popc64(earlier & eqK), cPrev = fs_popc64(earlier & eqP), cBelow = fs_popc64(earlier & ltK);
-            const uint32_t k8 = 8u * kq;
-            const uint32_t f = ((uint32_t)(c.F >> k8) & 0xFFu) + 4u * cSame;
-            const uint32_t fPrev = kq ? ((uint32_t)(c.F >> ((k8 - 8u) & 63u)) & 0xFFu) + 4u * cPrev : 0xFFFFu;
-            const bool bad = inWin && (f + 4u > fPrev || f + 4u > (uint32_t)MAX_FREQ);
-            const uint64_t badSet = fs_ballot(bad) & sm;               // of my context
-            const uint32_t firstBad = badSet ? fs_ctz64(badSet) : 64u;
-            cfDone = inWin && lane < firstBad;
-            const uint64_t below = c.F & ((1ull << k8) - 1ull);
-            const uint32_t tot = summ + 4u * cAll;
-            cfA = (fs_sum_bytes((uint32_t)below) + fs_sum_bytes((uint32_t)(below >> 32)) + 4u * cBelow) | (f << 16) | ((kq == 0u && 2u * f > tot) ? (1u << 23) : 0u);
-            cfM = tot;
-            cfSm = sm; cfFirstBad = firstBad; cfKb0 = kb0; cfKb1 = kb1; cfKb2 = kb2;
-        }
-        if (fs_ballot(inWin && !cfDone) == 0ull) FS_STAT_ADD(m.sh->winStats[5], 1u);     // a window without a single round
-        // The owners' part, and the rounds.  When a round finds that a position must go to the serial path (a rescale that
-        // drops a state), the window ends in front of it -- and only THIS part is done again for the shorter window: the
-        // lists, the chain, the context sets and the closed-form prices of the positions that stay do not depend on
-        // the positions that go.
-        const Packed c0 = c; const uint32_t summ0 = summ, flags0 = flags;
-        for (;;) {
-        inWin = lane < L; owner = inWin && ownerLane == lane;
-        c = c0; summ = summ0; flags = flags0; rlo = rhi = 0u; rounds = 0;
+        if (inWin) FS_LDS_OR(m.sh->winMask[2u * ownerLane + (lane >> 5)], 1u << (lane & 31u));
+        FS_WAVE_SYNC();
+    }
+    bool owner = inWin && ownerLane == lane;
+    uint32_t rlo = 0u, rhi = 0u;                                   // an owner's positions still to do
+    FS_PROF_ACC_W(m.sh->winStats[10], tp);                           // context sets
+    // Input read-ahead.  The stream is read once, so every new cache line of it is a trip to HBM (~900 clocks against
+    // ~200 for an L2 hit) -- paid by the first loads of a window and by the serial path's byte fetches.  A kilobyte
+    // ahead of the window, sixteen lines at a time, is requested HERE: the rounds that follow use no global memory,
+    // so the trip is over before the next load of this wave has to wait for it (loads complete in issue order).
+    uint32_t ahead = 0;
+    const bool pull = FS_UNI((uint32_t)(base + 1024u >= m.inAhead));
+    if (pull) {
+        const uint32_t want = base + 1024u + 16u * lane, last = (n - 4u) & ~3u;
+        ahead = *(fs_cgptr32)(in + (want < last ? want & ~3u : last));
+        m.inAhead = base + 2048u;
+    }
+    uint32_t rounds = 0;
+    // Closed form.  While a context neither swaps two states nor crosses MAX_FREQ, its states stay where they were
+    // fetched and every hit just adds 4 to one frequency and to the total -- so a position can price ITSELF from the
+    // list it fetched and three counts over the earlier positions of its context (all of them / those on its own
+    // state / those on states in front of it), taken from bit masks: the context's positions (its owner's mask) and
+    // the bit-sliced places of all 64 positions.  The first position of a context whose step would swap or rescale,
+    // and everything of that context behind it, is left to the rounds below; the owner accounts for what went
+    // before (frequencies and total) and keeps the rest of its mask.
+    uint32_t cfA = 0, cfM = 0; bool cfDone = false;
+    uint64_t cfSm = 0, cfKb0 = 0, cfKb1 = 0, cfKb2 = 0; uint32_t cfFirstBad = 64u;
+    const uint32_t summ0 = f.r0 >> 16, flags0 = (f.r0 >> 8) & 0xFFu;
+    {
+        const uint32_t smLo = m.sh->winMask[2u * ownerLane], smHi = m.sh->winMask[2u * ownerLane + 1u];
+        const uint64_t sm = inWin ? ((uint64_t)smHi << 32) | smLo : 0ull;
+        const uint64_t kb0 = fs_ballot(inWin && (k & 1u) != 0u), kb1 = fs_ballot(inWin && (k & 2u) != 0u), kb2 = fs_ballot(inWin && (k & 4u) != 0u);
+        const uint64_t earlier = sm & ((1ull << lane) - 1ull);
+        const uint32_t kq = k & 7u, kp = (kq - 1u) & 7u;
+        const uint64_t e0 = (kq & 1u) ? kb0 : ~kb0, e1 = (kq & 2u) ? kb1 : ~kb1, e2 = (kq & 4u) ? kb2 : ~kb2;
+        const uint64_t eqK = e0 & e1 & e2;
+        const uint64_t eqP = ((kp & 1u) ? kb0 : ~kb0) & ((kp & 2u) ? kb1 : ~kb1) & ((kp & 4u) ? kb2 : ~kb2);
+        const uint64_t ltK = ((kq & 4u) ? ~kb2 : 0ull) | (e2 & (((kq & 2u) ? ~kb1 : 0ull) | (e1 & ((kq & 1u) ? ~kb0 : 0ull))));
+        const uint32_t cAll = fs_popc64(earlier), cSame = fs_popc64(earlier & eqK), cPrev = fs_popc64(earlier & eqP), cBelow = fs_popc64(earlier & ltK);
+        const uint32_t k8 = 8u * kq;
+        const uint32_t fr = ((uint32_t)(f.c.F >> k8) & 0xFFu) + 4u * cSame;
+        const uint32_t fPrev = kq ? ((uint32_t)(f.c.F >> ((k8 - 8u) & 63u)) & 0xFFu) + 4u * cPrev : 0xFFFFu;
+        const bool bad = inWin && (fr + 4u > fPrev || fr + 4u > (uint32_t)MAX_FREQ);
+        const uint64_t badSet = fs_ballot(bad) & sm;               // of my context
+        const uint32_t firstBad = badSet ? fs_ctz64(badSet) : 64u;
+        cfDone = inWin && lane < firstBad;
+        const uint64_t below = f.c.F & ((1ull << k8) - 1ull);
+        const uint32_t tot = summ0 + 4u * cAll;
+        cfA = (fs_sum_bytes((uint32_t)below) + fs_sum_bytes((uint32_t)(below >> 32)) + 4u * cBelow) | (fr << 16) | ((kq == 0u && 2u * fr > tot) ? (1u << 23) : 0u);
+        cfM = tot;
+        cfSm = sm; cfFirstBad = firstBad; cfKb0 = kb0; cfKb1 = kb1; cfKb2 = kb2;
+    }
+    if (fs_ballot(inWin && !cfDone) == 0ull) FS_STAT_ADD(m.sh->winStats[5], 1u);     // a window without a single round
+    if (watchSeq != 0u && win_watch(m, watchSeq, base + s) != 0u) return WIN_ABORT;
+    // The owners' part, and the rounds.  When a round finds that a position must go to the serial path (a rescale that
+    // drops a state), the window ends in front of it -- and only THIS part is done again for the shorter window: the
+    // lists, the chain, the context sets and the closed-form prices of the positions that stay do not depend on
+    // the positions that go.
+    Packed c; uint32_t summ, flags;
+    for (;;) {
+        inWin = lane >= s && lane < E; owner = inWin && ownerLane == lane;
+        c = f.c; summ = summ0; flags = flags0; rlo = rhi = 0u; rounds = 0;
         {   // the owner: what its context's finished positions added, and what is left for the rounds
-            const uint64_t lim = L >= 64u ? ~0ull : (1ull << L) - 1ull;
+            const uint64_t lim = (E >= 64u ? ~0ull : (1ull << E) - 1ull) & (~0ull << s);
             const uint64_t doneSet = (cfFirstBad < 64u ? cfSm & ((1ull << cfFirstBad) - 1ull) : cfSm) & lim;
             if (owner) {
                 uint64_t add = 0;
@@ -371,15 +409,15 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
             const bool lost = act && kk >= 8u;                        // cannot happen while nothing drops out; never trust it
             const bool go = act && !lost;
             const uint32_t k8 = 8u * (kk & 7u);
-            const uint32_t f = (uint32_t)(c.F >> k8) & 0xFFu, fPrev = (kk & 7u) ? (uint32_t)(c.F >> ((k8 - 8u) & 63u)) & 0xFFu : 0u;
+            const uint32_t fr = (uint32_t)(c.F >> k8) & 0xFFu, fPrev = (kk & 7u) ? (uint32_t)(c.F >> ((k8 - 8u) & 63u)) & 0xFFu : 0u;
             const uint64_t below = c.F & ((1ull << k8) - 1ull);
             const uint32_t loCnt = fs_sum_bytes((uint32_t)below) + fs_sum_bytes((uint32_t)(below >> 32));
-            const uint32_t nf = f + 4u;
+            const uint32_t nf = fr + 4u;
             const bool doSwap = go && kk != 0u && nf > fPrev;
             const bool resc = go && nf > (uint32_t)MAX_FREQ && (kk == 0u || doSwap);
             // slot of position p: cumulative frequency | frequency << 16 | PrevSuccess << 23 ; the total
             const uint32_t at = go ? p : 64u + lane;
-            m.sh->winA[at] = loCnt | (f << 16) | ((kk == 0u && 2u * f > summ) ? (1u << 23) : 0u);
+            m.sh->winA[at] = loCnt | (fr << 16) | ((kk == 0u && 2u * fr > summ) ? (1u << 23) : 0u);
             m.sh->winM[at] = summ;
             c.F += go ? 4ull << k8 : 0ull;
             summ += go ? 4u : 0u;
@@ -423,52 +461,76 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
         FS_KEEP(ahead);
         FS_WAVE_SYNC();
         FS_STAT_ADD(m.sh->winStats[3], rounds);
-        FS_PROF_ACC(m.sh->winStats[11], tp);                           // rounds
+        FS_PROF_ACC_W(m.sh->winStats[11], tp);                           // rounds
         const uint32_t cutAt = FS_LDS_RD(m.sh->winCut);
-        if (cutAt < L) {                                              // nothing has been stored yet: shorten the window and do the owners' part again
+        if (cutAt < E) {                                              // nothing has been stored yet: shorten the window and do the owners' part again
             FS_STAT_ADD(m.sh->winStats[4], 1u);
-            L = cutAt;                                                // every redo is strictly shorter
-            if (L == 0u) { uint64_t te = tEnter; FS_PROF_ACC(m.sh->winStats[14], te); return 0u; }
+            E = cutAt;                                                // every redo is strictly shorter
+            if (E <= s) return E;
             continue;
         }
         break;
-        }
+    }
+    inWin = lane >= s && lane < E;
+    // every position's price: its own (closed form), or what its owner left in its slot
+    o.tA = inWin ? (cfDone ? cfA : m.sh->winA[lane]) : 0u; o.tM = inWin ? (cfDone ? cfM : m.sh->winM[lane]) : 0u;
+    o.ownerLane = ownerLane; o.owner = owner; o.c = c; o.summ = summ; o.flags = flags;
+    FS_WAVE_SYNC();
+    return E;
+}
 
-        // commit: every owner writes its context's list and record word back.  The successors go through the lane's
-        // eight words of LDS (the hash table's space, free again) to be picked up in their final order.
+// commit: every owner writes its context's list and record word back.  The successors go through the lane's eight words of
+// LDS (the hash table's space, free again) to be picked up in their final order.
+FS_DEV void win_write_back(Coder& m, const WinFetch& f, const WinSolved& o)
+{
+    const uint32_t lane = (uint32_t)FS_LANE();
+    #pragma unroll
+    for (int j = 0; j < 8; ++j) m.sh->winTab[8u * lane + (uint32_t)j] = f.sc[j];
+    FS_WAVE_SYNC();
+    if (o.owner) {
+        fs_gptr32 p = (fs_gptr32)HP(f.stats);
+        const uint32_t nst = f.ns + 1u;
+        uint32_t w[12], sf[8], so[8];
         #pragma unroll
-        for (int j = 0; j < 8; ++j) m.sh->winTab[8u * lane + (uint32_t)j] = sc[j];
-        FS_WAVE_SYNC();
-        if (owner) {
-            fs_gptr32 p = (fs_gptr32)HP(stats);
-            const uint32_t nst = ns + 1u, full = (3u * nst) >> 1;
-            uint32_t w[12], sf[8], so[8];
-            #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                sf[j] = ((uint32_t)(c.S >> (8 * j)) & 0xFFu) | (((uint32_t)(c.F >> (8 * j)) & 0xFFu) << 8);
-                so[j] = m.sh->winTab[8u * lane + ((c.P >> (4 * j)) & 7u)];
-            }
-            #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                w[3 * t] = sf[2 * t] | (so[2 * t] << 16);
-                w[3 * t + 1] = (so[2 * t] >> 16) | (sf[2 * t + 1] << 16);
-                w[3 * t + 2] = so[2 * t + 1];
-            }
-            // whole units (two states, three words) go back: the spare half of an odd list's last unit is never read
-            (void)full;
-            const uint32_t units = (nst + 1u) >> 1;
-            #pragma unroll
-            for (int u = 0; u < 4; ++u) if ((uint32_t)u < units) { p[3 * u] = w[3 * u]; p[3 * u + 1] = w[3 * u + 1]; p[3 * u + 2] = w[3 * u + 2]; }
-            *(fs_gptr32)HP(addr) = ns | (flags << 8) | (summ << 16);
+        for (int j = 0; j < 8; ++j) {
+            sf[j] = ((uint32_t)(o.c.S >> (8 * j)) & 0xFFu) | (((uint32_t)(o.c.F >> (8 * j)) & 0xFFu) << 8);
+            so[j] = m.sh->winTab[8u * lane + ((o.c.P >> (4 * j)) & 7u)];
         }
-        uint32_t tA = inWin ? (cfDone ? cfA : m.sh->winA[lane]) : 0u, tM = inWin ? (cfDone ? cfM : m.sh->winM[lane]) : 0u;
-        FS_WAVE_SYNC();
-        if (m.queued) {                                            // two-wave form: the slots go to the coder wave as they are
-            cq_push_lanes(m, tA, tM, L);
-            FS_PROF_ACC(m.sh->winStats[12], tp);
-        } else {
+        #pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            w[3 * t] = sf[2 * t] | (so[2 * t] << 16);
+            w[3 * t + 1] = (so[2 * t] >> 16) | (sf[2 * t + 1] << 16);
+            w[3 * t + 2] = so[2 * t + 1];
+        }
+        // whole units (two states, three words) go back: the spare half of an odd list's last unit is never read
+        const uint32_t units = (nst + 1u) >> 1;
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) if ((uint32_t)u < units) { p[3 * u] = w[3 * u]; p[3 * u + 1] = w[3 * u + 1]; p[3 * u + 2] = w[3 * u + 2]; }
+        *(fs_gptr32)HP(f.addr) = f.ns | (o.flags << 8) | (o.summ << 16);
+    }
+    FS_WAVE_SYNC();
+}
+
+// One window at position `pos` (the serial state is at the top of its loop with OrderFall == 0 and MinContext ==
+// MaxContext).  Returns the number of symbols coded, 0 if the first position is not a plain hit.  On return > 0 the model
+// memory, the coder, PrevSuccess, MaxContext and `hist` are exactly what the serial walk would have left.
+FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uint32_t MinContext, uint32_t& hist)
+{
+    uint64_t tp = FS_PROF_NOW(); const uint64_t tEnter = tp;
+    WinFetch f; WinSolved o;
+    win_fetch(m, in, n, pos, MinContext, f);
+    FS_STAT_ADD(m.sh->winStats[0], 1u);
+    FS_PROF_ACC(m.sh->winStats[8], tp);                                // input bytes, hint, record (and the list, now)
+    const uint32_t L = win_solve(m, in, n, pos, f, 0u, o, tp);
+    if (L == 0u) { uint64_t te = tEnter; FS_PROF_ACC(m.sh->winStats[14], te); return 0u; }
+    win_write_back(m, f, o);
+    uint32_t tA = o.tA, tM = o.tM;
+    if (m.queued) {                                            // two-wave form: the slots go to the coder wave as they are
+        cq_push_lanes(m, tA, tM, L);
+        FS_PROF_ACC(m.sh->winStats[12], tp);
+    } else {
         // every position: its slot, and the reciprocal of its total (all lanes at once)
-        if (inWin) {
+        if ((uint32_t)FS_LANE() < L) {
             const Recip rc = recip_make(tM);
             tA |= (rc.l - 1u) << 24; tM = rc.mul;
         }
@@ -490,16 +552,15 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
         }
         for (; i_ < L; ++i_) { const uint32_t A0 = FS_UNI(fs_readlane(tA, i_)), M0 = FS_UNI(fs_readlane(tM, i_)); FS_CODE_ONE(A0, M0); }
         #undef FS_CODE_ONE
-        }
-        m.PrevSuccess = (FS_UNI(fs_readlane(tA, L - 1u)) >> 23) & 1u;
-        m.MaxContext = FS_UNI(fs_readlane(succ, L - 1u));
-        const uint32_t kl = FS_UNI(fs_readlane(key, L - 1u)), sl = FS_UNI(fs_readlane(sym, L - 1u));
-        hist = (kl >> 8) | (sl << 24);
-        FS_STAT_ADD(m.sh->winStats[1], 1u);
-        FS_STAT_ADD(m.sh->winStats[2], L);
-        FS_PROF_ACC(m.sh->winStats[13], tp);                           // range coder
-        { uint64_t te = tEnter; FS_PROF_ACC(m.sh->winStats[14], te); }
-        return L;
     }
+    m.PrevSuccess = (FS_UNI(fs_readlane(tA, L - 1u)) >> 23) & 1u;
+    m.MaxContext = FS_UNI(fs_readlane(f.succ, L - 1u));
+    const uint32_t kl = FS_UNI(fs_readlane(f.key, L - 1u)), sl = FS_UNI(fs_readlane(f.sym, L - 1u));
+    hist = (kl >> 8) | (sl << 24);
+    FS_STAT_ADD(m.sh->winStats[1], 1u);
+    FS_STAT_ADD(m.sh->winStats[2], L);
+    FS_PROF_ACC(m.sh->winStats[13], tp);                           // range coder
+    { uint64_t te = tEnter; FS_PROF_ACC(m.sh->winStats[14], te); }
+    return L;
 }
 #undef FS_CE

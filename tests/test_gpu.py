@@ -63,6 +63,34 @@ def test_ppmd_device_matches_oracle_many_ragged_streams(packer, oracle):
         assert g == oracle_ppmd(oracle, s)
 
 
+@pytest.mark.parametrize("waves", [1, 2, 3])
+def test_ppmd_device_every_kernel_form_matches_the_oracle(packer, oracle, monkeypatch, waves):
+    # the same streams through the one-wave form, the two-wave form (model + coder wave) and the three-wave form (serial wave,
+    # coder wave, window wave: windows prepared ahead of the serial walk, ppmd_scout.h): long quality streams with read
+    # boundaries (episodes between windows), noise (no windows at all, model restarts), short and ragged streams that
+    # follow each other through one workgroup (the hand-over between streams), an empty one
+    monkeypatch.setenv("FS_WAVES", str(waves))
+    rng = np.random.default_rng(300 + waves)
+
+    def quality(n, read_len):
+        steps = np.array([-3, -1, 0, 0, 0, 0, 1, 1])[rng.integers(0, 8, n)].reshape(-1, read_len)
+        q = np.empty_like(steps); cur = np.full(steps.shape[0], 38)
+        for i in range(read_len):
+            cur = np.clip(cur + steps[:, i], 2, 40); q[:, i] = cur
+        return q.astype(np.uint8).tobytes()
+
+    streams = [quality(1_500_000, 150), b"", quality(600_000, 100), rng.integers(0, 41, 1_600_000, dtype=np.uint8).tobytes(), b"Q", quality(999 * 37, 37)]
+    for i in range(120):
+        n = int(rng.integers(1, 9000))
+        streams.append(quality(150 * (n // 150 + 1), 150)[:n] if i % 3 else rng.integers(0, 9, n).astype(np.uint8).tobytes())
+    got = packer.ppmd_encode(streams)
+    for i, (s, g) in enumerate(zip(streams, got)):
+        assert g == (oracle_ppmd(oracle, s) if s else b""), (waves, i, len(s))
+    if waves == 3:
+        st = packer.stats()
+        assert st["ppmd_windows_ahead"] > 10_000, st          # windows really were prepared ahead and used
+
+
 def test_ppmd_device_model_restart_and_allocator_exhaustion(packer, oracle):
     # > 2 MiB of 41-symbol noise: the text area overruns and the model restarts; 3 MiB of bytes noise
     # additionally drives the sub-allocator through GlueFreeBlocks / AllocUnitsRare
