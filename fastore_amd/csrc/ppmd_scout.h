@@ -210,7 +210,7 @@ FS_DEV void window_wave(FS_LDS Shared* sh)
         FS_EMU_JITTER(1);
         FS_SCOUT_PROF(sh->winStats[8], tq);
         uint64_t tp = FS_PROF_NOW();
-        WinFetch f; WinSolved o;
+        WinFetch<8> f; WinSolved<8> o;
         win_fetch(m, in, n, base, fresh ? rCtx : 0u, f);
         FS_STAT_ADD(sh->winStats[0], 1u);
         FS_PROF_ACC_W(sh->winStats[8], tp);
@@ -243,7 +243,7 @@ FS_DEV void window_wave(FS_LDS Shared* sh)
         uint32_t E;
         bool valid = true;
         for (uint32_t pass = 0;; ++pass) {
-            E = win_solve(m, in, n, base, f, s, o, tp, (!fresh && guessed && !haveReq) ? seen + 1u : 0u);
+            E = win_solve<8>(m, in, n, base, f, s, o, tp, (!fresh && guessed && !haveReq) ? seen + 1u : 0u);
             FS_SCOUT_PROF(sh->winStats[10], tq);
             if (fresh) break;
             if (E == (uint32_t)WIN_ABORT) {
@@ -309,7 +309,7 @@ FS_DEV void window_wave(FS_LDS Shared* sh)
             // wrDrained: scout_touch).
             late = fs_ballot(lane >= s && lane < E && f.addr == mc) == 0ull;
             if (!late) {
-                win_write_back(m, f, o);
+                win_write_back<8>(m, f, o);
                 FS_DRAIN_STORES();                               // the lists are where the serial wave will read them
             }
             FS_PROF_ACC_W(sh->winStats[12], tp);
@@ -323,7 +323,7 @@ FS_DEV void window_wave(FS_LDS Shared* sh)
         if (usedAhead) { FS_STAT_ADD(sh->wxStats[0], 1u); usedAhead = false; }
         if (late) {
             FS_EMU_JITTER(3);
-            win_write_back(m, f, o);
+            win_write_back<8>(m, f, o);
             FS_DRAIN_STORES();
             FS_Q_STORE(sh->wrDrained, seen);
             FS_SCOUT_PROF(sh->winStats[13], tq);

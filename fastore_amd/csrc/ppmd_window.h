@@ -54,11 +54,16 @@ FS_DEV uint32_t fs_mulhi(uint32_t a, uint32_t b)
 }
 FS_DEV uint32_t recip_div(uint32_t n, uint32_t mul, uint32_t l) { const uint32_t t = fs_mulhi(n, mul); return (t + ((n - t) >> 1)) >> (l - 1u); }
 
-// ---- packed state list of one context in a lane: eight states as bytes, no register arrays indexed at run time ----
-// S = symbols, F = frequencies (state j in byte j of the 64-bit value), P = nibble j names the original slot whose
-// successor field belongs to the state now at place j (the 32-bit successors themselves never move: they are gathered
-// through P when the list is written back).
-struct Packed { uint64_t S, F; uint32_t P; };
+// ---- packed state list of one context in a lane: N states as bytes, no register arrays indexed at run time ----
+// S = symbols, F = frequencies (state j in byte j of the word), P = nibble j names the original slot whose successor field
+// belongs to the state now at place j (the 32-bit successors themselves never move: they are gathered through P when the
+// list is written back).  N = 8: 64-bit words (contexts of up to eight states).  N = 4: 32-bit words -- every context of the
+// window has at most four states (decided wave-wide when the records are in: the usual case on quality data, where a
+// context rarely has more successors than that): half the instructions of everything below, half the list fetch.
+template <int N> struct PackedT;
+template <> struct PackedT<8> { typedef uint64_t W; uint64_t S, F; uint32_t P; };
+template <> struct PackedT<4> { typedef uint32_t W; uint32_t S, F; uint32_t P; };
+typedef PackedT<8> Packed;
 
 FS_DEV uint32_t fs_sum_bytes(uint32_t x)
 {
@@ -68,31 +73,41 @@ FS_DEV uint32_t fs_sum_bytes(uint32_t x)
     return (x & 0xFFu) + ((x >> 8) & 0xFFu) + ((x >> 16) & 0xFFu) + (x >> 24);
 #endif
 }
+FS_DEV uint32_t fs_sum_bytes_w(uint64_t x) { return fs_sum_bytes((uint32_t)x) + fs_sum_bytes((uint32_t)(x >> 32)); }
+FS_DEV uint32_t fs_sum_bytes_w(uint32_t x) { return fs_sum_bytes(x); }
+FS_DEV uint32_t fs_ctz_w(uint64_t x) { return (uint32_t)__builtin_ctzll(x); }
+FS_DEV uint32_t fs_ctz_w(uint32_t x) { return (uint32_t)__builtin_ctz(x); }
+template <class W> FS_DEV W fs_rep8(uint32_t b) { return (W)(0x0101010101010101ull * b); }      // the byte in every byte of the word
+// the bytes of the states 0 .. ns
+template <int N> FS_DEV typename PackedT<N>::W fs_valid_bytes(uint32_t ns)
+{ typedef typename PackedT<N>::W W; return ns >= (uint32_t)N - 1u ? (W)~(W)0 : (W)(((W)1 << (8u * (ns + 1u))) - (W)1); }
 FS_DEV uint32_t fs_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 FS_DEV uint32_t fs_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 // place of `sym` among the states 0..ns (8 = absent)
-FS_DEV uint32_t packed_find(const Packed& c, uint32_t ns, uint32_t sym)
+template <int N> FS_DEV uint32_t packed_find(const PackedT<N>& c, uint32_t ns, uint32_t sym)
 {
-    const uint64_t x = c.S ^ (0x0101010101010101ull * sym);
+    typedef typename PackedT<N>::W W;
+    const W x = c.S ^ fs_rep8<W>(sym);
     // a byte of x is zero <=> that state has the symbol; the lowest flagged byte of the classic test is always exact
-    uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
-    z &= ns >= 7u ? ~0ull : ((1ull << (8u * (ns + 1u))) - 1ull);
-    return z ? (uint32_t)__builtin_ctzll(z) >> 3 : 8u;
+    W z = (W)(x - fs_rep8<W>(1u)) & (W)~x & fs_rep8<W>(0x80u);
+    z &= fs_valid_bytes<N>(ns);
+    return z ? fs_ctz_w(z) >> 3 : 8u;
 }
 
 // The reference's rescale for OrderFall == 0 (Model.cpp:246-280) on a packed list: found state (place kf) to the front,
 // frequencies halved, stable insertion sort by the halved frequencies -- a 19-step min/max network on one word per
 // state --, SummFreq rebuilt, the found state's bonus.  Returns false and changes nothing when a state would drop out
 // (frequency 1 -> 0): that path frees units (ShrinkUnits / FreeUnits) and stays with the serial code.
-// N = 4: every context that rescales has at most four states (the caller checks, wave-wide): a five-step network and half
-// the packing -- the usual case on quality data, where a context rarely has more successors than that
-template <int N> FS_DEV bool packed_rescale(Packed& c, uint32_t ns, uint32_t kf, uint32_t& summ, uint32_t& flags)
+// K = 4: every context that rescales has at most four states (the caller checks, wave-wide): a five-step network and half
+// the packing
+template <int K, int N> FS_DEV bool packed_rescale(PackedT<N>& c, uint32_t ns, uint32_t kf, uint32_t& summ, uint32_t& flags)
 {
-    uint32_t key[N];
+    typedef typename PackedT<N>::W W;
+    uint32_t key[K];
     uint32_t sumOld = 0, sumNew = 0, f0 = 0; bool zeros = false, hiAny = false;
     #pragma unroll
-    for (uint32_t j = 0; j < (uint32_t)N; ++j) {
+    for (uint32_t j = 0; j < (uint32_t)K; ++j) {
         const uint32_t f = (uint32_t)(c.F >> (8u * j)) & 0xFFu, sy = (uint32_t)(c.S >> (8u * j)) & 0xFFu, pj = (c.P >> (4u * j)) & 0xFu, nf = f >> 1;
         const bool valid = j <= ns, isF = j == kf;
         const uint32_t r = isF ? 0u : (j < kf ? j + 1u : j);                 // place after the move-to-front
@@ -105,14 +120,14 @@ template <int N> FS_DEV bool packed_rescale(Packed& c, uint32_t ns, uint32_t kf,
     }
     if (zeros) return false;
     #define FS_CE(a, b) do { const uint32_t hi_ = fs_umax(key[a], key[b]), lo_ = fs_umin(key[a], key[b]); key[a] = hi_; key[b] = lo_; } while (0)
-    if (N == 8) {
-        FS_CE(0, 1); FS_CE(2, 3); FS_CE(4 % N, 5 % N); FS_CE(6 % N, 7 % N);
-        FS_CE(0, 2); FS_CE(1, 3); FS_CE(4 % N, 6 % N); FS_CE(5 % N, 7 % N);
-        FS_CE(1, 2); FS_CE(5 % N, 6 % N); FS_CE(0, 4 % N); FS_CE(3, 7 % N);
-        FS_CE(1, 5 % N); FS_CE(2, 6 % N);
-        FS_CE(1, 4 % N); FS_CE(3, 6 % N);
-        FS_CE(2, 4 % N); FS_CE(3, 5 % N);
-        FS_CE(3, 4 % N);
+    if (K == 8) {
+        FS_CE(0, 1); FS_CE(2, 3); FS_CE(4 % K, 5 % K); FS_CE(6 % K, 7 % K);
+        FS_CE(0, 2); FS_CE(1, 3); FS_CE(4 % K, 6 % K); FS_CE(5 % K, 7 % K);
+        FS_CE(1, 2); FS_CE(5 % K, 6 % K); FS_CE(0, 4 % K); FS_CE(3, 7 % K);
+        FS_CE(1, 5 % K); FS_CE(2, 6 % K);
+        FS_CE(1, 4 % K); FS_CE(3, 6 % K);
+        FS_CE(2, 4 % K); FS_CE(3, 5 % K);
+        FS_CE(3, 4 % K);
     } else {
         FS_CE(0, 1); FS_CE(2, 3); FS_CE(0, 2); FS_CE(1, 3); FS_CE(1, 2);
     }
@@ -126,11 +141,11 @@ template <int N> FS_DEV bool packed_rescale(Packed& c, uint32_t ns, uint32_t kf,
         a = (f0 * s - sfm * nf0 + a - 1u) / a;
         a = a < 2u ? 2u : (a > (uint32_t)MAX_FREQ / 2u - 18u ? (uint32_t)MAX_FREQ / 2u - 18u : a);
     } else a = 2u;
-    uint64_t S = 0, F = 0; uint32_t P = 0;
+    W S = 0, F = 0; uint32_t P = 0;
     #pragma unroll
-    for (uint32_t j = 0; j < (uint32_t)N; ++j) {
-        S |= (uint64_t)((key[j] >> 4) & 0xFFu) << (8u * j);
-        F |= (uint64_t)(j == 0u ? nf0 + a : ((key[j] >> 12) & 0xFFu)) << (8u * j);
+    for (uint32_t j = 0; j < (uint32_t)K; ++j) {
+        S |= (W)((key[j] >> 4) & 0xFFu) << (8u * j);
+        F |= (W)(j == 0u ? nf0 + a : ((key[j] >> 12) & 0xFFu)) << (8u * j);
         P |= (key[j] & 0xFu) << (4u * j);
     }
     c.S = S; c.F = F; c.P = P;
@@ -143,28 +158,30 @@ template <int N> FS_DEV bool packed_rescale(Packed& c, uint32_t ns, uint32_t kf,
 // there), and halving keeps the order of the others unless two of them were out of order before (a single +4 may lift a
 // state over TWO predecessors, and only one swap is made).  ok(): found state at place 0, halved frequencies of the places
 // 1 .. ns not increasing -- then the network would leave every state where it is, and the rest is byte arithmetic on the
-// packed words.  Same results as packed_rescale<N> on that domain (checked against it on the lock-step emulation).
-FS_DEV bool packed_rescale_quick_ok(const Packed& c, uint32_t ns, uint32_t kf)
+// packed words.  Same results as packed_rescale on that domain (checked against it on the lock-step emulation).
+template <int N> FS_DEV bool packed_rescale_quick_ok(const PackedT<N>& c, uint32_t ns, uint32_t kf)
 {
-    const uint64_t vm = ns >= 7u ? ~0ull : ((1ull << (8u * (ns + 1u))) - 1ull);           // the bytes of the valid states
-    const uint64_t nf = (c.F >> 1) & 0x7F7F7F7F7F7F7F7Full & vm;
-    const uint64_t ge = ((nf | 0x8080808080808080ull) - (nf >> 8)) & 0x8080808080808080ull;   // byte j: nf[j] >= nf[j+1] (both below 128: no borrow crosses a byte)
-    const uint64_t need = (vm >> 8) & ~0xFFull & 0x8080808080808080ull;                   // places 1 .. ns-1
+    typedef typename PackedT<N>::W W;
+    const W vm = fs_valid_bytes<N>(ns);                                                    // the bytes of the valid states
+    const W nf = (W)(c.F >> 1) & fs_rep8<W>(0x7Fu) & vm;
+    const W ge = (W)((nf | fs_rep8<W>(0x80u)) - (W)(nf >> 8)) & fs_rep8<W>(0x80u);          // byte j: nf[j] >= nf[j+1] (both below 128: no borrow crosses a byte)
+    const W need = (W)(vm >> 8) & (W)~(W)0xFFu & fs_rep8<W>(0x80u);                         // places 1 .. ns-1
     return kf == 0u && (ge & need) == need;
 }
 
-FS_DEV bool packed_rescale_quick(Packed& c, uint32_t ns, uint32_t& summ, uint32_t& flags, bool live)
+template <int N> FS_DEV bool packed_rescale_quick(PackedT<N>& c, uint32_t ns, uint32_t& summ, uint32_t& flags, bool live)
 {
-    const uint64_t vm = ns >= 7u ? ~0ull : ((1ull << (8u * (ns + 1u))) - 1ull);
-    const uint64_t nf = (c.F >> 1) & 0x7F7F7F7F7F7F7F7Full & vm;
+    typedef typename PackedT<N>::W W;
+    const W vm = fs_valid_bytes<N>(ns);
+    const W nf = (W)(c.F >> 1) & fs_rep8<W>(0x7Fu) & vm;
     // a state other than the found one that would drop to zero: the serial path's business (no early return: every lane
     // takes part in the vote below)
-    const uint64_t zx = nf | 0xFFull | ~vm;
-    const bool zeros = ((zx - 0x0101010101010101ull) & ~zx & 0x8080808080808080ull) != 0ull;
-    const uint64_t fv = c.F & vm;
-    const uint32_t sumOld = fs_sum_bytes((uint32_t)fv) + fs_sum_bytes((uint32_t)(fv >> 32)), sumNew = fs_sum_bytes((uint32_t)nf) + fs_sum_bytes((uint32_t)(nf >> 32));
+    const W zx = nf | (W)0xFFu | (W)~vm;
+    const bool zeros = ((W)(zx - fs_rep8<W>(1u)) & (W)~zx & fs_rep8<W>(0x80u)) != (W)0;
+    const W fv = c.F & vm;
+    const uint32_t sumOld = fs_sum_bytes_w(fv), sumNew = fs_sum_bytes_w(nf);
     const uint32_t f0 = (uint32_t)c.F & 0xFFu, nf0 = f0 >> 1;
-    const bool hiAny = (c.S & vm & ~0xFFull & 0xC0C0C0C0C0C0C0C0ull) != 0ull;
+    const bool hiAny = (c.S & vm & (W)~(W)0xFFu & fs_rep8<W>(0xC0u)) != (W)0;
     const uint32_t escFreq = summ - sumOld;
     uint32_t s = sumNew + ((escFreq + 1u) >> 1), a = 2u;
     // (a context's FIRST rescale sets the found state's bonus by a division -- forty instructions the wave only walks
@@ -178,9 +195,9 @@ FS_DEV bool packed_rescale_quick(Packed& c, uint32_t ns, uint32_t& summ, uint32_
         if ((flags & 0x04u) == 0u) a = d;
     }
     if (zeros) return false;
-    c.F = (nf & ~0xFFull) | (uint64_t)(nf0 + a);
+    c.F = (W)(nf & (W)~(W)0xFFu) | (W)(nf0 + a);
     c.S &= vm;
-    c.P &= ns >= 7u ? ~0u : ((1u << (4u * (ns + 1u))) - 1u);
+    c.P &= ns >= (uint32_t)N - 1u ? (N == 8 ? ~0u : 0xFFFFu) : ((1u << (4u * (ns + 1u))) - 1u);
     summ = s + a;
     flags = (flags & 0x14u) | (hiAny ? 0x08u : 0u) | 0x04u;
     return true;
@@ -200,21 +217,24 @@ FS_DEV bool packed_rescale_quick(Packed& c, uint32_t ns, uint32_t& summ, uint32_
 #else
   #define FS_PROF_ACC_W(w, t0) FS_PROF_ACC(w, t0)
 #endif
-struct WinFetch {                  // per lane, as fetched
-    uint32_t key, sym, addr, r0, stats, ns; bool ok;
-    Packed c; uint32_t sc[8];       // the state list as fetched: symbols, frequencies, successors
+struct WinHead {                   // per lane: the position, its context's record
+    uint32_t key, sym, addr, r0, stats, ns, la; bool ok;
+    uint32_t W;                     // positions left in the stream from `base` on, at most 64
+    bool narrow;                    // (wave-uniform) every usable context has at most four states: the N = 4 forms below will do
+};
+template <int N> struct WinFetch : WinHead {   // ... and its state list, as fetched
+    PackedT<N> c; uint32_t sc[N];   // symbols, frequencies, successors
     uint32_t k, succ; bool plain;   // place of the position's symbol in the list, its successor; a plain hit if the context is the right one
     bool link;                      // this lane's context is the successor the lane before found (lane 0: by definition)
-    uint32_t W;                     // positions left in the stream from `base` on, at most 64
 };
-struct WinSolved {                 // per lane, after the rounds
+template <int N> struct WinSolved {            // per lane, after the rounds
     uint32_t ownerLane; bool owner;
-    Packed c; uint32_t summ, flags; // an owner's context after all its positions
+    PackedT<N> c; uint32_t summ, flags;        // an owner's context after all its positions
     uint32_t tA, tM;                // the position's price: cumulative frequency | frequency << 16 | PrevSuccess << 23 ; the total
 };
 
 // lane0ctx != 0: the context of position `base` is known (the serial walk is there); otherwise every lane asks the hint table
-FS_DEV void win_fetch(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, uint32_t lane0ctx, WinFetch& f)
+FS_DEV void win_fetch_head(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, uint32_t lane0ctx, WinHead& f)
 {
     const uint32_t lane = (uint32_t)FS_LANE();
     f.W = n - base < (uint32_t)FS_WAVE ? n - base : (uint32_t)FS_WAVE;
@@ -240,32 +260,50 @@ FS_DEV void win_fetch(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, uint32_t
     { fs_cgptr32 p = (fs_cgptr32)HP(la); r0 = p[0]; r1 = p[1]; }
     const uint32_t ns = r0 & 0xFFu, stats = r1;
     ok = ok && ns >= 1u && ns <= WIN_MAX_NS && stats >= unitsStart && stats <= SA_SIZE - 47u && ((stats - 1u) & 3u) == 0u;
-    const uint32_t ls = ok ? stats : la;
-    f.r0 = r0; f.ns = ns; f.stats = stats; f.ok = ok;
-    {   // eight states = 48 bytes = twelve words; state j lives at byte 6 j
+    f.r0 = r0; f.ns = ns; f.stats = stats; f.ok = ok; f.la = la;
+    // (FS_WIN_NARROW: the 32-bit forms for windows whose contexts all have at most four states.  Measured in round 3 on a lone
+    // 7 M-symbol quality stream: 1 012 ms against 976 ms without -- half the ALU work of the rounds buys nothing, the window is
+    // bound by its chain of LDS and ballot round trips, and the extra vote costs; profiles/r03_narrow_windows.txt.  Kept for
+    // the lock-step emulation's tests, off in the product.)
+#if defined(FS_WIN_NARROW) && FS_WIN_NARROW
+    f.narrow = fs_ballot(ok && ns > 3u) == 0ull;
+#else
+    f.narrow = false;
+#endif
+}
+template <int N> FS_DEV void win_fetch_list(Coder& m, const WinHead& h, WinFetch<N>& f)
+{
+    typedef typename PackedT<N>::W W;
+    const uint32_t lane = (uint32_t)FS_LANE();
+    static_cast<WinHead&>(f) = h;
+    const uint32_t ls = h.ok ? h.stats : h.la;
+    {   // N states = 6 N bytes = 3 N / 2 words; state j lives at byte 6 j
         fs_cgptr32 p = (fs_cgptr32)HP(ls);
-        uint32_t w[12];
+        uint32_t w[3 * N / 2];
         #pragma unroll
-        for (int i = 0; i < 12; ++i) w[i] = p[i];
-        f.c.S = 0; f.c.F = 0; f.c.P = 0x76543210u;
+        for (int i = 0; i < 3 * N / 2; ++i) w[i] = p[i];
+        f.c.S = 0; f.c.F = 0; f.c.P = N == 8 ? 0x76543210u : 0x3210u;
         #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < N / 2; ++t) {
             const uint32_t x = w[3 * t], y = w[3 * t + 1], z = w[3 * t + 2];
-            f.c.S |= (uint64_t)((x & 0xFFu) | ((y >> 8) & 0xFF00u)) << (16 * t);
-            f.c.F |= (uint64_t)(((x >> 8) & 0xFFu) | ((y >> 16) & 0xFF00u)) << (16 * t);
+            f.c.S |= (W)((x & 0xFFu) | ((y >> 8) & 0xFF00u)) << (16 * t);
+            f.c.F |= (W)(((x >> 8) & 0xFFu) | ((y >> 16) & 0xFF00u)) << (16 * t);
             f.sc[2 * t] = (x >> 16) | (y << 16); f.sc[2 * t + 1] = z;
         }
     }
-    f.k = packed_find(f.c, ns, f.sym);
+    f.k = packed_find<N>(f.c, h.ns, h.sym);
     uint32_t succ = 0;
     #pragma unroll
-    for (int j = 0; j < 8; ++j) if ((uint32_t)j == f.k) succ = f.sc[j];
+    for (int j = 0; j < N; ++j) if ((uint32_t)j == f.k) succ = f.sc[j];
     f.succ = succ;
     // plain hit, given that the context is the right one; the chain proves the contexts
-    f.plain = ok && f.k < 8u && succ >= unitsStart;
+    f.plain = h.ok && f.k < 8u && succ >= m.UnitsStart;
     const uint32_t prevSucc = fs_bperm(succ, (lane + 63u) & 63u);
-    f.link = lane == 0u || addr == prevSucc;
+    f.link = lane == 0u || h.addr == prevSucc;
 }
+// (both steps with eight-state lists: the three-wave form)
+FS_DEV void win_fetch(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, uint32_t lane0ctx, WinFetch<8>& f)
+{ WinHead h; win_fetch_head(m, in, n, base, lane0ctx, h); win_fetch_list<8>(m, h, f); }
 
 // The window [s, E) of a fetch: E = the first lane from s on that is not a plain hit linked to the lane before it (lane s
 // itself needs no link: its context is known, or is checked by the caller), further shortened where a round finds a
@@ -274,8 +312,9 @@ FS_DEV void win_fetch(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, uint32_t
 // meanwhile and name another start lane, the solve is given up (WIN_ABORT) before its expensive part -- the caller solves again.
 enum : uint32_t { WIN_ABORT = 0xFFFFFFFFu };
 FS_DEV uint32_t win_watch(Coder& m, uint32_t watchSeq, uint32_t at);
-FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, const WinFetch& f, uint32_t s, WinSolved& o, uint64_t& tp, uint32_t watchSeq = 0u)
+template <int N> FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, const WinFetch<N>& f, uint32_t s, WinSolved<N>& o, uint64_t& tp, uint32_t watchSeq = 0u)
 {
+    typedef typename PackedT<N>::W W;
     const uint32_t lane = (uint32_t)FS_LANE();
     const uint32_t ns = f.ns, sym = f.sym, addr = f.addr, k = f.k;
     uint32_t E;
@@ -345,7 +384,7 @@ FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, cons
     {
         const uint32_t smLo = m.sh->winMask[2u * ownerLane], smHi = m.sh->winMask[2u * ownerLane + 1u];
         const uint64_t sm = inWin ? ((uint64_t)smHi << 32) | smLo : 0ull;
-        const uint64_t kb0 = fs_ballot(inWin && (k & 1u) != 0u), kb1 = fs_ballot(inWin && (k & 2u) != 0u), kb2 = fs_ballot(inWin && (k & 4u) != 0u);
+        const uint64_t kb0 = fs_ballot(inWin && (k & 1u) != 0u), kb1 = fs_ballot(inWin && (k & 2u) != 0u), kb2 = N == 8 ? fs_ballot(inWin && (k & 4u) != 0u) : 0ull;      // (N = 4: places 0..3)
         const uint64_t earlier = sm & ((1ull << lane) - 1ull);
         const uint32_t kq = k & 7u, kp = (kq - 1u) & 7u;
         const uint64_t e0 = (kq & 1u) ? kb0 : ~kb0, e1 = (kq & 2u) ? kb1 : ~kb1, e2 = (kq & 4u) ? kb2 : ~kb2;
@@ -355,14 +394,14 @@ FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, cons
         const uint32_t cAll = fs_popc64(earlier), cSame = fs_popc64(earlier & eqK), cPrev = fs_popc64(earlier & eqP), cBelow = fs_popc64(earlier & ltK);
         const uint32_t k8 = 8u * kq;
         const uint32_t fr = ((uint32_t)(f.c.F >> k8) & 0xFFu) + 4u * cSame;
-        const uint32_t fPrev = kq ? ((uint32_t)(f.c.F >> ((k8 - 8u) & 63u)) & 0xFFu) + 4u * cPrev : 0xFFFFu;
+        const uint32_t fPrev = kq ? ((uint32_t)(f.c.F >> ((k8 - 8u) & (8u * N - 1u))) & 0xFFu) + 4u * cPrev : 0xFFFFu;
         const bool bad = inWin && (fr + 4u > fPrev || fr + 4u > (uint32_t)MAX_FREQ);
         const uint64_t badSet = fs_ballot(bad) & sm;               // of my context
         const uint32_t firstBad = badSet ? fs_ctz64(badSet) : 64u;
         cfDone = inWin && lane < firstBad;
-        const uint64_t below = f.c.F & ((1ull << k8) - 1ull);
+        const W below = f.c.F & (W)(((W)1 << k8) - (W)1);
         const uint32_t tot = summ0 + 4u * cAll;
-        cfA = (fs_sum_bytes((uint32_t)below) + fs_sum_bytes((uint32_t)(below >> 32)) + 4u * cBelow) | (fr << 16) | ((kq == 0u && 2u * fr > tot) ? (1u << 23) : 0u);
+        cfA = (fs_sum_bytes_w(below) + 4u * cBelow) | (fr << 16) | ((kq == 0u && 2u * fr > tot) ? (1u << 23) : 0u);
         cfM = tot;
         cfSm = sm; cfFirstBad = firstBad; cfKb0 = kb0; cfKb1 = kb1; cfKb2 = kb2;
     }
@@ -372,7 +411,7 @@ FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, cons
     // drops a state), the window ends in front of it -- and only THIS part is done again for the shorter window: the
     // lists, the chain, the context sets and the closed-form prices of the positions that stay do not depend on
     // the positions that go.
-    Packed c; uint32_t summ, flags;
+    PackedT<N> c; uint32_t summ, flags;
     for (;;) {
         inWin = lane >= s && lane < E; owner = inWin && ownerLane == lane;
         c = f.c; summ = summ0; flags = flags0; rlo = rhi = 0u; rounds = 0;
@@ -380,11 +419,11 @@ FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, cons
             const uint64_t lim = (E >= 64u ? ~0ull : (1ull << E) - 1ull) & (~0ull << s);
             const uint64_t doneSet = (cfFirstBad < 64u ? cfSm & ((1ull << cfFirstBad) - 1ull) : cfSm) & lim;
             if (owner) {
-                uint64_t add = 0;
+                W add = 0;
                 #pragma unroll
-                for (uint32_t j = 0; j < 8u; ++j) {
+                for (uint32_t j = 0; j < (uint32_t)N; ++j) {
                     const uint64_t ej = ((j & 1u) ? cfKb0 : ~cfKb0) & ((j & 2u) ? cfKb1 : ~cfKb1) & ((j & 4u) ? cfKb2 : ~cfKb2);
-                    add |= (uint64_t)(4u * fs_popc64(doneSet & ej)) << (8u * j);      // no byte overflows: every frequency stays <= MAX_FREQ
+                    add |= (W)(4u * fs_popc64(doneSet & ej)) << (8u * j);      // no byte overflows: every frequency stays <= MAX_FREQ
                 }
                 c.F += add; summ += 4u * fs_popc64(doneSet);
                 const uint64_t rest = cfSm & lim & ~doneSet;
@@ -405,13 +444,13 @@ FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, cons
             { const uint32_t nlo = rlo & (rlo - 1u), nhi = rhi & (rhi - 1u); rhi = rlo == 0u ? nhi : rhi; rlo = nlo; }
             const uint32_t sy = fs_bperm(sym, p);
             // encodeSymbol1 + update1 on the owner's copy (Model.cpp:447-481)
-            const uint32_t kk = packed_find(c, ns, sy);
+            const uint32_t kk = packed_find<N>(c, ns, sy);
             const bool lost = act && kk >= 8u;                        // cannot happen while nothing drops out; never trust it
             const bool go = act && !lost;
             const uint32_t k8 = 8u * (kk & 7u);
-            const uint32_t fr = (uint32_t)(c.F >> k8) & 0xFFu, fPrev = (kk & 7u) ? (uint32_t)(c.F >> ((k8 - 8u) & 63u)) & 0xFFu : 0u;
-            const uint64_t below = c.F & ((1ull << k8) - 1ull);
-            const uint32_t loCnt = fs_sum_bytes((uint32_t)below) + fs_sum_bytes((uint32_t)(below >> 32));
+            const uint32_t fr = (uint32_t)(c.F >> k8) & 0xFFu, fPrev = (kk & 7u) ? (uint32_t)(c.F >> ((k8 - 8u) & (8u * N - 1u))) & 0xFFu : 0u;
+            const W below = c.F & (W)(((W)1 << k8) - (W)1);
+            const uint32_t loCnt = fs_sum_bytes_w(below);
             const uint32_t nf = fr + 4u;
             const bool doSwap = go && kk != 0u && nf > fPrev;
             const bool resc = go && nf > (uint32_t)MAX_FREQ && (kk == 0u || doSwap);
@@ -419,11 +458,11 @@ FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, cons
             const uint32_t at = go ? p : 64u + lane;
             m.sh->winA[at] = loCnt | (fr << 16) | ((kk == 0u && 2u * fr > summ) ? (1u << 23) : 0u);
             m.sh->winM[at] = summ;
-            c.F += go ? 4ull << k8 : 0ull;
+            c.F += go ? (W)4 << k8 : (W)0;
             summ += go ? 4u : 0u;
             {   // states kk and kk-1 change places: symbol, frequency, successor tag (the differences are zero without a swap)
-                const uint32_t j8 = (k8 - 8u) & 63u, j4 = (4u * kk - 4u) & 31u;
-                const uint64_t dS = doSwap ? ((c.S >> j8) ^ (c.S >> k8)) & 0xFFull : 0ull, dF = doSwap ? ((c.F >> j8) ^ (c.F >> k8)) & 0xFFull : 0ull;
+                const uint32_t j8 = (k8 - 8u) & (8u * N - 1u), j4 = (4u * kk - 4u) & 31u;
+                const W dS = doSwap ? (W)((c.S >> j8) ^ (c.S >> k8)) & (W)0xFFu : (W)0, dF = doSwap ? (W)((c.F >> j8) ^ (c.F >> k8)) & (W)0xFFu : (W)0;
                 c.S ^= (dS << j8) | (dS << k8); c.F ^= (dF << j8) | (dF << k8);
                 const uint32_t dP = doSwap ? ((c.P >> j4) ^ (c.P >> ((j4 + 4u) & 31u))) & 0xFu : 0u;
                 c.P ^= (dP << j4) | (dP << ((j4 + 4u) & 31u));
@@ -435,22 +474,23 @@ FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, cons
 #endif
             bool cut = lost;
             if (fs_ballot(resc) != 0ull) {
-                Packed c2 = c; uint32_t summ2 = summ, flags2 = flags;
+                PackedT<N> c2 = c; uint32_t summ2 = summ, flags2 = flags;
                 const uint32_t kf = doSwap ? kk - 1u : kk;
                 bool done;
-                if (fs_ballot(resc && !packed_rescale_quick_ok(c, ns, kf)) == 0ull) {
-                    done = packed_rescale_quick(c2, ns, summ2, flags2, resc);
+                if (fs_ballot(resc && !packed_rescale_quick_ok<N>(c, ns, kf)) == 0ull) {
+                    done = packed_rescale_quick<N>(c2, ns, summ2, flags2, resc);
 #if defined(FS_SIMT_EMU)
                     {   // the lock-step emulation holds the short form against the network, lane by lane
-                        Packed c3 = c; uint32_t summ3 = summ, flags3 = flags;
-                        const bool done3 = packed_rescale<8>(c3, ns, kf, summ3, flags3);
+                        PackedT<N> c3 = c; uint32_t summ3 = summ, flags3 = flags;
+                        const bool done3 = packed_rescale<N, N>(c3, ns, kf, summ3, flags3);
                         if (resc && (done3 != done || (done && (c3.S != c2.S || c3.F != c2.F || c3.P != c2.P || summ3 != summ2 || flags3 != flags2)))) {
                             fprintf(stderr, "packed_rescale_quick differs from the network (ns %u)\n", ns); abort();
                         }
                         if (resc) simt_count_quick_rescale();
                     }
 #endif
-                } else done = fs_ballot(resc && ns > 3u) == 0ull ? packed_rescale<4>(c2, ns, kf, summ2, flags2) : packed_rescale<8>(c2, ns, kf, summ2, flags2);
+                } else if (N == 4) done = packed_rescale<4, N>(c2, ns, kf, summ2, flags2);
+                else done = fs_ballot(resc && ns > 3u) == 0ull ? packed_rescale<4, N>(c2, ns, kf, summ2, flags2) : packed_rescale<(N == 8 ? 8 : 4), N>(c2, ns, kf, summ2, flags2);
                 if (resc && done) { c = c2; summ = summ2; flags = flags2; }
                 if (resc && !done) cut = true;                     // a state drops out: the serial path takes this symbol
             }
@@ -481,23 +521,23 @@ FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, cons
 
 // commit: every owner writes its context's list and record word back.  The successors go through the lane's eight words of
 // LDS (the hash table's space, free again) to be picked up in their final order.
-FS_DEV void win_write_back(Coder& m, const WinFetch& f, const WinSolved& o)
+template <int N> FS_DEV void win_write_back(Coder& m, const WinFetch<N>& f, const WinSolved<N>& o)
 {
     const uint32_t lane = (uint32_t)FS_LANE();
     #pragma unroll
-    for (int j = 0; j < 8; ++j) m.sh->winTab[8u * lane + (uint32_t)j] = f.sc[j];
+    for (int j = 0; j < N; ++j) m.sh->winTab[8u * lane + (uint32_t)j] = f.sc[j];
     FS_WAVE_SYNC();
     if (o.owner) {
         fs_gptr32 p = (fs_gptr32)HP(f.stats);
         const uint32_t nst = f.ns + 1u;
-        uint32_t w[12], sf[8], so[8];
+        uint32_t w[3 * N / 2], sf[N], so[N];
         #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < N; ++j) {
             sf[j] = ((uint32_t)(o.c.S >> (8 * j)) & 0xFFu) | (((uint32_t)(o.c.F >> (8 * j)) & 0xFFu) << 8);
             so[j] = m.sh->winTab[8u * lane + ((o.c.P >> (4 * j)) & 7u)];
         }
         #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < N / 2; ++t) {
             w[3 * t] = sf[2 * t] | (so[2 * t] << 16);
             w[3 * t + 1] = (so[2 * t] >> 16) | (sf[2 * t + 1] << 16);
             w[3 * t + 2] = so[2 * t + 1];
@@ -505,7 +545,7 @@ FS_DEV void win_write_back(Coder& m, const WinFetch& f, const WinSolved& o)
         // whole units (two states, three words) go back: the spare half of an odd list's last unit is never read
         const uint32_t units = (nst + 1u) >> 1;
         #pragma unroll
-        for (int u = 0; u < 4; ++u) if ((uint32_t)u < units) { p[3 * u] = w[3 * u]; p[3 * u + 1] = w[3 * u + 1]; p[3 * u + 2] = w[3 * u + 2]; }
+        for (int u = 0; u < N / 2; ++u) if ((uint32_t)u < units) { p[3 * u] = w[3 * u]; p[3 * u + 1] = w[3 * u + 1]; p[3 * u + 2] = w[3 * u + 2]; }
         *(fs_gptr32)HP(f.addr) = f.ns | (o.flags << 8) | (o.summ << 16);
     }
     FS_WAVE_SYNC();
@@ -514,16 +554,14 @@ FS_DEV void win_write_back(Coder& m, const WinFetch& f, const WinSolved& o)
 // One window at position `pos` (the serial state is at the top of its loop with OrderFall == 0 and MinContext ==
 // MaxContext).  Returns the number of symbols coded, 0 if the first position is not a plain hit.  On return > 0 the model
 // memory, the coder, PrevSuccess, MaxContext and `hist` are exactly what the serial walk would have left.
-FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uint32_t MinContext, uint32_t& hist)
+template <int N> FS_DEV uint32_t window_step_n(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, const WinHead& h, uint32_t& hist, uint64_t tp, const uint64_t tEnter)
 {
-    uint64_t tp = FS_PROF_NOW(); const uint64_t tEnter = tp;
-    WinFetch f; WinSolved o;
-    win_fetch(m, in, n, pos, MinContext, f);
-    FS_STAT_ADD(m.sh->winStats[0], 1u);
-    FS_PROF_ACC(m.sh->winStats[8], tp);                                // input bytes, hint, record (and the list, now)
-    const uint32_t L = win_solve(m, in, n, pos, f, 0u, o, tp);
+    WinFetch<N> f; WinSolved<N> o;
+    win_fetch_list<N>(m, h, f);
+    FS_PROF_ACC(m.sh->winStats[8], tp);                                // input bytes, hint, record, list
+    const uint32_t L = win_solve<N>(m, in, n, pos, f, 0u, o, tp);
     if (L == 0u) { uint64_t te = tEnter; FS_PROF_ACC(m.sh->winStats[14], te); return 0u; }
-    win_write_back(m, f, o);
+    win_write_back<N>(m, f, o);
     uint32_t tA = o.tA, tM = o.tM;
     if (m.queued) {                                            // two-wave form: the slots go to the coder wave as they are
         cq_push_lanes(m, tA, tM, L);
@@ -562,5 +600,17 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
     FS_PROF_ACC(m.sh->winStats[13], tp);                           // range coder
     { uint64_t te = tEnter; FS_PROF_ACC(m.sh->winStats[14], te); }
     return L;
+}
+FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uint32_t MinContext, uint32_t& hist)
+{
+    uint64_t tp = FS_PROF_NOW(); const uint64_t tEnter = tp;
+    WinHead h;
+    win_fetch_head(m, in, n, pos, MinContext, h);
+    FS_STAT_ADD(m.sh->winStats[0], 1u);
+    // (wave-uniform: no usable context of these 64 positions has more than four states -- the 32-bit forms)
+#if defined(FS_SIMT_EMU)
+    if (FS_LANE() == 0) simt_count_window_form(h.narrow);
+#endif
+    return FS_UB(h.narrow) ? window_step_n<4>(m, in, n, pos, h, hist, tp, tEnter) : window_step_n<8>(m, in, n, pos, h, hist, tp, tEnter);
 }
 #undef FS_CE

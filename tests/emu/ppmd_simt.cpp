@@ -24,6 +24,9 @@ static inline void simt_jitter(int site)
     x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
     for (unsigned k = x % (g_jitterMax + 1u); k > 0; --k) simt::barrier();
 }
+static unsigned long long g_windowForms[2];
+static inline void simt_count_window_form(bool narrow) { g_windowForms[narrow ? 1 : 0]++; }
+extern "C" void simt_window_forms(unsigned long long* out) { out[0] = g_windowForms[0]; out[1] = g_windowForms[1]; }
 static unsigned long long g_scoutWhy[8], g_scoutHist[16][16];
 static inline void simt_scout_hist(unsigned a, unsigned g) { if (a < 64) g_scoutHist[a < 15 ? a : 15][g < 15 ? g : 15]++; }
 extern "C" void simt_scout_histogram(unsigned long long* out) { memcpy(out, g_scoutHist, sizeof g_scoutHist); memset(g_scoutHist, 0, sizeof g_scoutHist); }

@@ -16,13 +16,14 @@ def simt():
     out = os.path.join(ROOT, "build", "libsimt_emu.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     # FS_EMU_DEFS: extra -D flags (kernel experiments, e.g. -DFS_WIN_PREFETCH=1) for the same tests
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU"] + os.environ.get("FS_EMU_DEFS", "").split() + ["-shared", "-fPIC", "-o", out,
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU", "-DFS_WIN_NARROW=1"] + os.environ.get("FS_EMU_DEFS", "").split() + ["-shared", "-fPIC", "-o", out,
                            os.path.join(ROOT, "tests", "emu", "ppmd_simt.cpp"), os.path.join(ROOT, "tests", "emu", "simt.cpp")])
     lib = ctypes.CDLL(out)
     lib.simt_ppmd_encode.restype = ctypes.c_size_t
     lib.simt_ppmd_encode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
     lib.simt_ppmd_encode_two_waves.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5
     lib.simt_quick_rescales.restype = ctypes.c_ulonglong
+    lib.simt_window_forms.argtypes = [ctypes.c_void_p]
     lib.simt_ppmd_encode_three_waves.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6
     lib.simt_set_jitter.argtypes = [ctypes.c_uint, ctypes.c_uint]
     return lib
@@ -77,6 +78,10 @@ def test_other_stream_kinds_through_the_64_lane_paths(simt, oracle):
     for name, data in streams.items():
         got, st = encode(simt, data)
         assert got == oracle_ppmd(oracle, data), name
+    # both forms of the window code have run by now: 32-bit packed lists (no context of a window has more than four states:
+    # the quality streams above) and 64-bit ones (up to eight: "skewed", "flags")
+    forms = (ctypes.c_ulonglong * 2)(); simt.simt_window_forms(forms)
+    assert forms[0] > 100 and forms[1] > 1000, list(forms)
 
 
 def test_reference_vectors_through_the_64_lane_paths(simt):
