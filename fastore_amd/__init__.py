@@ -95,6 +95,7 @@ def load_library(path=None):
     lib.fsgpu_gather_quality_binned.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fsgpu_tokeniser_check.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.fsgpu_matcher_check.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.fsgpu_pe_matcher_check.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.fsgpu_gather_quality.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fsgpu_rc_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fsgpu_set_quality_codebook.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
@@ -356,6 +357,12 @@ class Packer:
         """(reads searched, rows on which the device matcher and the host's window scan disagree) over the standard bins of a library."""
         r = C.c_uint64(0); d = C.c_uint64(0)
         self._check(self.lib.fsgpu_matcher_check(self.ctx, in_prefix.encode(), C.byref(r), C.byref(d)))
+        return r.value, d.value
+
+    def pe_matcher_check(self, in_prefix):
+        """(pairs searched, rows on which the device mate search and the host's disagree) over the standard bins of a paired-end library."""
+        r = C.c_uint64(0); d = C.c_uint64(0)
+        self._check(self.lib.fsgpu_pe_matcher_check(self.ctx, in_prefix.encode(), C.byref(r), C.byref(d)))
         return r.value, d.value
 
     def rc_encode(self, models, pair_streams):

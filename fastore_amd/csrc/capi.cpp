@@ -517,6 +517,12 @@ int fsgpu_tokeniser_check(fsgpu_ctx* ctx, const char* inPrefix, uint64_t* ids, u
     FS_GUARD(ctx, ctx->c.tokeniserCheck(inPrefix, *ids, *differingBins));
 }
 
+int fsgpu_pe_matcher_check(fsgpu_ctx* ctx, const char* inPrefix, uint64_t* pairs, uint64_t* differing)
+{
+    if (!ctx || !inPrefix || !pairs || !differing) return FSGPU_ERR_ARG;
+    FS_GUARD(ctx, ctx->c.mateMatcherCheck(inPrefix, *pairs, *differing));
+}
+
 int fsgpu_matcher_check(fsgpu_ctx* ctx, const char* inPrefix, uint64_t* reads, uint64_t* differing)
 {
     if (!ctx || !inPrefix || !reads || !differing) return FSGPU_ERR_ARG;

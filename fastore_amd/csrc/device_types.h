@@ -42,6 +42,17 @@ struct MatchParams { uint32_t window; int32_t shift_cost, mismatch_cost, encode_
 // that match (cost = threshold + 1 when none); identical: exact duplicate of a slot that is not the root copy
 struct MatchRow { int32_t match; int16_t cost, shift; uint8_t no_mismatches, identical, dummy, pad; };
 
+// Device-side mate search of paired-end bins (matcher.hip: fs_match_mates; LzCompressorPE::CompressPair, fastore_pack/
+// FastqCompressor.cpp:4610-4959).  A bin's pairs in the order the tree walk emits them: where the mate's bases are, how many,
+// and its encode threshold (seqLen / 1.5 in double, truncated -- computed by the host: the device does no floating point).
+struct MatePair { uint32_t mate_off; uint16_t mate_len; int16_t threshold; };
+struct MateJob { uint32_t first, count; };
+// -W (history entries), -s, -m; the archive's minimizer parameters (signature length <= 8: one bit per signature in LDS)
+struct MateParams { uint32_t window; int32_t shift_cost, mismatch_cost; uint32_t sig_len, skip_zone; uint8_t symbol_order[8]; };
+// cost 255: no candidate at all.  match: index (in the job's pair list) of the pair whose mate sits in the matched history
+// entry, valid when cost <= threshold; prev_id: that entry's place in the history at the time of the search
+struct MateRow { int32_t match; int16_t cost, shift; uint16_t prev_id; uint8_t no_mismatches, overflow; };
+
 // Device-side read-id tokeniser (fs_tokenise_ids).  Field table of a library, as the kernel reads it: n_fields, then per
 // field an IdField, then the token fields' value lists (per value: u32 offset from the blob start, u32 length), then bytes
 struct IdField { uint8_t separator, is_const, is_numeric, plog; uint32_t n_values, values_off; uint64_t min_value; };

@@ -72,6 +72,9 @@ int match_lane_reserve(Device* dev, MatchLane* m, size_t maxReads, size_t maxSeq
 int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, const fsdev::MatchRead* reads, size_t nReads,
                 const fsdev::MatchCall* calls, size_t nCalls, const uint32_t* warm, size_t nWarm, const fsdev::MatchParams& par,
                 fsdev::MatchRow* rows, double* kernelMs);
+// the mate searches of one paired-end bin (matcher.hip: fs_match_mates)
+int match_mates(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, const fsdev::MatePair* pairs, size_t nPairs, const uint32_t* validBits, size_t validWords,
+                const fsdev::MateParams& par, fsdev::MateRow* rows, double* kernelMs);
 // fs_gather_quality on its own: `input` = packed scores then the descriptors (plan.desc_off); returns the gathered bytes
 int gather_quality_raw(Device* dev, const uint8_t* input, size_t inputBytes, const fsdev::GatherPlan& plan, std::vector<uint8_t>& out, BatchTiming* timing);
 // fs_tokenise_ids on its own (parity checks): tok[j] / val[j] = the (symbol, context) pair streams of job j (its items: 2 j, 2 j + 1)

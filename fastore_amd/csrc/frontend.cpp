@@ -1136,6 +1136,16 @@ struct BinEncoder::Impl {
     // PE mate coder -- filled in by frontend_pe.inc
     void compressPair(int32_t v, ReadMatchType seType);
     void resetPair();
+    // the pairs of the bin in the order the walk met them; their searches and mate streams come behind the walk (frontend_pe.inc)
+    struct PairTodo { int32_t v; uint8_t seType; };
+    std::vector<PairTodo> pairTodo;
+    MateFn mateMatcher;                                   // the device's mate search (empty: the host's)
+    std::vector<fsdev::MateRow>* mateTrace = nullptr;     // parity harness: the host search's rows
+    std::vector<fsdev::MatePair> matePairs; std::vector<fsdev::MateRow> mateRows;
+    int32_t pairThreshold(const Rec& r) const { return par.pairEncodeThreshold == 0 ? (int32_t)(r.seqLen / 1.5) : par.pairEncodeThreshold; }
+    fsdev::MateRow searchPairHost(int32_t v, int32_t idx);
+    void emitPair(int32_t v, ReadMatchType seType, const fsdev::MateRow& row, int32_t matchV);
+    void finishPairs();
     struct PairState;
     PairState* pairState = nullptr;
 
@@ -1178,7 +1188,7 @@ struct BinEncoder::Impl {
         lzStack.clear(); consStack.clear();
         lzStack.push_back(LzContext());
         matchRle.start(&o.s[S_Match]); consMatchRle.start(&o.s[S_CMatch]); lzRle0.start(&o.s[S_LzId]);
-        if (pe) { matchRlePE.start(&o.s[S_MatchRlePE]); resetPair(); }
+        if (pe) { matchRlePE.start(&o.s[S_MatchRlePE]); resetPair(); pairTodo.clear(); }
         // CompressRecords (FastqCompressor.cpp:1228-1276): sort the top-level nodes, match, then per root contigs + BFS
         std::vector<int32_t> order(bin.topCount);
         for (uint32_t k = 0; k < bin.topCount; ++k) order[k] = (int32_t)(G->topNodes[bin.topBegin + k] - nodeBase);
@@ -1218,7 +1228,7 @@ struct BinEncoder::Impl {
             encodeTree(root, false);
         }
         matchRle.end(); consMatchRle.end(); lzRle0.end();
-        if (pe) matchRlePE.end();
+        if (pe) { finishPairs(); matchRlePE.end(); }
         if (stageTrace) { t4 = clk(); fprintf(stderr, "[bin] %u records: nodes + sort %.1f ms, match table + device search %.1f ms (pre %d), top-level tree %.1f ms, contigs + sub-trees + emission %.1f ms\n", bin.recCount, t1 - t0, t2 - t1, (int)havePre, t3 - t2, t4 - t3); }
     }
 };
@@ -1231,6 +1241,30 @@ namespace fs {
 
 BinEncoder::BinEncoder(const PackParams& par) : impl_(new Impl(par)) {}
 void BinEncoder::setMatcher(MatchFn fn) { impl_->matcher = std::move(fn); }
+void BinEncoder::setMateMatcher(MateFn fn) { impl_->mateMatcher = std::move(fn); }
+void BinEncoder::checkMateMatcher(const Batch& data, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, const MateFn& fn, uint64_t& pairs, uint64_t& differing)
+{
+    Impl& m = *impl_;
+    BinStreams tmp;
+    std::vector<fsdev::MateRow> host, dev;
+    const MateFn keep = m.mateMatcher; const MatchFn keepSe = m.matcher;
+    m.matcher = nullptr; m.mateMatcher = nullptr; m.mateTrace = &host;
+    m.encodeLz(data, graph, bin, arch, tmp);                       // pass 1: the host search, its rows traced
+    m.mateTrace = &dev; m.mateMatcher = fn;
+    m.encodeLz(data, graph, bin, arch, tmp);                       // pass 2: the device's rows (an exception if it could not run)
+    m.mateTrace = nullptr; m.mateMatcher = keep; m.matcher = keepSe;
+    if (host.size() != dev.size()) throw std::runtime_error("mate search check: the two passes met different numbers of pairs");
+    for (size_t i = 0; i < host.size(); ++i) {
+        const fsdev::MateRow &a = host[i], &b = dev[i];
+        ++pairs;
+        if (b.overflow) throw std::runtime_error("mate search check: the device's alignment list overflowed");
+        bool same = a.cost == b.cost;
+        if (same && a.cost < 255) same = a.shift == b.shift && a.no_mismatches == b.no_mismatches;
+        if (same && a.match >= 0) same = a.match == b.match && a.prev_id == b.prev_id;
+        if (same && a.match < 0) same = b.match < 0;
+        if (!same) ++differing;
+    }
+}
 void BinEncoder::checkMatcher(const Batch& data, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, const MatchFn& fn, uint64_t& reads, uint64_t& differing)
 {
     Impl& m = *impl_;

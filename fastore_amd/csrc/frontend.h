@@ -77,9 +77,18 @@ struct ArchiveParams { BinModuleConfigRaw cfg{}; HeaderStats head; QvzModel qvz;
 typedef std::function<bool(const uint8_t* seq, size_t seqBytes, const fsdev::MatchRead* reads, size_t nReads, const fsdev::MatchCall* calls,
                            size_t nCalls, const uint32_t* warm, size_t nWarm, const fsdev::MatchParams& par, fsdev::MatchRow* rows)> MatchFn;
 
+// The device-side mate search of a paired-end bin (matcher.hip: fs_match_mates): the bin's bases, its pairs in the order the
+// tree walk emits them, the archive's valid signatures (a bit each); one row per pair.  false: could not be run (host search).
+typedef std::function<bool(const uint8_t* seq, size_t seqBytes, const fsdev::MatePair* pairs, size_t nPairs, const uint32_t* validBits, size_t validWords,
+                           const fsdev::MateParams& par, fsdev::MateRow* rows)> MateFn;
+
 class BinEncoder {
 public:
     explicit BinEncoder(const PackParams& par);
+    // mate searches of the following encodeLz calls (paired-end bins) go through `fn` (empty: the host search)
+    void setMateMatcher(MateFn fn);
+    // parity check of the device mate search: the bin through the host search and through `fn`; pairs, and rows that differ
+    void checkMateMatcher(const Batch& data, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, const MateFn& fn, uint64_t& pairs, uint64_t& differing);
     // window searches of the following encodeLz calls go through `fn` (empty: the host scan)
     void setMatcher(MatchFn fn);
     // parity check of the device matcher: runs the bin through the host scan and through `fn`, returns the number of reads

@@ -185,6 +185,188 @@ template <int FW, bool MULTI> __global__ __launch_bounds__(MULTI ? 1024 : 64) vo
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// fs_match_mates -- the mate search of a paired-end bin: LzCompressorPE::CompressPair's history search
+// (fastore_pack/FastqCompressor.cpp:4610-4959) with the minimizer sets of FastqCategorizerBase::FindMinimizers
+// (fastore_bin/FastqCategorizer.cpp:109-151).
+//
+// What the reference does per pair, in the order the tree walk emits the records: the oldest of the W history entries leaves;
+// the mate's valid signatures are collected from its two halves (set 1: positions [0, ~len/2), set 2: [len/2, ..) minus what
+// set 1 holds; per signature its first position); every history entry that lists one of them (an entry lists up to four:
+// the smallest of its own sets) is aligned at each of its FOUR stored positions against that signature's position (shift =
+// entry position - mate position, |shift| <= 127, cost = |shift| * s + mismatches over the overlap * m); the cheapest
+// alignment wins, the first one in the order (signature ascending, entries oldest first, stored position 0..3) among equals.
+// At or below the threshold the mate is coded against that entry.  The mate then enters the history at the front -- or, if
+// it matched with cost 0 and no mismatch, at the back, from where the next pair drops it unseen.
+//
+// MI355X mapping: one 1024-thread workgroup per bin, the pairs one after the other (each depends on where the ones before
+// went).  Per pair: the mate's bases into LDS; a thread per position builds the signature and sets its bit in the sets'
+// bitmaps (one bit per signature: 8 KB each; distinct members are counted by who set a bit first); two wavefronts pick the
+// sets' four smallest members (DPP minimum, then strike the winner's signature, four times); a thread per history entry tests
+// its listed signatures against the bitmaps and puts its alignments on a list; the sixteen wavefronts price the list -- a
+// lane per base, the entry's bases from HBM (L2-resident: the bin's own bases), the mate's from LDS, ballot + popcount -- and
+// the cheapest goes to an LDS atomic minimum over (cost, order, list index).  The entry the pair replaces is rewritten by
+// its thread.  Rows come back as the host's serial search computes them (checked pair by pair: fsgpu_pe_matcher_check).
+enum : uint32_t { kMateThreads = 1024, kMateCand = 2048, kMateNone = 0xFFFFFFFFu };
+struct MateShared {
+    uint32_t mate[64];                      // the current mate's bases (bytes)
+    uint32_t sigAt[256];                    // per position: its signature if it is a member of set 1 / set 2, else kMateNone
+    uint32_t bmA[2048], bmB[2048], valid[2048];
+    uint32_t entSig[4][kMateThreads];       // per history entry: signature | position << 16 of its four slots (0 = unused: position 0 still counts)
+    uint32_t entOff[kMateThreads], entLen[kMateThreads], entPair[kMateThreads], entStamp[kMateThreads], entLive[kMateThreads];
+    uint32_t candE[kMateCand], candKey[kMateCand]; int32_t candShift[kMateCand];
+    uint32_t small1[4], small2[4];          // the sets' smallest members: signature << 8 | first position
+    uint32_t nCand, size1, size2, overflow;
+    unsigned long long best;
+    uint8_t idx[128];                       // base -> 0..3 (4: 'N', 255: anything else)
+};
+
+__global__ __launch_bounds__(kMateThreads) void fs_match_mates(const MateJob* __restrict__ jobs, const MatePair* __restrict__ pairs, const uint8_t* __restrict__ seq,
+                                                               const uint32_t* __restrict__ validBits, MateParams par, MateRow* __restrict__ rows)
+{
+    extern __shared__ uint8_t mateLds[];
+    MateShared& sh = *(MateShared*)mateLds;
+    const MateJob job = jobs[blockIdx.x];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t W = par.window, sigLen = par.sig_len, sigMask = (1u << (2u * sigLen)) - 1u;
+    for (uint32_t i = tid; i < 2048u; i += kMateThreads) { sh.bmA[i] = 0u; sh.bmB[i] = 0u; sh.valid[i] = (i << 5) <= sigMask ? validBits[i] : 0u; }
+    if (tid < 128u) { uint32_t v = 255u; for (uint32_t k = 0; k < 5u; ++k) if (par.symbol_order[k] == tid) v = k; sh.idx[tid] = (uint8_t)v; }
+    sh.entLive[tid] = 0u; sh.entStamp[tid] = 0u; sh.entPair[tid] = 0u; sh.entOff[tid] = 0u; sh.entLen[tid] = 0u;
+    for (int j = 0; j < 4; ++j) sh.entSig[j][tid] = 0u;
+    if (tid == 0u) { sh.nCand = 0u; sh.size1 = 0u; sh.size2 = 0u; sh.overflow = 0u; sh.best = ~0ull; }
+    __syncthreads();
+    // the history as a ring: slots leave in the order W-1, W-2, .., 0, W-1, .. -- except that a mate that went to the BACK leaves first
+    uint32_t ring = W - 1u, frontPushes = 0u, backSlot = kMateNone;
+    for (uint32_t p = 0; p < job.count; ++p) {
+        const MatePair pr = pairs[job.first + p];
+        const uint32_t plen = pr.mate_len;
+        const uint32_t slot = backSlot != kMateNone ? backSlot : ring;            // the entry that leaves (and will hold this mate)
+        if (tid == slot) sh.entLive[slot] = 0u;
+        if (tid < (plen + 3u) / 4u) { uint32_t w = 0; for (uint32_t b = 0; b < 4u; ++b) { const uint32_t q = 4u * tid + b; w |= (q < plen ? (uint32_t)seq[pr.mate_off + q] : (uint32_t)'N') << (8u * b); } sh.mate[tid] = w; }
+        __syncthreads();
+        // ---- the mate's signatures (FindMinimizers over the two halves)
+        const int32_t half = (int32_t)plen / 2;
+        const int32_t end1 = (int32_t)plen - (int32_t)sigLen - ((int32_t)par.skip_zone + half - ((int32_t)sigLen - 1));
+        const int32_t end2 = (int32_t)plen - (int32_t)sigLen - (int32_t)par.skip_zone;
+        uint32_t m = 0; bool ok = false, in1 = false, in2 = false;
+        if (tid < 256u && (int32_t)tid + (int32_t)sigLen <= (int32_t)plen) {
+            in1 = (int32_t)tid < end1; in2 = (int32_t)tid >= half && (int32_t)tid < end2;
+            if (in1 || in2) {
+                ok = true;
+                const uint8_t* mb = (const uint8_t*)sh.mate;
+                for (uint32_t k = 0; k < sigLen; ++k) { const uint32_t c = sh.idx[mb[tid + k] & 127u]; if (c > 3u) ok = false; m = (m << 2) | (c & 3u); }
+                ok = ok && ((sh.valid[m >> 5] >> (m & 31u)) & 1u) != 0u;
+            }
+        }
+        bool member = false;
+        if (ok && in1) { const uint32_t old = atomicOr(&sh.bmA[m >> 5], 1u << (m & 31u)); member = true; if (!((old >> (m & 31u)) & 1u)) atomicAdd(&sh.size1, 1u); }
+        __syncthreads();
+        if (ok && in2 && !in1) {
+            if (!((sh.bmA[m >> 5] >> (m & 31u)) & 1u)) { const uint32_t old = atomicOr(&sh.bmB[m >> 5], 1u << (m & 31u)); member = true; if (!((old >> (m & 31u)) & 1u)) atomicAdd(&sh.size2, 1u); }
+        }
+        if (tid < 256u) sh.sigAt[tid] = member ? m : kMateNone;
+        __syncthreads();
+        // ---- the four smallest members of each set, with their first positions (wave 0: set 1, wave 1: set 2)
+        if (wave < 2u) {
+            uint32_t key[4];
+            for (uint32_t q = 0; q < 4u; ++q) {
+                const uint32_t t = lane + 64u * q; const uint32_t sg = sh.sigAt[t];
+                const bool mine = sg != kMateNone && (wave == 0u ? (int32_t)t < end1 : (int32_t)t >= half);
+                key[q] = mine ? (sg << 8) | t : kMateNone;
+            }
+            for (uint32_t r = 0; r < 4u; ++r) {
+                uint32_t loc = key[0] < key[1] ? key[0] : key[1]; const uint32_t l2 = key[2] < key[3] ? key[2] : key[3]; loc = loc < l2 ? loc : l2;
+                const uint32_t best = wave_min_u32(loc);
+                if (lane == 0u) (wave == 0u ? sh.small1 : sh.small2)[r] = best;
+                for (uint32_t q = 0; q < 4u; ++q) if (best != kMateNone && (key[q] >> 8) == (best >> 8)) key[q] = kMateNone;
+            }
+        }
+        // ---- every live entry: its listed signatures against the sets; its alignments onto the list
+        if (tid < W && sh.entLive[tid]) {
+            const uint32_t pos = frontPushes - sh.entStamp[tid] - 1u;             // place in the history, newest = 0
+            const uint32_t rank = (W - 1u) - pos;                                  // oldest first
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const uint32_t sj = sh.entSig[j][tid] & 0xFFFFu;
+                if (sj == 0u) break;
+                if (!(((sh.bmA[sj >> 5] | sh.bmB[sj >> 5]) >> (sj & 31u)) & 1u)) continue;
+                uint32_t posH = 0;
+                for (; posH < 256u && sh.sigAt[posH] != sj; ++posH) {}
+                if (posH >= 256u) continue;
+                int32_t seen[4]; uint32_t nSeen = 0;
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const int32_t shift = (int32_t)(sh.entSig[k][tid] >> 16) - (int32_t)posH;
+                    if (shift > 127 || shift < -127) continue;
+                    bool dup = false;
+                    for (uint32_t q = 0; q < nSeen; ++q) dup = dup || seen[q] == shift;            // the same alignment again: the earlier one decides
+                    if (dup) continue;
+                    seen[nSeen++] = shift;
+                    const uint32_t at = atomicAdd(&sh.nCand, 1u);
+                    if (at < kMateCand) { sh.candE[at] = tid; sh.candShift[at] = shift; sh.candKey[at] = (sj << 12) | (rank << 2) | k; }
+                    else sh.overflow = 1u;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- price the list: a wavefront per alignment, a lane per base
+        {
+            const uint32_t nCand = sh.nCand < kMateCand ? sh.nCand : (uint32_t)kMateCand;
+            const uint8_t* mb = (const uint8_t*)sh.mate;
+            for (uint32_t c = wave; c < nCand; c += kMateThreads / 64u) {
+                const uint32_t e = sh.candE[c]; const int32_t shift = sh.candShift[c];
+                const uint32_t recOff = shift < 0 ? (uint32_t)-shift : 0u, lzOff = shift > 0 ? (uint32_t)shift : 0u;
+                const uint32_t lzLen = sh.entLen[e], a = plen - recOff, b = lzLen - lzOff, minLen = a < b ? a : b;
+                const uint8_t* lz = seq + sh.entOff[e] + lzOff;
+                uint32_t mism = 0;
+                for (uint32_t i = lane; i < ((minLen + 63u) & ~63u); i += 64u) {
+                    const bool diff = i < minLen && mb[recOff + i] != lz[i];
+                    mism += (uint32_t)__popcll(__ballot(diff));
+                }
+                const uint32_t ashift = (uint32_t)(shift < 0 ? -shift : shift);
+                const uint32_t cost = ashift * (uint32_t)par.shift_cost + mism * (uint32_t)par.mismatch_cost;
+                if (lane == 0u && cost < 255u) atomicMin(&sh.best, ((unsigned long long)cost << 44) | ((unsigned long long)sh.candKey[c] << 12) | c);
+            }
+        }
+        __syncthreads();
+        // ---- the answer, and the mate's own entry
+        const unsigned long long best = sh.best;
+        uint32_t cost = 255u, prevId = 0, matchPair = 0; int32_t shift = 0; bool noMism = false;
+        if (best != ~0ull) {
+            cost = (uint32_t)(best >> 44);
+            const uint32_t cc = (uint32_t)(best & 0xFFFull);
+            const uint32_t e = sh.candE[cc]; shift = sh.candShift[cc];
+            prevId = frontPushes - sh.entStamp[e] - 1u; matchPair = sh.entPair[e];
+            const uint32_t ashift = (uint32_t)(shift < 0 ? -shift : shift);
+            noMism = cost == ashift * (uint32_t)par.shift_cost;
+        }
+        const bool matched = (int32_t)cost <= (int32_t)pr.threshold;
+        const bool identical = matched && noMism && cost == 0u;
+        if (tid == 0u) {
+            MateRow row; row.match = matched ? (int32_t)matchPair : -1; row.cost = (int16_t)cost; row.shift = (int16_t)shift; row.prev_id = (uint16_t)prevId;
+            row.no_mismatches = noMism ? 1 : 0; row.overflow = (uint8_t)sh.overflow;
+            rows[job.first + p] = row;
+        }
+        // the sets' bits are taken back by the lanes that set them
+        if (member) { atomicAnd(&sh.bmA[m >> 5], ~(1u << (m & 31u))); atomicAnd(&sh.bmB[m >> 5], ~(1u << (m & 31u))); }
+        __syncthreads();
+        if (tid == slot) {
+            // two signatures from the smaller set, then from the other one up to four in all (their smallest members)
+            const uint32_t s1 = sh.size1, s2 = sh.size2;
+            const uint32_t* first = s1 > s2 ? sh.small2 : sh.small1; const uint32_t* second = s1 > s2 ? sh.small1 : sh.small2;
+            const uint32_t firstSize = s1 > s2 ? s2 : s1, total = s1 + s2;
+            uint32_t n = 0;
+            for (uint32_t q = 0; n < (firstSize < 2u ? firstSize : 2u); ++n, ++q) sh.entSig[n][slot] = (first[q] >> 8) | ((first[q] & 0xFFu) << 16);
+            for (uint32_t q = 0; n < (total < 4u ? total : 4u); ++n, ++q) sh.entSig[n][slot] = (second[q] >> 8) | ((second[q] & 0xFFu) << 16);
+            for (; n < 4u; ++n) sh.entSig[n][slot] = 0u;
+            sh.entOff[slot] = pr.mate_off; sh.entLen[slot] = plen; sh.entPair[slot] = p; sh.entStamp[slot] = frontPushes;
+            sh.entLive[slot] = identical ? 0u : 1u;                               // (at the back it is dropped before anyone looks)
+        }
+        if (tid == 0u) { sh.nCand = 0u; sh.size1 = 0u; sh.size2 = 0u; sh.best = ~0ull; }
+        if (identical) backSlot = slot;
+        else { ring = ring == 0u ? W - 1u : ring - 1u; backSlot = kMateNone; ++frontPushes; }      // (a slot that came back from the back IS the ring's current one)
+        __syncthreads();
+    }
+}
+
 template <class T> int ensureBuf(fsengine::Device* dev, T*& p, size_t& cap, size_t need)
 {
     if (need <= cap && p) return 0;
@@ -222,6 +404,7 @@ struct MatchLane {
     uint32_t* dWarm = nullptr; size_t capWarm = 0;
     uint32_t* dPlanes = nullptr; size_t capPlanes = 0;
     MatchRow* dRows = nullptr; size_t capRows = 0;
+    MatePair* dPairs = nullptr; size_t capPairs = 0; MateRow* dMateRows = nullptr; size_t capMateRows = 0; uint32_t* dValid = nullptr; size_t capValid = 0;
     uint8_t* hStage = nullptr; size_t capStage = 0; bool stagePageable = false;
 };
 
@@ -258,7 +441,7 @@ void match_lane_destroy(MatchLane* m)
         if (--p.users == 0) { for (int i = 0; i < kMatchStreamsMax; ++i) if (p.s[i]) { (void)hipStreamDestroy(p.s[i]); p.s[i] = nullptr; } }
         m->stream = nullptr;
     }
-    void* ptrs[] = {m->dSeq, m->dReads, m->dCalls, m->dIds, m->dWarm, m->dPlanes, m->dRows};
+    void* ptrs[] = {m->dSeq, m->dReads, m->dCalls, m->dIds, m->dWarm, m->dPlanes, m->dRows, m->dPairs, m->dMateRows, m->dValid};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->hStage) pinned_free(m->hStage, m->capStage, !m->stagePageable);
     if (m->evWait) (void)hipEventDestroy(m->evWait);
@@ -368,6 +551,41 @@ int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev1, st));
     HIP_TRY(hipMemcpyAsync(rows, m->dRows, nReads * sizeof(MatchRow), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(m->evWait, st));
+    HIP_TRY(hipEventSynchronize(m->evWait));
+    if (kernelMs) { float a = 0; (void)hipEventElapsedTime(&a, m->ev0, m->ev1); *kernelMs += a; }
+    return 0;
+}
+
+// One paired-end bin's mate searches.  seq: the bin's bases (ASCII); pairs: its pairs in the order the tree walk emits them;
+// validBits: one bit per signature (the archive's valid minimizers, 2^(2 sig_len) bits); rows[i] answers pairs[i].
+int match_mates(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, const MatePair* pairs, size_t nPairs, const uint32_t* validBits, size_t validWords,
+                const MateParams& par, MateRow* rows, double* kernelMs)
+{
+    if (nPairs == 0) return 0;
+    if (par.window < 1u || par.window > kMateThreads || par.sig_len < 2u || par.sig_len > 8u || validWords < ((1ull << (2u * par.sig_len)) + 31u) / 32u) {
+        snprintf(dev->err, sizeof dev->err, "device mate search: window %u / signature length %u not supported", par.window, par.sig_len); return -1;
+    }
+    HIP_TRY(hipSetDevice(m->deviceId));
+    for (size_t i = 0; i < nPairs; ++i)
+        if ((uint64_t)pairs[i].mate_off + pairs[i].mate_len > seqBytes || pairs[i].mate_len > 255u || pairs[i].mate_len < par.sig_len) { snprintf(dev->err, sizeof dev->err, "device mate search: pair %zu outside the bases", i); return -1; }
+    if (ensureBuf(dev, m->dSeq, m->capSeq, seqBytes + 64) || ensureBuf(dev, m->dPairs, m->capPairs, nPairs * sizeof(MatePair)) || ensureBuf(dev, m->dMateRows, m->capMateRows, nPairs * sizeof(MateRow)) ||
+        ensureBuf(dev, m->dValid, m->capValid, 8192 + 64) || ensureBuf(dev, m->dCalls, m->capCalls, sizeof(MateJob) + 64)) return -1;
+    hipStream_t st = m->stream;
+    const MateJob job{0u, (uint32_t)nPairs};
+    std::vector<uint32_t> vb(2048, 0u);
+    memcpy(vb.data(), validBits, std::min<size_t>(validWords, 2048) * 4u);
+    HIP_TRY(hipMemcpyAsync(m->dSeq, seq, seqBytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->dPairs, pairs, nPairs * sizeof(MatePair), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->dValid, vb.data(), 8192, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->dCalls, &job, sizeof job, hipMemcpyHostToDevice, st));
+    static bool attrSet[16] = {};
+    if (!attrSet[m->deviceId & 15]) { HIP_TRY(hipFuncSetAttribute((const void*)fs_match_mates, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MateShared))); attrSet[m->deviceId & 15] = true; }
+    HIP_TRY(hipEventRecord(m->ev0, st));
+    hipLaunchKernelGGL(fs_match_mates, dim3(1), dim3(kMateThreads), sizeof(MateShared), st, (const MateJob*)m->dCalls, (const MatePair*)m->dPairs, (const uint8_t*)m->dSeq, (const uint32_t*)m->dValid, par, m->dMateRows);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(m->ev1, st));
+    HIP_TRY(hipMemcpyAsync(rows, m->dMateRows, nPairs * sizeof(MateRow), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(m->evWait, st));
     HIP_TRY(hipEventSynchronize(m->evWait));
     if (kernelMs) { float a = 0; (void)hipEventElapsedTime(&a, m->ev0, m->ev1); *kernelMs += a; }

@@ -437,6 +437,43 @@ MatchFn Context::matcherFor(uint32_t tid)
     };
 }
 
+MateFn Context::mateMatcherFor(uint32_t tid)
+{
+    if (!deviceMatcher) return MateFn();
+    if (matchLanes.size() <= tid) throw std::runtime_error("matcher lanes not sized");
+    return [this, tid](const uint8_t* seq, size_t seqBytes, const fsdev::MatePair* pairs, size_t nPairs, const uint32_t* validBits, size_t validWords,
+                       const fsdev::MateParams& mp, fsdev::MateRow* rows) -> bool {
+        if (!deviceReadyWithin(300)) return false;
+        fsengine::Device* dev = device();
+        if (!matchLanes[tid]) { if (fsengine::match_lane_create(dev, &matchLanes[tid]) != 0) throw std::runtime_error(std::string("device: ") + dev->err); }
+        const double t0 = nowMs(); double kms = 0;
+        if (fsengine::match_mates(dev, matchLanes[tid], seq, seqBytes, pairs, nPairs, validBits, validWords, mp, rows, &kms) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+        matedPairs += nPairs; mateUs += (uint64_t)((nowMs() - t0) * 1e3); mateKernelUs += (uint64_t)(kms * 1e3);
+        return true;
+    };
+}
+
+void Context::mateMatcherCheck(const std::string& inPrefix, uint64_t& pairs, uint64_t& differing)
+{
+    pairs = differing = 0;
+    (void)device();
+    BinFile bf; bf.open(inPrefix, par.minBinSize);
+    ArchiveParams arch; arch.cfg = bf.config(); arch.head = bf.headData(); arch.qvz = bf.qvz();
+    if (arch.cfg.archiveType.readType != READ_PE) return;
+    const std::vector<uint32_t>& sigs = bf.stdSignatures();
+    std::mutex mx;
+    const bool keep = deviceMatcher; deviceMatcher = true;
+    if (matchLanes.size() < hostThreads) matchLanes.resize(hostThreads, nullptr);
+    parallelFor((uint32_t)sigs.size(), std::min<uint32_t>(hostThreads, 8u), [&](uint32_t k, uint32_t tid) {
+        Batch b; bf.unpack(sigs[k], b, true);
+        BinEncoder enc(par);
+        uint64_t r = 0, d = 0;
+        enc.checkMateMatcher(b, b, b.bins.at(0), arch, mateMatcherFor(tid), r, d);
+        std::lock_guard<std::mutex> g(mx); pairs += r; differing += d;
+    });
+    deviceMatcher = keep;
+}
+
 // Parity check of the device matcher on every standard bin of a library: host scan vs device, row by row
 void Context::matcherCheck(const std::string& inPrefix, uint64_t& reads, uint64_t& differing)
 {
@@ -963,6 +1000,13 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             // Later the coder kernels hold every register of the chip (3 waves x 168 VGPRs per SIMD): a search would wait
             // for coder waves to leave, longer than the host scan takes, so the lighter bins keep the host scan.
             encs[tid]->setMatcher(k < matcherBins ? matcherFor(tid) : MatchFn());
+            // (paired-end bins: fs_match_mates gives the host search's rows pair for pair -- 61 404 of 61 404 on a fresh library, every
+            // golden bin at five history sizes -- but it is NOT the product's default: one 1024-thread workgroup per bin on the two
+            // streams the searches share, every alignment priced in full (the host's search gives up on an alignment at the
+            // first base past the best cost so far): the 6 M-pair step took 45 s with it against 2.6 s without,
+            // profiles/r03_device_mate_search.txt.  FS_DEVICE_MATES=1 switches it on.)
+            static const bool deviceMates = getenv("FS_DEVICE_MATES") && atoi(getenv("FS_DEVICE_MATES")) != 0;
+            encs[tid]->setMateMatcher(k < matcherBins && deviceMates ? mateMatcherFor(tid) : MateFn());
             const double ta = trace ? nowMs() : 0.0;
             produce(b, *encs[tid], st[b], info[b], recBytes[b]);
             if (trace) busyMs[tid] += nowMs() - ta;

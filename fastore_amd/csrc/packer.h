@@ -123,7 +123,11 @@ struct Context {
     struct { size_t reads = 0, seqBytes = 0, calls = 0, warm = 0; } matchReserve;     // bounds of the largest bin of the coming batch (0: grow on demand)
     std::atomic<uint64_t> matchedReads{0}, matchUs{0}, matchKernelUs{0};
     MatchFn matcherFor(uint32_t tid);
+    MateFn mateMatcherFor(uint32_t tid);          // the mate searches of host thread `tid` (paired-end bins): the same lane
+    std::atomic<uint64_t> matedPairs{0}, mateUs{0}, mateKernelUs{0};
     void matcherCheck(const std::string& inPrefix, uint64_t& reads, uint64_t& differing);
+    // parity check of the device mate search: every standard bin of a paired-end library through the host search and fs_match_mates
+    void mateMatcherCheck(const std::string& inPrefix, uint64_t& pairs, uint64_t& differing);
     // parity check of the device tokeniser: every standard bin's read ids through the host tokeniser and through fs_tokenise_ids
     void tokeniserCheck(const std::string& inPrefix, uint64_t& ids, uint64_t& differingBins);
     // merged small bins + N bin (batch with ONE bin, records already in stored order): RawCompressorSE/PE

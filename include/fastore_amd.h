@@ -181,6 +181,13 @@ int fsgpu_gather_quality_binned(fsgpu_ctx* ctx, const uint8_t* packed, size_t pa
  * mismatch-free flag, exact-duplicate flag) on which the two disagree. */
 int fsgpu_matcher_check(fsgpu_ctx* ctx, const char* in_prefix, uint64_t* reads, uint64_t* differing);
 
+/* Parity check of the device-side mate search of paired-end bins (matcher.hip: fs_match_mates; LzCompressorPE::CompressPair's
+ * history search, fastore_pack/FastqCompressor.cpp:4610-4959, with the minimizer sets of FastqCategorizerBase::FindMinimizers,
+ * fastore_bin/FastqCategorizer.cpp:109-151): every standard bin of the paired-end library <in_prefix> goes through the host's
+ * serial search and through the device; *pairs = pairs searched, *differing = rows (cost, shift, mismatch-free flag, matched
+ * pair, its place in the history) on which the two disagree.  A single-end library gives 0 / 0. */
+int fsgpu_pe_matcher_check(fsgpu_ctx* ctx, const char* in_prefix, uint64_t* pairs, uint64_t* differing);
+
 /* Parity check of the device-side read-id tokeniser (fs_tokenise_ids; IHeaderStoreBase::CompressReadId, fastore_pack/
  * FastqCompressor.cpp:504-583): every standard bin's read ids, in stored order, through the host's restatement (unpacked
  * headers) and through the kernel (packed .bhead bytes); *ids = read ids tokenised, *differing_bins = bins whose IdToken or

@@ -7,6 +7,7 @@
 #include <string.h>
 #include <thread>
 #include <algorithm>
+#include <map>
 #include <vector>
 #include <atomic>
 #include "../../fastore_amd/csrc/engine.h"
@@ -134,6 +135,64 @@ int match_reads(Device*, MatchLane*, const uint8_t* seq, size_t, const MatchRead
             }
             rows[r] = row;
             if (!identical) { win.insert(win.begin(), r); if (win.size() > cap) win.pop_back(); }
+        }
+    }
+    return 0;
+}
+
+// what fs_match_mates computes, as a plain loop over a history kept newest first (test-only stand-in; the rules are those of
+// LzCompressorPE::CompressPair, restated from the kernel's description, not from the product's host search)
+int match_mates(Device*, MatchLane*, const uint8_t* seq, size_t, const MatePair* pairs, size_t nPairs, const uint32_t* validBits, size_t, const MateParams& par, MateRow* rows, double*)
+{
+    struct Entry { uint32_t sig[4]; uint32_t pos[4]; uint32_t off, len; int32_t pair; bool live; };
+    std::vector<Entry> hist;                                           // newest first; only entries that went to the front
+    uint8_t idx[128]; memset(idx, 255, sizeof idx);
+    for (int k = 0; k < 5; ++k) idx[par.symbol_order[k] & 127] = (uint8_t)k;
+    const uint32_t L = par.sig_len;
+    for (size_t p = 0; p < nPairs; ++p) {
+        const MatePair& pr = pairs[p];
+        const uint8_t* m8 = seq + pr.mate_off; const int32_t plen = pr.mate_len, half = plen / 2;
+        if (hist.size() >= par.window) hist.pop_back();                // the oldest leaves (an entry that went to the back never got in)
+        const int32_t end1 = plen - (int32_t)L - ((int32_t)par.skip_zone + half - ((int32_t)L - 1)), end2 = plen - (int32_t)L - (int32_t)par.skip_zone;
+        std::map<uint32_t, uint32_t> set1, set2;                       // signature -> first position
+        auto sigAt = [&](int32_t t, uint32_t& m) { m = 0; for (uint32_t k = 0; k < L; ++k) { const uint32_t c = idx[m8[t + k] & 127]; if (c > 3) return false; m = (m << 2) | c; } return ((validBits[m >> 5] >> (m & 31u)) & 1u) != 0u; };
+        for (int32_t t = 0; t < end1; ++t) { uint32_t m; if (sigAt(t, m) && !set1.count(m)) set1[m] = (uint32_t)t; }
+        for (int32_t t = half; t < end2; ++t) { uint32_t m; if (sigAt(t, m) && !set1.count(m) && !set2.count(m)) set2[m] = (uint32_t)t; }
+        std::map<uint32_t, uint32_t> all = set1; all.insert(set2.begin(), set2.end());
+        int32_t best = 255, bestShift = 0; int64_t bestAt = -1; bool bestNoMism = false;
+        for (const auto& sp : all)                                      // signatures ascending
+            for (size_t h = hist.size(); h-- > 0;) {                   // entries oldest first
+                const Entry& e = hist[h];
+                bool lists = false; for (int k = 0; k < 4; ++k) lists = lists || (e.sig[k] != 0 && e.sig[k] == sp.first);
+                if (!lists) continue;
+                for (int k = 0; k < 4; ++k) {
+                    const int32_t shift = (int32_t)e.pos[k] - (int32_t)sp.second, ashift = shift < 0 ? -shift : shift;
+                    if (ashift > 127) continue;
+                    const uint32_t recOff = shift < 0 ? (uint32_t)ashift : 0u, lzOff = shift > 0 ? (uint32_t)ashift : 0u;
+                    const uint32_t n = std::min<uint32_t>((uint32_t)plen - recOff, e.len - lzOff);
+                    int32_t mism = 0;
+                    for (uint32_t i = 0; i < n; ++i) mism += m8[recOff + i] != seq[e.off + lzOff + i];
+                    const int32_t cc = ashift * par.shift_cost + mism * par.mismatch_cost;
+                    if (cc < best) { best = cc; bestShift = shift; bestAt = (int64_t)h; bestNoMism = mism == 0; }
+                }
+            }
+        MateRow row; memset(&row, 0, sizeof row);
+        row.cost = (int16_t)best; row.shift = (int16_t)bestShift; row.no_mismatches = bestNoMism; row.match = -1;
+        const bool matched = best <= pr.threshold;
+        if (matched) { row.match = hist[(size_t)bestAt].pair; row.prev_id = (uint16_t)bestAt; }
+        rows[p] = row;
+        const bool identical = matched && bestNoMism && best == 0;
+        if (!identical) {
+            Entry e; memset(&e, 0, sizeof e);
+            e.off = pr.mate_off; e.len = (uint32_t)plen; e.pair = (int32_t)p; e.live = true;
+            const std::map<uint32_t, uint32_t>& first = set1.size() > set2.size() ? set2 : set1; const std::map<uint32_t, uint32_t>& second = set1.size() > set2.size() ? set1 : set2;
+            uint32_t n = 0;
+            for (auto it = first.begin(); it != first.end() && n < 2u; ++it, ++n) { e.sig[n] = it->first; e.pos[n] = it->second; }
+            for (auto it = second.begin(); it != second.end() && n < 4u; ++it, ++n) { e.sig[n] = it->first; e.pos[n] = it->second; }
+            hist.insert(hist.begin(), e);
+        } else if (hist.size() + 1 >= par.window && !hist.empty()) {
+            // the mate sits at the back until the next pair drops it -- IN PLACE of the oldest entry, which the pop in front of this
+            // search has already taken away: nothing to undo
         }
     }
     return 0;

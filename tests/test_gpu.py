@@ -424,6 +424,44 @@ def test_device_matcher_agrees_with_the_host_window_scan(name, paired, flags):
     assert reads > 1000 and differing == 0, (reads, differing)
 
 
+@pytest.mark.parametrize("name,paired,flags", [m for m in manifest() if m[1]])
+def test_device_mate_search_agrees_with_the_host_search(name, paired, flags):
+    # fs_match_mates (paired-end bins: LzCompressorPE::CompressPair's history search, FastqCompressor.cpp:4610-4959) row for row
+    # against the host's serial search on every standard bin of the golden paired-end libraries; small histories too
+    import fastore_amd
+    for window in (None, 2, 5, 64, 1000):
+        kn = knobs_from_flags(flags)
+        if window:
+            kn["max_pair_lz_window"] = window
+        with fastore_amd.Packer(device_id=0, **kn) as p:
+            pairs, differing = p.pe_matcher_check(os.path.join(GOLDEN, name + ".in"))
+        assert pairs > 1000 and differing == 0, (window, pairs, differing)
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)), reason="reference binaries (oracle/_ref) not shipped")
+def test_device_mate_search_on_a_fresh_library_and_same_archive_either_way(tmp_path, monkeypatch):
+    # a fresh 150 000-pair library (bins of thousands of pairs: the history is full and turns over many times): rows against the
+    # host's search, and the archive with the device's searches and with the host's against the live reference
+    import fastore_amd
+    from conftest import reference_blocks
+    t = str(tmp_path)
+    binned, pe = ref_pipeline(t, "mates", 150_000, 150, 2 * 150_000 * 150 // 50, 21, True, 0, threads=8)
+    flags = ["-r", "-f256", "-c10", "-d8", "-w1024", "-W1024"]
+    subprocess.check_call([REF_DRIVER, "pack", "-i" + binned, "-o" + os.path.join(t, "ref"), "-t8"] + flags + pe)
+    want = reference_blocks(os.path.join(t, "ref"))
+    with fastore_amd.Packer(device_id=0) as p:
+        pairs, differing = p.pe_matcher_check(binned)
+        assert pairs > 50_000 and differing == 0, (pairs, differing)      # (the standard bins of such a small library hold 40 % of its pairs)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FS_DEVICE_MATES", mode)
+        with fastore_amd.Packer(device_id=0) as p:
+            p.pack_file(binned, os.path.join(t, "gpu" + mode))
+        got = reference_blocks(os.path.join(t, "gpu" + mode))
+        assert sorted(got) == sorted(want)
+        for sg in want:
+            assert got[sg] == want[sg], (mode, sg)
+
+
 @pytest.mark.parametrize("window", [2, 3, 5, 64, 65, 66, 129, 300, 1025])
 def test_device_matcher_window_sizes(window):
     # windows of one slot up to the largest the kernel takes (one thread per slot, 1 .. 16 wavefronts): ring wrap-around,

@@ -450,6 +450,34 @@ def test_matcher_table_and_trace_against_the_scalar_restatement(emu_lib, name, p
         assert reads > 1000 and differing == 0, (window, reads, differing)
 
 
+@pytest.mark.parametrize("name,paired,flags", [m for m in manifest() if m[1]])
+def test_mate_search_rows_against_the_scalar_restatement(emu_lib, name, paired, flags):
+    # paired-end bins: the pairs the front end hands to the device mate search (fs_match_mates) in walk order, and the rows the
+    # host's search traces for the parity check, against the test-only scalar history search (tests/emu/engine_emu.cpp) -- the
+    # model the kernel implements (minimizer sets of the mate's halves, entries oldest first, four stored positions each,
+    # identical mates to the back), pinned without a GPU; small histories make the ring wrap many times
+    import fastore_amd
+    for window in (None, 2, 5, 64):
+        kn = knobs_from_flags(flags)
+        if window:
+            kn["max_pair_lz_window"] = window
+        with fastore_amd.Packer(lib=emu_lib, device_id=0, **kn) as p:
+            pairs, differing = p.pe_matcher_check(os.path.join(GOLDEN, name + ".in"))
+        assert pairs > 1000 and differing == 0, (window, pairs, differing)
+
+
+@pytest.mark.parametrize("name,paired,flags", [m for m in manifest() if m[1]])
+def test_device_mate_search_is_taken_and_changes_no_byte(emu_lib, tmp_path, monkeypatch, name, paired, flags):
+    # the archive with the mate searches taken from the "device" (here: the emulation's stand-in) and with the host's search
+    import fastore_amd
+    ref = open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FS_DEVICE_MATES", mode)
+        with fastore_amd.Packer(lib=emu_lib, device_id=0, **knobs_from_flags(flags)) as p:
+            p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o" + mode)))
+        assert open(str(tmp_path / ("o" + mode)) + ".cdata", "rb").read() == ref
+
+
 @pytest.mark.parametrize("name,paired,flags", [m for m in manifest() if m[0] != "se_noheader"])
 def test_device_tokeniser_is_taken_and_changes_no_byte(emu_lib, tmp_path, monkeypatch, name, paired, flags):
     # archives with read ids packed from .b* files keep their headers packed: the IdToken / IdValue streams are written by the
