@@ -9,7 +9,7 @@
 #include "../../include/fastore_amd.h"
 #include "packer.h"
 
-struct fsgpu_ctx { fs::Context c; };
+struct fsgpu_ctx { fs::Context c; fsgpu_ctx* helper = nullptr; };      // helper: the second pipeline of a library of several batches (packSplit)
 
 static thread_local std::string g_createError;
 
@@ -115,6 +115,7 @@ void fsgpu_destroy(fsgpu_ctx* ctx)
     const bool trace = getenv("FS_TRACE") != nullptr;
     auto clk = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; };
     const double t0 = clk();
+    if (ctx->helper) { fsgpu_destroy(ctx->helper); ctx->helper = nullptr; }
     for (fsengine::MatchLane* m : ctx->c.matchLanes) fsengine::match_lane_destroy(m);
     const double t1 = clk();
     for (size_t i = 1; i < ctx->c.lanes.size(); ++i) fsengine::device_destroy(ctx->c.lanes[i]);      // lanes[0] == dev
@@ -529,10 +530,77 @@ int fsgpu_matcher_check(fsgpu_ctx* ctx, const char* inPrefix, uint64_t* reads, u
     FS_GUARD(ctx, ctx->c.matcherCheck(inPrefix, *reads, *differing));
 }
 
+// A library of several device batches (more standard-bin bases than one batch holds: tens of millions of reads) is bound by the
+// streams of its heaviest bins -- a 40 M-pair library has a 150 M-symbol quality stream, 25 s of one wavefront -- and with the
+// batches one after the other everything else waited in line behind them (round 3: 41 s, of which 27 s the first batch,
+// profiles/r03_config2_40Mpairs_trace.txt).  Such a library goes through TWO pipelines on the one device: this context packs
+// the heaviest bins (one batch), a helper context everything else, at the same time; the blocks are held, the two size
+// tables added and every pipeline writes its blocks at their places -- the path of a bin-sharded pack over two ranks, with
+// the bins dealt by weight class.  FS_SPLIT_PIPELINES=0: one pipeline as before.
+static bool wantsSplit(fsgpu_ctx* ctx, const std::string& in)
+{
+    if (ctx->c.cfg.world_size > 1) return false;
+    if (const char* e = getenv("FS_SPLIT_PIPELINES")) { if (atoi(e) == 0) return false; }
+    fs::BinFile bf; bf.open(in, ctx->c.par.minBinSize);
+    uint64_t bases = 0;
+    for (uint32_t sg : bf.stdSignatures()) bases += bf.bins().at(sg).totalRawDnaSize;
+    const uint64_t cap = ctx->c.cfg.batch_bases ? ctx->c.cfg.batch_bases : (3072ull << 20);
+    return bases > cap && bf.stdSignatures().size() >= 64;
+}
+
+static void packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& out, int verbose)
+{
+    fs::Context& a = ctx->c;
+    if (!ctx->helper) {
+        fsgpu_config hc = a.cfg;
+        hc.one_shot = 0; hc.rank = 1; hc.world_size = 2; hc.pipeline_lanes = 8;
+        hc.host_threads = std::max(1u, a.hostThreads - std::min(a.hostThreads - 1u, std::max(1u, a.hostThreads / 3u)));      // (two thirds of the host threads: it has most of the bins)
+        ctx->helper = fsgpu_create(&hc);
+        if (!ctx->helper) throw std::runtime_error(std::string("device: second pipeline: ") + fsgpu_create_error());
+    }
+    fs::Context& b = ctx->helper->c;
+    struct Keep { fs::Context& c; fsgpu_config cfg; uint32_t threads; ~Keep() { c.cfg = cfg; c.hostThreads = threads; c.splitRole = 0; } } keep{a, a.cfg, a.hostThreads};
+    // (6 + 8 coder lanes + the two matcher streams: the 16 hardware queues)
+    a.cfg.rank = 0; a.cfg.world_size = 2; a.cfg.pipeline_slices = 6; a.cfg.pipeline_lanes = 6; a.hostThreads = std::max(1u, keep.threads / 3u); a.splitRole = 1;
+    b.splitRole = 2;
+    std::string errB;
+    std::thread tb([&]() { try { b.shardPack({in}); } catch (const std::exception& e) { errB = e.what(); } });
+    std::string errA;
+    try { a.shardPack({in}); } catch (const std::exception& e) { errA = e.what(); }
+    tb.join();
+    if (!errA.empty()) throw std::runtime_error(errA);
+    if (!errB.empty()) throw std::runtime_error(errB);
+    std::vector<uint32_t> sg, sg2; std::vector<uint64_t> sa, sb;
+    a.shardTable(0, sg, sa); b.shardTable(0, sg2, sb);
+    if (sg != sg2) throw std::runtime_error("the two pipelines disagree about the archive's block table");
+    for (size_t i = 0; i < sa.size(); ++i) sa[i] += sb[i];
+    std::thread wb([&]() { try { b.shardWrite(0, out, sa); } catch (const std::exception& e) { errB = e.what(); } });
+    try { a.shardWrite(0, out, sa); } catch (const std::exception& e) { errA = e.what(); }
+    wb.join();
+    if (!errA.empty()) throw std::runtime_error(errA);
+    if (!errB.empty()) throw std::runtime_error(errB);
+    // what the helper did counts as this context's (the callers read one context's statistics)
+    a.stats.bins += b.stats.bins; a.stats.records += b.stats.records; a.stats.algorithmic_bytes += b.stats.algorithmic_bytes; a.stats.cdata_bytes += b.stats.cdata_bytes;
+    a.stats.device_batches += b.stats.device_batches; a.stats.frontend_ms = std::max(a.stats.frontend_ms, b.stats.frontend_ms);
+    a.timing.encode_ms += b.timing.encode_ms; a.timing.assemble_ms += b.timing.assemble_ms; a.timing.launches += b.timing.launches; a.timing.items += b.timing.items;
+    a.timing.ppmd_symbols += b.timing.ppmd_symbols; a.timing.rc_symbols += b.timing.rc_symbols; a.timing.restarts += b.timing.restarts; a.timing.max_restarts = std::max(a.timing.max_restarts, b.timing.max_restarts);
+    a.timing.h2d_bytes += b.timing.h2d_bytes; a.timing.gather_ms += b.timing.gather_ms; a.timing.gather_symbols += b.timing.gather_symbols; a.timing.gather_bytes += b.timing.gather_bytes; a.timing.id_strings += b.timing.id_strings;
+    for (int w = 0; w < 16; ++w) a.timing.win[w] += b.timing.win[w];
+    b.stats = fsgpu_stats(); b.timing = fsengine::BatchTiming();
+    if (verbose) {
+        fprintf(stderr, "\rParts processed: %zu (100%%) \n", sa.size());
+        char err[256] = {0};
+        if (verbose == 1 && fsgpu_print_stream_sizes(out.c_str(), err, sizeof err) != 0) throw std::runtime_error(err);
+    }
+}
+
 int fsgpu_pack_file(fsgpu_ctx* ctx, const char* inPrefix, const char* outPrefix, int verbose)
 {
     if (!ctx || !inPrefix || !outPrefix) return FSGPU_ERR_ARG;
-    FS_GUARD(ctx, ctx->c.packFiles({std::string(inPrefix)}, {std::string(outPrefix)}, verbose));
+    FS_GUARD(ctx, {
+        if (wantsSplit(ctx, inPrefix)) packSplit(ctx, inPrefix, outPrefix, verbose);
+        else ctx->c.packFiles({std::string(inPrefix)}, {std::string(outPrefix)}, verbose);
+    });
 }
 
 int fsgpu_shard_pack(fsgpu_ctx* ctx, const char* inPrefix, size_t* nBlocks)

@@ -1155,8 +1155,24 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         const auto& stdSigs = libs[l]->bf.stdSignatures();
         std::vector<uint64_t> w(stdSigs.size());
         for (uint32_t i = 0; i < stdSigs.size(); ++i) w[i] = libs[l]->bf.bins().at(stdSigs[i]).totalRecordsCount;
-        const std::vector<uint32_t> owner = shardOwners(w, world);
+        std::vector<uint32_t> owner;
+        if (splitRole != 0 && world == 2) {
+            // the heaviest bins, as many as one batch holds, are rank 0's; all the others rank 1's (the longest streams of the
+            // job start at once and run beside everything else, instead of in front of it)
+            const uint64_t cap = cfg.batch_bases ? cfg.batch_bases : (3072ull << 20);
+            std::vector<uint32_t> idx(stdSigs.size());
+            for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = i;
+            std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
+            owner.assign(stdSigs.size(), 1u);
+            uint64_t bases = 0;
+            for (uint32_t i : idx) {
+                const uint64_t add = libs[l]->bf.bins().at(stdSigs[i]).totalRawDnaSize;
+                if (bases != 0 && bases + add > cap) break;
+                owner[i] = 0u; bases += add;
+            }
+        } else owner = shardOwners(w, world);
         for (uint32_t i = 0; i < stdSigs.size(); ++i) if (owner[i] == rank) work.push_back(Work{(uint32_t)l, stdSigs[i]});
+        if (getenv("FS_TRACE")) fprintf(stderr, "[trace] library %zu: rank %u of %u (split role %u) packs %zu of %zu standard bins\n", l, rank, world, splitRole, work.size(), stdSigs.size());
     }
     haveArchive = true;
     // block 0 of every library (rank 0): merged small bins + N bin, compressed on host cores.  Its threads start when the
@@ -1441,7 +1457,7 @@ void Context::shardWrite(size_t lib, const std::string& outPrefix, const std::ve
     }
     if (cfg.rank == 0) ok = ok && ::ftruncate(fd, (off_t)off[sigs.size()]) == 0;
     if (::close(fd) != 0 || !ok) throw std::runtime_error("Cannot write " + name);
-    stats.cdata_bytes += shard.aw->dataBytes();
+    // (the held bytes were counted when they were packed: packFiles)
     if (cfg.rank == 0) shard.aw->writeMeta(outPrefix, allSizes, sigs, shard.arch.head, shard.arch.qvz);
     shard = Shard();
 }

@@ -120,6 +120,9 @@ struct Context {
     // device-side window search (matcher.hip): a matcher lane per host thread, made on first use; deviceMatcher off = host scan
     std::vector<fsengine::MatchLane*> matchLanes;
     bool deviceMatcher = true;
+    // two pipelines on one device for libraries of several batches (capi.cpp: packSplit): 0 = none, 1 = this context packs the
+    // heaviest bins (one batch's worth: their streams are the longest of the job), 2 = all the others
+    uint32_t splitRole = 0;
     struct { size_t reads = 0, seqBytes = 0, calls = 0, warm = 0; } matchReserve;     // bounds of the largest bin of the coming batch (0: grow on demand)
     std::atomic<uint64_t> matchedReads{0}, matchUs{0}, matchKernelUs{0};
     MatchFn matcherFor(uint32_t tid);

@@ -287,6 +287,20 @@ def test_gpu_pack_equals_live_reference_on_a_library_with_long_streams(tmp_path,
         assert open(os.path.join(t, "cli" + e), "rb").read() == open(os.path.join(t, "gpu" + e), "rb").read(), e
 
 
+@pytest.mark.parametrize("name,paired,flags", manifest()[:2])
+def test_gpu_library_of_several_batches_goes_through_two_pipelines(tmp_path, monkeypatch, name, paired, flags):
+    # fsgpu_pack_file on a library of more bases than a device batch holds: two pipelines on the one device (the heaviest bins /
+    # all the others), or one (FS_SPLIT_PIPELINES=0) -- the reference's archive either way
+    import fastore_amd
+    ref = open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
+    for split in ("1", "0"):
+        monkeypatch.setenv("FS_SPLIT_PIPELINES", split)
+        with fastore_amd.Packer(device_id=0, batch_bases=300_000, **knobs_from_flags(flags)) as p:
+            st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("s" + split)))
+        assert st["device_batches"] >= 2
+        assert open(str(tmp_path / ("s" + split)) + ".cdata", "rb").read() == ref, split
+
+
 @pytest.mark.skipif(not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)), reason="reference binaries (oracle/_ref) not shipped")
 def test_gpu_pack_many_batches_and_model_restarts_inside_standard_bins(tmp_path):
     # What a library of BASELINE configs[2]'s size does to the pipeline, at a size a test can afford: 3.5 M pairs with

@@ -450,6 +450,24 @@ def test_matcher_table_and_trace_against_the_scalar_restatement(emu_lib, name, p
         assert reads > 1000 and differing == 0, (window, reads, differing)
 
 
+@pytest.mark.parametrize("name,paired,flags", manifest()[:3])
+def test_library_of_several_batches_goes_through_two_pipelines(emu_lib, tmp_path, monkeypatch, name, paired, flags):
+    # more standard-bin bases than one device batch holds: fsgpu_pack_file deals the heaviest bins (one batch) to the context and
+    # all the others to a helper context, both pack at once and write their blocks at their places -- same archive as one
+    # pipeline gives, and as the reference's
+    import fastore_amd
+    ref = open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
+    for split in ("1", "0"):
+        monkeypatch.setenv("FS_SPLIT_PIPELINES", split)
+        with fastore_amd.Packer(lib=emu_lib, device_id=0, batch_bases=300_000, **knobs_from_flags(flags)) as p:
+            st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("s" + split)))
+            assert st["device_batches"] >= 2, st["device_batches"]
+            again = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("t" + split)))       # the helper context is reused
+        for o in ("s", "t"):
+            assert open(str(tmp_path / (o + split)) + ".cdata", "rb").read() == ref, (split, o)
+        assert again["bins"] == 2 * st["bins"]
+
+
 @pytest.mark.parametrize("name,paired,flags", [m for m in manifest() if m[1]])
 def test_mate_search_rows_against_the_scalar_restatement(emu_lib, name, paired, flags):
     # paired-end bins: the pairs the front end hands to the device mate search (fs_match_mates) in walk order, and the rows the
