@@ -64,6 +64,9 @@ struct Shared {
     uint8_t CharMask[256];
     uint8_t QT[260];             // QTable, tabulated once per wave
     uint32_t GlueCount, GlueCount1, restarts;   // touched only by the allocator's rare paths / model restarts: kept out of the registers
+    // the sub-allocator's free-list heads (BList[0..N_INDEXES] + one scratch head) of the two- and three-wave forms: first block of each
+    // list, 0 = empty (blk_head).  The heads' Stamp counters (SubAlloc.hpp:41-55) are never read by var.J's allocator and are not kept.
+    uint32_t blHead[N_INDEXES + 2];
     uint32_t winA[128], winM[128], winCut;      // [64..127]: spare slots for lanes that have nothing to store in a round
     uint32_t winTab[512], winMask[128];      // owner search: lowest lane per hash slot, per-owner position masks; then the successor words on their way back      // windowed hit path: per-position results, first position that must go back to the serial path
     // coder queue (two-wave form: the model wave produces, the coder wave consumes; see the range-coder section)
@@ -107,6 +110,7 @@ struct Coder {
     uint32_t pfCtx; CtxRaw pf;     // record of the next symbol's first context, requested ahead of this symbol's stores (0 = none)
     uint32_t inAhead;              // windowed path: the input has been pulled into the cache up to here
     uint32_t three;                // three-wave form: the windows are another wave's work (ppmd_scout.h)
+    uint32_t ldsHeads;             // the sub-allocator's list heads live in LDS (else behind the heap)
     uint32_t wSeq, wHintDue;       // three-wave form, serial wave: requests posted so far; the forecast of the running episode is still to be made
 };
 
@@ -192,27 +196,33 @@ FS_DEV St st_load(Coder& m, uint32_t s)
 FS_DEV void fs_reload(Coder& m) { if (m.FoundState) { const St t = st_load(m, m.FoundState); m.fsSym = t.sym; m.fsFreq = t.freq; m.fsSucc = t.succ; } }
 
 // ---------------- sub-allocator ----------------
-FS_DEV uint32_t blk_remove(Coder& m, uint32_t n)
-{ uint32_t p = B_NEXT(n); B_NEXT_SET(n, B_NEXT(p)); B_STAMP_SET(n, B_STAMP(n) - 1u); return p; }
-FS_DEV void blk_insert(Coder& m, uint32_t n, uint32_t pv, uint32_t nu)
-{ B_NEXT_SET(pv, B_NEXT(n)); B_NEXT_SET(n, pv); B_STAMP_SET(pv, 0xFFFFFFFFu); B_NU_SET(pv, nu); B_STAMP_SET(n, B_STAMP(n) + 1u); }
-FS_DEV bool blk_avail(Coder& m, uint32_t n) { return B_NEXT(n) != 0u; }
+// (list number i: BLK_NODE::remove / insert / avail of SubAlloc.hpp:41-55.  The head -- first block of the list, 0 = empty -- lives
+// in LDS in the forms that walk single long streams (m.ldsHeads: two and three waves), behind the heap in HBM in the one-wave
+// form: measured, profiles/r03_free_list_heads.txt -- a lone 7 M-symbol stream 976 -> 941 ms with the heads in LDS, but
+// 3 072 one-wave streams side by side 6.35 -> 4.43 G symbols/s, so each form keeps what suits it.)
+FS_DEV uint32_t blk_head(Coder& m, uint32_t i) { return m.ldsHeads ? FS_LDS_RD(m.sh->blHead[i]) : B_NEXT(BL(i)); }
+FS_DEV void blk_head_set(Coder& m, uint32_t i, uint32_t v) { if (m.ldsHeads) { m.sh->blHead[i] = v; FS_EMU_MEET(); } else B_NEXT_SET(BL(i), v); }
+FS_DEV uint32_t blk_remove(Coder& m, uint32_t i)
+{ const uint32_t p = blk_head(m, i); const uint32_t nx = B_NEXT(p); blk_head_set(m, i, nx); return p; }
+FS_DEV void blk_insert(Coder& m, uint32_t i, uint32_t pv, uint32_t nu)
+{ B_NEXT_SET(pv, blk_head(m, i)); blk_head_set(m, i, pv); B_STAMP_SET(pv, 0xFFFFFFFFu); B_NU_SET(pv, nu); }
+FS_DEV bool blk_avail(Coder& m, uint32_t i) { return blk_head(m, i) != 0u; }
 
 FS_DEV void SplitBlock(Coder& m, uint32_t pv, uint32_t oldI, uint32_t newI)
 {
     uint32_t i, k, UDiff = (uint32_t)kIndx2Units[oldI] - kIndx2Units[newI];
     uint32_t p = pv + 12u * kIndx2Units[newI];
     if (kIndx2Units[i = kUnits2Indx[UDiff - 1]] != UDiff) {
-        k = kIndx2Units[--i]; blk_insert(m, BL(i), p, k);
+        k = kIndx2Units[--i]; blk_insert(m, (i), p, k);
         p += 12u * k; UDiff -= k;
     }
-    blk_insert(m, BL(kUnits2Indx[UDiff - 1]), p, UDiff);
+    blk_insert(m, (kUnits2Indx[UDiff - 1]), p, UDiff);
 }
 
 FS_DEV void InitSubAllocator(Coder& m)
 {
-    // memset(BList, 0)  -- heads are 4-byte words behind the heap
-    for (uint32_t i = (uint32_t)FS_LANE(); i < 3u * (N_INDEXES + 2); i += FS_WAVE) *(fs_gptr32)(HP(BL(0)) + 4u * i) = 0u;
+    // memset(BList, 0)
+    for (uint32_t i = (uint32_t)FS_LANE(); i < (uint32_t)N_INDEXES + 2u; i += FS_WAVE) { m.sh->blHead[i] = 0u; *(fs_gptr32)(HP(BL(i)) + 4u) = 0u; }
     FS_WAVE_SYNC();
     m.pText = 1u; m.HiUnit = 1u + SA_SIZE;
     const uint32_t Diff = 12u * (SA_SIZE / 8 / UNIT_SIZE * 7);
@@ -223,23 +233,24 @@ FS_DEV_NOINLINE void GlueFreeBlocks(Coder& m)
 {
     FS_REGION(7);
     uint32_t i, k, sz, p, p0, p1;
-    const uint32_t s0 = BL(N_INDEXES + 1);
+    const uint32_t s0 = N_INDEXES + 1;                 // the scratch list
     if (m.LoUnit != m.HiUnit) fs_st8(HP(m.LoUnit), 0);
-    p0 = s0; B_NEXT_SET(s0, 0); B_STAMP_SET(s0, 0); B_NU_SET(s0, 0);
+    p0 = 0; blk_head_set(m, s0, 0u);                   // p0 = 0: the next block goes in right behind the head
     for (i = 0; i <= N_INDEXES; i++)
-        while (blk_avail(m, BL(i))) {
-            p = blk_remove(m, BL(i));
+        while (blk_avail(m, (i))) {
+            p = blk_remove(m, (i));
             if (!B_NU(p)) continue;
             while (B_STAMP(p1 = p + 12u * B_NU(p)) == 0xFFFFFFFFu) { B_NU_SET(p, B_NU(p) + B_NU(p1)); B_NU_SET(p1, 0); }
-            B_NEXT_SET(p, B_NEXT(p0)); B_NEXT_SET(p0, p);
+            if (p0 == 0u) { B_NEXT_SET(p, blk_head(m, s0)); blk_head_set(m, s0, p); }
+            else { B_NEXT_SET(p, B_NEXT(p0)); B_NEXT_SET(p0, p); }
             p0 = p;
         }
     while (blk_avail(m, s0)) {
         p = blk_remove(m, s0); sz = B_NU(p);
         if (!sz) continue;
-        for (; sz > 128; sz -= 128, p += 12u * 128) blk_insert(m, BL(N_INDEXES - 1), p, 128);
-        if (kIndx2Units[i = kUnits2Indx[sz - 1]] != sz) { k = sz - kIndx2Units[--i]; blk_insert(m, BL(k - 1), p + 12u * (sz - k), k); }
-        blk_insert(m, BL(i), p, kIndx2Units[i]);
+        for (; sz > 128; sz -= 128, p += 12u * 128) blk_insert(m, (N_INDEXES - 1), p, 128);
+        if (kIndx2Units[i = kUnits2Indx[sz - 1]] != sz) { k = sz - kIndx2Units[--i]; blk_insert(m, (k - 1), p + 12u * (sz - k), k); }
+        blk_insert(m, (i), p, kIndx2Units[i]);
     }
     { const uint32_t g1 = FS_LDS_RD(m.sh->GlueCount1); m.sh->GlueCount = 1u << (13 + g1); m.sh->GlueCount1 = g1 + 1u; }
 }
@@ -253,14 +264,14 @@ FS_DEV_NOINLINE uint32_t AllocUnitsRare(Coder& m, uint32_t indx)
             const uint32_t gc = FS_LDS_RD(m.sh->GlueCount); m.sh->GlueCount = gc - 1u;
             if (!gc) {
                 GlueFreeBlocks(m);
-                if (blk_avail(m, BL(i = indx))) return blk_remove(m, BL(i));
+                if (blk_avail(m, (i = indx))) return blk_remove(m, (i));
             } else {
                 i = 12u * kIndx2Units[indx];
                 return (m.UnitsStart - m.pText > i) ? (m.UnitsStart -= i) : 0u;
             }
         }
-    } while (!blk_avail(m, BL(i)));
-    uint32_t r = blk_remove(m, BL(i)); SplitBlock(m, r, i, indx);
+    } while (!blk_avail(m, (i)));
+    uint32_t r = blk_remove(m, (i)); SplitBlock(m, r, i, indx);
     return r;
 }
 
@@ -268,7 +279,7 @@ FS_DEV uint32_t AllocUnits(Coder& m, uint32_t NU)
 {
     FS_REGION(6);
     uint32_t indx = kUnits2Indx[NU - 1];
-    if (blk_avail(m, BL(indx))) return blk_remove(m, BL(indx));
+    if (blk_avail(m, (indx))) return blk_remove(m, (indx));
     uint32_t r = m.LoUnit; m.LoUnit += 12u * kIndx2Units[indx];
     if (m.LoUnit <= m.HiUnit) return r;
     m.LoUnit -= 12u * kIndx2Units[indx]; return AllocUnitsRare(m, indx);
@@ -278,7 +289,7 @@ FS_DEV uint32_t AllocContext(Coder& m)
 {
     FS_REGION(6);
     if (m.HiUnit != m.LoUnit) return (m.HiUnit -= UNIT_SIZE);
-    return blk_avail(m, BL(0)) ? blk_remove(m, BL(0)) : AllocUnitsRare(m, 0);
+    return blk_avail(m, (0)) ? blk_remove(m, (0)) : AllocUnitsRare(m, 0);
 }
 
 FS_DEV uint32_t ExpandUnits(Coder& m, uint32_t oldPtr, uint32_t oldNU)
@@ -287,7 +298,7 @@ FS_DEV uint32_t ExpandUnits(Coder& m, uint32_t oldPtr, uint32_t oldNU)
     uint32_t i0 = kUnits2Indx[oldNU - 1], i1 = kUnits2Indx[oldNU - 1 + 1];
     if (i0 == i1) return oldPtr;
     uint32_t ptr = AllocUnits(m, oldNU + 1);
-    if (ptr) { fs_wave_copy4(HP(ptr), HP(oldPtr), 12u * oldNU); blk_insert(m, BL(i0), oldPtr, oldNU); }
+    if (ptr) { fs_wave_copy4(HP(ptr), HP(oldPtr), 12u * oldNU); blk_insert(m, (i0), oldPtr, oldNU); }
     return ptr;
 }
 
@@ -296,16 +307,16 @@ FS_DEV uint32_t ShrinkUnits(Coder& m, uint32_t oldPtr, uint32_t oldNU, uint32_t 
     FS_REGION(6);
     uint32_t i0 = kUnits2Indx[oldNU - 1], i1 = kUnits2Indx[newNU - 1];
     if (i0 == i1) return oldPtr;
-    if (blk_avail(m, BL(i1))) {
-        uint32_t ptr = blk_remove(m, BL(i1)); fs_wave_copy4(HP(ptr), HP(oldPtr), 12u * newNU);
-        blk_insert(m, BL(i0), oldPtr, kIndx2Units[i0]);
+    if (blk_avail(m, (i1))) {
+        uint32_t ptr = blk_remove(m, (i1)); fs_wave_copy4(HP(ptr), HP(oldPtr), 12u * newNU);
+        blk_insert(m, (i0), oldPtr, kIndx2Units[i0]);
         return ptr;
     }
     SplitBlock(m, oldPtr, i0, i1); return oldPtr;
 }
 
 FS_DEV void FreeUnits(Coder& m, uint32_t ptr, uint32_t NU)
-{ uint32_t indx = kUnits2Indx[NU - 1]; blk_insert(m, BL(indx), ptr, kIndx2Units[indx]); }
+{ uint32_t indx = kUnits2Indx[NU - 1]; blk_insert(m, (indx), ptr, kIndx2Units[indx]); }
 
 // ---------------- range coder ----------------
 // The carry-less coder of Coder.hpp:7-28.  One-wave form: the walking wave codes as it goes.  Two-wave form
@@ -1003,6 +1014,7 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
 {
     Coder m;
     m.three = three ? 1u : 0u; m.wSeq = 0u; m.wHintDue = 0u;
+    m.ldsHeads = queued ? 1u : 0u;
     m.hb = arena - 1; m.sh = sh; m.out = out; m.outCap = outCap; m.outPos = 0; sh->restarts = 0;
     m.queued = queued ? 1u : 0u; m.qTail = qTail; m.qHeadSeen = qTail;
     m.inAhead = 0;

@@ -51,7 +51,7 @@ typedef struct fsgpu_config {
     uint32_t host_threads;              /* worker threads of the host stages (0 = all cores) */
     uint32_t max_waves;                 /* resident coder wavefronts (0 = 12 per CU = 3 per SIMD, memory permitting) */
     uint64_t batch_bases;               /* bases per device batch (0 = default) */
-    uint32_t rank, world_size;          /* bin sharding: this context packs bins i with i % world_size == rank */
+    uint32_t rank, world_size;          /* bin sharding: this context packs its share of the standard bins -- longest-processing-time-first over the .bmeta record totals, the same table on every rank (packer.cpp: shardOwners); block 0 is rank 0's */
     uint32_t pipeline_slices;           /* slices a batch is cut into so that host front end and device overlap (0 = default 8, 1 = off) */
     uint32_t pipeline_lanes;            /* engine instances (HIP streams) whose kernels may overlap on the GPU (0 = one per slice, at most 8) */
     uint32_t one_shot;       /* 1: the context packs once and is destroyed (the CLI): its device is made on a thread of its own (a missing
@@ -99,8 +99,8 @@ typedef struct fsgpu_stats {
     uint64_t h2d_bytes, d2h_bytes;
     uint64_t bins, records, algorithmic_bytes;      /* 2*(seq+aux)+head per record + block bytes */
     uint64_t block0_records, block0_bytes, cdata_bytes;
-    /* standard-bin PPMd streams that the scheduler gave to idle host cores (same coder core, one lane -- what block 0
-     * always does) because they were predicted to outlast the balanced device step; 0 unless host_residue is enabled */
+    /* always 0: no standard-bin stream is ever coded on the host (there is no CPU fallback for the device stages; the fields stay
+     * for the layout's sake and so that a caller can assert it) */
     uint64_t host_coded_symbols, host_coded_streams;
     /* windowed PPMd hit path (ppmd_window.h): window attempts, windows coded, symbols coded inside windows (of
      * ppmd_symbols), rounds (positions sharing a context are processed one rank per round), windows redone shorter */

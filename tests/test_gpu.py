@@ -279,7 +279,7 @@ def test_gpu_pack_equals_live_reference_on_a_library_with_long_streams(tmp_path,
     # the longest quality stream of the library: records of the largest standard block x 150 (x 2 mates)
     biggest = max(struct.unpack_from(">Q", b, 4)[0] for sg, b in got.items() if sg != max(sigs))
     assert biggest * 150 * (2 if paired else 1) > (2 << 20), biggest
-    assert st["host_coded_symbols"] == 0          # everything above ran on the device (host_residue is off by default)
+    assert st["host_coded_symbols"] == 0          # every standard-bin stream above was coded on the device
     # the same library through the CLI: a ONE-SHOT context (lanes and staging buffers made beside the front end, matcher
     # lanes by their threads, pageable staging, archive pages reserved ahead, no teardown) must write the same archive
     subprocess.check_call([fastore_amd.PACK_CLI, "e", "-i" + binned, "-o" + os.path.join(t, "cli")] + flags + pe)
