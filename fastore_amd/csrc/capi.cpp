@@ -2,6 +2,7 @@
 #include <stdlib.h>
 #include <sched.h>
 #include <string.h>
+#include <unistd.h>
 #include <stdexcept>
 #include <string>
 #include <future>
@@ -116,6 +117,7 @@ void fsgpu_destroy(fsgpu_ctx* ctx)
     auto clk = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; };
     const double t0 = clk();
     if (ctx->helper) { fsgpu_destroy(ctx->helper); ctx->helper = nullptr; }
+    for (const std::string& n : ctx->c.stealNames) (void)unlink(n.c_str());      // (the node's work counters of the last sharded packs)
     for (fsengine::MatchLane* m : ctx->c.matchLanes) fsengine::match_lane_destroy(m);
     const double t1 = clk();
     for (size_t i = 1; i < ctx->c.lanes.size(); ++i) fsengine::device_destroy(ctx->c.lanes[i]);      // lanes[0] == dev
@@ -684,7 +686,8 @@ int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out)
     out->tokenised_ids = ctx->c.timing.id_strings; out->matcher_reads = ctx->c.matchedReads.load(); out->matcher_call_ms = ctx->c.matchUs.load() / 1e3; out->matcher_kernel_ms = ctx->c.matchKernelUs.load() / 1e3;
     out->gather_kernel_ms = ctx->c.timing.gather_ms; out->gather_symbols = ctx->c.timing.gather_symbols; out->gather_bytes = ctx->c.timing.gather_bytes;
     out->rc_symbols = ctx->c.timing.rc_symbols; out->ppmd_restarts = ctx->c.timing.restarts; out->ppmd_max_restarts = ctx->c.timing.max_restarts;
-    out->ppmd_windows_ahead = ctx->c.timing.win[8]; out->ppmd_windows_ahead_in_vain = ctx->c.timing.win[9];       // (-DFS_WIN_PROFILE builds of the kernels keep phase clocks in these two slots instead) out->h2d_bytes = ctx->c.timing.h2d_bytes; out->d2h_bytes = ctx->c.timing.d2h_bytes;
+    out->ppmd_windows_ahead = ctx->c.timing.win[8]; out->ppmd_windows_ahead_in_vain = ctx->c.timing.win[9];       // (-DFS_WIN_PROFILE builds of the kernels keep phase clocks in these two slots instead)
+    out->h2d_bytes = ctx->c.timing.h2d_bytes; out->d2h_bytes = ctx->c.timing.d2h_bytes;
     return FSGPU_OK;
 }
 

@@ -1123,6 +1123,47 @@ void Context::compressRawBlock(Batch& batch, const ArchiveParams& arch, std::vec
 }
 
 // ------------------------------------------------------------------------------------------------
+// The work-stealing tail of a bin-sharded pack ("LPT-greedy over G GPUs with a work-stealing tail (atomic next-bin
+// counter per node)").  The heaviest bins -- all but the lightest `kTailPercent` of the records -- are dealt up front by
+// shardOwners; the rest is cut into chunks that the ranks claim from ONE counter as they run out of work.  The counter is a
+// 64-byte file in /dev/shm that every rank of the job maps: named by what the ranks of one job share and another job does not --
+// the launcher's process id (the ranks of torch.distributed.run are its children; contexts inside one process: that
+// process), the libraries' names, and how many sharded packs the context has made.  Which rank packs a block never shows in
+// the archive; that EVERY block was packed by exactly one rank is checked when the size tables come together (shardWrite).
+namespace {
+enum : uint32_t { kTailPercent = 15, kChunksPerRank = 4 };
+struct StealCounter {
+    std::atomic<uint32_t>* p = nullptr; int fd = -1; std::string name;
+    // what the ranks of one job share and another job does not: FS_STEAL_KEY (fastore_amd/shard.py broadcasts a random number once
+    // per job; fastore_pack -G, whose contexts live in one process, sets its process id), else torch.distributed's rendezvous
+    // (MASTER_ADDR : MASTER_PORT).  Neither: no tail -- every bin is dealt up front, as before.
+    static std::string fileName(const std::vector<std::string>& prefixes, uint32_t seq)
+    {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const char* s) { for (; s && *s; ++s) { h ^= (unsigned char)*s; h *= 1099511628211ull; } h ^= 0xFFu; h *= 1099511628211ull; };
+        for (const std::string& s : prefixes) mix(s.c_str());
+        if (const char* k = getenv("FS_STEAL_KEY")) { mix("key"); mix(k); }
+        else if (getenv("MASTER_PORT")) { mix("rdzv"); mix(getenv("MASTER_ADDR")); mix(getenv("MASTER_PORT")); }
+        char buf[96]; snprintf(buf, sizeof buf, "/dev/shm/fastore_steal.%016llx.%u", (unsigned long long)h, seq);
+        return buf;
+    }
+    bool open(const std::vector<std::string>& prefixes, uint32_t seq)
+    {
+        name = fileName(prefixes, seq);
+        fd = ::open(name.c_str(), O_CREAT | O_RDWR, 0600);
+        if (fd < 0) return false;
+        if (ftruncate(fd, 64) != 0) { ::close(fd); fd = -1; return false; }          // (new bytes read as zero; a file that is there keeps its count)
+        void* m = mmap(nullptr, 64, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) { ::close(fd); fd = -1; return false; }
+        p = (std::atomic<uint32_t>*)m;
+        return true;
+    }
+    uint32_t claim() { return p->fetch_add(1u, std::memory_order_relaxed); }
+    ~StealCounter() { if (p) munmap((void*)p, 64); if (fd >= 0) ::close(fd); }
+};
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
 void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::vector<std::string>& outPrefixes, int verbose, bool hold)
 {
     const double tStart = nowMs();
@@ -1151,7 +1192,18 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         if (hold) L.aw.startInMemory(archives[l].cfg);
         else L.aw.start(world > 1 ? outPrefixes[l] + ".part" + std::to_string(rank) : outPrefixes[l], archives[l].cfg);
     });
+    // the tail's chunks of all libraries: [library l's chunks at l * nChunks ...); claimed in this order by every rank
+    StealCounter steal;
+    const bool wantSteal = world > 1 && splitRole == 0 && !(getenv("FS_STEAL") && atoi(getenv("FS_STEAL")) == 0) && (getenv("FS_STEAL_KEY") || getenv("MASTER_PORT"));
+    if (wantSteal) {
+        if (!steal.open(inPrefixes, stealSeq)) throw std::runtime_error("Cannot open the node's work counter in /dev/shm");
+        stealNames.push_back(steal.name);
+        while (stealNames.size() > 2) { (void)unlink(stealNames.front().c_str()); stealNames.erase(stealNames.begin()); }      // (every rank has long opened a counter two packs old)
+        ++stealSeq;
+    }
+    std::vector<std::vector<Work>> tail(steal.p ? nLibs * world * kChunksPerRank : 0);
     for (size_t l = 0; l < nLibs; ++l) {
+        const size_t chunkBase = l * world * kChunksPerRank;
         const auto& stdSigs = libs[l]->bf.stdSignatures();
         std::vector<uint64_t> w(stdSigs.size());
         for (uint32_t i = 0; i < stdSigs.size(); ++i) w[i] = libs[l]->bf.bins().at(stdSigs[i]).totalRecordsCount;
@@ -1170,6 +1222,20 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                 if (bases != 0 && bases + add > cap) break;
                 owner[i] = 0u; bases += add;
             }
+        } else if (steal.p) {
+            // head: all but the lightest kTailPercent of the records, dealt by shardOwners; tail: chunks, dealt round robin by weight
+            std::vector<uint32_t> idx(stdSigs.size());
+            for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = i;
+            std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
+            uint64_t total = 0, acc = 0; for (uint64_t v : w) total += v;
+            size_t headN = idx.size();
+            for (size_t k = idx.size(); k-- > 0;) { acc += w[idx[k]]; if (acc * 100u > total * kTailPercent) break; headN = k; }
+            std::vector<uint64_t> hw(headN); for (size_t k = 0; k < headN; ++k) hw[k] = w[idx[k]];
+            const std::vector<uint32_t> ho = shardOwners(hw, world);
+            owner.assign(stdSigs.size(), ~0u);
+            for (size_t k = 0; k < headN; ++k) owner[idx[k]] = ho[k];
+            const uint32_t nChunks = world * kChunksPerRank;
+            for (size_t k = headN; k < idx.size(); ++k) tail[(chunkBase + (k - headN) % nChunks)].push_back(Work{(uint32_t)l, stdSigs[idx[k]]});
         } else owner = shardOwners(w, world);
         for (uint32_t i = 0; i < stdSigs.size(); ++i) if (owner[i] == rank) work.push_back(Work{(uint32_t)l, stdSigs[i]});
         if (getenv("FS_TRACE")) fprintf(stderr, "[trace] library %zu: rank %u of %u (split role %u) packs %zu of %zu standard bins\n", l, rank, world, splitRole, work.size(), stdSigs.size());
@@ -1235,8 +1301,24 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         L.pending.clear();
     };
     Batch& batch = workBatch; std::vector<uint32_t> binArch; size_t next = 0, done = 0;
+    // the tail: one more chunk whenever what is left of this rank's work fits one batch (ranks that are behind do not ask)
+    bool tailOpen = steal.p != nullptr; uint64_t stolenBins = 0;
+    auto claimChunk = [&]() {
+        if (!tailOpen) return;
+        uint64_t left = 0;
+        for (size_t k = next; k < work.size() && left <= budget; ++k) left += libs[work[k].lib]->bf.bins().at(work[k].sig).totalRawDnaSize;
+        if (left > budget) return;
+        for (;;) {                                                  // (empty chunks -- tiny libraries -- are stepped over)
+            const uint32_t c = steal.claim();
+            if (c >= tail.size()) { tailOpen = false; return; }
+            if (tail[c].empty()) continue;
+            for (const Work& w : tail[c]) work.push_back(w);
+            stolenBins += tail[c].size(); stats.stolen_bins += tail[c].size();
+            return;
+        }
+    };
     try {
-        while (next < work.size()) {
+        for (claimChunk(); next < work.size(); claimChunk()) {
             batch.clear(); binArch.clear();
             double tio = nowMs();
             // choose the bins of this batch by their (known) unpacked size, unpack them in parallel, then concatenate
@@ -1291,7 +1373,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             std::vector<Batch> graph(nb);                              // per bin: its stored graph (node indices local to it)
             for (size_t k = first; k < next; ++k) binArch.push_back(work[k].lib);
             stats.io_ms += nowMs() - tio;
-            const bool lastBatchNow = next >= work.size();
+            const bool lastBatchNow = next >= work.size() && !tailOpen;
             // what the archives will hold at the end, roughly: what they hold, what is pending, block 0 and a quarter of this
             // batch's staged bytes (PPMd on quality scores) -- their page-cache pages are made while the device works
             std::vector<uint64_t> aheadBytes(nLibs, 0);
@@ -1327,7 +1409,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                 graph[k] = Batch();
             });
             const double tRoute = nowMs();
-            const bool lastBatch = next >= work.size();
+            const bool lastBatch = lastBatchNow;
             if (!lastBatch) {
                 for (size_t b = 0; b < nb;) {                          // route the blocks to their libraries (runs of equal lib)
                     const uint32_t l = binArch[b]; Lib::Pending p;
@@ -1442,7 +1524,12 @@ void Context::shardWrite(size_t lib, const std::string& outPrefix, const std::ve
     shardTable(lib, sigs, own);
     if (allSizes.size() != sigs.size()) throw std::runtime_error("size table does not match the archive's block table");
     std::vector<uint64_t> off(sigs.size() + 1, 0);
-    for (size_t i = 0; i < sigs.size(); ++i) { if (own[i] && own[i] != allSizes[i]) throw std::runtime_error("size table disagrees with the held blocks"); off[i + 1] = off[i] + allSizes[i]; }
+    for (size_t i = 0; i < sigs.size(); ++i) {
+        if (own[i] && own[i] != allSizes[i]) throw std::runtime_error("size table disagrees with the held blocks");
+        // (a block is never empty: its header alone is 42 bytes -- a zero here is a bin that no rank packed)
+        if (allSizes[i] == 0) throw std::runtime_error("size table: a block of the archive was packed by no rank");
+        off[i + 1] = off[i] + allSizes[i];
+    }
     // O_CREAT without O_TRUNC and positional writes: the ranks need no order among themselves (nobody cuts the file below
     // its final size; rank 0 cuts a longer file of an earlier run down to it)
     const std::string name = outPrefix + ".cdata";

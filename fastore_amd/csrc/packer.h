@@ -123,6 +123,10 @@ struct Context {
     // two pipelines on one device for libraries of several batches (capi.cpp: packSplit): 0 = none, 1 = this context packs the
     // heaviest bins (one batch's worth: their streams are the longest of the job), 2 = all the others
     uint32_t splitRole = 0;
+    // bin-sharded packs (world_size > 1): the lightest bins are not dealt up front but claimed, a chunk at a time, by whichever rank
+    // runs out of work first -- a counter the ranks of the node share (packer.cpp: StealCounter).  Calls so far: names the counter.
+    uint32_t stealSeq = 0;
+    std::vector<std::string> stealNames;          // the counters of the last packs (files in /dev/shm: taken away two packs later, and with the context)
     struct { size_t reads = 0, seqBytes = 0, calls = 0, warm = 0; } matchReserve;     // bounds of the largest bin of the coming batch (0: grow on demand)
     std::atomic<uint64_t> matchedReads{0}, matchUs{0}, matchKernelUs{0};
     MatchFn matcherFor(uint32_t tid);

@@ -117,6 +117,7 @@ typedef struct fsgpu_stats {
     /* three-wave form of the coder kernel (ppmd_scout.h): windows prepared by the window wave AHEAD of the serial walk and
      * used / prepared in vain (forecast unusable, or the serial walk touched one of the window's contexts) */
     uint64_t ppmd_windows_ahead, ppmd_windows_ahead_in_vain;
+    uint64_t stolen_bins;                /* bin-sharded packs: bins of the job's work-stealing tail that this rank claimed (the lightest 15 % of the records are not dealt up front) */
 } fsgpu_stats;
 
 void fsgpu_config_defaults(fsgpu_config* cfg);

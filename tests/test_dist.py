@@ -21,6 +21,7 @@ lib = fastore_amd.load_library(os.path.join(sys.argv[1], "build", "libfastore_em
 knobs = eval(sys.argv[7])
 with fastore_amd.Packer(lib=lib, host_threads=2, rank=dist.get_rank(), world_size=dist.get_world_size(), **knobs) as p:
     shard.pack_sharded(p, sys.argv[5], sys.argv[6], dist)
+    open(sys.argv[6] + ".stolen%d" % dist.get_rank(), "w").write("%d %d" % (p.stats()["stolen_bins"], p.stats()["bins"]))
 dist.destroy_process_group()
 '''
 
@@ -37,6 +38,11 @@ def test_sharded_pack_equals_single_writer(emu_lib, tmp_path, name, world):
         assert p.wait(timeout=300) == 0
     assert_same_archive(str(tmp_path / "o"), os.path.join(GOLDEN, name + ".ref"))
     assert not [f for f in os.listdir(tmp_path) if ".part" in f]
+    # the work-stealing tail: the lightest bins were claimed from the node's counter (by whichever ranks asked first), every
+    # bin was packed exactly once (the archive above), and the counter's file is gone with the contexts
+    got = [tuple(int(x) for x in open(str(tmp_path / "o") + ".stolen%d" % r).read().split()) for r in range(world)]
+    assert sum(s for s, _ in got) > 10 and all(b > 0 for _, b in got), got
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("fastore_steal.")]
 
 
 WORKER_SET = r'''
