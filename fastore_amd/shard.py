@@ -12,14 +12,17 @@ import os
 import numpy as np
 
 
-def _job_key(dist):
+def _job_key(dist, device=None):
     """The ranks of a job claim the lightest bins from one counter in /dev/shm (the work-stealing tail of the split, packer.cpp:
     StealCounter); its name must be the job's own: a random number from rank 0, broadcast ONCE per job (control plane -- the data
     path's collective stays the one all-reduce of the size table per pack).  FS_STEAL_KEY set by the launcher is kept."""
     if "FS_STEAL_KEY" not in os.environ:
-        box = [os.urandom(8).hex() if dist.get_rank() == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        os.environ["FS_STEAL_KEY"] = box[0]
+        import torch
+        t = torch.tensor([int.from_bytes(os.urandom(7), "little")], dtype=torch.int64)       # (a plain tensor: the same call under RCCL and gloo)
+        if device is not None:
+            t = t.to(device)
+        dist.broadcast(t, src=0)
+        os.environ["FS_STEAL_KEY"] = "%x" % int(t.item())
 
 
 
@@ -27,7 +30,7 @@ def pack_sharded(packer, in_prefix, out_prefix, dist, device=None):
     """packer: fastore_amd.Packer created with rank=dist.get_rank(), world_size=dist.get_world_size().
     device: torch device of the collective's tensor (the rank's GPU under nccl = RCCL; None = CPU for gloo)."""
     import torch
-    _job_key(dist)
+    _job_key(dist, device)
     _, sizes = packer.shard_pack(in_prefix)
     t = torch.from_numpy(sizes.astype(np.int64))
     if device is not None:
@@ -44,7 +47,7 @@ def pack_sharded_set(packer, in_prefixes, out_prefixes, dist, device=None):
     pipeline (so a rank's long streams of all libraries overlap), then the same exchange: ONE all-reduce over the
     concatenated block-size tables, positional writes per library.  Returns the total .cdata bytes."""
     import torch
-    _job_key(dist)
+    _job_key(dist, device)
     tables = packer.shard_pack_set(list(in_prefixes))
     cat = np.concatenate([t[1].astype(np.int64) for t in tables]) if tables else np.zeros(0, dtype=np.int64)
     t = torch.from_numpy(cat)
