@@ -78,6 +78,7 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
     c.hostCores = std::max(1u, usableCores() / localRanks);
     c.hostThreads = cfg->host_threads ? cfg->host_threads : std::max(localRanks > 1 ? 4u : 1u, std::min(24u, share));
     if (getenv("FS_HOST_THREADS")) c.hostThreads = std::max(1, atoi(getenv("FS_HOST_THREADS")));     // experiments
+    if (getenv("FS_BATCH_BASES") && atoll(getenv("FS_BATCH_BASES")) > 0) c.cfg.batch_bases = (uint64_t)atoll(getenv("FS_BATCH_BASES"));      // (tests: small device batches)
     if (getenv("FS_PIPELINE_SLICES") && atoi(getenv("FS_PIPELINE_SLICES")) > 0) c.cfg.pipeline_slices = (uint32_t)atoi(getenv("FS_PIPELINE_SLICES"));
     if (getenv("FS_PIPELINE_LANES") && atoi(getenv("FS_PIPELINE_LANES")) > 0) c.cfg.pipeline_lanes = (uint32_t)atoi(getenv("FS_PIPELINE_LANES"));
     if (getenv("FS_DEVICE_MATCHER") && atoi(getenv("FS_DEVICE_MATCHER")) == 0) c.deviceMatcher = false;       // A/B runs: the host window scan

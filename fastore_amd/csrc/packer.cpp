@@ -1381,6 +1381,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                 for (uint32_t k = 0; k < nb; ++k) aheadBytes[work[first + k].lib] += stageEstimate[k] / 4;
                 for (size_t l = 0; l < nLibs; ++l) {
                     Lib& L = *libs[l];
+                    std::lock_guard<std::mutex> lk(L.awMx);                      // (block 0's thread may be putting its block at the archive's head right now)
                     uint64_t have = L.aw.dataBytes() + (24u << 20);             // (+ block 0 and slack; what does not fit is written behind the extent)
                     for (const Lib::Pending& pd : L.pending) have += pd.data.size();
                     aheadBytes[l] += have;
