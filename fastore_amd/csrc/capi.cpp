@@ -10,7 +10,7 @@
 #include "../../include/fastore_amd.h"
 #include "packer.h"
 
-struct fsgpu_ctx { fs::Context c; fsgpu_ctx* helper = nullptr; };      // helper: the second pipeline of a library of several batches (packSplit)
+struct fsgpu_ctx { fs::Context c; std::vector<fsgpu_ctx*> helpers; };      // helpers: the further pipelines of a library of several batches (packSplit)
 
 static thread_local std::string g_createError;
 
@@ -117,7 +117,8 @@ void fsgpu_destroy(fsgpu_ctx* ctx)
     const bool trace = getenv("FS_TRACE") != nullptr;
     auto clk = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; };
     const double t0 = clk();
-    if (ctx->helper) { fsgpu_destroy(ctx->helper); ctx->helper = nullptr; }
+    for (fsgpu_ctx* h : ctx->helpers) fsgpu_destroy(h);
+    ctx->helpers.clear();
     for (const std::string& n : ctx->c.stealNames) (void)unlink(n.c_str());      // (the node's work counters of the last sharded packs)
     for (fsengine::MatchLane* m : ctx->c.matchLanes) fsengine::match_lane_destroy(m);
     const double t1 = clk();
@@ -540,58 +541,81 @@ int fsgpu_matcher_check(fsgpu_ctx* ctx, const char* inPrefix, uint64_t* reads, u
 // the heaviest bins (one batch), a helper context everything else, at the same time; the blocks are held, the two size
 // tables added and every pipeline writes its blocks at their places -- the path of a bin-sharded pack over two ranks, with
 // the bins dealt by weight class.  FS_SPLIT_PIPELINES=0: one pipeline as before.
-static bool wantsSplit(fsgpu_ctx* ctx, const std::string& in)
+static uint32_t wantsSplit(fsgpu_ctx* ctx, const std::string& in)      // 0: one pipeline; else how many
 {
-    if (ctx->c.cfg.world_size > 1) return false;
-    if (const char* e = getenv("FS_SPLIT_PIPELINES")) { if (atoi(e) == 0) return false; }
+    if (ctx->c.cfg.world_size > 1) return 0;
+    uint32_t most = 3;
+    if (const char* e = getenv("FS_SPLIT_PIPELINES")) { if (atoi(e) == 0) return 0; if (atoi(e) >= 2) most = std::min(3, atoi(e)); }
     fs::BinFile bf; bf.open(in, ctx->c.par.minBinSize);
     uint64_t bases = 0;
     for (uint32_t sg : bf.stdSignatures()) bases += bf.bins().at(sg).totalRawDnaSize;
     const uint64_t cap = ctx->c.cfg.batch_bases ? ctx->c.cfg.batch_bases : (3072ull << 20);
-    return bases > cap && bf.stdSignatures().size() >= 64;
+    if (!(bases > cap && bf.stdSignatures().size() >= 64)) return 0;
+    return bases > 2 * cap ? most : 2u;
 }
 
-static void packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& out, int verbose)
+// pipelines: 2 (two device batches) or 3 (more): the context takes the heaviest batch's worth of bins, the first helper the next
+// batch's worth (three pipelines), the last helper everything else.  (Measured at 60 M pairs with two: the helper's OWN batches
+// ran one after the other, 16.9 + 8.0 + 5.9 + 3.6 + 1.7 s beside the context's 26.7 s.)
+static void packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& out, int verbose, uint32_t pipelines)
 {
     fs::Context& a = ctx->c;
-    if (!ctx->helper) {
+    const uint32_t T = a.hostThreads;
+    // coder lanes: the two matcher streams and all pipelines' lanes share the 16 hardware queues
+    const uint32_t lanesOf[2][3] = {{6, 8, 0}, {4, 4, 6}};
+    const uint32_t* lanes = lanesOf[pipelines == 3 ? 1 : 0];
+    const uint32_t want = pipelines - 1;
+    while (ctx->helpers.size() < want) {
         fsgpu_config hc = a.cfg;
-        hc.one_shot = 0; hc.rank = 1; hc.world_size = 2; hc.pipeline_lanes = 8;
-        hc.host_threads = std::max(1u, a.hostThreads - std::min(a.hostThreads - 1u, std::max(1u, a.hostThreads / 3u)));      // (two thirds of the host threads: it has most of the bins)
-        ctx->helper = fsgpu_create(&hc);
-        if (!ctx->helper) throw std::runtime_error(std::string("device: second pipeline: ") + fsgpu_create_error());
+        hc.one_shot = 0; hc.world_size = 1; hc.rank = 0; hc.host_threads = 1;      // (set for each pack below)
+        fsgpu_ctx* h = fsgpu_create(&hc);
+        if (!h) throw std::runtime_error(std::string("device: pipeline ") + std::to_string(ctx->helpers.size() + 2) + ": " + fsgpu_create_error());
+        ctx->helpers.push_back(h);
     }
-    fs::Context& b = ctx->helper->c;
-    struct Keep { fs::Context& c; fsgpu_config cfg; uint32_t threads; ~Keep() { c.cfg = cfg; c.hostThreads = threads; c.splitRole = 0; } } keep{a, a.cfg, a.hostThreads};
-    // (6 + 8 coder lanes + the two matcher streams: the 16 hardware queues)
-    a.cfg.rank = 0; a.cfg.world_size = 2; a.cfg.pipeline_slices = 6; a.cfg.pipeline_lanes = 6; a.hostThreads = std::max(1u, keep.threads / 3u); a.splitRole = 1;
-    b.splitRole = 2;
-    std::string errB;
-    std::thread tb([&]() { try { b.shardPack({in}); } catch (const std::exception& e) { errB = e.what(); } });
-    std::string errA;
-    try { a.shardPack({in}); } catch (const std::exception& e) { errA = e.what(); }
-    tb.join();
-    if (!errA.empty()) throw std::runtime_error(errA);
-    if (!errB.empty()) throw std::runtime_error(errB);
-    std::vector<uint32_t> sg, sg2; std::vector<uint64_t> sa, sb;
-    a.shardTable(0, sg, sa); b.shardTable(0, sg2, sb);
-    if (sg != sg2) throw std::runtime_error("the two pipelines disagree about the archive's block table");
-    for (size_t i = 0; i < sa.size(); ++i) sa[i] += sb[i];
-    std::thread wb([&]() { try { b.shardWrite(0, out, sa); } catch (const std::exception& e) { errB = e.what(); } });
-    try { a.shardWrite(0, out, sa); } catch (const std::exception& e) { errA = e.what(); }
-    wb.join();
-    if (!errA.empty()) throw std::runtime_error(errA);
-    if (!errB.empty()) throw std::runtime_error(errB);
-    // what the helper did counts as this context's (the callers read one context's statistics)
-    a.stats.bins += b.stats.bins; a.stats.records += b.stats.records; a.stats.algorithmic_bytes += b.stats.algorithmic_bytes; a.stats.cdata_bytes += b.stats.cdata_bytes;
-    a.stats.device_batches += b.stats.device_batches; a.stats.frontend_ms = std::max(a.stats.frontend_ms, b.stats.frontend_ms);
-    a.timing.encode_ms += b.timing.encode_ms; a.timing.assemble_ms += b.timing.assemble_ms; a.timing.launches += b.timing.launches; a.timing.items += b.timing.items;
-    a.timing.ppmd_symbols += b.timing.ppmd_symbols; a.timing.rc_symbols += b.timing.rc_symbols; a.timing.restarts += b.timing.restarts; a.timing.max_restarts = std::max(a.timing.max_restarts, b.timing.max_restarts);
-    a.timing.h2d_bytes += b.timing.h2d_bytes; a.timing.gather_ms += b.timing.gather_ms; a.timing.gather_symbols += b.timing.gather_symbols; a.timing.gather_bytes += b.timing.gather_bytes; a.timing.id_strings += b.timing.id_strings;
-    for (int w = 0; w < 16; ++w) a.timing.win[w] += b.timing.win[w];
-    b.stats = fsgpu_stats(); b.timing = fsengine::BatchTiming();
+    std::vector<fs::Context*> cs{&a};
+    for (uint32_t k = 0; k < want; ++k) cs.push_back(&ctx->helpers[k]->c);
+    struct Keep { std::vector<fs::Context*> cs; std::vector<fsgpu_config> cfg; std::vector<uint32_t> threads;
+                  ~Keep() { for (size_t i = 0; i < cs.size(); ++i) { cs[i]->cfg = cfg[i]; cs[i]->hostThreads = threads[i]; cs[i]->splitRole = 0; } } } keep;
+    for (fs::Context* c : cs) { keep.cs.push_back(c); keep.cfg.push_back(c->cfg); keep.threads.push_back(c->hostThreads); }
+    for (uint32_t k = 0; k < pipelines; ++k) {
+        fs::Context& c = *cs[k];
+        c.cfg.rank = k; c.cfg.world_size = pipelines; c.cfg.batch_bases = a.cfg.batch_bases; c.splitRole = k + 1;
+        c.cfg.pipeline_lanes = lanes[k]; c.cfg.pipeline_slices = k + 1 < pipelines ? lanes[k] : 0;      // (the heavy classes: a slice per lane)
+        // host threads: the last pipeline has most of the bins -- half of them (two thirds of two), the others share the rest
+        const uint32_t heavy = std::max(1u, pipelines == 3 ? T / 4u : T / 3u);
+        c.hostThreads = k + 1 < pipelines ? heavy : std::max(1u, T > heavy * (pipelines - 1) ? T - heavy * (pipelines - 1) : 1u);
+    }
+    std::vector<std::string> errs(pipelines);
+    auto all = [&](const std::function<void(uint32_t)>& f) {
+        std::vector<std::thread> th;
+        for (uint32_t k = 1; k < pipelines; ++k) th.emplace_back([&, k]() { try { f(k); } catch (const std::exception& e) { errs[k] = e.what(); } });
+        try { f(0); } catch (const std::exception& e) { errs[0] = e.what(); }
+        for (auto& t : th) t.join();
+        for (const std::string& e : errs) if (!e.empty()) throw std::runtime_error(e);
+    };
+    all([&](uint32_t k) { cs[k]->shardPack({in}); });
+    std::vector<uint32_t> sg; std::vector<uint64_t> sum;
+    a.shardTable(0, sg, sum);
+    for (uint32_t k = 1; k < pipelines; ++k) {
+        std::vector<uint32_t> sg2; std::vector<uint64_t> sz;
+        cs[k]->shardTable(0, sg2, sz);
+        if (sg != sg2) throw std::runtime_error("the pipelines disagree about the archive's block table");
+        for (size_t i = 0; i < sum.size(); ++i) sum[i] += sz[i];
+    }
+    all([&](uint32_t k) { cs[k]->shardWrite(0, out, sum); });
+    // what the helpers did counts as this context's (the callers read one context's statistics)
+    for (uint32_t k = 1; k < pipelines; ++k) {
+        fs::Context& b = *cs[k];
+        a.stats.bins += b.stats.bins; a.stats.records += b.stats.records; a.stats.algorithmic_bytes += b.stats.algorithmic_bytes; a.stats.cdata_bytes += b.stats.cdata_bytes;
+        a.stats.device_batches += b.stats.device_batches; a.stats.frontend_ms = std::max(a.stats.frontend_ms, b.stats.frontend_ms);
+        a.timing.encode_ms += b.timing.encode_ms; a.timing.assemble_ms += b.timing.assemble_ms; a.timing.launches += b.timing.launches; a.timing.items += b.timing.items;
+        a.timing.ppmd_symbols += b.timing.ppmd_symbols; a.timing.rc_symbols += b.timing.rc_symbols; a.timing.restarts += b.timing.restarts; a.timing.max_restarts = std::max(a.timing.max_restarts, b.timing.max_restarts);
+        a.timing.h2d_bytes += b.timing.h2d_bytes; a.timing.gather_ms += b.timing.gather_ms; a.timing.gather_symbols += b.timing.gather_symbols; a.timing.gather_bytes += b.timing.gather_bytes; a.timing.id_strings += b.timing.id_strings;
+        for (int w = 0; w < 16; ++w) a.timing.win[w] += b.timing.win[w];
+        b.stats = fsgpu_stats(); b.timing = fsengine::BatchTiming();
+    }
     if (verbose) {
-        fprintf(stderr, "\rParts processed: %zu (100%%) \n", sa.size());
+        fprintf(stderr, "\rParts processed: %zu (100%%) \n", sum.size());
         char err[256] = {0};
         if (verbose == 1 && fsgpu_print_stream_sizes(out.c_str(), err, sizeof err) != 0) throw std::runtime_error(err);
     }
@@ -601,7 +625,7 @@ int fsgpu_pack_file(fsgpu_ctx* ctx, const char* inPrefix, const char* outPrefix,
 {
     if (!ctx || !inPrefix || !outPrefix) return FSGPU_ERR_ARG;
     FS_GUARD(ctx, {
-        if (wantsSplit(ctx, inPrefix)) packSplit(ctx, inPrefix, outPrefix, verbose);
+        if (const uint32_t pipelines = wantsSplit(ctx, inPrefix)) packSplit(ctx, inPrefix, outPrefix, verbose, pipelines);
         else ctx->c.packFiles({std::string(inPrefix)}, {std::string(outPrefix)}, verbose);
     });
 }

@@ -1208,19 +1208,21 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         std::vector<uint64_t> w(stdSigs.size());
         for (uint32_t i = 0; i < stdSigs.size(); ++i) w[i] = libs[l]->bf.bins().at(stdSigs[i]).totalRecordsCount;
         std::vector<uint32_t> owner;
-        if (splitRole != 0 && world == 2) {
-            // the heaviest bins, as many as one batch holds, are rank 0's; all the others rank 1's (the longest streams of the
-            // job start at once and run beside everything else, instead of in front of it)
+        if (splitRole != 0) {
+            // weight classes: the heaviest bins, as many as one batch holds, are rank 0's; (three pipelines) the next batch's worth
+            // rank 1's; all the others the last rank's -- the longest streams of the job start at once and run beside everything
+            // else, instead of in front of it
             const uint64_t cap = cfg.batch_bases ? cfg.batch_bases : (3072ull << 20);
             std::vector<uint32_t> idx(stdSigs.size());
             for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = i;
             std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
-            owner.assign(stdSigs.size(), 1u);
-            uint64_t bases = 0;
+            owner.assign(stdSigs.size(), world - 1u);
+            uint64_t bases = 0; uint32_t cls = 0;
             for (uint32_t i : idx) {
+                if (cls + 1u >= world) break;
                 const uint64_t add = libs[l]->bf.bins().at(stdSigs[i]).totalRawDnaSize;
-                if (bases != 0 && bases + add > cap) break;
-                owner[i] = 0u; bases += add;
+                if (bases != 0 && bases + add > cap) { ++cls; bases = 0; if (cls + 1u >= world) break; }
+                owner[i] = cls; bases += add;
             }
         } else if (steal.p) {
             // head: all but the lightest kTailPercent of the records, dealt by shardOwners; tail: chunks, dealt round robin by weight
