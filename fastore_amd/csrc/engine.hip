@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <time.h>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <shared_mutex>
 #include <vector>
@@ -507,6 +508,18 @@ static int lane_init(Device* dev, char* err, size_t errLen)
     auto fail = [&](const char* what, hipError_t c) { snprintf(err, errLen, "%s: %s", what, hipGetErrorString(c)); return -1; };
     if ((e = hipSetDevice(dev->deviceId)) != hipSuccess) return fail("hipSetDevice", e);
     dev->stagePageable = g_pageableStaging ? 1u : 0u;
+    // Experiment (FS_XCD_SPLIT=<m|b>:<xcds>:<lanes>): the first <lanes> coder lanes of the process -- the ones the slices with the longest
+    // streams take -- launch on <xcds> of the eight XCDs only, all later lanes on the others: an L2 (4 MB per XCD) and TLB of their own
+    // for the long streams.  m: CU-mask bit i belongs to XCD i % 8 (the runtime deals the mask round robin); b: to XCD i / 32.
+    static std::atomic<uint32_t> laneNo{0};
+    const uint32_t myLane = laneNo++;
+    const char* xs = getenv("FS_XCD_SPLIT");
+    uint32_t xk = 0, xl = 0; char xm = 0;
+    if (xs && sscanf(xs, "%c:%u:%u", &xm, &xk, &xl) == 3 && xk >= 1 && xk <= 7 && (xm == 'm' || xm == 'b')) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t i = 0; i < 256u; ++i) { const uint32_t xcd = xm == 'm' ? i % 8u : i / 32u; if ((xcd < xk) == (myLane < xl)) mask[i >> 5] |= 1u << (i & 31u); }
+        if ((e = hipExtStreamCreateWithCUMask((hipStream_t*)&dev->stream, 8, mask)) != hipSuccess) return fail("hipExtStreamCreateWithCUMask", e);
+    } else
     if ((e = hipStreamCreateWithFlags((hipStream_t*)&dev->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipMalloc((void**)&dev->queueHead, 64)) != hipSuccess) return fail("hipMalloc(queue)", e);
     for (int i = 0; i < 6; ++i) if ((e = hipEventCreate((hipEvent_t*)&dev->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
