@@ -580,11 +580,11 @@ static void packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& 
     for (uint32_t k = 0; k < pipelines; ++k) {
         fs::Context& c = *cs[k];
         c.cfg.rank = k; c.cfg.world_size = pipelines; c.cfg.batch_bases = a.cfg.batch_bases; c.splitRole = k + 1;
-        // (the heavy classes: two slices per lane, so that the first slice is the first ROUND of the host threads -- the heaviest bins'
-        // streams start when those bins are through the front end, not when a quarter of the class is)
-        c.cfg.pipeline_lanes = lanes[k]; c.cfg.pipeline_slices = k + 1 < pipelines ? 2u * lanes[k] : 0;
-        // host threads: a third each (measured at 60 M pairs: with a quarter the heaviest class's front end -- 17 s -- held its streams back)
-        const uint32_t heavy = std::max(1u, T / 3u);
+        // (the heavy classes: a slice per lane -- measured at 60 M pairs: with two slices per lane the later slices wait for lanes that the
+        // first ones hold for the whole of their long streams, 32.6 -> 43.8 s; host threads a quarter each of three, a third of two: with a
+        // third each of three the last pipeline, which has most of the bins, becomes the longest, profiles/r03_config2_60Mpairs_*)
+        c.cfg.pipeline_lanes = lanes[k]; c.cfg.pipeline_slices = k + 1 < pipelines ? lanes[k] : 0;
+        const uint32_t heavy = std::max(1u, pipelines == 3 ? T / 4u : T / 3u);
         c.hostThreads = k + 1 < pipelines ? heavy : std::max(1u, T > heavy * (pipelines - 1) ? T - heavy * (pipelines - 1) : 1u);
     }
     std::vector<std::string> errs(pipelines);
