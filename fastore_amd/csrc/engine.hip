@@ -84,6 +84,7 @@ template <int WAVES> __device__ __forceinline__ void encode_streams_body()
 {
     constexpr bool TWO = WAVES >= 2, THREE = WAVES == 3;
     __shared__ fsppmd::Shared sh;
+    static_assert(sizeof(fsppmd::Shared) <= 12800, "above 12 800 bytes of LDS a compute unit holds eleven one-wave workgroups, not twelve (profiles/r03_free_list_heads.txt)");
     uint32_t qTail = 0;
     if (TWO) {
         if (threadIdx.x == 0) { sh.qTail = 0u; sh.qHead = 0u; sh.qStarts = 0u; sh.qOpened = 0u; if (THREE) fsppmd::scout_init((FS_LDS fsppmd::Shared*)&sh); }
@@ -182,8 +183,8 @@ template <int WAVES> __device__ __forceinline__ void encode_streams_body()
                 else if (t >= 8u && t < 15u) v = sh.winStats[t];
                 else if (t == 15u) v = (uint32_t)((FS_PROF_NOW() - tStream) >> 6);
 #if !defined(FS_WIN_PROFILE) && !defined(FS_SER_PROFILE)
-                if (THREE && t == 8u) v = sh.wxStats[0] - sh.wxBase[0];                  // windows prepared ahead of the serial walk and used
-                if (THREE && t == 9u) v = sh.wxStats[1] + sh.wxStats[2] - sh.wxBase[1] - sh.wxBase[2];    // prepared in vain (start lane unusable, or the check failed)
+                if (THREE && t == 8u) v = sh.wxStats[0];                  // windows prepared ahead of the serial walk and used
+                if (THREE && t == 9u) v = sh.wxStats[1] + sh.wxStats[2];    // prepared in vain (start lane unusable, or the check failed)
 #endif
             }
             if (t == 0u) v = rs;

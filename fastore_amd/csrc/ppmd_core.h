@@ -86,7 +86,9 @@ struct Shared {
     uint32_t wrSeq, wr[8];                     // reply number, its words
     uint32_t wrDrained;                        // the window wave's stores for every reply up to this number are complete
     uint32_t wsNewStream, wsRestartsSeen;      // serial wave only
-    uint32_t wxStats[4], wxBase[4];            // windows prepared ahead and used / start lanes that could not be used / prepared in vain / solved again; their values when the stream began
+    uint32_t wxStats[4];                       // (per stream) windows prepared ahead and used / start lanes that could not be used / prepared in vain / solved again
+    // (LDS per workgroup stays below 12 800 bytes: above it a compute unit holds eleven one-wave workgroups instead of twelve --
+    // measured as 3 072 equal streams taking two rounds instead of one, profiles/r03_free_list_heads.txt)
     uint32_t winStats[16];
 #if defined(FS_SER_PROFILE)
     uint32_t serStats[8];        // design study: [0] symbol start -> first context ready, [1] first-context coding + coder hand-off, [2] tail of the loop, [3] serial symbols, [4] failed window attempts (clocks / 64)
@@ -198,8 +200,9 @@ FS_DEV void fs_reload(Coder& m) { if (m.FoundState) { const St t = st_load(m, m.
 // ---------------- sub-allocator ----------------
 // (list number i: BLK_NODE::remove / insert / avail of SubAlloc.hpp:41-55.  The head -- first block of the list, 0 = empty -- lives
 // in LDS in the forms that walk single long streams (m.ldsHeads: two and three waves), behind the heap in HBM in the one-wave
-// form: measured, profiles/r03_free_list_heads.txt -- a lone 7 M-symbol stream 976 -> 941 ms with the heads in LDS, but
-// 3 072 one-wave streams side by side 6.35 -> 4.43 G symbols/s, so each form keeps what suits it.)
+// form: measured, profiles/r03_free_list_heads.txt -- a lone 7 M-symbol stream 976 -> 941 ms with the heads in LDS.  The one-wave
+// form was first thought to lose by them (3 072 streams side by side 6.35 -> 4.43 G symbols/s); that loss was the workgroup's LDS
+// passing 12 800 bytes, see Shared, and is gone at 12 796 bytes: 6.60 G symbols/s.)
 FS_DEV uint32_t blk_head(Coder& m, uint32_t i) { return m.ldsHeads ? FS_LDS_RD(m.sh->blHead[i]) : B_NEXT(BL(i)); }
 FS_DEV void blk_head_set(Coder& m, uint32_t i, uint32_t v) { if (m.ldsHeads) { m.sh->blHead[i] = v; FS_EMU_MEET(); } else B_NEXT_SET(BL(i), v); }
 FS_DEV uint32_t blk_remove(Coder& m, uint32_t i)

@@ -137,7 +137,7 @@ FS_DEV uint32_t scout_window(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, ui
 // a new stream begins (encode_member): its first request tells the window wave
 FS_DEV void scout_begin_stream(Coder& m)
 {
-    if (FS_LANE() == 0) { m.sh->wsNewStream = 1u; m.sh->wq[WQ_NT] = 0u; m.sh->wsRestartsSeen = 0u; for (int i = 0; i < 4; ++i) m.sh->wxBase[i] = m.sh->wxStats[i]; }
+    if (FS_LANE() == 0) { m.sh->wsNewStream = 1u; m.sh->wq[WQ_NT] = 0u; m.sh->wsRestartsSeen = 0u; for (int i = 0; i < 4; ++i) m.sh->wxStats[i] = 0u; }      // (the window wave may be adding to them: statistics only)
     m.wHintDue = 0u; m.wSeq = FS_LDS_RD(m.sh->wqSeq);
     FS_WAVE_SYNC();
 }
@@ -151,7 +151,7 @@ FS_DEV void scout_send_exit(FS_LDS Shared* sh)
 FS_DEV void scout_init(FS_LDS Shared* sh)
 {
     sh->wqSeq = 0u; sh->whSeq = 0u; sh->whPos = 0u; sh->wsDrained = 0u; sh->wrSeq = 0u; sh->wrDrained = 0u; sh->wq[WQ_NT] = 0u; sh->wsNewStream = 1u; sh->wsRestartsSeen = 0u;
-    for (int i = 0; i < 4; ++i) { sh->wxStats[i] = 0u; sh->wxBase[i] = 0u; }
+    for (int i = 0; i < 4; ++i) sh->wxStats[i] = 0u;
 }
 
 // ---- window wave ----

@@ -64,7 +64,7 @@ extern "C" int simt_ppmd_encode_three_waves(int nStreams, const uint8_t* const* 
     sh->qTail = sh->qHead = 0; sh->qStarts = sh->qOpened = 0;
     fsppmd::scout_init(sh);
     memset(g_jitterCalls, 0, sizeof g_jitterCalls);
-    uint64_t win[3] = {0, 0, 0};
+    uint64_t win[3] = {0, 0, 0}, ahead[3] = {0, 0, 0};
     simt::run_waves(3, [&](int wave, int) {
         if (wave == 1) { fsppmd::coder_wave(sh); return; }
         if (wave == 2) { fsppmd::window_wave(sh); return; }
@@ -73,12 +73,12 @@ extern "C" int simt_ppmd_encode_three_waves(int nStreams, const uint8_t* const* 
             uint32_t r0 = 0;
             if (n[s] == 0) { if (simt::lane() == 0) sizes[s] = 0; continue; }
             fsppmd::encode_member(arena, sh, in[s], (uint32_t)n[s], out[s], (uint32_t)cap[s], &r0, true, &sizes[s], q, &q, true);
-            if (simt::lane() == 0) { win[0] += sh->winStats[1]; win[1] += sh->winStats[2]; }
+            if (simt::lane() == 0) { win[0] += sh->winStats[1]; win[1] += sh->winStats[2]; for (int i = 0; i < 3; ++i) ahead[i] += sh->wxStats[i]; }   // (per stream, as the kernel reports them)
         }
         fsppmd::scout_send_exit(sh);
         fsppmd::cq_send_exit(sh, q);
     });
-    if (stats) { stats[0] = sh->wxStats[0]; stats[1] = sh->wxStats[1]; stats[2] = sh->wxStats[2]; stats[3] = win[0]; stats[4] = win[1]; }
+    if (stats) { stats[0] = ahead[0]; stats[1] = ahead[1]; stats[2] = ahead[2]; stats[3] = win[0]; stats[4] = win[1]; }
     delete sh; free(arena);
     return 0;
 }
