@@ -222,7 +222,9 @@ def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome,
                                   "achieved_GBps": round(st["gather_bytes"] / max(1e-9, st["gather_kernel_ms"] / 1e3) / 1e9, 1) if st["gather_kernel_ms"] > 0 else None,
                                   "frac_of_hbm_peak": round(st["gather_bytes"] / max(1e-9, st["gather_kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if st["gather_kernel_ms"] > 0 else None},
             "fs_match_reads": {"reads_per_step": st["matcher_reads"] // steps, "kernel_ms_per_step": round(st["matcher_kernel_ms"] / steps, 1),
-                               "host_wait_ms_per_step_summed_over_threads": round(st["matcher_call_ms"] / steps, 1)}},
+                               "host_wait_ms_per_step_summed_over_threads": round(st["matcher_call_ms"] / steps, 1),
+                               # its bases: unpacked on the device from the bin's .bdna bytes (fs_unpack_planes), or ASCII from the host
+                               "reads_unpacked_on_device_per_step": st["matcher_unpacked_reads"] // steps, "bases_h2d_bytes_per_step": st["matcher_bases_h2d_bytes"] // steps}},
         "h2d_bytes_per_step": int(st["h2d_bytes"]) // steps,
         "stages_ms_per_step": dict({k: round(st[k] / steps, 1) for k in ("encode_kernel_ms", "assemble_kernel_ms", "frontend_ms", "io_ms", "total_ms")},
                                    block0_ms=round(st["block0_ms"], 1)),      # block0_ms is the longest single step's (a max in the library), not a sum

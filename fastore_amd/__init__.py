@@ -40,7 +40,8 @@ class Stats(C.Structure):
                 ("gather_kernel_ms", C.c_double), ("gather_symbols", C.c_uint64), ("gather_bytes", C.c_uint64),
                 ("matcher_reads", C.c_uint64), ("matcher_call_ms", C.c_double), ("matcher_kernel_ms", C.c_double), ("tokenised_ids", C.c_uint64),
                 ("device_batches", C.c_uint64), ("ppmd_max_restarts", C.c_uint64),
-                ("ppmd_windows_ahead", C.c_uint64), ("ppmd_windows_ahead_in_vain", C.c_uint64), ("stolen_bins", C.c_uint64)]
+                ("ppmd_windows_ahead", C.c_uint64), ("ppmd_windows_ahead_in_vain", C.c_uint64), ("stolen_bins", C.c_uint64),
+                ("matcher_bases_h2d_bytes", C.c_uint64), ("matcher_unpacked_reads", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -96,6 +97,7 @@ def load_library(path=None):
     lib.fsgpu_tokeniser_check.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.fsgpu_matcher_check.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.fsgpu_pe_matcher_check.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.fsgpu_unpack_check.argtypes = [C.c_void_p, C.c_char_p] + [C.POINTER(C.c_uint64)] * 4
     lib.fsgpu_gather_quality.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fsgpu_rc_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fsgpu_set_quality_codebook.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
@@ -358,6 +360,13 @@ class Packer:
         r = C.c_uint64(0); d = C.c_uint64(0)
         self._check(self.lib.fsgpu_matcher_check(self.ctx, in_prefix.encode(), C.byref(r), C.byref(d)))
         return r.value, d.value
+
+    def unpack_check(self, in_prefix):
+        """(plane words compared, words on which fs_unpack_planes -- bases as the bin file packs them -- and fs_pack_bases -- the
+        host's unpacked bases -- disagree, reads searched, rows differing from the host scan) over the standard bins of a library."""
+        v = [C.c_uint64(0) for _ in range(4)]
+        self._check(self.lib.fsgpu_unpack_check(self.ctx, in_prefix.encode(), *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
 
     def pe_matcher_check(self, in_prefix):
         """(pairs searched, rows on which the device mate search and the host's disagree) over the standard bins of a paired-end library."""

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <stdexcept>
 #include "bitio.h"
+#include "device_types.h"
 
 namespace fs {
 
@@ -61,9 +62,13 @@ struct Unpacker {
         for (uint32_t w = 0; w < 256; ++w) { const uint8_t q[4] = {(uint8_t)o[w >> 6], (uint8_t)o[(w >> 4) & 3], (uint8_t)o[(w >> 2) & 3], (uint8_t)o[w & 3]}; memcpy(&dna4[w], q, 4); }
     }
 
+    // packedD: the packed bases are kept beside the unpacked ones (Batch::dnaPacked / dnaBit / dnaInfo): where the last readDna
+    // began in the bin's bytes, and in which form it was stored
+    bool packedD = false; uint64_t dnaBitBase = 0, dnaStart = 0; bool dnaPlain = false;
     void readDna(uint8_t* seq, uint32_t seqLen, uint32_t minimPos, uint32_t suffixLen)
     {
         const bool plain = meta.getBit() != 0;
+        dnaStart = dnaBitBase + dna.bitPosition(); dnaPlain = plain;
         const char* idxToDna = cfg.minimizer.dnaSymbolOrder;
         if (plain) {
             // sixteen bases per window read: four table look-ups of four bases each
@@ -128,6 +133,12 @@ struct Unpacker {
         // before any base is stored: the position comes from 8 untrusted bits
         if (s.suffixLen != 0 && minimPos + s.suffixLen > len) throw std::runtime_error("Corrupted bin: signature position outside the read");
         readDna(b.seq.data() + seqOff, len, minimPos, s.suffixLen);
+        if (packedD && !isMate2) {      // (the window search reads first mates only)
+            const size_t idx = (size_t)(&r - b.recs.data());
+            if (dnaStart > 0xFFFFFFFFull) throw std::runtime_error("bin with more than 512 MiB of packed bases");
+            b.dnaBit[idx] = (uint32_t)dnaStart;
+            b.dnaInfo[idx] = (dnaPlain ? fsdev::PACKED_PLAIN : 0u) | (s.suffixLen != 0 ? fsdev::PACKED_HAS_SIG | (s.signatureId & ((1u << fsdev::PACKED_SIG_BITS) - 1u)) | (minimPos << fsdev::PACKED_SIG_BITS) : 0u);
+        }
         readQuality(seqOff, len);
         if (packedQ) noteQuality(r, len, isMate2);
         if (s.usesHeaders) readHeader(r);
@@ -176,6 +187,7 @@ struct Unpacker {
         r.seqOff = allocSeq((uint32_t)r.seqLen + r.auxLen);
         memcpy(b.seq.data() + r.seqOff, b.seq.data() + mainRec.seqOff, mainRec.seqLen);
         r.minimPos = mainRec.minimPos;
+        if (packedD) { const size_t idx = (size_t)(&r - b.recs.data()), mi = (size_t)(&mainRec - b.recs.data()); b.dnaBit[idx] = b.dnaBit[mi]; b.dnaInfo[idx] = b.dnaInfo[mi]; }
         readQuality(r.seqOff, r.seqLen);
         if (packedQ) noteQuality(r, r.seqLen, false);
         if (cfg.archiveType.readsHaveHeaders) readHeader(r);
@@ -360,11 +372,16 @@ void BinFile::readFooter(const std::vector<uint8_t>& buf)
     }
 }
 
-void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin) const { unpackImpl(signature, batch, batch, asNewBin, false, 0, 0, 0, -1, -1); }
-void BinFile::unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, uint64_t headBase, uint32_t recBase, Batch& graph, int64_t quaBase, int64_t headPackedBase) const
-{ unpackImpl(signature, data, graph, true, true, seqBase, headBase, recBase, quaBase, headPackedBase); }
+void BinFile::unpack(uint32_t signature, Batch& batch, bool asNewBin, bool keepPackedDna) const
+{
+    int64_t at = -1;
+    if (keepPackedDna && asNewBin) { at = (int64_t)((batch.dnaPacked.size() + 15u) & ~(size_t)15u); batch.dnaPacked.resize((size_t)at + bins_.at(signature).totalDnaSize + 16u); }
+    unpackImpl(signature, batch, batch, asNewBin, false, 0, 0, 0, -1, -1, at);
+}
+void BinFile::unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, uint64_t headBase, uint32_t recBase, Batch& graph, int64_t quaBase, int64_t headPackedBase, int64_t dnaPackedBase) const
+{ unpackImpl(signature, data, graph, true, true, seqBase, headBase, recBase, quaBase, headPackedBase, dnaPackedBase); }
 
-void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase, int64_t quaBase, int64_t headPackedBase) const
+void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase, int64_t quaBase, int64_t headPackedBase, int64_t dnaPackedBase) const
 {
     // gather buffers of the calling thread, kept across bins: fresh vectors of this size are mmap'ed by malloc, and the
     // map/unmap/first-touch churn of thousands of them per second serialises the host threads in the kernel
@@ -375,6 +392,8 @@ void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asN
     // BinFileReader::ReadBlock: gather the signature's slices from the four streams
     if (bMeta_.size() < bi.totalMetaSize) bMeta_.resize(bi.totalMetaSize);
     if (bDna_.size() < bi.totalDnaSize) bDna_.resize(bi.totalDnaSize);
+    const bool packedD = dnaPackedBase >= 0 && asNewBin;
+    if (packedD && (uint64_t)dnaPackedBase + bi.totalDnaSize > data.dnaPacked.size()) throw std::runtime_error("packed bases: batch arrays not sized");
     const bool packedQ = quaBase >= 0;
     if (packedQ) {
         if (!placed || cfg_.quaParams.method == MET_QVZ) throw std::runtime_error("packed qualities: placed unpack of a lossless, 8-bin or binary archive only");
@@ -401,13 +420,21 @@ void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asN
     }
     BinIn& bin = graph.bins.back();
     bin.rawDnaSize += rawDna;
+    if (packedD) {      // (the reader below works on the gather buffer: the kept copy is the device's)
+        memcpy(data.dnaPacked.data() + dnaPackedBase, bDna_.data(), dO);
+        bin.dnaPackedOff = (uint64_t)dnaPackedBase; bin.dnaPackedBytes = dO;
+    }
     uint32_t recIdx;
     if (placed) { recIdx = recBase; if ((uint64_t)recBase + records > data.recs.size()) throw std::runtime_error("bin footer understates the records"); }
     else { recIdx = (uint32_t)data.recs.size(); data.recs.resize(data.recs.size() + records, Rec{}); }
+    if (packedD) {
+        if (!placed) { data.dnaBit.resize(data.recs.size(), 0u); data.dnaInfo.resize(data.recs.size(), 0u); }
+        else if (data.dnaBit.size() != data.recs.size() || data.dnaInfo.size() != data.recs.size()) throw std::runtime_error("packed bases: batch arrays not sized");
+    }
     const uint32_t recFirst = recIdx;
 
     Unpacker u(cfg_, data, graph, bMeta_, mo, bDna_, dO, quaDst, qo, headDst, ho);
-    u.packedH = packedH;
+    u.packedH = packedH; u.packedD = packedD;
     u.packedQ = packedQ; u.quaBits = cfg_.quaParams.method == MET_BINARY ? 1u : (cfg_.quaParams.method == MET_8BIN ? 3u : 6u);
     u.placed = placed; u.seqCur = seqBase; u.headCur = headBase;
     // a placed bin owns exactly the footer's totals of the shared arrays; a footer that understates them must not spill

@@ -33,17 +33,18 @@ public:
     // Unpack one signature into `batch`.  asNewBin: start a new BinIn; otherwise append the
     // records/nodes to the last bin of the batch (block-0 merge of small bins and the N bin).
     // Thread-safe: only reads the mapped files and the footer tables.
-    void unpack(uint32_t signature, Batch& batch, bool asNewBin) const;
+    // keepPackedDna (new bins only): the bin's .bdna bytes and every record's place in them are kept too (Batch::dnaPacked / dnaBit / dnaInfo)
+    void unpack(uint32_t signature, Batch& batch, bool asNewBin, bool keepPackedDna = false) const;
     // Placed form for parallel batch assembly: bases/quals/headers/records go to pre-sized arrays of `data` at the given
     // offsets (their sizes are known from the footer); the graph tables and the BinIn go to `graph` (node indices local to it).
     // quaBase >= 0: the qualities are not unpacked; the bin's .bqua bytes go to data.quaPacked at quaBase and every record's
     // bit offset into them to data.quaBit (lossless archives only; see Batch)
     // headPackedBase >= 0: the same for the read ids (data.headPacked / data.headBit)
-    void unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, uint64_t headBase, uint32_t recBase, Batch& graph, int64_t quaBase = -1, int64_t headPackedBase = -1) const;
+    void unpackPlaced(uint32_t signature, Batch& data, uint64_t seqBase, uint64_t headBase, uint32_t recBase, Batch& graph, int64_t quaBase = -1, int64_t headPackedBase = -1, int64_t dnaPackedBase = -1) const;
 
 private:
     void readFooter(const std::vector<uint8_t>& buf);
-    void unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase, int64_t quaBase, int64_t headPackedBase) const;
+    void unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asNewBin, bool placed, uint64_t seqBase, uint64_t headBase, uint32_t recBase, int64_t quaBase, int64_t headPackedBase, int64_t dnaPackedBase) const;
     struct Map { const uint8_t* p = nullptr; uint64_t size = 0; };    // read-only mmap of one stream file
     static Map mapFile(const std::string& name);
     static void unmap(Map& m);

@@ -534,6 +534,16 @@ int fsgpu_matcher_check(fsgpu_ctx* ctx, const char* inPrefix, uint64_t* reads, u
     FS_GUARD(ctx, ctx->c.matcherCheck(inPrefix, *reads, *differing));
 }
 
+int fsgpu_unpack_check(fsgpu_ctx* ctx, const char* inPrefix, uint64_t* words, uint64_t* differing, uint64_t* reads, uint64_t* differingRows)
+{
+    if (!ctx || !inPrefix || !words || !differing || !reads || !differingRows) return FSGPU_ERR_ARG;
+    *words = *differing = 0;
+    if (!fs::Context::deviceUnpack()) { ctx->c.err = "device-side unpack is switched off (FS_DEVICE_UNPACK=0)"; return FSGPU_ERR_ARG; }
+    fsengine::unpack_check(true);
+    struct Off { ~Off() { fsengine::unpack_check(false); } } off;
+    FS_GUARD(ctx, { ctx->c.matcherCheck(inPrefix, *reads, *differingRows); fsengine::unpack_check_counts(words, differing); });
+}
+
 // A library of several device batches (more standard-bin bases than one batch holds: tens of millions of reads) is bound by the
 // streams of its heaviest bins -- a 40 M-pair library has a 150 M-symbol quality stream, 25 s of one wavefront -- and with the
 // batches one after the other everything else waited in line behind them (round 3: 41 s, of which 27 s the first batch,
@@ -614,6 +624,8 @@ static void packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& 
         a.timing.ppmd_symbols += b.timing.ppmd_symbols; a.timing.rc_symbols += b.timing.rc_symbols; a.timing.restarts += b.timing.restarts; a.timing.max_restarts = std::max(a.timing.max_restarts, b.timing.max_restarts);
         a.timing.h2d_bytes += b.timing.h2d_bytes; a.timing.gather_ms += b.timing.gather_ms; a.timing.gather_symbols += b.timing.gather_symbols; a.timing.gather_bytes += b.timing.gather_bytes; a.timing.id_strings += b.timing.id_strings;
         for (int w = 0; w < 16; ++w) a.timing.win[w] += b.timing.win[w];
+        a.matchedReads += b.matchedReads.load(); a.matchUs += b.matchUs.load(); a.matchKernelUs += b.matchKernelUs.load(); a.matchBasesUp += b.matchBasesUp.load(); a.matchUnpackedReads += b.matchUnpackedReads.load();
+        b.matchedReads = 0; b.matchUs = 0; b.matchKernelUs = 0; b.matchBasesUp = 0; b.matchUnpackedReads = 0;
         b.stats = fsgpu_stats(); b.timing = fsengine::BatchTiming();
     }
     if (verbose) {
@@ -698,7 +710,7 @@ int fsgpu_pack_files(fsgpu_ctx* ctx, size_t n, const char* const* inPrefixes, co
 int fsgpu_reset_stats(fsgpu_ctx* ctx)
 {
     if (!ctx) return FSGPU_ERR_ARG;
-    ctx->c.stats = fsgpu_stats(); ctx->c.timing = fsengine::BatchTiming(); ctx->c.matchedReads = 0; ctx->c.matchUs = 0; ctx->c.matchKernelUs = 0;
+    ctx->c.stats = fsgpu_stats(); ctx->c.timing = fsengine::BatchTiming(); ctx->c.matchedReads = 0; ctx->c.matchUs = 0; ctx->c.matchKernelUs = 0; ctx->c.matchBasesUp = 0; ctx->c.matchUnpackedReads = 0;
     return FSGPU_OK;
 }
 
@@ -711,6 +723,7 @@ int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out)
     out->ppmd_window_attempts = ctx->c.timing.win[1]; out->ppmd_windows = ctx->c.timing.win[2]; out->ppmd_window_symbols = ctx->c.timing.win[3];
     out->ppmd_window_rounds = ctx->c.timing.win[4]; out->ppmd_windows_redone = ctx->c.timing.win[5]; out->ppmd_window_light_rounds = ctx->c.timing.win[6];
     out->tokenised_ids = ctx->c.timing.id_strings; out->matcher_reads = ctx->c.matchedReads.load(); out->matcher_call_ms = ctx->c.matchUs.load() / 1e3; out->matcher_kernel_ms = ctx->c.matchKernelUs.load() / 1e3;
+    out->matcher_bases_h2d_bytes = ctx->c.matchBasesUp.load(); out->matcher_unpacked_reads = ctx->c.matchUnpackedReads.load();
     out->gather_kernel_ms = ctx->c.timing.gather_ms; out->gather_symbols = ctx->c.timing.gather_symbols; out->gather_bytes = ctx->c.timing.gather_bytes;
     out->rc_symbols = ctx->c.timing.rc_symbols; out->ppmd_restarts = ctx->c.timing.restarts; out->ppmd_max_restarts = ctx->c.timing.max_restarts;
     out->ppmd_windows_ahead = ctx->c.timing.win[8]; out->ppmd_windows_ahead_in_vain = ctx->c.timing.win[9];       // (-DFS_WIN_PROFILE builds of the kernels keep phase clocks in these two slots instead)

@@ -33,6 +33,14 @@ struct GatherPlan { uint64_t desc_off = 0; uint32_t n_strings = 0; uint64_t out_
 // Device-side read matcher (matcher.hip): the reads of a bin's match-tree constructions, each construction's reads in
 // processing order; a row of answers per read
 struct MatchRead { uint32_t seq_off; uint16_t len, min_pos; };            // bases (ASCII) at seq[seq_off .. +len); signature position
+// The same read as the bin file stores it (.bdna, fastore_bin/FastqPacker.cpp:290-411): its bases from bit `bit_off` of the bin's
+// packed bytes on, MSB first, two bits each (index into the archive's symbol order) or three when the read holds an 'N' -- all
+// but the bases of the signature, which are not stored: they stand at sig_pos and are the digits of sig_id (base 4, first base
+// in the highest digit).  info = sig_id (bits 0-21) | sig_pos << 22 (8 bits) | two-bit form << 30 | has a signature << 31.
+struct PackedRead { uint32_t bit_off, info; };
+enum : uint32_t { PACKED_SIG_BITS = 22u, PACKED_PLAIN = 1u << 30, PACKED_HAS_SIG = 1u << 31 };
+// a bin's packed bases for the matcher: reads[i] describes MatchRead i
+struct PackedDna { const uint8_t* dna; size_t bytes; const PackedRead* reads; uint8_t symbol_order[8]; uint32_t sig_len; };
 // reads[first .. first+count) in processing order; aux: read holding the sub-tree's root copy, or -1; warm: the window as it
 // stands in front of reads[first] when this is a later piece of a long construction -- warm_count reads, oldest first, named
 // in the warm-up list from warm_first on (a piece's answers do not depend on how the construction was cut)

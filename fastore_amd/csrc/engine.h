@@ -69,9 +69,14 @@ struct MatchLane;
 int match_lane_create(Device* dev, MatchLane** out);
 void match_lane_destroy(MatchLane* m);
 int match_lane_reserve(Device* dev, MatchLane* m, size_t maxReads, size_t maxSeqBytes, size_t maxCalls, size_t maxWarm);
-int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, const fsdev::MatchRead* reads, size_t nReads,
+// packed != nullptr: the bases come as the bin file stores them and are unpacked on the device (fs_unpack_planes); `seq` then
+// only travels for the FS_UNPACK_CHECK=1 comparison of the two ways
+int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, const fsdev::PackedDna* packed, const fsdev::MatchRead* reads, size_t nReads,
                 const fsdev::MatchCall* calls, size_t nCalls, const uint32_t* warm, size_t nWarm, const fsdev::MatchParams& par,
                 fsdev::MatchRow* rows, double* kernelMs);
+// parity check of fs_unpack_planes: while on, every packed search also builds the planes from `seq` and counts the words that differ
+void unpack_check(bool on);
+void unpack_check_counts(uint64_t* words, uint64_t* differing);
 // the mate searches of one paired-end bin (matcher.hip: fs_match_mates)
 int match_mates(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, const fsdev::MatePair* pairs, size_t nPairs, const uint32_t* validBits, size_t validWords,
                 const fsdev::MateParams& par, fsdev::MateRow* rows, double* kernelMs);

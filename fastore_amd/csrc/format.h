@@ -89,6 +89,7 @@ struct BinIn {            // one bin = one future archive block
     uint64_t rawDnaSize;
     uint32_t recBegin, recCount;     // records of the bin in Batch::recs
     uint32_t topBegin, topCount;     // top-level nodes: Batch::topNodes[topBegin .. +topCount) -> Batch::nodes
+    uint64_t dnaPackedOff, dnaPackedBytes;   // the bin's .bdna bytes in Batch::dnaPacked (0 bytes: not kept)
 };
 
 void fs_advise_huge(void* p, size_t bytes);      // madvise(MADV_HUGEPAGE) where the platform has it (binfile.cpp)
@@ -130,6 +131,12 @@ struct Batch {
     // record r's first stored character in its bin's bytes (Rec::headLen is set, `head` stays empty)
     ByteVec headPacked;
     std::vector<uint32_t, NoInitAlloc<uint32_t>> headBit;
+    // Device-side unpack of the bases for the window search (matcher.hip: fs_unpack_planes): the bins' .bdna bytes as stored,
+    // dnaBit[r] = bit offset of record r's first stored base in ITS BIN's bytes, dnaInfo[r] = the rest of fsdev::PackedRead
+    // (an exact-match record names its main record's bases: it has none of its own).  `seq` is filled as ever: the host's
+    // tree building reads it.
+    ByteVec dnaPacked;
+    std::vector<uint32_t, NoInitAlloc<uint32_t>> dnaBit, dnaInfo;
     std::vector<NodeIn> nodes;
     std::vector<uint32_t> topNodes;
     std::vector<uint32_t> emRecs;
@@ -137,7 +144,7 @@ struct Batch {
     std::vector<BinIn> bins;
     // append `o` (whole bins) behind this batch, re-basing every index
     void append(const Batch& o);
-    void clear() { seq.clear(); qua.clear(); head.clear(); recs.clear(); quaPacked.clear(); quaBit.clear(); headPacked.clear(); headBit.clear(); nodes.clear(); topNodes.clear(); emRecs.clear(); trees.clear(); bins.clear(); }
+    void clear() { seq.clear(); qua.clear(); head.clear(); recs.clear(); quaPacked.clear(); quaBit.clear(); headPacked.clear(); headBit.clear(); dnaPacked.clear(); dnaBit.clear(); dnaInfo.clear(); nodes.clear(); topNodes.clear(); emRecs.clear(); trees.clear(); bins.clear(); }
 };
 
 }  // namespace fs

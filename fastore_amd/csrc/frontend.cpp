@@ -296,6 +296,18 @@ struct BinEncoder::Impl {
     // tree, FastqCompressor.cpp:1784-1818).  mReads/mCalls are that table; mRows the answers (from the device, or traced
     // from the host scan for the parity check); callOfTree[t] = construction of sub-tree t (-1 top level = call 0).
     std::vector<fsdev::MatchRead> mReads; std::vector<fsdev::MatchCall> mCalls; std::vector<fsdev::MatchRow> mRows;
+    std::vector<fsdev::PackedRead> mPacked;    // the reads of mReads as the bin file stores them (bins whose .bdna bytes were kept)
+    bool packedBases = false;
+    const BinIn* curBin = nullptr;
+    fsdev::PackedDna packedDnaBuf{};
+    const fsdev::PackedDna* packedDna()
+    {
+        if (!packedBases || mPacked.size() != mReads.size()) return nullptr;
+        packedDnaBuf.dna = B->dnaPacked.data() + curBin->dnaPackedOff; packedDnaBuf.bytes = (size_t)curBin->dnaPackedBytes; packedDnaBuf.reads = mPacked.data();
+        memset(packedDnaBuf.symbol_order, 0, sizeof packedDnaBuf.symbol_order); memcpy(packedDnaBuf.symbol_order, cfg.minimizer.dnaSymbolOrder, 5);
+        packedDnaBuf.sig_len = cfg.minimizer.signatureLen;
+        return &packedDnaBuf;
+    }
     std::vector<uint32_t> mWarm;              // warm-up lists of the pieces of the top-level construction
     struct Slot3 { uint64_t hash; uint32_t read, push; };
     std::vector<Slot3> dupTable;
@@ -309,12 +321,14 @@ struct BinEncoder::Impl {
 
     void buildMatchTable(const std::vector<int32_t>& topOrder)
     {
-        mReads.clear(); mCalls.clear(); callOfTree.assign(G->trees.size(), -1);
+        mReads.clear(); mCalls.clear(); mPacked.clear(); callOfTree.assign(G->trees.size(), -1);
+        packedBases = curBin && curBin->dnaPackedBytes != 0 && B->dnaBit.size() == B->recs.size() && cfg.minimizer.signatureLen * 2u <= fsdev::PACKED_SIG_BITS;
         uint64_t lo = ~0ull, hi = 0;
         auto add = [&](uint32_t rec, uint32_t minPos) {
             const Rec& r = B->recs[rec];
             lo = std::min<uint64_t>(lo, r.seqOff); hi = std::max<uint64_t>(hi, (uint64_t)r.seqOff + r.seqLen);
             mReads.push_back(fsdev::MatchRead{r.seqOff, r.seqLen, (uint16_t)minPos});
+            if (packedBases) mPacked.push_back(fsdev::PackedRead{B->dnaBit[rec], B->dnaInfo[rec]});
         };
         // The top-level construction is long (most of a bin's reads).  Which of its reads are exact duplicates -- and stay
         // out of the window -- can be told without searching: a read is one exactly when an equal read (same bases, same
@@ -1181,7 +1195,7 @@ struct BinEncoder::Impl {
         auto clk = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; };
         const double t0 = stageTrace ? clk() : 0; double t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         setArchive(arch);
-        B = &batch; G = &graph; out = &o; curSig = bin.signature;
+        B = &batch; G = &graph; out = &o; curSig = bin.signature; curBin = &bin;
         o.reset(pe ? S_PE_COUNT : S_SE_COUNT);
         if (cfg.quaParams.method == MET_QVZ) well.reset(arch.qvz.wellSeed);
         initNodes(bin);
@@ -1204,7 +1218,7 @@ struct BinEncoder::Impl {
         if (matchTrace && traceResize) { matchTrace->assign(mReads.size(), fsdev::MatchRow{-1, 0, 0, 0, 0, 0, 0}); }
         if (matcher && !matchTrace && par.maxLzWindowSize >= 2 && par.maxLzWindowSize <= 1025 && bin.maxLen <= 256) {
             mRows.resize(mReads.size());
-            if (matcher(B->seq.data() + matchSeqBase, matchSeqBytes, mReads.data(), mReads.size(), mCalls.data(), mCalls.size(), mWarm.data(), mWarm.size(), matchParams(), mRows.data())) {
+            if (matcher(B->seq.data() + matchSeqBase, matchSeqBytes, packedDna(), mReads.data(), mReads.size(), mCalls.data(), mCalls.size(), mWarm.data(), mWarm.size(), matchParams(), mRows.data())) {
                 havePre = true;
                 for (const fsdev::MatchCall& c : mCalls) for (uint32_t i = 0; i < c.count && havePre; ++i) if (mRows[c.first + i].dummy) havePre = false;
             }
@@ -1277,9 +1291,10 @@ void BinEncoder::checkMatcher(const Batch& data, const Batch& graph, const BinIn
     m.encodeLz(data, graph, bin, arch, tmp);
     m.matchTrace = nullptr; m.traceResize = false;
     const std::vector<fsdev::MatchRead> tReads = m.mReads; const std::vector<fsdev::MatchCall> tCalls = m.mCalls; const std::vector<uint32_t> tWarm = m.mWarm;
+    m.curBin = &bin; m.B = &data;
     std::vector<fsdev::MatchRow> dev(tReads.size());
     memset(dev.data(), 0, dev.size() * sizeof(fsdev::MatchRow));
-    if (!fn(data.seq.data() + m.matchSeqBase, m.matchSeqBytes, tReads.data(), tReads.size(), tCalls.data(), tCalls.size(), tWarm.data(), tWarm.size(), m.matchParams(), dev.data())) throw std::runtime_error("device matcher did not run");
+    if (!fn(data.seq.data() + m.matchSeqBase, m.matchSeqBytes, m.packedDna(), tReads.data(), tReads.size(), tCalls.data(), tCalls.size(), tWarm.data(), tWarm.size(), m.matchParams(), dev.data())) throw std::runtime_error("device matcher did not run");
     for (const fsdev::MatchCall& c : tCalls)
         for (uint32_t i = 0; i < c.count; ++i) {
             const fsdev::MatchRow &a = host[c.first + i], &b = dev[c.first + i];

@@ -74,7 +74,8 @@ struct ArchiveParams { BinModuleConfigRaw cfg{}; HeaderStats head; QvzModel qvz;
 
 // The device-side window search (matcher.hip) as the front end sees it: the bin's bases, the table of its match-tree
 // constructions, one row of answers per read.  Returns false when the search could not be run (the host scan is used).
-typedef std::function<bool(const uint8_t* seq, size_t seqBytes, const fsdev::MatchRead* reads, size_t nReads, const fsdev::MatchCall* calls,
+// packed != nullptr: the same bases as the bin file stores them (fsdev::PackedDna): the device unpacks them itself and `seq` does not travel.
+typedef std::function<bool(const uint8_t* seq, size_t seqBytes, const fsdev::PackedDna* packed, const fsdev::MatchRead* reads, size_t nReads, const fsdev::MatchCall* calls,
                            size_t nCalls, const uint32_t* warm, size_t nWarm, const fsdev::MatchParams& par, fsdev::MatchRow* rows)> MatchFn;
 
 // The device-side mate search of a paired-end bin (matcher.hip: fs_match_mates): the bin's bases, its pairs in the order the

@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -59,6 +60,53 @@ template <int FW> __global__ __launch_bounds__(256) void fs_pack_bases(const uin
     }
     uint32_t* o = planes + (size_t)r * (4 * FW);
     o[w] = p0; o[FW + w] = p1; o[2 * FW + w] = pn; o[3 * FW + w] = pv;
+}
+
+// The same planes straight from the bin file's packed bases (the reader of fastore_bin/FastqPacker.cpp:290-411,
+// IFastqPacker::ReadNextRecord: a read's bases MSB first, two bits each -- index into the archive's symbol order -- or three
+// when the read holds an 'N'; the signature's bases are not stored, they are the base-4 digits of the signature at sig_pos).
+// One thread per plane word again: its 32 bases are at most 96 consecutive bits of the stream.  No ASCII in between: the code
+// of a base goes through the symbol order to the same three plane bits fs_pack_bases takes from the character.
+// order: the five symbols of the archive (MinimizerParameters::dnaSymbolOrder), a byte each in two words.
+template <int FW> __global__ __launch_bounds__(256) void fs_unpack_planes(const uint8_t* __restrict__ dna, const PackedRead* __restrict__ packed, const MatchRead* __restrict__ reads,
+                                                                           uint32_t nReads, uint32_t order0, uint32_t order1, uint32_t sigLen, uint32_t* __restrict__ planes)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t r = g / FW, w = g % FW;
+    if (r >= nReads) return;
+    const MatchRead rd = reads[r];
+    const PackedRead pk = packed[r];
+    const bool plain = (pk.info & PACKED_PLAIN) != 0u, hasSig = (pk.info & PACKED_HAS_SIG) != 0u;
+    const uint32_t sigId = pk.info & ((1u << PACKED_SIG_BITS) - 1u), sigPos = (pk.info >> PACKED_SIG_BITS) & 0xFFu, hole = hasSig ? sigLen : 0u;
+    const uint32_t bits = plain ? 2u : 3u;
+    const int32_t OFF = 32 * (FW / 2);
+    uint32_t p0 = 0, p1 = 0, pn = 0, pv = 0;
+    for (uint32_t b = 0; b < 32u; ++b) {
+        const int32_t pos = (int32_t)(32u * w + b) - OFF + (int32_t)rd.min_pos;
+        if (pos < 0 || pos >= (int32_t)rd.len) continue;
+        uint32_t code;
+        if (hasSig && (uint32_t)pos >= sigPos && (uint32_t)pos < sigPos + hole) code = (sigId >> (2u * (hole - 1u - ((uint32_t)pos - sigPos)))) & 3u;
+        else {
+            const uint32_t j = (uint32_t)pos < sigPos || !hasSig ? (uint32_t)pos : (uint32_t)pos - hole;
+            const uint64_t at = (uint64_t)pk.bit_off + (uint64_t)bits * j;
+            const uint8_t* q = dna + (at >> 3);
+            const uint32_t two = ((uint32_t)q[0] << 8) | (uint32_t)q[1];                  // (the buffer ends with spare bytes)
+            code = (two >> (16u - (uint32_t)(at & 7u) - bits)) & ((1u << bits) - 1u);
+        }
+        const uint32_t c = code < 4u ? (order0 >> (8u * code)) & 0xFFu : (code == 4u ? order1 & 0xFFu : 0u);
+        const bool acgt = c == 'A' || c == 'C' || c == 'G' || c == 'T';
+        const uint32_t pc = acgt ? (c >> 1) & 3u : 0u;
+        p0 |= (pc & 1u) << b; p1 |= (pc >> 1) << b; pn |= (acgt ? 0u : 1u) << b; pv |= 1u << b;
+    }
+    uint32_t* o = planes + (size_t)r * (4 * FW);
+    o[w] = p0; o[FW + w] = p1; o[2 * FW + w] = pn; o[3 * FW + w] = pv;
+}
+
+// FS_UNPACK_CHECK=1: both ways of making the planes, word by word
+__global__ void fs_compare_words(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n, uint32_t* __restrict__ differing)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n && a[i] != b[i]) atomicAdd(differing, 1u);
 }
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x)
@@ -394,11 +442,18 @@ struct StreamPool { hipStream_t s[kMatchStreamsMax] = {}; int users = 0; unsigne
 static int matchStreams() { static const int n = []() { const char* e = getenv("FS_MATCHER_STREAMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > kMatchStreamsMax ? (int)kMatchStreamsMax : v); }(); return n; }
 static std::mutex g_poolMx; static StreamPool g_pool[16];
 
+// parity check of the device-side unpack (fsgpu_unpack_check, or FS_UNPACK_CHECK=1 for a whole run): plane words compared / differing
+std::atomic<bool> g_unpackCheck{getenv("FS_UNPACK_CHECK") && atoi(getenv("FS_UNPACK_CHECK")) != 0};
+std::atomic<uint64_t> g_unpackChecked{0}, g_unpackDiffering{0};
+void unpack_check(bool on) { g_unpackCheck = on; if (on) { g_unpackChecked = 0; g_unpackDiffering = 0; } }
+void unpack_check_counts(uint64_t* words, uint64_t* differing) { *words = g_unpackChecked.load(); *differing = g_unpackDiffering.load(); }
+
 struct MatchLane {
     int deviceId = 0;
     hipStream_t stream = nullptr; hipEvent_t evWait = nullptr, ev0 = nullptr, ev1 = nullptr;
     uint8_t* dSeq = nullptr; size_t capSeq = 0;
     MatchRead* dReads = nullptr; size_t capReads = 0;
+    PackedRead* dPacked = nullptr; size_t capPacked = 0;      // (device-side unpack: dSeq then holds the bin's packed bases)
     MatchCall* dCalls = nullptr; size_t capCalls = 0;
     uint32_t* dIds = nullptr; size_t capIds = 0;
     uint32_t* dWarm = nullptr; size_t capWarm = 0;
@@ -441,7 +496,7 @@ void match_lane_destroy(MatchLane* m)
         if (--p.users == 0) { for (int i = 0; i < kMatchStreamsMax; ++i) if (p.s[i]) { (void)hipStreamDestroy(p.s[i]); p.s[i] = nullptr; } }
         m->stream = nullptr;
     }
-    void* ptrs[] = {m->dSeq, m->dReads, m->dCalls, m->dIds, m->dWarm, m->dPlanes, m->dRows, m->dPairs, m->dMateRows, m->dValid};
+    void* ptrs[] = {m->dSeq, m->dReads, m->dPacked, m->dCalls, m->dIds, m->dWarm, m->dPlanes, m->dRows, m->dPairs, m->dMateRows, m->dValid};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->hStage) pinned_free(m->hStage, m->capStage, !m->stagePageable);
     if (m->evWait) (void)hipEventDestroy(m->evWait);
@@ -456,10 +511,10 @@ int match_lane_reserve(Device* dev, MatchLane* m, size_t maxReads, size_t maxSeq
 {
     HIP_TRY(hipSetDevice(m->deviceId));
     const size_t planeBytes = maxReads * (size_t)(4 * 16) * 4u;
-    if (ensureBuf(dev, m->dSeq, m->capSeq, maxSeqBytes + 64) || ensureBuf(dev, m->dReads, m->capReads, maxReads * sizeof(MatchRead)) ||
+    if (ensureBuf(dev, m->dSeq, m->capSeq, maxSeqBytes + 64) || ensureBuf(dev, m->dReads, m->capReads, maxReads * sizeof(MatchRead)) || ensureBuf(dev, m->dPacked, m->capPacked, maxReads * sizeof(PackedRead)) ||
         ensureBuf(dev, m->dCalls, m->capCalls, maxCalls * sizeof(MatchCall)) || ensureBuf(dev, m->dIds, m->capIds, maxCalls * 4u) || ensureBuf(dev, m->dWarm, m->capWarm, maxWarm * 4u + 16) ||
         ensureBuf(dev, m->dPlanes, m->capPlanes, planeBytes) || ensureBuf(dev, m->dRows, m->capRows, maxReads * sizeof(MatchRow))) return -1;
-    const size_t upBytes = ((maxSeqBytes + 15) & ~(size_t)15) + ((maxReads * sizeof(MatchRead) + 15) & ~(size_t)15) + ((maxCalls * sizeof(MatchCall) + 15) & ~(size_t)15) + ((maxCalls * 4u + 15) & ~(size_t)15) + maxWarm * 4u + 64;
+    const size_t upBytes = ((maxSeqBytes + 64 + 15) & ~(size_t)15) + ((maxReads * sizeof(PackedRead) + 15) & ~(size_t)15) + ((maxReads * sizeof(MatchRead) + 15) & ~(size_t)15) + ((maxCalls * sizeof(MatchCall) + 15) & ~(size_t)15) + ((maxCalls * 4u + 15) & ~(size_t)15) + maxWarm * 4u + 64;
     if (upBytes > m->capStage) {
         if (m->hStage) pinned_free(m->hStage, m->capStage, !m->stagePageable);
         m->hStage = nullptr; m->capStage = 0;
@@ -473,13 +528,24 @@ int match_lane_reserve(Device* dev, MatchLane* m, size_t maxReads, size_t maxSeq
 
 // One bin's searches.  seq: the bin's bases (ASCII); reads: every read of every construction, each construction's reads in
 // processing order (a sub-tree's root copy is one more read, named by its call); rows[i] answers reads[i] (root copies: unset).
-int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, const MatchRead* reads, size_t nReads,
+int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, const PackedDna* packed, const MatchRead* reads, size_t nReads,
                 const MatchCall* calls, size_t nCalls, const uint32_t* warm, size_t nWarm, const MatchParams& par, MatchRow* rows, double* kernelMs)
 {
     if (nReads == 0 || nCalls == 0) return 0;
     if (par.window < 2u || par.window > 1025u) { snprintf(dev->err, sizeof dev->err, "device matcher: window of %u slots not supported (2..1025)", par.window); return -1; }
     HIP_TRY(hipSetDevice(m->deviceId));
     uint32_t maxLen = 0;
+    if (packed) {      // every read's stored bits inside the packed bytes: nothing the kernel reads is taken on trust
+        if (packed->sig_len * 2u > PACKED_SIG_BITS || !packed->dna || !packed->reads) { snprintf(dev->err, sizeof dev->err, "device matcher: packed bases with a signature of %u bases", packed->sig_len); return -1; }
+        for (size_t i = 0; i < nReads; ++i) {
+            const PackedRead& q = packed->reads[i];
+            const uint32_t hole = (q.info & PACKED_HAS_SIG) ? packed->sig_len : 0u, sigPos = (q.info >> PACKED_SIG_BITS) & 0xFFu;
+            if (hole > reads[i].len || (hole && sigPos + hole > reads[i].len)) { snprintf(dev->err, sizeof dev->err, "device matcher: read %zu: signature outside the read", i); return -1; }
+            const uint64_t endBit = (uint64_t)q.bit_off + (uint64_t)((q.info & PACKED_PLAIN) ? 2u : 3u) * (reads[i].len - hole);
+            if (endBit > 8ull * packed->bytes) { snprintf(dev->err, sizeof dev->err, "device matcher: read %zu outside the packed bases", i); return -1; }
+        }
+    }
+    const size_t srcBytes = packed ? packed->bytes : seqBytes;         // what goes up in dSeq
     for (size_t i = 0; i < nReads; ++i) {
         if ((uint64_t)reads[i].seq_off + reads[i].len > seqBytes || reads[i].min_pos > reads[i].len) { snprintf(dev->err, sizeof dev->err, "device matcher: read %zu outside the bases", i); return -1; }
         maxLen = std::max<uint32_t>(maxLen, reads[i].len);
@@ -500,11 +566,11 @@ int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
         else large[slots <= 128u ? 0 : (slots <= 256u ? 1 : (slots <= 512u ? 2 : 3))].push_back((uint32_t)c);
     }
     const size_t planeBytes = nReads * (size_t)(4 * FW) * 4u;
-    if (ensureBuf(dev, m->dSeq, m->capSeq, seqBytes + 64) || ensureBuf(dev, m->dReads, m->capReads, nReads * sizeof(MatchRead)) ||
+    if (ensureBuf(dev, m->dSeq, m->capSeq, srcBytes + 64) || ensureBuf(dev, m->dReads, m->capReads, nReads * sizeof(MatchRead)) || (packed && ensureBuf(dev, m->dPacked, m->capPacked, nReads * sizeof(PackedRead))) ||
         ensureBuf(dev, m->dCalls, m->capCalls, nCalls * sizeof(MatchCall)) || ensureBuf(dev, m->dIds, m->capIds, nCalls * 4u) || ensureBuf(dev, m->dWarm, m->capWarm, nWarm * 4u + 16) ||
         ensureBuf(dev, m->dPlanes, m->capPlanes, planeBytes) || ensureBuf(dev, m->dRows, m->capRows, nReads * sizeof(MatchRow))) return -1;
     // pinned staging for everything that goes up (the callers' arrays are pageable)
-    const size_t upBytes = ((seqBytes + 15) & ~(size_t)15) + ((nReads * sizeof(MatchRead) + 15) & ~(size_t)15) + ((nCalls * sizeof(MatchCall) + 15) & ~(size_t)15) + ((nCalls * 4u + 15) & ~(size_t)15) + nWarm * 4u + 64;
+    const size_t upBytes = ((srcBytes + 64 + 15) & ~(size_t)15) + (packed ? (nReads * sizeof(PackedRead) + 15) & ~(size_t)15 : 0) + ((nReads * sizeof(MatchRead) + 15) & ~(size_t)15) + ((nCalls * sizeof(MatchCall) + 15) & ~(size_t)15) + ((nCalls * 4u + 15) & ~(size_t)15) + nWarm * 4u + 64;
     if (upBytes > m->capStage) {
         if (m->hStage) pinned_free(m->hStage, m->capStage, !m->stagePageable);
         m->hStage = nullptr; m->capStage = 0;
@@ -514,7 +580,9 @@ int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
         m->capStage = want;
     }
     uint8_t* h = m->hStage; size_t o = 0;
-    memcpy(h + o, seq, seqBytes); const size_t oSeq = o; o += (seqBytes + 15) & ~(size_t)15;
+    memcpy(h + o, packed ? packed->dna : seq, srcBytes); memset(h + o + srcBytes, 0, 64); const size_t oSeq = o; o += (srcBytes + 64 + 15) & ~(size_t)15;      // (spare bytes: the unpack kernel reads two bytes per base)
+    size_t oPacked = 0;
+    if (packed) { memcpy(h + o, packed->reads, nReads * sizeof(PackedRead)); oPacked = o; o += (nReads * sizeof(PackedRead) + 15) & ~(size_t)15; }
     memcpy(h + o, reads, nReads * sizeof(MatchRead)); const size_t oReads = o; o += (nReads * sizeof(MatchRead) + 15) & ~(size_t)15;
     memcpy(h + o, calls, nCalls * sizeof(MatchCall)); const size_t oCalls = o; o += (nCalls * sizeof(MatchCall) + 15) & ~(size_t)15;
     uint32_t* hid = (uint32_t*)(h + o); const size_t oIds = o; size_t nid = 0;
@@ -524,16 +592,39 @@ int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
     const size_t oWarm = o;
     if (nWarm) memcpy(h + o, warm, nWarm * 4u);
     hipStream_t st = m->stream;
-    HIP_TRY(hipMemcpyAsync(m->dSeq, h + oSeq, seqBytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->dSeq, h + oSeq, srcBytes + (packed ? 64 : 0), hipMemcpyHostToDevice, st));
+    if (packed) HIP_TRY(hipMemcpyAsync(m->dPacked, h + oPacked, nReads * sizeof(PackedRead), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->dReads, h + oReads, nReads * sizeof(MatchRead), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->dCalls, h + oCalls, nCalls * sizeof(MatchCall), hipMemcpyHostToDevice, st));
     if (nid) HIP_TRY(hipMemcpyAsync(m->dIds, h + oIds, nid * 4u, hipMemcpyHostToDevice, st));
     if (nWarm) HIP_TRY(hipMemcpyAsync(m->dWarm, h + oWarm, nWarm * 4u, hipMemcpyHostToDevice, st));
     HIP_TRY(hipEventRecord(m->ev0, st));
     const uint32_t packBlocks = (uint32_t)((nReads * (size_t)FW + 255) / 256);
-    if (FW == 10) hipLaunchKernelGGL(fs_pack_bases<10>, dim3(packBlocks), dim3(256), 0, st, (const uint8_t*)m->dSeq, (const MatchRead*)m->dReads, (uint32_t)nReads, m->dPlanes);
-    else hipLaunchKernelGGL(fs_pack_bases<16>, dim3(packBlocks), dim3(256), 0, st, (const uint8_t*)m->dSeq, (const MatchRead*)m->dReads, (uint32_t)nReads, m->dPlanes);
-    HIP_TRY(hipGetLastError());
+    if (packed) {
+        uint32_t o0 = 0, o1 = 0; memcpy(&o0, packed->symbol_order, 4); memcpy(&o1, packed->symbol_order + 4, 4);
+        if (FW == 10) hipLaunchKernelGGL(fs_unpack_planes<10>, dim3(packBlocks), dim3(256), 0, st, (const uint8_t*)m->dSeq, (const PackedRead*)m->dPacked, (const MatchRead*)m->dReads, (uint32_t)nReads, o0, o1, packed->sig_len, m->dPlanes);
+        else hipLaunchKernelGGL(fs_unpack_planes<16>, dim3(packBlocks), dim3(256), 0, st, (const uint8_t*)m->dSeq, (const PackedRead*)m->dPacked, (const MatchRead*)m->dReads, (uint32_t)nReads, o0, o1, packed->sig_len, m->dPlanes);
+        HIP_TRY(hipGetLastError());
+        if (g_unpackCheck.load()) {      // the planes once more from the ASCII bases (what the host unpacked), word by word against the device's own
+            uint8_t* dAscii = nullptr; uint32_t* dPlanes2 = nullptr; uint32_t* dDiff = nullptr; uint32_t diff = 0;
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipMalloc((void**)&dAscii, seqBytes + 64)); HIP_TRY(hipMalloc((void**)&dPlanes2, planeBytes)); HIP_TRY(hipMalloc((void**)&dDiff, 4));
+            HIP_TRY(hipMemcpy(dAscii, seq, seqBytes, hipMemcpyHostToDevice)); HIP_TRY(hipMemset(dDiff, 0, 4));
+            if (FW == 10) hipLaunchKernelGGL(fs_pack_bases<10>, dim3(packBlocks), dim3(256), 0, st, (const uint8_t*)dAscii, (const MatchRead*)m->dReads, (uint32_t)nReads, dPlanes2);
+            else hipLaunchKernelGGL(fs_pack_bases<16>, dim3(packBlocks), dim3(256), 0, st, (const uint8_t*)dAscii, (const MatchRead*)m->dReads, (uint32_t)nReads, dPlanes2);
+            const size_t words = planeBytes / 4u;
+            hipLaunchKernelGGL(fs_compare_words, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, st, (const uint32_t*)m->dPlanes, (const uint32_t*)dPlanes2, words, dDiff);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipMemcpy(&diff, dDiff, 4, hipMemcpyDeviceToHost));
+            (void)hipFree(dAscii); (void)hipFree(dPlanes2); (void)hipFree(dDiff);
+            g_unpackChecked += words; g_unpackDiffering += diff;
+        }
+    } else {
+        if (FW == 10) hipLaunchKernelGGL(fs_pack_bases<10>, dim3(packBlocks), dim3(256), 0, st, (const uint8_t*)m->dSeq, (const MatchRead*)m->dReads, (uint32_t)nReads, m->dPlanes);
+        else hipLaunchKernelGGL(fs_pack_bases<16>, dim3(packBlocks), dim3(256), 0, st, (const uint8_t*)m->dSeq, (const MatchRead*)m->dReads, (uint32_t)nReads, m->dPlanes);
+        HIP_TRY(hipGetLastError());
+    }
     auto launch = [&](size_t at, size_t n, uint32_t threads) {
         if (!n) return;
         const uint32_t* idp = m->dIds + at;

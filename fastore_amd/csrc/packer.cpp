@@ -417,7 +417,7 @@ MatchFn Context::matcherFor(uint32_t tid)
 {
     if (!deviceMatcher) return MatchFn();
     if (matchLanes.size() <= tid) throw std::runtime_error("matcher lanes not sized");       // (sized by the callers before their threads start)
-    return [this, tid](const uint8_t* seq, size_t seqBytes, const fsdev::MatchRead* reads, size_t nReads, const fsdev::MatchCall* calls, size_t nCalls,
+    return [this, tid](const uint8_t* seq, size_t seqBytes, const fsdev::PackedDna* packed, const fsdev::MatchRead* reads, size_t nReads, const fsdev::MatchCall* calls, size_t nCalls,
                        const uint32_t* warm, size_t nWarm, const fsdev::MatchParams& mp, fsdev::MatchRow* rows) -> bool {
         // (a device still on its way -- one-shot contexts -- is waited for a little: the heaviest bins, searched first, gain
         // most from it; should it take longer -- a driver clearing memory -- the host scan gives the same rows)
@@ -431,7 +431,8 @@ MatchFn Context::matcherFor(uint32_t tid)
                 throw std::runtime_error(std::string("device: ") + dev->err);
         }
         const double t0 = nowMs(); double kms = 0;
-        if (fsengine::match_reads(dev, matchLanes[tid], seq, seqBytes, reads, nReads, calls, nCalls, warm, nWarm, mp, rows, &kms) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+        if (fsengine::match_reads(dev, matchLanes[tid], seq, seqBytes, packed, reads, nReads, calls, nCalls, warm, nWarm, mp, rows, &kms) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+        matchBasesUp += packed ? packed->bytes + nReads * sizeof(fsdev::PackedRead) : seqBytes; if (packed) matchUnpackedReads += nReads;
         matchedReads += nReads; matchUs += (uint64_t)((nowMs() - t0) * 1e3); matchKernelUs += (uint64_t)(kms * 1e3);
         return true;
     };
@@ -486,7 +487,7 @@ void Context::matcherCheck(const std::string& inPrefix, uint64_t& reads, uint64_
     const bool keep = deviceMatcher; deviceMatcher = true;
     if (matchLanes.size() < hostThreads) matchLanes.resize(hostThreads, nullptr);
     parallelFor((uint32_t)sigs.size(), std::min<uint32_t>(hostThreads, 8u), [&](uint32_t k, uint32_t tid) {
-        Batch b; bf.unpack(sigs[k], b, true);
+        Batch b; bf.unpack(sigs[k], b, true, deviceUnpack());
         BinEncoder enc(par);
         uint64_t r = 0, d = 0;
         enc.checkMatcher(b, b, b.bins.at(0), arch, matcherFor(tid), r, d);
@@ -1334,7 +1335,9 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             ++stats.device_batches;
             // record arrays are placed: their sizes are in the .bmeta footer, so every bin knows its offsets up front and
             // is unpacked by the same host task that runs its front end (no barrier between the two stages)
-            std::vector<uint64_t> seqBase(nb + 1, 0), headBase(nb + 1, 0), recBase(nb + 1, 0), quaBase(nb + 1, 0), hpBase(nb + 1, 0), weight(nb);
+            std::vector<uint64_t> seqBase(nb + 1, 0), headBase(nb + 1, 0), recBase(nb + 1, 0), quaBase(nb + 1, 0), hpBase(nb + 1, 0), dpBase(nb + 1, 0), weight(nb);
+            // device-side unpack of the bases for the window search: the bins' .bdna bytes are kept as stored (FS_DEVICE_UNPACK=0: the ASCII bases go up)
+            const bool packedD = deviceMatcher && deviceUnpack();
             // device-side read-id tokeniser: the headers stay packed too (FS_DEVICE_IDS=0: host tokeniser)
             bool packedH = !(getenv("FS_DEVICE_IDS") && atoi(getenv("FS_DEVICE_IDS")) == 0);
             for (uint32_t k = 0; k < nb; ++k) if (!libs[work[first + k].lib]->bf.usesHeaders()) packedH = false;
@@ -1348,6 +1351,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                 seqBase[k + 1] = seqBase[k] + bi.totalRawDnaSize; headBase[k + 1] = headBase[k] + bi.totalRawHeadSize; recBase[k + 1] = recBase[k] + bi.totalRecordsCount;
                 quaBase[k + 1] = quaBase[k] + ((bi.totalQuaSize + 15u) & ~15ull);
                 hpBase[k + 1] = hpBase[k] + ((bi.totalHeadSize + 15u) & ~15ull);
+                dpBase[k + 1] = dpBase[k] + ((bi.totalDnaSize + 16u + 15u) & ~15ull);
                 weight[k] = bi.totalRecordsCount;
             }
             // what a bin brings into a lane's staging buffer, roughly: its quality scores (packed, or a byte / a pair each), its
@@ -1372,6 +1376,8 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             }
             if (packedQ) { batch.qua.clear(); batch.quaPacked.resize(quaBase[nb]); batch.quaBit.resize(recBase[nb]); }
             else { batch.qua.resize(seqBase[nb]); batch.quaPacked.clear(); batch.quaBit.clear(); }
+            if (packedD) { batch.dnaPacked.resize(dpBase[nb]); batch.dnaBit.resize(recBase[nb]); batch.dnaInfo.resize(recBase[nb]); }
+            else { batch.dnaPacked.clear(); batch.dnaBit.clear(); batch.dnaInfo.clear(); }
             std::vector<Batch> graph(nb);                              // per bin: its stored graph (node indices local to it)
             for (size_t k = first; k < next; ++k) binArch.push_back(work[k].lib);
             stats.io_ms += nowMs() - tio;
@@ -1402,7 +1408,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             compressBins(nb, weight, binArch, [&](uint32_t k, BinEncoder& enc, BinStreams& out, BinIn& info, uint64_t& recBytes) {
                 const Work& w = work[first + k];
                 const double tu = getenv("FS_BIN_TRACE") ? nowMs() : 0;
-                libs[w.lib]->bf.unpackPlaced(w.sig, batch, seqBase[k], headBase[k], (uint32_t)recBase[k], graph[k], packedQ ? (int64_t)quaBase[k] : -1, packedH ? (int64_t)hpBase[k] : -1);
+                libs[w.lib]->bf.unpackPlaced(w.sig, batch, seqBase[k], headBase[k], (uint32_t)recBase[k], graph[k], packedQ ? (int64_t)quaBase[k] : -1, packedH ? (int64_t)hpBase[k] : -1, packedD ? (int64_t)dpBase[k] : -1);
                 if (tu > 0 && recBase[k + 1] - recBase[k] >= 40000) fprintf(stderr, "[bin] %llu records: unpack %.1f ms\n", (unsigned long long)(recBase[k + 1] - recBase[k]), nowMs() - tu);
                 info = graph[k].bins.at(0);
                 enc.encodeLz(batch, graph[k], info, archives[w.lib], out);

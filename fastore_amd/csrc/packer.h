@@ -2,6 +2,7 @@
 // blocks; plus the merged small-bins/N block and the archive writer (drop-in boundary).
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 #include <atomic>
 #include <functional>
 #include <memory>
@@ -128,7 +129,9 @@ struct Context {
     uint32_t stealSeq = 0;
     std::vector<std::string> stealNames;          // the counters of the last packs (files in /dev/shm: taken away two packs later, and with the context)
     struct { size_t reads = 0, seqBytes = 0, calls = 0, warm = 0; } matchReserve;     // bounds of the largest bin of the coming batch (0: grow on demand)
-    std::atomic<uint64_t> matchedReads{0}, matchUs{0}, matchKernelUs{0};
+    std::atomic<uint64_t> matchedReads{0}, matchUs{0}, matchKernelUs{0}, matchBasesUp{0}, matchUnpackedReads{0};
+    // the device unpacks the bases of the window search itself from the bin's .bdna bytes (FS_DEVICE_UNPACK=0: ASCII bases go up)
+    static bool deviceUnpack() { const char* e = getenv("FS_DEVICE_UNPACK"); return !(e && atoi(e) == 0); }      // (read per batch)
     MatchFn matcherFor(uint32_t tid);
     MateFn mateMatcherFor(uint32_t tid);          // the mate searches of host thread `tid` (paired-end bins): the same lane
     std::atomic<uint64_t> matedPairs{0}, mateUs{0}, mateKernelUs{0};

@@ -118,6 +118,10 @@ typedef struct fsgpu_stats {
      * used / prepared in vain (forecast unusable, or the serial walk touched one of the window's contexts) */
     uint64_t ppmd_windows_ahead, ppmd_windows_ahead_in_vain;
     uint64_t stolen_bins;                /* bin-sharded packs: bins of the job's work-stealing tail that this rank claimed (the lightest 15 % of the records are not dealt up front) */
+    /* window search (fs_match_reads): bytes of bases that went up for it -- packed as the bin file stores them (.bdna) plus a
+     * descriptor per read when the device unpacks them itself (fs_unpack_planes; FastqPacker.cpp:290-411), else ASCII --
+     * and the reads whose bases the device unpacked */
+    uint64_t matcher_bases_h2d_bytes, matcher_unpacked_reads;
 } fsgpu_stats;
 
 void fsgpu_config_defaults(fsgpu_config* cfg);
@@ -181,6 +185,14 @@ int fsgpu_gather_quality_binned(fsgpu_ctx* ctx, const uint8_t* packed, size_t pa
  * serial window scan and through the device; *reads = reads searched, *differing = rows (matched read, cost, shift,
  * mismatch-free flag, exact-duplicate flag) on which the two disagree. */
 int fsgpu_matcher_check(fsgpu_ctx* ctx, const char* in_prefix, uint64_t* reads, uint64_t* differing);
+
+/* Parity check of the device-side unpack of the bases (matcher.hip: fs_unpack_planes; the reader side of the bin file,
+ * IFastqPacker::ReadNextRecord, fastore_bin/FastqPacker.cpp:290-411, and the signature the packer leaves out): every standard bin
+ * of the library <in_prefix> goes through the window search with its bases as the bin file stores them (.bdna bytes + a descriptor
+ * per read) while the same bit planes are built from the bases the host unpacked; *plane_words = words compared, *differing =
+ * words on which the two disagree; *reads / *differing_rows as fsgpu_matcher_check (the rows of the search on the device-unpacked
+ * bases against the host scan). */
+int fsgpu_unpack_check(fsgpu_ctx* ctx, const char* in_prefix, uint64_t* plane_words, uint64_t* differing, uint64_t* reads, uint64_t* differing_rows);
 
 /* Parity check of the device-side mate search of paired-end bins (matcher.hip: fs_match_mates; LzCompressorPE::CompressPair's
  * history search, fastore_pack/FastqCompressor.cpp:4610-4959, with the minimizer sets of FastqCategorizerBase::FindMinimizers,

@@ -98,9 +98,39 @@ struct MatchLane { int unused; };
 int match_lane_create(Device*, MatchLane** out) { *out = new MatchLane(); return 0; }
 void match_lane_destroy(MatchLane* m) { delete m; }
 int match_lane_reserve(Device*, MatchLane*, size_t, size_t, size_t, size_t) { return 0; }
-int match_reads(Device*, MatchLane*, const uint8_t* seq, size_t, const MatchRead* reads, size_t, const MatchCall* calls, size_t nCalls,
+static std::atomic<uint64_t> g_unpackWords{0}, g_unpackDiff{0};
+void unpack_check(bool on) { if (on) { g_unpackWords = 0; g_unpackDiff = 0; } }
+void unpack_check_counts(uint64_t* words, uint64_t* differing) { *words = g_unpackWords.load(); *differing = g_unpackDiff.load(); }
+int match_reads(Device* dev, MatchLane*, const uint8_t* seqIn, size_t seqBytes, const PackedDna* packed, const MatchRead* reads, size_t nReads, const MatchCall* calls, size_t nCalls,
                 const uint32_t* warm, size_t, const MatchParams& par, MatchRow* rows, double*)
 {
+    // packed bases: what fs_unpack_planes reads, base by base (the stand-in searches on THESE bases, and holds them against the
+    // host's unpacked ones: a wrong descriptor shows as a differing base here and as different rows in the parity tests)
+    std::vector<uint8_t> own;
+    const uint8_t* seq = seqIn;
+    if (packed) {
+        own.assign(seqBytes, 0);
+        for (size_t i = 0; i < nReads; ++i) {
+            const PackedRead& q = packed->reads[i]; const MatchRead& rd = reads[i];
+            const bool plain = (q.info & PACKED_PLAIN) != 0u, hasSig = (q.info & PACKED_HAS_SIG) != 0u;
+            const uint32_t sigId = q.info & ((1u << PACKED_SIG_BITS) - 1u), sigPos = (q.info >> PACKED_SIG_BITS) & 0xFFu, hole = hasSig ? packed->sig_len : 0u, bits = plain ? 2u : 3u;
+            for (uint32_t pos = 0; pos < rd.len; ++pos) {
+                uint32_t code;
+                if (hasSig && pos >= sigPos && pos < sigPos + hole) code = (sigId >> (2u * (hole - 1u - (pos - sigPos)))) & 3u;
+                else {
+                    const uint32_t j = pos < sigPos || !hasSig ? pos : pos - hole;
+                    const uint64_t at = (uint64_t)q.bit_off + (uint64_t)bits * j;
+                    if (at + bits > 8ull * packed->bytes) { snprintf(dev->err, sizeof dev->err, "device matcher: read %zu outside the packed bases", i); return -1; }
+                    code = 0;
+                    for (uint32_t b = 0; b < bits; ++b) { const uint64_t x = at + b; code = (code << 1) | ((packed->dna[x >> 3] >> (7u - (uint32_t)(x & 7u))) & 1u); }
+                }
+                const uint8_t c = code < 5u ? packed->symbol_order[code] : 0;
+                own[rd.seq_off + pos] = c;
+                ++g_unpackWords; if (c != seqIn[rd.seq_off + pos]) ++g_unpackDiff;
+            }
+        }
+        seq = own.data();
+    }
     const uint32_t cap = par.window - 1u;
     for (size_t c = 0; c < nCalls; ++c) {
         const MatchCall& call = calls[c];

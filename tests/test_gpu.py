@@ -476,6 +476,29 @@ def test_device_mate_search_on_a_fresh_library_and_same_archive_either_way(tmp_p
             assert got[sg] == want[sg], (mode, sg)
 
 
+@pytest.mark.parametrize("name,paired,flags", manifest())
+def test_device_unpack_of_the_bases_agrees_with_the_host_unpack(tmp_path, monkeypatch, name, paired, flags):
+    # fs_unpack_planes (the reader of FastqPacker.cpp:290-411 on the device): the window search's bit planes from
+    # the bin's .bdna bytes -- two- and three-bit reads, the signature that is not stored, sub-tree reads with their own
+    # signature, exact-match records that have no bases of their own -- word by word against the planes fs_pack_bases makes
+    # from the host's unpacked bases, on every golden bin; the rows of the search on them against the host scan; and the
+    # archive, which is the reference's either way while only the packed bytes go up
+    import fastore_amd
+    with fastore_amd.Packer(device_id=0, **knobs_from_flags(flags)) as p:
+        words, differing, reads, rows = p.unpack_check(os.path.join(GOLDEN, name + ".in"))
+    assert words >= 40 * reads and differing == 0 and reads > 1000 and rows == 0, (words, differing, reads, rows)
+    ref = open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
+    seen = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FS_DEVICE_UNPACK", mode)
+        with fastore_amd.Packer(device_id=0, **knobs_from_flags(flags)) as p:
+            seen[mode] = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o" + mode)))
+        assert open(str(tmp_path / ("o" + mode)) + ".cdata", "rb").read() == ref
+    assert seen["0"]["matcher_unpacked_reads"] == 0 and seen["0"]["matcher_reads"] > 0
+    assert seen["1"]["matcher_unpacked_reads"] == seen["1"]["matcher_reads"] > 0
+    assert seen["1"]["matcher_bases_h2d_bytes"] < 0.45 * seen["0"]["matcher_bases_h2d_bytes"]
+
+
 @pytest.mark.parametrize("window", [2, 3, 5, 64, 65, 66, 129, 300, 1025])
 def test_device_matcher_window_sizes(window):
     # windows of one slot up to the largest the kernel takes (one thread per slot, 1 .. 16 wavefronts): ring wrap-around,
@@ -500,6 +523,8 @@ def test_device_matcher_on_fresh_libraries_and_same_archive_either_way(tmp_path,
     with fastore_amd.Packer(device_id=0, **kn) as p:
         n, differing = p.matcher_check(binned)
         assert n > reads // 4 and differing == 0, (n, differing)
+        words, wrong, n2, rows = p.unpack_check(binned)         # ... and the planes from the packed bases against those from the unpacked ones
+        assert words >= 40 * n2 and wrong == 0 and n2 == n and rows == 0, (words, wrong, n2, rows)
         ids, bad_bins = p.tokeniser_check(binned)              # the same libraries through the device tokeniser
         assert ids > reads // 4 and bad_bins == 0, (ids, bad_bins)
         p.pack_file(binned, os.path.join(t, "dev"))

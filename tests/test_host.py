@@ -40,7 +40,7 @@ def test_c_abi_exports_every_declared_symbol(product_lib):
 def test_structs_match_header_layout(product_lib):
     import fastore_amd
     assert ctypes.sizeof(fastore_amd.Config) == 96
-    assert ctypes.sizeof(fastore_amd.Stats) == 312
+    assert ctypes.sizeof(fastore_amd.Stats) == 328
     cfg = fastore_amd.Config()
     product_lib.fsgpu_config_defaults(ctypes.byref(cfg))
     # reference defaults: fastore_pack/Params.h:18-147, fastore_bin/Globals.h:61-62
@@ -448,6 +448,28 @@ def test_matcher_table_and_trace_against_the_scalar_restatement(emu_lib, name, p
         with fastore_amd.Packer(lib=emu_lib, device_id=0, **kn) as p:
             reads, differing = p.matcher_check(os.path.join(GOLDEN, name + ".in"))
         assert reads > 1000 and differing == 0, (window, reads, differing)
+
+
+@pytest.mark.parametrize("name,paired,flags", manifest())
+def test_packed_bases_and_their_descriptors_against_the_unpacked_ones(emu_lib, tmp_path, monkeypatch, name, paired, flags):
+    # the bin's .bdna bytes + one descriptor per read (bit offset, two- or three-bit form, where the signature stands and which)
+    # that the window search gets instead of ASCII bases: the test-only stand-in reads them base by base, as fs_unpack_planes
+    # does, and holds every base against the host's unpacked one; the pack takes that way by default and changes no byte
+    import fastore_amd
+    with fastore_amd.Packer(lib=emu_lib, device_id=0, **knobs_from_flags(flags)) as p:
+        bases, differing, reads, rows = p.unpack_check(os.path.join(GOLDEN, name + ".in"))
+    assert bases > 100_000 and differing == 0 and reads > 1000 and rows == 0, (bases, differing, reads, rows)
+    ref = open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
+    seen = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FS_DEVICE_UNPACK", mode)
+        with fastore_amd.Packer(lib=emu_lib, device_id=0, **knobs_from_flags(flags)) as p:
+            st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o" + mode)))
+        assert open(str(tmp_path / ("o" + mode)) + ".cdata", "rb").read() == ref
+        seen[mode] = st
+    assert seen["0"]["matcher_unpacked_reads"] == 0 and seen["0"]["matcher_reads"] > 0
+    assert seen["1"]["matcher_unpacked_reads"] == seen["1"]["matcher_reads"] > 0
+    assert seen["1"]["matcher_bases_h2d_bytes"] < 0.45 * seen["0"]["matcher_bases_h2d_bytes"]
 
 
 @pytest.mark.parametrize("name,paired,flags", manifest()[:3])
