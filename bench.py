@@ -45,6 +45,12 @@ PACK_FLAGS = ["-r", "-f256", "-c10", "-d8", "-w1024", "-W1024"]
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy rate
 
 
+# quality / read-id mode of the library = what scripts/fastore_compress.sh:135-140 hands to fastore_bin (--lossless / --reduced / --lossy);
+# the pack stage's own flags do not change with it
+QUALITY_MODES = {"lossless": ["-H", "-q0"], "reduced": ["-H", "-C", "-q2"], "lossy": ["-H", "-C", "-q3"]}
+QUALITY = "lossless"
+
+
 def sh(cmd, **kw):
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, **kw)
 
@@ -58,7 +64,7 @@ def prepare_library(work, name, reads, length, genome, seed, threads, paired=Fal
     fq = [base + "_1.fastq"] + ([base + "_2.fastq"] if paired else [])
     if not (os.path.exists(binned + ".bmeta") and os.path.exists(base + ".done")):
         sh([GEN, "--reads", str(reads), "--len", str(length), "--genome", str(genome), "--seed", str(seed), "--out", base] + (["--paired"] if paired else []))
-        sh([REF_GCC, "bin", "-i" + " ".join(fq), "-o" + base + ".b0", "-t%d" % threads, "-H", "-q0", "-p8", "-s0", "-b256"] + pe)
+        sh([REF_GCC, "bin", "-i" + " ".join(fq), "-o" + base + ".b0", "-t%d" % threads] + QUALITY_MODES[QUALITY] + ["-p8", "-s0", "-b256"] + pe)
         prev = base + ".b0"
         for p in (2, 4, 8):
             cur = base + ".b%d" % p
@@ -209,8 +215,8 @@ def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome,
     rf["ppmd_symbols_per_s_whole_job"] = round(st["ppmd_symbols"] / dt, 1)
     res = {
         "value": round(fastq_bytes * steps / dt / 1e6, 2), "unit": "MB/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
-        "config": {"workload": "ONE library of %.1f M x %d bp %s synthetic FASTQ (gen_fastq genome %d bp, seed 8), --lossless, C1 profile%s"
-                               % (reads / 1e6, L, "PE pairs" if paired else "SE reads", genome, "" if not paired else " (configs[2] scaled by %g)" % (reads / 100e6)),
+        "config": {"workload": "ONE library of %.1f M x %d bp %s synthetic FASTQ (gen_fastq genome %d bp, seed 8), --%s, C1 profile%s"
+                               % (reads / 1e6, L, "PE pairs" if paired else "SE reads", genome, QUALITY, "" if not paired else " (configs[2] scaled by %g)" % (reads / 100e6)),
                    "fastq_bytes": fastq_bytes, "pack_flags": " ".join(PACK_FLAGS + (["-z"] if paired else [])), "parallelism": "1 GPU"},
         "roofline": rf,
         "host_coded_symbol_fraction": round(float(st.get("host_coded_symbols", 0)) / sym, 4),
@@ -294,7 +300,11 @@ def main():
     ap.add_argument("--rehearse", action="store_true", help="N ranks on ONE device over gloo (no RCCL): a dry run of the N > 1 code path on a one-GPU box")
     ap.add_argument("--strong", action="store_true", help="--gpus N: ONLY the strong line (the ONE library of the N = 1 run sharded over the ranks)")
     ap.add_argument("--replicas", "--weak", dest="replicas", action="store_true", help="--gpus N: every rank packs the whole library into its own archive")
+    ap.add_argument("--quality", choices=sorted(QUALITY_MODES), default="lossless",
+                    help="mode of the library as scripts/fastore_compress.sh names it: lossless (-q0, the BASELINE metric's), reduced (8-bin scores, -q2 -C: configs[3]'s), lossy (QVZ, -q3 -C)")
     args = ap.parse_args()
+    global QUALITY
+    QUALITY = args.quality
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
@@ -315,7 +325,7 @@ def main():
 
     L = 150
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
-    name = ("pe%dk" if args.paired else "se%dk") % (args.reads // 1000)
+    name = ("pe%dk" if args.paired else "se%dk") % (args.reads // 1000) + ("" if QUALITY == "lossless" else "_" + QUALITY)
     cov = 2 if args.paired else 1            # bases per record: the genome is sized for ~50x coverage either way
     genome = cov * args.reads * L // 50
 
@@ -341,7 +351,7 @@ def main():
             # configs[2] is 100 M pairs x 150 bp PE; what fits this run's window is a library of --pe-reads pairs from the same
             # generator (genome scaled for the same 50x coverage): its own value, reference baseline, parity and roofline
             pk, ps, pw = args.pe_reads, max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
-            pleg, _ = one_library_leg(fastore_amd, torch, args, args.work, "pe%dk" % (pk // 1000), pk, True, 2 * pk * L // 50, ps, pw, cores, lib, 0 if args.no_cli else 3)
+            pleg, _ = one_library_leg(fastore_amd, torch, args, args.work, "pe%dk" % (pk // 1000) + ("" if QUALITY == "lossless" else "_" + QUALITY), pk, True, 2 * pk * L // 50, ps, pw, cores, lib, 0 if args.no_cli else 3)
             res["pe"] = pleg
         print(json.dumps(res), flush=True)
         return
@@ -444,9 +454,9 @@ def main():
             "metric": "fastore_pack compressed MB/s (input FASTQ)", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s of %.1f M x %d bp %s synthetic FASTQ (gen_fastq genome %d bp, seed%s), --lossless, C1 profile%s"
+            "config": {"workload": "%s of %.1f M x %d bp %s synthetic FASTQ (gen_fastq genome %d bp, seed%s), --%s, C1 profile%s"
                                    % ("ONE library" if not lib_set else "a SET of %d libraries, each" % world, args.reads / 1e6, L, "PE pairs" if args.paired else "SE reads", genome,
-                                      " 8" if not lib_set else "s 8..%d" % (7 + world),
+                                      " 8" if not lib_set else "s 8..%d" % (7 + world), QUALITY,
                                       "" if not args.paired else " (configs[2] scaled by %g)" % (args.reads / 100e6)),
                        "fastq_bytes": fastq_bytes, "pack_flags": " ".join(PACK_FLAGS),
                        "parallelism": ("%d ranks, each the whole library (replicas)" % world if args.replicas else

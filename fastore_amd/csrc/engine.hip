@@ -80,7 +80,16 @@ __device__ __forceinline__ KernArgs kernargs()
 // the coder wave (ppmd_core.h: coder_wave).  Range-coded and QVZ items are coded by wave 0 alone, as in the one-wave form.
 // WAVES = 3: the three-wave form (192-thread workgroups): wave 2 is the window wave, which prepares the windows of the hit path
 // ahead of wave 0's serial walk (ppmd_scout.h).
-template <int WAVES> __device__ __forceinline__ void encode_streams_body()
+// The windowed range coders (rc_core.h) live in kernels of their own (RCWIN: fs_encode_streams_w / fs_encode_streams2_w), taken
+// by launches that hold a long range-coded stream (a --reduced or --max library's quality scores), and out of line there.
+// In the kernels every lossless launch takes they cost the PPMd walk: inlined, nine more vector registers and ten more
+// spilled scalars in the two-wave form (a lone 7 M-symbol stream 938 -> 968 ms, the step 5 %); out of line still 2-3 % of
+// the step, alternating builds on one box (profiles/r03_reduced_mode.txt).  Those kernels keep the one-symbol loop, which
+// is all their short range-coded streams (read ids, flags, letters) need.
+__device__ __noinline__ uint32_t rc_encode_out_of_line(uint32_t model, fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap)
+{ return fsrc::encode_model(model, table, pairs, n, out, cap); }
+
+template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_streams_body()
 {
     constexpr bool TWO = WAVES >= 2, THREE = WAVES == 3;
     __shared__ fsppmd::Shared sh;
@@ -158,7 +167,7 @@ template <int WAVES> __device__ __forceinline__ void encode_streams_body()
         } else if (kind == KIND_QVZ) {
             size = fsqvz::encode_stream(ar, (fs_cgptr)(k->in + item.aux_off), src, n, dst, cap);
         } else {
-            size = fsrc::encode_model(kind - KIND_RC_BASE, ar, src, n, dst, cap);
+            size = RCWIN ? rc_encode_out_of_line(kind - KIND_RC_BASE, ar, src, n, dst, cap) : fsrc::encode_model_serial(kind - KIND_RC_BASE, ar, src, n, dst, cap);
         }
         if (threadIdx.x < 16u) {
             KernArgs k2 = kernargs();
@@ -209,6 +218,9 @@ __global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(EncodeArg
 __global__ __launch_bounds__(128, 2) void fs_encode_streams2(EncodeArgs /* read through kernargs() */) { encode_streams_body<2>(); }
 // (the three-wave form: serial wave, coder wave, window wave -- for launches whose longest stream decides the step)
 __global__ __launch_bounds__(192, 2) void fs_encode_streams3(EncodeArgs /* read through kernargs() */) { encode_streams_body<3>(); }
+// the same two forms with the windowed range coders (launches with a long range-coded stream)
+__global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams_w(EncodeArgs /* read through kernargs() */) { encode_streams_body<1, true>(); }
+__global__ __launch_bounds__(128, 2) void fs_encode_streams2_w(EncodeArgs /* read through kernargs() */) { encode_streams_body<2, true>(); }
 
 // fs_gather_quality -- the quality stream of a lossless bin, built on the device (SURVEY 8 a8 + f1): the stored scores
 // (.bqua: six bits each, MSB first, fastore_bin/FastqPacker.cpp:157-287) are unpacked, turned back to front where the read
@@ -558,9 +570,19 @@ int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size
     // One arena slot per resident wavefront (kWavesPerSimd x 4 SIMDs per CU), in kXcc equal partitions; the pool takes
     // at most 55 % of the free HBM.
     const uint32_t waves = maxWaves ? maxWaves : (uint32_t)dev->cus * 4u * kWavesPerSimd;
-    const uint64_t stride = ((fsppmd::ARENA_BYTES + kGuard) + 4095ull) & ~4095ull;
+    // A slot holds a PPMd arena (16.8 MB) -- or, where the device has the room, the largest table of the range coders: the
+    // <8,6> model of 8-bin quality scores and the full <256,1> model are 32 MiB.  A launch with a table that does not fit a
+    // slot runs ALONE on the device (encode_streams_raw: exclusive), one slice after the other: a --reduced library's step
+    // was 7.1 s that way against 1.x s with its fourteen slices side by side (profiles/r03_reduced_mode.txt).  288 GB of
+    // HBM hold 3 072 slots of 32 MiB (103 GB) with room to spare; a device that does not keeps the small slots.
+    uint64_t stride = ((fsppmd::ARENA_BYTES + kGuard) + 4095ull) & ~4095ull;
     uint32_t perXcc = std::min<uint32_t>((waves + kXcc - 1) / kXcc, kBitmapWords * 64u);
     const uint64_t budget = (uint64_t)((double)freeB * 0.55);
+    {
+        const uint64_t big = ((std::max<uint64_t>(fsppmd::ARENA_BYTES, fsrc::model_table_bytes(fsrc::M_A8O6)) + kGuard) + 4095ull) & ~4095ull;
+        const char* bs = getenv("FS_BIG_SLOTS");
+        if ((bs ? atoi(bs) != 0 : true) && (uint64_t)perXcc * kXcc * big <= budget) stride = big;
+    }
     while (perXcc > 1 && (uint64_t)perXcc * kXcc * stride > budget) --perXcc;
     pool->slotStride = stride; pool->slotsPerXcc = perXcc; pool->bytes = (uint64_t)perXcc * kXcc * stride;
     if (pool->bytes > budget) { snprintf(err, errLen, "not enough device memory for the coder arenas"); delete pool; delete dev; return -1; }
@@ -837,8 +859,14 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         uint32_t waves = maxLen >= (256u << 10) ? 2u : 1u;
         if (const char* tw = getenv("FS_TWO_WAVE")) waves = atoi(tw) != 0 ? 2u : 1u;
         if (const char* tw = getenv("FS_WAVES")) waves = (uint32_t)std::max(1, std::min(3, atoi(tw)));
+        // a long range-coded stream (small alphabet: the models with a windowed form) in the launch: the kernels that have it
+        uint32_t maxRc = 0;
+        for (const auto& it : items) if (it.kind >= KIND_RC_BASE && it.kind != KIND_QVZ && it.kind != KIND_PPMD && it.kind - KIND_RC_BASE <= fsrc::M_A8O6) maxRc = std::max(maxRc, it.in_len);
+        bool rcWin = maxRc >= 4096u;
+        if (const char* rw = getenv("FS_RC_WINDOWS")) rcWin = atoi(rw) != 0;
         if (waves == 3u) { const uint32_t g3 = std::max(1u, std::min(grid, dev->nWaves / 3u)); hipLaunchKernelGGL(fs_encode_streams3, dim3(g3), dim3(192), 0, st, ka); }
-        else if (waves == 2u) { const uint32_t g2 = std::max(1u, std::min(grid, dev->nWaves / 2u)); hipLaunchKernelGGL(fs_encode_streams2, dim3(g2), dim3(128), 0, st, ka); }
+        else if (waves == 2u) { const uint32_t g2 = std::max(1u, std::min(grid, dev->nWaves / 2u)); if (rcWin) hipLaunchKernelGGL(fs_encode_streams2_w, dim3(g2), dim3(128), 0, st, ka); else hipLaunchKernelGGL(fs_encode_streams2, dim3(g2), dim3(128), 0, st, ka); }
+        else if (rcWin) hipLaunchKernelGGL(fs_encode_streams_w, dim3(grid), dim3(64), 0, st, ka);
         else hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, ka);
         HIP_TRY(hipGetLastError());
     }

@@ -99,3 +99,19 @@ extern "C" size_t simt_ppmd_encode(const uint8_t* in, size_t n, uint8_t* out, si
     delete sh; free(arena);
     return result;
 }
+
+// the windowed form of the small-alphabet range coders (rc_core.h: encode_stream_windowed) on one emulated wave;
+// pairs = interleaved (symbol, ctx0) bytes
+#include "../../fastore_amd/csrc/rc_core.h"
+extern "C" size_t simt_rc_encode(unsigned model, const uint8_t* pairs, size_t n, uint8_t* out, size_t cap)
+{
+    const uint64_t tb = fsrc::model_table_bytes(model);
+    uint8_t* table = (uint8_t*)aligned_alloc(64, (tb + 63) & ~63ull);
+    uint32_t size = 0;
+    simt::run_waves(1, [&](int, int) {
+        const uint32_t s = fsrc::encode_model(model, table, pairs, (uint32_t)n, out, (uint32_t)cap);
+        if (simt::lane() == 0) size = s;
+    });
+    free(table);
+    return size == 0xFFFFFFFFu ? (size_t)-1 : size;
+}

@@ -102,7 +102,12 @@ def test_ppmd_device_model_restart_and_allocator_exhaustion(packer, oracle):
     assert got[1] == oracle_ppmd(oracle, b)
 
 
-def test_rc_device_matches_oracle_all_models_with_rescale(packer, oracle):
+@pytest.mark.parametrize("windows", ["1", "0", None])
+def test_rc_device_matches_oracle_all_models_with_rescale(packer, oracle, monkeypatch, windows):
+    # windows: the kernels with the windowed form of the small-alphabet coders (64 symbols per step: rc_core.h) forced on,
+    # forced off (the one-symbol loop), and the product's choice (windowed when the launch holds a stream of 4 096 symbols or more)
+    if windows is not None:
+        monkeypatch.setenv("FS_RC_WINDOWS", windows)
     rng = np.random.default_rng(33)
     models, ins = [], []
     for name, (mid, bits, order, adv) in MODELS.items():
@@ -112,6 +117,13 @@ def test_rc_device_matches_oracle_all_models_with_rescale(packer, oracle):
             ctx = rng.integers(0, min(A, 8), n, dtype=np.uint8)
             pairs = np.stack([sym, ctx], 1).tobytes()
             models.append(mid); ins.append((name, pairs))
+    # quality-like streams: runs of one symbol in position-dependent contexts -- most of a window on one row, rescales in the middle of windows
+    for name in ("a8o6", "a2o10", "s2o4"):
+        mid, bits, order, adv = MODELS[name]
+        A = 1 << bits; n = 300_000
+        sym = np.clip(np.cumsum(rng.integers(-1, 2, n)) // 60 % A, 0, A - 1).astype(np.uint8)
+        ctx = ((np.arange(n) % 150) * A // 150).astype(np.uint8) if adv else np.zeros(n, np.uint8)
+        models.append(mid); ins.append((name, np.stack([sym, ctx], 1).tobytes()))
     got = packer.rc_encode(models, [p for _, p in ins])
     for (name, pairs), g in zip(ins, got):
         assert g == oracle_rc(oracle, name, pairs), name

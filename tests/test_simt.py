@@ -159,3 +159,40 @@ def test_three_wave_form_under_shifted_wave_timings(simt, oracle, seed, steps):
     for i, (s, g) in enumerate(zip(streams, got)):
         assert g == oracle_ppmd(oracle, s), (i, st)
     assert st["ahead_used"] > 100, st
+
+
+def rc_encode(lib, model, pairs):
+    lib.simt_rc_encode.restype = ctypes.c_size_t
+    lib.simt_rc_encode.argtypes = [ctypes.c_uint, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    buf = ctypes.create_string_buffer(len(pairs) + 4096)
+    n = lib.simt_rc_encode(model, pairs + b"\0" * 256, len(pairs) // 2, buf, len(buf))
+    return None if n == ctypes.c_size_t(-1).value else buf.raw[:n]
+
+
+@pytest.mark.parametrize("model", ["s2o4", "s8o4", "a8o4", "a2o10", "a8o6"])
+def test_windowed_range_coder_reproduces_the_one_symbol_loop(simt, oracle, model):
+    # encode_stream_windowed (64 symbols per step: rows fetched side by side, shared rows by rank, write-back by the last
+    # position, the range coder in stream order) against the oracle's restatement of the reference's coder stack
+    from conftest import MODELS, oracle_rc
+    mid, bits, order, adv = MODELS[model]
+    rng = np.random.default_rng(5 + mid)
+    A = 1 << bits
+    cases = []
+    for n in (0, 1, 2, 63, 64, 65, 127, 1000, 40_000):
+        sym = rng.integers(0, A, n).astype(np.uint8)
+        ctx = rng.integers(0, A if adv else 1, n).astype(np.uint8)
+        cases.append((sym, ctx))
+    # quality-like: long runs of one symbol in few contexts -- the same row again and again inside a window, and often enough
+    # to reach the rescale limit (65 536 - 8 A: a row of a two-symbol alphabet is due after 8 190 hits)
+    n = 60_000
+    walk = np.clip(np.cumsum(rng.integers(-1, 2, n)) // 40 % A, 0, A - 1).astype(np.uint8)
+    pos = ((np.arange(n) % 150) * A // 150).astype(np.uint8) if adv else np.zeros(n, np.uint8)
+    cases.append((walk, pos))
+    cases.append((np.zeros(30_000, np.uint8), np.zeros(30_000, np.uint8)))              # one row only: a rescale every few thousand symbols
+    cases.append((np.full(20_000, A - 1, np.uint8), np.full(20_000, (A - 1) if adv else 0, np.uint8)))
+    for sym, ctx in cases:
+        pairs = np.stack([sym, ctx], axis=1).astype(np.uint8).tobytes()
+        assert rc_encode(simt, mid, pairs) == oracle_rc(oracle, model, pairs), (model, len(sym))
+    # a symbol outside the alphabet, a context outside its field: the stream is given up as in the one-symbol loop
+    bad = bytearray(np.stack([np.zeros(200, np.uint8), np.zeros(200, np.uint8)], axis=1).tobytes()); bad[2 * 130] = A
+    assert rc_encode(simt, mid, bytes(bad)) is None
