@@ -296,7 +296,8 @@ def main():
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end run of the fastore_pack CLI (process start -> exit)")
     ap.add_argument("--paired", action="store_true", help="the headline leg packs ONE paired-end library of --reads pairs (configs[2] scaled)")
     ap.add_argument("--pe-reads", type=int, default=6_000_000, help="pairs of the paired-end leg of the N = 1 line (configs[2] scaled to what the run's window holds)")
-    ap.add_argument("--no-pe", action="store_true", help="N = 1: skip the paired-end leg")
+    ap.add_argument("--no-pe", action="store_true", help="N = 1: the headline leg only (skips the paired-end leg and the --reduced leg)")
+    ap.add_argument("--no-reduced", action="store_true", help="N = 1: skip the --reduced leg (the same reads with 8-bin quality scores)")
     ap.add_argument("--rehearse", action="store_true", help="N ranks on ONE device over gloo (no RCCL): a dry run of the N > 1 code path on a one-GPU box")
     ap.add_argument("--strong", action="store_true", help="--gpus N: ONLY the strong line (the ONE library of the N = 1 run sharded over the ranks)")
     ap.add_argument("--replicas", "--weak", dest="replicas", action="store_true", help="--gpus N: every rank packs the whole library into its own archive")
@@ -353,6 +354,16 @@ def main():
             pk, ps, pw = args.pe_reads, max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
             pleg, _ = one_library_leg(fastore_amd, torch, args, args.work, "pe%dk" % (pk // 1000) + ("" if QUALITY == "lossless" else "_" + QUALITY), pk, True, 2 * pk * L // 50, ps, pw, cores, lib, 0 if args.no_cli else 3)
             res["pe"] = pleg
+        if not args.paired and not args.no_pe and not args.no_reduced and QUALITY == "lossless":      # (--no-pe: the headline leg only)
+            # configs[3]'s mode (--reduced: 8-bin quality scores, range-coded with the <8,6> model instead of PPMd) on the same
+            # reads: its own value, reference baseline and parity (the windowed range coders, rc_core.h)
+            global_q = QUALITY
+            globals()["QUALITY"] = "reduced"
+            try:
+                rleg, _ = one_library_leg(fastore_amd, torch, args, args.work, name + "_reduced", args.reads, False, genome, max(1, min(args.steps, 3)), 1, cores, lib, 0)
+            finally:
+                globals()["QUALITY"] = global_q
+            res["reduced"] = rleg
         print(json.dumps(res), flush=True)
         return
 

@@ -112,17 +112,30 @@ FS_DEV uint32_t encode_stream(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32
     const uint32_t msbShift = M_BITS - 1, smsbShift = M_BITS - 2, clearMask = (1u << msbShift) - 1u;
     const FS_GLOBAL uint32_t* sym = (const FS_GLOBAL uint32_t*)in;
 
+    // The symbol word and its context's descriptor do not depend on the coder: those of symbol i + 1 are requested while
+    // symbol i is coded (two of the three dependent memory trips of a symbol, out of its chain).
+    uint32_t wNext = n ? sym[0] : 0u, offNext = 0, cardNext = 0;
+    if (n && (wNext & 0xFFFFFFu) < nCtx) { offNext = desc[wNext & 0xFFFFFFu].off; cardNext = desc[wNext & 0xFFFFFFu].card; }
     for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t w = FS_UNI(sym[i]);
+        const uint32_t w = FS_UNI(wNext);
         const uint32_t ctx = w & 0xFFFFFFu, x = w >> 24;
         if (ctx >= nCtx) { bad = 1; break; }
-        const uint32_t off = FS_UNI(desc[ctx].off), card = FS_UNI(desc[ctx].card);
+        const uint32_t off = FS_UNI(offNext), card = FS_UNI(cardNext);
+        if (i + 1u < n) {
+            wNext = sym[i + 1u];
+            const uint32_t cN = wNext & 0xFFFFFFu;
+            if (cN < nCtx) { offNext = desc[cN].off; cardNext = desc[cN].card; }
+        }
         if (x >= card || card > MAX_CARD) { bad = 1; break; }
         uint32_t cumLo, cnt, total;
         model_step(stat + off, card, x, cumLo, cnt, total);
+        // (range <= 2^22, counts <= total < 2^20: the products are below 2^42 and the quotients below 2^22; a double holds both
+        // operands exactly and its quotient is off by less than 2^-31, while a quotient that is not a whole number is at least
+        // 1 / total > 2^-20 away from the next one: truncation gives the integer quotient of arith.cpp:44-45, without the
+        // hundred-instruction 64-bit division)
         const uint64_t range = (uint64_t)u - l + 1u;
-        u = l + (uint32_t)((range * (cumLo + cnt)) / total) - 1u;
-        l = l + (uint32_t)((range * cumLo) / total);
+        u = l + (uint32_t)((double)(range * (cumLo + cnt)) / (double)total) - 1u;
+        l = l + (uint32_t)((double)(range * cumLo) / (double)total);
         for (;;) {
             const uint32_t msbL = l >> msbShift, msbU = u >> msbShift;
             if (msbL == msbU) {
