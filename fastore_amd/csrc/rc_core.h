@@ -182,7 +182,7 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
     uint64_t hash = 0;                                   // the symbols in front of position k, the latest in the lowest bits
     fs_cgptr16 pairs16 = (fs_cgptr16)pairs;
     for (uint32_t k = 0; k < n;) {
-        const uint32_t left = n - k, W = left < 64u ? left : 64u;
+        const uint32_t left = FS_UNI(n - k), W = left < 64u ? left : 64u;
         const bool valid = lane < W;
         const uint32_t pr = valid ? (uint32_t)pairs16[k + lane] : 0u;
         FS_EMU_MEET();
@@ -230,7 +230,7 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
         const uint32_t acc = tot + 8u * fs_popc64(earlier), f = mine + 8u * fs_popc64(earlier & eqS), lo = below + 8u * fs_popc64(earlier & ltS);
         // the window ends in front of the first position whose row is due for a rescale
         const uint64_t due = fs_ballot(valid && acc >= limit);
-        const uint32_t cnt = due ? fs_ctz64(due) : W;
+        const uint32_t cnt = FS_UNI(due ? fs_ctz64(due) : W);
         if (cnt != 0u) {
             const uint64_t inWin = cnt >= 64u ? ~0ull : (1ull << cnt) - 1ull;
             const uint64_t g = grp & inWin;
@@ -252,7 +252,11 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
             // the range coder over the triples, in stream order; range / total by a reciprocal per position (total in [2, 65535])
             uint32_t rmul = 0, rl = 1;
             if (lane < cnt) { const fsppmd::Recip rc = fsppmd::recip_make(acc); rmul = rc.mul; rl = rc.l; }
-            uint64_t low = e.low; uint32_t range = e.range;
+            // (the coder's state is wave-uniform by construction; said so, the pass is scalar code with scalar branches -- left to the
+            // compiler's divergence analysis it was vector code under exec masks, two saved masks per symbol and two per byte)
+            uint64_t low = ((uint64_t)FS_UNI((uint32_t)(e.low >> 32)) << 32) | FS_UNI((uint32_t)e.low);
+            uint32_t range = FS_UNI(e.range), pos = FS_UNI(e.pos);
+            const uint32_t capU = FS_UNI(e.cap);
             for (uint32_t i = 0; i < cnt; ++i) {
                 const uint32_t F = fs_readlane(f, i), LO = fs_readlane(lo, i), M = fs_readlane(rmul, i), L = fs_readlane(rl, i);
                 range = fsppmd::recip_div(range, M, L);
@@ -260,11 +264,12 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
                 range *= F;
                 while (range <= 0x00ffffffu) {
                     if ((low ^ (low + range)) & 0xff00000000000000ULL) { const uint32_t x = (uint32_t)low; range = (x | 0x00ffffffu) - x; }
-                    put(e, (uint32_t)(low >> 56));
+                    if (pos < capU) fs_st8(e.out + pos, (uint32_t)(low >> 56));
+                    pos++;
                     low <<= 8; range <<= 8;
                 }
             }
-            e.low = low; e.range = range;
+            e.low = low; e.range = range; e.pos = pos;
             // the symbols in front of position k + cnt
             uint64_t nh = 0;
             #pragma unroll
