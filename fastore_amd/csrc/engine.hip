@@ -515,6 +515,34 @@ struct Pool {
 
 static bool g_pageableStaging = false;
 
+// A launch whose largest coder table does not fit an arena slot -- the <8,6> model of 8-bin quality scores and the full <256,1>
+// model are 32 MiB, a slot 16.8 MB -- runs ALONE on the device (encode_streams_raw: exclusive), one slice after the other: a
+// --reduced library's step was 7.1 s that way against 1.15 s with its fourteen slices side by side (profiles/r03_reduced_mode.txt).
+// So the first such launch makes the pool's slots big enough, once, with nothing in flight (the gate taken alone): same number of
+// slots, 3 072 x 32 MiB = 103 GB of the 288.  Only then: lossless packs -- and the helper pipelines of libraries of several
+// batches, each with a pool of its own -- keep the 53 GB pool.  No room for it (or FS_BIG_SLOTS=0): the exclusive launches stay.
+static void pool_grow(Device* dev, Pool* pool, uint64_t need)
+{
+    const char* bs = getenv("FS_BIG_SLOTS");
+    if (bs && atoi(bs) == 0) return;
+    const uint64_t big = ((need + kGuard) + 4095ull) & ~4095ull;
+    std::unique_lock<std::shared_mutex> alone(pool->gate);                    // every launch in flight has drained
+    if (big <= pool->slotStride) return;                                    // another lane was first
+    const uint64_t want = (uint64_t)pool->slotsPerXcc * kXcc * big;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || (uint64_t)freeB + pool->bytes < want + (24ull << 30)) return;      // (24 GB stay for the batches' buffers)
+    uint8_t* old = pool->arenas;
+    if (hipFree(old) != hipSuccess) return;
+    uint8_t* fresh = nullptr;
+    if (hipMalloc((void**)&fresh, want) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc((void**)&fresh, pool->bytes) != hipSuccess) { pool->arenas = nullptr; snprintf(dev->err, sizeof dev->err, "arena pool lost while growing it"); return; }
+        pool->arenas = fresh; return;
+    }
+    pool->arenas = fresh; pool->bytes = want; pool->slotStride = big;
+    if (getenv("FS_TRACE")) fprintf(stderr, "[trace] arena pool grown to %u slots of %.1f MB (%.1f GB) for a %.1f MB coder table\n", pool->slotsPerXcc * kXcc, big / 1e6, want / 1e6 / 1e3, need / 1e6);
+}
+
 static int lane_init(Device* dev, char* err, size_t errLen)
 {
     hipError_t e;
@@ -570,19 +598,10 @@ int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size
     // One arena slot per resident wavefront (kWavesPerSimd x 4 SIMDs per CU), in kXcc equal partitions; the pool takes
     // at most 55 % of the free HBM.
     const uint32_t waves = maxWaves ? maxWaves : (uint32_t)dev->cus * 4u * kWavesPerSimd;
-    // A slot holds a PPMd arena (16.8 MB) -- or, where the device has the room, the largest table of the range coders: the
-    // <8,6> model of 8-bin quality scores and the full <256,1> model are 32 MiB.  A launch with a table that does not fit a
-    // slot runs ALONE on the device (encode_streams_raw: exclusive), one slice after the other: a --reduced library's step
-    // was 7.1 s that way against 1.x s with its fourteen slices side by side (profiles/r03_reduced_mode.txt).  288 GB of
-    // HBM hold 3 072 slots of 32 MiB (103 GB) with room to spare; a device that does not keeps the small slots.
-    uint64_t stride = ((fsppmd::ARENA_BYTES + kGuard) + 4095ull) & ~4095ull;
+    // (a slot holds a PPMd arena, 16.8 MB; the pool grows to slots of a coder table's size when a launch first needs one: pool_grow)
+    const uint64_t stride = ((fsppmd::ARENA_BYTES + kGuard) + 4095ull) & ~4095ull;
     uint32_t perXcc = std::min<uint32_t>((waves + kXcc - 1) / kXcc, kBitmapWords * 64u);
     const uint64_t budget = (uint64_t)((double)freeB * 0.55);
-    {
-        const uint64_t big = ((std::max<uint64_t>(fsppmd::ARENA_BYTES, fsrc::model_table_bytes(fsrc::M_A8O6)) + kGuard) + 4095ull) & ~4095ull;
-        const char* bs = getenv("FS_BIG_SLOTS");
-        if ((bs ? atoi(bs) != 0 : true) && (uint64_t)perXcc * kXcc * big <= budget) stride = big;
-    }
     while (perXcc > 1 && (uint64_t)perXcc * kXcc * stride > budget) --perXcc;
     pool->slotStride = stride; pool->slotsPerXcc = perXcc; pool->bytes = (uint64_t)perXcc * kXcc * stride;
     if (pool->bytes > budget) { snprintf(err, errLen, "not enough device memory for the coder arenas"); delete pool; delete dev; return -1; }
@@ -785,7 +804,15 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         else if (it.kind != KIND_PPMD) need = std::max<uint64_t>(need, fsrc::model_table_bytes(it.kind - KIND_RC_BASE));
     }
     Pool* pool = dev->pool;
-    const bool exclusive = ((need + kGuard + 4095ull) & ~4095ull) > pool->slotStride;      // table larger than an arena slot
+    // The gate is held from here until this launch has drained: the slot size is read under it (every launch in flight at
+    // the same time must place its slots by the same stride; pool_grow changes it only with the gate taken alone), and
+    // exclusive launches never overlap ring launches.
+    std::shared_lock<std::shared_mutex> shared(pool->gate);
+    if (((need + kGuard + 4095ull) & ~4095ull) > pool->slotStride) { shared.unlock(); pool_grow(dev, pool, need); shared.lock(); }
+    if (!pool->arenas) return -1;
+    const bool exclusive = ((need + kGuard + 4095ull) & ~4095ull) > pool->slotStride;      // table larger than an arena slot (and the pool could not grow)
+    std::unique_lock<std::shared_mutex> alone(pool->gate, std::defer_lock);
+    if (exclusive) { shared.unlock(); alone.lock(); }
     const uint64_t stride = exclusive ? ((need + kGuard) + 4095ull) & ~4095ull : pool->slotStride;
     uint32_t maxLen = 0;
     for (const auto& it : items) if (it.kind == KIND_PPMD) maxLen = std::max(maxLen, it.in_len);
@@ -827,10 +854,6 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     const uint32_t grid = exclusive ? (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nItems, dev->nWaves), pool->bytes / stride)
                                     : std::min<uint32_t>(std::max(nRest, 1u), dev->nWaves);
     if (grid == 0) { snprintf(dev->err, sizeof dev->err, "arena pool too small for a %llu-byte coder table", (unsigned long long)need); return -1; }
-    // the gate is held until this launch has drained: exclusive launches never overlap ring launches
-    std::shared_lock<std::shared_mutex> shared(pool->gate, std::defer_lock);
-    std::unique_lock<std::shared_mutex> alone(pool->gate, std::defer_lock);
-    if (exclusive) alone.lock(); else shared.lock();
     if (ids && ids->n_jobs) {
         // every job's strings, table and output inside the buffers, checked here: the kernel trusts its descriptors
         const IdJob* jb = (const IdJob*)(input + ids->jobs_off); const IdString* ss = (const IdString*)(input + ids->strings_off);

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import check_compress_bins_seam, GOLDEN, MODELS, REF_DRIVER, REF_DRIVER_GCC, ROOT, VECTORS, flag_variants, knobs_from_flags, manifest, ref_pipeline, oracle_ppmd, oracle_qvz, oracle_rc
+from conftest import check_compress_bins_seam, GOLDEN, MODELS, REF_DRIVER, REF_DRIVER_GCC, ROOT, VECTORS, flag_variants, knobs_from_flags, manifest, ref_pipeline, reference_pack_mt, oracle_ppmd, oracle_qvz, oracle_rc
 
 import sys
 sys.path.insert(0, GOLDEN)
@@ -277,7 +277,7 @@ def test_gpu_pack_equals_live_reference_on_a_library_with_long_streams(tmp_path,
         if f.endswith(".fastq") or ".b0." in f or ".b2." in f or ".b4." in f:
             os.remove(os.path.join(t, f))
     flags = ["-r", "-f256", "-c10", "-d8", "-w1024", "-W1024"]
-    subprocess.check_call([REF_DRIVER, "pack", "-i" + binned, "-o" + os.path.join(t, "ref"), "-t%d" % min(16, cores)] + flags + pe)
+    reference_pack_mt(binned, os.path.join(t, "ref"), flags, pe, min(16, cores))
     with fastore_amd.Packer(device_id=0) as p:
         st = p.pack_file(binned, os.path.join(t, "gpu"))
     want = reference_blocks(os.path.join(t, "ref")); got = reference_blocks(os.path.join(t, "gpu"))
@@ -331,7 +331,7 @@ def test_gpu_pack_many_batches_and_model_restarts_inside_standard_bins(tmp_path)
         if f.endswith(".fastq") or ".b0." in f or ".b2." in f or ".b4." in f:
             os.remove(os.path.join(t, f))
     flags = ["-r", "-f256", "-c10", "-d8", "-w1024", "-W1024"]
-    subprocess.check_call([REF_DRIVER, "pack", "-i" + binned, "-o" + os.path.join(t, "ref"), "-t%d" % min(16, cores)] + flags + pe)
+    reference_pack_mt(binned, os.path.join(t, "ref"), flags, pe, min(16, cores))
     with fastore_amd.Packer(device_id=0, batch_bases=250_000_000) as p:
         st = p.pack_file(binned, os.path.join(t, "gpu"))
     want = reference_blocks(os.path.join(t, "ref")); got = reference_blocks(os.path.join(t, "gpu"))
@@ -473,7 +473,7 @@ def test_device_mate_search_on_a_fresh_library_and_same_archive_either_way(tmp_p
     t = str(tmp_path)
     binned, pe = ref_pipeline(t, "mates", 150_000, 150, 2 * 150_000 * 150 // 50, 21, True, 0, threads=8)
     flags = ["-r", "-f256", "-c10", "-d8", "-w1024", "-W1024"]
-    subprocess.check_call([REF_DRIVER, "pack", "-i" + binned, "-o" + os.path.join(t, "ref"), "-t8"] + flags + pe)
+    reference_pack_mt(binned, os.path.join(t, "ref"), flags, pe, 8)
     want = reference_blocks(os.path.join(t, "ref"))
     with fastore_amd.Packer(device_id=0) as p:
         pairs, differing = p.pe_matcher_check(binned)
