@@ -60,9 +60,9 @@ FS_DEV void model_step(FS_GLOBAL uint32_t* blk, uint32_t card, uint32_t x, uint3
         v2 = 64u + lane <= card ? blk[64u + lane] : 0u;
         part += (64u + lane <= x) ? v2 : 0u;
     }
-    #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) part += (uint32_t)__shfl_xor((int)part, s, 64);
-    cumLo = FS_UNI(part);
+    // (the sum over the lanes by DPP row shifts and broadcasts -- six adds; as six __shfl_xor steps it was six trips through the
+    // LDS crossbar, one behind the other, in every symbol's chain)
+    cumLo = fs_wave_sum8(part, true);
     total = fs_readlane(v, 0);
     const uint32_t w = x + 1u;                           // word of the coded symbol
     cnt = w < 64u ? fs_readlane(v, w) : fs_readlane(v2, w - 64u);
@@ -73,9 +73,7 @@ FS_DEV void model_step(FS_GLOBAL uint32_t* blk, uint32_t card, uint32_t x, uint3
         if (lane >= 1u && lane <= card && c) c = (c >> 1) + 1u;
         if (64u + lane <= card && c2) c2 = (c2 >> 1) + 1u;
         uint32_t s = ((lane >= 1u && lane <= card) ? c : 0u) + ((64u + lane <= card) ? c2 : 0u);
-        #pragma unroll
-        for (int k = 32; k >= 1; k >>= 1) s += (uint32_t)__shfl_xor((int)s, k, 64);
-        nt = FS_UNI(s);
+        nt = fs_wave_sum8(s, true);
         if (lane >= 1u && lane <= card) blk[lane] = c;
         if (64u + lane <= card) blk[64u + lane] = c2;
         if (lane == 0u) blk[0] = nt;
