@@ -81,7 +81,7 @@ __device__ __forceinline__ KernArgs kernargs()
 // WAVES = 3: the three-wave form (192-thread workgroups): wave 2 is the window wave, which prepares the windows of the hit path
 // ahead of wave 0's serial walk (ppmd_scout.h).
 // The windowed range coders (rc_core.h) live in kernels of their own (RCWIN: fs_encode_streams_w / fs_encode_streams2_w), taken
-// by launches that hold a long range-coded stream (a --reduced or --max library's quality scores), and out of line there.
+// by launches whose range-coded symbols weigh beside their PPMd symbols (a --reduced or --max library's quality scores), and out of line there.
 // In the kernels every lossless launch takes they cost the PPMd walk: inlined, nine more vector registers and ten more
 // spilled scalars in the two-wave form (a lone 7 M-symbol stream 938 -> 968 ms, the step 5 %); out of line still 2-3 % of
 // the step, alternating builds on one box (profiles/r03_reduced_mode.txt).  Those kernels keep the one-symbol loop, which
@@ -882,10 +882,16 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         uint32_t waves = maxLen >= (256u << 10) ? 2u : 1u;
         if (const char* tw = getenv("FS_TWO_WAVE")) waves = atoi(tw) != 0 ? 2u : 1u;
         if (const char* tw = getenv("FS_WAVES")) waves = (uint32_t)std::max(1, std::min(3, atoi(tw)));
-        // a long range-coded stream (small alphabet: the models with a windowed form) in the launch: the kernels that have it
-        uint32_t maxRc = 0;
-        for (const auto& it : items) if (it.kind >= KIND_RC_BASE && it.kind != KIND_QVZ && it.kind != KIND_PPMD && it.kind - KIND_RC_BASE <= fsrc::M_A8O6) maxRc = std::max(maxRc, it.in_len);
-        bool rcWin = maxRc >= 4096u;
+        // Launches whose range-coded symbols (small alphabets: the models with a windowed form) weigh beside their PPMd symbols
+        // -- the quality scores of a --reduced or --max library -- take the kernels with the windowed coders.  A lossless
+        // launch (flags and letters: a few per cent of its PPMd symbols) keeps the kernels it had: with a plain length
+        // threshold every launch of the BASELINE library qualified, and its step was 1-2 % longer for it.
+        uint64_t sumRc = 0, sumPpmd = 0;
+        for (const auto& it : items) {
+            if (it.kind == KIND_PPMD) sumPpmd += it.in_len;
+            else if (it.kind != KIND_QVZ && it.kind - KIND_RC_BASE <= fsrc::M_A8O6) sumRc += it.in_len;
+        }
+        bool rcWin = sumRc >= 4096u && 4u * sumRc >= sumPpmd;
         if (const char* rw = getenv("FS_RC_WINDOWS")) rcWin = atoi(rw) != 0;
         if (waves == 3u) { const uint32_t g3 = std::max(1u, std::min(grid, dev->nWaves / 3u)); hipLaunchKernelGGL(fs_encode_streams3, dim3(g3), dim3(192), 0, st, ka); }
         else if (waves == 2u) { const uint32_t g2 = std::max(1u, std::min(grid, dev->nWaves / 2u)); if (rcWin) hipLaunchKernelGGL(fs_encode_streams2_w, dim3(g2), dim3(128), 0, st, ka); else hipLaunchKernelGGL(fs_encode_streams2, dim3(g2), dim3(128), 0, st, ka); }

@@ -1195,7 +1195,12 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
     });
     // the tail's chunks of all libraries: [library l's chunks at l * nChunks ...); claimed in this order by every rank
     StealCounter steal;
-    const bool wantSteal = world > 1 && splitRole == 0 && !(getenv("FS_STEAL") && atoi(getenv("FS_STEAL")) == 0) && (getenv("FS_STEAL_KEY") || getenv("MASTER_PORT"));
+    // (FS_STEAL=1 switches the tail ON.  It is off by default since the end of round 3: every chunk a rank claims after its
+    // first batch is a device batch of its own -- slices, launches, a drain: 150 ms and more for a few hundred light bins -- and
+    // with one chunk claimed per pass a rank ran four of them behind its share: two ranks on one device, 2 M-read libraries,
+    // 1 677 ms per step without the tail and 2 335 with it (profiles/r03_rehearse_2ranks*.json).  The shares dealt by
+    // shardOwners (longest stream first) are within a few per cent of each other; a tail costs more than it can level.)
+    const bool wantSteal = world > 1 && splitRole == 0 && (getenv("FS_STEAL") && atoi(getenv("FS_STEAL")) != 0) && (getenv("FS_STEAL_KEY") || getenv("MASTER_PORT"));
     if (wantSteal) {
         if (!steal.open(inPrefixes, stealSeq)) throw std::runtime_error("Cannot open the node's work counter in /dev/shm");
         stealNames.push_back(steal.name);
@@ -1305,19 +1310,23 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
     };
     Batch& batch = workBatch; std::vector<uint32_t> binArch; size_t next = 0, done = 0;
     // the tail: one more chunk whenever what is left of this rank's work fits one batch (ranks that are behind do not ask)
-    bool tailOpen = steal.p != nullptr; uint64_t stolenBins = 0;
+    // (the first claim, in front of the rank's first batch, takes all but one of the chunks a rank would get if all claimed
+    // alike -- they ride in that batch; every later claim is one chunk, a batch of its own: only a rank that is ahead pays it)
+    bool tailOpen = steal.p != nullptr; uint64_t stolenBins = 0; bool firstClaim = true;
     auto claimChunk = [&]() {
         if (!tailOpen) return;
         uint64_t left = 0;
         for (size_t k = next; k < work.size() && left <= budget; ++k) left += libs[work[k].lib]->bf.bins().at(work[k].sig).totalRawDnaSize;
         if (left > budget) return;
-        for (;;) {                                                  // (empty chunks -- tiny libraries -- are stepped over)
+        uint32_t want = firstClaim ? (uint32_t)std::max<size_t>(1, tail.size() / std::max(1u, world) - 1u) : 1u;      // (tail.size() / world = a rank's share of the chunks)
+        firstClaim = false;
+        while (want) {                                              // (empty chunks -- tiny libraries -- are stepped over)
             const uint32_t c = steal.claim();
             if (c >= tail.size()) { tailOpen = false; return; }
             if (tail[c].empty()) continue;
             for (const Work& w : tail[c]) work.push_back(w);
             stolenBins += tail[c].size(); stats.stolen_bins += tail[c].size();
-            return;
+            --want;
         }
     };
     try {

@@ -105,7 +105,7 @@ def test_ppmd_device_model_restart_and_allocator_exhaustion(packer, oracle):
 @pytest.mark.parametrize("windows", ["1", "0", None])
 def test_rc_device_matches_oracle_all_models_with_rescale(packer, oracle, monkeypatch, windows):
     # windows: the kernels with the windowed form of the small-alphabet coders (64 symbols per step: rc_core.h) forced on,
-    # forced off (the one-symbol loop), and the product's choice (windowed when the launch holds a stream of 4 096 symbols or more)
+    # forced off (the one-symbol loop), and the product's choice (windowed when the launch's range-coded symbols weigh beside its PPMd symbols: here they are all it holds)
     if windows is not None:
         monkeypatch.setenv("FS_RC_WINDOWS", windows)
     rng = np.random.default_rng(33)
