@@ -89,6 +89,16 @@ __device__ __forceinline__ KernArgs kernargs()
 __device__ __noinline__ uint32_t rc_encode_out_of_line(uint32_t model, fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap)
 { return fsrc::encode_model(model, table, pairs, n, out, cap); }
 
+// (the QVZ coder out of line in every kernel: its double-precision quotients and DPP sums are nothing the PPMd walk's register
+// allocation should have to share a function with)
+__device__ __noinline__ uint32_t qvz_encode_out_of_line(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32_t n, fs_gptr out, uint32_t cap)
+{ return fsqvz::encode_stream(arena, model, in, n, out, cap); }
+
+// (and the one-symbol loop of the range coders: with every coder but PPMd out of line no kernel spills a vector register any more --
+// the one-wave kernel had 19-37 spilled and 64-136 bytes of scratch per lane all round; 3 072 equal PPMd streams 6.60 -> 6.86 G symbols/s)
+__device__ __noinline__ uint32_t rc_serial_out_of_line(uint32_t model, fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap)
+{ return fsrc::encode_model_serial(model, table, pairs, n, out, cap); }
+
 template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_streams_body()
 {
     constexpr bool TWO = WAVES >= 2, THREE = WAVES == 3;
@@ -165,9 +175,9 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
                 else size = fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs);
             }
         } else if (kind == KIND_QVZ) {
-            size = fsqvz::encode_stream(ar, (fs_cgptr)(k->in + item.aux_off), src, n, dst, cap);
+            size = qvz_encode_out_of_line(ar, (fs_cgptr)(k->in + item.aux_off), src, n, dst, cap);
         } else {
-            size = RCWIN ? rc_encode_out_of_line(kind - KIND_RC_BASE, ar, src, n, dst, cap) : fsrc::encode_model_serial(kind - KIND_RC_BASE, ar, src, n, dst, cap);
+            size = RCWIN ? rc_encode_out_of_line(kind - KIND_RC_BASE, ar, src, n, dst, cap) : rc_serial_out_of_line(kind - KIND_RC_BASE, ar, src, n, dst, cap);
         }
         if (threadIdx.x < 16u) {
             KernArgs k2 = kernargs();
