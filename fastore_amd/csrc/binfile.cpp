@@ -64,7 +64,7 @@ struct Unpacker {
 
     // packedD: the packed bases are kept beside the unpacked ones (Batch::dnaPacked / dnaBit / dnaInfo): where the last readDna
     // began in the bin's bytes, and in which form it was stored
-    bool packedD = false; uint64_t dnaBitBase = 0, dnaStart = 0; bool dnaPlain = false;
+    bool packedD = false; uint64_t dnaBitBase = 0, dnaStart = 0; bool dnaPlain = false, dnaTooLong = false;      // dnaTooLong: a bit offset past 32 bits -- the bin's packed form is not offered (ASCII bases go up)
     void readDna(uint8_t* seq, uint32_t seqLen, uint32_t minimPos, uint32_t suffixLen)
     {
         const bool plain = meta.getBit() != 0;
@@ -135,7 +135,7 @@ struct Unpacker {
         readDna(b.seq.data() + seqOff, len, minimPos, s.suffixLen);
         if (packedD && !isMate2) {      // (the window search reads first mates only)
             const size_t idx = (size_t)(&r - b.recs.data());
-            if (dnaStart > 0xFFFFFFFFull) throw std::runtime_error("bin with more than 512 MiB of packed bases");
+            if (dnaStart > 0xFFFFFFFFull) dnaTooLong = true;
             b.dnaBit[idx] = (uint32_t)dnaStart;
             b.dnaInfo[idx] = (dnaPlain ? fsdev::PACKED_PLAIN : 0u) | (s.suffixLen != 0 ? fsdev::PACKED_HAS_SIG | (s.signatureId & ((1u << fsdev::PACKED_SIG_BITS) - 1u)) | (minimPos << fsdev::PACKED_SIG_BITS) : 0u);
         }
@@ -459,6 +459,7 @@ void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asN
         }
         u.meta.flushWord(); u.dna.flushWord(); u.qua.flushWord(); u.head.flushWord();
     }
+    if (u.dnaTooLong) { bin.dnaPackedBytes = 0; }        // (more than 512 MiB of packed bases in one bin: the window search gets its bases as ASCII)
     bin.minLen = s.minLen; bin.maxLen = s.maxLen;     // the reference keeps the last slice's values (NodesPacker.cpp:560-563)
     bin.recCount = (placed ? recIdx : (uint32_t)data.recs.size()) - bin.recBegin;
     bin.topCount = (uint32_t)graph.topNodes.size() - bin.topBegin;
