@@ -19,10 +19,10 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     # a GPU test that stops (a device call that never returns, a reference tool that dead-locks) is reported with every thread's
-    # stack after six minutes instead of keeping the whole run silent until it is killed from outside
+    # stack after fifteen minutes instead of keeping the whole run silent until it is killed from outside
     for it in items:
         if it.get_closest_marker("gpu") and not it.get_closest_marker("timeout"):
-            it.add_marker(pytest.mark.timeout(360, method="thread"))
+            it.add_marker(pytest.mark.timeout(900, method="thread"))
 
 
 def _make(target_dir, *args):
