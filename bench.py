@@ -352,7 +352,11 @@ def main():
             # configs[2] is 100 M pairs x 150 bp PE; what fits this run's window is a library of --pe-reads pairs from the same
             # generator (genome scaled for the same 50x coverage): its own value, reference baseline, parity and roofline
             pk, ps, pw = args.pe_reads, max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
-            pleg, _ = one_library_leg(fastore_amd, torch, args, args.work, "pe%dk" % (pk // 1000) + ("" if QUALITY == "lossless" else "_" + QUALITY), pk, True, 2 * pk * L // 50, ps, pw, cores, lib, 0 if args.no_cli else 3)
+            # (a leg beside the headline must never cost the line itself: what goes wrong in it is reported in its place)
+            try:
+                pleg, _ = one_library_leg(fastore_amd, torch, args, args.work, "pe%dk" % (pk // 1000) + ("" if QUALITY == "lossless" else "_" + QUALITY), pk, True, 2 * pk * L // 50, ps, pw, cores, lib, 0 if args.no_cli else 3)
+            except Exception as e:          # noqa: BLE001
+                pleg = {"error": "%s: %s" % (type(e).__name__, e)}
             res["pe"] = pleg
         if not args.paired and not args.no_pe and not args.no_reduced and QUALITY == "lossless":      # (--no-pe: the headline leg only)
             # configs[3]'s mode (--reduced: 8-bin quality scores, range-coded with the <8,6> model instead of PPMd) on the same
@@ -361,6 +365,8 @@ def main():
             globals()["QUALITY"] = "reduced"
             try:
                 rleg, _ = one_library_leg(fastore_amd, torch, args, args.work, name + "_reduced", args.reads, False, genome, max(1, min(args.steps, 3)), 1, cores, lib, 0)
+            except Exception as e:          # noqa: BLE001
+                rleg = {"error": "%s: %s" % (type(e).__name__, e)}
             finally:
                 globals()["QUALITY"] = global_q
             res["reduced"] = rleg
