@@ -50,7 +50,7 @@ FS_DEV void put_decided(BitOut& o, uint32_t bit, uint32_t& scale3)
 // cumulative count below x, the count of x and the total of the context block `blk`; then the adaptive update
 FS_DEV void model_step(FS_GLOBAL uint32_t* blk, uint32_t card, uint32_t x, uint32_t& cumLo, uint32_t& cnt, uint32_t& total)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if FS_WIDE
     const uint32_t lane = (uint32_t)FS_LANE();
     // words 0..card of the block: lane j holds word j, lanes 0..8 also hold word 64 + j (card <= 72)
     uint32_t v = lane <= card ? blk[lane] : 0u;
@@ -60,6 +60,7 @@ FS_DEV void model_step(FS_GLOBAL uint32_t* blk, uint32_t card, uint32_t x, uint3
         v2 = 64u + lane <= card ? blk[64u + lane] : 0u;
         part += (64u + lane <= x) ? v2 : 0u;
     }
+    FS_EMU_MEET();
     // (the sum over the lanes by DPP row shifts and broadcasts -- six adds; as six __shfl_xor steps it was six trips through the
     // LDS crossbar, one behind the other, in every symbol's chain)
     cumLo = fs_wave_sum8(part, true);
@@ -82,6 +83,7 @@ FS_DEV void model_step(FS_GLOBAL uint32_t* blk, uint32_t card, uint32_t x, uint3
         if (lane == w) blk[w] = v + STEP;
         if (64u + lane == w) blk[w] = v2 + STEP;
     }
+    FS_EMU_MEET();
 #else
     uint32_t lo = 0;
     for (uint32_t i = 0; i < x; ++i) lo += blk[1 + i];
@@ -155,5 +157,99 @@ FS_DEV uint32_t encode_stream(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32
     FS_WAVE_SYNC();
     return (o.overflow || bad) ? 0xFFFFFFFFu : o.pos;
 }
+
+#if FS_WIDE
+// ---- windowed form (NOT in the product's kernels yet: built with -DFS_QVZ_WINDOWS=1; bit-exact on the lock-step emulation,
+// tests/test_simt.py; unmeasured on the device at the end of round 3) ----
+// A symbol's context is a pure function of the input (the front end put it into the symbol's word), and the contexts of
+// consecutive symbols differ -- a context belongs to a column -- so 64 lanes take 64 consecutive symbols: every lane fetches
+// its descriptor, its context's total and count, and sums the counts below its symbol from its own block; no wave-wide sum, no
+// chain of three dependent loads per symbol.  A window ends in front of the first symbol that shares its context with an
+// earlier one of the window, whose context is due for a rescale, or that is malformed; that symbol takes the one-symbol step.
+// The arithmetic coder (arith.cpp:33-125) then passes over the window's (low count, count, total) triples in stream order.
+FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32_t n, fs_gptr out, uint32_t cap)
+{
+    const FS_GLOBAL ModelHeader* hdr = (const FS_GLOBAL ModelHeader*)model;
+    const uint32_t nCtx = FS_UNI(hdr->n_ctx), words = FS_UNI(hdr->image_words);
+    const FS_GLOBAL Desc* desc = (const FS_GLOBAL Desc*)(model + sizeof(ModelHeader));
+    fs_cgptr image = model + sizeof(ModelHeader) + (uint64_t)nCtx * sizeof(Desc);
+    fs_wave_copy4(arena, image, words * 4u);
+    FS_GLOBAL uint32_t* stat = (FS_GLOBAL uint32_t*)arena;
+    const uint32_t lane = (uint32_t)FS_LANE();
+
+    BitOut o; o.out = out; o.pos = 0; o.cap = cap; o.acc = 0; o.nb = 0; o.overflow = 0;
+    uint32_t l = 0, u = (1u << M_BITS) - 1u, scale3 = 0, bad = 0;
+    const uint32_t msbShift = M_BITS - 1, smsbShift = M_BITS - 2, clearMask = (1u << msbShift) - 1u;
+    const FS_GLOBAL uint32_t* sym = (const FS_GLOBAL uint32_t*)in;
+    // one symbol through the interval: arithmetic_encoder_step (arith.cpp:33-78)
+    auto code = [&](uint32_t cumLo, uint32_t cnt, uint32_t total) {
+        const uint64_t range = (uint64_t)u - l + 1u;
+        u = l + (uint32_t)((double)(range * (cumLo + cnt)) / (double)total) - 1u;
+        l = l + (uint32_t)((double)(range * cumLo) / (double)total);
+        for (;;) {
+            const uint32_t msbL = l >> msbShift, msbU = u >> msbShift;
+            if (msbL == msbU) {
+                put_decided(o, msbL, scale3);
+                l = (l & clearMask) << 1;
+                u = ((u & clearMask) << 1) + 1u;
+            } else if ((l >> smsbShift) == 1u && (u >> smsbShift) == 2u) {
+                scale3 += 1u;
+                u = (((u << 1) & clearMask) | (1u << msbShift)) + 1u;
+                l = (l << 1) & clearMask;
+            } else break;
+        }
+    };
+    for (uint32_t k = 0; k < n && !bad;) {
+        const uint32_t left = FS_UNI(n - k), W = left < 64u ? left : 64u;
+        const bool valid = lane < W;
+        const uint32_t w = valid ? sym[k + lane] : 0u;
+        const uint32_t ctx = w & 0xFFFFFFu, x = w >> 24;
+        bool wrong = valid && ctx >= nCtx;
+        uint32_t off = 0, card = 0;
+        if (valid && !wrong) { off = desc[ctx].off; card = desc[ctx].card; }
+        wrong = wrong || (valid && (x >= card || card > MAX_CARD));
+        FS_EMU_MEET();
+        // an earlier symbol of the window in the same context?
+        bool shared = false;
+        for (uint32_t d = 1; d < W; ++d) {
+            const uint32_t other = fs_bperm(ctx, (lane - d) & 63u);
+            shared = shared || (valid && lane >= d && other == ctx);
+        }
+        // my context's total, my symbol's count, the counts below it
+        uint32_t total = 1, cnt = 0, cumLo = 0;
+        const bool fetch = valid && !wrong;
+        FS_GLOBAL uint32_t* blk = stat + off;
+        if (fetch) { total = blk[0]; cnt = blk[1u + x]; }
+        for (uint32_t j = 0; fs_ballot(fetch && j < x) != 0ull; ++j) if (fetch && j < x) cumLo += blk[1u + j];
+        FS_EMU_MEET();
+        const bool due = fetch && total + STEP > RESCALE_AT;
+        const uint64_t stop = fs_ballot(valid && (wrong || shared || due));
+        const uint32_t take = FS_UNI(stop ? fs_ctz64(stop) : W);
+        // the window's updates: every context is there once
+        if (lane < take) { blk[0] = total + STEP; blk[1u + x] = cnt + STEP; }
+        FS_EMU_MEET();
+        l = FS_UNI(l); u = FS_UNI(u); scale3 = FS_UNI(scale3);
+        for (uint32_t i = 0; i < take; ++i) code(fs_readlane(cumLo, i), fs_readlane(cnt, i), fs_readlane(total, i));
+        k += take;
+        if (take < W) {          // symbol k: shares its context, is due for a rescale, or is malformed -- the one-symbol step
+            const uint32_t w1 = FS_UNI(fs_readlane(w, take));
+            const uint32_t ctx1 = w1 & 0xFFFFFFu, x1 = w1 >> 24;
+            if (ctx1 >= nCtx) { bad = 1; break; }
+            const uint32_t off1 = FS_UNI(desc[ctx1].off), card1 = FS_UNI(desc[ctx1].card);
+            if (x1 >= card1 || card1 > MAX_CARD) { bad = 1; break; }
+            uint32_t c1, n1, t1;
+            model_step(stat + off1, card1, x1, c1, n1, t1);
+            code(c1, n1, t1);
+            ++k;
+        }
+    }
+    const uint32_t msbL = l >> msbShift;
+    put_decided(o, msbL, scale3);
+    put_bits(o, l & clearMask, M_BITS - 1);
+    if (o.nb) put_bits(o, 0u, 8u - o.nb);
+    FS_WAVE_SYNC();
+    return (o.overflow || bad) ? 0xFFFFFFFFu : o.pos;
+}
+#endif
 
 }  // namespace fsqvz

@@ -115,3 +115,17 @@ extern "C" size_t simt_rc_encode(unsigned model, const uint8_t* pairs, size_t n,
     free(table);
     return size == 0xFFFFFFFFu ? (size_t)-1 : size;
 }
+
+// the QVZ coder on one emulated wave: form 0 = one symbol per trip (encode_stream), 1 = the windowed form
+#include "../../fastore_amd/csrc/qvz_core.h"
+extern "C" long simt_qvz_encode(int form, const uint8_t* blob, const uint8_t* syms, size_t n, size_t arenaBytes, uint8_t* out, size_t cap)
+{
+    uint8_t* arena = (uint8_t*)aligned_alloc(64, (arenaBytes + 4096 + 63) & ~63ull);
+    uint32_t size = 0;
+    simt::run_waves(1, [&](int, int) {
+        const uint32_t s = form ? fsqvz::encode_stream_windowed(arena, blob, syms, (uint32_t)n, out, (uint32_t)cap) : fsqvz::encode_stream(arena, blob, syms, (uint32_t)n, out, (uint32_t)cap);
+        if (simt::lane() == 0) size = s;
+    });
+    free(arena);
+    return size == 0xFFFFFFFFu ? -1 : (long)size;
+}

@@ -17,7 +17,7 @@ def simt():
     os.makedirs(os.path.dirname(out), exist_ok=True)
     # FS_EMU_DEFS: extra -D flags (kernel experiments, e.g. -DFS_WIN_PREFETCH=1) for the same tests
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU", "-DFS_WIN_NARROW=1"] + os.environ.get("FS_EMU_DEFS", "").split() + ["-shared", "-fPIC", "-o", out,
-                           os.path.join(ROOT, "tests", "emu", "ppmd_simt.cpp"), os.path.join(ROOT, "tests", "emu", "simt.cpp")])
+                           os.path.join(ROOT, "tests", "emu", "ppmd_simt.cpp"), os.path.join(ROOT, "tests", "emu", "simt.cpp"), os.path.join(ROOT, "tests", "emu", "qvz_host_ref.cpp")])
     lib = ctypes.CDLL(out)
     lib.simt_ppmd_encode.restype = ctypes.c_size_t
     lib.simt_ppmd_encode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
@@ -196,3 +196,48 @@ def test_windowed_range_coder_reproduces_the_one_symbol_loop(simt, oracle, model
     # a symbol outside the alphabet, a context outside its field: the stream is given up as in the one-symbol loop
     bad = bytearray(np.stack([np.zeros(200, np.uint8), np.zeros(200, np.uint8)], axis=1).tobytes()); bad[2 * 130] = A
     assert rc_encode(simt, mid, bytes(bad)) is None
+
+
+def qvz_case(rng, n_ctx, n, max_card, same_ctx_runs):
+    """a synthetic model blob (ModelHeader | Desc[n_ctx] | image: per context its total and its counts) and n symbols ctx | x << 24"""
+    cards = rng.integers(1, max_card + 1, n_ctx).astype(np.uint32)
+    offs = np.concatenate([[0], np.cumsum(cards + 1)[:-1]]).astype(np.uint32)
+    image = []
+    for c in cards:
+        counts = rng.integers(1, 40, int(c)).astype(np.uint32)
+        image += [int(counts.sum())] + [int(v) for v in counts]
+    image = np.array(image, np.uint32)
+    blob = np.array([n_ctx, len(image), 0, 0], np.uint32).tobytes() + np.stack([offs, cards], 1).astype(np.uint32).tobytes() + image.tobytes()
+    ctx = rng.integers(0, n_ctx, n).astype(np.uint32)
+    if same_ctx_runs:                                   # the same context several times in a row, and one hot context: shared windows, rescales
+        for i in range(0, n - 8, 97):
+            ctx[i:i + int(rng.integers(2, 8))] = ctx[i]
+        ctx[rng.random(n) < 0.5] = 0
+    x = (rng.integers(0, 1 << 30, n) % cards[ctx]).astype(np.uint32)
+    return blob, (ctx | (x << 24)).astype(np.uint32).tobytes(), 4 * len(image)
+
+
+def test_qvz_forms_on_the_emulated_wave_reproduce_the_one_lane_coder(simt):
+    # the QVZ coder's 64-lane forms -- the one the kernels run (a symbol per trip, lanes over the context's counts) and the windowed
+    # form (64 symbols per step; not in the kernels yet) -- against the same header compiled for one lane
+    for f in (simt.simt_qvz_encode, simt.host_qvz_encode):
+        f.restype = ctypes.c_long
+    simt.simt_qvz_encode.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    simt.host_qvz_encode.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    rng = np.random.default_rng(77)
+    for n_ctx, n, max_card, runs in ((300, 0, 8, False), (300, 1, 8, False), (300, 63, 8, False), (300, 64, 8, False), (300, 65, 8, False), (300, 20_000, 8, False),
+                                     (40, 30_000, 72, True), (3, 150_000, 5, True)):
+        blob, syms, arena = qvz_case(rng, n_ctx, n, max_card, runs)
+        cap = 4 * n + 64
+        want = ctypes.create_string_buffer(cap); nw = simt.host_qvz_encode(blob, syms + b"\0" * 256, n, arena, want, cap)
+        assert nw >= 0
+        for form in (0, 1):
+            got = ctypes.create_string_buffer(cap); ng = simt.simt_qvz_encode(form, blob, syms + b"\0" * 256, n, arena, got, cap)
+            assert ng == nw and got.raw[:ng] == want.raw[:nw], (form, n_ctx, n)
+    # a symbol outside its context's alphabet gives the stream up in every form
+    blob, syms, arena = qvz_case(rng, 50, 500, 6, False)
+    bad = bytearray(syms); bad[4 * 300 + 3] = 200
+    out = ctypes.create_string_buffer(4096)
+    assert simt.host_qvz_encode(blob, bytes(bad) + b"\0" * 256, 500, arena, out, 4096) == -1
+    for form in (0, 1):
+        assert simt.simt_qvz_encode(form, blob, bytes(bad) + b"\0" * 256, 500, arena, out, 4096) == -1
