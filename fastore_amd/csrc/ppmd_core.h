@@ -332,9 +332,14 @@ FS_DEV void FreeUnits(Coder& m, uint32_t ptr, uint32_t NU)
 //   A = 2^31 | low     a step of the serial path: M = frequency | total << 16; a binary context's step is the same with
 //                      the total 2^14 (Model.cpp:415-432: range >>= TOT_BITS is the division by it)
 //   A = 0xFFFFFFFF     command M: stream start (header bytes), stream end (flush, size), exit
-enum : uint32_t { CQ_SIZE = 256u, CQ_SERIAL = 0x80000000u, CQ_CMD = 0xFFFFFFFFu, CQ_START = 1u, CQ_END = 2u, CQ_EXIT = 3u };
+enum : uint32_t { CQ_SIZE = 256u, CQ_SERIAL = 0x80000000u, CQ_CMD = 0xFFFFFFFFu, CQ_START = 1u, CQ_END = 2u, CQ_EXIT = 3u,
+                  // -DFS_RC_ON_CODER_WAVE builds (not the product's yet): a range-coded stream's triples through the same ring.  Entry:
+                  // A = cumulative frequency | (frequency & 0x3FFF) << 16 | CQ_RC ; M = total | (frequency >> 14) << 16
+                  CQ_START_RC = 4u, CQ_END_RC = 5u, CQ_END_RC_BAD = 6u, CQ_RC = 1u << 30 };
 
 FS_DEV void put_byte(Coder& m, uint32_t c) { if (m.outPos < m.outCap) fs_st8(m.out + m.outPos, c); m.outPos += (m.outPos < m.outCap); }
+// (a range-coded stream's byte: its size counts on past the capacity, as rc_core.h's put does)
+FS_DEV void rc_put(Coder& m, uint32_t c) { if (m.outPos < m.outCap) fs_st8(m.out + m.outPos, c); m.outPos++; }
 FS_DEV void rc_shift_out(Coder& m)
 {
     while ((m.low ^ (m.low + m.range)) < TOP || (m.range < BOT && ((m.range = (0u - m.low) & (BOT - 1)), true))) {
@@ -1019,7 +1024,10 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
     m.three = three ? 1u : 0u; m.wSeq = 0u; m.wHintDue = 0u;
     m.ldsHeads = queued ? 1u : 0u;
     m.hb = arena - 1; m.sh = sh; m.out = out; m.outCap = outCap; m.outPos = 0; sh->restarts = 0;
-    m.queued = queued ? 1u : 0u; m.qTail = qTail; m.qHeadSeen = qTail;
+    // (nothing is assumed about how far the coder wave has come with the stream before: the first push looks.  `qHeadSeen = qTail`
+    // -- "the ring is empty" -- held in practice, the model's start-up outlasts any backlog, but was a promise nobody made:
+    // found on the lock-step emulation at the end of round 3, where a range-coded stream's last windows were still in the ring)
+    m.queued = queued ? 1u : 0u; m.qTail = qTail; m.qHeadSeen = qTail - CQ_SIZE;
     m.inAhead = 0;
     m.NumMasked = 0; m.FoundState = 0; m.BSumm = 0; m.rLow = m.rHigh = m.rScale = 0; m.fsSym = m.fsFreq = m.fsSucc = 0;
     for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) sh->winStats[i] = 0u;
@@ -1185,6 +1193,9 @@ FS_DEV void coder_wave(FS_LDS Shared* sh)
     FS_GLOBAL uint32_t* sizeOut = nullptr;
     const uint32_t lane = (uint32_t)FS_LANE();
     uint32_t head = 0, starts = 0;
+#if defined(FS_RC_ON_CODER_WAVE)
+    uint64_t rcLow = 0; uint32_t rcRange = 0xFFFFFFFFu; bool rcMode = false;      // the range coder of rc_core.h (64-bit low) while a range-coded stream is open
+#endif
     for (;;) {
         uint32_t tail;
         for (;;) { tail = FS_Q_LOAD(sh->qTail); if (tail != head) break; FS_Q_IDLE(); }
@@ -1194,6 +1205,14 @@ FS_DEV void coder_wave(FS_LDS Shared* sh)
         head += n;
         FS_Q_STORE(sh->qHead, head);                            // the batch is in registers: its slots are free again
         const bool special = lane < n && (eA >> 31) != 0u;
+#if defined(FS_RC_ON_CODER_WAVE)
+        uint32_t eL = 1u;
+        if (lane < n && !special && (eA & CQ_RC) != 0u) {       // a range-coded stream's triple: frequency | cumulative frequency, reciprocal of the total
+            const uint32_t F = ((eA >> 16) & 0x3FFFu) | (((eM >> 16) & 3u) << 14), LO = eA & 0xFFFFu;
+            const Recip rc = recip_make(eM & 0xFFFFu);
+            eA = LO | (F << 16); eM = rc.mul; eL = rc.l;
+        } else
+#endif
         if (lane < n && !special) {                             // all the batch's reciprocals at once
             const Recip rc = recip_make(eM);
             eA = (eA & 0x00FFFFFFu) | ((rc.l - 1u) << 24); eM = rc.mul;
@@ -1203,6 +1222,21 @@ FS_DEV void coder_wave(FS_LDS Shared* sh)
         for (uint32_t i = 0; i < n;) {
             const uint64_t ahead = todo >> i;
             const uint32_t stop = ahead ? i + fs_ctz64(ahead) : n;
+#if defined(FS_RC_ON_CODER_WAVE)
+            if (rcMode) {      // RangeEncoder::EncodeFrequency (rc/RangeCoder.h:40-84) over the triples [i, stop)
+                for (; i < stop; ++i) {
+                    const uint32_t FL = FS_UNI(fs_readlane(eA, i)), M0 = FS_UNI(fs_readlane(eM, i)), L0 = FS_UNI(fs_readlane(eL, i));
+                    rcRange = recip_div(rcRange, M0, L0);
+                    rcLow += (uint32_t)(rcRange * (FL & 0xFFFFu));
+                    rcRange *= FL >> 16;
+                    while (rcRange <= 0x00ffffffu) {
+                        if ((rcLow ^ (rcLow + rcRange)) & 0xff00000000000000ULL) { const uint32_t x = (uint32_t)rcLow; rcRange = (x | 0x00ffffffu) - x; }
+                        rc_put(m, (uint32_t)(rcLow >> 56));
+                        rcLow <<= 8; rcRange <<= 8;
+                    }
+                }
+            }
+#endif
             // plain hits [i, stop): Coder.hpp:13-17 with the division by multiplication, then Model.cpp:580
             #define FS_CODE_ONE(A_, M_) do { \
                 const uint32_t t_ = fs_mulhi(m.range, M_), rr_ = (t_ + ((m.range - t_) >> 1)) >> (A_ >> 24); \
@@ -1233,6 +1267,19 @@ FS_DEV void coder_wave(FS_LDS Shared* sh)
             } else if (M == CQ_END) {
                 for (int k = 0; k < 4; k++) { put_byte(m, m.low >> 24); m.low <<= 8; }
                 if (sizeOut) *sizeOut = m.outPos;
+#if defined(FS_RC_ON_CODER_WAVE)
+            } else if (M == CQ_START_RC) {
+                FS_LDS uint32_t* box = sh->qBox[starts & 1u];
+                const uint64_t o = (uint64_t)FS_LDS_RD(box[0]) | ((uint64_t)FS_LDS_RD(box[1]) << 32), z = (uint64_t)FS_LDS_RD(box[3]) | ((uint64_t)FS_LDS_RD(box[4]) << 32);
+                m.out = (fs_gptr)(uintptr_t)o; sizeOut = (FS_GLOBAL uint32_t*)(uintptr_t)z; m.outCap = FS_LDS_RD(box[2]); m.outPos = 0;
+                ++starts; FS_Q_STORE(sh->qStarts, starts);
+                rcLow = 0; rcRange = 0xFFFFFFFFu; rcMode = true;
+
+            } else if (M == CQ_END_RC || M == CQ_END_RC_BAD) {
+                for (int k = 0; k < 8; k++) { rc_put(m, (uint32_t)(rcLow >> 56)); rcLow <<= 8; }      // TEncoder::End: eight flush bytes
+                if (sizeOut) *sizeOut = M == CQ_END_RC ? m.outPos : 0xFFFFFFFFu;
+                rcMode = false;
+#endif
             } else return;                                      // CQ_EXIT
         }
     }

@@ -157,8 +157,12 @@ FS_DEV uint32_t encode_stream(fs_gptr table /*16-byte aligned, table_bytes()*/, 
 // triples in stream order, scalar code with one reciprocal per position made by all lanes at once.
 // A position whose row reaches the rescale limit ends the window in front of it and is coded by the one-symbol step.
 // The bytes are those of the loop above by construction: a different schedule of the same updates.
+// q (-DFS_RC_ON_CODER_WAVE builds; not the product's yet): the triples go to the coder wave of the two-wave form through the
+// PPMd walk's ring (ppmd_core.h: coder_wave) instead of being coded here -- the model side of window k + 1 then runs beside
+// the range coder's pass over window k; the stream's size is written by the coder wave, the return value is 0.
+struct RcQueue { fsppmd::Coder m; FS_GLOBAL uint32_t* sizeOut; };
 template <int BITS, int ORDER, bool ADV, int CTXBITS>
-FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap)
+FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap, RcQueue* q = nullptr)
 {
     static_assert(BITS == 1 || BITS == 3, "small alphabets only");
     constexpr uint32_t A = 1u << BITS;
@@ -179,6 +183,23 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
         FS_WAVE_SYNC();
     }
     Enc e; e.low = 0; e.range = 0xffffffffu; e.out = out; e.cap = cap; e.pos = 0;
+#if defined(FS_RC_ON_CODER_WAVE)
+    if (q) {      // hand the coder wave this stream's output buffer (the mailbox protocol of fsppmd::encode_member)
+        fsppmd::Coder& m = q->m;
+        const uint32_t s = FS_UNI(FS_LDS_RD(m.sh->qOpened));
+        if (s >= 2u) fsppmd::cq_wait_starts(m, s - 1u);
+        if (FS_LANE() == 0) {
+            const uint64_t o = (uint64_t)(uintptr_t)out, z = (uint64_t)(uintptr_t)q->sizeOut;
+            FS_LDS uint32_t* box = m.sh->qBox[s & 1u];
+            box[0] = (uint32_t)o; box[1] = (uint32_t)(o >> 32); box[2] = cap; box[3] = (uint32_t)z; box[4] = (uint32_t)(z >> 32);
+            m.sh->qOpened = s + 1u;
+        }
+        FS_WAVE_SYNC();
+        fsppmd::cq_push(m, fsppmd::CQ_CMD, fsppmd::CQ_START_RC);
+    }
+#else
+    (void)q;
+#endif
     uint64_t hash = 0;                                   // the symbols in front of position k, the latest in the lowest bits
     fs_cgptr16 pairs16 = (fs_cgptr16)pairs;
     for (uint32_t k = 0; k < n;) {
@@ -187,7 +208,12 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
         const uint32_t pr = valid ? (uint32_t)pairs16[k + lane] : 0u;
         FS_EMU_MEET();
         const uint32_t sym = pr & 0xFFu, ctx = pr >> 8;
-        if (fs_ballot(valid && (sym >= A || (ADV && CTXBITS < 8 && ctx >= (1u << CTXBITS)))) != 0ull) return 0xFFFFFFFFu;    // (as the loop above: the stream is given up)
+        if (fs_ballot(valid && (sym >= A || (ADV && CTXBITS < 8 && ctx >= (1u << CTXBITS)))) != 0ull) {      // (as the loop above: the stream is given up)
+#if defined(FS_RC_ON_CODER_WAVE)
+            if (q) fsppmd::cq_push(q->m, fsppmd::CQ_CMD, fsppmd::CQ_END_RC_BAD);
+#endif
+            return 0xFFFFFFFFu;
+        }
         // the ORDER symbols in front of every position: from the lanes below, and from `hash` for the first lanes
         uint32_t hs = 0;
         #pragma unroll
@@ -249,6 +275,11 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
                 if (writer) *(FS_GLOBAL uint32_t*)st = nv[0] | (nv[1] << 16);
             }
             FS_EMU_MEET();
+#if defined(FS_RC_ON_CODER_WAVE)
+            if (q) fsppmd::cq_push_lanes(q->m, lo | ((f & 0x3FFFu) << 16) | fsppmd::CQ_RC, acc | ((f >> 14) << 16), cnt);
+            else
+#endif
+            {
             // the range coder over the triples, in stream order; range / total by a reciprocal per position (total in [2, 65535])
             uint32_t rmul = 0, rl = 1;
             if (lane < cnt) { const fsppmd::Recip rc = fsppmd::recip_make(acc); rmul = rc.mul; rl = rc.l; }
@@ -270,6 +301,7 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
                 }
             }
             e.low = low; e.range = range; e.pos = pos;
+            }
             // the symbols in front of position k + cnt
             uint64_t nh = 0;
             #pragma unroll
@@ -299,11 +331,18 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
             for (uint32_t j = 0; j < A; ++j) { if (j < s1) lo1 += w[j]; if (j == s1) f1 = w[j]; }
             fs_st16((fs_gptr)(st1 + s1), f1 + 8);
             FS_EMU_MEET();
+#if defined(FS_RC_ON_CODER_WAVE)
+            if (q) fsppmd::cq_push(q->m, lo1 | ((f1 & 0x3FFFu) << 16) | fsppmd::CQ_RC, acc1 | ((f1 >> 14) << 16));
+            else
+#endif
             encode_freq(e, f1, lo1, acc1);
             hash = (hash << BITS) | s1;
             ++k;
         }
     }
+#if defined(FS_RC_ON_CODER_WAVE)
+    if (q) { fsppmd::cq_push(q->m, fsppmd::CQ_CMD, fsppmd::CQ_END_RC); return 0u; }
+#endif
     for (int i = 0; i < 8; ++i) { put(e, (uint32_t)(e.low >> 56)); e.low <<= 8; }
     return e.pos;
 }
@@ -347,6 +386,20 @@ FS_DEV uint32_t encode_model(uint32_t model, fs_gptr table, fs_cgptr pairs, uint
     default: return encode_stream<8, 1, true>(table, pairs, n, out, cap);
     }
 }
+#if FS_WIDE && defined(FS_RC_ON_CODER_WAVE)
+// the small alphabets with their triples sent to the coder wave; false: not a model with a windowed form (the caller codes it itself)
+FS_DEV bool encode_model_queued(uint32_t model, fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap, RcQueue* q)
+{
+    switch (model) {
+    case M_S2O4: (void)encode_stream_windowed<1, 4, false, 1>(table, pairs, n, out, cap, q); return true;
+    case M_S8O4: (void)encode_stream_windowed<3, 4, false, 3>(table, pairs, n, out, cap, q); return true;
+    case M_A8O4: (void)encode_stream_windowed<3, 4, true, 3>(table, pairs, n, out, cap, q); return true;
+    case M_A2O10: (void)encode_stream_windowed<1, 10, true, 1>(table, pairs, n, out, cap, q); return true;
+    case M_A8O6: (void)encode_stream_windowed<3, 6, true, 3>(table, pairs, n, out, cap, q); return true;
+    default: return false;
+    }
+}
+#endif
 FS_DEV uint64_t model_table_bytes(uint32_t model)
 {
     switch (model) {

@@ -129,3 +129,34 @@ extern "C" long simt_qvz_encode(int form, const uint8_t* blob, const uint8_t* sy
     free(arena);
     return size == 0xFFFFFFFFu ? -1 : (long)size;
 }
+
+
+#if defined(FS_RC_ON_CODER_WAVE)
+// range-coded streams with their triples coded by the coder wave (two emulated waves), a PPMd member before and behind them:
+// the ring carries both kinds of entries, the coder wave switches between its two range coders at the streams' commands
+extern "C" int simt_rc_encode_two_waves(int nStreams, const unsigned* models /* 0xFFFFFFFF: a PPMd member */, const uint8_t* const* in, const size_t* n,
+                                        uint8_t* const* out, const size_t* cap, uint32_t* sizes)
+{
+    uint8_t* arena = (uint8_t*)aligned_alloc(64, (size_t)48 << 20);
+    fsppmd::Shared* sh = new fsppmd::Shared;
+    sh->qTail = sh->qHead = 0; sh->qStarts = sh->qOpened = 0;
+    simt::run_waves(2, [&](int wave, int) {
+        if (wave == 1) { fsppmd::coder_wave(sh); return; }
+        uint32_t q = 0;
+        for (int s = 0; s < nStreams; ++s) {
+            if (models[s] == 0xFFFFFFFFu) {
+                uint32_t r0 = 0;
+                if (n[s] == 0) { if (simt::lane() == 0) sizes[s] = 0; continue; }
+                fsppmd::encode_member(arena, sh, in[s], (uint32_t)n[s], out[s], (uint32_t)cap[s], &r0, true, &sizes[s], q, &q);
+            } else {
+                fsrc::RcQueue rq; rq.m.sh = sh; rq.m.qTail = q; rq.m.qHeadSeen = q - fsppmd::CQ_SIZE; rq.sizeOut = &sizes[s];
+                (void)fsrc::encode_model_queued(models[s], arena, in[s], (uint32_t)n[s], out[s], (uint32_t)cap[s], &rq);
+                q = rq.m.qTail;
+            }
+        }
+        fsppmd::cq_send_exit(sh, q);
+    });
+    delete sh; free(arena);
+    return 0;
+}
+#endif

@@ -241,3 +241,41 @@ def test_qvz_forms_on_the_emulated_wave_reproduce_the_one_lane_coder(simt):
     assert simt.host_qvz_encode(blob, bytes(bad) + b"\0" * 256, 500, arena, out, 4096) == -1
     for form in (0, 1):
         assert simt.simt_qvz_encode(form, blob, bytes(bad) + b"\0" * 256, 500, arena, out, 4096) == -1
+
+
+def test_range_coded_streams_through_the_coder_wave(oracle):
+    # -DFS_RC_ON_CODER_WAVE (not the product's build yet): the windowed range coders send their triples through the PPMd walk's
+    # ring and the coder wave of the two-wave form codes them; PPMd members in between -- the coder wave keeps two range coders
+    # apart.  Against the oracle's coders, on two emulated waves.
+    from conftest import MODELS, oracle_rc
+    out = os.path.join(ROOT, "build", "libsimt_emu_rcq.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU", "-DFS_WIN_NARROW=1", "-DFS_RC_ON_CODER_WAVE", "-shared", "-fPIC", "-o", out,
+                           os.path.join(ROOT, "tests", "emu", "ppmd_simt.cpp"), os.path.join(ROOT, "tests", "emu", "simt.cpp"), os.path.join(ROOT, "tests", "emu", "qvz_host_ref.cpp")])
+    lib = ctypes.CDLL(out)
+    lib.simt_rc_encode_two_waves.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6
+    rng = np.random.default_rng(41)
+    streams = []                                        # (model id or None, bytes)
+    for name in ("a8o6", "s2o4", "a2o10", "a8o4", "s8o4"):
+        mid, bits, order, adv = MODELS[name]
+        A = 1 << bits
+        for n in (0, 1, 64, 65, 3000):
+            sym = rng.integers(0, A, n).astype(np.uint8); ctx = rng.integers(0, A if adv else 1, n).astype(np.uint8)
+            streams.append((name, np.stack([sym, ctx], 1).astype(np.uint8).tobytes()))
+        n = 40_000                                      # quality-like: shared rows inside windows, rescales
+        sym = np.clip(np.cumsum(rng.integers(-1, 2, n)) // 40 % A, 0, A - 1).astype(np.uint8)
+        ctx = ((np.arange(n) % 150) * A // 150).astype(np.uint8) if adv else np.zeros(n, np.uint8)
+        streams.append((name, np.stack([sym, ctx], 1).tobytes()))
+        streams.append((None, quality(3000, 9)))        # a PPMd member between the range-coded streams
+    streams.append(("a8o6", np.stack([np.zeros(30_000, np.uint8), np.zeros(30_000, np.uint8)], 1).tobytes()))
+    k = len(streams)
+    models = (ctypes.c_uint * k)(*[0xFFFFFFFF if m is None else MODELS[m][0] for m, _ in streams])
+    ins = [ctypes.create_string_buffer(d + b"\0" * 256) for _, d in streams]
+    lens = (ctypes.c_size_t * k)(*[len(d) if m is None else len(d) // 2 for m, d in streams])
+    bufs = [ctypes.create_string_buffer(2 * len(d) + 4096) for _, d in streams]
+    caps = (ctypes.c_size_t * k)(*[len(b) for b in bufs])
+    sizes = (ctypes.c_uint32 * k)()
+    inp = (ctypes.c_void_p * k)(*[ctypes.addressof(b) for b in ins]); outp = (ctypes.c_void_p * k)(*[ctypes.addressof(b) for b in bufs])
+    assert lib.simt_rc_encode_two_waves(k, models, inp, lens, outp, caps, sizes) == 0
+    for i, (m, d) in enumerate(streams):
+        want = oracle_ppmd(oracle, d) if m is None else oracle_rc(oracle, m, d)
+        assert bufs[i].raw[:sizes[i]] == want, (i, m, len(d))
