@@ -96,6 +96,21 @@ __device__ __noinline__ uint32_t qvz_encode_out_of_line(fs_gptr arena, fs_cgptr 
 
 // (and the one-symbol loop of the range coders: with every coder but PPMd out of line no kernel spills a vector register any more --
 // the one-wave kernel had 19-37 spilled and 64-136 bytes of scratch per lane all round; 3 072 equal PPMd streams 6.60 -> 6.86 G symbols/s)
+#if defined(FS_RC_ON_CODER_WAVE)
+__device__ __noinline__ bool rc_encode_queued_out_of_line(uint32_t model, fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap,
+                                                          FS_LDS fsppmd::Shared* sh, FS_GLOBAL uint32_t* sizeOut, uint32_t* qTail)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    fsrc::RcQueue rq; rq.m.sh = sh; rq.m.qTail = *qTail; rq.m.qHeadSeen = *qTail - fsppmd::CQ_SIZE; rq.sizeOut = sizeOut;
+    const bool done = fsrc::encode_model_queued(model, table, pairs, n, out, cap, &rq);
+    *qTail = rq.m.qTail;
+    return done;
+#else
+    (void)model; (void)table; (void)pairs; (void)n; (void)out; (void)cap; (void)sh; (void)sizeOut; (void)qTail;
+    return false;                 // (the host pass of the compiler only parses this)
+#endif
+}
+#endif
 __device__ __noinline__ uint32_t rc_serial_out_of_line(uint32_t model, fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap)
 { return fsrc::encode_model_serial(model, table, pairs, n, out, cap); }
 
@@ -168,6 +183,7 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
         fs_gptr dst = (fs_gptr)(k->out + item.out_off);
         fs_gptr ar = (fs_gptr)arena;
         uint32_t size = 0, rs = 0;
+        bool rcQueued = false;             // (-DFS_RC_ON_CODER_WAVE builds: this stream's size comes from the coder wave)
         const uint64_t tStream = FS_PROF_NOW();
         if (kind == KIND_PPMD) {
             if (n > 0) {
@@ -177,11 +193,18 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
         } else if (kind == KIND_QVZ) {
             size = qvz_encode_out_of_line(ar, (fs_cgptr)(k->in + item.aux_off), src, n, dst, cap);
         } else {
+#if defined(FS_RC_ON_CODER_WAVE)
+            // (not the product's build: rc_core.h -- the small alphabets' triples coded by the coder wave of the two-wave form)
+            if (TWO && RCWIN && kind - KIND_RC_BASE <= fsrc::M_A8O6) {
+                KernArgs k3 = kernargs();
+                rcQueued = rc_encode_queued_out_of_line(kind - KIND_RC_BASE, ar, src, n, dst, cap, (FS_LDS fsppmd::Shared*)&sh, (FS_GLOBAL uint32_t*)(k3->outSizes + it), &qTail);
+            } else
+#endif
             size = RCWIN ? rc_encode_out_of_line(kind - KIND_RC_BASE, ar, src, n, dst, cap) : rc_serial_out_of_line(kind - KIND_RC_BASE, ar, src, n, dst, cap);
         }
         if (threadIdx.x < 16u) {
             KernArgs k2 = kernargs();
-            if (threadIdx.x == 0 && !(TWO && kind == KIND_PPMD && n > 0)) k2->outSizes[it] = size;       // (two-wave form: a PPMd member's size comes from the coder wave)
+            if (threadIdx.x == 0 && !(TWO && kind == KIND_PPMD && n > 0) && !rcQueued) k2->outSizes[it] = size;       // (two-wave form: a PPMd member's size comes from the coder wave)
             // per-stream telemetry: [0] model restarts, [1..6] windowed hit path (attempts, windows, symbols, rounds, redone
             // windows, light rounds), [8..14] phase clocks / 64 and [15] the stream's whole time / 64 (FS_WIN_PROFILE builds, else 0)
             const uint32_t t = threadIdx.x;
@@ -902,6 +925,13 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
             else if (it.kind != KIND_QVZ && it.kind - KIND_RC_BASE <= fsrc::M_A8O6) sumRc += it.in_len;
         }
         bool rcWin = sumRc >= 4096u && 4u * sumRc >= sumPpmd;
+#if defined(FS_RC_ON_CODER_WAVE)
+        {   // the coder wave takes the range coder's pass: worth a second wave per stream where a long range-coded stream ends the launch
+            uint32_t maxRc = 0;
+            for (const auto& it : items) if (it.kind != KIND_PPMD && it.kind != KIND_QVZ && it.kind - KIND_RC_BASE <= fsrc::M_A8O6) maxRc = std::max(maxRc, it.in_len);
+            if (rcWin && maxRc >= (256u << 10) && !getenv("FS_WAVES") && !getenv("FS_TWO_WAVE")) waves = 2u;
+        }
+#endif
         if (const char* rw = getenv("FS_RC_WINDOWS")) rcWin = atoi(rw) != 0;
         if (waves == 3u) { const uint32_t g3 = std::max(1u, std::min(grid, dev->nWaves / 3u)); hipLaunchKernelGGL(fs_encode_streams3, dim3(g3), dim3(192), 0, st, ka); }
         else if (waves == 2u) { const uint32_t g2 = std::max(1u, std::min(grid, dev->nWaves / 2u)); if (rcWin) hipLaunchKernelGGL(fs_encode_streams2_w, dim3(g2), dim3(128), 0, st, ka); else hipLaunchKernelGGL(fs_encode_streams2, dim3(g2), dim3(128), 0, st, ka); }
