@@ -40,7 +40,7 @@ class Stats(C.Structure):
                 ("gather_kernel_ms", C.c_double), ("gather_symbols", C.c_uint64), ("gather_bytes", C.c_uint64),
                 ("matcher_reads", C.c_uint64), ("matcher_call_ms", C.c_double), ("matcher_kernel_ms", C.c_double), ("tokenised_ids", C.c_uint64),
                 ("device_batches", C.c_uint64), ("ppmd_max_restarts", C.c_uint64),
-                ("ppmd_windows_ahead", C.c_uint64), ("ppmd_windows_ahead_in_vain", C.c_uint64), ("stolen_bins", C.c_uint64),
+                ("stolen_bins", C.c_uint64),
                 ("matcher_bases_h2d_bytes", C.c_uint64), ("matcher_unpacked_reads", C.c_uint64)]
 
     def as_dict(self):

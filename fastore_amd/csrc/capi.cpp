@@ -726,7 +726,6 @@ int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out)
     out->matcher_bases_h2d_bytes = ctx->c.matchBasesUp.load(); out->matcher_unpacked_reads = ctx->c.matchUnpackedReads.load();
     out->gather_kernel_ms = ctx->c.timing.gather_ms; out->gather_symbols = ctx->c.timing.gather_symbols; out->gather_bytes = ctx->c.timing.gather_bytes;
     out->rc_symbols = ctx->c.timing.rc_symbols; out->ppmd_restarts = ctx->c.timing.restarts; out->ppmd_max_restarts = ctx->c.timing.max_restarts;
-    out->ppmd_windows_ahead = ctx->c.timing.win[8]; out->ppmd_windows_ahead_in_vain = ctx->c.timing.win[9];       // (-DFS_WIN_PROFILE builds of the kernels keep phase clocks in these two slots instead)
     out->h2d_bytes = ctx->c.timing.h2d_bytes; out->d2h_bytes = ctx->c.timing.d2h_bytes;
     return FSGPU_OK;
 }

@@ -78,8 +78,6 @@ __device__ __forceinline__ KernArgs kernargs()
 
 // TWO: the two-wave form (128-thread workgroups): wave 0 walks the models and queues every PPMd coding step, wave 1 is
 // the coder wave (ppmd_core.h: coder_wave).  Range-coded and QVZ items are coded by wave 0 alone, as in the one-wave form.
-// WAVES = 3: the three-wave form (192-thread workgroups): wave 2 is the window wave, which prepares the windows of the hit path
-// ahead of wave 0's serial walk (ppmd_scout.h).
 // The windowed range coders (rc_core.h) live in kernels of their own (RCWIN: fs_encode_streams_w / fs_encode_streams2_w), taken
 // by launches whose range-coded symbols weigh beside their PPMd symbols (a --reduced or --max library's quality scores), and out of line there.
 // In the kernels every lossless launch takes they cost the PPMd walk: inlined, nine more vector registers and ten more
@@ -116,16 +114,15 @@ __device__ __noinline__ uint32_t rc_serial_out_of_line(uint32_t model, fs_gptr t
 
 template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_streams_body()
 {
-    constexpr bool TWO = WAVES >= 2, THREE = WAVES == 3;
+    constexpr bool TWO = WAVES == 2;
     __shared__ fsppmd::Shared sh;
     static_assert(sizeof(fsppmd::Shared) <= 12800, "above 12 800 bytes of LDS a compute unit holds eleven one-wave workgroups, not twelve (profiles/r03_free_list_heads.txt)");
     uint32_t qTail = 0;
     if (TWO) {
-        if (threadIdx.x == 0) { sh.qTail = 0u; sh.qHead = 0u; sh.qStarts = 0u; sh.qOpened = 0u; if (THREE) fsppmd::scout_init((FS_LDS fsppmd::Shared*)&sh); }
+        if (threadIdx.x == 0) { sh.qTail = 0u; sh.qHead = 0u; sh.qStarts = 0u; sh.qOpened = 0u; }
         __syncthreads();                               // the workgroup's only barrier: from here on the waves go separate ways
         const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         if (wv == 1u) { fsppmd::coder_wave((FS_LDS fsppmd::Shared*)&sh); return; }
-        if (THREE && wv == 2u) { __builtin_amdgcn_s_setprio(2); fsppmd::window_wave((FS_LDS fsppmd::Shared*)&sh); return; }
     }
     // maps == nullptr: exclusive launch (no other kernel in flight), one arena per workgroup index
     uint32_t slot = blockIdx.x, xcc = 0, word = 0, bit = 0;
@@ -187,7 +184,7 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
         const uint64_t tStream = FS_PROF_NOW();
         if (kind == KIND_PPMD) {
             if (n > 0) {
-                if (TWO) { KernArgs k3 = kernargs(); (void)fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs, true, (FS_GLOBAL uint32_t*)(k3->outSizes + it), qTail, &qTail, THREE); }
+                if (TWO) { KernArgs k3 = kernargs(); (void)fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs, true, (FS_GLOBAL uint32_t*)(k3->outSizes + it), qTail, &qTail); }
                 else size = fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs);
             }
         } else if (kind == KIND_QVZ) {
@@ -224,17 +221,12 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
 #endif
                 else if (t >= 8u && t < 15u) v = sh.winStats[t];
                 else if (t == 15u) v = (uint32_t)((FS_PROF_NOW() - tStream) >> 6);
-#if !defined(FS_WIN_PROFILE) && !defined(FS_SER_PROFILE)
-                if (THREE && t == 8u) v = sh.wxStats[0];                  // windows prepared ahead of the serial walk and used
-                if (THREE && t == 9u) v = sh.wxStats[1] + sh.wxStats[2];    // prepared in vain (start lane unusable, or the check failed)
-#endif
             }
             if (t == 0u) v = rs;
             k2->restarts[16u * it + t] = v;
         }
         FS_WAVE_SYNC();
     }
-    if (THREE) fsppmd::scout_send_exit((FS_LDS fsppmd::Shared*)&sh);
     if (TWO) fsppmd::cq_send_exit((FS_LDS fsppmd::Shared*)&sh, qTail);
     if (useMaps && threadIdx.x == 0) {
         KernArgs k = kernargs();
@@ -249,8 +241,6 @@ __global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams(EncodeArg
 // off the time of a lone long stream against the 170 of three per SIMD, profiles/r02_qq_two_waves_per_simd.txt; the one-wave
 // form codes the slices of short streams, where the number of resident waves counts)
 __global__ __launch_bounds__(128, 2) void fs_encode_streams2(EncodeArgs /* read through kernargs() */) { encode_streams_body<2>(); }
-// (the three-wave form: serial wave, coder wave, window wave -- for launches whose longest stream decides the step)
-__global__ __launch_bounds__(192, 2) void fs_encode_streams3(EncodeArgs /* read through kernargs() */) { encode_streams_body<3>(); }
 // the same two forms with the windowed range coders (launches with a long range-coded stream)
 __global__ __launch_bounds__(64, kWavesPerSimd) void fs_encode_streams_w(EncodeArgs /* read through kernargs() */) { encode_streams_body<1, true>(); }
 __global__ __launch_bounds__(128, 2) void fs_encode_streams2_w(EncodeArgs /* read through kernargs() */) { encode_streams_body<2, true>(); }
@@ -907,14 +897,12 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         ka.nItems = nRest; ka.longLen = longLen; ka.slotsPerXcc = pool->slotsPerXcc; ka.pad = 0;
         // two-wave form where the step is bound by its longest PPMd stream (the coder runs beside the model walk: ~1.4x per
         // stream, but a stream takes two wave slots); FS_TWO_WAVE=0/1 forces either form
-        // (FS_WAVES=1/2/3 forces a form; FS_TWO_WAVE=0/1 is the older switch between the first two.  The three-wave form --
-        // windows prepared by a wave of their own ahead of the serial walk, ppmd_scout.h -- is bit-exact and tested, but as
-        // measured in round 3 it does not yet beat the two-wave form on a lone 7 M-symbol stream (1.10 s against 0.97 s:
-        // 44 % of the windows prepared ahead cannot be used and are prepared again while the serial wave waits,
-        // profiles/r03_three_wave_*.txt), so it stays opt-in.)
+        // (FS_WAVES=1/2 forces a form; FS_TWO_WAVE=0/1 is the older switch.  Round 3's three-wave form -- windows prepared by a
+        // wave of their own ahead of the serial walk -- was bit-exact and slower, 1.10 s against 0.97 s on a lone 7 M-symbol
+        // stream, and left the tree in round 4; its measurements stay in profiles/r03_three_wave_*.txt.)
         uint32_t waves = maxLen >= (256u << 10) ? 2u : 1u;
         if (const char* tw = getenv("FS_TWO_WAVE")) waves = atoi(tw) != 0 ? 2u : 1u;
-        if (const char* tw = getenv("FS_WAVES")) waves = (uint32_t)std::max(1, std::min(3, atoi(tw)));
+        if (const char* tw = getenv("FS_WAVES")) waves = (uint32_t)std::max(1, std::min(2, atoi(tw)));
         // Launches whose range-coded symbols (small alphabets: the models with a windowed form) weigh beside their PPMd symbols
         // -- the quality scores of a --reduced or --max library -- take the kernels with the windowed coders.  A lossless
         // launch (flags and letters: a few per cent of its PPMd symbols) keeps the kernels it had: with a plain length
@@ -933,8 +921,7 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         }
 #endif
         if (const char* rw = getenv("FS_RC_WINDOWS")) rcWin = atoi(rw) != 0;
-        if (waves == 3u) { const uint32_t g3 = std::max(1u, std::min(grid, dev->nWaves / 3u)); hipLaunchKernelGGL(fs_encode_streams3, dim3(g3), dim3(192), 0, st, ka); }
-        else if (waves == 2u) { const uint32_t g2 = std::max(1u, std::min(grid, dev->nWaves / 2u)); if (rcWin) hipLaunchKernelGGL(fs_encode_streams2_w, dim3(g2), dim3(128), 0, st, ka); else hipLaunchKernelGGL(fs_encode_streams2, dim3(g2), dim3(128), 0, st, ka); }
+        if (waves == 2u) { const uint32_t g2 = std::max(1u, std::min(grid, dev->nWaves / 2u)); if (rcWin) hipLaunchKernelGGL(fs_encode_streams2_w, dim3(g2), dim3(128), 0, st, ka); else hipLaunchKernelGGL(fs_encode_streams2, dim3(g2), dim3(128), 0, st, ka); }
         else if (rcWin) hipLaunchKernelGGL(fs_encode_streams_w, dim3(grid), dim3(64), 0, st, ka);
         else hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, ka);
         HIP_TRY(hipGetLastError());

@@ -64,7 +64,7 @@ struct Shared {
     uint8_t CharMask[256];
     uint8_t QT[260];             // QTable, tabulated once per wave
     uint32_t GlueCount, GlueCount1, restarts;   // touched only by the allocator's rare paths / model restarts: kept out of the registers
-    // the sub-allocator's free-list heads (BList[0..N_INDEXES] + one scratch head) of the two- and three-wave forms: first block of each
+    // the sub-allocator's free-list heads (BList[0..N_INDEXES] + one scratch head) of the two-wave form: first block of each
     // list, 0 = empty (blk_head).  The heads' Stamp counters (SubAlloc.hpp:41-55) are never read by var.J's allocator and are not kept.
     uint32_t blHead[N_INDEXES + 2];
     uint32_t winA[128], winM[128], winCut;      // [64..127]: spare slots for lanes that have nothing to store in a round
@@ -79,14 +79,6 @@ struct Shared {
     uint32_t qBox[2][5];          // qOutLo, qOutHi, qOutCap, qSizeLo, qSizeHi
     uint32_t qStarts;             // written by the coder wave
     uint32_t qOpened;             // model wave only: streams it has started in this workgroup
-    // three-wave form (ppmd_scout.h): the serial wave's requests and forecasts, the window wave's replies
-    uint32_t wqSeq, wq[16], wqT[16];           // request number, its words (wq[WQ_NT] = how many of wqT count), the full-order contexts the last episode started in or made
-    uint32_t whSeq, whPos;                     // forecast for request number whSeq: where the episode should end
-    uint32_t wsDrained;                        // the serial wave's stores before request number wsDrained are complete
-    uint32_t wrSeq, wr[8];                     // reply number, its words
-    uint32_t wrDrained;                        // the window wave's stores for every reply up to this number are complete
-    uint32_t wsNewStream, wsRestartsSeen;      // serial wave only
-    uint32_t wxStats[4];                       // (per stream) windows prepared ahead and used / start lanes that could not be used / prepared in vain / solved again
     // (LDS per workgroup stays below 12 800 bytes: above it a compute unit holds eleven one-wave workgroups instead of twelve --
     // measured as 3 072 equal streams taking two rounds instead of one, profiles/r03_free_list_heads.txt)
     uint32_t winStats[16];
@@ -111,12 +103,14 @@ struct Coder {
     uint32_t queued, qTail, qHeadSeen;   // queued != 0: every coding step goes to the coder wave through sh->qA/qM (this wave never reads low/range)
     uint32_t pfCtx; CtxRaw pf;     // record of the next symbol's first context, requested ahead of this symbol's stores (0 = none)
     uint32_t inAhead;              // windowed path: the input has been pulled into the cache up to here
-    uint32_t three;                // three-wave form: the windows are another wave's work (ppmd_scout.h)
     uint32_t ldsHeads;             // the sub-allocator's list heads live in LDS (else behind the heap)
-    uint32_t wSeq, wHintDue;       // three-wave form, serial wave: requests posted so far; the forecast of the running episode is still to be made
 };
 
-#define HP(ix) (m.hb + (ix))
+#if defined(FS_HEAP_STATS)      // design study (tools/heap_locality.cpp, host emulation only): which heap addresses the walk touches
+  #define HP(ix) (m.hb + fs_heap_stat(ix))
+#else
+  #define HP(ix) (m.hb + (ix))
+#endif
 // PPM_CONTEXT: NumStats@0 Flags@1 SummFreq@2 iStats@4 iSuffix@8 ; oneState = STATE at +2
 #define C_NS(c) fs_ld8(HP(c))
 #define C_NS_SET(c, v) fs_st8(HP(c), (v))
@@ -199,7 +193,7 @@ FS_DEV void fs_reload(Coder& m) { if (m.FoundState) { const St t = st_load(m, m.
 
 // ---------------- sub-allocator ----------------
 // (list number i: BLK_NODE::remove / insert / avail of SubAlloc.hpp:41-55.  The head -- first block of the list, 0 = empty -- lives
-// in LDS in the forms that walk single long streams (m.ldsHeads: two and three waves), behind the heap in HBM in the one-wave
+// in LDS in the form that walks single long streams (m.ldsHeads: two waves), behind the heap in HBM in the one-wave
 // form: measured, profiles/r03_free_list_heads.txt -- a lone 7 M-symbol stream 976 -> 941 ms with the heads in LDS.  The one-wave
 // form was first thought to lose by them (3 072 streams side by side 6.35 -> 4.43 G symbols/s); that loss was the workgroup's LDS
 // passing 12 800 bytes, see Shared, and is gone at 12 796 bytes: 6.60 G symbols/s.)
@@ -389,9 +383,6 @@ FS_DEV void cq_send_exit(FS_LDS Shared* sh, uint32_t qTail)
 FS_DEV void cq_push(Coder&, uint32_t, uint32_t) {}
 FS_DEV void cq_send_exit(FS_LDS Shared*, uint32_t) {}
 FS_DEV void coder_wave(FS_LDS Shared*) {}
-FS_DEV void scout_init(FS_LDS Shared*) {}
-FS_DEV void window_wave(FS_LDS Shared*) {}
-FS_DEV void scout_send_exit(FS_LDS Shared*) {}
 #endif
 
 // after a coding step (Model.cpp:569, 580)
@@ -501,17 +492,6 @@ FS_DEV Hit find_in(Coder& m, const Ctx& pc, uint32_t sym)
     }
 }
 
-// three-wave form (ppmd_scout.h): a context made by the serial walk did not exist when the window wave fetched for the window
-// it is preparing -- whatever that wave read at its address (a hint left by an earlier stream or model may name it) is not
-// this context.  The serial wave lists it with the contexts its episode has rewritten.
-#if FS_WIDE
-FS_DEV void scout_touch(Coder& m, uint32_t c);
-FS_DEV bool scout_lists_back(Coder& m);
-FS_DEV void scout_wait_lists_back(Coder& m);
-  #define FS_SCOUT_CREATED(m, c) do { if ((m).three) scout_touch(m, c); } while (0)
-#else
-  #define FS_SCOUT_CREATED(m, c) ((void)0)
-#endif
 // CreateSuccessors (Model.cpp:282-337).  p/pSucc: state to start from in the suffix of pc (0 = none) and its successor.
 // haveRecs: pcRec / sufRec are register copies of the records of pc and (when p != 0) of its suffix
 FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc, uint32_t pc, uint32_t fsSym, uint32_t fsSucc,
@@ -567,7 +547,6 @@ FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc
         const uint32_t pc1 = AllocContext(m);
         if (!pc1) return 0;
         fs_st32(HP(pc1), w0); fs_st32(HP(pc1) + 4, iUpBranch + 1u); fs_st32(HP(pc1) + 8, pc);
-        FS_SCOUT_CREATED(m, pc1);
         S_SUCC_SET(ps[--pps], pc = pc1);
     } while (pps != 0);
     return pc;
@@ -824,9 +803,6 @@ FS_DEV void UpdateModel(Coder& m, uint32_t MinContext, const Ctx& mcMin, bool ha
 FS_DEV void prefetch_successor(Coder& m, uint32_t c, uint32_t succ)
 {
     m.pfCtx = 0;
-#if FS_WIDE
-    if (m.three && !scout_lists_back(m)) return;        // (three-wave form: the window wave may still be writing that context's list back)
-#endif
     if (!m.OrderFall && succ >= m.UnitsStart && succ != c) { m.pf = ctx_issue(m, succ); m.pfCtx = succ; }
 }
 
@@ -1010,7 +986,6 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
 
 #if FS_WIDE
 #include "ppmd_window.h"
-#include "ppmd_scout.h"
 #endif
 
 // Encode one member.  `arena` = ARENA_BYTES of 16-byte aligned scratch (content irrelevant),
@@ -1018,10 +993,9 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
 // queued (64-lane builds): the caller runs coder_wave() on a second wavefront of the workgroup; the member's size then
 // goes to *sizeOut from there and the return value is 0.
 FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uint32_t n, fs_gptr out, uint32_t outCap,
-                              uint32_t* restartsOut, bool queued = false, FS_GLOBAL uint32_t* sizeOut = nullptr, uint32_t qTail = 0, uint32_t* qTailOut = nullptr, bool three = false)
+                              uint32_t* restartsOut, bool queued = false, FS_GLOBAL uint32_t* sizeOut = nullptr, uint32_t qTail = 0, uint32_t* qTailOut = nullptr)
 {
     Coder m;
-    m.three = three ? 1u : 0u; m.wSeq = 0u; m.wHintDue = 0u;
     m.ldsHeads = queued ? 1u : 0u;
     m.hb = arena - 1; m.sh = sh; m.out = out; m.outCap = outCap; m.outPos = 0; sh->restarts = 0;
     // (nothing is assumed about how far the coder wave has come with the stream before: the first push looks.  `qHeadSeen = qTail`
@@ -1035,9 +1009,6 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
     for (uint32_t i = (uint32_t)FS_LANE(); i < 8u; i += FS_WAVE) sh->serStats[i] = 0u;
 #endif
     for (uint32_t i = (uint32_t)FS_LANE(); i < 260u; i += FS_WAVE) sh->QT[i] = (uint8_t)QTable(i);
-#if FS_WIDE
-    if (m.three) scout_begin_stream(m);
-#endif
     // zero the 64-byte guard behind the heap: GlueFreeBlocks may read one stamp past the end
     for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) *(fs_gptr32)(arena + SA_SIZE + 4u * i) = 0u;
     FS_WAVE_SYNC();
@@ -1081,7 +1052,7 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
                 uint64_t tW = FS_PROF_NOW();
 #endif
                 const uint32_t penaltyIfNone = winPenalty + 1u, skipIfNone = penaltyIfNone <= 3u ? 1u : (penaltyIfNone >= 9u ? 64u : 1u << (penaltyIfNone - 3u));
-                const uint32_t done = m.three ? scout_window(m, in, n, FS_UNI(pos), FS_UNI(MinContext), hist, skipIfNone) : window_step(m, in, n, FS_UNI(pos), FS_UNI(MinContext), hist);
+                const uint32_t done = window_step(m, in, n, FS_UNI(pos), FS_UNI(MinContext), hist);
 #if defined(FS_SER_PROFILE)
                 if (done == 0u) FS_PROF_ACC(m.sh->serStats[4], tW);
 #endif
@@ -1125,16 +1096,9 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
         m.MaxContext = FS_UNI(m.MaxContext); m.BSumm = (int32_t)FS_UNI(m.BSumm);
         // first context of the symbol: still in registers (a context that succeeded itself), requested during the
         // previous symbol, or fetched now
-#if FS_WIDE
-        // three-wave form: a full-order context other than the one the reply named may belong to the window whose lists are on their way back
-        if (m.three && windows && FS_UNI((uint32_t)m.OrderFall) == 0u) scout_wait_lists_back(m);
-#endif
         if (m.pfCtx == MinContext) mc = ctx_finish(m.pf);
         else if (!(FS_UNI(keep) && MinContext == prevCtx)) mc = ctx_load(m, MinContext);
         m.pfCtx = 0; keep = 0; prevCtx = MinContext; sufCtx = 0;
-#if FS_WIDE
-        if (m.three && windows && FS_UNI((uint32_t)m.OrderFall) == 0u) scout_touch(m, MinContext);      // this symbol's episode rewrites the context it starts in
-#endif
         mc.a = FS_UNI(mc.a); mc.w1 = FS_UNI(mc.w1); mc.suff = FS_UNI(mc.suff);
         FS_PATH(g_path[0]);
 #if defined(FS_SER_PROFILE)
@@ -1161,9 +1125,6 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
             if (m.FoundState) FS_PATH(g_path[6]);
         }
         if (FS_UNI(stop)) break;
-#if FS_WIDE
-        if (m.three && windows) scout_forecast(m, FS_UNI(pos), FS_UNI(winSkip));
-#endif
         FS_PROF_ACC(m.sh->winStats[6], tSer);                          // escapes: suffix walk + encodeSymbol2 rounds
         const uint32_t succ = FS_UNI(m.fsSucc);
         FS_SYMHOOK(prevCtx, MinContext, mc, m, succ);

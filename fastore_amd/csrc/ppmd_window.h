@@ -57,12 +57,12 @@ FS_DEV uint32_t recip_div(uint32_t n, uint32_t mul, uint32_t l) { const uint32_t
 // ---- packed state list of one context in a lane: N states as bytes, no register arrays indexed at run time ----
 // S = symbols, F = frequencies (state j in byte j of the word), P = nibble j names the original slot whose successor field
 // belongs to the state now at place j (the 32-bit successors themselves never move: they are gathered through P when the
-// list is written back).  N = 8: 64-bit words (contexts of up to eight states).  N = 4: 32-bit words -- every context of the
-// window has at most four states (decided wave-wide when the records are in: the usual case on quality data, where a
-// context rarely has more successors than that): half the instructions of everything below, half the list fetch.
+// list is written back).  N = 8: 64-bit words (contexts of up to eight states).  (Round 3 also had 32-bit forms for windows
+// whose contexts all have at most four states: half the ALU work, and SLOWER -- 1 012 ms against 976 ms on a lone 7 M-symbol
+// stream, profiles/r03_narrow_windows.txt: the window is bound by its chain of LDS and ballot round trips, and the extra
+// wave-wide vote costs more than the halved arithmetic saves.  They left the tree in round 4.)
 template <int N> struct PackedT;
 template <> struct PackedT<8> { typedef uint64_t W; uint64_t S, F; uint32_t P; };
-template <> struct PackedT<4> { typedef uint32_t W; uint32_t S, F; uint32_t P; };
 typedef PackedT<8> Packed;
 
 FS_DEV uint32_t fs_sum_bytes(uint32_t x)
@@ -205,22 +205,15 @@ template <int N> FS_DEV bool packed_rescale_quick(PackedT<N>& c, uint32_t ns, ui
 
 // ---- a window in three steps: fetch (per position, independent of where the window starts), solve (which positions form
 // the window, who owns which context, every position's price), commit (lists and records back, the prices to the coder).
-// One wave can do all three in a row (window_step below: the one- and two-wave forms), or a wave of its own can fetch and
-// solve AHEAD of the serial walk and commit once the walk has caught up (ppmd_scout.h: the three-wave form).
+// One wave does all three in a row (window_step below).
 //
 // Window = the lanes [s, E): lane i holds position base + i.  Positions that share a context are taken by the lane of the
 // FIRST of them (the owner): it keeps the context's states in its registers and walks its positions in stream order, one
 // per round, so the rounds of a window are as many as the most popular context has positions.
-// (-DFS_SCOUT_PROFILE builds use the phase slots for the window wave's own timeline: ppmd_scout.h)
-#if defined(FS_SCOUT_PROFILE)
-  #define FS_PROF_ACC_W(w, t0) ((void)(t0))
-#else
-  #define FS_PROF_ACC_W(w, t0) FS_PROF_ACC(w, t0)
-#endif
+#define FS_PROF_ACC_W(w, t0) FS_PROF_ACC(w, t0)
 struct WinHead {                   // per lane: the position, its context's record
     uint32_t key, sym, addr, r0, stats, ns, la; bool ok;
     uint32_t W;                     // positions left in the stream from `base` on, at most 64
-    bool narrow;                    // (wave-uniform) every usable context has at most four states: the N = 4 forms below will do
 };
 template <int N> struct WinFetch : WinHead {   // ... and its state list, as fetched
     PackedT<N> c; uint32_t sc[N];   // symbols, frequencies, successors
@@ -261,15 +254,6 @@ FS_DEV void win_fetch_head(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, uin
     const uint32_t ns = r0 & 0xFFu, stats = r1;
     ok = ok && ns >= 1u && ns <= WIN_MAX_NS && stats >= unitsStart && stats <= SA_SIZE - 47u && ((stats - 1u) & 3u) == 0u;
     f.r0 = r0; f.ns = ns; f.stats = stats; f.ok = ok; f.la = la;
-    // (FS_WIN_NARROW: the 32-bit forms for windows whose contexts all have at most four states.  Measured in round 3 on a lone
-    // 7 M-symbol quality stream: 1 012 ms against 976 ms without -- half the ALU work of the rounds buys nothing, the window is
-    // bound by its chain of LDS and ballot round trips, and the extra vote costs; profiles/r03_narrow_windows.txt.  Kept for
-    // the lock-step emulation's tests, off in the product.)
-#if defined(FS_WIN_NARROW) && FS_WIN_NARROW
-    f.narrow = fs_ballot(ok && ns > 3u) == 0ull;
-#else
-    f.narrow = false;
-#endif
 }
 template <int N> FS_DEV void win_fetch_list(Coder& m, const WinHead& h, WinFetch<N>& f)
 {
@@ -301,18 +285,10 @@ template <int N> FS_DEV void win_fetch_list(Coder& m, const WinHead& h, WinFetch
     const uint32_t prevSucc = fs_bperm(succ, (lane + 63u) & 63u);
     f.link = lane == 0u || h.addr == prevSucc;
 }
-// (both steps with eight-state lists: the three-wave form)
-FS_DEV void win_fetch(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, uint32_t lane0ctx, WinFetch<8>& f)
-{ WinHead h; win_fetch_head(m, in, n, base, lane0ctx, h); win_fetch_list<8>(m, h, f); }
-
 // The window [s, E) of a fetch: E = the first lane from s on that is not a plain hit linked to the lane before it (lane s
 // itself needs no link: its context is known, or is checked by the caller), further shortened where a round finds a
 // position for the serial path (a rescale that drops a state).  Returns E; E <= s: no window.
-// watchSeq != 0 (three-wave form, start lane guessed): should the serial wave's forecast or request number watchSeq turn up
-// meanwhile and name another start lane, the solve is given up (WIN_ABORT) before its expensive part -- the caller solves again.
-enum : uint32_t { WIN_ABORT = 0xFFFFFFFFu };
-FS_DEV uint32_t win_watch(Coder& m, uint32_t watchSeq, uint32_t at);
-template <int N> FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, const WinFetch<N>& f, uint32_t s, WinSolved<N>& o, uint64_t& tp, uint32_t watchSeq = 0u)
+template <int N> FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, uint32_t base, const WinFetch<N>& f, uint32_t s, WinSolved<N>& o, uint64_t& tp)
 {
     typedef typename PackedT<N>::W W;
     const uint32_t lane = (uint32_t)FS_LANE();
@@ -406,7 +382,6 @@ template <int N> FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, ui
         cfSm = sm; cfFirstBad = firstBad; cfKb0 = kb0; cfKb1 = kb1; cfKb2 = kb2;
     }
     if (fs_ballot(inWin && !cfDone) == 0ull) FS_STAT_ADD(m.sh->winStats[5], 1u);     // a window without a single round
-    if (watchSeq != 0u && win_watch(m, watchSeq, base + s) != 0u) return WIN_ABORT;
     // The owners' part, and the rounds.  When a round finds that a position must go to the serial path (a rescale that
     // drops a state), the window ends in front of it -- and only THIS part is done again for the shorter window: the
     // lists, the chain, the context sets and the closed-form prices of the positions that stay do not depend on
@@ -489,8 +464,7 @@ template <int N> FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, ui
                         if (resc) simt_count_quick_rescale();
                     }
 #endif
-                } else if (N == 4) done = packed_rescale<4, N>(c2, ns, kf, summ2, flags2);
-                else done = fs_ballot(resc && ns > 3u) == 0ull ? packed_rescale<4, N>(c2, ns, kf, summ2, flags2) : packed_rescale<(N == 8 ? 8 : 4), N>(c2, ns, kf, summ2, flags2);
+                } else done = fs_ballot(resc && ns > 3u) == 0ull ? packed_rescale<4, N>(c2, ns, kf, summ2, flags2) : packed_rescale<(N == 8 ? 8 : 4), N>(c2, ns, kf, summ2, flags2);
                 if (resc && done) { c = c2; summ = summ2; flags = flags2; }
                 if (resc && !done) cut = true;                     // a state drops out: the serial path takes this symbol
             }
@@ -605,12 +579,11 @@ FS_DEV uint32_t window_step(Coder& m, fs_cgptr in, uint32_t n, uint32_t pos, uin
 {
     uint64_t tp = FS_PROF_NOW(); const uint64_t tEnter = tp;
     WinHead h;
+#if defined(FS_HEAP_STATS)
+    struct InWin { InWin() { fs_heap_stat_window(1); } ~InWin() { fs_heap_stat_window(0); } } inWin_;
+#endif
     win_fetch_head(m, in, n, pos, MinContext, h);
     FS_STAT_ADD(m.sh->winStats[0], 1u);
-    // (wave-uniform: no usable context of these 64 positions has more than four states -- the 32-bit forms)
-#if defined(FS_SIMT_EMU)
-    if (FS_LANE() == 0) simt_count_window_form(h.narrow);
-#endif
-    return FS_UB(h.narrow) ? window_step_n<4>(m, in, n, pos, h, hist, tp, tEnter) : window_step_n<8>(m, in, n, pos, h, hist, tp, tEnter);
+    return window_step_n<8>(m, in, n, pos, h, hist, tp, tEnter);
 }
 #undef FS_CE

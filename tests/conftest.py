@@ -2,6 +2,7 @@ import ctypes
 import os
 import subprocess
 import sys
+import time
 
 import pytest
 
@@ -17,12 +18,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+# The driver gives `pytest -m gpu` 900 s on a fresh box.  The suite is built to end well inside that: every GPU test has a
+# timeout of its own (120 s unless it names another), the kernel-level parity tests run first and the tests that make a library
+# with the live reference's tools run last, and a session clock fails the NEXT test by name once the run has used its budget --
+# a loud failure with a test name in it instead of a silent kill from outside.
+GPU_TEST_TIMEOUT_S = 120
+GPU_SESSION_BUDGET_S = float(os.environ.get("FS_GPU_SESSION_BUDGET_S", "600"))
+_SESSION_T0 = time.monotonic()
+_LATE = ("live_reference", "fresh_librar", "long_streams", "many_batches")
+
+
 def pytest_collection_modifyitems(config, items):
-    # a GPU test that stops (a device call that never returns, a reference tool that dead-locks) is reported with every thread's
-    # stack after fifteen minutes instead of keeping the whole run silent until it is killed from outside
     for it in items:
         if it.get_closest_marker("gpu") and not it.get_closest_marker("timeout"):
-            it.add_marker(pytest.mark.timeout(900, method="thread"))
+            it.add_marker(pytest.mark.timeout(GPU_TEST_TIMEOUT_S, method="thread"))
+    # stable: the order inside each class stays the order of the files
+    items.sort(key=lambda it: 1 if (it.get_closest_marker("gpu") and any(k in it.name for k in _LATE)) else 0)
+
+
+def pytest_runtest_setup(item):
+    if item.get_closest_marker("gpu"):
+        used = time.monotonic() - _SESSION_T0
+        if used > GPU_SESSION_BUDGET_S:
+            pytest.fail("GPU session clock: %.0f s used of a budget of %.0f s before %s -- the suite must finish inside the driver's window"
+                        % (used, GPU_SESSION_BUDGET_S, item.nodeid), pytrace=False)
 
 
 def _make(target_dir, *args):
@@ -105,36 +124,89 @@ def flag_variants():
     return out
 
 
-def ref_pipeline(tmp, name, reads, length, genome, seed, paired, q, threads=8, gen_flags=()):
+C1_FLAGS = ["-r", "-f256", "-c10", "-d8", "-w1024", "-W1024"]          # scripts/fastore_compress.sh:146-148 (the C1 profile's pack flags)
+REF_STAGE_TIMEOUT_S = 60
+
+
+def _ref_stage(argv, threads):
+    """One stage of the live reference under a SHORT timeout.  Its multi-threaded stages are known to dead-lock now and then
+    (its pack at -t64 and, once in a suite run of round 3, at -t16), so a stage that does not finish in a minute is run
+    once more with one worker; a second miss fails the test.  No stage here may wait longer than the test's own timeout."""
+    for t in ([threads, 1] if threads > 1 else [1]):
+        try:
+            subprocess.run([a.replace("@T", str(t)) for a in argv], check=True, timeout=REF_STAGE_TIMEOUT_S, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            return t
+        except subprocess.TimeoutExpired:
+            continue
+    raise RuntimeError("a stage of the reference did not finish in %d s, not even with one worker: %s" % (REF_STAGE_TIMEOUT_S, " ".join(argv[:2])))
+
+
+def ref_pipeline(tmp, name, reads, length, genome, seed, paired, q, threads=4, gen_flags=()):
     """synthetic FASTQ -> fastore_bin -> 3 x fastore_rebin with the REAL reference (C1 profile); returns (binned prefix, pe flags)"""
     gen = os.path.join(ROOT, "build", "gen_fastq")
     if not os.path.exists(gen):
+        os.makedirs(os.path.dirname(gen), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-o", gen, os.path.join(ROOT, "tools", "gen_fastq.cpp")])
     base = os.path.join(tmp, name)
     subprocess.check_call([gen, "--reads", str(reads), "--len", str(length), "--genome", str(genome), "--seed", str(seed), "--out", base] + (["--paired"] if paired else []) + list(gen_flags))
     pe = ["-z"] if paired else []
     inp = base + "_1.fastq" + ((" " + base + "_2.fastq") if paired else "")
-    # (the reference's stages under a timeout: a stage that hangs -- its pack is known to, SURVEY 0.1 -- fails the test instead of stopping the run)
-    subprocess.check_call([REF_DRIVER_GCC, "bin", "-i" + inp, "-o" + base + ".b0", "-t%d" % threads, "-H", "-q%d" % q, "-p8", "-s0", "-b256"] + pe, timeout=900)
+    _ref_stage([REF_DRIVER_GCC, "bin", "-i" + inp, "-o" + base + ".b0", "-t@T", "-H", "-q%d" % q, "-p8", "-s0", "-b256"] + pe, threads)
     prev = base + ".b0"
     for p in (2, 4, 8):
         cur = base + ".b%d" % p
-        subprocess.check_call([REF_DRIVER_GCC, "rebin", "-i" + prev, "-o" + cur, "-t%d" % threads, "-r", "-w1024", "-W1024", "-p%d" % p] + pe, timeout=900)
+        _ref_stage([REF_DRIVER_GCC, "rebin", "-i" + prev, "-o" + cur, "-t@T", "-r", "-w1024", "-W1024", "-p%d" % p] + pe, threads)
+        for e in (".bmeta", ".bdna", ".bqua", ".bhead"):          # the stage before is not read again
+            if os.path.exists(prev + e):
+                os.remove(prev + e)
         prev = cur
     return prev, pe
 
 
-def reference_pack_mt(binned, out, flags, pe, threads):
-    """the live reference's pack with several workers: its multi-threaded pack is known to dead-lock now and then (seen
-    at -t64 and, once in a suite run of round 3, at -t16), so it runs under a timeout and steps down to fewer workers"""
-    for t in [threads] + [x for x in (8, 4, 1) if x < threads]:
-        try:
-            subprocess.run([REF_DRIVER, "pack", "-i" + binned, "-o" + out, "-t%d" % t] + list(flags) + list(pe), check=True, timeout=180 if t > 1 else 1200,
-                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-            return t
-        except subprocess.TimeoutExpired:
-            continue
-    raise RuntimeError("the reference pack did not finish")
+def reference_pack(binned, out, pe, flags=C1_FLAGS, threads=1):
+    """the live reference's pack: -t1 is the archive the product must equal byte for byte; with more workers the blocks
+    come in completion order and are compared by signature (reference_blocks)"""
+    return _ref_stage([REF_DRIVER, "pack", "-i" + binned, "-o" + out, "-t@T"] + list(flags) + list(pe), threads)
+
+
+class RefLibs:
+    """Libraries made by the live reference's tools, ONE copy per session: several tests read the same binned library (and the same
+    reference archive of it), and each costs 5-40 s to make.  Shapes (see `shapes`): a SMALL genome at HIGH coverage gives the bins of
+    a BASELINE-sized library -- tens of thousands of reads, quality streams of several million PPMd symbols -- from a few hundred
+    thousand reads, which the reference's tools bin in seconds (the standard bins of a library are its signatures, and they grow
+    with coverage, not with the genome)."""
+    shapes = {
+        # name: (reads or pairs, genome, seed, paired, quality mode, generator flags)
+        "se_long": (400_000, 6_000, 8, False, 0, ()),            # 39 standard bins, the largest > 30 000 reads = 4.5 M quality symbols
+        "pe_long": (200_000, 6_000, 8, True, 0, ()),             # bins of > 10 000 pairs: both mates in one stream, > 3 M symbols
+        "pe_noisy": (100_000, 2_000, 11, True, 0, ("--noisy-quality",)),  # one bin of > 30 000 pairs of structureless scores: >= 3 model restarts
+    }
+
+    def __init__(self, root):
+        self.root = root; self.libs = {}; self.packs = {}
+
+    def library(self, name, shape=None):
+        if name not in self.libs:
+            reads, genome, seed, paired, q, gen_flags = shape or self.shapes[name]
+            d = os.path.join(self.root, name); os.makedirs(d, exist_ok=True)
+            binned, pe = ref_pipeline(d, "lib", reads, 150, genome, seed, paired, q, gen_flags=gen_flags)
+            self.libs[name] = (binned, pe, d)
+        return self.libs[name]
+
+    def packed(self, name, threads=1):
+        """(prefix of the reference's archive of the library, workers it was written with)"""
+        if name not in self.packs:
+            binned, pe, d = self.library(name)
+            out = os.path.join(d, "ref")
+            self.packs[name] = (out, reference_pack(binned, out, pe, threads=threads))
+        return self.packs[name]
+
+
+@pytest.fixture(scope="session")
+def ref_libs(tmp_path_factory):
+    if not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)):
+        pytest.skip("reference binaries (oracle/_ref) not shipped")
+    return RefLibs(str(tmp_path_factory.mktemp("reflibs")))
 
 
 def reference_blocks(prefix):

@@ -9,29 +9,7 @@
 static std::atomic<unsigned long long> g_quickRescales{0};
 static inline void simt_count_quick_rescale() { g_quickRescales++; }
 extern "C" unsigned long long simt_quick_rescales() { return g_quickRescales.load(); }
-// extra meeting points at the marked sites of the three-wave form (ppmd_scout.h): a wave that passes one lets the other waves
-// run that many steps first, so the serial wave and the window wave meet each other in ever different phases.  The count
-// is a function of (seed, wave, site, how often this lane has been here): every lane of a wave draws the same numbers.
 #include "simt.h"
-static unsigned g_jitterSeed = 0, g_jitterMax = 0;
-static unsigned g_jitterCalls[4][64][4];
-extern "C" void simt_set_jitter(unsigned seed, unsigned maxSteps) { g_jitterSeed = seed; g_jitterMax = maxSteps; }
-static inline void simt_jitter(int site)
-{
-    if (!g_jitterMax) return;
-    const int w = simt::wave() & 3, l = simt::lane();
-    unsigned x = g_jitterSeed * 0x9E3779B1u ^ (unsigned)(w * 7919 + site * 104729) ^ (g_jitterCalls[w][l][site & 3]++ * 0x85EBCA6Bu);
-    x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
-    for (unsigned k = x % (g_jitterMax + 1u); k > 0; --k) simt::barrier();
-}
-static unsigned long long g_windowForms[2];
-static inline void simt_count_window_form(bool narrow) { g_windowForms[narrow ? 1 : 0]++; }
-extern "C" void simt_window_forms(unsigned long long* out) { out[0] = g_windowForms[0]; out[1] = g_windowForms[1]; }
-static unsigned long long g_scoutWhy[8], g_scoutHist[16][16];
-static inline void simt_scout_hist(unsigned a, unsigned g) { if (a < 64) g_scoutHist[a < 15 ? a : 15][g < 15 ? g : 15]++; }
-extern "C" void simt_scout_histogram(unsigned long long* out) { memcpy(out, g_scoutHist, sizeof g_scoutHist); memset(g_scoutHist, 0, sizeof g_scoutHist); }
-static inline void simt_scout_why(int i) { g_scoutWhy[i & 7]++; }
-extern "C" void simt_scout_reasons(unsigned long long* out) { for (int i = 0; i < 8; ++i) { out[i] = g_scoutWhy[i]; g_scoutWhy[i] = 0; } }
 #include "../../fastore_amd/csrc/ppmd_core.h"
 
 // the two-wave form: wave 0 walks the model and queues the coding steps, wave 1 is the coder wave; several streams one
@@ -51,34 +29,6 @@ extern "C" int simt_ppmd_encode_two_waves(int nStreams, const uint8_t* const* in
         }
         fsppmd::cq_send_exit(sh, q);
     });
-    delete sh; free(arena);
-    return 0;
-}
-
-// the three-wave form: wave 0 = serial wave, wave 1 = coder wave, wave 2 = window wave (ppmd_scout.h); several streams one
-// after the other through the same three waves.  stats: windows prepared ahead and used / forecasts unusable / prepared in vain
-extern "C" int simt_ppmd_encode_three_waves(int nStreams, const uint8_t* const* in, const size_t* n, uint8_t* const* out, const size_t* cap, uint32_t* sizes, uint64_t* stats)
-{
-    uint8_t* arena = (uint8_t*)aligned_alloc(64, (fsppmd::ARENA_BYTES + 4096 + 63) & ~63ull);
-    fsppmd::Shared* sh = new fsppmd::Shared;
-    sh->qTail = sh->qHead = 0; sh->qStarts = sh->qOpened = 0;
-    fsppmd::scout_init(sh);
-    memset(g_jitterCalls, 0, sizeof g_jitterCalls);
-    uint64_t win[3] = {0, 0, 0}, ahead[3] = {0, 0, 0};
-    simt::run_waves(3, [&](int wave, int) {
-        if (wave == 1) { fsppmd::coder_wave(sh); return; }
-        if (wave == 2) { fsppmd::window_wave(sh); return; }
-        uint32_t q = 0;
-        for (int s = 0; s < nStreams; ++s) {
-            uint32_t r0 = 0;
-            if (n[s] == 0) { if (simt::lane() == 0) sizes[s] = 0; continue; }
-            fsppmd::encode_member(arena, sh, in[s], (uint32_t)n[s], out[s], (uint32_t)cap[s], &r0, true, &sizes[s], q, &q, true);
-            if (simt::lane() == 0) { win[0] += sh->winStats[1]; win[1] += sh->winStats[2]; for (int i = 0; i < 3; ++i) ahead[i] += sh->wxStats[i]; }   // (per stream, as the kernel reports them)
-        }
-        fsppmd::scout_send_exit(sh);
-        fsppmd::cq_send_exit(sh, q);
-    });
-    if (stats) { stats[0] = ahead[0]; stats[1] = ahead[1]; stats[2] = ahead[2]; stats[3] = win[0]; stats[4] = win[1]; }
     delete sh; free(arena);
     return 0;
 }

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import check_compress_bins_seam, GOLDEN, MODELS, REF_DRIVER, REF_DRIVER_GCC, ROOT, VECTORS, flag_variants, knobs_from_flags, manifest, ref_pipeline, reference_pack_mt, oracle_ppmd, oracle_qvz, oracle_rc
+from conftest import RefLibs, check_compress_bins_seam, GOLDEN, MODELS, REF_DRIVER, REF_DRIVER_GCC, ROOT, VECTORS, flag_variants, knobs_from_flags, manifest, ref_pipeline, reference_pack, reference_blocks, C1_FLAGS, oracle_ppmd, oracle_qvz, oracle_rc
 
 import sys
 sys.path.insert(0, GOLDEN)
@@ -63,10 +63,9 @@ def test_ppmd_device_matches_oracle_many_ragged_streams(packer, oracle):
         assert g == oracle_ppmd(oracle, s)
 
 
-@pytest.mark.parametrize("waves", [1, 2, 3])
+@pytest.mark.parametrize("waves", [1, 2])
 def test_ppmd_device_every_kernel_form_matches_the_oracle(packer, oracle, monkeypatch, waves):
-    # the same streams through the one-wave form, the two-wave form (model + coder wave) and the three-wave form (serial wave,
-    # coder wave, window wave: windows prepared ahead of the serial walk, ppmd_scout.h): long quality streams with read
+    # the same streams through the one-wave form and the two-wave form (model wave + coder wave): long quality streams with read
     # boundaries (episodes between windows), noise (no windows at all, model restarts), short and ragged streams that
     # follow each other through one workgroup (the hand-over between streams), an empty one
     monkeypatch.setenv("FS_WAVES", str(waves))
@@ -83,12 +82,13 @@ def test_ppmd_device_every_kernel_form_matches_the_oracle(packer, oracle, monkey
     for i in range(120):
         n = int(rng.integers(1, 9000))
         streams.append(quality(150 * (n // 150 + 1), 150)[:n] if i % 3 else rng.integers(0, 9, n).astype(np.uint8).tobytes())
+    # the same stream again and again through one arena: the hint table the stream before left names, at every key, the address
+    # the context of that key gets AGAIN (stale hints must be proven wrong by the chain, never believed)
+    again = quality(150 * 400, 150)
+    streams += [again, again, again]
     got = packer.ppmd_encode(streams)
     for i, (s, g) in enumerate(zip(streams, got)):
         assert g == (oracle_ppmd(oracle, s) if s else b""), (waves, i, len(s))
-    if waves == 3:
-        st = packer.stats()
-        assert st["ppmd_windows_ahead"] > 10_000, st          # windows really were prepared ahead and used
 
 
 def test_ppmd_device_model_restart_and_allocator_exhaustion(packer, oracle):
@@ -190,15 +190,14 @@ def test_gpu_pack_equals_live_reference_on_fresh_library(tmp_path, paired, q, re
     import fastore_amd
     t = str(tmp_path)
     binned, pe = ref_pipeline(t, "lib", reads, 150, reads * 150 // 50, 77 + q + int(paired), paired, q)
-    flags = ["-r", "-f256", "-c10", "-d8", "-w1024", "-W1024"]
-    subprocess.check_call([REF_DRIVER, "pack", "-i" + binned, "-o" + os.path.join(t, "ref"), "-t1"] + flags + pe)
+    reference_pack(binned, os.path.join(t, "ref"), pe)
     with fastore_amd.Packer(device_id=0) as p:
         st = p.pack_file(binned, os.path.join(t, "gpu"))
     assert_same_archive(os.path.join(t, "gpu"), os.path.join(t, "ref"))
     assert st["bins"] >= 10
     # independent check: the reference DECODER accepts our archive and returns the same multiset of reads
     outs = [os.path.join(t, "dec_1.fastq")] + ([os.path.join(t, "dec_2.fastq")] if paired else [])
-    subprocess.check_call([REF_DRIVER, "unpack", "-i" + os.path.join(t, "gpu"), "-o" + " ".join(outs), "-t1"] + pe)
+    subprocess.check_call([REF_DRIVER, "unpack", "-i" + os.path.join(t, "gpu"), "-o" + " ".join(outs), "-t1"] + pe, timeout=60)
     def records(path):
         lines = open(path, "rb").read().split(b"\n")
         return sorted(zip(lines[0::4], lines[1::4], lines[3::4]))
@@ -261,40 +260,34 @@ def test_gpu_libraries_larger_than_a_device_batch(tmp_path):
             assert open(o + ".cdata", "rb").read() == open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
 
 
-@pytest.mark.skipif(not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)), reason="reference binaries (oracle/_ref) not shipped")
-@pytest.mark.parametrize("paired,reads", [(False, 5_000_000), (True, 1_500_000)])
-def test_gpu_pack_equals_live_reference_on_a_library_with_long_streams(tmp_path, paired, reads):
-    # BASELINE-shaped bins: a 5 M-read SE library has bins of > 20 000 reads (quality streams of > 3 M PPMd symbols), a
-    # 1.5 M-pair PE library quality streams of > 2 M symbols (both mates in one stream) -- the tail of a device step.
-    # The reference runs multi-threaded here (its block order then differs), so blocks are compared by signature and the
-    # product's own order is checked against the -t1 rule (block 0, then ascending signature).
-    import fastore_amd
-    from conftest import reference_blocks
+def _archive_signatures(prefix):
+    import struct
+    m = open(prefix + ".cmeta", "rb").read(); foff, _ = struct.unpack_from("<QQ", m, 0); n, = struct.unpack_from("<I", m, foff)
+    return list(struct.unpack_from("<%dI" % n, m, foff + 4 + 8 * n))
+
+
+@pytest.mark.parametrize("lib", ["se_long", "pe_long"])
+def test_gpu_pack_equals_live_reference_on_a_library_with_long_streams(tmp_path, ref_libs, lib):
+    # BASELINE-shaped bins from a small library (conftest.RefLibs: a 6 kbp genome at 10 000-fold coverage): standard bins of > 25 000
+    # reads (quality streams of > 3.5 M PPMd symbols) single-end, > 8 000 pairs (both mates in one stream: > 2.4 M symbols)
+    # paired-end -- the tail of a device step.  The reference packs with one worker, so the archives are compared whole.
+    import fastore_amd, struct
+    binned, pe, _ = ref_libs.library(lib)
+    ref, _ = ref_libs.packed(lib)
     t = str(tmp_path)
-    cores = len(os.sched_getaffinity(0))
-    binned, pe = ref_pipeline(t, "big", reads, 150, (2 if paired else 1) * reads * 150 // 50, 8, paired, 0, threads=min(16, cores))
-    for f in os.listdir(t):
-        if f.endswith(".fastq") or ".b0." in f or ".b2." in f or ".b4." in f:
-            os.remove(os.path.join(t, f))
-    flags = ["-r", "-f256", "-c10", "-d8", "-w1024", "-W1024"]
-    reference_pack_mt(binned, os.path.join(t, "ref"), flags, pe, min(16, cores))
     with fastore_amd.Packer(device_id=0) as p:
         st = p.pack_file(binned, os.path.join(t, "gpu"))
-    want = reference_blocks(os.path.join(t, "ref")); got = reference_blocks(os.path.join(t, "gpu"))
-    assert sorted(want) == sorted(got)
-    for sg in want:
-        assert got[sg] == want[sg], "block of signature %d differs" % sg
-    import struct
-    m = open(os.path.join(t, "gpu.cmeta"), "rb").read(); foff, _ = struct.unpack_from("<QQ", m, 0); n, = struct.unpack_from("<I", m, foff)
-    sigs = list(struct.unpack_from("<%dI" % n, m, foff + 4 + 8 * n))
+    assert_same_archive(os.path.join(t, "gpu"), ref)
+    got = reference_blocks(os.path.join(t, "gpu"))
+    sigs = _archive_signatures(os.path.join(t, "gpu"))
     assert sigs[0] == max(sigs) and sigs[1:] == sorted(sigs[1:])
     # the longest quality stream of the library: records of the largest standard block x 150 (x 2 mates)
     biggest = max(struct.unpack_from(">Q", b, 4)[0] for sg, b in got.items() if sg != max(sigs))
-    assert biggest * 150 * (2 if paired else 1) > (2 << 20), biggest
+    assert biggest * 150 * (2 if pe else 1) > (2 << 20), biggest
     assert st["host_coded_symbols"] == 0          # every standard-bin stream above was coded on the device
     # the same library through the CLI: a ONE-SHOT context (lanes and staging buffers made beside the front end, matcher
     # lanes by their threads, pageable staging, archive pages reserved ahead, no teardown) must write the same archive
-    subprocess.check_call([fastore_amd.PACK_CLI, "e", "-i" + binned, "-o" + os.path.join(t, "cli")] + flags + pe)
+    subprocess.check_call([fastore_amd.PACK_CLI, "e", "-i" + binned, "-o" + os.path.join(t, "cli")] + C1_FLAGS + pe, timeout=90)
     for e in (".cdata", ".cmeta"):
         assert open(os.path.join(t, "cli" + e), "rb").read() == open(os.path.join(t, "gpu" + e), "rb").read(), e
 
@@ -313,37 +306,24 @@ def test_gpu_library_of_several_batches_goes_through_two_pipelines(tmp_path, mon
         assert open(str(tmp_path / ("s" + split)) + ".cdata", "rb").read() == ref, split
 
 
-@pytest.mark.skipif(not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)), reason="reference binaries (oracle/_ref) not shipped")
-def test_gpu_pack_many_batches_and_model_restarts_inside_standard_bins(tmp_path):
-    # What a library of BASELINE configs[2]'s size does to the pipeline, at a size a test can afford: 3.5 M pairs with
-    # bins of > 15 000 pairs, a device batch budget that cuts the standard bins into >= 3 batches (blocks of the earlier
-    # batches wait behind block 0), and quality scores without structure (gen_fastq --noisy-quality), so that the PPMd
-    # model of a standard bin's quality stream outgrows its heap and restarts >= 3 times inside ONE stream
-    # (ppmd/Model.cpp:109-140 + the sub-allocator's exhaustion paths, SubAlloc.hpp:98-163).  Every block against the
-    # live reference's block of the same signature.
+def test_gpu_pack_many_batches_and_model_restarts_inside_standard_bins(tmp_path, ref_libs):
+    # What a library of BASELINE configs[2]'s size does to the pipeline, at a size a test can afford (conftest.RefLibs "pe_noisy":
+    # 100 000 pairs over a 2 kbp genome): a bin of > 30 000 pairs, a device batch budget that cuts the standard bins into >= 3
+    # batches (blocks of the earlier batches wait behind block 0), and quality scores without structure (gen_fastq
+    # --noisy-quality), so that the PPMd model of a standard bin's quality stream outgrows its heap and restarts >= 3 times inside
+    # ONE stream (ppmd/Model.cpp:109-140 + the sub-allocator's exhaustion paths, SubAlloc.hpp:98-163).  The whole archive against
+    # the live reference's.
     import fastore_amd
-    from conftest import reference_blocks
+    binned, pe, _ = ref_libs.library("pe_noisy")
+    ref, _ = ref_libs.packed("pe_noisy")
     t = str(tmp_path)
-    cores = len(os.sched_getaffinity(0))
-    pairs = 3_500_000
-    binned, pe = ref_pipeline(t, "many", pairs, 150, 2 * pairs * 150 // 50, 11, True, 0, threads=min(16, cores), gen_flags=["--noisy-quality"])
-    for f in os.listdir(t):
-        if f.endswith(".fastq") or ".b0." in f or ".b2." in f or ".b4." in f:
-            os.remove(os.path.join(t, f))
-    flags = ["-r", "-f256", "-c10", "-d8", "-w1024", "-W1024"]
-    reference_pack_mt(binned, os.path.join(t, "ref"), flags, pe, min(16, cores))
-    with fastore_amd.Packer(device_id=0, batch_bases=250_000_000) as p:
+    with fastore_amd.Packer(device_id=0, batch_bases=12_000_000) as p:
         st = p.pack_file(binned, os.path.join(t, "gpu"))
-    want = reference_blocks(os.path.join(t, "ref")); got = reference_blocks(os.path.join(t, "gpu"))
-    assert sorted(want) == sorted(got)
-    for sg in want:
-        assert got[sg] == want[sg], "block of signature %d differs" % sg
+    assert_same_archive(os.path.join(t, "gpu"), ref)
     assert st["device_batches"] >= 3, st["device_batches"]
     assert st["ppmd_max_restarts"] >= 3, st["ppmd_max_restarts"]
     assert st["host_coded_symbols"] == 0
-    import struct
-    m = open(os.path.join(t, "gpu.cmeta"), "rb").read(); foff, _ = struct.unpack_from("<QQ", m, 0); n, = struct.unpack_from("<I", m, foff)
-    sigs = list(struct.unpack_from("<%dI" % n, m, foff + 4 + 8 * n))
+    sigs = _archive_signatures(os.path.join(t, "gpu"))
     assert sigs[0] == max(sigs) and sigs[1:] == sorted(sigs[1:])          # -t1 order although the batches finished one after the other
 
 
@@ -464,28 +444,21 @@ def test_device_mate_search_agrees_with_the_host_search(name, paired, flags):
         assert pairs > 1000 and differing == 0, (window, pairs, differing)
 
 
-@pytest.mark.skipif(not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)), reason="reference binaries (oracle/_ref) not shipped")
-def test_device_mate_search_on_a_fresh_library_and_same_archive_either_way(tmp_path, monkeypatch):
-    # a fresh 150 000-pair library (bins of thousands of pairs: the history is full and turns over many times): rows against the
+def test_device_mate_search_on_a_fresh_library_and_same_archive_either_way(tmp_path, monkeypatch, ref_libs):
+    # a fresh 200 000-pair library (bins of thousands of pairs: the history is full and turns over many times): rows against the
     # host's search, and the archive with the device's searches and with the host's against the live reference
     import fastore_amd
-    from conftest import reference_blocks
+    binned, pe, _ = ref_libs.library("pe_long")
+    ref, _ = ref_libs.packed("pe_long")
     t = str(tmp_path)
-    binned, pe = ref_pipeline(t, "mates", 150_000, 150, 2 * 150_000 * 150 // 50, 21, True, 0, threads=8)
-    flags = ["-r", "-f256", "-c10", "-d8", "-w1024", "-W1024"]
-    reference_pack_mt(binned, os.path.join(t, "ref"), flags, pe, 8)
-    want = reference_blocks(os.path.join(t, "ref"))
     with fastore_amd.Packer(device_id=0) as p:
         pairs, differing = p.pe_matcher_check(binned)
-        assert pairs > 50_000 and differing == 0, (pairs, differing)      # (the standard bins of such a small library hold 40 % of its pairs)
+        assert pairs > 50_000 and differing == 0, (pairs, differing)
     for mode in ("1", "0"):
         monkeypatch.setenv("FS_DEVICE_MATES", mode)
         with fastore_amd.Packer(device_id=0) as p:
             p.pack_file(binned, os.path.join(t, "gpu" + mode))
-        got = reference_blocks(os.path.join(t, "gpu" + mode))
-        assert sorted(got) == sorted(want)
-        for sg in want:
-            assert got[sg] == want[sg], (mode, sg)
+        assert_same_archive(os.path.join(t, "gpu" + mode), ref)
 
 
 @pytest.mark.parametrize("name,paired,flags", manifest())
@@ -523,14 +496,14 @@ def test_device_matcher_window_sizes(window):
     assert reads > 1000 and differing == 0, (window, reads, differing)
 
 
-@pytest.mark.skipif(not (os.path.exists(REF_DRIVER) and os.path.exists(REF_DRIVER_GCC)), reason="reference binaries (oracle/_ref) not shipped")
-@pytest.mark.parametrize("paired,reads", [(False, 400_000), (True, 150_000)])
-def test_device_matcher_on_fresh_libraries_and_same_archive_either_way(tmp_path, monkeypatch, paired, reads):
+@pytest.mark.parametrize("lib", ["se_long", "pe_long"])
+def test_device_matcher_on_fresh_libraries_and_same_archive_either_way(tmp_path, monkeypatch, ref_libs, lib):
     # C1-profile libraries (bins of thousands of reads: full 1023-slot windows, sub-trees): the device's rows equal the host
     # scan's, and the archive is the same bytes with the device matcher and with the host scan (FS_DEVICE_MATCHER=0)
     import fastore_amd
+    binned, pe, _ = ref_libs.library(lib)
+    reads = RefLibs.shapes[lib][0]
     t = str(tmp_path)
-    binned, pe = ref_pipeline(t, "m", reads, 150, (2 if paired else 1) * reads * 150 // 50, 11, paired, 0, threads=min(16, len(os.sched_getaffinity(0))))
     kn = dict(min_bin_size=256, max_lz_window=1024, max_pair_lz_window=1024, extra_reduce_hard_reads=1, min_consensus_size=10, max_hamming_distance=8)
     with fastore_amd.Packer(device_id=0, **kn) as p:
         n, differing = p.matcher_check(binned)

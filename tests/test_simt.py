@@ -16,16 +16,13 @@ def simt():
     out = os.path.join(ROOT, "build", "libsimt_emu.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     # FS_EMU_DEFS: extra -D flags (kernel experiments, e.g. -DFS_WIN_PREFETCH=1) for the same tests
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU", "-DFS_WIN_NARROW=1"] + os.environ.get("FS_EMU_DEFS", "").split() + ["-shared", "-fPIC", "-o", out,
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU"] + os.environ.get("FS_EMU_DEFS", "").split() + ["-shared", "-fPIC", "-o", out,
                            os.path.join(ROOT, "tests", "emu", "ppmd_simt.cpp"), os.path.join(ROOT, "tests", "emu", "simt.cpp"), os.path.join(ROOT, "tests", "emu", "qvz_host_ref.cpp")])
     lib = ctypes.CDLL(out)
     lib.simt_ppmd_encode.restype = ctypes.c_size_t
     lib.simt_ppmd_encode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
     lib.simt_ppmd_encode_two_waves.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5
     lib.simt_quick_rescales.restype = ctypes.c_ulonglong
-    lib.simt_window_forms.argtypes = [ctypes.c_void_p]
-    lib.simt_ppmd_encode_three_waves.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6
-    lib.simt_set_jitter.argtypes = [ctypes.c_uint, ctypes.c_uint]
     return lib
 
 
@@ -78,10 +75,6 @@ def test_other_stream_kinds_through_the_64_lane_paths(simt, oracle):
     for name, data in streams.items():
         got, st = encode(simt, data)
         assert got == oracle_ppmd(oracle, data), name
-    # both forms of the window code have run by now: 32-bit packed lists (no context of a window has more than four states:
-    # the quality streams above) and 64-bit ones (up to eight: "skewed", "flags")
-    forms = (ctypes.c_ulonglong * 2)(); simt.simt_window_forms(forms)
-    assert forms[0] > 100 and forms[1] > 1000, list(forms)
 
 
 def test_reference_vectors_through_the_64_lane_paths(simt):
@@ -116,49 +109,6 @@ def test_two_wave_form_model_wave_and_coder_wave(simt, oracle):
     got = encode_two_waves(simt, streams)
     for i, (s, g) in enumerate(zip(streams, got)):
         assert g == (oracle_ppmd(oracle, s) if s else b""), i
-
-
-def encode_three_waves(lib, streams, jitter=(0, 0)):
-    """the three-wave form: serial wave, coder wave and window wave (64 fibers each); `jitter` = (seed, most extra steps) moves
-    the serial and the window wave against each other at the marked sites of ppmd_scout.h"""
-    k = len(streams)
-    pads = [s + b"\0" * 32 for s in streams]
-    ins = (ctypes.c_char_p * k)(*pads); lens = (ctypes.c_size_t * k)(*[len(s) for s in streams])
-    bufs = [ctypes.create_string_buffer(2 * len(s) + 4096) for s in streams]
-    outs = (ctypes.c_void_p * k)(*[ctypes.addressof(b) for b in bufs]); caps = (ctypes.c_size_t * k)(*[len(b) for b in bufs])
-    sizes = (ctypes.c_uint32 * k)(); st = (ctypes.c_uint64 * 8)()
-    lib.simt_set_jitter(*jitter)
-    lib.simt_ppmd_encode_three_waves(k, ins, lens, outs, caps, sizes, st)
-    lib.simt_set_jitter(0, 0)
-    return [bufs[i].raw[:sizes[i]] for i in range(k)], {"ahead_used": st[0], "forecast_unusable": st[1], "ahead_in_vain": st[2], "windows": st[3], "covered": st[4]}
-
-
-def test_three_wave_form_windows_prepared_ahead_of_the_serial_walk(simt, oracle):
-    rng = np.random.default_rng(19)
-    streams = [quality(150_000, 12), b"", rng.choice(np.frombuffer(b"ACGTN.", dtype=np.uint8), 20_000).tobytes(), b"Q",
-               rng.integers(0, 256, 6_000).astype(np.uint8).tobytes(), rng.integers(0, 9, 15_000).astype(np.uint8).tobytes(),
-               quality(777, 5), bytes(range(40)) * 300, quality(64, 6), quality(65, 7), quality(40_000, 8, read_len=37)]
-    # the same stream again and again through the same arena: the hint table left by the stream before names, at every key, the
-    # address the context of that key gets AGAIN -- a context the serial walk creates during an episode is then "known" to the
-    # window wave before it exists (what it fetched there is the old stream's memory): such windows must be thrown away
-    again = quality(20_000, 3); short = quality(5742, 4)
-    streams += [again, again, short, short, again, short]
-    got, st = encode_three_waves(simt, streams)
-    for i, (s, g) in enumerate(zip(streams, got)):
-        assert g == (oracle_ppmd(oracle, s) if s else b""), i
-    # the path under test really ran: windows prepared during an episode were used, and some had to be thrown away
-    assert st["ahead_used"] > 1000 and st["ahead_in_vain"] + st["forecast_unusable"] > 0, st
-
-
-@pytest.mark.parametrize("seed,steps", [(1, 3), (2, 17), (3, 60), (4, 250)])
-def test_three_wave_form_under_shifted_wave_timings(simt, oracle, seed, steps):
-    # the window wave fetches while the serial wave rewrites the model: whatever the two waves' relative timing, a window
-    # prepared from memory the episode has touched since must be thrown away (and one that was not, may be used)
-    streams = [quality(60_000, 20 + seed), quality(30_000, 30 + seed, read_len=23), np.random.default_rng(seed).integers(0, 9, 10_000).astype(np.uint8).tobytes()]
-    got, st = encode_three_waves(simt, streams, jitter=(seed, steps))
-    for i, (s, g) in enumerate(zip(streams, got)):
-        assert g == oracle_ppmd(oracle, s), (i, st)
-    assert st["ahead_used"] > 100, st
 
 
 def rc_encode(lib, model, pairs):
@@ -249,7 +199,7 @@ def test_range_coded_streams_through_the_coder_wave(oracle):
     # apart.  Against the oracle's coders, on two emulated waves.
     from conftest import MODELS, oracle_rc
     out = os.path.join(ROOT, "build", "libsimt_emu_rcq.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU", "-DFS_WIN_NARROW=1", "-DFS_RC_ON_CODER_WAVE", "-shared", "-fPIC", "-o", out,
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU", "-DFS_RC_ON_CODER_WAVE", "-shared", "-fPIC", "-o", out,
                            os.path.join(ROOT, "tests", "emu", "ppmd_simt.cpp"), os.path.join(ROOT, "tests", "emu", "simt.cpp"), os.path.join(ROOT, "tests", "emu", "qvz_host_ref.cpp")])
     lib = ctypes.CDLL(out)
     lib.simt_rc_encode_two_waves.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6
