@@ -567,7 +567,9 @@ static uint32_t wantsSplit(fsgpu_ctx* ctx, const std::string& in)      // 0: one
 // pipelines: 2 (two device batches) or 3 (more): the context takes the heaviest batch's worth of bins, the first helper the next
 // batch's worth (three pipelines), the last helper everything else.  (Measured at 60 M pairs with two: the helper's OWN batches
 // ran one after the other, 16.9 + 8.0 + 5.9 + 3.6 + 1.7 s beside the context's 26.7 s.)
-static void packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& out, int verbose, uint32_t pipelines)
+// Returns false -- nothing done -- when the device has no room for another pipeline (a helper context brings an arena pool and
+// staging buffers of its own): the caller then packs with the one pipeline it has, batch after batch, as round 2 did.
+static bool packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& out, int verbose, uint32_t pipelines)
 {
     fs::Context& a = ctx->c;
     const uint32_t T = a.hostThreads;
@@ -579,13 +581,18 @@ static void packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& 
         fsgpu_config hc = a.cfg;
         hc.one_shot = 0; hc.world_size = 1; hc.rank = 0; hc.host_threads = 1;      // (set for each pack below)
         fsgpu_ctx* h = fsgpu_create(&hc);
-        if (!h) throw std::runtime_error(std::string("device: pipeline ") + std::to_string(ctx->helpers.size() + 2) + ": " + fsgpu_create_error());
+        if (!h) {
+            if (verbose > 1 || getenv("FS_TRACE")) fprintf(stderr, "[split] pipeline %zu could not be made (%s): one pipeline\n", ctx->helpers.size() + 2, fsgpu_create_error());
+            return false;
+        }
         ctx->helpers.push_back(h);
     }
     std::vector<fs::Context*> cs{&a};
     for (uint32_t k = 0; k < want; ++k) cs.push_back(&ctx->helpers[k]->c);
-    struct Keep { std::vector<fs::Context*> cs; std::vector<fsgpu_config> cfg; std::vector<uint32_t> threads;
-                  ~Keep() { for (size_t i = 0; i < cs.size(); ++i) { cs[i]->cfg = cfg[i]; cs[i]->hostThreads = threads[i]; cs[i]->splitRole = 0; } } } keep;
+    // (whatever happens, the contexts get their own configuration back; after an error none of them keeps the blocks it held --
+    // a library of this size is tens of gigabytes of them)
+    struct Keep { std::vector<fs::Context*> cs; std::vector<fsgpu_config> cfg; std::vector<uint32_t> threads; bool done = false;
+                  ~Keep() { for (size_t i = 0; i < cs.size(); ++i) { cs[i]->cfg = cfg[i]; cs[i]->hostThreads = threads[i]; cs[i]->splitRole = 0; if (!done) { cs[i]->shards.clear(); cs[i]->shards.shrink_to_fit(); } } } } keep;
     for (fs::Context* c : cs) { keep.cs.push_back(c); keep.cfg.push_back(c->cfg); keep.threads.push_back(c->hostThreads); }
     for (uint32_t k = 0; k < pipelines; ++k) {
         fs::Context& c = *cs[k];
@@ -633,14 +640,16 @@ static void packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& 
         char err[256] = {0};
         if (verbose == 1 && fsgpu_print_stream_sizes(out.c_str(), err, sizeof err) != 0) throw std::runtime_error(err);
     }
+    keep.done = true;
+    return true;
 }
 
 int fsgpu_pack_file(fsgpu_ctx* ctx, const char* inPrefix, const char* outPrefix, int verbose)
 {
     if (!ctx || !inPrefix || !outPrefix) return FSGPU_ERR_ARG;
     FS_GUARD(ctx, {
-        if (const uint32_t pipelines = wantsSplit(ctx, inPrefix)) packSplit(ctx, inPrefix, outPrefix, verbose, pipelines);
-        else ctx->c.packFiles({std::string(inPrefix)}, {std::string(outPrefix)}, verbose);
+        const uint32_t pipelines = wantsSplit(ctx, inPrefix);
+        if (!(pipelines && packSplit(ctx, inPrefix, outPrefix, verbose, pipelines))) ctx->c.packFiles({std::string(inPrefix)}, {std::string(outPrefix)}, verbose);
     });
 }
 

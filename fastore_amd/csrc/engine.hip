@@ -324,6 +324,13 @@ __global__ __launch_bounds__(256) void fs_gather_quality_pairs(const QuaPairStri
 // and leaves its pair counts and the chunk's totals; fs_id_write places a chunk behind the totals of the bin's earlier chunks
 // and parses again to write.  Characters come eight at a time: 56 stored bits from one unaligned 64-bit load.)
 struct IdChunk { uint32_t job, c0, first_chunk, pad; };          // reads [c0, c0 + 256) of the job; the job's first chunk
+// A read id's stored characters -- seven bits each from bit src_bit on -- lie inside the uploaded input.  IdChars::get refills with
+// ONE unaligned 64-bit load at the byte of the character it needs, so its last load of a string can reach seven bytes past the
+// string's last byte; those bytes are never used, and they are always readable: every buffer that holds the input (dIn) is made
+// kInSlack bytes longer than anything addressed in it (the `+ kInSlack` of every ensure(dev->dIn ...) below).
+constexpr uint32_t kInSlack = 64;
+static_assert(kInSlack >= 8, "IdChars::get reads eight bytes at a time");
+static inline bool id_string_inside(uint64_t src_bit, uint32_t len, uint64_t inputBytes) { return (src_bit + 7ull * len + 7ull) / 8ull <= inputBytes; }
 struct IdChars {
     const uint8_t* in; uint64_t src_bit; uint64_t buf; uint32_t first;      // stored characters [first, first + 8) sit in the top 56 bits of buf
     __device__ __forceinline__ uint32_t get(uint32_t j)
@@ -814,7 +821,7 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     }
     IdLaunch idl;
     if (ids && ids->n_jobs) id_launch_plan((const IdJob*)(input + ids->jobs_off), ids->n_jobs, ids->n_strings, gatherBase + gatherBytes, idl);
-    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + gatherBytes + idl.bytes + 64)) return -1;
+    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + gatherBytes + idl.bytes + kInSlack)) return -1;
     if (ensure(dev, dev->dScratch, dev->capScratch, scratch + 16)) return -1;
     if (ensure(dev, dev->dItems, dev->capItems, sizeof(StreamItem) * nItems)) return -1;
     if (ensure(dev, dev->dOrder, dev->capOrder, 4ull * nItems)) return -1;
@@ -878,12 +885,13 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
                                     : std::min<uint32_t>(std::max(nRest, 1u), dev->nWaves);
     if (grid == 0) { snprintf(dev->err, sizeof dev->err, "arena pool too small for a %llu-byte coder table", (unsigned long long)need); return -1; }
     if (ids && ids->n_jobs) {
-        // every job's strings, table and output inside the buffers, checked here: the kernel trusts its descriptors
+        // every job's strings, table and output inside the buffers, checked here: the kernel trusts its descriptors (and may read up
+        // to seven bytes past a string's end: kInSlack)
         const IdJob* jb = (const IdJob*)(input + ids->jobs_off); const IdString* ss = (const IdString*)(input + ids->strings_off);
         for (uint32_t j = 0; j < ids->n_jobs; ++j) {
             bool ok = (uint64_t)jb[j].first + jb[j].count <= ids->n_strings && jb[j].tok_item < nItems && jb[j].val_item < nItems && jb[j].table_off + 8u <= inputBytes && (jb[j].table_off & 7u) == 0 &&
                       jb[j].tok_out + 2ull * items[jb[j].tok_item].in_len <= gatherBytes && jb[j].val_out + 2ull * items[jb[j].val_item].in_len <= gatherBytes;
-            for (uint32_t k = 0; ok && k < jb[j].count; ++k) { const IdString& s = ss[jb[j].first + k]; ok = s.len <= 255u && (s.src_bit >> 3) + (7ull * s.len + 7u) / 8u + 2u <= inputBytes; }
+            for (uint32_t k = 0; ok && k < jb[j].count; ++k) { const IdString& s = ss[jb[j].first + k]; ok = s.len <= 255u && id_string_inside(s.src_bit, s.len, inputBytes); }
             if (!ok) { snprintf(dev->err, sizeof dev->err, "read-id job %u outside the batch input", j); return -1; }
         }
         if (id_launch(dev, st, *ids, gatherBase, idl)) return -1;
@@ -996,7 +1004,7 @@ int gather_quality_raw(Device* dev, const uint8_t* input, size_t inputBytes, con
             if ((qs[i].src_bit >> 3) + ((uint64_t)plan.bits * qs[i].len + 7u) / 8u + 2u > plan.desc_off || qs[i].n_count > qs[i].len || 2ull * ((uint64_t)qs[i].dst_off + qs[i].len - qs[i].n_count) > plan.out_bytes ||
                 (uint64_t)qs[i].n_off + qs[i].n_count > plan.n_list_bytes) { snprintf(dev->err, sizeof dev->err, "quality string %u outside the input", i); return -1; }
     }
-    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + plan.out_bytes + 64)) return -1;
+    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + plan.out_bytes + kInSlack)) return -1;
     HIP_TRY(hipMemcpyAsync(dev->dIn, input, inputBytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[4], st));
     const uint32_t blocks = std::max(1u, std::min<uint32_t>((plan.n_strings + 3u) / 4u, (uint32_t)dev->cus * 16u));
@@ -1030,12 +1038,12 @@ int tokenise_ids_raw(Device* dev, const uint8_t* input, size_t inputBytes, const
     for (uint32_t j = 0; j < plan.n_jobs; ++j) {
         bool ok = (uint64_t)jb[j].first + jb[j].count <= plan.n_strings && jb[j].tok_item == 2 * j && jb[j].val_item == 2 * j + 1 && jb[j].table_off + 8u <= inputBytes && (jb[j].table_off & 7u) == 0 &&
                   jb[j].tok_out <= plan.out_bytes && jb[j].val_out <= plan.out_bytes;
-        for (uint32_t k = 0; ok && k < jb[j].count; ++k) { const IdString& s = ss[jb[j].first + k]; ok = s.len <= 255u && (s.src_bit >> 3) + (7ull * s.len + 7u) / 8u + 2u <= inputBytes; }
+        for (uint32_t k = 0; ok && k < jb[j].count; ++k) { const IdString& s = ss[jb[j].first + k]; ok = s.len <= 255u && id_string_inside(s.src_bit, s.len, inputBytes); }
         if (!ok) { snprintf(dev->err, sizeof dev->err, "read-id job %u outside the input", j); return -1; }
     }
     IdLaunch idl;
     id_launch_plan(jb, plan.n_jobs, plan.n_strings, gatherBase + plan.out_bytes, idl);
-    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + plan.out_bytes + idl.bytes + 64)) return -1;
+    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + plan.out_bytes + idl.bytes + kInSlack)) return -1;
     if (ensure(dev, dev->dItems, dev->capItems, sizeof(StreamItem) * items.size() + 64)) return -1;
     HIP_TRY(hipMemcpyAsync(dev->dIn, input, inputBytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dev->dItems, items.data(), sizeof(StreamItem) * items.size(), hipMemcpyHostToDevice, st));

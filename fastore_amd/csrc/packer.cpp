@@ -11,6 +11,7 @@
 #include <chrono>
 #include <stdexcept>
 #include <thread>
+#include <errno.h>
 #include <fcntl.h>
 #include <unistd.h>
 #include <sys/mman.h>
@@ -1148,12 +1149,24 @@ struct StealCounter {
         char buf[96]; snprintf(buf, sizeof buf, "/dev/shm/fastore_steal.%016llx.%u", (unsigned long long)h, seq);
         return buf;
     }
+    // The rank that CREATES the file (O_EXCL: exactly one does) sizes it, which zeroes the count; the others open what is there
+    // and wait until it has its 64 bytes.  A file left behind by a job that died cannot be told from a live one by a rank that
+    // merely finds it, so a key must not be used twice: shard.py draws a fresh one per job, `fastore_pack -G` removes its own
+    // (process id + prefixes) before its contexts start, a launcher that sets FS_STEAL_KEY owns its uniqueness -- and every
+    // context removes its counters when it goes, error paths included (capi.cpp: fsgpu_destroy; packFiles' catch).
     bool open(const std::vector<std::string>& prefixes, uint32_t seq)
     {
         name = fileName(prefixes, seq);
-        fd = ::open(name.c_str(), O_CREAT | O_RDWR, 0600);
-        if (fd < 0) return false;
-        if (ftruncate(fd, 64) != 0) { ::close(fd); fd = -1; return false; }          // (new bytes read as zero; a file that is there keeps its count)
+        fd = ::open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0) { if (ftruncate(fd, 64) != 0) { ::close(fd); fd = -1; (void)unlink(name.c_str()); return false; } }
+        else {
+            if (errno != EEXIST) return false;
+            fd = ::open(name.c_str(), O_RDWR);
+            if (fd < 0) return false;
+            struct stat sb; int tries = 0;
+            while (fstat(fd, &sb) == 0 && sb.st_size < 64 && tries++ < 2000) usleep(1000);      // (the creator is between open and ftruncate)
+            if (sb.st_size < 64) { ::close(fd); fd = -1; return false; }
+        }
         void* m = mmap(nullptr, 64, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         if (m == MAP_FAILED) { ::close(fd); fd = -1; return false; }
         p = (std::atomic<uint32_t>*)m;
@@ -1200,7 +1213,14 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
     // with one chunk claimed per pass a rank ran four of them behind its share: two ranks on one device, 2 M-read libraries,
     // 1 677 ms per step without the tail and 2 335 with it (profiles/r03_rehearse_2ranks*.json).  The shares dealt by
     // shardOwners (longest stream first) are within a few per cent of each other; a tail costs more than it can level.)
-    const bool wantSteal = world > 1 && splitRole == 0 && (getenv("FS_STEAL") && atoi(getenv("FS_STEAL")) != 0) && (getenv("FS_STEAL_KEY") || getenv("MASTER_PORT"));
+    // The counter is a file of THIS node, so the tail is only dealt when every rank of the job runs on it: contexts of one process
+    // (fastore_pack -G, the tests), or a launcher that says so (torch.distributed.run exports LOCAL_WORLD_SIZE; equal to the job's
+    // world size = one node).  A job over several nodes deals every bin up front: with a counter per node every node would claim
+    // the whole tail, and the summed size table would count those blocks twice.
+    bool oneNode = true;
+    if (const char* lw = getenv("LOCAL_WORLD_SIZE")) oneNode = (uint32_t)atoi(lw) == world;
+    else if (getenv("MASTER_PORT") && !getenv("FS_STEAL_ONE_NODE")) oneNode = false;         // a rendezvous, and nobody vouches for the node
+    const bool wantSteal = world > 1 && oneNode && splitRole == 0 && (getenv("FS_STEAL") && atoi(getenv("FS_STEAL")) != 0) && (getenv("FS_STEAL_KEY") || getenv("MASTER_PORT"));
     if (wantSteal) {
         if (!steal.open(inPrefixes, stealSeq)) throw std::runtime_error("Cannot open the node's work counter in /dev/shm");
         stealNames.push_back(steal.name);
