@@ -22,6 +22,13 @@ curve); `--replicas` makes every rank pack the whole library into its own archiv
 cpu_baseline = the real reference fastore_pack (oracle/_ref) on the same library at -t min(32, cores) (and at
 -t1 with --cpu-t1, ~4 min); parity = every block of the product's archive against the reference's block of the same
 signature, and the product's block order against the -t1 order (block 0, then ascending signature).
+
+Two regimes, both printed and labelled (SURVEY 8(d) defines the metric on the PROCESS): `value` / `ms_per_step` = the K timed
+warm steps of the contract (context made, file to file); `process` = the `fastore_pack e` process from start to exit, median of
+three runs.  `speedup` holds both ratios against the reference PROCESS; `speedup_vs_cpu_baseline` is the like-with-like one,
+process against process.  N = 1 legs beside the headline: `pe` (configs[2] scaled to what the driver's window holds, 15 M pairs by
+default), `reduced` (configs[3]'s mode) and `lossy` (QVZ) on the headline's reads.  All legs' libraries are prepared side by side
+before the first timed step.
 """
 import argparse
 import json
@@ -55,16 +62,17 @@ def sh(cmd, **kw):
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, **kw)
 
 
-def prepare_library(work, name, reads, length, genome, seed, threads, paired=False):
+def prepare_library(work, name, reads, length, genome, seed, threads, paired=False, quality=None):
     """FASTQ -> fastore_bin -> 3 x fastore_rebin with the real reference (C1 profile,
     scripts/fastore_compress.sh:146-148,186-209). Cached in `work`."""
+    quality = quality or QUALITY
     base = os.path.join(work, name)
     binned = base + ".b8"
     pe = ["-z"] if paired else []
     fq = [base + "_1.fastq"] + ([base + "_2.fastq"] if paired else [])
     if not (os.path.exists(binned + ".bmeta") and os.path.exists(base + ".done")):
         sh([GEN, "--reads", str(reads), "--len", str(length), "--genome", str(genome), "--seed", str(seed), "--out", base] + (["--paired"] if paired else []))
-        sh([REF_GCC, "bin", "-i" + " ".join(fq), "-o" + base + ".b0", "-t%d" % threads] + QUALITY_MODES[QUALITY] + ["-p8", "-s0", "-b256"] + pe)
+        sh([REF_GCC, "bin", "-i" + " ".join(fq), "-o" + base + ".b0", "-t%d" % threads] + QUALITY_MODES[quality] + ["-p8", "-s0", "-b256"] + pe)
         prev = base + ".b0"
         for p in (2, 4, 8):
             cur = base + ".b%d" % p
@@ -163,12 +171,13 @@ def reference_pack(binned, refp, cores, pe, sweep=False):
     return nt, tn, others
 
 
-def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome, steps, warmup, cores, lib, cli_runs, traffic_file=None, sweep=False):
+def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome, steps, warmup, cores, lib, cli_runs, traffic_file=None, sweep=False, quality=None):
     """ONE library on ONE GPU: K timed pack steps (file to file), then the CLI process, the reference on the same library,
     and the block-for-block comparison.  Returns the leg's result dict."""
     L = 150
+    quality = quality or QUALITY
     t0 = time.time()
-    binned, fastq_bytes = prepare_library(work, name, reads, L, genome, 8, min(cores, 32), paired)
+    binned, fastq_bytes = prepare_library(work, name, reads, L, genome, 8, min(cores, 32), paired, quality)
     prep_s = time.time() - t0
     packer = fastore_amd.Packer(device_id=0, lib=lib, host_threads=0)
     out_base = os.path.join(work, "out_" + name)
@@ -209,14 +218,18 @@ def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome,
         drop(o)
     traffic = None
     if traffic_file and os.path.exists(traffic_file):
+        # HBM bytes need the PMC counters, i.e. rocprofv3 around the process: they come from the committed counter passes of this
+        # very command (tools/pmc_passes.sh -> tools/hbm_traffic.py; the file is named in the line), not from this run
         traffic = json.load(open(traffic_file))["hbm_bytes_per_step"] / max(1.0, int(st["kernel_launches"]) / steps)
     sym = max(1.0, float(st["ppmd_symbols"]))
     rf = roofline_of(st, steps, traffic)
+    if traffic is not None:
+        rf["traffic_source"] = os.path.relpath(traffic_file, ROOT)
     rf["ppmd_symbols_per_s_whole_job"] = round(st["ppmd_symbols"] / dt, 1)
     res = {
         "value": round(fastq_bytes * steps / dt / 1e6, 2), "unit": "MB/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
         "config": {"workload": "ONE library of %.1f M x %d bp %s synthetic FASTQ (gen_fastq genome %d bp, seed 8), --%s, C1 profile%s"
-                               % (reads / 1e6, L, "PE pairs" if paired else "SE reads", genome, QUALITY, "" if not paired else " (configs[2] scaled by %g)" % (reads / 100e6)),
+                               % (reads / 1e6, L, "PE pairs" if paired else "SE reads", genome, quality, "" if not paired else " (configs[2] scaled by %g)" % (reads / 100e6)),
                    "fastq_bytes": fastq_bytes, "pack_flags": " ".join(PACK_FLAGS + (["-z"] if paired else [])), "parallelism": "1 GPU"},
         "roofline": rf,
         "host_coded_symbol_fraction": round(float(st.get("host_coded_symbols", 0)) / sym, 4),
@@ -256,10 +269,11 @@ def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome,
         # (the first processes on a fresh box wait 1-4 s in their first large device allocation while the driver clears
         # memory it has not handed out before -- profiles/r02_mm_alloc_sizes.txt: not the program's time --, hence
         # several runs; the MEDIAN is quoted, all runs are listed)
-        res["cli_end_to_end"] = {"value": round(fastq_bytes / med / 1e6, 2) if rc == 0 else None, "unit": "MB/s", "seconds": med, "runs_seconds": runs,
-                                 "best_seconds": min(runs), "quoted": "median of the runs", "exit": rc,
-                                 "archive_identical_to_the_in_process_one": bool(rc == 0 and all(open(cli_out + e, "rb").read() == open(out + e, "rb").read() for e in (".cdata", ".cmeta"))),
-                                 "command": "fastore_pack e " + " ".join(PACK_FLAGS + pe)}
+        res["process"] = {"value": round(fastq_bytes / med / 1e6, 2) if rc == 0 else None, "unit": "MB/s", "seconds": med, "runs_seconds": runs,
+                          "what": "SURVEY 8(d)'s metric: the fastore_pack e PROCESS, start -> exit (HIP init, arena allocation, .b* in, .c* out), page cache warm",
+                          "best_seconds": min(runs), "quoted": "median of the runs", "exit": rc,
+                          "archive_identical_to_the_in_process_one": bool(rc == 0 and all(open(cli_out + e, "rb").read() == open(out + e, "rb").read() for e in (".cdata", ".cmeta"))),
+                          "command": "fastore_pack e " + " ".join(PACK_FLAGS + pe)}
         drop(cli_out)
     if not args.no_cpu_baseline:
         refp = os.path.join(work, "ref_" + name)
@@ -270,7 +284,12 @@ def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome,
                                    "threads": nt, "seconds": round(tn, 2)}
             if others:
                 res["cpu_baseline"]["thread_sweep"] = others
-            res["speedup_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 2)
+            # like with like: process against process; the warm step against the reference's process is the other regime, labelled
+            ref_v = res["cpu_baseline"]["value"]
+            res["speedup"] = {"process_vs_reference_process": round(res["process"]["value"] / ref_v, 2) if res.get("process", {}).get("value") else None,
+                              "warm_step_vs_reference_process": round(res["value"] / ref_v, 2)}
+            res["speedup_vs_cpu_baseline"] = res["speedup"]["process_vs_reference_process"] or res["speedup"]["warm_step_vs_reference_process"]
+            res["speedup_vs_cpu_baseline_regime"] = "process vs process" if res["speedup"]["process_vs_reference_process"] else "warm step vs reference process (no CLI run)"
             res["parity"] = {"every_block_bit_identical_to_reference": bool(same_blocks(out, refp)), "block_order": "-t1 (block 0, ascending signature)",
                              "on": "the whole workload archive (%d blocks)" % len(read_archive(out)[0])}
         if args.cpu_t1:
@@ -295,9 +314,10 @@ def main():
     ap.add_argument("--cpu-sweep", action="store_true", help="also time the reference at -t16 and -t48 once")
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end run of the fastore_pack CLI (process start -> exit)")
     ap.add_argument("--paired", action="store_true", help="the headline leg packs ONE paired-end library of --reads pairs (configs[2] scaled)")
-    ap.add_argument("--pe-reads", type=int, default=6_000_000, help="pairs of the paired-end leg of the N = 1 line (configs[2] scaled to what the run's window holds)")
+    ap.add_argument("--pe-reads", type=int, default=15_000_000, help="pairs of the paired-end leg of the N = 1 line (configs[2] scaled to what the run's window holds)")
     ap.add_argument("--no-pe", action="store_true", help="N = 1: the headline leg only (skips the paired-end leg and the --reduced leg)")
     ap.add_argument("--no-reduced", action="store_true", help="N = 1: skip the --reduced leg (the same reads with 8-bin quality scores)")
+    ap.add_argument("--no-lossy", action="store_true", help="N = 1: skip the --lossy leg (the same reads with QVZ-coded quality scores)")
     ap.add_argument("--rehearse", action="store_true", help="N ranks on ONE device over gloo (no RCCL): a dry run of the N > 1 code path on a one-GPU box")
     ap.add_argument("--strong", action="store_true", help="--gpus N: ONLY the strong line (the ONE library of the N = 1 run sharded over the ranks)")
     ap.add_argument("--replicas", "--weak", dest="replicas", action="store_true", help="--gpus N: every rank packs the whole library into its own archive")
@@ -337,43 +357,67 @@ def main():
     lib = fastore_amd.load_library(alt) if alt else None
 
     if world == 1:
-        # ---- the N = 1 line: the headline leg (configs[1], or --paired) and, beside it, the paired-end leg ----
-        traffic_file = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json") if (args.reads == 10_000_000 and not args.paired) else None
+        # ---- the N = 1 line: the headline leg (configs[1], or --paired) and, beside it, the paired-end, --reduced and --lossy legs ----
+        if args.gpus != 1:
+            raise SystemExit("bench.py --gpus %d needs %d ranks (python -m torch.distributed.run --nproc-per-node %d ...); WORLD_SIZE is 1" % (args.gpus, args.gpus, args.gpus))
+        pk = args.pe_reads
+        legs = [("main", name, args.reads, args.paired, genome, QUALITY)]
+        if not args.paired and not args.no_pe:
+            legs.append(("pe", "pe%dk" % (pk // 1000) + ("" if QUALITY == "lossless" else "_" + QUALITY), pk, True, 2 * pk * L // 50, QUALITY))
+            if QUALITY == "lossless" and not args.no_reduced:
+                legs.append(("reduced", name + "_reduced", args.reads, False, genome, "reduced"))
+            if QUALITY == "lossless" and not args.no_lossy:
+                legs.append(("lossy", name + "_lossy", args.reads, False, genome, "lossy"))
+        # every leg's library is generated and binned by the reference's tools BEFORE the first timed step, side by side (the
+        # stages are untimed, but one after the other they were half of the run's wall time)
+        per = max(4, min(32, cores // max(1, len(legs))))
+        errs = {}
+
+        def prep(leg):
+            try:
+                prepare_library(args.work, leg[1], leg[2], L, leg[4], 8, per, leg[3], leg[5])
+            except Exception as e:      # noqa: BLE001
+                errs[leg[0]] = "%s: %s" % (type(e).__name__, e)
+        t0 = time.time()
+        th = [threading.Thread(target=prep, args=(leg,)) for leg in legs]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        prep_all_s = time.time() - t0
+        if "main" in errs:
+            raise SystemExit("could not prepare the headline library: " + errs["main"])
+        traffic_file = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json") if (args.reads == 10_000_000 and not args.paired and QUALITY == "lossless") else None
         leg, dev = one_library_leg(fastore_amd, torch, args, args.work, name, args.reads, args.paired, genome, args.steps, args.warmup, cores, lib,
                                    0 if args.no_cli else 3, traffic_file, args.cpu_sweep)
         res = {"metric": "fastore_pack compressed MB/s (input FASTQ)", "value": leg["value"], "unit": "MB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic"}
+               "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "value_is": "the K timed warm steps (file to file, context made); `process` holds SURVEY 8(d)'s process start -> exit, `speedup` both ratios"}
         for k, v in leg.items():
             if k not in res:
                 res[k] = v
         res["stages_ms_per_step_rank0"] = res.pop("stages_ms_per_step")
-        res["device"] = dev; res["host_cores"] = cores
-        if not args.paired and not args.no_pe:
-            # configs[2] is 100 M pairs x 150 bp PE; what fits this run's window is a library of --pe-reads pairs from the same
-            # generator (genome scaled for the same 50x coverage): its own value, reference baseline, parity and roofline
-            pk, ps, pw = args.pe_reads, max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))
+        res["device"] = dev; res["host_cores"] = cores; res["prep_all_legs_s"] = round(prep_all_s, 1)
+        for key, lname, lreads, lpaired, lgenome, lq in legs[1:]:
             # (a leg beside the headline must never cost the line itself: what goes wrong in it is reported in its place)
+            if key in errs:
+                res[key] = {"error": errs[key]}
+                continue
+            ls, lw = (max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))) if key == "pe" else (max(1, min(args.steps, 3)), 1)
             try:
-                pleg, _ = one_library_leg(fastore_amd, torch, args, args.work, "pe%dk" % (pk // 1000) + ("" if QUALITY == "lossless" else "_" + QUALITY), pk, True, 2 * pk * L // 50, ps, pw, cores, lib, 0 if args.no_cli else 3)
+                lleg, _ = one_library_leg(fastore_amd, torch, args, args.work, lname, lreads, lpaired, lgenome, ls, lw, cores, lib, 0 if args.no_cli else 3, quality=lq)
             except Exception as e:          # noqa: BLE001
-                pleg = {"error": "%s: %s" % (type(e).__name__, e)}
-            res["pe"] = pleg
-        if not args.paired and not args.no_pe and not args.no_reduced and QUALITY == "lossless":      # (--no-pe: the headline leg only)
-            # configs[3]'s mode (--reduced: 8-bin quality scores, range-coded with the <8,6> model instead of PPMd) on the same
-            # reads: its own value, reference baseline and parity (the windowed range coders, rc_core.h)
-            global_q = QUALITY
-            globals()["QUALITY"] = "reduced"
-            try:
-                rleg, _ = one_library_leg(fastore_amd, torch, args, args.work, name + "_reduced", args.reads, False, genome, max(1, min(args.steps, 3)), 1, cores, lib, 0)
-            except Exception as e:          # noqa: BLE001
-                rleg = {"error": "%s: %s" % (type(e).__name__, e)}
-            finally:
-                globals()["QUALITY"] = global_q
-            res["reduced"] = rleg
+                lleg = {"error": "%s: %s" % (type(e).__name__, e)}
+            res[key] = lleg
         print(json.dumps(res), flush=True)
         return
 
     # ---- N > 1 ----
+    if args.gpus != world or dist.get_world_size() != world:
+        raise SystemExit("bench.py --gpus %d was started with %d ranks (WORLD_SIZE) / a process group of %d" % (args.gpus, world, dist.get_world_size()))
+    backend = dist.get_backend()
+    if not args.rehearse and backend != "nccl":
+        raise SystemExit("bench.py --gpus N runs over RCCL (torch.distributed backend \"nccl\"); the process group's backend is %r" % backend)
     prep_s = 0.0
     lib_set = not args.strong and not args.replicas       # the default N > 1 job: N libraries, bin-sharded -- and the strong line beside it
     names = [name if r == 0 else "%s_s%d" % (name, 8 + r) for r in range(world)]
@@ -461,6 +505,23 @@ def main():
                   "workload": "ONE library (library 0 of the set, %.1f MB FASTQ) bin-sharded over the %d ranks" % (fastq_one / 1e6, world),
                   "roofline": roofline_of(stot, ks)}
 
+    # parity of the SET line: rank r runs the reference on library r (the ranks side by side, each with its share of the host's
+    # cores) and compares the archive the N ranks wrote for it block for block; rank 0 collects the verdicts
+    set_parity = None
+    if lib_set and not args.no_cpu_baseline:
+        pe_flag = ["-z"] if args.paired else []
+        refp_r = os.path.join(args.work, "ref_" + names[rank])
+        nt_r, tn_r, _ = reference_pack(binned_set[rank], refp_r, max(4, cores // world), pe_flag)
+        ok_r = bool(nt_r is not None and same_blocks(last[rank], refp_r))
+        strong_ok = bool(nt_r is not None and same_blocks(slast[0], refp_r)) if (rank == 0 and strong is not None) else None
+        for e in (".cdata", ".cmeta"):
+            try:
+                os.remove(refp_r + e)
+            except OSError:
+                pass
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (ok_r, nt_r, tn_r, strong_ok))
+        set_parity = gathered
     if rank == 0:
         jobs = world if args.replicas else 1
         fastq_bytes = fastq_set if lib_set else fastq_one
@@ -484,12 +545,24 @@ def main():
             "stages_ms_per_step_rank0": dict({k: round(st[k] / args.steps, 1) for k in ("encode_kernel_ms", "assemble_kernel_ms", "frontend_ms", "io_ms", "total_ms")}, block0_ms=round(st["block0_ms"], 1)),
             "archive": {"cdata_bytes": int(tot["cdata_bytes"]) // args.steps, "bins": int(tot["bins"]) // args.steps, "records": int(tot["records"]) // args.steps},
             "device": packer.device_name, "host_cores": cores, "prep_s": round(prep_s, 1),
+            "ranks": world, "collective_backend": "%s (%s)" % (backend, "RCCL over xGMI" if backend == "nccl" else "CPU rehearsal on one device"),
         }
         if strong is not None:
             res["strong"] = strong
-        if not args.no_cpu_baseline and sharded:
-            # parity of the N > 1 job: library 0's archive (the set's, and the strong line's) against the reference's pack of
-            # that library; the reference is timed on rank 0's host cores while the other ranks wait
+        if set_parity is not None:
+            ok0, nt0, tn0, strong_ok = set_parity[0]
+            if nt0 is not None:
+                res["cpu_baseline"] = {"value": round(fastq_one / tn0 / 1e6, 2), "unit": "MB/s", "cores": min(nt0, max(4, cores // world)), "kind": "reference",
+                                       "sample": "reference fastore_pack e -t%d on library 0 (%.1f MB FASTQ) while the other ranks run it on their libraries, %d host cores" % (nt0, fastq_one / 1e6, cores),
+                                       "threads": nt0, "seconds": round(tn0, 2)}
+            res["parity"] = {"every_library_every_block_bit_identical_to_reference": bool(all(g[0] for g in set_parity)),
+                             "per_library": [bool(g[0]) for g in set_parity],
+                             "on": "all %d archives of the SET as the %d ranks wrote them, each against the reference's pack of that library" % (world, world)}
+            if strong_ok is not None:
+                res["parity"]["strong_line_archive_identical_to_reference"] = bool(strong_ok)
+        elif not args.no_cpu_baseline and sharded:
+            # parity of the N > 1 job (--strong): the ONE library's archive against the reference's pack of it; the reference is
+            # timed on rank 0's host cores while the other ranks wait
             pe = ["-z"] if args.paired else []
             refp = os.path.join(args.work, "ref_" + name)
             nt, tn, _ = reference_pack(binned, refp, cores, pe)

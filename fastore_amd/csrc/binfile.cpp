@@ -249,7 +249,7 @@ void BinFile::close() { unmap(meta_); unmap(dna_); unmap(qua_); unmap(headf_); }
 BinFile::Map BinFile::mapFile(const std::string& name)
 {
     const int fd = ::open(name.c_str(), O_RDONLY);
-    if (fd < 0) throw std::runtime_error("Cannot open file: " + name);
+    if (fd < 0) throw std::runtime_error("Cannot open file to read: " + name);      // (FileStreamReader, fastore_bin/FileStream.cpp:134)
     struct stat st;
     if (fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error("Cannot open file: " + name); }
     Map m; m.size = (uint64_t)st.st_size;
@@ -396,7 +396,7 @@ void BinFile::unpackImpl(uint32_t signature, Batch& data, Batch& graph, bool asN
     if (packedD && (uint64_t)dnaPackedBase + bi.totalDnaSize > data.dnaPacked.size()) throw std::runtime_error("packed bases: batch arrays not sized");
     const bool packedQ = quaBase >= 0;
     if (packedQ) {
-        if (!placed || cfg_.quaParams.method == MET_QVZ) throw std::runtime_error("packed qualities: placed unpack of a lossless, 8-bin or binary archive only");
+        if (!placed) throw std::runtime_error("packed qualities: placed unpack only");
         if ((uint64_t)quaBase + bi.totalQuaSize > data.quaPacked.size() || data.quaBit.size() != data.recs.size()) throw std::runtime_error("packed qualities: batch arrays not sized");
     } else if (bQua_.size() < bi.totalQuaSize) bQua_.resize(bi.totalQuaSize);
     uint8_t* const quaDst = packedQ ? data.quaPacked.data() + quaBase : bQua_.data();

@@ -26,9 +26,24 @@ struct QuaString { uint64_t src_bit; uint32_t dst_off; uint16_t len; uint16_t re
 // (emitted index * 8 or 2) / length; the n_count positions listed (stored indices, n_off into the slice's list) lie under
 // an 'N' base and are left out.  dst_off counts PAIRS.
 struct QuaPairString { uint64_t src_bit; uint32_t dst_off, n_off; uint16_t len; uint8_t reverse, n_count; };
-// bits: 6 = QuaString descriptors and byte output; 3 / 1 = QuaPairString descriptors, pair output, n_list_off = the 'N' positions
+// --lossy (QVZ) archives, fs_gather_quality_qvz: the stream is one u32 per score, context | state << 24 -- the context is the
+// conditional quantizer chosen for the score (column, previous quantized value, the low or the high one by a 7-bit draw of the
+// archive's WELL-1024a generator), the state the place of the quantized value in that quantizer's output alphabet
+// (IQualityStoreBase::CompressReadQuality, MET_QVZ: fastore_pack/FastqCompressor.cpp:318-364; choose_quantizer, quantizer.cpp:522-531).
+// dst_off counts BYTES in the gather region; draw0 = scores of the bin's stream in front of this string (the generator is
+// re-seeded per bin and draws once per score, in emission order); model16 = place of the library's QvzSymHeader in the batch
+// input, in 16-byte units
+struct QuaQvzString { uint64_t src_bit; uint32_t dst_off, draw0, model16; uint16_t len, reverse; };
+// The tables of one library's conditional quantizers as fs_gather_quality_qvz reads them (built by fs::QvzModel::parse from the
+// codebook in .bmeta; byte offsets from the header's start): col_ctx_base u32[columns]; col_index u16[columns][82] (previous
+// quantized value -> index in the column's input alphabet, 0xFFFF absent); qratio u8[n_ctx / 2]; quant, state_of u8[n_ctx][72]
+// (score -> quantized value / its place in the output alphabet, 0xFF unused); well u32[well_words]: the generator's outputs from
+// the archive's seed on -- four 7-bit draws per word, the word's top four bits unused (well_1024a_bits, well.cpp:42-55)
+struct QvzSymHeader { uint32_t columns, n_ctx, col_ctx_base_off, col_index_off, qratio_off, quant_off, state_of_off, well_off, well_words, total_bytes, pad[2]; };
+// bits: 6 = QuaString descriptors and byte output (qvz: QuaQvzString descriptors and u32 output); 3 / 1 = QuaPairString descriptors, pair output, n_list_off = the 'N' positions
 struct GatherPlan { uint64_t desc_off = 0; uint32_t n_strings = 0; uint64_t out_bytes = 0; uint64_t symbols = 0; uint32_t bits = 6; uint64_t n_list_off = 0, n_list_bytes = 0;
-                    uint32_t sym_of_bit[2] = {0, 1}; };      // binary archives: the coded symbol of a stored 0 / 1 (score 6 / 40 against the archive's threshold)
+                    uint32_t sym_of_bit[2] = {0, 1};      // binary archives: the coded symbol of a stored 0 / 1 (score 6 / 40 against the archive's threshold)
+                    uint32_t qvz = 0; };                  // bits == 6 and qvz: QuaQvzString descriptors, fs_gather_quality_qvz
 
 // Device-side read matcher (matcher.hip): the reads of a bin's match-tree constructions, each construction's reads in
 // processing order; a row of answers per read

@@ -89,12 +89,21 @@ __device__ __noinline__ uint32_t rc_encode_out_of_line(uint32_t model, fs_gptr t
 
 // (the QVZ coder out of line in every kernel: its double-precision quotients and DPP sums are nothing the PPMd walk's register
 // allocation should have to share a function with)
+// (FS_QVZ_WINDOWS=0 builds: the one-symbol form, a wave-wide sum and three dependent loads per symbol -- the A/B partner of the windows)
+#if !defined(FS_QVZ_WINDOWS)
+  #define FS_QVZ_WINDOWS 1
+#endif
 __device__ __noinline__ uint32_t qvz_encode_out_of_line(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32_t n, fs_gptr out, uint32_t cap)
-{ return fsqvz::encode_stream(arena, model, in, n, out, cap); }
+{
+#if defined(__HIP_DEVICE_COMPILE__) && FS_QVZ_WINDOWS
+    return fsqvz::encode_stream_windowed(arena, model, in, n, out, cap);
+#else
+    return fsqvz::encode_stream(arena, model, in, n, out, cap);      // (and what the compiler's host pass parses)
+#endif
+}
 
 // (and the one-symbol loop of the range coders: with every coder but PPMd out of line no kernel spills a vector register any more --
 // the one-wave kernel had 19-37 spilled and 64-136 bytes of scratch per lane all round; 3 072 equal PPMd streams 6.60 -> 6.86 G symbols/s)
-#if defined(FS_RC_ON_CODER_WAVE)
 __device__ __noinline__ bool rc_encode_queued_out_of_line(uint32_t model, fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap,
                                                           FS_LDS fsppmd::Shared* sh, FS_GLOBAL uint32_t* sizeOut, uint32_t* qTail)
 {
@@ -108,7 +117,6 @@ __device__ __noinline__ bool rc_encode_queued_out_of_line(uint32_t model, fs_gpt
     return false;                 // (the host pass of the compiler only parses this)
 #endif
 }
-#endif
 __device__ __noinline__ uint32_t rc_serial_out_of_line(uint32_t model, fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap)
 { return fsrc::encode_model_serial(model, table, pairs, n, out, cap); }
 
@@ -122,7 +130,7 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
         if (threadIdx.x == 0) { sh.qTail = 0u; sh.qHead = 0u; sh.qStarts = 0u; sh.qOpened = 0u; }
         __syncthreads();                               // the workgroup's only barrier: from here on the waves go separate ways
         const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        if (wv == 1u) { fsppmd::coder_wave((FS_LDS fsppmd::Shared*)&sh); return; }
+        if (wv == 1u) { fsppmd::coder_wave<RCWIN>((FS_LDS fsppmd::Shared*)&sh); return; }
     }
     // maps == nullptr: exclusive launch (no other kernel in flight), one arena per workgroup index
     uint32_t slot = blockIdx.x, xcc = 0, word = 0, bit = 0;
@@ -180,7 +188,7 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
         fs_gptr dst = (fs_gptr)(k->out + item.out_off);
         fs_gptr ar = (fs_gptr)arena;
         uint32_t size = 0, rs = 0;
-        bool rcQueued = false;             // (-DFS_RC_ON_CODER_WAVE builds: this stream's size comes from the coder wave)
+        bool rcQueued = false;             // (two-wave kernel with the windowed range coders: this stream's size comes from the coder wave)
         const uint64_t tStream = FS_PROF_NOW();
         if (kind == KIND_PPMD) {
             if (n > 0) {
@@ -190,13 +198,11 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
         } else if (kind == KIND_QVZ) {
             size = qvz_encode_out_of_line(ar, (fs_cgptr)(k->in + item.aux_off), src, n, dst, cap);
         } else {
-#if defined(FS_RC_ON_CODER_WAVE)
-            // (not the product's build: rc_core.h -- the small alphabets' triples coded by the coder wave of the two-wave form)
+            // (rc_core.h: the small alphabets' triples coded by the coder wave of the two-wave form)
             if (TWO && RCWIN && kind - KIND_RC_BASE <= fsrc::M_A8O6) {
                 KernArgs k3 = kernargs();
                 rcQueued = rc_encode_queued_out_of_line(kind - KIND_RC_BASE, ar, src, n, dst, cap, (FS_LDS fsppmd::Shared*)&sh, (FS_GLOBAL uint32_t*)(k3->outSizes + it), &qTail);
             } else
-#endif
             size = RCWIN ? rc_encode_out_of_line(kind - KIND_RC_BASE, ar, src, n, dst, cap) : rc_serial_out_of_line(kind - KIND_RC_BASE, ar, src, n, dst, cap);
         }
         if (threadIdx.x < 16u) {
@@ -308,6 +314,58 @@ __global__ __launch_bounds__(256) void fs_gather_quality_pairs(const QuaPairStri
             const uint32_t ctx = i * ctxMul / len;
             const uint16_t v = (uint16_t)(sym | (ctx << 8));
             __builtin_memcpy(out + 2ull * (d.dst_off + i - before), &v, 2);
+        }
+    }
+}
+
+// fs_gather_quality_qvz -- the quality stream of a --lossy (QVZ) bin, built on the device (SURVEY 8 a8 + f1): per score the
+// conditional quantizer is chosen (column = emitted index, the previous QUANTIZED value, and a 7-bit draw of the archive's
+// WELL-1024a generator against the pair's ratio: choose_quantizer, fastore_pack/quantizer.cpp:522-531), the score is quantized and
+// the place of the quantized value in that quantizer's output alphabet goes to the arithmetic coder with the quantizer's number
+// as its context (IQualityStoreBase::CompressReadQuality, MET_QVZ: FastqCompressor.cpp:318-364).  A read is a chain -- every
+// choice needs the quantized value before it -- but reads are independent, and so are the draws: the generator is re-seeded at
+// every bin and draws once per score in emission order, so draw number d of ANY bin is bits [7 (d mod 4), +7) of its output
+// number d / 4 (well_1024a_bits keeps 28 of an output's 32 bits, well.cpp:42-55), a table the host makes once per archive.
+// One read per lane.  A read the codebook cannot take (longer than its
+// columns, a previous value outside the column's alphabet, a score its quantizer has no entry for) gets the word 0xFFFFFFFF,
+// which the coder kernel answers with the stream's error -- as the host's symbolisation throws.
+__global__ __launch_bounds__(256) void fs_gather_quality_qvz(const QuaQvzString* __restrict__ strings, uint32_t nStrings, const uint8_t* __restrict__ in, uint8_t* __restrict__ out)
+{
+    for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < nStrings; s += gridDim.x * 256u) {
+        const QuaQvzString d = strings[s];
+        const uint8_t* model = in + 16ull * d.model16;
+        const QvzSymHeader* h = (const QvzSymHeader*)model;
+        const uint32_t columns = h->columns, nCtx = h->n_ctx, wellWords = h->well_words;
+        const uint32_t* colCtxBase = (const uint32_t*)(model + h->col_ctx_base_off);
+        const uint16_t* colIndex = (const uint16_t*)(model + h->col_index_off);
+        const uint8_t* qratio = model + h->qratio_off; const uint8_t* quant = model + h->quant_off; const uint8_t* stateOf = model + h->state_of_off;
+        const uint32_t* well = (const uint32_t*)(model + h->well_off);
+        uint32_t* dst = (uint32_t*)(out + d.dst_off);
+        const uint32_t len = d.len;
+        uint32_t prev = 0; bool bad = len > columns;
+        for (uint32_t i = 0; i < len; ++i) {
+            uint32_t w = 0xFFFFFFFFu;
+            if (!bad) {
+                const uint32_t ii = d.reverse ? len - 1u - i : i;
+                const uint64_t bit = d.src_bit + 6ull * ii;
+                const uint32_t two = ((uint32_t)in[bit >> 3] << 8) | in[(bit >> 3) + 1];
+                const uint32_t qv = (two >> (10u - (uint32_t)(bit & 7u))) & 63u;
+                const uint32_t idx = prev < 82u ? colIndex[i * 82u + prev] : 0xFFFFu;
+                const uint32_t dn = d.draw0 + i;
+                if (idx == 0xFFFFu || (dn >> 2) >= wellWords) bad = true;
+                else {
+                    const uint32_t pair = colCtxBase[i] / 2u + idx;
+                    const uint32_t draw = (well[dn >> 2] >> (7u * (dn & 3u))) & 127u;
+                    const uint32_t ctx = 2u * pair + (draw >= qratio[pair] ? 1u : 0u);
+                    if (ctx >= nCtx) bad = true;
+                    else {
+                        const uint32_t st = stateOf[ctx * 72u + qv];
+                        if (st == 0xFFu) bad = true;
+                        else { w = ctx | (st << 24); prev = quant[ctx * 72u + qv]; }
+                    }
+                }
+            }
+            dst[i] = w;
         }
     }
 }
@@ -814,7 +872,7 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     if (ids && (ids->jobs_off & 7u || ids->strings_off & 7u || ids->jobs_off + (uint64_t)ids->n_jobs * sizeof(IdJob) > inputBytes || ids->strings_off + (uint64_t)ids->n_strings * sizeof(IdString) > inputBytes)) {
         snprintf(dev->err, sizeof dev->err, "read-id plan outside the batch input"); return -1;
     }
-    const size_t descBytes = gather ? (gather->bits == 6u ? sizeof(QuaString) : sizeof(QuaPairString)) : 0;
+    const size_t descBytes = gather ? (gather->qvz ? sizeof(QuaQvzString) : (gather->bits == 6u ? sizeof(QuaString) : sizeof(QuaPairString))) : 0;
     if (gather && (gather->desc_off & 15u || gather->desc_off + (uint64_t)gather->n_strings * descBytes > inputBytes || gatherBase + gatherBytes > 0xFFFFFF00ull ||
                    (gather->bits != 6u && gather->bits != 3u && gather->bits != 1u) || (gather->bits != 6u && gather->n_list_off + gather->n_list_bytes > inputBytes))) {
         snprintf(dev->err, sizeof dev->err, "quality gather plan outside the batch input"); return -1;
@@ -856,7 +914,33 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     HIP_TRY(hipMemsetAsync(dev->dSizes, 0xFF, 4ull * nItems, st));          // a size no wave writes reads as 0xFFFFFFFF: the callers' error path, not last launch's value
     if (gather && gather->n_strings) {
         // every string's source and destination inside the buffer, checked here: the kernel trusts its descriptors
-        if (gather->bits == 6u) {
+        if (gather->qvz) {
+            // ... and the tables it reads through them: the library's header, every table and the generator's outputs inside the input
+            if (gather->bits != 6u) { snprintf(dev->err, sizeof dev->err, "QVZ quality gather of other than six-bit scores"); return -1; }
+            const QuaQvzString* qs = (const QuaQvzString*)(input + gather->desc_off);
+            uint64_t lastModel = ~0ull;
+            for (uint32_t i = 0; i < gather->n_strings; ++i) {
+                const uint64_t mo = 16ull * qs[i].model16;
+                if (mo != lastModel) {
+                    QvzSymHeader h;
+                    bool ok = mo + sizeof h <= inputBytes;
+                    if (ok) {
+                        memcpy(&h, input + mo, sizeof h);
+                        const uint64_t end = h.total_bytes;
+                        ok = mo + end <= inputBytes && h.columns >= 1u && h.columns <= 255u && (h.n_ctx & 1u) == 0u && h.n_ctx < (1u << 24) &&
+                             (h.col_ctx_base_off & 3u) == 0u && h.col_ctx_base_off + 4ull * h.columns <= end && (h.col_index_off & 1u) == 0u && h.col_index_off + 164ull * h.columns <= end &&
+                             h.qratio_off + (uint64_t)h.n_ctx / 2u <= end && h.quant_off + 72ull * h.n_ctx <= end && h.state_of_off + 72ull * h.n_ctx <= end &&
+                             (h.well_off & 3u) == 0u && h.well_off + 4ull * h.well_words <= end;
+                        // (a column's first context + an input-alphabet index stays inside the table: the kernel checks ctx < n_ctx itself)
+                    }
+                    if (!ok) { snprintf(dev->err, sizeof dev->err, "QVZ quantizer tables outside the batch input"); return -1; }
+                    lastModel = mo;
+                }
+                if ((qs[i].src_bit >> 3) + (6ull * qs[i].len + 7u) / 8u + 2u > inputBytes || (qs[i].dst_off & 3u) || (uint64_t)qs[i].dst_off + 4ull * qs[i].len > gatherBytes) {
+                    snprintf(dev->err, sizeof dev->err, "quality string %u outside the batch input", i); return -1;
+                }
+            }
+        } else if (gather->bits == 6u) {
             const QuaString* qs = (const QuaString*)(input + gather->desc_off);
             for (uint32_t i = 0; i < gather->n_strings; ++i)
                 if ((qs[i].src_bit >> 3) + (6ull * qs[i].len + 7u) / 8u + 4u > inputBytes || (uint64_t)qs[i].dst_off + qs[i].len > gatherBytes) {
@@ -872,7 +956,10 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         }
         HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[4], st));
         const uint32_t blocks = std::min<uint32_t>((gather->n_strings + 3u) / 4u, (uint32_t)dev->cus * 16u);
-        if (gather->bits == 6u)
+        if (gather->qvz)      // a read per lane
+            hipLaunchKernelGGL(fs_gather_quality_qvz, dim3(std::min<uint32_t>((gather->n_strings + 255u) / 256u, (uint32_t)dev->cus * 32u)), dim3(256), 0, st,
+                               (const QuaQvzString*)(dev->dIn + gather->desc_off), gather->n_strings, (const uint8_t*)dev->dIn, (uint8_t*)(dev->dIn + gatherBase));
+        else if (gather->bits == 6u)
             hipLaunchKernelGGL(fs_gather_quality, dim3(blocks), dim3(256), 0, st, (const QuaString*)(dev->dIn + gather->desc_off), gather->n_strings,
                                (const uint8_t*)dev->dIn, (uint8_t*)(dev->dIn + gatherBase));
         else
@@ -921,13 +1008,11 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
             else if (it.kind != KIND_QVZ && it.kind - KIND_RC_BASE <= fsrc::M_A8O6) sumRc += it.in_len;
         }
         bool rcWin = sumRc >= 4096u && 4u * sumRc >= sumPpmd;
-#if defined(FS_RC_ON_CODER_WAVE)
         {   // the coder wave takes the range coder's pass: worth a second wave per stream where a long range-coded stream ends the launch
             uint32_t maxRc = 0;
             for (const auto& it : items) if (it.kind != KIND_PPMD && it.kind != KIND_QVZ && it.kind - KIND_RC_BASE <= fsrc::M_A8O6) maxRc = std::max(maxRc, it.in_len);
             if (rcWin && maxRc >= (256u << 10) && !getenv("FS_WAVES") && !getenv("FS_TWO_WAVE")) waves = 2u;
         }
-#endif
         if (const char* rw = getenv("FS_RC_WINDOWS")) rcWin = atoi(rw) != 0;
         if (waves == 2u) { const uint32_t g2 = std::max(1u, std::min(grid, dev->nWaves / 2u)); if (rcWin) hipLaunchKernelGGL(fs_encode_streams2_w, dim3(g2), dim3(128), 0, st, ka); else hipLaunchKernelGGL(fs_encode_streams2, dim3(g2), dim3(128), 0, st, ka); }
         else if (rcWin) hipLaunchKernelGGL(fs_encode_streams_w, dim3(grid), dim3(64), 0, st, ka);
@@ -949,7 +1034,8 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         if (gather && gather->n_strings) {
             float g = 0; (void)hipEventElapsedTime(&g, (hipEvent_t)dev->ev[4], (hipEvent_t)dev->ev[5]);
             timing->gather_ms += g; timing->gather_symbols += gather->symbols;
-            timing->gather_bytes += gather->bits == 6u ? gather->symbols + (gather->symbols * 3u + 3u) / 4u : 2u * gather->symbols + (gather->symbols * gather->bits + 7u) / 8u;
+            timing->gather_bytes += gather->qvz ? 4u * gather->symbols + (gather->symbols * 3u + 3u) / 4u + gather->symbols / 4u
+                                                : (gather->bits == 6u ? gather->symbols + (gather->symbols * 3u + 3u) / 4u : 2u * gather->symbols + (gather->symbols * gather->bits + 7u) / 8u);
         }
         for (uint32_t i = 0; i < nItems; ++i) { timing->restarts += restarts[16ull * i]; if (items[i].kind == KIND_PPMD) timing->max_restarts = std::max<uint64_t>(timing->max_restarts, restarts[16ull * i]); for (int k = 1; k < 16; ++k) timing->win[k] += restarts[16ull * i + k]; if (items[i].kind == KIND_PPMD) timing->ppmd_symbols += items[i].in_len; else timing->rc_symbols += items[i].in_len; }
     }
@@ -991,6 +1077,7 @@ int gather_quality_raw(Device* dev, const uint8_t* input, size_t inputBytes, con
     HIP_TRY(hipSetDevice(dev->deviceId));
     hipStream_t st = (hipStream_t)dev->stream;
     const uint64_t gatherBase = ((uint64_t)inputBytes + 15u) & ~15ull;
+    if (plan.qvz) { snprintf(dev->err, sizeof dev->err, "the QVZ gather runs inside a batch (its tables travel with the streams)"); return -1; }
     const size_t descBytes = plan.bits == 6u ? sizeof(QuaString) : sizeof(QuaPairString);
     if (plan.desc_off & 15u || plan.desc_off + (uint64_t)plan.n_strings * descBytes > inputBytes || (plan.bits != 6u && plan.bits != 3u && plan.bits != 1u) ||
         (plan.bits != 6u && plan.n_list_off + plan.n_list_bytes > inputBytes)) { snprintf(dev->err, sizeof dev->err, "quality gather plan outside the input"); return -1; }

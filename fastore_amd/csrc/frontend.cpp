@@ -932,7 +932,7 @@ struct BinEncoder::Impl {
     void refQuality(const uint8_t* s, uint32_t bit, uint32_t len, bool reverse)
     {
         QuaRef r{bit, (uint16_t)len, (uint8_t)(reverse ? 1 : 0), 0, (uint32_t)out->quaN.size()};
-        if (cfg.quaParams.method != MET_NONE) {                      // the scores under an 'N' are left out
+        if (cfg.quaParams.method == MET_8BIN || cfg.quaParams.method == MET_BINARY) {      // the scores under an 'N' are left out (QVZ codes them all)
             uint32_t cnt = 0;
             for (const uint8_t* q = (const uint8_t*)memchr(s, 'N', len); q; q = (const uint8_t*)memchr(q + 1, 'N', (size_t)(s + len - q - 1))) { out->quaN.push_back((uint8_t)(q - s)); ++cnt; }
             r.nCount = (uint8_t)cnt;                                 // len <= 255, and a read of nothing but 'N' has no signature

@@ -255,14 +255,16 @@ template <int FW, bool MULTI> __global__ __launch_bounds__(MULTI ? 1024 : 64) vo
 // lane per base, the entry's bases from HBM (L2-resident: the bin's own bases), the mate's from LDS, ballot + popcount -- and
 // the cheapest goes to an LDS atomic minimum over (cost, order, list index).  The entry the pair replaces is rewritten by
 // its thread.  Rows come back as the host's serial search computes them (checked pair by pair: fsgpu_pe_matcher_check).
-enum : uint32_t { kMateThreads = 1024, kMateCand = 2048, kMateNone = 0xFFFFFFFFu };
+// (the list holds (entry, listed signature) pairs -- at most four per entry, so kMateCand = 4 x kMateThreads can never overflow; the
+// up to four alignments of a pair are made by the wavefront that prices it)
+enum : uint32_t { kMateThreads = 1024, kMateCand = 4096, kMateNone = 0xFFFFFFFFu };
 struct MateShared {
     uint32_t mate[64];                      // the current mate's bases (bytes)
     uint32_t sigAt[256];                    // per position: its signature if it is a member of set 1 / set 2, else kMateNone
     uint32_t bmA[2048], bmB[2048], valid[2048];
     uint32_t entSig[4][kMateThreads];       // per history entry: signature | position << 16 of its four slots (0 = unused: position 0 still counts)
     uint32_t entOff[kMateThreads], entLen[kMateThreads], entPair[kMateThreads], entStamp[kMateThreads], entLive[kMateThreads];
-    uint32_t candE[kMateCand], candKey[kMateCand]; int32_t candShift[kMateCand];
+    uint32_t candE[kMateCand], candKey[kMateCand]; uint32_t candPos[kMateCand];      // entry, (signature, age) key, the signature's first position in the mate
     uint32_t small1[4], small2[4];          // the sets' smallest members: signature << 8 | first position
     uint32_t nCand, size1, size2, overflow;
     unsigned long long best;
@@ -340,18 +342,9 @@ __global__ __launch_bounds__(kMateThreads) void fs_match_mates(const MateJob* __
                 uint32_t posH = 0;
                 for (; posH < 256u && sh.sigAt[posH] != sj; ++posH) {}
                 if (posH >= 256u) continue;
-                int32_t seen[4]; uint32_t nSeen = 0;
-                for (uint32_t k = 0; k < 4u; ++k) {
-                    const int32_t shift = (int32_t)(sh.entSig[k][tid] >> 16) - (int32_t)posH;
-                    if (shift > 127 || shift < -127) continue;
-                    bool dup = false;
-                    for (uint32_t q = 0; q < nSeen; ++q) dup = dup || seen[q] == shift;            // the same alignment again: the earlier one decides
-                    if (dup) continue;
-                    seen[nSeen++] = shift;
-                    const uint32_t at = atomicAdd(&sh.nCand, 1u);
-                    if (at < kMateCand) { sh.candE[at] = tid; sh.candShift[at] = shift; sh.candKey[at] = (sj << 12) | (rank << 2) | k; }
-                    else sh.overflow = 1u;
-                }
+                const uint32_t at = atomicAdd(&sh.nCand, 1u);
+                if (at < kMateCand) { sh.candE[at] = tid; sh.candPos[at] = posH; sh.candKey[at] = (sj << 12) | (rank << 2); }
+                else sh.overflow = 1u;                                                           // (cannot happen: four per entry at most)
             }
         }
         __syncthreads();
@@ -360,7 +353,17 @@ __global__ __launch_bounds__(kMateThreads) void fs_match_mates(const MateJob* __
             const uint32_t nCand = sh.nCand < kMateCand ? sh.nCand : (uint32_t)kMateCand;
             const uint8_t* mb = (const uint8_t*)sh.mate;
             for (uint32_t c = wave; c < nCand; c += kMateThreads / 64u) {
-                const uint32_t e = sh.candE[c]; const int32_t shift = sh.candShift[c];
+              const uint32_t e = sh.candE[c]; const int32_t posH = (int32_t)sh.candPos[c];
+              // the entry's FOUR stored positions against the signature's position in the mate (unused zeros included, as the
+              // reference does); the same alignment again: the earlier one decides
+              int32_t seen[4]; uint32_t nSeen = 0;
+              for (uint32_t k = 0; k < 4u; ++k) {
+                const int32_t shift = (int32_t)(sh.entSig[k][e] >> 16) - posH;
+                if (shift > 127 || shift < -127) continue;
+                bool dup = false;
+                for (uint32_t q = 0; q < nSeen; ++q) dup = dup || seen[q] == shift;
+                if (dup) continue;
+                seen[nSeen++] = shift;
                 const uint32_t recOff = shift < 0 ? (uint32_t)-shift : 0u, lzOff = shift > 0 ? (uint32_t)shift : 0u;
                 const uint32_t lzLen = sh.entLen[e], a = plen - recOff, b = lzLen - lzOff, minLen = a < b ? a : b;
                 const uint8_t* lz = seq + sh.entOff[e] + lzOff;
@@ -371,7 +374,8 @@ __global__ __launch_bounds__(kMateThreads) void fs_match_mates(const MateJob* __
                 }
                 const uint32_t ashift = (uint32_t)(shift < 0 ? -shift : shift);
                 const uint32_t cost = ashift * (uint32_t)par.shift_cost + mism * (uint32_t)par.mismatch_cost;
-                if (lane == 0u && cost < 255u) atomicMin(&sh.best, ((unsigned long long)cost << 44) | ((unsigned long long)sh.candKey[c] << 12) | c);
+                if (lane == 0u && cost < 255u) atomicMin(&sh.best, ((unsigned long long)cost << 44) | ((unsigned long long)(sh.candKey[c] | k) << 12) | c);
+              }
             }
         }
         __syncthreads();
@@ -381,7 +385,8 @@ __global__ __launch_bounds__(kMateThreads) void fs_match_mates(const MateJob* __
         if (best != ~0ull) {
             cost = (uint32_t)(best >> 44);
             const uint32_t cc = (uint32_t)(best & 0xFFFull);
-            const uint32_t e = sh.candE[cc]; shift = sh.candShift[cc];
+            const uint32_t e = sh.candE[cc], kk = (uint32_t)(best >> 12) & 3u;
+            shift = (int32_t)(sh.entSig[kk][e] >> 16) - (int32_t)sh.candPos[cc];
             prevId = frontPushes - sh.entStamp[e] - 1u; matchPair = sh.entPair[e];
             const uint32_t ashift = (uint32_t)(shift < 0 ? -shift : shift);
             noMism = cost == ashift * (uint32_t)par.shift_cost;

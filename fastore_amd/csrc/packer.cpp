@@ -170,7 +170,8 @@ void ArchiveWriter::start(const std::string& prefix, const BinModuleConfigRaw& c
     prefix_ = prefix;
     meta_ = fopen((prefix + ".cmeta").c_str(), "wb");
     data_ = fopen((prefix + ".cdata").c_str(), "w+b");      // (read access too: the blocks go in through a shared mapping)
-    if (!meta_ || !data_) throw std::runtime_error("Cannot open file: " + prefix + ".cmeta/.cdata");
+    // (FileStreamWriter, fastore_bin/FileStream.cpp:305; ArchiveFileWriter opens the .cmeta first, fastore_pack/ArchiveFile.cpp:44-50)
+    if (!meta_ || !data_) throw std::runtime_error("Cannot open file to write: " + prefix + (!meta_ ? ".cmeta" : ".cdata"));
     memset(&conf_, 0, sizeof conf_);                       // padding bytes are zero here (stack garbage in the reference)
     conf_.archType = cfg.archiveType; conf_.minParams = cfg.minimizer;
     conf_.quaParams.method = cfg.quaParams.method; conf_.quaParams.binaryThreshold = cfg.quaParams.binaryThreshold;
@@ -304,7 +305,7 @@ void ArchiveWriter::writeMeta(const std::string& prefix, const std::vector<uint6
     ArchiveWriter w;
     w.prefix_ = prefix; w.conf_ = conf_; w.sizes_ = sizes; w.sigs_ = sigs;
     w.meta_ = fopen((prefix + ".cmeta").c_str(), "wb");
-    if (!w.meta_) throw std::runtime_error("Cannot open file: " + prefix + ".cmeta");
+    if (!w.meta_) throw std::runtime_error("Cannot open file to write: " + prefix + ".cmeta");
     static const uint8_t zeros[24] = {0};
     if (fwrite(zeros, 1, 24, w.meta_) != 24) throw std::runtime_error("Cannot write " + prefix + ".cmeta");
     w.finish(head, qvz);
@@ -765,12 +766,19 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 idFieldBlob(archives[a].head, idTab[a], idTok[a], idVal[a]);
                 idTabOff[a] = inBytes; inBytes += (idTab[a].size() + 15) & ~15ull;
             }
+            // ... and, when the device symbolises their scores (fs_gather_quality_qvz), the quantizer tables and as many outputs of the
+            // archive's generator as the slice's longest stream of that library draws from (four 7-bit draws per output)
+            std::vector<uint64_t> qvzSymOff(archives.size(), ~0ull); std::vector<uint32_t> qvzWell(archives.size(), 0);
             for (uint32_t k = 0; k < count; ++k) {
-                const uint32_t a = binArch[byWork[first + k]];
-                if (archives[a].cfg.quaParams.method != MET_QVZ || qvzOff[a] != ~0ull) continue;
+                const uint32_t b = byWork[first + k], a = binArch[b];
+                if (archives[a].cfg.quaParams.method != MET_QVZ) continue;
+                if (!st[b].quaRefs.empty()) qvzWell[a] = std::max<uint32_t>(qvzWell[a], (uint32_t)(st[b].quaSymbols / 4u + 2u));
+                if (qvzOff[a] != ~0ull) continue;
                 if (!archives[a].qvz.present) throw std::runtime_error("QVZ archive without its codebook (fsgpu_set_quality_codebook)");
                 qvzOff[a] = inBytes; inBytes += (archives[a].qvz.blob.size() + 15) & ~15ull;
             }
+            for (size_t a = 0; a < archives.size(); ++a) if (qvzWell[a]) { qvzSymOff[a] = inBytes; inBytes += (archives[a].qvz.symBlobBytes(qvzWell[a]) + 15u) & ~15ull; }
+            bool gatherQvz = false;
             for (uint32_t k = 0; k < count; ++k) {
                 const uint32_t b = byWork[first + k];
                 const BinIn& bin = info[b]; BinStreams& bs = st[b];
@@ -786,15 +794,17 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 for (uint32_t s = 0; s < bs.nStreams; ++s) {
                     const bool rc = streamIsRangeCoded(s, qm);
                     if (s == S_Quality && !bs.quaRefs.empty()) {       // device-side quality path: the stream is gathered on the device
-                        if (!bs.quaPacked || qm == MET_QVZ) throw std::runtime_error("quality references without packed scores");
-                        const uint32_t bits = qm == MET_NONE ? 6u : (qm == MET_8BIN ? 3u : 1u);
-                        if (gatherBits && gatherBits != bits) throw std::runtime_error("libraries of different quality modes in one device batch");
-                        gatherBits = bits;
-                        if (bs.quaSymbols > 0x70000000ull) throw std::runtime_error("stream larger than 4 GiB");
+                        if (!bs.quaPacked) throw std::runtime_error("quality references without packed scores");
+                        const bool qvzQ = qm == MET_QVZ;
+                        const uint32_t bits = (qm == MET_NONE || qvzQ) ? 6u : (qm == MET_8BIN ? 3u : 1u);
+                        if (gatherBits && (gatherBits != bits || gatherQvz != qvzQ)) throw std::runtime_error("libraries of different quality modes in one device batch");
+                        gatherBits = bits; gatherQvz = qvzQ;
+                        if (bs.quaSymbols > (qvzQ ? 0x38000000ull : 0x70000000ull)) throw std::runtime_error("stream larger than 4 GiB");
                         StreamItem it; memset(&it, 0, sizeof it);
                         it.bin = k;
-                        const uint64_t outBytes = rc ? 2ull * bs.quaSymbols : bs.quaSymbols;      // (symbol, context) pairs for the range coder, bytes for PPMd
-                        if (rc) { it.kind = KIND_RC_BASE + streamModel(s, qm); it.in_len = (uint32_t)bs.quaSymbols; it.out_cap = 2 * it.in_len + 32; pl.work_size[s] = ~0ull; }
+                        const uint64_t outBytes = qvzQ ? 4ull * bs.quaSymbols : (rc ? 2ull * bs.quaSymbols : bs.quaSymbols);      // (context, state) words for the QVZ coder, (symbol, context) pairs for the range coder, bytes for PPMd
+                        if (qvzQ) { it.kind = KIND_QVZ; it.in_len = (uint32_t)bs.quaSymbols; it.out_cap = 3 * it.in_len + 64; it.aux_off = qvzOff[binArch[b]]; pl.work_size[s] = ~0ull; }
+                        else if (rc) { it.kind = KIND_RC_BASE + streamModel(s, qm); it.in_len = (uint32_t)bs.quaSymbols; it.out_cap = 2 * it.in_len + 32; pl.work_size[s] = ~0ull; }
                         else { it.kind = KIND_PPMD; it.in_len = (uint32_t)bs.quaSymbols; it.out_cap = (uint32_t)(bs.quaSymbols + bs.quaSymbols / 8 + 64); pl.work_size[s] = bs.quaSymbols; }
                         it.in_off = gatherBytes;                         // relative to the gather region for now (its base is known after the layout)
                         gatherBytes += (outBytes + 15u + 16u) & ~15ull;
@@ -845,8 +855,8 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             fsdev::GatherPlan gp; uint64_t gatherBaseQ = 0;
             if (nStrings) {
                 if (nStrings > 0xFFFFFFF0ull || gatherBytes > 0xF0000000ull) throw std::runtime_error("quality gather larger than 4 GiB");
-                gp.desc_off = inBytes; gp.n_strings = (uint32_t)nStrings; gp.out_bytes = gatherBytes; gp.symbols = gatherSymbols; gp.bits = gatherBits;
-                inBytes += (nStrings * (gatherBits == 6u ? sizeof(fsdev::QuaString) : sizeof(fsdev::QuaPairString)) + 15u) & ~15ull;
+                gp.desc_off = inBytes; gp.n_strings = (uint32_t)nStrings; gp.out_bytes = gatherBytes; gp.symbols = gatherSymbols; gp.bits = gatherBits; gp.qvz = gatherQvz ? 1u : 0u;
+                inBytes += (nStrings * (gatherQvz ? sizeof(fsdev::QuaQvzString) : (gatherBits == 6u ? sizeof(fsdev::QuaString) : sizeof(fsdev::QuaPairString))) + 15u) & ~15ull;
                 if (gatherBits != 6u) {
                     if (nListBytes > 0xFFFFFFF0ull) throw std::runtime_error("quality gather larger than 4 GiB");
                     gp.n_list_off = inBytes; gp.n_list_bytes = nListBytes; inBytes += (nListBytes + 15u) & ~15ull;
@@ -876,6 +886,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             S.bufMs = nowMs() - tb;
             if (!input) throw std::runtime_error(std::string("device: ") + L->err);
             for (size_t a = 0; a < archives.size(); ++a) if (qvzOff[a] != ~0ull) memcpy(input + qvzOff[a], archives[a].qvz.blob.data(), archives[a].qvz.blob.size());
+            for (size_t a = 0; a < archives.size(); ++a) if (qvzSymOff[a] != ~0ull) archives[a].qvz.writeSymBlob(input + qvzSymOff[a], qvzWell[a]);
             for (size_t a = 0; a < archives.size(); ++a) if (idTabOff[a] != ~0ull) memcpy(input + idTabOff[a], idTab[a].data(), idTab[a].size());
             if (!idJobs.empty()) {
                 memcpy(input + ip.jobs_off, idJobs.data(), idJobs.size() * sizeof(fsdev::IdJob));
@@ -909,7 +920,16 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                     // input size rounded up to 16, see encode_batch)
                     uint64_t dst = S.items[pl.first_item + S_Quality].in_off - ((inBytes + 15u) & ~15ull);
                     const uint64_t srcBase = 8ull * packedOff[k], maxBit = 8ull * st[b].quaPackedBytes;
-                    if (gp.bits == 6u) {
+                    if (gp.qvz) {
+                        fsdev::QuaQvzString* qs = (fsdev::QuaQvzString*)(input + gp.desc_off) + stringBase[k];
+                        const uint32_t model16 = (uint32_t)(qvzSymOff[binArch[b]] >> 4);
+                        uint32_t draw = 0;
+                        for (const QuaRef& r : st[b].quaRefs) {
+                            if ((uint64_t)r.bit + 6ull * r.len > maxBit) throw std::runtime_error("Corrupted bin: quality string outside the bin's quality bytes");
+                            qs->src_bit = srcBase + r.bit; qs->dst_off = (uint32_t)dst; qs->draw0 = draw; qs->model16 = model16; qs->len = r.len; qs->reverse = r.reverse; ++qs;
+                            dst += 4ull * r.len; draw += r.len;
+                        }
+                    } else if (gp.bits == 6u) {
                         fsdev::QuaString* qs = (fsdev::QuaString*)(input + gp.desc_off) + stringBase[k];
                         for (const QuaRef& r : st[b].quaRefs) {
                             if ((uint64_t)r.bit + 6ull * r.len > maxBit) throw std::runtime_error("Corrupted bin: quality string outside the bin's quality bytes");
@@ -1373,8 +1393,9 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             // device-side quality path: lossless archives keep their scores packed (fs_gather_quality unpacks, orients and
             // orders them on the device); FS_DEVICE_QUALITY=0 keeps the host symbolisation (A/B runs)
             bool packedQ = !(getenv("FS_DEVICE_QUALITY") && atoi(getenv("FS_DEVICE_QUALITY")) == 0);
-            // (all libraries of the batch must share one mode: lossless bytes, or the (symbol, context) pairs of 8-bin / binary)
-            for (uint32_t k = 0; k < nb; ++k) { const uint32_t qmk = archives[work[first + k].lib].cfg.quaParams.method; if (qmk == MET_QVZ || qmk != archives[work[first].lib].cfg.quaParams.method) packedQ = false; }
+            // (all libraries of the batch must share one mode: lossless bytes, the (symbol, context) pairs of 8-bin / binary, or the
+            // (context, state) words of --lossy archives -- those may each bring a codebook of their own)
+            for (uint32_t k = 0; k < nb; ++k) { const uint32_t qmk = archives[work[first + k].lib].cfg.quaParams.method; if (qmk != archives[work[first].lib].cfg.quaParams.method) packedQ = false; }
             for (uint32_t k = 0; k < nb; ++k) {
                 const BinInfo& bi = libs[work[first + k].lib]->bf.bins().at(work[first + k].sig);
                 seqBase[k + 1] = seqBase[k] + bi.totalRawDnaSize; headBase[k + 1] = headBase[k] + bi.totalRawHeadSize; recBase[k + 1] = recBase[k] + bi.totalRecordsCount;
@@ -1389,7 +1410,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             for (uint32_t k = 0; k < nb; ++k) {
                 const BinInfo& bi = libs[work[first + k].lib]->bf.bins().at(work[first + k].sig);
                 const uint32_t qmk = archives[work[first + k].lib].cfg.quaParams.method;
-                const uint64_t q = packedQ ? bi.totalQuaSize : (qmk == MET_NONE ? bi.totalRawDnaSize : (qmk == MET_QVZ ? 4ull : 2ull) * bi.totalRawDnaSize);
+                const uint64_t q = packedQ ? bi.totalQuaSize + (qmk == MET_QVZ ? bi.totalRawDnaSize / 4u * 4u + (2ull << 20) : 0ull) : (qmk == MET_NONE ? bi.totalRawDnaSize : (qmk == MET_QVZ ? 4ull : 2ull) * bi.totalRawDnaSize);
                 stageEstimate[k] = q + (packedH ? bi.totalHeadSize : 2ull * bi.totalRawHeadSize) + 80ull * bi.totalRecordsCount;
             }
             if (seqBase[nb] > 0xFFFFFFF0ull || headBase[nb] > 0xFFFFFFF0ull || recBase[nb] > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB");

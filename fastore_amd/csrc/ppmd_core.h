@@ -327,7 +327,7 @@ FS_DEV void FreeUnits(Coder& m, uint32_t ptr, uint32_t NU)
 //                      the total 2^14 (Model.cpp:415-432: range >>= TOT_BITS is the division by it)
 //   A = 0xFFFFFFFF     command M: stream start (header bytes), stream end (flush, size), exit
 enum : uint32_t { CQ_SIZE = 256u, CQ_SERIAL = 0x80000000u, CQ_CMD = 0xFFFFFFFFu, CQ_START = 1u, CQ_END = 2u, CQ_EXIT = 3u,
-                  // -DFS_RC_ON_CODER_WAVE builds (not the product's yet): a range-coded stream's triples through the same ring.  Entry:
+                  // a range-coded stream's triples through the same ring (coder_wave<true>: the kernel with the windowed range coders).  Entry:
                   // A = cumulative frequency | (frequency & 0x3FFF) << 16 | CQ_RC ; M = total | (frequency >> 14) << 16
                   CQ_START_RC = 4u, CQ_END_RC = 5u, CQ_END_RC_BAD = 6u, CQ_RC = 1u << 30 };
 
@@ -382,7 +382,11 @@ FS_DEV void cq_send_exit(FS_LDS Shared* sh, uint32_t qTail)
 #else
 FS_DEV void cq_push(Coder&, uint32_t, uint32_t) {}
 FS_DEV void cq_send_exit(FS_LDS Shared*, uint32_t) {}
-FS_DEV void coder_wave(FS_LDS Shared*) {}
+#if defined(__HIPCC__)      // (the compiler's host pass over a kernel that names the template: it must find a callable declaration)
+template <bool RC> __host__ __device__ inline void coder_wave(FS_LDS Shared*) {}
+#else
+template <bool RC> FS_DEV void coder_wave(FS_LDS Shared*) {}
+#endif
 #endif
 
 // after a coding step (Model.cpp:569, 580)
@@ -1147,16 +1151,16 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
 #if FS_WIDE
 // The coder wave of the two-wave form: works the entries of the ring off in order (see the range-coder section).  Runs
 // until the exit command; every wait is for the model wave, which never waits for anything but ring space.
-FS_DEV void coder_wave(FS_LDS Shared* sh)
+// RC: the wave also owns the range coder of rc_core.h (64-bit low) for the range-coded streams whose triples come through the ring
+// (fs_encode_streams2_w); the kernel every lossless launch takes instantiates coder_wave<false> and carries none of it.
+template <bool RC> FS_DEV void coder_wave(FS_LDS Shared* sh)
 {
     Coder m;                                                   // only the coder's own fields are used here
     m.sh = sh; m.queued = 0; m.low = 0; m.range = 0xFFFFFFFFu; m.out = nullptr; m.outCap = 0; m.outPos = 0;
     FS_GLOBAL uint32_t* sizeOut = nullptr;
     const uint32_t lane = (uint32_t)FS_LANE();
     uint32_t head = 0, starts = 0;
-#if defined(FS_RC_ON_CODER_WAVE)
-    uint64_t rcLow = 0; uint32_t rcRange = 0xFFFFFFFFu; bool rcMode = false;      // the range coder of rc_core.h (64-bit low) while a range-coded stream is open
-#endif
+    uint64_t rcLow = 0; uint32_t rcRange = 0xFFFFFFFFu; bool rcMode = false;      // (RC) the range coder of rc_core.h (64-bit low) while a range-coded stream is open
     for (;;) {
         uint32_t tail;
         for (;;) { tail = FS_Q_LOAD(sh->qTail); if (tail != head) break; FS_Q_IDLE(); }
@@ -1166,15 +1170,12 @@ FS_DEV void coder_wave(FS_LDS Shared* sh)
         head += n;
         FS_Q_STORE(sh->qHead, head);                            // the batch is in registers: its slots are free again
         const bool special = lane < n && (eA >> 31) != 0u;
-#if defined(FS_RC_ON_CODER_WAVE)
         uint32_t eL = 1u;
-        if (lane < n && !special && (eA & CQ_RC) != 0u) {       // a range-coded stream's triple: frequency | cumulative frequency, reciprocal of the total
+        if (RC && lane < n && !special && (eA & CQ_RC) != 0u) {       // a range-coded stream's triple: frequency | cumulative frequency, reciprocal of the total
             const uint32_t F = ((eA >> 16) & 0x3FFFu) | (((eM >> 16) & 3u) << 14), LO = eA & 0xFFFFu;
             const Recip rc = recip_make(eM & 0xFFFFu);
             eA = LO | (F << 16); eM = rc.mul; eL = rc.l;
-        } else
-#endif
-        if (lane < n && !special) {                             // all the batch's reciprocals at once
+        } else if (lane < n && !special) {                             // all the batch's reciprocals at once
             const Recip rc = recip_make(eM);
             eA = (eA & 0x00FFFFFFu) | ((rc.l - 1u) << 24); eM = rc.mul;
         }
@@ -1183,8 +1184,7 @@ FS_DEV void coder_wave(FS_LDS Shared* sh)
         for (uint32_t i = 0; i < n;) {
             const uint64_t ahead = todo >> i;
             const uint32_t stop = ahead ? i + fs_ctz64(ahead) : n;
-#if defined(FS_RC_ON_CODER_WAVE)
-            if (rcMode) {      // RangeEncoder::EncodeFrequency (rc/RangeCoder.h:40-84) over the triples [i, stop)
+            if (RC && rcMode) {      // RangeEncoder::EncodeFrequency (rc/RangeCoder.h:40-84) over the triples [i, stop)
                 for (; i < stop; ++i) {
                     const uint32_t FL = FS_UNI(fs_readlane(eA, i)), M0 = FS_UNI(fs_readlane(eM, i)), L0 = FS_UNI(fs_readlane(eL, i));
                     rcRange = recip_div(rcRange, M0, L0);
@@ -1197,7 +1197,6 @@ FS_DEV void coder_wave(FS_LDS Shared* sh)
                     }
                 }
             }
-#endif
             // plain hits [i, stop): Coder.hpp:13-17 with the division by multiplication, then Model.cpp:580
             #define FS_CODE_ONE(A_, M_) do { \
                 const uint32_t t_ = fs_mulhi(m.range, M_), rr_ = (t_ + ((m.range - t_) >> 1)) >> (A_ >> 24); \
@@ -1228,19 +1227,16 @@ FS_DEV void coder_wave(FS_LDS Shared* sh)
             } else if (M == CQ_END) {
                 for (int k = 0; k < 4; k++) { put_byte(m, m.low >> 24); m.low <<= 8; }
                 if (sizeOut) *sizeOut = m.outPos;
-#if defined(FS_RC_ON_CODER_WAVE)
-            } else if (M == CQ_START_RC) {
+            } else if (RC && M == CQ_START_RC) {
                 FS_LDS uint32_t* box = sh->qBox[starts & 1u];
                 const uint64_t o = (uint64_t)FS_LDS_RD(box[0]) | ((uint64_t)FS_LDS_RD(box[1]) << 32), z = (uint64_t)FS_LDS_RD(box[3]) | ((uint64_t)FS_LDS_RD(box[4]) << 32);
                 m.out = (fs_gptr)(uintptr_t)o; sizeOut = (FS_GLOBAL uint32_t*)(uintptr_t)z; m.outCap = FS_LDS_RD(box[2]); m.outPos = 0;
                 ++starts; FS_Q_STORE(sh->qStarts, starts);
                 rcLow = 0; rcRange = 0xFFFFFFFFu; rcMode = true;
-
-            } else if (M == CQ_END_RC || M == CQ_END_RC_BAD) {
+            } else if (RC && (M == CQ_END_RC || M == CQ_END_RC_BAD)) {
                 for (int k = 0; k < 8; k++) { rc_put(m, (uint32_t)(rcLow >> 56)); rcLow <<= 8; }      // TEncoder::End: eight flush bytes
                 if (sizeOut) *sizeOut = M == CQ_END_RC ? m.outPos : 0xFFFFFFFFu;
                 rcMode = false;
-#endif
             } else return;                                      // CQ_EXIT
         }
     }

@@ -3,6 +3,7 @@
 #include <string.h>
 #include <stdexcept>
 #include "qvz_core.h"
+#include "device_types.h"
 
 namespace fs {
 namespace {
@@ -129,6 +130,41 @@ void QvzModel::parse(BitReader& r)
         image[desc[i].off] = card[i];
         for (uint32_t k = 0; k < card[i]; ++k) image[desc[i].off + 1 + k] = 1;
     }
+
+    // ---- the quantizer tables for the device's symbolisation (fs_gather_quality_qvz) ----
+    {
+        fsdev::QvzSymHeader sh; memset(&sh, 0, sizeof sh);
+        auto place = [](size_t& at, size_t bytes) { const size_t o = at; at = (at + bytes + 15u) & ~(size_t)15u; return (uint32_t)o; };
+        size_t at = (sizeof sh + 15u) & ~(size_t)15u;
+        sh.columns = columns; sh.n_ctx = nCtx;
+        sh.col_ctx_base_off = place(at, 4ull * columns);
+        sh.col_index_off = place(at, 2ull * columns * QVZ_INDEX_SLOTS);
+        sh.qratio_off = place(at, qratio.size());
+        sh.quant_off = place(at, quant.size());
+        sh.state_of_off = place(at, stateOf.size());
+        sh.total_bytes = (uint32_t)at; sh.well_off = (uint32_t)at; sh.well_words = 0;
+        symBlob.assign(at, 0);
+        memcpy(symBlob.data(), &sh, sizeof sh);
+        memcpy(symBlob.data() + sh.col_ctx_base_off, colCtxBase.data(), 4ull * columns);
+        memcpy(symBlob.data() + sh.col_index_off, colIndex.data(), 2ull * columns * QVZ_INDEX_SLOTS);
+        memcpy(symBlob.data() + sh.qratio_off, qratio.data(), qratio.size());
+        memcpy(symBlob.data() + sh.quant_off, quant.data(), quant.size());
+        memcpy(symBlob.data() + sh.state_of_off, stateOf.data(), stateOf.size());
+    }
+    well_ = std::make_shared<WellCache>();
+    well_->rng.reset(wellSeed);
+}
+
+void QvzModel::writeSymBlob(uint8_t* dst, uint32_t wellWords) const
+{
+    memcpy(dst, symBlob.data(), symBlob.size());
+    fsdev::QvzSymHeader sh; memcpy(&sh, dst, sizeof sh);
+    sh.well_off = (uint32_t)((symBlob.size() + 15u) & ~(size_t)15u); sh.well_words = wellWords; sh.total_bytes = sh.well_off + 4u * wellWords;
+    memcpy(dst, &sh, sizeof sh);
+    if (!well_) throw std::runtime_error("QVZ model without its generator");
+    std::lock_guard<std::mutex> lk(well_->mx);
+    while (well_->words.size() < wellWords) well_->words.push_back(well_->rng.next());      // (the front of well_1024a_bits: one output per four draws)
+    memcpy(dst + sh.well_off, well_->words.data(), 4ull * wellWords);
 }
 
 void qvzSymbolise(const QvzModel& m, WellRng& rng, const uint8_t* qua, uint32_t len, uint32_t qualityOffset, bool reverse, std::vector<uint8_t>& out)

@@ -7,6 +7,8 @@
 // quantizer.cpp:449-480, PRNG fastore_pack/well.cpp:16-57, per-read loop FastqCompressor.cpp:318-364.
 #pragma once
 #include <stdint.h>
+#include <memory>
+#include <mutex>
 #include <vector>
 #include "bitio.h"
 
@@ -55,9 +57,19 @@ struct QvzModel {
 
     // device blob (fsqvz::ModelHeader, descriptors, initial statistics image): see qvz_core.h
     std::vector<uint8_t> blob;
+    // the quantizer tables as fs_gather_quality_qvz reads them (fsdev::QvzSymHeader + tables, WITHOUT the generator's words)
+    std::vector<uint8_t> symBlob;
+    // fsdev::QvzSymHeader | tables | the generator's first `wellWords` outputs, into dst (symBlobBytes(wellWords) bytes).  The
+    // outputs are the same for every bin of the archive (the generator is re-seeded per bin): made once, kept, extended on demand
+    size_t symBlobBytes(uint32_t wellWords) const { return ((symBlob.size() + 15u) & ~(size_t)15u) + 4ull * wellWords; }
+    void writeSymBlob(uint8_t* dst, uint32_t wellWords) const;
 
     // parses the footer section at the reader's position (byte aligned) and builds everything above
     void parse(BitReader& r);
+
+private:
+    struct WellCache { std::mutex mx; WellRng rng; std::vector<uint32_t> words; };
+    std::shared_ptr<WellCache> well_;           // shared by the copies of one archive's model
 };
 
 // FastqCompressor.cpp:318-364: one read's qualities -> one u32 per position (context | state << 24)

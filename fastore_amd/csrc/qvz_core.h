@@ -159,14 +159,62 @@ FS_DEV uint32_t encode_stream(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32
 }
 
 #if FS_WIDE
-// ---- windowed form (NOT in the product's kernels yet: built with -DFS_QVZ_WINDOWS=1; bit-exact on the lock-step emulation,
-// tests/test_simt.py; unmeasured on the device at the end of round 3) ----
-// A symbol's context is a pure function of the input (the front end put it into the symbol's word), and the contexts of
+// ---- windowed form (the product's kernels since round 4) ----
+// A symbol's context is a pure function of the input (fs_gather_quality_qvz put it into the symbol's word), and the contexts of
 // consecutive symbols differ -- a context belongs to a column -- so 64 lanes take 64 consecutive symbols: every lane fetches
-// its descriptor, its context's total and count, and sums the counts below its symbol from its own block; no wave-wide sum, no
-// chain of three dependent loads per symbol.  A window ends in front of the first symbol that shares its context with an
-// earlier one of the window, whose context is due for a rescale, or that is malformed; that symbol takes the one-symbol step.
-// The arithmetic coder (arith.cpp:33-125) then passes over the window's (low count, count, total) triples in stream order.
+// its descriptor, then its context's total and its counts up to its symbol in one go; no wave-wide sum, no chain of three
+// dependent loads per symbol.  A window ends in front of the first symbol that shares its context with an earlier one of the
+// window, whose context is due for a rescale, or that is malformed; that symbol takes the one-symbol step.  The arithmetic coder
+// (arith.cpp:33-125) then passes over the window's (low count, count, total) triples in stream order -- with the reciprocals of
+// all the window's totals made beforehand, one per lane, and the interval's rescaling in closed form (below).
+//
+// Shared contexts.  Contexts are numbered by column, so inside one read the context numbers of a window rise; a read boundary
+// shows as a descent.  No descent: no two symbols share a context.  One descent at lane b (the usual case when a window holds
+// the end of one read and the start of the next): a symbol of the second read can only share with the first read's part if its
+// context number reaches that of lane 0, the smallest there.  Anything else (reads shorter than a window) is compared pair by pair.
+struct QRecip { double inv; };
+// floor(range * c / total) for range <= 2^22, c <= total < 2^20 (arith.cpp:44-45 computes it by a 64-bit integer division).
+// range * c < 2^42 is exact in a double; times the correctly rounded 1 / total the result is off by less than 2^-29, and a
+// quotient that is not whole is at least 1 / total > 2^-20 away from the next whole number: truncation can only be one short,
+// and only when the division is exact -- which the remainder shows.
+FS_DEV uint32_t q_div(uint32_t range, uint32_t c, uint32_t total, double inv)
+{
+    const double a = (double)range * (double)c;
+    uint32_t q = (uint32_t)(a * inv);
+    const uint64_t r = (uint64_t)range * c - (uint64_t)q * total;
+    q += r >= (uint64_t)total ? 1u : 0u;
+    return q;
+}
+// One symbol through the interval: arithmetic_encoder_step (arith.cpp:33-103), the E1/E2/E3 loop in closed form.  The loop
+// first shifts out the leading bits that l and u share (each is a decided bit; the pending opposite bits follow the first),
+// and only then -- the top bits now differ: l = 0.., u = 1.. -- counts the steps in which l continues 01 and u continues 10
+// (E3: the top bits stay different, so no decided bit can follow).  So: k1 = the length of the common prefix of l and u, k3 = the
+// length of the run, behind the top bit, of positions where l has a one and u a zero.
+FS_DEV void q_code(BitOut& o, uint32_t& l, uint32_t& u, uint32_t& scale3, uint32_t cumLo, uint32_t cnt, uint32_t total, double inv)
+{
+    const uint32_t M22 = (1u << M_BITS) - 1u, clearMask = (1u << (M_BITS - 1)) - 1u;
+    const uint32_t range = u - l + 1u;                       // <= 2^22
+    u = l + q_div(range, cumLo + cnt, total, inv) - 1u;
+    l = l + q_div(range, cumLo, total, inv);
+    const uint32_t x = (l ^ u) & M22;
+    const uint32_t k1 = x ? (uint32_t)__builtin_clz(x) - (32u - M_BITS) : (uint32_t)M_BITS;
+    if (k1) {
+        const uint32_t top = l >> (M_BITS - k1);             // the k1 shared bits, first decided bit on top
+        put_decided(o, top >> (k1 - 1u), scale3);
+        if (k1 > 1u) put_bits(o, top & ((1u << (k1 - 1u)) - 1u), k1 - 1u);
+        l = (l << k1) & M22; u = ((u << k1) | ((1u << k1) - 1u)) & M22;
+    }
+    // (here l = 0.., u = 1.. -- or k1 = 22 and l = 0, u = 2^22 - 1, the same shape)
+    const uint32_t t = (l << 1) & (~u << 1) & M22;            // bit 21 - j: the step j + 1 of the run would be an E3 step
+    const uint32_t nt = ~t & M22;
+    const uint32_t k3 = nt ? (uint32_t)__builtin_clz(nt) - (32u - M_BITS) : (uint32_t)M_BITS - 1u;
+    if (k3) {
+        scale3 += k3;
+        l = (l << k3) & clearMask;
+        u = ((u << k3) & clearMask) | (1u << (M_BITS - 1)) | ((1u << k3) - 1u);
+    }
+}
+
 FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32_t n, fs_gptr out, uint32_t cap)
 {
     const FS_GLOBAL ModelHeader* hdr = (const FS_GLOBAL ModelHeader*)model;
@@ -179,26 +227,8 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr i
 
     BitOut o; o.out = out; o.pos = 0; o.cap = cap; o.acc = 0; o.nb = 0; o.overflow = 0;
     uint32_t l = 0, u = (1u << M_BITS) - 1u, scale3 = 0, bad = 0;
-    const uint32_t msbShift = M_BITS - 1, smsbShift = M_BITS - 2, clearMask = (1u << msbShift) - 1u;
+    const uint32_t msbShift = M_BITS - 1, clearMask = (1u << msbShift) - 1u;
     const FS_GLOBAL uint32_t* sym = (const FS_GLOBAL uint32_t*)in;
-    // one symbol through the interval: arithmetic_encoder_step (arith.cpp:33-78)
-    auto code = [&](uint32_t cumLo, uint32_t cnt, uint32_t total) {
-        const uint64_t range = (uint64_t)u - l + 1u;
-        u = l + (uint32_t)((double)(range * (cumLo + cnt)) / (double)total) - 1u;
-        l = l + (uint32_t)((double)(range * cumLo) / (double)total);
-        for (;;) {
-            const uint32_t msbL = l >> msbShift, msbU = u >> msbShift;
-            if (msbL == msbU) {
-                put_decided(o, msbL, scale3);
-                l = (l & clearMask) << 1;
-                u = ((u & clearMask) << 1) + 1u;
-            } else if ((l >> smsbShift) == 1u && (u >> smsbShift) == 2u) {
-                scale3 += 1u;
-                u = (((u << 1) & clearMask) | (1u << msbShift)) + 1u;
-                l = (l << 1) & clearMask;
-            } else break;
-        }
-    };
     for (uint32_t k = 0; k < n && !bad;) {
         const uint32_t left = FS_UNI(n - k), W = left < 64u ? left : 64u;
         const bool valid = lane < W;
@@ -211,16 +241,37 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr i
         FS_EMU_MEET();
         // an earlier symbol of the window in the same context?
         bool shared = false;
-        for (uint32_t d = 1; d < W; ++d) {
-            const uint32_t other = fs_bperm(ctx, (lane - d) & 63u);
-            shared = shared || (valid && lane >= d && other == ctx);
+        {
+            const uint32_t before = fs_bperm(ctx, (lane + 63u) & 63u);
+            const uint64_t descents = fs_ballot(valid && lane > 0u && ctx <= before);      // (equal neighbours count: they share)
+            bool slow = false;
+            if (descents != 0ull) {
+                const uint32_t b = fs_ctz64(descents), first = fs_readlane(ctx, 0);
+                if ((descents & (descents - 1ull)) != 0ull) slow = true;                   // more than one read boundary in the window
+                else if (fs_ballot(valid && lane >= b && ctx >= first) != 0ull) slow = true;
+            }
+            if (FS_UB(slow))
+                for (uint32_t d = 1; d < W; ++d) {
+                    const uint32_t other = fs_bperm(ctx, (lane - d) & 63u);
+                    shared = shared || (valid && lane >= d && other == ctx);
+                }
         }
-        // my context's total, my symbol's count, the counts below it
+        // my context's total, my symbol's count, the counts below it: the block's first eight words in one go, the rest in turn
         uint32_t total = 1, cnt = 0, cumLo = 0;
         const bool fetch = valid && !wrong;
-        FS_GLOBAL uint32_t* blk = stat + off;
-        if (fetch) { total = blk[0]; cnt = blk[1u + x]; }
-        for (uint32_t j = 0; fs_ballot(fetch && j < x) != 0ull; ++j) if (fetch && j < x) cumLo += blk[1u + j];
+        FS_GLOBAL uint32_t* blk = stat + (fetch ? off : 0u);
+        {
+            uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
+            if (fetch) { b0 = blk[0]; b1 = blk[1]; if (card >= 2u) b2 = blk[2]; if (card >= 3u) b3 = blk[3]; if (card >= 4u) b4 = blk[4]; if (card >= 5u) b5 = blk[5]; if (card >= 6u) b6 = blk[6]; if (card >= 7u) b7 = blk[7]; }
+            total = fetch ? b0 : 1u;
+            cumLo = (x > 0u ? b1 : 0u) + (x > 1u ? b2 : 0u) + (x > 2u ? b3 : 0u) + (x > 3u ? b4 : 0u) + (x > 4u ? b5 : 0u) + (x > 5u ? b6 : 0u) + (x > 6u ? b7 : 0u);
+            cnt = x == 0u ? b1 : (x == 1u ? b2 : (x == 2u ? b3 : (x == 3u ? b4 : (x == 4u ? b5 : (x == 5u ? b6 : b7)))));
+            if (fs_ballot(fetch && x > 6u) != 0ull) {
+                if (fetch && x > 6u) cnt = blk[1u + x];
+                for (uint32_t j = 7u; fs_ballot(fetch && j < x) != 0ull; ++j) if (fetch && j < x) cumLo += blk[1u + j];
+            }
+            if (!fetch) { cumLo = 0; cnt = 0; }
+        }
         FS_EMU_MEET();
         const bool due = fetch && total + STEP > RESCALE_AT;
         const uint64_t stop = fs_ballot(valid && (wrong || shared || due));
@@ -228,8 +279,15 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr i
         // the window's updates: every context is there once
         if (lane < take) { blk[0] = total + STEP; blk[1u + x] = cnt + STEP; }
         FS_EMU_MEET();
+        // every total's reciprocal, all lanes at once
+        const double inv = 1.0 / (double)(total ? total : 1u);
         l = FS_UNI(l); u = FS_UNI(u); scale3 = FS_UNI(scale3);
-        for (uint32_t i = 0; i < take; ++i) code(fs_readlane(cumLo, i), fs_readlane(cnt, i), fs_readlane(total, i));
+        for (uint32_t i = 0; i < take; ++i) {
+            const uint32_t c0 = FS_UNI(fs_readlane(cumLo, i)), c1 = FS_UNI(fs_readlane(cnt, i)), tt = FS_UNI(fs_readlane(total, i));
+            const uint64_t ib = (uint64_t)__builtin_bit_cast(uint64_t, inv);
+            const uint64_t iu = (uint64_t)FS_UNI(fs_readlane((uint32_t)ib, i)) | ((uint64_t)FS_UNI(fs_readlane((uint32_t)(ib >> 32), i)) << 32);
+            q_code(o, l, u, scale3, c0, c1, tt, __builtin_bit_cast(double, iu));
+        }
         k += take;
         if (take < W) {          // symbol k: shares its context, is due for a rescale, or is malformed -- the one-symbol step
             const uint32_t w1 = FS_UNI(fs_readlane(w, take));
@@ -239,7 +297,7 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr i
             if (x1 >= card1 || card1 > MAX_CARD) { bad = 1; break; }
             uint32_t c1, n1, t1;
             model_step(stat + off1, card1, x1, c1, n1, t1);
-            code(c1, n1, t1);
+            q_code(o, l, u, scale3, c1, n1, t1, 1.0 / (double)t1);
             ++k;
         }
     }

@@ -157,9 +157,10 @@ FS_DEV uint32_t encode_stream(fs_gptr table /*16-byte aligned, table_bytes()*/, 
 // triples in stream order, scalar code with one reciprocal per position made by all lanes at once.
 // A position whose row reaches the rescale limit ends the window in front of it and is coded by the one-symbol step.
 // The bytes are those of the loop above by construction: a different schedule of the same updates.
-// q (-DFS_RC_ON_CODER_WAVE builds; not the product's yet): the triples go to the coder wave of the two-wave form through the
-// PPMd walk's ring (ppmd_core.h: coder_wave) instead of being coded here -- the model side of window k + 1 then runs beside
-// the range coder's pass over window k; the stream's size is written by the coder wave, the return value is 0.
+// q (the two-wave kernel with the windowed coders, fs_encode_streams2_w, since round 4): the triples go to the coder wave
+// through the PPMd walk's ring (ppmd_core.h: coder_wave<true>) instead of being coded here -- the model side of window k + 1
+// then runs beside the range coder's pass over window k; the stream's size is written by the coder wave, the return value
+// is 0.  Measured on a lone 7 M-symbol <8,6> stream: 0.110 -> 0.084 us per symbol (profiles/r04_rc_on_coder_wave.txt).
 struct RcQueue { fsppmd::Coder m; FS_GLOBAL uint32_t* sizeOut; };
 template <int BITS, int ORDER, bool ADV, int CTXBITS>
 FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap, RcQueue* q = nullptr)
@@ -183,7 +184,6 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
         FS_WAVE_SYNC();
     }
     Enc e; e.low = 0; e.range = 0xffffffffu; e.out = out; e.cap = cap; e.pos = 0;
-#if defined(FS_RC_ON_CODER_WAVE)
     if (q) {      // hand the coder wave this stream's output buffer (the mailbox protocol of fsppmd::encode_member)
         fsppmd::Coder& m = q->m;
         const uint32_t s = FS_UNI(FS_LDS_RD(m.sh->qOpened));
@@ -197,9 +197,6 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
         FS_WAVE_SYNC();
         fsppmd::cq_push(m, fsppmd::CQ_CMD, fsppmd::CQ_START_RC);
     }
-#else
-    (void)q;
-#endif
     uint64_t hash = 0;                                   // the symbols in front of position k, the latest in the lowest bits
     fs_cgptr16 pairs16 = (fs_cgptr16)pairs;
     for (uint32_t k = 0; k < n;) {
@@ -209,9 +206,7 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
         FS_EMU_MEET();
         const uint32_t sym = pr & 0xFFu, ctx = pr >> 8;
         if (fs_ballot(valid && (sym >= A || (ADV && CTXBITS < 8 && ctx >= (1u << CTXBITS)))) != 0ull) {      // (as the loop above: the stream is given up)
-#if defined(FS_RC_ON_CODER_WAVE)
             if (q) fsppmd::cq_push(q->m, fsppmd::CQ_CMD, fsppmd::CQ_END_RC_BAD);
-#endif
             return 0xFFFFFFFFu;
         }
         // the ORDER symbols in front of every position: from the lanes below, and from `hash` for the first lanes
@@ -275,10 +270,8 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
                 if (writer) *(FS_GLOBAL uint32_t*)st = nv[0] | (nv[1] << 16);
             }
             FS_EMU_MEET();
-#if defined(FS_RC_ON_CODER_WAVE)
             if (q) fsppmd::cq_push_lanes(q->m, lo | ((f & 0x3FFFu) << 16) | fsppmd::CQ_RC, acc | ((f >> 14) << 16), cnt);
             else
-#endif
             {
             // the range coder over the triples, in stream order; range / total by a reciprocal per position (total in [2, 65535])
             uint32_t rmul = 0, rl = 1;
@@ -331,18 +324,14 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
             for (uint32_t j = 0; j < A; ++j) { if (j < s1) lo1 += w[j]; if (j == s1) f1 = w[j]; }
             fs_st16((fs_gptr)(st1 + s1), f1 + 8);
             FS_EMU_MEET();
-#if defined(FS_RC_ON_CODER_WAVE)
             if (q) fsppmd::cq_push(q->m, lo1 | ((f1 & 0x3FFFu) << 16) | fsppmd::CQ_RC, acc1 | ((f1 >> 14) << 16));
             else
-#endif
             encode_freq(e, f1, lo1, acc1);
             hash = (hash << BITS) | s1;
             ++k;
         }
     }
-#if defined(FS_RC_ON_CODER_WAVE)
     if (q) { fsppmd::cq_push(q->m, fsppmd::CQ_CMD, fsppmd::CQ_END_RC); return 0u; }
-#endif
     for (int i = 0; i < 8; ++i) { put(e, (uint32_t)(e.low >> 56)); e.low <<= 8; }
     return e.pos;
 }
@@ -386,7 +375,7 @@ FS_DEV uint32_t encode_model(uint32_t model, fs_gptr table, fs_cgptr pairs, uint
     default: return encode_stream<8, 1, true>(table, pairs, n, out, cap);
     }
 }
-#if FS_WIDE && defined(FS_RC_ON_CODER_WAVE)
+#if FS_WIDE
 // the small alphabets with their triples sent to the coder wave; false: not a model with a windowed form (the caller codes it itself)
 FS_DEV bool encode_model_queued(uint32_t model, fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap, RcQueue* q)
 {

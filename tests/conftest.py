@@ -25,7 +25,7 @@ def pytest_configure(config):
 GPU_TEST_TIMEOUT_S = 120
 GPU_SESSION_BUDGET_S = float(os.environ.get("FS_GPU_SESSION_BUDGET_S", "600"))
 _SESSION_T0 = time.monotonic()
-_LATE = ("live_reference", "fresh_librar", "long_streams", "many_batches")
+_LATE = ("live_reference", "fresh_librar", "long_streams", "many_batches")      # tests that run the reference's tools on the box
 
 
 def pytest_collection_modifyitems(config, items):
@@ -179,7 +179,7 @@ class RefLibs:
         # name: (reads or pairs, genome, seed, paired, quality mode, generator flags)
         "se_long": (400_000, 6_000, 8, False, 0, ()),            # 39 standard bins, the largest > 30 000 reads = 4.5 M quality symbols
         "pe_long": (200_000, 6_000, 8, True, 0, ()),             # bins of > 10 000 pairs: both mates in one stream, > 3 M symbols
-        "pe_noisy": (100_000, 2_000, 11, True, 0, ("--noisy-quality",)),  # one bin of > 30 000 pairs of structureless scores: >= 3 model restarts
+        "pe_noisy": (70_000, 1_500, 11, True, 0, ("--noisy-quality",)),   # one bin of 17 000 pairs of structureless scores (5.1 M symbols): 3 model restarts
     }
 
     def __init__(self, root):

@@ -83,6 +83,38 @@ static void gatherQuality(uint8_t* buf, size_t inputBytes, const GatherPlan& g)
         }
         return;
     }
+    if (g.qvz) {                                                   // --lossy: (context | state << 24) words, what fs_gather_quality_qvz writes
+        const QuaQvzString* qs = (const QuaQvzString*)(buf + g.desc_off);
+        uint8_t* out = buf + ((inputBytes + 15u) & ~(size_t)15u);
+        for (uint32_t i = 0; i < g.n_strings; ++i) {
+            const QuaQvzString& d = qs[i];
+            const uint8_t* model = buf + 16ull * d.model16;
+            QvzSymHeader h; memcpy(&h, model, sizeof h);
+            const uint32_t* colCtxBase = (const uint32_t*)(model + h.col_ctx_base_off); const uint16_t* colIndex = (const uint16_t*)(model + h.col_index_off);
+            const uint8_t* qratio = model + h.qratio_off; const uint8_t* quant = model + h.quant_off; const uint8_t* stateOf = model + h.state_of_off;
+            const uint32_t* well = (const uint32_t*)(model + h.well_off);
+            uint32_t prev = 0; bool bad = d.len > h.columns;
+            for (uint32_t j = 0; j < d.len; ++j) {
+                uint32_t w = 0xFFFFFFFFu;
+                if (!bad) {
+                    const uint64_t bit = d.src_bit + 6ull * (d.reverse ? d.len - 1u - j : j);
+                    const uint32_t two = ((uint32_t)buf[bit >> 3] << 8) | buf[(bit >> 3) + 1];
+                    const uint32_t qv = (two >> (10u - (uint32_t)(bit & 7u))) & 63u;
+                    const uint32_t idx = prev < 82u ? colIndex[j * 82u + prev] : 0xFFFFu;
+                    const uint32_t dn = d.draw0 + j;
+                    if (idx == 0xFFFFu || (dn >> 2) >= h.well_words) bad = true;
+                    else {
+                        const uint32_t pair = colCtxBase[j] / 2u + idx;
+                        const uint32_t ctx = 2u * pair + (((well[dn >> 2] >> (7u * (dn & 3u))) & 127u) >= qratio[pair] ? 1u : 0u);
+                        if (ctx >= h.n_ctx || stateOf[ctx * 72u + qv] == 0xFFu) bad = true;
+                        else { w = ctx | ((uint32_t)stateOf[ctx * 72u + qv] << 24); prev = quant[ctx * 72u + qv]; }
+                    }
+                }
+                memcpy(out + d.dst_off + 4ull * j, &w, 4);
+            }
+        }
+        return;
+    }
     const QuaString* qs = (const QuaString*)(buf + g.desc_off);
     uint8_t* out = buf + ((inputBytes + 15u) & ~(size_t)15u);
     for (uint32_t i = 0; i < g.n_strings; ++i)

@@ -20,7 +20,7 @@ extern "C" int simt_ppmd_encode_two_waves(int nStreams, const uint8_t* const* in
     fsppmd::Shared* sh = new fsppmd::Shared;
     sh->qTail = sh->qHead = 0; sh->qStarts = sh->qOpened = 0;
     simt::run_waves(2, [&](int wave, int) {
-        if (wave == 1) { fsppmd::coder_wave(sh); return; }
+        if (wave == 1) { fsppmd::coder_wave<false>(sh); return; }
         uint32_t q = 0;
         for (int s = 0; s < nStreams; ++s) {
             uint32_t r0 = 0;
@@ -81,7 +81,6 @@ extern "C" long simt_qvz_encode(int form, const uint8_t* blob, const uint8_t* sy
 }
 
 
-#if defined(FS_RC_ON_CODER_WAVE)
 // range-coded streams with their triples coded by the coder wave (two emulated waves), a PPMd member before and behind them:
 // the ring carries both kinds of entries, the coder wave switches between its two range coders at the streams' commands
 extern "C" int simt_rc_encode_two_waves(int nStreams, const unsigned* models /* 0xFFFFFFFF: a PPMd member */, const uint8_t* const* in, const size_t* n,
@@ -91,7 +90,7 @@ extern "C" int simt_rc_encode_two_waves(int nStreams, const unsigned* models /* 
     fsppmd::Shared* sh = new fsppmd::Shared;
     sh->qTail = sh->qHead = 0; sh->qStarts = sh->qOpened = 0;
     simt::run_waves(2, [&](int wave, int) {
-        if (wave == 1) { fsppmd::coder_wave(sh); return; }
+        if (wave == 1) { fsppmd::coder_wave<true>(sh); return; }
         uint32_t q = 0;
         for (int s = 0; s < nStreams; ++s) {
             if (models[s] == 0xFFFFFFFFu) {
@@ -109,4 +108,3 @@ extern "C" int simt_rc_encode_two_waves(int nStreams, const unsigned* models /* 
     delete sh; free(arena);
     return 0;
 }
-#endif

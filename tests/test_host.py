@@ -546,3 +546,33 @@ def test_tokeniser_checker_against_the_scalar_restatement(emu_lib):
         assert differing == 0, (name, ids, differing)
         total += ids
     assert total > 10000
+
+
+REF_CLI = os.path.join(ROOT, "oracle", "_ref", "fastore_pack_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CLI), reason="the reference's own CLI (oracle/_ref/fastore_pack_ref) not built")
+def test_cli_matches_the_reference_cli(tmp_path):
+    # the reference's OWN command line (its main.cpp, compiled unmodified by oracle/Makefile) beside the product's: the same exit
+    # status and the same `Error: ...` line for every malformed call, usage on stderr for too few arguments -- and, on a golden
+    # library, the same archive and the same -v statistics on stdout (the product's CLI here over the test-only emulation:
+    # the device build's is held against the same files in the GPU suite)
+    subprocess.check_call(["make", "-C", CSRC, "-j", "8", "emu"], stdout=subprocess.DEVNULL)
+    ours = os.path.join(ROOT, "build", "fastore_pack_emu")
+    cases = [[], ["e"], ["x", "-ia", "-ob"], ["e", "-ofoo", "-t1"], ["e", "-ifoo", "-t1"], ["e", "-ifoo", "-obar", "-t99"], ["e", "-ifoo", "-obar", "-t0"],
+             ["e", "-i" + str(tmp_path / "nothing_here"), "-o" + str(tmp_path / "o"), "-t1"],
+             ["e", "-i" + os.path.join(GOLDEN, manifest()[0][0] + ".in"), "-o" + str(tmp_path / "no_such_dir" / "o"), "-t1"] + manifest()[0][2]]
+    for argv in cases:
+        a = subprocess.run([ours] + argv, capture_output=True); b = subprocess.run([REF_CLI] + argv, capture_output=True)
+        assert a.returncode == b.returncode == 255, (argv, a.returncode, b.returncode)
+        err = lambda r: [l for l in r.stderr.decode(errors="replace").splitlines() if l.startswith("Error:")]
+        assert err(a) == err(b), (argv, err(a), err(b))
+        assert (b"usage" in a.stderr) == (b"usage" in b.stderr), argv
+    name, paired, flags = manifest()[0]
+    pe = ["-z"] if paired else []
+    a = subprocess.run([ours, "e", "-i" + os.path.join(GOLDEN, name + ".in"), "-o" + str(tmp_path / "a"), "-t1", "-v"] + flags + pe, capture_output=True)
+    b = subprocess.run([REF_CLI, "e", "-i" + os.path.join(GOLDEN, name + ".in"), "-o" + str(tmp_path / "b"), "-t1", "-v"] + flags + pe, capture_output=True, timeout=300)
+    assert a.returncode == b.returncode == 0, (a.stderr[-300:], b.stderr[-300:])
+    assert a.stdout == b.stdout                                    # StreamSizes: ... (CompressorModule.cpp:357-441)
+    assert open(str(tmp_path / "a.cdata"), "rb").read() == open(str(tmp_path / "b.cdata"), "rb").read()
+    assert_same_archive(str(tmp_path / "a"), str(tmp_path / "b"))

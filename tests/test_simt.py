@@ -193,15 +193,12 @@ def test_qvz_forms_on_the_emulated_wave_reproduce_the_one_lane_coder(simt):
         assert simt.simt_qvz_encode(form, blob, bytes(bad) + b"\0" * 256, 500, arena, out, 4096) == -1
 
 
-def test_range_coded_streams_through_the_coder_wave(oracle):
-    # -DFS_RC_ON_CODER_WAVE (not the product's build yet): the windowed range coders send their triples through the PPMd walk's
-    # ring and the coder wave of the two-wave form codes them; PPMd members in between -- the coder wave keeps two range coders
+def test_range_coded_streams_through_the_coder_wave(simt, oracle):
+    # the two-wave kernel with the windowed range coders (fs_encode_streams2_w): they send their triples through the PPMd walk's
+    # ring and the coder wave codes them (coder_wave<true>); PPMd members in between -- the coder wave keeps two range coders
     # apart.  Against the oracle's coders, on two emulated waves.
     from conftest import MODELS, oracle_rc
-    out = os.path.join(ROOT, "build", "libsimt_emu_rcq.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU", "-DFS_RC_ON_CODER_WAVE", "-shared", "-fPIC", "-o", out,
-                           os.path.join(ROOT, "tests", "emu", "ppmd_simt.cpp"), os.path.join(ROOT, "tests", "emu", "simt.cpp"), os.path.join(ROOT, "tests", "emu", "qvz_host_ref.cpp")])
-    lib = ctypes.CDLL(out)
+    lib = simt
     lib.simt_rc_encode_two_waves.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6
     rng = np.random.default_rng(41)
     streams = []                                        # (model id or None, bytes)
