@@ -95,6 +95,7 @@ def load_library(path=None):
     lib.fsgpu_ppmd_encode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.fsgpu_gather_quality_binned.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.fsgpu_tokeniser_check.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.fsgpu_emit_check.argtypes = [C.c_void_p, C.c_char_p] + [C.POINTER(C.c_uint64)] * 3
     lib.fsgpu_matcher_check.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.fsgpu_pe_matcher_check.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.fsgpu_unpack_check.argtypes = [C.c_void_p, C.c_char_p] + [C.POINTER(C.c_uint64)] * 4
@@ -348,6 +349,12 @@ class Packer:
         out = C.create_string_buffer(2 * total + 16); got = C.c_size_t(0)
         self._check(self.lib.fsgpu_gather_quality_binned(self.ctx, packed, len(packed), bits, binary_threshold, arr, len(strings), out, total, C.byref(got)))
         return out.raw[:2 * got.value]
+
+    def emit_check(self, in_prefix):
+        """(ops expanded, pre-entropy streams compared, streams that differ) between the device's emission kernels and the host's walk over a library."""
+        v = [C.c_uint64(0) for _ in range(3)]
+        self._check(self.lib.fsgpu_emit_check(self.ctx, in_prefix.encode(), *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
 
     def tokeniser_check(self, in_prefix):
         """(read ids tokenised, bins whose IdToken / IdValue streams differ between the device tokeniser and the host's) over a library."""

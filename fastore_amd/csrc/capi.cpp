@@ -522,6 +522,12 @@ int fsgpu_tokeniser_check(fsgpu_ctx* ctx, const char* inPrefix, uint64_t* ids, u
     FS_GUARD(ctx, ctx->c.tokeniserCheck(inPrefix, *ids, *differingBins));
 }
 
+int fsgpu_emit_check(fsgpu_ctx* ctx, const char* inPrefix, uint64_t* ops, uint64_t* streams, uint64_t* differing)
+{
+    if (!ctx || !inPrefix || !ops || !streams || !differing) return FSGPU_ERR_ARG;
+    FS_GUARD(ctx, ctx->c.emitCheck(inPrefix, *ops, *streams, *differing));
+}
+
 int fsgpu_pe_matcher_check(fsgpu_ctx* ctx, const char* inPrefix, uint64_t* pairs, uint64_t* differing)
 {
     if (!ctx || !inPrefix || !pairs || !differing) return FSGPU_ERR_ARG;

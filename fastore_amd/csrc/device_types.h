@@ -84,6 +84,54 @@ struct IdString { uint64_t src_bit; uint32_t len, pad; };      // first stored c
 struct IdJob { uint32_t first, count, tok_item, val_item; uint64_t tok_out, val_out, table_off; };
 struct IdPlan { uint64_t jobs_off = 0, strings_off = 0; uint32_t n_jobs = 0, n_strings = 0; uint64_t out_bytes = 0; };
 
+// Device-side stream emission (fs_emit_count / fs_emit_scan / fs_emit_write, fs_rle_binary, fs_rle0: SURVEY 8 a6 + a11).  The host's walk
+// over a bin's match trees decides WHAT is coded (CompressNode ... CompressSubTree, fastore_pack/FastqCompressor.cpp:1279-2119) and
+// leaves one op per record whose coding reads bases; the device compares the bases and writes the streams that hold them:
+//   HARD      a read without a match: its bases around the signature              -> HardReads            (CompressHardRead, :1388-1410)
+//   MATCH     a read against its LZ match at a shift: the overhangs' letters, per overlapping position (bar the signature) a match
+//             bit (run-length coded: BinaryRleEncoder) or a match symbol, a letter with the matched base as context per mismatch
+//                                                                                 -> LettersX, Match | MatchBinary (CompressNormalMatch, :1460-1560)
+//   CREAD     a read of a contig against the consensus: the cut zones in full, elsewhere the variant positions
+//                                                                                 -> CLetters             (CompressContigRead, :1690-1760)
+//   CDEF      a contig's definition: a bit per position (variant or not, run-length coded), the consensus letters of the ends
+//             and the variants                                                    -> CMatch, CLetters     (StoreContigDefinition, :1620-1680)
+//   PE_HARD / PE_MATCH  the mate of a pair, likewise                              -> HardPE | LettersXPE, MatchRlePE | MatchBinaryPE
+//                                                                                    (LzCompressorPE::CompressPair, :4740-4900)
+// and the LZ ids of a bin (one per MATCH, in order) go through Rle0Encoder on the device                   -> LzId
+// Offsets seq_a / seq_b count from the bin's first base in the slice's base region; a contig's bytes (sequence[2 L], variant[2 L])
+// from the bin's first contig byte.
+enum : uint32_t { EMIT_HARD = 1, EMIT_MATCH = 2, EMIT_CREAD = 3, EMIT_CDEF = 4, EMIT_PE_HARD = 5, EMIT_PE_MATCH = 6 };
+enum : uint32_t { EMIT_SHIFT_ONLY = 0, EMIT_FULL = 1, EMIT_EXPENSIVE = 2 };
+// channels: what the ops write.  L = bytes or (symbol, context) pairs, B = bits (one byte each, for the run-length coder) or match symbols
+enum : uint32_t { ECH_HARD = 0, ECH_LETTERS = 1, ECH_MATCH_BITS = 2, ECH_MATCH_BIN = 3, ECH_CMATCH_BITS = 4, ECH_CLETTERS = 5,
+                  ECH_HARD_PE = 6, ECH_LETTERS_PE = 7, ECH_MATCH_BITS_PE = 8, ECH_MATCH_BIN_PE = 9, ECH_COUNT = 10 };
+struct EmitOp {
+    uint32_t kind;            // EMIT_*
+    uint32_t seq_a;           // the read's (mate's) bases
+    uint32_t seq_b;           // MATCH / PE_MATCH: the matched read's (mate's) bases; CREAD / CDEF: the contig's bytes
+    uint16_t len_a, len_b;    // lengths of a and b; CDEF: rangeFirst, rangeSecond
+    uint16_t pos_a, pos_b;    // HARD / CREAD: the read's signature position; MATCH: the matched read's; CDEF: the main read's; (CREAD) pos_b = the contig's read length
+    int16_t shift;            // MATCH / PE_MATCH
+    uint8_t mode;             // MATCH / PE_MATCH: EMIT_SHIFT_ONLY / EMIT_FULL / EMIT_EXPENSIVE
+    uint8_t pad;
+    uint32_t pad2[2];
+};
+// one bin's emission: its ops, its LZ ids, where its bases and contig bytes stand (byte offsets in the batch input), the stream items
+// of the eleven streams the device writes (their in_len is set by the kernels) and where each stream goes (byte offsets in the
+// device-only region behind the input).  raw_off[c]: scratch space of the run-length coded channels (a byte per bit).
+struct EmitJob {
+    uint32_t first_op, n_ops, first_id, n_ids;
+    uint64_t seq_off, contig_off;          // the bin's bases and contig bytes in the batch input ...
+    uint32_t seq_bytes, contig_bytes;      // ... and how many there are
+    uint32_t sig_len, begin_cut, end_cut, pad;
+    uint32_t cap[ECH_COUNT + 1];           // room of every stream in its units (bytes, pairs, bits; [ECH_COUNT]: LzId bytes)
+    uint32_t item[ECH_COUNT + 1];          // stream item per channel; [ECH_COUNT] = LzId; 0xFFFFFFFF: the bin has no such stream (single-end)
+    uint64_t out_off[ECH_COUNT + 1];       // where the stream's bytes go
+    uint64_t raw_off[ECH_COUNT];           // bit channels only (ECH_MATCH_BITS, ECH_CMATCH_BITS, ECH_MATCH_BITS_PE)
+    uint8_t dna_to_idx[128];               // character -> the archive's symbol index (MinimizerParameters::dnaSymbolOrder; 255: none), as the host's d2i
+};
+struct EmitPlan { uint64_t jobs_off = 0, ops_off = 0, ids_off = 0; uint32_t n_jobs = 0, n_ops = 0, n_ids = 0; uint64_t out_bytes = 0; };
+
 enum : uint32_t { MAX_STREAMS = 23 };
 
 // per-bin block assembly plan (reference block layout: SURVEY §8 a13,

@@ -1,0 +1,164 @@
+// Stream emission of one record: what the ops of fsdev::EmitOp write.  One source for the device kernels
+// (fs_emit_count / fs_emit_write: a thread per op, the same walk twice -- first counting, then writing behind the counts of the
+// ops in front) and for the test-only host emulation.
+//
+// Reference (fastore_pack/FastqCompressor.cpp): CompressHardRead :1388-1410, CompressNormalMatch :1460-1560, CompressContigRead
+// :1690-1760, StoreContigDefinition :1620-1680, LzCompressorPE::CompressPair's letter and match loops :4790-4900.
+#pragma once
+#include <stdint.h>
+#include "device_types.h"
+
+#if defined(__HIPCC__)
+  #define FS_EMIT_FN __host__ __device__ inline
+#else
+  #define FS_EMIT_FN inline
+#endif
+
+namespace fsemit {
+
+// what one op writes: L = bytes (HARD) or (symbol, context) pairs, B = match bits (a byte each) or (match symbol, 0) pairs
+struct Sink {
+    uint32_t nL = 0, nB = 0;
+    uint8_t* outL = nullptr; uint8_t* outB = nullptr;        // null: count only
+};
+FS_EMIT_FN void put_byte(Sink& s, uint32_t b) { if (s.outL) s.outL[s.nL] = (uint8_t)b; s.nL++; }
+FS_EMIT_FN void put_letter(Sink& s, uint32_t sym, uint32_t ctx) { if (s.outL) { s.outL[2u * s.nL] = (uint8_t)sym; s.outL[2u * s.nL + 1u] = (uint8_t)ctx; } s.nL++; }
+FS_EMIT_FN void put_bit(Sink& s, bool b) { if (s.outB) s.outB[s.nB] = b ? 1u : 0u; s.nB++; }
+FS_EMIT_FN void put_match_symbol(Sink& s, bool b) { if (s.outB) { s.outB[2u * s.nB] = b ? 1u : 0u; s.outB[2u * s.nB + 1u] = 0u; } s.nB++; }
+
+// the channels an op writes to (fsdev::ECH_*; ECH_COUNT: none)
+FS_EMIT_FN uint32_t channel_l(const fsdev::EmitOp& op)
+{
+    switch (op.kind) {
+    case fsdev::EMIT_HARD: return fsdev::ECH_HARD;
+    case fsdev::EMIT_MATCH: return fsdev::ECH_LETTERS;
+    case fsdev::EMIT_CREAD: case fsdev::EMIT_CDEF: return fsdev::ECH_CLETTERS;
+    case fsdev::EMIT_PE_HARD: return fsdev::ECH_HARD_PE;
+    case fsdev::EMIT_PE_MATCH: return fsdev::ECH_LETTERS_PE;
+    default: return fsdev::ECH_COUNT;
+    }
+}
+FS_EMIT_FN uint32_t channel_b(const fsdev::EmitOp& op)
+{
+    switch (op.kind) {
+    case fsdev::EMIT_MATCH: return op.mode == fsdev::EMIT_FULL ? fsdev::ECH_MATCH_BITS : (op.mode == fsdev::EMIT_EXPENSIVE ? fsdev::ECH_MATCH_BIN : fsdev::ECH_COUNT);
+    case fsdev::EMIT_CDEF: return fsdev::ECH_CMATCH_BITS;
+    case fsdev::EMIT_PE_MATCH: return op.mode == fsdev::EMIT_FULL ? fsdev::ECH_MATCH_BITS_PE : (op.mode == fsdev::EMIT_EXPENSIVE ? fsdev::ECH_MATCH_BIN_PE : fsdev::ECH_COUNT);
+    default: return fsdev::ECH_COUNT;
+    }
+}
+// bytes per unit of a channel's L / B output as the stream holds it
+FS_EMIT_FN uint32_t unit_l(uint32_t ch) { return (ch == fsdev::ECH_HARD || ch == fsdev::ECH_HARD_PE) ? 1u : 2u; }
+FS_EMIT_FN bool is_bit_channel(uint32_t ch) { return ch == fsdev::ECH_MATCH_BITS || ch == fsdev::ECH_CMATCH_BITS || ch == fsdev::ECH_MATCH_BITS_PE; }
+
+// seq: the bin's bases; contig: the bin's contig bytes (per contig: sequence[2 L] then variant[2 L], L = the contig's read length)
+FS_EMIT_FN void emit_op(const fsdev::EmitOp& op, const fsdev::EmitJob& job, const uint8_t* seq, const uint8_t* contig, Sink& s)
+{
+    const uint8_t* d2i = job.dna_to_idx;
+    const uint32_t sigLen = job.sig_len;
+    const uint32_t idxN = d2i['N'];
+    switch (op.kind) {
+    case fsdev::EMIT_HARD: {
+        const uint8_t* a = seq + op.seq_a;
+        const int32_t L = (int32_t)op.len_a, m = (int32_t)op.pos_a;
+        for (int32_t i = 0; i < L; ++i) {
+            if (i < m || i >= m + (int32_t)sigLen) put_byte(s, a[i]);
+            else if (i == m) put_byte(s, '.');
+        }
+        break;
+    }
+    case fsdev::EMIT_PE_HARD: {
+        const uint8_t* a = seq + op.seq_a;
+        for (uint32_t i = 0; i < op.len_a; ++i) put_byte(s, a[i]);
+        break;
+    }
+    case fsdev::EMIT_MATCH: case fsdev::EMIT_PE_MATCH: {
+        const bool pe = op.kind == fsdev::EMIT_PE_MATCH;
+        const uint8_t* newSeq = seq + op.seq_a; const uint8_t* bestSeq = seq + op.seq_b;
+        uint32_t newLen = op.len_a, bestLen = op.len_b, bestPos = op.pos_b;
+        const int32_t shift = op.shift;
+        if (shift >= 0) { bestSeq += shift; bestLen -= (uint32_t)shift; bestPos -= (uint32_t)shift; }
+        else {
+            for (int32_t i = 0; i < -shift; ++i) put_letter(s, d2i[newSeq[i] & 127u], idxN);
+            newSeq += -shift; newLen -= (uint32_t)(-shift);
+        }
+        const uint32_t minLen = bestLen < newLen ? bestLen : newLen;
+        if (op.mode == fsdev::EMIT_FULL || op.mode == fsdev::EMIT_EXPENSIVE) {
+            for (uint32_t i = 0; i < minLen; ++i) {
+                if (!pe && i == bestPos) { i += sigLen - 1u; continue; }      // (the signature is not coded; the mate has none)
+                const bool eq = bestSeq[i] == newSeq[i];
+                if (op.mode == fsdev::EMIT_FULL) put_bit(s, eq); else put_match_symbol(s, eq);
+                if (!eq) put_letter(s, d2i[newSeq[i] & 127u], d2i[bestSeq[i] & 127u]);
+            }
+        }
+        for (uint32_t i = minLen; i < newLen; ++i) put_letter(s, d2i[newSeq[i] & 127u], idxN);
+        break;
+    }
+    case fsdev::EMIT_CREAD: {
+        const uint8_t* a = seq + op.seq_a;
+        const uint32_t readLen = op.len_a, m = op.pos_a;
+        const uint8_t* cs = contig + op.seq_b; const uint8_t* var = cs + 2u * op.pos_b;      // (pos_b: the contig's read length)
+        const uint32_t consStart = readLen - m;
+        uint32_t it = 0;
+        while (it < job.begin_cut) {
+            if (it == m) { it += sigLen; continue; }
+            put_letter(s, d2i[a[it] & 127u], d2i[cs[consStart + it] & 127u]); it++;
+        }
+        while (it < readLen - job.end_cut) {
+            if (it == m) { it += sigLen; continue; }
+            if (var[consStart + it]) put_letter(s, d2i[a[it] & 127u], d2i[cs[consStart + it] & 127u]);
+            it++;
+        }
+        while (it < readLen) { put_letter(s, d2i[a[it] & 127u], d2i[cs[consStart + it] & 127u]); it++; }
+        break;
+    }
+    case fsdev::EMIT_CDEF: {
+        const uint32_t readLen = op.pos_b, mainSigPos = op.pos_a;
+        const uint8_t* cs = contig + op.seq_b; const uint8_t* var = cs + 2u * readLen;
+        const uint32_t lzFirst = readLen - mainSigPos, lzSecond = lzFirst + readLen;
+        for (uint32_t i = op.len_a; i < op.len_b; ++i) {
+            if (i == readLen) { i += sigLen - 1u; continue; }
+            put_bit(s, var[i] == 0);
+            if (i < lzFirst + 2u || i >= lzSecond - 2u || var[i] != 0) put_letter(s, d2i[cs[i] & 127u], idxN);
+        }
+        break;
+    }
+    default: break;
+    }
+}
+
+// ---- the run-length coders, one symbol at a time (the emulation's form, and the tail of the kernels' chunks) ----
+// BinaryRleEncoder (rle/RleEncoder.h:21-79): a byte per zero -- the ones in front of it + 2 when there are any, else 0 --, a byte 255
+// per 253 ones in a row, and the ones left at the end + 2.  Returns the bytes written.
+FS_EMIT_FN uint32_t rle_binary_serial(const uint8_t* bits, uint32_t n, uint8_t* out)
+{
+    uint32_t cur = 0, w = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (bits[i]) { if (++cur == 253u) { out[w++] = 255u; cur = 0; } }
+        else { out[w++] = cur ? (uint8_t)(cur + 2u) : (uint8_t)0; cur = 0; }
+    }
+    if (cur) out[w++] = (uint8_t)(cur + 2u);
+    return w;
+}
+// Rle0Encoder (rle/RleEncoder.h:140-212): zeros in pairs -- a byte 0 per pair, a byte 1 for one left over in front of the next
+// value or the end --, a value v > 0 as v + 1 in one byte (< 253), three (0xFE, 16 bits) or five (0xFF, 32 bits)
+FS_EMIT_FN uint32_t rle0_value_bytes(uint32_t v) { const uint32_t ss = v + 1u; return ss < 253u ? 1u : (ss < 65535u ? 3u : 5u); }
+FS_EMIT_FN uint32_t rle0_put_value(uint32_t v, uint8_t* o)
+{
+    const uint32_t ss = v + 1u;
+    if (ss < 253u) { o[0] = (uint8_t)ss; return 1u; }
+    if (ss < 65535u) { o[0] = 0xFE; o[1] = (uint8_t)(ss >> 8); o[2] = (uint8_t)ss; return 3u; }
+    o[0] = 0xFF; o[1] = (uint8_t)(ss >> 24); o[2] = (uint8_t)(ss >> 16); o[3] = (uint8_t)(ss >> 8); o[4] = (uint8_t)ss; return 5u;
+}
+FS_EMIT_FN uint32_t rle0_serial(const uint32_t* v, uint32_t n, uint8_t* out)
+{
+    uint32_t prev = 0, w = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (v[i] == 0u) { if (prev == 0u) prev = 1u; else { out[w++] = 0u; prev = 0u; } }
+        else { if (prev == 1u) { out[w++] = 1u; prev = 0u; } w += rle0_put_value(v[i], out + w); }
+    }
+    if (prev == 1u) out[w++] = 1u;
+    return w;
+}
+
+}  // namespace fsemit

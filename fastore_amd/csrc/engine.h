@@ -84,10 +84,13 @@ int match_mates(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
 int gather_quality_raw(Device* dev, const uint8_t* input, size_t inputBytes, const fsdev::GatherPlan& plan, std::vector<uint8_t>& out, BatchTiming* timing);
 // fs_tokenise_ids on its own (parity checks): tok[j] / val[j] = the (symbol, context) pair streams of job j (its items: 2 j, 2 j + 1)
 int tokenise_ids_raw(Device* dev, const uint8_t* input, size_t inputBytes, const fsdev::IdPlan& plan, std::vector<std::vector<uint8_t>>& tok, std::vector<std::vector<uint8_t>>& val);
+// the emission kernels on their own (parity checks): `input` holds the plan's jobs, ops, ids, bases and contig bytes; on return
+// streams[j][c] = the bytes of channel c of job j as the kernels left them (c = fsdev::ECH_COUNT: the run-length coded LZ ids)
+int emit_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, const fsdev::EmitPlan& plan, std::vector<fsdev::StreamItem>& items, std::vector<std::vector<std::vector<uint8_t>>>& streams);
 // gather (optional): quality streams that fs_gather_quality writes behind the uploaded input (at inputBytes rounded up to
 // 16) from the packed scores inside it; their items' in_off already point there
 int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,
                  std::vector<fsdev::BlockPlan>& plans, std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes,
-                 BatchTiming* timing, const fsdev::GatherPlan* gather = nullptr, const fsdev::IdPlan* ids = nullptr);
+                 BatchTiming* timing, const fsdev::GatherPlan* gather = nullptr, const fsdev::IdPlan* ids = nullptr, const fsdev::EmitPlan* emit = nullptr);
 
 }  // namespace fsengine

@@ -30,6 +30,7 @@
 #include "ppmd_core.h"
 #include "rc_core.h"
 #include "qvz_core.h"
+#include "emit_core.h"
 
 using namespace fsdev;
 
@@ -508,6 +509,185 @@ __global__ __launch_bounds__(256) void fs_id_write(const IdChunk* __restrict__ c
     if (tid == 0u && ck.c0 + 256u >= job.count) { items[job.tok_item].in_len = tokBase + totT; items[job.val_item].in_len = valBase + totV; }
 }
 
+
+// ---- device-side stream emission (SURVEY 8 a6 + a11): fsdev::EmitOp, emit_core.h ----
+// The streams of a bin that hold bases are written here from the ops the host's walk left.  A thread per op, the op's walk twice
+// (fs_emit_count, then fs_emit_write behind the counts of the ops in front of it in ITS channels: fs_emit_scan, a workgroup per
+// bin); the match bits of the run-length coded channels land as a byte each and go through fs_rle_binary, the bin's LZ ids through
+// fs_rle0 -- BinaryRleEncoder and Rle0Encoder (rle/RleEncoder.h:21-79, 140-212) as block scans: what a position emits depends on
+// the symbols in front of it only through the length of the run it stands in (mod 253: a byte 255 is due every 253 ones; mod 2:
+// zeros go in pairs), and "the run so far" is a scan of maps that either restart the count (a zero / a value) or add to it.
+template <int T> __device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* sm, uint32_t& total)
+{
+    const uint32_t tid = threadIdx.x;
+    sm[tid] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < (uint32_t)T; d <<= 1) {
+        const uint32_t a = tid >= d ? sm[tid - d] : 0u;
+        __syncthreads();
+        sm[tid] += a;
+        __syncthreads();
+    }
+    const uint32_t incl = sm[tid]; total = sm[T - 1];
+    __syncthreads();
+    return incl - v;
+}
+// Every thread holds a map of a counter: `restart` -> the counter becomes v, else -> (counter + v) mod M.  Returns the counter as
+// it stands IN FRONT of this thread when `carry` stands in front of the block; carryOut: behind the block's last thread.
+template <int T> __device__ __forceinline__ uint32_t block_counter_scan(bool restart, uint32_t v, uint32_t M, uint32_t carry, uint32_t* sk, uint32_t* sv, uint32_t& carryOut)
+{
+    const uint32_t tid = threadIdx.x;
+    sk[tid] = restart ? 1u : 0u; sv[tid] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < (uint32_t)T; d <<= 1) {
+        // the map of [tid - d - ..., tid - d] applied first, then mine
+        const uint32_t ok = tid >= d ? sk[tid - d] : 0u, ov = tid >= d ? sv[tid - d] : 0u;
+        const uint32_t mk = sk[tid], mv = sv[tid];
+        __syncthreads();
+        if (tid >= d && !mk) { sk[tid] = ok; sv[tid] = (ov + mv) % M; }
+        __syncthreads();
+    }
+    const uint32_t lk = sk[T - 1], lv = sv[T - 1];
+    carryOut = lk ? lv : (carry + lv) % M;
+    uint32_t before = carry;
+    if (tid > 0u) { const uint32_t pk = sk[tid - 1], pv = sv[tid - 1]; before = pk ? pv : (carry + pv) % M; }
+    __syncthreads();
+    return before;
+}
+
+__global__ __launch_bounds__(256) void fs_emit_count(const EmitJob* __restrict__ jobs, const EmitOp* __restrict__ ops, uint32_t nOps, const uint8_t* __restrict__ in, uint32_t* __restrict__ counts)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= nOps) return;
+    const EmitOp op = ops[g];
+    const EmitJob& job = jobs[op.pad2[0]];
+    fsemit::Sink s;
+    fsemit::emit_op(op, job, in + job.seq_off, in + job.contig_off, s);
+    counts[2u * g] = s.nL; counts[2u * g + 1u] = s.nB;
+}
+
+// one workgroup per bin: every op's place in its channels; the channels' totals; the lengths of the streams that are complete with
+// fs_emit_write (all but the run-length coded ones) into their stream items
+__global__ __launch_bounds__(256) void fs_emit_scan(const EmitJob* __restrict__ jobs, const EmitOp* __restrict__ ops, const uint32_t* __restrict__ counts, uint32_t* __restrict__ offs,
+                                                    uint32_t* __restrict__ totals, StreamItem* items)
+{
+    __shared__ uint32_t sm[256];
+    __shared__ uint32_t run[ECH_COUNT];
+    const EmitJob& job = jobs[blockIdx.x];
+    const uint32_t tid = threadIdx.x;
+    if (tid < ECH_COUNT) run[tid] = 0u;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < job.n_ops; c0 += 256u) {
+        const bool active = c0 + tid < job.n_ops;
+        const uint32_t g = job.first_op + c0 + tid;
+        uint32_t chL = ECH_COUNT, chB = ECH_COUNT, nL = 0, nB = 0;
+        if (active) { const EmitOp op = ops[g]; chL = fsemit::channel_l(op); chB = fsemit::channel_b(op); nL = counts[2u * g]; nB = counts[2u * g + 1u]; }
+        uint32_t offL = 0, offB = 0;
+        for (uint32_t c = 0; c < ECH_COUNT; ++c) {
+            // (a channel is either an L or a B channel, never both)
+            const uint32_t mine = chL == c ? nL : (chB == c ? nB : 0u);
+            if (__syncthreads_or(mine != 0u) == 0) continue;
+            uint32_t total;
+            const uint32_t ex = block_exclusive_sum<256>(mine, sm, total);
+            const uint32_t base = run[c];
+            if (chL == c) offL = base + ex;
+            if (chB == c) offB = base + ex;
+            __syncthreads();
+            if (tid == 0u) run[c] = base + total;
+            __syncthreads();
+        }
+        if (active) { offs[2u * g] = offL; offs[2u * g + 1u] = offB; }
+    }
+    __syncthreads();
+    if (tid < ECH_COUNT) {
+        totals[(ECH_COUNT + 1u) * blockIdx.x + tid] = run[tid];
+        if (!fsemit::is_bit_channel(tid) && job.item[tid] != 0xFFFFFFFFu) items[job.item[tid]].in_len = run[tid];
+    }
+}
+
+__global__ __launch_bounds__(256) void fs_emit_write(const EmitJob* __restrict__ jobs, const EmitOp* __restrict__ ops, uint32_t nOps, const uint8_t* __restrict__ in, const uint32_t* __restrict__ offs,
+                                                     uint8_t* __restrict__ out)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= nOps) return;
+    const EmitOp op = ops[g];
+    const EmitJob& job = jobs[op.pad2[0]];
+    const uint32_t chL = fsemit::channel_l(op), chB = fsemit::channel_b(op);
+    fsemit::Sink s;
+    uint8_t dummy[2];
+    s.outL = chL < ECH_COUNT ? out + job.out_off[chL] + (uint64_t)fsemit::unit_l(chL) * offs[2u * g] : dummy;
+    s.outB = chB < ECH_COUNT ? (fsemit::is_bit_channel(chB) ? out + job.raw_off[chB] + offs[2u * g + 1u] : out + job.out_off[chB] + 2ull * offs[2u * g + 1u]) : dummy;
+    fsemit::emit_op(op, job, in + job.seq_off, in + job.contig_off, s);
+}
+
+// BinaryRleEncoder over one bit channel of one bin (blockIdx.x = 3 * bin + which).  A thread takes 16 bits; a chunk is 4 096 bits.
+__global__ __launch_bounds__(256) void fs_rle_binary(const EmitJob* __restrict__ jobs, const uint32_t* __restrict__ totals, uint8_t* out, StreamItem* items)
+{
+    __shared__ uint32_t sk[256], sv[256];
+    const uint32_t chOf[3] = {ECH_MATCH_BITS, ECH_CMATCH_BITS, ECH_MATCH_BITS_PE};
+    const uint32_t j = blockIdx.x / 3u, ch = chOf[blockIdx.x % 3u];
+    const EmitJob& job = jobs[j];
+    if (job.item[ch] == 0xFFFFFFFFu) return;                              // (uniform: the whole workgroup)
+    const uint32_t n = totals[(ECH_COUNT + 1u) * j + ch], tid = threadIdx.x;
+    const uint8_t* bits = out + job.raw_off[ch];
+    uint8_t* dst = out + job.out_off[ch];
+    uint32_t carry = 0, written = 0;
+    for (uint32_t base = 0; base < n; base += 4096u) {
+        const uint32_t i0 = base + 16u * tid, cnt = i0 >= n ? 0u : (n - i0 < 16u ? n - i0 : 16u);
+        uint32_t m = 0;                                                    // bit k: position i0 + k holds a one
+        for (uint32_t k = 0; k < cnt; ++k) m |= (bits[i0 + k] ? 1u : 0u) << k;
+        const uint32_t zeros = cnt ? ~m & ((1u << cnt) - 1u) : 0u;
+        const uint32_t lead = zeros ? (uint32_t)__builtin_ctz(zeros) : cnt;              // ones in front of my first zero
+        const uint32_t tail = zeros ? cnt - 1u - (31u - (uint32_t)__builtin_clz(zeros)) : 0u;      // ones behind my last zero
+        uint32_t carryOut;
+        const uint32_t before = block_counter_scan<256>(zeros != 0u, zeros ? tail : cnt, 253u, carry, sk, sv, carryOut);
+        // my bytes: one per zero, and one 255 if the run I continue reaches 253 inside my leading ones
+        const uint32_t mine = (uint32_t)__popc(zeros) + ((lead > 0u && before + lead >= 253u) ? 1u : 0u);
+        uint32_t total;
+        const uint32_t at = written + block_exclusive_sum<256>(mine, sk, total);
+        uint32_t cur = before, w = at;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            if ((m >> k) & 1u) { if (++cur == 253u) { dst[w++] = 255u; cur = 0u; } }
+            else { dst[w++] = cur ? (uint8_t)(cur + 2u) : (uint8_t)0; cur = 0u; }
+        }
+        carry = carryOut; written += total;
+    }
+    if (tid == 0u) {
+        if (carry) dst[written++] = (uint8_t)(carry + 2u);
+        items[job.item[ch]].in_len = written;
+    }
+}
+
+// Rle0Encoder over the LZ ids of one bin.  A thread takes one id; the counter is the parity of the zeros in front of it.
+__global__ __launch_bounds__(256) void fs_rle0(const EmitJob* __restrict__ jobs, const uint32_t* __restrict__ ids, uint8_t* out, StreamItem* items)
+{
+    __shared__ uint32_t sk[256], sv[256];
+    const EmitJob& job = jobs[blockIdx.x];
+    if (job.item[ECH_COUNT] == 0xFFFFFFFFu) return;
+    const uint32_t n = job.n_ids, tid = threadIdx.x;
+    uint8_t* dst = out + job.out_off[ECH_COUNT];
+    uint32_t carry = 0, written = 0;
+    for (uint32_t base = 0; base < n; base += 256u) {
+        const bool active = base + tid < n;
+        const uint32_t v = active ? ids[job.first_id + base + tid] : 0u;
+        uint32_t carryOut;
+        // a value restarts the count of zeros at 0; a zero adds one (mod 2); a thread past the end leaves it as it is
+        const uint32_t odd = block_counter_scan<256>(active && v != 0u, (active && v == 0u) ? 1u : 0u, 2u, carry, sk, sv, carryOut);
+        const uint32_t mine = !active ? 0u : (v == 0u ? (odd ? 1u : 0u) : (odd ? 1u : 0u) + fsemit::rle0_value_bytes(v));
+        uint32_t total;
+        uint32_t w = written + block_exclusive_sum<256>(mine, sk, total);
+        if (active) {
+            if (v == 0u) { if (odd) dst[w] = 0u; }
+            else { if (odd) dst[w++] = 1u; (void)fsemit::rle0_put_value(v, dst + w); }
+        }
+        carry = carryOut; written += total;
+    }
+    if (tid == 0u) {
+        if (carry) dst[written++] = 1u;
+        items[job.item[ECH_COUNT]].in_len = written;
+    }
+}
+
 __device__ __forceinline__ void put_be(uint8_t* p, uint64_t v, int nbytes)
 { for (int i = 0; i < nbytes; ++i) p[i] = (uint8_t)(v >> (8 * (nbytes - 1 - i))); }
 
@@ -534,7 +714,8 @@ __global__ __launch_bounds__(256) void fs_assemble_blocks(const BlockPlan* __res
         put_be(h, pos, 8); h += 8;                    // footerOffset
         put_be(h, 1, 4); h += 4;                      // footerSize
         if (pl.has_headers) { put_be(h, pl.raw_id_size, 8); h += 8; }
-        for (uint32_t s = 0; s < N; ++s) { put_be(h, pl.work_size[s] == ~0ull ? (uint64_t)sizes[pl.first_item + s] : pl.work_size[s], 8); h += 8; }  // range-coded streams: work size == coded size
+        // (range-coded streams: work size == coded size; streams the device wrote itself, ~1: their length as its kernels left it)
+        for (uint32_t s = 0; s < N; ++s) { const uint64_t ws = pl.work_size[s]; put_be(h, ws == ~0ull ? (uint64_t)sizes[pl.first_item + s] : (ws == ~1ull ? (uint64_t)items[pl.first_item + s].in_len : ws), 8); h += 8; }
         for (uint32_t s = 0; s < N; ++s) { put_be(h, sizes[pl.first_item + s], 8); h += 8; }
         while (h < blk + headerSize) *h++ = 0;        // the 8-byte hole of header-less archives: defined as zero here
         blk[pos] = 0;                                 // footer: sampleValue
@@ -834,8 +1015,85 @@ static int id_launch(Device* dev, hipStream_t st, const IdPlan& plan, uint64_t g
     return 0;
 }
 
+
+// the emission's scratch behind the streams it writes: per op its two counts and its two places, per bin its channels' totals
+struct EmitLaunch { uint64_t countsOff = 0, offsOff = 0, totalsOff = 0, bytes = 0; };
+static void emit_launch_plan(const EmitPlan& plan, uint64_t scratchBase, EmitLaunch& L)
+{
+    L.countsOff = (scratchBase + 15u) & ~15ull;
+    L.offsOff = L.countsOff + 8ull * plan.n_ops;
+    L.totalsOff = L.offsOff + 8ull * plan.n_ops;
+    L.bytes = L.totalsOff + 4ull * (ECH_COUNT + 1u) * plan.n_jobs + 16u - scratchBase;
+}
+// every op inside its bin's bases and contig bytes, every stream inside the emission's region with room for the most its ops can
+// write, every item an item: checked here, the kernels trust their descriptors
+static int emit_check(Device* dev, const uint8_t* input, size_t inputBytes, const EmitPlan& plan, uint32_t nItems)
+{
+    if ((plan.jobs_off & 7u) || (plan.ops_off & 7u) || (plan.ids_off & 3u) || plan.jobs_off + (uint64_t)plan.n_jobs * sizeof(EmitJob) > inputBytes ||
+        plan.ops_off + (uint64_t)plan.n_ops * sizeof(EmitOp) > inputBytes || plan.ids_off + 4ull * plan.n_ids > inputBytes) {
+        snprintf(dev->err, sizeof dev->err, "emission plan outside the batch input"); return -1;
+    }
+    const EmitJob* jobs = (const EmitJob*)(input + plan.jobs_off); const EmitOp* ops = (const EmitOp*)(input + plan.ops_off);
+    for (uint32_t j = 0; j < plan.n_jobs; ++j) {
+        const EmitJob& jb = jobs[j];
+        bool ok = (uint64_t)jb.first_op + jb.n_ops <= plan.n_ops && (uint64_t)jb.first_id + jb.n_ids <= plan.n_ids && jb.seq_off + jb.seq_bytes <= inputBytes &&
+                  jb.contig_off + jb.contig_bytes <= inputBytes && jb.sig_len >= 1u && jb.sig_len <= 32u;
+        uint64_t need[ECH_COUNT + 1] = {0};
+        need[ECH_COUNT] = 6ull * jb.n_ids + 2u;
+        for (uint32_t k = 0; ok && k < jb.n_ops; ++k) {
+            const EmitOp& op = ops[jb.first_op + k];
+            const uint32_t chL = fsemit::channel_l(op), chB = fsemit::channel_b(op);
+            ok = op.pad2[0] == j && chL < ECH_COUNT;
+            if (!ok) break;
+            switch (op.kind) {
+            case EMIT_HARD: case EMIT_PE_HARD: ok = (uint64_t)op.seq_a + op.len_a <= jb.seq_bytes; need[chL] += op.len_a + 1u; break;
+            case EMIT_MATCH: case EMIT_PE_MATCH: {
+                const uint32_t as = (uint32_t)(op.shift < 0 ? -op.shift : op.shift);
+                ok = (uint64_t)op.seq_a + op.len_a <= jb.seq_bytes && (uint64_t)op.seq_b + op.len_b <= jb.seq_bytes && as <= op.len_a && as <= op.len_b && op.mode <= EMIT_EXPENSIVE;
+                need[chL] += op.len_a; if (chB < ECH_COUNT) need[chB] += op.len_a;
+                break; }
+            case EMIT_CREAD: ok = (uint64_t)op.seq_a + op.len_a <= jb.seq_bytes && op.pos_a <= op.len_a && op.pos_b == op.len_a && (uint64_t)op.seq_b + 4ull * op.pos_b <= jb.contig_bytes &&
+                                  jb.end_cut <= op.len_a; need[chL] += op.len_a; break;
+            case EMIT_CDEF: ok = op.len_a <= op.len_b && op.len_b <= 2u * op.pos_b && op.pos_a <= op.pos_b && (uint64_t)op.seq_b + 4ull * op.pos_b <= jb.contig_bytes;
+                            need[chL] += 2u * op.pos_b; need[chB] += 2u * op.pos_b; break;
+            default: ok = false;
+            }
+        }
+        for (uint32_t c = 0; ok && c <= ECH_COUNT; ++c) {
+            if (need[c] == 0 && jb.item[c] == 0xFFFFFFFFu) continue;
+            const uint64_t unit = c == ECH_COUNT ? 1u : (fsemit::is_bit_channel(c) ? 1u : ((c == ECH_HARD || c == ECH_HARD_PE) ? 1u : 2u));
+            ok = jb.item[c] < nItems && need[c] <= jb.cap[c] && jb.out_off[c] + unit * jb.cap[c] + 2u <= plan.out_bytes &&
+                 (c == ECH_COUNT || !fsemit::is_bit_channel(c) || jb.raw_off[c] + (uint64_t)jb.cap[c] <= plan.out_bytes);
+        }
+        if (!ok) { snprintf(dev->err, sizeof dev->err, "emission job %u outside the batch input", j); return -1; }
+    }
+    return 0;
+}
+static int emit_launch(Device* dev, hipStream_t st, const EmitPlan& plan, uint64_t emitBase, const EmitLaunch& L)
+{
+    if (plan.n_jobs == 0) return 0;
+    const EmitJob* jobs = (const EmitJob*)(dev->dIn + plan.jobs_off); const EmitOp* ops = (const EmitOp*)(dev->dIn + plan.ops_off);
+    uint32_t* counts = (uint32_t*)(dev->dIn + L.countsOff); uint32_t* offs = (uint32_t*)(dev->dIn + L.offsOff); uint32_t* totals = (uint32_t*)(dev->dIn + L.totalsOff);
+    uint8_t* out = (uint8_t*)(dev->dIn + emitBase);
+    if (plan.n_ops) {
+        hipLaunchKernelGGL(fs_emit_count, dim3((plan.n_ops + 255u) / 256u), dim3(256), 0, st, jobs, ops, plan.n_ops, (const uint8_t*)dev->dIn, counts);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(fs_emit_scan, dim3(plan.n_jobs), dim3(256), 0, st, jobs, ops, (const uint32_t*)counts, offs, totals, (StreamItem*)dev->dItems);
+    HIP_TRY(hipGetLastError());
+    if (plan.n_ops) {
+        hipLaunchKernelGGL(fs_emit_write, dim3((plan.n_ops + 255u) / 256u), dim3(256), 0, st, jobs, ops, plan.n_ops, (const uint8_t*)dev->dIn, (const uint32_t*)offs, out);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(fs_rle_binary, dim3(3u * plan.n_jobs), dim3(256), 0, st, jobs, (const uint32_t*)totals, out, (StreamItem*)dev->dItems);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(fs_rle0, dim3(plan.n_jobs), dim3(256), 0, st, jobs, (const uint32_t*)(dev->dIn + plan.ids_off), out, (StreamItem*)dev->dItems);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items,
-                      std::vector<uint32_t>& sizes, uint64_t& scratchBytes, BatchTiming* timing, const GatherPlan* gather = nullptr, const IdPlan* ids = nullptr)
+                      std::vector<uint32_t>& sizes, uint64_t& scratchBytes, BatchTiming* timing, const GatherPlan* gather = nullptr, const IdPlan* ids = nullptr, const EmitPlan* emit = nullptr)
 {
     HIP_TRY(hipSetDevice(dev->deviceId));
     hipStream_t st = (hipStream_t)dev->stream;
@@ -868,7 +1126,10 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
 
     // the gathered quality streams live behind the uploaded bytes
     // (quality streams first, then the read-id streams)
-    const uint64_t gatherBase = ((uint64_t)inputBytes + 15u) & ~15ull, gatherBytes = (gather ? gather->out_bytes : 0) + (ids ? ids->out_bytes : 0);
+    // (quality streams first, then the read-id streams, then what the emission kernels write)
+    const uint64_t emitBase = (((uint64_t)inputBytes + 15u) & ~15ull) + (gather ? gather->out_bytes : 0) + (ids ? ids->out_bytes : 0);
+    const uint64_t gatherBase = ((uint64_t)inputBytes + 15u) & ~15ull, gatherBytes = (gather ? gather->out_bytes : 0) + (ids ? ids->out_bytes : 0) + (emit ? emit->out_bytes : 0);
+    if (emit && emit->n_jobs && emit_check(dev, input, inputBytes, *emit, (uint32_t)items.size())) return -1;
     if (ids && (ids->jobs_off & 7u || ids->strings_off & 7u || ids->jobs_off + (uint64_t)ids->n_jobs * sizeof(IdJob) > inputBytes || ids->strings_off + (uint64_t)ids->n_strings * sizeof(IdString) > inputBytes)) {
         snprintf(dev->err, sizeof dev->err, "read-id plan outside the batch input"); return -1;
     }
@@ -877,9 +1138,11 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
                    (gather->bits != 6u && gather->bits != 3u && gather->bits != 1u) || (gather->bits != 6u && gather->n_list_off + gather->n_list_bytes > inputBytes))) {
         snprintf(dev->err, sizeof dev->err, "quality gather plan outside the batch input"); return -1;
     }
-    IdLaunch idl;
+    IdLaunch idl; EmitLaunch eml;
     if (ids && ids->n_jobs) id_launch_plan((const IdJob*)(input + ids->jobs_off), ids->n_jobs, ids->n_strings, gatherBase + gatherBytes, idl);
-    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + gatherBytes + idl.bytes + kInSlack)) return -1;
+    if (emit && emit->n_jobs) emit_launch_plan(*emit, gatherBase + gatherBytes + idl.bytes, eml);
+    if (gatherBase + gatherBytes + idl.bytes + eml.bytes > 0xFFFFFF00ull) { snprintf(dev->err, sizeof dev->err, "batch input and device-written streams beyond 4 GiB"); return -1; }
+    if (ensure(dev, dev->dIn, dev->capIn, gatherBase + gatherBytes + idl.bytes + eml.bytes + kInSlack)) return -1;
     if (ensure(dev, dev->dScratch, dev->capScratch, scratch + 16)) return -1;
     if (ensure(dev, dev->dItems, dev->capItems, sizeof(StreamItem) * nItems)) return -1;
     if (ensure(dev, dev->dOrder, dev->capOrder, 4ull * nItems)) return -1;
@@ -983,6 +1246,7 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         }
         if (id_launch(dev, st, *ids, gatherBase, idl)) return -1;
     }
+    if (emit && emit->n_jobs && emit_launch(dev, st, *emit, emitBase, eml)) return -1;
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[0], st));
     {
         EncodeArgs ka;
@@ -1164,15 +1428,46 @@ int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std
 
 // Entropy-code a batch of bins and assemble their blocks: `input` holds every stream's pre-entropy
 // bytes / (symbol, ctx) pairs.
+static uint64_t emit_stream_bytes(uint32_t c, uint32_t inLen)
+{ return (c == ECH_COUNT || fsemit::is_bit_channel(c) || c == ECH_HARD || c == ECH_HARD_PE) ? (uint64_t)inLen : 2ull * inLen; }
+
+int emit_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, const EmitPlan& plan, std::vector<StreamItem>& items, std::vector<std::vector<std::vector<uint8_t>>>& streams)
+{
+    HIP_TRY(hipSetDevice(dev->deviceId));
+    hipStream_t st = (hipStream_t)dev->stream;
+    if (emit_check(dev, input, inputBytes, plan, (uint32_t)items.size())) return -1;
+    const uint64_t emitBase = ((uint64_t)inputBytes + 15u) & ~15ull;
+    EmitLaunch eml; emit_launch_plan(plan, emitBase + plan.out_bytes, eml);
+    if (ensure(dev, dev->dIn, dev->capIn, emitBase + plan.out_bytes + eml.bytes + kInSlack)) return -1;
+    if (ensure(dev, dev->dItems, dev->capItems, sizeof(StreamItem) * items.size() + 64)) return -1;
+    HIP_TRY(hipMemcpyAsync(dev->dIn, input, inputBytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dev->dItems, items.data(), sizeof(StreamItem) * items.size(), hipMemcpyHostToDevice, st));
+    if (emit_launch(dev, st, plan, emitBase, eml)) return -1;
+    std::vector<uint8_t> out(plan.out_bytes + 16);
+    HIP_TRY(hipMemcpyAsync(out.data(), dev->dIn + emitBase, plan.out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(items.data(), dev->dItems, sizeof(StreamItem) * items.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(wait_stream(dev, st));
+    const EmitJob* jobs = (const EmitJob*)(input + plan.jobs_off);
+    streams.assign(plan.n_jobs, std::vector<std::vector<uint8_t>>(ECH_COUNT + 1));
+    for (uint32_t j = 0; j < plan.n_jobs; ++j)
+        for (uint32_t c = 0; c <= ECH_COUNT; ++c) {
+            if (jobs[j].item[c] == 0xFFFFFFFFu) continue;
+            const uint64_t n = emit_stream_bytes(c, items[jobs[j].item[c]].in_len);
+            if (jobs[j].out_off[c] + n > plan.out_bytes) { snprintf(dev->err, sizeof dev->err, "emission job %u: stream %u longer than its room", j, c); return -1; }
+            streams[j][c].assign(out.begin() + (ptrdiff_t)jobs[j].out_off[c], out.begin() + (ptrdiff_t)(jobs[j].out_off[c] + n));
+        }
+    return 0;
+}
+
 int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items,
                  std::vector<BlockPlan>& plans, std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes,
-                 BatchTiming* timing, const GatherPlan* gather, const IdPlan* ids)
+                 BatchTiming* timing, const GatherPlan* gather, const IdPlan* ids, const EmitPlan* emit)
 {
     const uint32_t nItems = (uint32_t)items.size(), nBins = (uint32_t)plans.size();
     blockSizes.assign(nBins, 0);                 // `blocks` keeps its size between calls: resize() below does not re-zero what is overwritten anyway
     if (nItems == 0) { blocks.clear(); return 0; }
     std::vector<uint32_t> sizes; uint64_t scratch = 0;
-    if (run_encode(dev, input, inputBytes, items, sizes, scratch, timing, gather, ids)) return -1;
+    if (run_encode(dev, input, inputBytes, items, sizes, scratch, timing, gather, ids, emit)) return -1;
     hipStream_t st = (hipStream_t)dev->stream;
     if (ensure(dev, dev->dPlans, dev->capPlans, sizeof(BlockPlan) * nBins)) return -1;
     // a stream that filled its scratch slot was clipped: refuse rather than emit a corrupt block

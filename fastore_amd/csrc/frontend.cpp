@@ -201,7 +201,16 @@ struct BinEncoder::Impl {
 
     struct LzContext { std::vector<int32_t> history; };
     std::vector<LzContext> lzStack;
-    struct ConsEnc { int32_t lastMinimPos = 0; const Contig* def = nullptr; };
+    struct ConsEnc { int32_t lastMinimPos = 0; const Contig* def = nullptr; uint32_t defOff = 0; };      // defOff: the contig's bytes in out->contigBytes (device-side emission)
+    // device-side emission: the walk leaves an op where it would compare bases (emit_core.h does that on the device)
+    bool devEmit = false;
+    uint32_t seqRel(const uint8_t* p) const { return (uint32_t)((uint64_t)(p - B->seq.data()) - out->emitSeqLo); }
+    void pushOp(uint32_t kind, uint32_t a, uint32_t b, uint32_t lenA, uint32_t lenB, uint32_t posA, uint32_t posB, int32_t shift, uint32_t mode)
+    {
+        fsdev::EmitOp op; memset(&op, 0, sizeof op);
+        op.kind = kind; op.seq_a = a; op.seq_b = b; op.len_a = (uint16_t)lenA; op.len_b = (uint16_t)lenB; op.pos_a = (uint16_t)posA; op.pos_b = (uint16_t)posB; op.shift = (int16_t)shift; op.mode = (uint8_t)mode;
+        out->emitOps.push_back(op);
+    }
     std::vector<ConsEnc> consStack;
 
     explicit Impl(const PackParams& p) : par(p) { memset(dnaToIdx, -1, sizeof dnaToIdx); }
@@ -316,6 +325,7 @@ struct BinEncoder::Impl {
     bool havePre = false;                      // mRows hold the device's answers: constructMatchTree does not scan
     bool traceResize = false;
     std::vector<fsdev::MatchRow>* matchTrace = nullptr;   // host scan: note every read's answer here (same indexing as mRows)
+    bool wantDevEmit = false;            // BinEncoder::setDeviceEmit
     MatchFn matcher;
     uint64_t matchSeqBase = 0, matchSeqBytes = 0;
 
@@ -950,6 +960,7 @@ struct BinEncoder::Impl {
         putSym(S_Rev, isReverse(v));
         putByte(S_Flag, ReadDifficult);
         const uint8_t* s = seq(v); const int32_t L = (int32_t)seqLen(v), m = (int32_t)minimPos(v);
+        if (devEmit) { pushOp(fsdev::EMIT_HARD, seqRel(s), 0, (uint32_t)L, 0, (uint32_t)m, 0, 0, 0); out->emitBound[fsdev::ECH_HARD] += (uint32_t)L + 1u; return; }
         for (int32_t i = 0; i < L; ++i) {
             if (i < m || i >= m + (int32_t)sigLen) putByte(S_HardReads, s[i]);
             else if (i == m) putByte(S_HardReads, '.');
@@ -962,11 +973,19 @@ struct BinEncoder::Impl {
         const int32_t v = n.vrec, lv = n.lzVrec;
         putSym(S_Rev, isReverse(v));
         putByte(S_Shift, (uint32_t)(ShiftOffset + n.shift));
-        lzRle0.put(lzId);
+        if (devEmit) out->lzIds.push_back(lzId); else lzRle0.put(lzId);
         const int32_t flag = n.noMismatches ? ReadShiftOnly : (expensive ? ReadFullExpensive : ReadFullEncode);
         putByte(S_Flag, (uint32_t)flag);
         const uint8_t* bestSeq = seq(lv); uint32_t bestLen = seqLen(lv), bestPos = minimPos(lv);
         const uint8_t* newSeq = seq(v); uint32_t newLen = seqLen(v);
+        if (devEmit) {
+            const uint32_t mode = flag == ReadFullEncode ? fsdev::EMIT_FULL : (flag == ReadFullExpensive ? fsdev::EMIT_EXPENSIVE : fsdev::EMIT_SHIFT_ONLY);
+            pushOp(fsdev::EMIT_MATCH, seqRel(newSeq), seqRel(bestSeq), newLen, bestLen, 0, bestPos, n.shift, mode);
+            out->emitBound[fsdev::ECH_LETTERS] += newLen;
+            if (mode == fsdev::EMIT_FULL) out->emitBound[fsdev::ECH_MATCH_BITS] += newLen; else if (mode == fsdev::EMIT_EXPENSIVE) out->emitBound[fsdev::ECH_MATCH_BIN] += newLen;
+            out->emitBound[fsdev::ECH_COUNT] += 6u;
+            return;
+        }
         if (n.shift >= 0) { bestSeq += n.shift; bestLen -= n.shift; bestPos -= n.shift; }
         else {
             for (int32_t i = 0; i < -n.shift; ++i) putSym(S_LettersX, d2i(newSeq[i]), d2i('N'));
@@ -1000,6 +1019,7 @@ struct BinEncoder::Impl {
         const uint32_t consStart = readLen - m;
         const uint8_t* s = seq(v); const Contig& def = *ce.def;
         if (readLen != def.readLen) throw std::runtime_error("reads of different lengths in one read cluster: variable-length libraries are not supported (neither by the reference encoder)");
+        if (devEmit) { pushOp(fsdev::EMIT_CREAD, seqRel(s), ce.defOff, readLen, 0, (uint32_t)m, def.readLen, 0, 0); out->emitBound[fsdev::ECH_CLETTERS] += readLen; return; }
         uint32_t it = 0;
         while (it < par.beginCut) {
             if (it == (uint32_t)m) { it += sigLen; continue; }
@@ -1056,6 +1076,16 @@ struct BinEncoder::Impl {
             const int32_t rangeDiff = (int32_t)d.rangeSecond - (int32_t)d.rangeFirst;
             const int32_t rescale = (int32_t)sigLen + 2 + 2;      // Default::BeginCut + Default::EndCut
             putByte(S_TreeShift, (uint32_t)(rangeDiff - (int32_t)d.readLen + rescale));
+        }
+        if (devEmit) {
+            ConsEnc& ce = consStack.back();
+            ce.defOff = (uint32_t)out->contigBytes.size();
+            out->contigBytes.insert(out->contigBytes.end(), (const uint8_t*)d.sequence.data(), (const uint8_t*)d.sequence.data() + d.sequence.size());
+            out->contigBytes.insert(out->contigBytes.end(), d.variant.begin(), d.variant.end());
+            if (d.sequence.size() != 2u * d.readLen || d.variant.size() != 2u * d.readLen) throw std::runtime_error("contig of an unexpected extent");
+            pushOp(fsdev::EMIT_CDEF, 0, ce.defOff, d.rangeFirst, d.rangeSecond, mainSigPos, d.readLen, 0, 0);
+            out->emitBound[fsdev::ECH_CLETTERS] += 2u * d.readLen; out->emitBound[fsdev::ECH_CMATCH_BITS] += 2u * d.readLen;
+            return;
         }
         for (uint32_t i = d.rangeFirst; i < d.rangeSecond; ++i) {
             if (i == d.readLen) { i += sigLen - 1; continue; }
@@ -1199,6 +1229,13 @@ struct BinEncoder::Impl {
         o.reset(pe ? S_PE_COUNT : S_SE_COUNT);
         if (cfg.quaParams.method == MET_QVZ) well.reset(arch.qvz.wellSeed);
         initNodes(bin);
+        devEmit = wantDevEmit && bin.recCount > 0 && bin.maxLen <= 255;
+        if (devEmit) {      // the bin's bases: one stretch of the batch's base array (its records were unpacked one behind the other)
+            uint64_t lo = ~0ull, hi = 0;
+            for (uint32_t i = 0; i < bin.recCount; ++i) { const Rec& r = B->recs[bin.recBegin + i]; lo = std::min<uint64_t>(lo, r.seqOff); hi = std::max<uint64_t>(hi, (uint64_t)r.seqOff + r.seqLen + r.auxLen); }
+            if (hi - lo > 0xFFFFFF00ull) devEmit = false;
+            else { o.deviceEmit = true; o.emitSeqLo = lo; o.emitSeqHi = hi; o.emitSeq = B->seq.data() + lo; o.emitBound[fsdev::ECH_COUNT] = 2; }
+        }
         lzStack.clear(); consStack.clear();
         lzStack.push_back(LzContext());
         matchRle.start(&o.s[S_Match]); consMatchRle.start(&o.s[S_CMatch]); lzRle0.start(&o.s[S_LzId]);
@@ -1255,6 +1292,7 @@ namespace fs {
 
 BinEncoder::BinEncoder(const PackParams& par) : impl_(new Impl(par)) {}
 void BinEncoder::setMatcher(MatchFn fn) { impl_->matcher = std::move(fn); }
+void BinEncoder::setDeviceEmit(bool on) { impl_->wantDevEmit = on; }
 void BinEncoder::setMateMatcher(MateFn fn) { impl_->mateMatcher = std::move(fn); }
 void BinEncoder::checkMateMatcher(const Batch& data, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, const MateFn& fn, uint64_t& pairs, uint64_t& differing)
 {

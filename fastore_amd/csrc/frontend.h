@@ -61,7 +61,15 @@ struct BinStreams {
     const uint8_t* quaPacked = nullptr; uint64_t quaPackedBytes = 0;      // the bin's .bqua bytes (owned by the batch)
     // device-side read-id tokeniser: s[S_IdToken] / s[S_IdValue] stay empty, the device writes them from these
     std::vector<IdRef> idRefs; const uint8_t* headPacked = nullptr; uint64_t headPackedBytes = 0;
-    void reset(uint32_t n) { nStreams = n; rawIdSize = 0; for (auto& v : s) v.clear(); quaRefs.clear(); quaSymbols = 0; quaN.clear(); quaPacked = nullptr; quaPackedBytes = 0; idRefs.clear(); headPacked = nullptr; headPackedBytes = 0; }
+    // device-side emission (fsdev::EmitOp, emit_core.h): the streams that hold bases -- HardReads, LettersX, Match, MatchBinary, CMatch,
+    // CLetters, their paired-end counterparts -- and LzId stay empty; the device writes them from the ops the walk left, the bin's
+    // bases [emitSeqLo, emitSeqHi) of the batch's base array, its contigs' bytes and its LZ ids
+    bool deviceEmit = false;
+    std::vector<fsdev::EmitOp> emitOps; std::vector<uint32_t> lzIds; std::vector<uint8_t> contigBytes;
+    uint64_t emitSeqLo = 0, emitSeqHi = 0; const uint8_t* emitSeq = nullptr;      // (emitSeq: the first of those bases; owned by the batch)
+    uint64_t emitBound[fsdev::ECH_COUNT + 1] = {0};          // per channel: an upper bound of its units (bytes, pairs, bits); [ECH_COUNT]: LzId bytes
+    void reset(uint32_t n) { nStreams = n; rawIdSize = 0; for (auto& v : s) v.clear(); quaRefs.clear(); quaSymbols = 0; quaN.clear(); quaPacked = nullptr; quaPackedBytes = 0; idRefs.clear(); headPacked = nullptr; headPackedBytes = 0;
+                             deviceEmit = false; emitOps.clear(); lzIds.clear(); contigBytes.clear(); emitSeqLo = emitSeqHi = 0; emitSeq = nullptr; for (auto& b : emitBound) b = 0; }
 };
 
 // which streams are range-coded in place (true) vs PPMd-compressed (false), and with which model
@@ -92,6 +100,8 @@ public:
     void checkMateMatcher(const Batch& data, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, const MateFn& fn, uint64_t& pairs, uint64_t& differing);
     // window searches of the following encodeLz calls go through `fn` (empty: the host scan)
     void setMatcher(MatchFn fn);
+    // the streams that hold bases are written by the device from ops (fsdev::EmitOp) instead of by the walk itself
+    void setDeviceEmit(bool on);
     // parity check of the device matcher: runs the bin through the host scan and through `fn`, returns the number of reads
     // and of rows that differ (match, cost, shift, mismatch-free flag, duplicate flag)
     void checkMatcher(const Batch& data, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, const MatchFn& fn, uint64_t& reads, uint64_t& differing);

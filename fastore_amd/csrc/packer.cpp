@@ -498,6 +498,75 @@ void Context::matcherCheck(const std::string& inPrefix, uint64_t& reads, uint64_
     deviceMatcher = keep;
 }
 
+// Parity harness of the emission kernels (fs_emit_count / _scan / _write, fs_rle_binary, fs_rle0): every standard bin of a library
+// through the walk twice -- once writing the streams that hold bases itself (the host restatement of CompressHardRead ...
+// StoreContigDefinition and of the run-length coders), once leaving ops -- and the ops through the device; the eleven streams
+// (seven in single-end bins) byte for byte.
+void Context::emitCheck(const std::string& inPrefix, uint64_t& ops, uint64_t& streamsCompared, uint64_t& differing)
+{
+    ops = streamsCompared = differing = 0;
+    (void)device();
+    BinFile bf; bf.open(inPrefix, par.minBinSize);
+    ArchiveParams arch; arch.cfg = bf.config(); arch.head = bf.headData(); arch.qvz = bf.qvz();
+    static const uint32_t streamOf[fsdev::ECH_COUNT + 1] = {S_HardReads, S_LettersX, S_Match, S_MatchBinary, S_CMatch, S_CLetters, S_HardPE, S_LettersXPE, S_MatchRlePE, S_MatchBinaryPE, S_LzId};
+    for (uint32_t sig : bf.stdSignatures()) {
+        Batch b; bf.unpack(sig, b, true);
+        BinEncoder enc(par);
+        BinStreams host, dev;
+        enc.setDeviceEmit(false); enc.encodeLz(b, b, b.bins.at(0), arch, host);
+        enc.setDeviceEmit(true); enc.encodeLz(b, b, b.bins.at(0), arch, dev);
+        if (!dev.deviceEmit) throw std::runtime_error("the walk left no ops");
+        const bool pe = dev.nStreams == S_PE_COUNT;
+        // one job: the bin's bases, contig bytes, ops and ids; every stream's room by the walk's bounds
+        fsdev::EmitJob job; memset(&job, 0, sizeof job);
+        uint64_t off = 0, outBytes = 0;
+        job.seq_off = off; job.seq_bytes = (uint32_t)(dev.emitSeqHi - dev.emitSeqLo); off += (job.seq_bytes + 15u) & ~15ull;
+        job.contig_off = off; job.contig_bytes = (uint32_t)dev.contigBytes.size(); off += (job.contig_bytes + 15u) & ~15ull;
+        fsdev::EmitPlan plan; plan.n_jobs = 1; plan.n_ops = (uint32_t)dev.emitOps.size(); plan.n_ids = (uint32_t)dev.lzIds.size();
+        plan.jobs_off = off; off += (sizeof job + 15u) & ~15ull;
+        plan.ops_off = off; off += (dev.emitOps.size() * sizeof(fsdev::EmitOp) + 15u) & ~15ull;
+        plan.ids_off = off; off += (4ull * dev.lzIds.size() + 15u) & ~15ull;
+        job.n_ops = plan.n_ops; job.n_ids = plan.n_ids;
+        job.sig_len = arch.cfg.minimizer.signatureLen; job.begin_cut = par.beginCut; job.end_cut = par.endCut;
+        memset(job.dna_to_idx, 0xFF, sizeof job.dna_to_idx);
+        for (int q = 0; q < 5; ++q) job.dna_to_idx[(uint8_t)arch.cfg.minimizer.dnaSymbolOrder[q] & 127u] = (uint8_t)q;
+        std::vector<fsdev::StreamItem> items;
+        for (uint32_t c = 0; c <= fsdev::ECH_COUNT; ++c) {
+            const bool peChannel = c >= fsdev::ECH_HARD_PE && c < fsdev::ECH_COUNT;
+            if (peChannel && !pe) { job.item[c] = 0xFFFFFFFFu; continue; }
+            const bool bits = c == fsdev::ECH_MATCH_BITS || c == fsdev::ECH_CMATCH_BITS || c == fsdev::ECH_MATCH_BITS_PE;
+            const uint64_t unit = (c == fsdev::ECH_COUNT || bits || c == fsdev::ECH_HARD || c == fsdev::ECH_HARD_PE) ? 1u : 2u;
+            const uint64_t bound = dev.emitBound[c] + 2u;
+            fsdev::StreamItem it; memset(&it, 0, sizeof it); it.in_len = (uint32_t)bound;
+            job.item[c] = (uint32_t)items.size(); job.cap[c] = (uint32_t)bound; job.out_off[c] = outBytes; outBytes += (unit * bound + 2u + 15u) & ~15ull;
+            if (bits) { job.raw_off[c] = outBytes; outBytes += (bound + 15u) & ~15ull; }
+            items.push_back(it);
+        }
+        plan.out_bytes = outBytes;
+        std::vector<uint8_t> input(off + 16, 0);
+        memcpy(input.data() + job.seq_off, dev.emitSeq, job.seq_bytes);
+        if (job.contig_bytes) memcpy(input.data() + job.contig_off, dev.contigBytes.data(), job.contig_bytes);
+        memcpy(input.data() + plan.jobs_off, &job, sizeof job);
+        if (plan.n_ops) memcpy(input.data() + plan.ops_off, dev.emitOps.data(), dev.emitOps.size() * sizeof(fsdev::EmitOp));      // (pad2[0] = job 0 already)
+        if (plan.n_ids) memcpy(input.data() + plan.ids_off, dev.lzIds.data(), 4ull * dev.lzIds.size());
+        std::vector<std::vector<std::vector<uint8_t>>> got;
+        if (fsengine::emit_streams_raw(device(), input.data(), off, plan, items, got) != 0) throw std::runtime_error(std::string("device: ") + device()->err);
+        ops += plan.n_ops;
+        for (uint32_t c = 0; c <= fsdev::ECH_COUNT; ++c) {
+            if (job.item[c] == 0xFFFFFFFFu) continue;
+            ++streamsCompared;
+            if (got[0][c] != host.s[streamOf[c]]) ++differing;
+        }
+        // (every other stream is the walk's own either way)
+        for (uint32_t s = 0; s < dev.nStreams; ++s) {
+            bool devStream = false;
+            for (uint32_t c = 0; c <= fsdev::ECH_COUNT; ++c) devStream = devStream || streamOf[c] == s;
+            if (!devStream && dev.s[s] != host.s[s]) ++differing;
+            if (devStream && !dev.s[s].empty()) ++differing;
+        }
+    }
+}
+
 void Context::tokeniserCheck(const std::string& inPrefix, uint64_t& ids, uint64_t& differingBins)
 {
     ids = differingBins = 0;
@@ -760,6 +829,16 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             std::vector<uint64_t> idTabOff(archives.size(), ~0ull); std::vector<std::vector<uint8_t>> idTab(archives.size());
             std::vector<uint32_t> idTok(archives.size(), 0), idVal(archives.size(), 0);
             std::vector<uint64_t> headOff(count, 0); std::vector<fsdev::IdJob> idJobs; std::vector<uint32_t> idJobBin; uint64_t idBytes = 0, nIdStrings = 0;
+            // device-side emission (fsdev::EmitOp): per bin a job -- its ops, LZ ids, bases and contig bytes in the input, the streams it writes
+            std::vector<fsdev::EmitJob> emitJobs; std::vector<uint32_t> emitJobBin, emitItems; uint64_t emitBytes = 0, nEmitOps = 0, nEmitIds = 0;
+            auto emitChannelOf = [](uint32_t s) -> int {
+                switch (s) {
+                case S_HardReads: return fsdev::ECH_HARD; case S_LettersX: return fsdev::ECH_LETTERS; case S_Match: return fsdev::ECH_MATCH_BITS; case S_MatchBinary: return fsdev::ECH_MATCH_BIN;
+                case S_CMatch: return fsdev::ECH_CMATCH_BITS; case S_CLetters: return fsdev::ECH_CLETTERS; case S_LzId: return fsdev::ECH_COUNT;
+                case S_HardPE: return fsdev::ECH_HARD_PE; case S_LettersXPE: return fsdev::ECH_LETTERS_PE; case S_MatchRlePE: return fsdev::ECH_MATCH_BITS_PE; case S_MatchBinaryPE: return fsdev::ECH_MATCH_BIN_PE;
+                default: return -1;
+                }
+            };
             for (uint32_t k = 0; k < count; ++k) {
                 const uint32_t b = byWork[first + k], a = binArch[b];
                 if (st[b].idRefs.empty() || idTabOff[a] != ~0ull) continue;
@@ -837,6 +916,32 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                         S.items.push_back(it);
                         continue;
                     }
+                    if (bs.deviceEmit && emitChannelOf(s) >= 0) {      // written on the device from the walk's ops: in_len is set there (here: its bound)
+                        const uint32_t c = (uint32_t)emitChannelOf(s);
+                        if (emitJobBin.empty() || emitJobBin.back() != k) {      // (the bin's first device-written stream: its job)
+                            fsdev::EmitJob j; memset(&j, 0, sizeof j);
+                            for (uint32_t q = 0; q <= fsdev::ECH_COUNT; ++q) j.item[q] = 0xFFFFFFFFu;
+                            j.first_op = (uint32_t)nEmitOps; j.n_ops = (uint32_t)bs.emitOps.size(); j.first_id = (uint32_t)nEmitIds; j.n_ids = (uint32_t)bs.lzIds.size();
+                            nEmitOps += bs.emitOps.size(); nEmitIds += bs.lzIds.size();
+                            emitJobs.push_back(j); emitJobBin.push_back(k);
+                        }
+                        fsdev::EmitJob& j = emitJobs.back();
+                        const uint64_t bound = bs.emitBound[c] + 2u;
+                        if (bound > 0x38000000ull) throw std::runtime_error("stream larger than 4 GiB");
+                        StreamItem it; memset(&it, 0, sizeof it);
+                        it.bin = k; it.in_len = (uint32_t)bound;
+                        const bool bits = c < fsdev::ECH_COUNT && (c == fsdev::ECH_MATCH_BITS || c == fsdev::ECH_CMATCH_BITS || c == fsdev::ECH_MATCH_BITS_PE);
+                        const uint64_t unit = (c == fsdev::ECH_COUNT || bits || c == fsdev::ECH_HARD || c == fsdev::ECH_HARD_PE) ? 1u : 2u;
+                        if (rc) { uint32_t model = streamModel(s, qm); it.kind = KIND_RC_BASE + model; it.out_cap = 2 * it.in_len + 32; pl.work_size[s] = ~0ull; }
+                        else { it.kind = KIND_PPMD; it.out_cap = (uint32_t)(bound + bound / 8 + 64); pl.work_size[s] = ~1ull; }      // (~1: the length the kernels leave in the item)
+                        j.item[c] = (uint32_t)S.items.size(); j.cap[c] = (uint32_t)bound;
+                        j.out_off[c] = emitBytes; it.in_off = emitBytes;            // relative to the emission's part of the device-only region for now
+                        emitBytes += (unit * bound + 2u + 15u) & ~15ull;
+                        if (bits) { j.raw_off[c] = emitBytes; emitBytes += (bound + 15u) & ~15ull; }
+                        emitItems.push_back((uint32_t)S.items.size());
+                        S.items.push_back(it);
+                        continue;
+                    }
                     StreamItem it; memset(&it, 0, sizeof it);
                     it.bin = k; it.in_off = inBytes;
                     // header-less archives never create the read-id coders: their streams stay empty (FastqCompressor.cpp:923-930)
@@ -853,6 +958,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 }
             }
             fsdev::GatherPlan gp; uint64_t gatherBaseQ = 0;
+            uint64_t devBase = 0;          // where the device-only region stands as the items placed in it so far see it (the input grows with every plan behind them)
             if (nStrings) {
                 if (nStrings > 0xFFFFFFF0ull || gatherBytes > 0xF0000000ull) throw std::runtime_error("quality gather larger than 4 GiB");
                 gp.desc_off = inBytes; gp.n_strings = (uint32_t)nStrings; gp.out_bytes = gatherBytes; gp.symbols = gatherSymbols; gp.bits = gatherBits; gp.qvz = gatherQvz ? 1u : 0u;
@@ -866,6 +972,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 }
                 gatherBaseQ = (inBytes + 15u) & ~15ull;
                 for (uint32_t gi : gatherItems) S.items[gi].in_off += gatherBaseQ;
+                devBase = gatherBaseQ;
             }
             fsdev::IdPlan ip;
             if (!idJobs.empty()) {
@@ -878,6 +985,36 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 if (nStrings) for (uint32_t gi : gatherItems) S.items[gi].in_off += gatherBase - gatherBaseQ;
                 for (uint32_t gi : idItems) S.items[gi].in_off += gatherBase + gatherBytes;
                 for (fsdev::IdJob& j : idJobs) { j.tok_out += gatherBytes; j.val_out += gatherBytes; }
+                devBase = gatherBase;
+            }
+            fsdev::EmitPlan ep;
+            std::vector<uint64_t> emitSeqOff(emitJobs.size(), 0), emitContigOff(emitJobs.size(), 0);
+            if (!emitJobs.empty()) {
+                if (nEmitOps > 0xFFFFFFF0ull || emitBytes > 0xF0000000ull) throw std::runtime_error("emitted streams larger than 4 GiB");
+                for (size_t j = 0; j < emitJobs.size(); ++j) {
+                    const BinStreams& bs = st[byWork[first + emitJobBin[j]]];
+                    emitSeqOff[j] = inBytes; inBytes += (bs.emitSeqHi - bs.emitSeqLo + 15u) & ~15ull;
+                    emitContigOff[j] = inBytes; inBytes += (bs.contigBytes.size() + 15u) & ~15ull;
+                }
+                ep.n_jobs = (uint32_t)emitJobs.size(); ep.n_ops = (uint32_t)nEmitOps; ep.n_ids = (uint32_t)nEmitIds; ep.out_bytes = emitBytes;
+                ep.jobs_off = inBytes; inBytes += (emitJobs.size() * sizeof(fsdev::EmitJob) + 15u) & ~15ull;
+                ep.ops_off = inBytes; inBytes += (nEmitOps * sizeof(fsdev::EmitOp) + 15u) & ~15ull;
+                ep.ids_off = inBytes; inBytes += (4ull * nEmitIds + 15u) & ~15ull;
+                // (the device-only region begins behind an input that has grown: the earlier parts' items are based again, this part's for the first time)
+                const uint64_t newBase = (inBytes + 15u) & ~15ull;
+                if (nStrings) for (uint32_t gi : gatherItems) S.items[gi].in_off += newBase - devBase;
+                for (uint32_t gi : idItems) S.items[gi].in_off += newBase - devBase;
+                for (uint32_t gi : emitItems) S.items[gi].in_off += newBase + gatherBytes + idBytes;
+                devBase = newBase;
+                for (size_t j = 0; j < emitJobs.size(); ++j) {
+                    const uint32_t b = byWork[first + emitJobBin[j]]; const BinStreams& bs = st[b];
+                    const BinModuleConfigRaw& binCfg = archives[binArch[b]].cfg;
+                    fsdev::EmitJob& jb = emitJobs[j];
+                    jb.seq_off = emitSeqOff[j]; jb.seq_bytes = (uint32_t)(bs.emitSeqHi - bs.emitSeqLo); jb.contig_off = emitContigOff[j]; jb.contig_bytes = (uint32_t)bs.contigBytes.size();
+                    jb.sig_len = binCfg.minimizer.signatureLen; jb.begin_cut = par.beginCut; jb.end_cut = par.endCut;
+                    memset(jb.dna_to_idx, 0xFF, sizeof jb.dna_to_idx);
+                    for (int q = 0; q < 5; ++q) jb.dna_to_idx[(uint8_t)binCfg.minimizer.dnaSymbolOrder[q] & 127u] = (uint8_t)q;
+                }
             }
             fsengine::Device* L;
             { std::lock_guard<std::mutex> lk(laneMx); L = lanes[(uint32_t)S.lane]; }
@@ -902,6 +1039,18 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                     }
                 });
             }
+            if (!emitJobs.empty()) {
+                memcpy(input + ep.jobs_off, emitJobs.data(), emitJobs.size() * sizeof(fsdev::EmitJob));
+                parallelFor((uint32_t)emitJobs.size(), 4, [&](uint32_t j, uint32_t) {
+                    const BinStreams& bs = st[byWork[first + emitJobBin[j]]];
+                    memcpy(input + emitSeqOff[j], bs.emitSeq, bs.emitSeqHi - bs.emitSeqLo);
+                    if (!bs.contigBytes.empty()) memcpy(input + emitContigOff[j], bs.contigBytes.data(), bs.contigBytes.size());
+                    fsdev::EmitOp* ops = (fsdev::EmitOp*)(input + ep.ops_off) + emitJobs[j].first_op;
+                    if (!bs.emitOps.empty()) memcpy(ops, bs.emitOps.data(), bs.emitOps.size() * sizeof(fsdev::EmitOp));
+                    for (size_t q = 0; q < bs.emitOps.size(); ++q) ops[q].pad2[0] = j;
+                    if (!bs.lzIds.empty()) memcpy(input + ep.ids_off + 4ull * emitJobs[j].first_id, bs.lzIds.data(), 4ull * bs.lzIds.size());
+                });
+            }
             // staging copy on a few helper threads of its own (the host threads are busy with the next slices' front end)
             std::vector<uint64_t> stringBase(count + 1, 0);          // first descriptor of every bin
             if (nStrings) for (uint32_t k = 0; k < count; ++k) stringBase[k + 1] = stringBase[k] + st[byWork[first + k]].quaRefs.size();
@@ -910,6 +1059,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 const bool gathered = !st[b].quaRefs.empty();
                 for (uint32_t s = 0; s < pl.n_streams; ++s) {
                     if (gathered && s == S_Quality) continue;
+                    if (st[b].deviceEmit && emitChannelOf(s) >= 0) continue;
                     const auto& v = st[b].s[s];
                     if (!v.empty()) memcpy(input + S.items[pl.first_item + s].in_off, v.data(), v.size());
                 }
@@ -949,7 +1099,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 }
             });
             S.tSubmit = nowMs(); S.inBytes = inBytes;
-            if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, sliceBlocks[si], S.sizes, &S.timing, nStrings ? &gp : nullptr, idJobs.empty() ? nullptr : &ip) != 0) S.err = std::string("device: ") + L->err;
+            if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, sliceBlocks[si], S.sizes, &S.timing, nStrings ? &gp : nullptr, idJobs.empty() ? nullptr : &ip, emitJobs.empty() ? nullptr : &ep) != 0) S.err = std::string("device: ") + L->err;
         } catch (const std::exception& e) { S.err = e.what(); }
         S.tDone = nowMs();
         { std::lock_guard<std::mutex> lk(laneMx); freeLanes.push_back((uint32_t)S.lane); }
@@ -1008,6 +1158,8 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     if (trace) fprintf(stderr, "[trace] batch set-up (slices, %u lanes, matcher lanes) %.1f ms\n", nLanes, tf - t0);
     try {
         std::mutex roundMx; std::condition_variable roundCv; uint32_t binsDone = 0;
+        const bool deviceMates = getenv("FS_DEVICE_MATES") && atoi(getenv("FS_DEVICE_MATES")) != 0;       // (read per batch: the tests switch it inside one process)
+        const bool deviceEmit = !(getenv("FS_DEVICE_EMIT") && atoi(getenv("FS_DEVICE_EMIT")) == 0);
         parallelFor(nBins, hostThreads, [&](uint32_t k, uint32_t tid) {
             const uint32_t b = byWork[k];
             if (abort.load()) return;                                // (the device could not be made: nothing left to do for the bins)
@@ -1027,8 +1179,10 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             // streams the searches share, every alignment priced in full (the host's search gives up on an alignment at the
             // first base past the best cost so far): the 6 M-pair step took 45 s with it against 2.6 s without,
             // profiles/r03_device_mate_search.txt.  FS_DEVICE_MATES=1 switches it on.)
-            static const bool deviceMates = getenv("FS_DEVICE_MATES") && atoi(getenv("FS_DEVICE_MATES")) != 0;
             encs[tid]->setMateMatcher(k < matcherBins && deviceMates ? mateMatcherFor(tid) : MateFn());
+            // the streams that hold bases (HardReads, LettersX, Match, ...: fsdev::EmitOp) and the LZ ids' run-length coding: written
+            // by the device from the ops the walk leaves (FS_DEVICE_EMIT=0: by the walk itself, A/B runs)
+            encs[tid]->setDeviceEmit(deviceEmit);
             const double ta = trace ? nowMs() : 0.0;
             produce(b, *encs[tid], st[b], info[b], recBytes[b]);
             if (trace) busyMs[tid] += nowMs() - ta;

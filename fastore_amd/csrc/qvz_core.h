@@ -172,17 +172,29 @@ FS_DEV uint32_t encode_stream(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32
 // shows as a descent.  No descent: no two symbols share a context.  One descent at lane b (the usual case when a window holds
 // the end of one read and the start of the next): a symbol of the second read can only share with the first read's part if its
 // context number reaches that of lane 0, the smallest there.  Anything else (reads shorter than a window) is compared pair by pair.
-struct QRecip { double inv; };
-// floor(range * c / total) for range <= 2^22, c <= total < 2^20 (arith.cpp:44-45 computes it by a 64-bit integer division).
-// range * c < 2^42 is exact in a double; times the correctly rounded 1 / total the result is off by less than 2^-29, and a
-// quotient that is not whole is at least 1 / total > 2^-20 away from the next whole number: truncation can only be one short,
-// and only when the division is exact -- which the remainder shows.
-FS_DEV uint32_t q_div(uint32_t range, uint32_t c, uint32_t total, double inv)
+// floor(range * c / total) for range <= 2^22, c <= total < 2^20 (arith.cpp:44-45 computes it by a 64-bit integer division), with
+// the fraction c / total made beforehand as a 32-bit fixed-point number f ~ c * 2^32 / total (q_frac: all the window's lanes at
+// once): mulhi(range, f) is the quotient or one beside it (range * 2^-32 < 2^-10 per unit of f's error), and the remainder -- its
+// low 32 bits are all of it, |r| < 2^21 -- says which.
+FS_DEV uint32_t q_frac(uint32_t c, uint32_t total)
 {
-    const double a = (double)range * (double)c;
-    uint32_t q = (uint32_t)(a * inv);
-    const uint64_t r = (uint64_t)range * c - (uint64_t)q * total;
-    q += r >= (uint64_t)total ? 1u : 0u;
+    const double x = (double)c * 4294967296.0 / (double)total;          // c * 2^32 < 2^52: exact before the division
+    return x >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)x;                // (c == total: the correction below lands on range)
+}
+FS_DEV uint32_t q_mulhi(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+FS_DEV uint32_t q_div(uint32_t range, uint32_t c, uint32_t total, uint32_t f)
+{
+    uint32_t q = q_mulhi(range, f);
+    const int32_t r = (int32_t)(range * c - q * total);                 // (mod 2^32: the true remainder is far inside)
+    q += r >= (int32_t)total ? 1u : 0u;
+    q -= r < 0 ? 1u : 0u;
     return q;
 }
 // One symbol through the interval: arithmetic_encoder_step (arith.cpp:33-103), the E1/E2/E3 loop in closed form.  The loop
@@ -190,12 +202,12 @@ FS_DEV uint32_t q_div(uint32_t range, uint32_t c, uint32_t total, double inv)
 // and only then -- the top bits now differ: l = 0.., u = 1.. -- counts the steps in which l continues 01 and u continues 10
 // (E3: the top bits stay different, so no decided bit can follow).  So: k1 = the length of the common prefix of l and u, k3 = the
 // length of the run, behind the top bit, of positions where l has a one and u a zero.
-FS_DEV void q_code(BitOut& o, uint32_t& l, uint32_t& u, uint32_t& scale3, uint32_t cumLo, uint32_t cnt, uint32_t total, double inv)
+FS_DEV void q_code(BitOut& o, uint32_t& l, uint32_t& u, uint32_t& scale3, uint32_t cumLo, uint32_t cnt, uint32_t total, uint32_t fLo, uint32_t fHi)
 {
     const uint32_t M22 = (1u << M_BITS) - 1u, clearMask = (1u << (M_BITS - 1)) - 1u;
     const uint32_t range = u - l + 1u;                       // <= 2^22
-    u = l + q_div(range, cumLo + cnt, total, inv) - 1u;
-    l = l + q_div(range, cumLo, total, inv);
+    u = l + q_div(range, cumLo + cnt, total, fHi) - 1u;
+    l = l + q_div(range, cumLo, total, fLo);
     const uint32_t x = (l ^ u) & M22;
     const uint32_t k1 = x ? (uint32_t)__builtin_clz(x) - (32u - M_BITS) : (uint32_t)M_BITS;
     if (k1) {
@@ -279,14 +291,13 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr i
         // the window's updates: every context is there once
         if (lane < take) { blk[0] = total + STEP; blk[1u + x] = cnt + STEP; }
         FS_EMU_MEET();
-        // every total's reciprocal, all lanes at once
-        const double inv = 1.0 / (double)(total ? total : 1u);
+        // every position's two fractions, all lanes at once
+        const uint32_t tsafe = total ? total : 1u;
+        const uint32_t fLo = q_frac(cumLo, tsafe), fHi = q_frac(cumLo + cnt, tsafe);
         l = FS_UNI(l); u = FS_UNI(u); scale3 = FS_UNI(scale3);
         for (uint32_t i = 0; i < take; ++i) {
             const uint32_t c0 = FS_UNI(fs_readlane(cumLo, i)), c1 = FS_UNI(fs_readlane(cnt, i)), tt = FS_UNI(fs_readlane(total, i));
-            const uint64_t ib = (uint64_t)__builtin_bit_cast(uint64_t, inv);
-            const uint64_t iu = (uint64_t)FS_UNI(fs_readlane((uint32_t)ib, i)) | ((uint64_t)FS_UNI(fs_readlane((uint32_t)(ib >> 32), i)) << 32);
-            q_code(o, l, u, scale3, c0, c1, tt, __builtin_bit_cast(double, iu));
+            q_code(o, l, u, scale3, c0, c1, tt, FS_UNI(fs_readlane(fLo, i)), FS_UNI(fs_readlane(fHi, i)));
         }
         k += take;
         if (take < W) {          // symbol k: shares its context, is due for a rescale, or is malformed -- the one-symbol step
@@ -297,7 +308,7 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr i
             if (x1 >= card1 || card1 > MAX_CARD) { bad = 1; break; }
             uint32_t c1, n1, t1;
             model_step(stat + off1, card1, x1, c1, n1, t1);
-            q_code(o, l, u, scale3, c1, n1, t1, 1.0 / (double)t1);
+            q_code(o, l, u, scale3, c1, n1, t1, q_frac(c1, t1), q_frac(c1 + n1, t1));
             ++k;
         }
     }

@@ -204,6 +204,15 @@ int fsgpu_pe_matcher_check(fsgpu_ctx* ctx, const char* in_prefix, uint64_t* pair
  * IdValue pair stream differs. */
 int fsgpu_tokeniser_check(fsgpu_ctx* ctx, const char* in_prefix, uint64_t* ids, uint64_t* differing_bins);
 
+/* Parity check of the device-side stream emission (fs_emit_count / fs_emit_scan / fs_emit_write, fs_rle_binary, fs_rle0): the
+ * streams of a bin that hold bases -- HardReads, LettersX, Match, MatchBinary, CMatch, CLetters, their paired-end counterparts --
+ * and the run-length coded LZ ids (CompressHardRead / CompressNormalMatch / CompressContigRead / StoreContigDefinition,
+ * fastore_pack/FastqCompressor.cpp:1388-1760; LzCompressorPE::CompressPair :4740-4900; BinaryRleEncoder / Rle0Encoder,
+ * rle/RleEncoder.h:21-79, 140-212).  Every standard bin through the host's walk twice -- writing those streams itself, and leaving
+ * ops for the device -- and the ops through the kernels: *ops = ops expanded, *streams = streams compared byte for byte (pre-entropy),
+ * *differing = streams that differ (every other stream of the bin must be the walk's own either way and counts here too). */
+int fsgpu_emit_check(fsgpu_ctx* ctx, const char* in_prefix, uint64_t* ops, uint64_t* streams, uint64_t* differing);
+
 /* Whole `fastore_pack e -i<in_prefix> -o<out_prefix>`: reads .bmeta/.bdna/.bqua/.bhead, writes
  * .cmeta/.cdata in the reference's -t1 block order. */
 int fsgpu_pack_file(fsgpu_ctx* ctx, const char* in_prefix, const char* out_prefix, int verbose /* 0 quiet, 1 = -v, 2 = progress line only */);

@@ -14,6 +14,7 @@
 #include "../../fastore_amd/csrc/ppmd_core.h"
 #include "../../fastore_amd/csrc/rc_core.h"
 #include "../../fastore_amd/csrc/qvz_core.h"
+#include "../../fastore_amd/csrc/emit_core.h"
 
 using namespace fsdev;
 namespace fsengine {
@@ -329,16 +330,63 @@ int gather_quality_raw(Device*, const uint8_t* input, size_t inputBytes, const G
     return 0;
 }
 
+// what fs_emit_count / fs_emit_scan / fs_emit_write / fs_rle_binary / fs_rle0 do, one op after the other (emit_core.h is the kernels' own source)
+static void emitStreams(uint8_t* buf, const EmitPlan& plan, uint64_t emitBase, std::vector<StreamItem>& items)
+{
+    const EmitJob* jobs = (const EmitJob*)(buf + plan.jobs_off); const EmitOp* ops = (const EmitOp*)(buf + plan.ops_off);
+    const uint32_t* ids = (const uint32_t*)(buf + plan.ids_off);
+    uint8_t* out = buf + emitBase;
+    for (uint32_t j = 0; j < plan.n_jobs; ++j) {
+        const EmitJob& job = jobs[j];
+        uint32_t at[ECH_COUNT] = {0};
+        for (uint32_t k = 0; k < job.n_ops; ++k) {
+            const EmitOp& op = ops[job.first_op + k];
+            const uint32_t chL = fsemit::channel_l(op), chB = fsemit::channel_b(op);
+            fsemit::Sink s; uint8_t dummy[4];
+            s.outL = chL < ECH_COUNT ? out + job.out_off[chL] + (uint64_t)fsemit::unit_l(chL) * at[chL] : dummy;
+            s.outB = chB < ECH_COUNT ? (fsemit::is_bit_channel(chB) ? out + job.raw_off[chB] + at[chB] : out + job.out_off[chB] + 2ull * at[chB]) : dummy;
+            fsemit::emit_op(op, job, buf + job.seq_off, buf + job.contig_off, s);
+            if (chL < ECH_COUNT) at[chL] += s.nL;
+            if (chB < ECH_COUNT) at[chB] += s.nB;
+        }
+        for (uint32_t c = 0; c < ECH_COUNT; ++c) {
+            if (job.item[c] == 0xFFFFFFFFu) continue;
+            items[job.item[c]].in_len = fsemit::is_bit_channel(c) ? fsemit::rle_binary_serial(out + job.raw_off[c], at[c], out + job.out_off[c]) : at[c];
+        }
+        if (job.item[ECH_COUNT] != 0xFFFFFFFFu) items[job.item[ECH_COUNT]].in_len = fsemit::rle0_serial(ids + job.first_id, job.n_ids, out + job.out_off[ECH_COUNT]);
+    }
+}
+
+int emit_streams_raw(Device*, const uint8_t* input, size_t inputBytes, const EmitPlan& plan, std::vector<StreamItem>& items, std::vector<std::vector<std::vector<uint8_t>>>& streams)
+{
+    const uint64_t emitBase = ((uint64_t)inputBytes + 15u) & ~15ull;
+    std::vector<uint8_t> work(emitBase + plan.out_bytes + 64);
+    memcpy(work.data(), input, inputBytes);
+    emitStreams(work.data(), plan, emitBase, items);
+    const EmitJob* jobs = (const EmitJob*)(input + plan.jobs_off);
+    streams.assign(plan.n_jobs, std::vector<std::vector<uint8_t>>(ECH_COUNT + 1));
+    for (uint32_t j = 0; j < plan.n_jobs; ++j)
+        for (uint32_t c = 0; c <= ECH_COUNT; ++c) {
+            if (jobs[j].item[c] == 0xFFFFFFFFu) continue;
+            const uint32_t len = items[jobs[j].item[c]].in_len;
+            const uint64_t n = (c == ECH_COUNT || fsemit::is_bit_channel(c) || c == ECH_HARD || c == ECH_HARD_PE) ? (uint64_t)len : 2ull * len;
+            streams[j][c].assign(work.begin() + (ptrdiff_t)(emitBase + jobs[j].out_off[c]), work.begin() + (ptrdiff_t)(emitBase + jobs[j].out_off[c] + n));
+        }
+    return 0;
+}
+
 int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<StreamItem>& items, std::vector<BlockPlan>& plans,
-                 std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes, BatchTiming* t, const GatherPlan* gather, const IdPlan* ids)
+                 std::vector<uint8_t>& blocks, std::vector<uint64_t>& blockSizes, BatchTiming* t, const GatherPlan* gather, const IdPlan* ids, const EmitPlan* emit)
 {
     std::vector<uint8_t> scratch; std::vector<uint32_t> sizes;
     std::vector<uint8_t> work;                          // the device's input buffer: uploaded bytes + gather region
-    if ((gather && gather->n_strings) || (ids && ids->n_jobs)) {
-        work.resize(((inputBytes + 15u) & ~(size_t)15u) + (gather ? gather->out_bytes : 0) + (ids ? ids->out_bytes : 0) + 64);
+    if ((gather && gather->n_strings) || (ids && ids->n_jobs) || (emit && emit->n_jobs)) {
+        const uint64_t emitBase = ((inputBytes + 15u) & ~(size_t)15u) + (gather ? gather->out_bytes : 0) + (ids ? ids->out_bytes : 0);
+        work.resize(emitBase + (emit ? emit->out_bytes : 0) + 64);
         memcpy(work.data(), input, inputBytes);
         if (gather && gather->n_strings) gatherQuality(work.data(), inputBytes, *gather);
         if (ids && ids->n_jobs) tokeniseIds(work.data(), inputBytes, *ids, items);
+        if (emit && emit->n_jobs) emitStreams(work.data(), *emit, emitBase, items);
         input = work.data();
         if (t && gather) { t->gather_symbols += gather->symbols; }
         if (t && ids) t->id_strings += ids->n_strings;
@@ -359,7 +407,7 @@ int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vect
         for (uint32_t k = 0; k < N; ++k) { const uint32_t s = pl.copy_order[k]; dstOff[s] = pos; pos += sizes[pl.first_item + s]; }
         putBe(h, pl.signature, 4); putBe(h, pl.records, 8); *h++ = pl.min_len; *h++ = pl.max_len; putBe(h, pl.raw_dna_size, 8); putBe(h, pos, 8); putBe(h, 1, 4);
         if (pl.has_headers) putBe(h, pl.raw_id_size, 8);
-        for (uint32_t s = 0; s < N; ++s) putBe(h, pl.work_size[s] == ~0ull ? (uint64_t)sizes[pl.first_item + s] : pl.work_size[s], 8);
+        for (uint32_t s = 0; s < N; ++s) putBe(h, pl.work_size[s] == ~0ull ? (uint64_t)sizes[pl.first_item + s] : (pl.work_size[s] == ~1ull ? (uint64_t)items[pl.first_item + s].in_len : pl.work_size[s]), 8);
         for (uint32_t s = 0; s < N; ++s) putBe(h, sizes[pl.first_item + s], 8);
         for (uint32_t s = 0; s < N; ++s) memcpy(blk + dstOff[s], scratch.data() + items[pl.first_item + s].out_off, sizes[pl.first_item + s]);
         blk[pos] = 0;

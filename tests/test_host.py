@@ -576,3 +576,21 @@ def test_cli_matches_the_reference_cli(tmp_path):
     assert a.stdout == b.stdout                                    # StreamSizes: ... (CompressorModule.cpp:357-441)
     assert open(str(tmp_path / "a.cdata"), "rb").read() == open(str(tmp_path / "b.cdata"), "rb").read()
     assert_same_archive(str(tmp_path / "a"), str(tmp_path / "b"))
+
+
+@pytest.mark.parametrize("name,paired,flags", manifest())
+def test_device_emission_ops_and_the_host_walk_write_the_same_streams(emu_lib, tmp_path, monkeypatch, name, paired, flags):
+    # device-side emission (fsdev::EmitOp, emit_core.h): the walk leaves an op where it would compare bases, and the streams that
+    # hold bases -- HardReads, LettersX, Match, MatchBinary, CMatch, CLetters, the paired-end ones, the run-length coded LZ ids -- are
+    # written from the ops.  Here through the emulation's serial form of emit_core.h (the kernels' own source): pre-entropy bytes
+    # of every standard bin against the walk's own, and the archive with the ops and without (FS_DEVICE_EMIT=0)
+    import fastore_amd
+    with fastore_amd.Packer(lib=emu_lib, device_id=0, **knobs_from_flags(flags)) as p:
+        ops, streams, differing = p.emit_check(os.path.join(GOLDEN, name + ".in"))
+    assert ops > 1000 and streams >= 7 * 20 and differing == 0, (ops, streams, differing)
+    ref = open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FS_DEVICE_EMIT", mode)
+        with fastore_amd.Packer(lib=emu_lib, device_id=0, **knobs_from_flags(flags)) as p:
+            p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o" + mode)))
+        assert open(str(tmp_path / ("o" + mode)) + ".cdata", "rb").read() == ref, mode
