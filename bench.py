@@ -62,6 +62,15 @@ def sh(cmd, **kw):
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, **kw)
 
 
+_T0 = time.time()
+
+
+def say(msg):
+    """progress on stderr (the one JSON line on stdout stays alone): a run of several minutes that says nothing looks hung from outside"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %6.1f s] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
+
 def prepare_library(work, name, reads, length, genome, seed, threads, paired=False, quality=None):
     """FASTQ -> fastore_bin -> 3 x fastore_rebin with the real reference (C1 profile,
     scripts/fastore_compress.sh:146-148,186-209). Cached in `work`."""
@@ -71,6 +80,7 @@ def prepare_library(work, name, reads, length, genome, seed, threads, paired=Fal
     pe = ["-z"] if paired else []
     fq = [base + "_1.fastq"] + ([base + "_2.fastq"] if paired else [])
     if not (os.path.exists(binned + ".bmeta") and os.path.exists(base + ".done")):
+        say("preparing library %s (%d %s, --%s): gen_fastq, fastore_bin, 3 x fastore_rebin at -t%d" % (name, reads, "pairs" if paired else "reads", quality, threads))
         sh([GEN, "--reads", str(reads), "--len", str(length), "--genome", str(genome), "--seed", str(seed), "--out", base] + (["--paired"] if paired else []))
         sh([REF_GCC, "bin", "-i" + " ".join(fq), "-o" + base + ".b0", "-t%d" % threads] + QUALITY_MODES[quality] + ["-p8", "-s0", "-b256"] + pe)
         prev = base + ".b0"
@@ -81,6 +91,7 @@ def prepare_library(work, name, reads, length, genome, seed, threads, paired=Fal
                 if os.path.exists(prev + "." + e):
                     os.remove(prev + "." + e)
             prev = cur
+            say("library %s: rebin -p%d done" % (name, p))
         size = sum(os.path.getsize(f) for f in fq)
         for f in fq:                       # the FASTQ itself is not needed again: only its size enters the metric
             os.remove(f)
@@ -203,6 +214,7 @@ def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome,
         made.append(o)
         packer.pack_file(binned, o)
 
+    say("leg %s: %d warm-up + %d timed steps" % (name, warmup, steps))
     for _ in range(warmup):
         step()
     packer.reset_stats()
@@ -212,6 +224,7 @@ def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome,
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    say("leg %s: %.1f ms per step" % (name, dt / steps * 1e3))
     st = packer.stats()
     out = made[-1]
     for o in made[:-1]:
@@ -260,6 +273,7 @@ def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome,
         cli_out = os.path.join(work, "cli_" + name)
         cli = [fastore_amd.PACK_CLI, "e", "-i" + binned, "-o" + cli_out] + PACK_FLAGS + pe
         runs, rc = [], 0
+        say("leg %s: the fastore_pack e process, %d runs" % (name, cli_runs))
         for _ in range(cli_runs):
             t = time.perf_counter(); rc = subprocess.call(cli, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); tc = time.perf_counter() - t
             runs.append(round(tc, 2))
@@ -277,7 +291,9 @@ def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome,
         drop(cli_out)
     if not args.no_cpu_baseline:
         refp = os.path.join(work, "ref_" + name)
+        say("leg %s: the reference's fastore_pack on the same library" % name)
         nt, tn, others = reference_pack(binned, refp, cores, pe, sweep)
+        say("leg %s: reference done (%s s at -t%s); comparing every block" % (name, "%.1f" % tn if tn else "-", nt))
         if nt is not None:
             res["cpu_baseline"] = {"value": round(fastq_bytes / tn / 1e6, 2), "unit": "MB/s", "cores": min(nt, cores), "kind": "reference",
                                    "sample": "reference fastore_pack e -t%d on the SAME library (whole workload, %.1f MB FASTQ), %d host cores" % (nt, fastq_bytes / 1e6, cores),

@@ -5,6 +5,7 @@
 // Reference (fastore_pack/FastqCompressor.cpp): CompressHardRead :1388-1410, CompressNormalMatch :1460-1560, CompressContigRead
 // :1690-1760, StoreContigDefinition :1620-1680, LzCompressorPE::CompressPair's letter and match loops :4790-4900.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include "device_types.h"
 
@@ -159,6 +160,53 @@ FS_EMIT_FN uint32_t rle0_serial(const uint32_t* v, uint32_t n, uint8_t* out)
     }
     if (prev == 1u) out[w++] = 1u;
     return w;
+}
+
+// Host-side validation of an emission plan: every op inside its bin's bases and contig bytes, every stream inside the emission's
+// region with room for the most its ops can write, every item an item.  The kernels trust their descriptors; the engine (and the
+// test emulation) call this first.  Returns nullptr, or what is wrong (badJob: where).
+inline const char* plan_error(const uint8_t* input, size_t inputBytes, const fsdev::EmitPlan& plan, uint32_t nItems, uint32_t& badJob)
+{
+    using namespace fsdev;
+    badJob = 0;
+    if ((plan.jobs_off & 7u) || (plan.ops_off & 7u) || (plan.ids_off & 3u) || plan.jobs_off + (uint64_t)plan.n_jobs * sizeof(EmitJob) > inputBytes ||
+        plan.ops_off + (uint64_t)plan.n_ops * sizeof(EmitOp) > inputBytes || plan.ids_off + 4ull * plan.n_ids > inputBytes) return "plan outside the batch input";
+    const EmitJob* jobs = (const EmitJob*)(input + plan.jobs_off); const EmitOp* ops = (const EmitOp*)(input + plan.ops_off);
+    for (uint32_t j = 0; j < plan.n_jobs; ++j) {
+        badJob = j;
+        const EmitJob& jb = jobs[j];
+        if (!((uint64_t)jb.first_op + jb.n_ops <= plan.n_ops && (uint64_t)jb.first_id + jb.n_ids <= plan.n_ids && jb.seq_off + jb.seq_bytes <= inputBytes &&
+              jb.contig_off + jb.contig_bytes <= inputBytes && jb.sig_len >= 1u && jb.sig_len <= 32u)) return "ops, ids, bases or contig bytes outside the batch input";
+        uint64_t need[ECH_COUNT + 1] = {0};
+        need[ECH_COUNT] = 6ull * jb.n_ids + 2u;
+        for (uint32_t k = 0; k < jb.n_ops; ++k) {
+            const EmitOp& op = ops[jb.first_op + k];
+            const uint32_t chL = channel_l(op), chB = channel_b(op);
+            if (op.pad2[0] != j || chL >= ECH_COUNT) return "an op of another job or of no kind";
+            bool ok = true;
+            switch (op.kind) {
+            case EMIT_HARD: case EMIT_PE_HARD: ok = (uint64_t)op.seq_a + op.len_a <= jb.seq_bytes; need[chL] += op.len_a + (op.kind == EMIT_HARD ? 1u : 0u); break;
+            case EMIT_MATCH: case EMIT_PE_MATCH: {
+                const uint32_t as = (uint32_t)(op.shift < 0 ? -op.shift : op.shift);
+                ok = (uint64_t)op.seq_a + op.len_a <= jb.seq_bytes && (uint64_t)op.seq_b + op.len_b <= jb.seq_bytes && as <= op.len_a && as <= op.len_b && op.mode <= EMIT_EXPENSIVE;
+                need[chL] += op.len_a; if (chB < ECH_COUNT) need[chB] += op.len_a;
+                break; }
+            case EMIT_CREAD: ok = (uint64_t)op.seq_a + op.len_a <= jb.seq_bytes && op.pos_a <= op.len_a && op.pos_b == op.len_a && (uint64_t)op.seq_b + 4ull * op.pos_b <= jb.contig_bytes &&
+                                  jb.end_cut <= op.len_a; need[chL] += op.len_a; break;
+            case EMIT_CDEF: ok = op.len_a <= op.len_b && op.len_b <= 2u * op.pos_b && op.pos_a <= op.pos_b && (uint64_t)op.seq_b + 4ull * op.pos_b <= jb.contig_bytes;
+                            need[chL] += 2u * op.pos_b; need[chB] += 2u * op.pos_b; break;
+            default: ok = false;
+            }
+            if (!ok) return "an op outside its bin's bases or contig bytes";
+        }
+        for (uint32_t c = 0; c <= ECH_COUNT; ++c) {
+            if (need[c] == 0 && jb.item[c] == 0xFFFFFFFFu) continue;
+            const uint64_t unit = c == ECH_COUNT ? 1u : (is_bit_channel(c) ? 1u : ((c == ECH_HARD || c == ECH_HARD_PE) ? 1u : 2u));
+            if (!(jb.item[c] < nItems && need[c] <= jb.cap[c] && jb.out_off[c] + unit * jb.cap[c] + 2u <= plan.out_bytes &&
+                  (c == ECH_COUNT || !is_bit_channel(c) || jb.raw_off[c] + (uint64_t)jb.cap[c] <= plan.out_bytes))) return "a stream without an item or without room for what its ops can write";
+        }
+    }
+    return nullptr;
 }
 
 }  // namespace fsemit

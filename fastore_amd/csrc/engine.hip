@@ -1025,48 +1025,13 @@ static void emit_launch_plan(const EmitPlan& plan, uint64_t scratchBase, EmitLau
     L.totalsOff = L.offsOff + 8ull * plan.n_ops;
     L.bytes = L.totalsOff + 4ull * (ECH_COUNT + 1u) * plan.n_jobs + 16u - scratchBase;
 }
-// every op inside its bin's bases and contig bytes, every stream inside the emission's region with room for the most its ops can
-// write, every item an item: checked here, the kernels trust their descriptors
+// (every op inside its bin's bases and contig bytes, every stream with room for the most its ops can write: fsemit::plan_error,
+// emit_core.h -- checked on the host, the kernels trust their descriptors)
 static int emit_check(Device* dev, const uint8_t* input, size_t inputBytes, const EmitPlan& plan, uint32_t nItems)
 {
-    if ((plan.jobs_off & 7u) || (plan.ops_off & 7u) || (plan.ids_off & 3u) || plan.jobs_off + (uint64_t)plan.n_jobs * sizeof(EmitJob) > inputBytes ||
-        plan.ops_off + (uint64_t)plan.n_ops * sizeof(EmitOp) > inputBytes || plan.ids_off + 4ull * plan.n_ids > inputBytes) {
-        snprintf(dev->err, sizeof dev->err, "emission plan outside the batch input"); return -1;
-    }
-    const EmitJob* jobs = (const EmitJob*)(input + plan.jobs_off); const EmitOp* ops = (const EmitOp*)(input + plan.ops_off);
-    for (uint32_t j = 0; j < plan.n_jobs; ++j) {
-        const EmitJob& jb = jobs[j];
-        bool ok = (uint64_t)jb.first_op + jb.n_ops <= plan.n_ops && (uint64_t)jb.first_id + jb.n_ids <= plan.n_ids && jb.seq_off + jb.seq_bytes <= inputBytes &&
-                  jb.contig_off + jb.contig_bytes <= inputBytes && jb.sig_len >= 1u && jb.sig_len <= 32u;
-        uint64_t need[ECH_COUNT + 1] = {0};
-        need[ECH_COUNT] = 6ull * jb.n_ids + 2u;
-        for (uint32_t k = 0; ok && k < jb.n_ops; ++k) {
-            const EmitOp& op = ops[jb.first_op + k];
-            const uint32_t chL = fsemit::channel_l(op), chB = fsemit::channel_b(op);
-            ok = op.pad2[0] == j && chL < ECH_COUNT;
-            if (!ok) break;
-            switch (op.kind) {
-            case EMIT_HARD: case EMIT_PE_HARD: ok = (uint64_t)op.seq_a + op.len_a <= jb.seq_bytes; need[chL] += op.len_a + 1u; break;
-            case EMIT_MATCH: case EMIT_PE_MATCH: {
-                const uint32_t as = (uint32_t)(op.shift < 0 ? -op.shift : op.shift);
-                ok = (uint64_t)op.seq_a + op.len_a <= jb.seq_bytes && (uint64_t)op.seq_b + op.len_b <= jb.seq_bytes && as <= op.len_a && as <= op.len_b && op.mode <= EMIT_EXPENSIVE;
-                need[chL] += op.len_a; if (chB < ECH_COUNT) need[chB] += op.len_a;
-                break; }
-            case EMIT_CREAD: ok = (uint64_t)op.seq_a + op.len_a <= jb.seq_bytes && op.pos_a <= op.len_a && op.pos_b == op.len_a && (uint64_t)op.seq_b + 4ull * op.pos_b <= jb.contig_bytes &&
-                                  jb.end_cut <= op.len_a; need[chL] += op.len_a; break;
-            case EMIT_CDEF: ok = op.len_a <= op.len_b && op.len_b <= 2u * op.pos_b && op.pos_a <= op.pos_b && (uint64_t)op.seq_b + 4ull * op.pos_b <= jb.contig_bytes;
-                            need[chL] += 2u * op.pos_b; need[chB] += 2u * op.pos_b; break;
-            default: ok = false;
-            }
-        }
-        for (uint32_t c = 0; ok && c <= ECH_COUNT; ++c) {
-            if (need[c] == 0 && jb.item[c] == 0xFFFFFFFFu) continue;
-            const uint64_t unit = c == ECH_COUNT ? 1u : (fsemit::is_bit_channel(c) ? 1u : ((c == ECH_HARD || c == ECH_HARD_PE) ? 1u : 2u));
-            ok = jb.item[c] < nItems && need[c] <= jb.cap[c] && jb.out_off[c] + unit * jb.cap[c] + 2u <= plan.out_bytes &&
-                 (c == ECH_COUNT || !fsemit::is_bit_channel(c) || jb.raw_off[c] + (uint64_t)jb.cap[c] <= plan.out_bytes);
-        }
-        if (!ok) { snprintf(dev->err, sizeof dev->err, "emission job %u outside the batch input", j); return -1; }
-    }
+    uint32_t badJob = 0;
+    const char* why = fsemit::plan_error(input, inputBytes, plan, nItems, badJob);
+    if (why) { snprintf(dev->err, sizeof dev->err, "emission job %u: %s", badJob, why); return -1; }
     return 0;
 }
 static int emit_launch(Device* dev, hipStream_t st, const EmitPlan& plan, uint64_t emitBase, const EmitLaunch& L)
@@ -1233,6 +1198,9 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     }
     const uint32_t grid = exclusive ? (uint32_t)std::min<uint64_t>(std::min<uint64_t>(nItems, dev->nWaves), pool->bytes / stride)
                                     : std::min<uint32_t>(std::max(nRest, 1u), dev->nWaves);
+    // (Round 4 tried to keep the short streams from crowding the long ones out of the L2s -- a launch with a workgroup per stream of a
+    // million symbols and more and only k more for everything else: 2 305 / 2 382 MB/s without, 2 283 with k = 256, 1 963 / 1 974 with 64,
+    // 831 with 16, profiles/r04_short_waves_sweep.txt: the short streams need the resident waves more than the long ones need the cache.)
     if (grid == 0) { snprintf(dev->err, sizeof dev->err, "arena pool too small for a %llu-byte coder table", (unsigned long long)need); return -1; }
     if (ids && ids->n_jobs) {
         // every job's strings, table and output inside the buffers, checked here: the kernel trusts its descriptors (and may read up

@@ -1229,7 +1229,9 @@ struct BinEncoder::Impl {
         o.reset(pe ? S_PE_COUNT : S_SE_COUNT);
         if (cfg.quaParams.method == MET_QVZ) well.reset(arch.qvz.wellSeed);
         initNodes(bin);
-        devEmit = wantDevEmit && bin.recCount > 0 && bin.maxLen <= 255;
+        // (a slice's input and device-written streams share one 32-bit address space, and the streams get room for the most their ops
+        // can write -- about five bytes per base; a bin whose share would pass a quarter of a gigabyte keeps the walk's own loops)
+        devEmit = wantDevEmit && bin.recCount > 0 && bin.maxLen <= 255 && (uint64_t)bin.rawDnaSize * 5u <= (256ull << 20);
         if (devEmit) {      // the bin's bases: one stretch of the batch's base array (its records were unpacked one behind the other)
             uint64_t lo = ~0ull, hi = 0;
             for (uint32_t i = 0; i < bin.recCount; ++i) { const Rec& r = B->recs[bin.recBegin + i]; lo = std::min<uint64_t>(lo, r.seqOff); hi = std::max<uint64_t>(hi, (uint64_t)r.seqOff + r.seqLen + r.auxLen); }

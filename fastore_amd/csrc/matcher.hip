@@ -266,6 +266,7 @@ struct MateShared {
     uint32_t entOff[kMateThreads], entLen[kMateThreads], entPair[kMateThreads], entStamp[kMateThreads], entLive[kMateThreads];
     uint32_t candE[kMateCand], candKey[kMateCand]; uint32_t candPos[kMateCand];      // entry, (signature, age) key, the signature's first position in the mate
     uint32_t small1[4], small2[4];          // the sets' smallest members: signature << 8 | first position
+    uint32_t posTab[1024];                  // open-addressing table of the mate's member signatures: (signature << 8 | position) + 1, 0 = empty (at most 256 members)
     uint32_t nCand, size1, size2, overflow;
     unsigned long long best;
     uint8_t idx[128];                       // base -> 0..3 (4: 'N', 255: anything else)
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(kMateThreads) void fs_match_mates(const MateJob* __
     sh.entLive[tid] = 0u; sh.entStamp[tid] = 0u; sh.entPair[tid] = 0u; sh.entOff[tid] = 0u; sh.entLen[tid] = 0u;
     for (int j = 0; j < 4; ++j) sh.entSig[j][tid] = 0u;
     if (tid == 0u) { sh.nCand = 0u; sh.size1 = 0u; sh.size2 = 0u; sh.overflow = 0u; sh.best = ~0ull; }
+    sh.posTab[tid] = 0u;
     __syncthreads();
     // the history as a ring: slots leave in the order W-1, W-2, .., 0, W-1, .. -- except that a mate that went to the BACK leaves first
     uint32_t ring = W - 1u, frontPushes = 0u, backSlot = kMateNone;
@@ -315,6 +317,10 @@ __global__ __launch_bounds__(kMateThreads) void fs_match_mates(const MateJob* __
             if (!((sh.bmA[m >> 5] >> (m & 31u)) & 1u)) { const uint32_t old = atomicOr(&sh.bmB[m >> 5], 1u << (m & 31u)); member = true; if (!((old >> (m & 31u)) & 1u)) atomicAdd(&sh.size2, 1u); }
         }
         if (tid < 256u) sh.sigAt[tid] = member ? m : kMateNone;
+        if (member) {      // where a member signature stands: looked up by the entries that list it
+            uint32_t h = (m * 0x9E3779B1u) >> 22;
+            while (atomicCAS(&sh.posTab[h], 0u, ((m << 8) | tid) + 1u) != 0u) h = (h + 1u) & 1023u;
+        }
         __syncthreads();
         // ---- the four smallest members of each set, with their first positions (wave 0: set 1, wave 1: set 2)
         if (wave < 2u) {
@@ -339,8 +345,12 @@ __global__ __launch_bounds__(kMateThreads) void fs_match_mates(const MateJob* __
                 const uint32_t sj = sh.entSig[j][tid] & 0xFFFFu;
                 if (sj == 0u) break;
                 if (!(((sh.bmA[sj >> 5] | sh.bmB[sj >> 5]) >> (sj & 31u)) & 1u)) continue;
-                uint32_t posH = 0;
-                for (; posH < 256u && sh.sigAt[posH] != sj; ++posH) {}
+                uint32_t posH = 256u;
+                for (uint32_t h = (sj * 0x9E3779B1u) >> 22;; h = (h + 1u) & 1023u) {
+                    const uint32_t e = sh.posTab[h];
+                    if (e == 0u) break;
+                    if (((e - 1u) >> 8) == sj) { posH = (e - 1u) & 255u; break; }
+                }
                 if (posH >= 256u) continue;
                 const uint32_t at = atomicAdd(&sh.nCand, 1u);
                 if (at < kMateCand) { sh.candE[at] = tid; sh.candPos[at] = posH; sh.candKey[at] = (sj << 12) | (rank << 2); }
@@ -367,13 +377,19 @@ __global__ __launch_bounds__(kMateThreads) void fs_match_mates(const MateJob* __
                 const uint32_t recOff = shift < 0 ? (uint32_t)-shift : 0u, lzOff = shift > 0 ? (uint32_t)shift : 0u;
                 const uint32_t lzLen = sh.entLen[e], a = plen - recOff, b = lzLen - lzOff, minLen = a < b ? a : b;
                 const uint8_t* lz = seq + sh.entOff[e] + lzOff;
-                uint32_t mism = 0;
+                const uint32_t ashift = (uint32_t)(shift < 0 ? -shift : shift);
+                // an alignment that already costs MORE than the cheapest one found so far cannot win (equal cost still can: the order
+                // among equals decides); the bound only ever falls, so a stale look at it prunes less, never wrongly
+                const uint32_t bound = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((volatile uint32_t*)&sh.best)[1] >> 12));      // (cost: bits 44.. of the word; one look for the whole wavefront)
+                uint32_t mism = 0, cost = ashift * (uint32_t)par.shift_cost;
+                if (cost > bound) continue;
                 for (uint32_t i = lane; i < ((minLen + 63u) & ~63u); i += 64u) {
                     const bool diff = i < minLen && mb[recOff + i] != lz[i];
                     mism += (uint32_t)__popcll(__ballot(diff));
+                    if (ashift * (uint32_t)par.shift_cost + mism * (uint32_t)par.mismatch_cost > bound) break;
                 }
-                const uint32_t ashift = (uint32_t)(shift < 0 ? -shift : shift);
-                const uint32_t cost = ashift * (uint32_t)par.shift_cost + mism * (uint32_t)par.mismatch_cost;
+                cost = ashift * (uint32_t)par.shift_cost + mism * (uint32_t)par.mismatch_cost;
+                if (cost > bound) continue;
                 if (lane == 0u && cost < 255u) atomicMin(&sh.best, ((unsigned long long)cost << 44) | ((unsigned long long)(sh.candKey[c] | k) << 12) | c);
               }
             }
@@ -398,7 +414,8 @@ __global__ __launch_bounds__(kMateThreads) void fs_match_mates(const MateJob* __
             row.no_mismatches = noMism ? 1 : 0; row.overflow = (uint8_t)sh.overflow;
             rows[job.first + p] = row;
         }
-        // the sets' bits are taken back by the lanes that set them
+        // the sets' bits and the table's entries are taken back by the lanes that set them
+        sh.posTab[tid] = 0u;
         if (member) { atomicAnd(&sh.bmA[m >> 5], ~(1u << (m & 31u))); atomicAnd(&sh.bmB[m >> 5], ~(1u << (m & 31u))); }
         __syncthreads();
         if (tid == slot) {

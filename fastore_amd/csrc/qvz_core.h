@@ -173,13 +173,23 @@ FS_DEV uint32_t encode_stream(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32
 // the end of one read and the start of the next): a symbol of the second read can only share with the first read's part if its
 // context number reaches that of lane 0, the smallest there.  Anything else (reads shorter than a window) is compared pair by pair.
 // floor(range * c / total) for range <= 2^22, c <= total < 2^20 (arith.cpp:44-45 computes it by a 64-bit integer division), with
-// the fraction c / total made beforehand as a 32-bit fixed-point number f ~ c * 2^32 / total (q_frac: all the window's lanes at
-// once): mulhi(range, f) is the quotient or one beside it (range * 2^-32 < 2^-10 per unit of f's error), and the remainder -- its
-// low 32 bits are all of it, |r| < 2^21 -- says which.
-FS_DEV uint32_t q_frac(uint32_t c, uint32_t total)
+// the fraction c / total made beforehand -- by all the window's lanes at once -- as F = ceil(c * 2^42 / total), exactly: then
+// (range * F) >> 42 IS the quotient.  (F exceeds the true fraction by less than 2^-42, range times that is below 2^-20 < 1 / total,
+// the least distance of a quotient that is not whole from the next whole number; a whole quotient is met from above.)  The product
+// needs 64 bits, its bits from 42 on only mulhi(range, F's low word) + range * (F's high word): three scalar multiplications and
+// no comparison in the symbol's chain.
+struct QFrac { uint32_t lo, hi; };
+FS_DEV QFrac q_frac(uint32_t c, uint32_t total)
 {
-    const double x = (double)c * 4294967296.0 / (double)total;          // c * 2^32 < 2^52: exact before the division
-    return x >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)x;                // (c == total: the correction below lands on range)
+    // an estimate from the double-precision quotient (good to a few units), set right by the remainder: n = c * 2^42 = e * total + r
+    const uint64_t n = (uint64_t)c << 42;
+    uint64_t e = (uint64_t)((double)c * 4398046511104.0 / (double)total);
+    int64_t r = (int64_t)(n - e * total);
+    while (r < 0) { --e; r += total; }
+    while (r >= (int64_t)total) { ++e; r -= total; }
+    e += r != 0 ? 1u : 0u;                                               // ceil
+    QFrac f; f.lo = (uint32_t)e; f.hi = (uint32_t)(e >> 32);
+    return f;
 }
 FS_DEV uint32_t q_mulhi(uint32_t a, uint32_t b)
 {
@@ -189,25 +199,19 @@ FS_DEV uint32_t q_mulhi(uint32_t a, uint32_t b)
     return (uint32_t)(((uint64_t)a * b) >> 32);
 #endif
 }
-FS_DEV uint32_t q_div(uint32_t range, uint32_t c, uint32_t total, uint32_t f)
-{
-    uint32_t q = q_mulhi(range, f);
-    const int32_t r = (int32_t)(range * c - q * total);                 // (mod 2^32: the true remainder is far inside)
-    q += r >= (int32_t)total ? 1u : 0u;
-    q -= r < 0 ? 1u : 0u;
-    return q;
-}
+// (c == total: F = 2^42, whose high word times a full range leaves 32 bits -- the quotient is the range itself)
+FS_DEV uint32_t q_div(uint32_t range, uint32_t fLo, uint32_t fHi) { const uint32_t q = (q_mulhi(range, fLo) + range * fHi) >> 10; return (fHi >> 10) ? range : q; }
 // One symbol through the interval: arithmetic_encoder_step (arith.cpp:33-103), the E1/E2/E3 loop in closed form.  The loop
 // first shifts out the leading bits that l and u share (each is a decided bit; the pending opposite bits follow the first),
 // and only then -- the top bits now differ: l = 0.., u = 1.. -- counts the steps in which l continues 01 and u continues 10
 // (E3: the top bits stay different, so no decided bit can follow).  So: k1 = the length of the common prefix of l and u, k3 = the
 // length of the run, behind the top bit, of positions where l has a one and u a zero.
-FS_DEV void q_code(BitOut& o, uint32_t& l, uint32_t& u, uint32_t& scale3, uint32_t cumLo, uint32_t cnt, uint32_t total, uint32_t fLo, uint32_t fHi)
+FS_DEV void q_code(BitOut& o, uint32_t& l, uint32_t& u, uint32_t& scale3, QFrac below, QFrac upto)
 {
     const uint32_t M22 = (1u << M_BITS) - 1u, clearMask = (1u << (M_BITS - 1)) - 1u;
     const uint32_t range = u - l + 1u;                       // <= 2^22
-    u = l + q_div(range, cumLo + cnt, total, fHi) - 1u;
-    l = l + q_div(range, cumLo, total, fLo);
+    u = l + q_div(range, upto.lo, upto.hi) - 1u;
+    l = l + q_div(range, below.lo, below.hi);
     const uint32_t x = (l ^ u) & M22;
     const uint32_t k1 = x ? (uint32_t)__builtin_clz(x) - (32u - M_BITS) : (uint32_t)M_BITS;
     if (k1) {
@@ -293,11 +297,12 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr i
         FS_EMU_MEET();
         // every position's two fractions, all lanes at once
         const uint32_t tsafe = total ? total : 1u;
-        const uint32_t fLo = q_frac(cumLo, tsafe), fHi = q_frac(cumLo + cnt, tsafe);
+        const QFrac fB = q_frac(cumLo, tsafe), fU = q_frac(cumLo + cnt, tsafe);
         l = FS_UNI(l); u = FS_UNI(u); scale3 = FS_UNI(scale3);
         for (uint32_t i = 0; i < take; ++i) {
-            const uint32_t c0 = FS_UNI(fs_readlane(cumLo, i)), c1 = FS_UNI(fs_readlane(cnt, i)), tt = FS_UNI(fs_readlane(total, i));
-            q_code(o, l, u, scale3, c0, c1, tt, FS_UNI(fs_readlane(fLo, i)), FS_UNI(fs_readlane(fHi, i)));
+            QFrac b1, u1;
+            b1.lo = FS_UNI(fs_readlane(fB.lo, i)); b1.hi = FS_UNI(fs_readlane(fB.hi, i)); u1.lo = FS_UNI(fs_readlane(fU.lo, i)); u1.hi = FS_UNI(fs_readlane(fU.hi, i));
+            q_code(o, l, u, scale3, b1, u1);
         }
         k += take;
         if (take < W) {          // symbol k: shares its context, is due for a rescale, or is malformed -- the one-symbol step
@@ -308,7 +313,7 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr i
             if (x1 >= card1 || card1 > MAX_CARD) { bad = 1; break; }
             uint32_t c1, n1, t1;
             model_step(stat + off1, card1, x1, c1, n1, t1);
-            q_code(o, l, u, scale3, c1, n1, t1, q_frac(c1, t1), q_frac(c1 + n1, t1));
+            q_code(o, l, u, scale3, q_frac(c1, t1), q_frac(c1 + n1, t1));
             ++k;
         }
     }

@@ -357,8 +357,10 @@ static void emitStreams(uint8_t* buf, const EmitPlan& plan, uint64_t emitBase, s
     }
 }
 
-int emit_streams_raw(Device*, const uint8_t* input, size_t inputBytes, const EmitPlan& plan, std::vector<StreamItem>& items, std::vector<std::vector<std::vector<uint8_t>>>& streams)
+int emit_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, const EmitPlan& plan, std::vector<StreamItem>& items, std::vector<std::vector<std::vector<uint8_t>>>& streams)
 {
+    uint32_t badJob = 0;
+    if (const char* why = fsemit::plan_error(input, inputBytes, plan, (uint32_t)items.size(), badJob)) { snprintf(dev->err, sizeof dev->err, "emission job %u: %s", badJob, why); return -1; }
     const uint64_t emitBase = ((uint64_t)inputBytes + 15u) & ~15ull;
     std::vector<uint8_t> work(emitBase + plan.out_bytes + 64);
     memcpy(work.data(), input, inputBytes);
@@ -386,7 +388,11 @@ int encode_batch(Device* dev, const uint8_t* input, size_t inputBytes, std::vect
         memcpy(work.data(), input, inputBytes);
         if (gather && gather->n_strings) gatherQuality(work.data(), inputBytes, *gather);
         if (ids && ids->n_jobs) tokeniseIds(work.data(), inputBytes, *ids, items);
-        if (emit && emit->n_jobs) emitStreams(work.data(), *emit, emitBase, items);
+        if (emit && emit->n_jobs) {
+            uint32_t badJob = 0;
+            if (const char* why = fsemit::plan_error(input, inputBytes, *emit, (uint32_t)items.size(), badJob)) { snprintf(dev->err, sizeof dev->err, "emission job %u: %s", badJob, why); return -1; }
+            emitStreams(work.data(), *emit, emitBase, items);
+        }
         input = work.data();
         if (t && gather) { t->gather_symbols += gather->symbols; }
         if (t && ids) t->id_strings += ids->n_strings;
