@@ -256,7 +256,10 @@ def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome,
             "fs_match_reads": {"reads_per_step": st["matcher_reads"] // steps, "kernel_ms_per_step": round(st["matcher_kernel_ms"] / steps, 1),
                                "host_wait_ms_per_step_summed_over_threads": round(st["matcher_call_ms"] / steps, 1),
                                # its bases: unpacked on the device from the bin's .bdna bytes (fs_unpack_planes), or ASCII from the host
-                               "reads_unpacked_on_device_per_step": st["matcher_unpacked_reads"] // steps, "bases_h2d_bytes_per_step": st["matcher_bases_h2d_bytes"] // steps}},
+                               "reads_unpacked_on_device_per_step": st["matcher_unpacked_reads"] // steps, "bases_h2d_bytes_per_step": st["matcher_bases_h2d_bytes"] // steps},
+            # the mate searches of paired-end bins that ran on the device (0: the host's search did them)
+            "fs_match_mates": {"pairs_per_step": st["mate_pairs"] // steps, "kernel_ms_per_step": round(st["mate_kernel_ms"] / steps, 1),
+                               "call_ms_per_step_summed_over_callers": round(st["mate_call_ms"] / steps, 1)}},
         "h2d_bytes_per_step": int(st["h2d_bytes"]) // steps,
         "stages_ms_per_step": dict({k: round(st[k] / steps, 1) for k in ("encode_kernel_ms", "assemble_kernel_ms", "frontend_ms", "io_ms", "total_ms")},
                                    block0_ms=round(st["block0_ms"], 1)),      # block0_ms is the longest single step's (a max in the library), not a sum

@@ -41,7 +41,8 @@ class Stats(C.Structure):
                 ("matcher_reads", C.c_uint64), ("matcher_call_ms", C.c_double), ("matcher_kernel_ms", C.c_double), ("tokenised_ids", C.c_uint64),
                 ("device_batches", C.c_uint64), ("ppmd_max_restarts", C.c_uint64),
                 ("stolen_bins", C.c_uint64),
-                ("matcher_bases_h2d_bytes", C.c_uint64), ("matcher_unpacked_reads", C.c_uint64)]
+                ("matcher_bases_h2d_bytes", C.c_uint64), ("matcher_unpacked_reads", C.c_uint64),
+                ("mate_pairs", C.c_uint64), ("mate_call_ms", C.c_double), ("mate_kernel_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

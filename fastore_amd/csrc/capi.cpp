@@ -638,6 +638,7 @@ static bool packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& 
         a.timing.h2d_bytes += b.timing.h2d_bytes; a.timing.gather_ms += b.timing.gather_ms; a.timing.gather_symbols += b.timing.gather_symbols; a.timing.gather_bytes += b.timing.gather_bytes; a.timing.id_strings += b.timing.id_strings;
         for (int w = 0; w < 16; ++w) a.timing.win[w] += b.timing.win[w];
         a.matchedReads += b.matchedReads.load(); a.matchUs += b.matchUs.load(); a.matchKernelUs += b.matchKernelUs.load(); a.matchBasesUp += b.matchBasesUp.load(); a.matchUnpackedReads += b.matchUnpackedReads.load();
+        a.matedPairs += b.matedPairs.load(); a.mateUs += b.mateUs.load(); a.mateKernelUs += b.mateKernelUs.load(); b.matedPairs = 0; b.mateUs = 0; b.mateKernelUs = 0;
         b.matchedReads = 0; b.matchUs = 0; b.matchKernelUs = 0; b.matchBasesUp = 0; b.matchUnpackedReads = 0;
         b.stats = fsgpu_stats(); b.timing = fsengine::BatchTiming();
     }
@@ -726,6 +727,7 @@ int fsgpu_reset_stats(fsgpu_ctx* ctx)
 {
     if (!ctx) return FSGPU_ERR_ARG;
     ctx->c.stats = fsgpu_stats(); ctx->c.timing = fsengine::BatchTiming(); ctx->c.matchedReads = 0; ctx->c.matchUs = 0; ctx->c.matchKernelUs = 0; ctx->c.matchBasesUp = 0; ctx->c.matchUnpackedReads = 0;
+    ctx->c.matedPairs = 0; ctx->c.mateUs = 0; ctx->c.mateKernelUs = 0;
     return FSGPU_OK;
 }
 
@@ -739,6 +741,7 @@ int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out)
     out->ppmd_window_rounds = ctx->c.timing.win[4]; out->ppmd_windows_redone = ctx->c.timing.win[5]; out->ppmd_window_light_rounds = ctx->c.timing.win[6];
     out->tokenised_ids = ctx->c.timing.id_strings; out->matcher_reads = ctx->c.matchedReads.load(); out->matcher_call_ms = ctx->c.matchUs.load() / 1e3; out->matcher_kernel_ms = ctx->c.matchKernelUs.load() / 1e3;
     out->matcher_bases_h2d_bytes = ctx->c.matchBasesUp.load(); out->matcher_unpacked_reads = ctx->c.matchUnpackedReads.load();
+    out->mate_pairs = ctx->c.matedPairs.load(); out->mate_call_ms = ctx->c.mateUs.load() / 1e3; out->mate_kernel_ms = ctx->c.mateKernelUs.load() / 1e3;
     out->gather_kernel_ms = ctx->c.timing.gather_ms; out->gather_symbols = ctx->c.timing.gather_symbols; out->gather_bytes = ctx->c.timing.gather_bytes;
     out->rc_symbols = ctx->c.timing.rc_symbols; out->ppmd_restarts = ctx->c.timing.restarts; out->ppmd_max_restarts = ctx->c.timing.max_restarts;
     out->h2d_bytes = ctx->c.timing.h2d_bytes; out->d2h_bytes = ctx->c.timing.d2h_bytes;

@@ -45,6 +45,7 @@ struct Device {
 };
 
 int device_count();
+uint32_t search_cus();      // FS_SEARCH_CUS: compute units kept for the search kernels (the coder lanes launch on the others); 0 = no partition
 int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size_t errLen);
 int lane_create(Device* first, Device** out, char* err, size_t errLen);      // another lane on the GPU (and pool) of `first`
 void device_destroy(Device* dev);                                            // a lane; the pool goes with its last lane
@@ -80,6 +81,9 @@ void unpack_check_counts(uint64_t* words, uint64_t* differing);
 // the mate searches of one paired-end bin (matcher.hip: fs_match_mates)
 int match_mates(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, const fsdev::MatePair* pairs, size_t nPairs, const uint32_t* validBits, size_t validWords,
                 const fsdev::MateParams& par, fsdev::MateRow* rows, double* kernelMs);
+// ... of several bins in one launch (a workgroup per bin): jobs[j].rows[i] answers jobs[j].pairs[i]
+struct MateBatchJob { const uint8_t* seq; size_t seqBytes; const fsdev::MatePair* pairs; size_t nPairs; fsdev::MateRow* rows; };
+int match_mates_batch(Device* dev, MatchLane* m, const MateBatchJob* jobs, size_t nJobs, const uint32_t* validBits, size_t validWords, const fsdev::MateParams& par, double* kernelMs);
 // fs_gather_quality on its own: `input` = packed scores then the descriptors (plan.desc_off); returns the gathered bytes
 int gather_quality_raw(Device* dev, const uint8_t* input, size_t inputBytes, const fsdev::GatherPlan& plan, std::vector<uint8_t>& out, BatchTiming* timing);
 // fs_tokenise_ids on its own (parity checks): tok[j] / val[j] = the (symbol, context) pair streams of job j (its items: 2 j, 2 j + 1)

@@ -812,6 +812,13 @@ static void pool_grow(Device* dev, Pool* pool, uint64_t need)
     if (getenv("FS_TRACE")) fprintf(stderr, "[trace] arena pool grown to %u slots of %.1f MB (%.1f GB) for a %.1f MB coder table\n", pool->slotsPerXcc * kXcc, big / 1e6, want / 1e6 / 1e3, need / 1e6);
 }
 
+// (engine.h) compute units kept for the search kernels: FS_SEARCH_CUS, 0 = none
+uint32_t search_cus()
+{
+    static const uint32_t n = []() { const char* e = getenv("FS_SEARCH_CUS"); const int v = e ? atoi(e) : 0; return (uint32_t)(v < 8 ? 0 : (v > 128 ? 128 : v & ~7)); }();
+    return n;
+}
+
 static int lane_init(Device* dev, char* err, size_t errLen)
 {
     hipError_t e;
@@ -828,6 +835,13 @@ static int lane_init(Device* dev, char* err, size_t errLen)
     if (xs && sscanf(xs, "%c:%u:%u", &xm, &xk, &xl) == 3 && xk >= 1 && xk <= 7 && (xm == 'm' || xm == 'b')) {
         uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (uint32_t i = 0; i < 256u; ++i) { const uint32_t xcd = xm == 'm' ? i % 8u : i / 32u; if ((xcd < xk) == (myLane < xl)) mask[i >> 5] |= 1u << (i & 31u); }
+        if ((e = hipExtStreamCreateWithCUMask((hipStream_t*)&dev->stream, 8, mask)) != hipSuccess) return fail("hipExtStreamCreateWithCUMask", e);
+    } else if (const uint32_t sc = search_cus()) {
+        // FS_SEARCH_CUS=<n> (a multiple of 8): n compute units -- n / 8 on every XCD: CU-mask bit i belongs to XCD i % 8 -- are kept for the
+        // search kernels (fs_match_reads, fs_match_mates, whose workgroups need sixteen free wave slots and up to 110 KB of LDS on ONE
+        // compute unit: behind the coder kernels' resident waves they wait for a launch to drain); the coder lanes launch on the others
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t i = sc; i < 256u; ++i) mask[i >> 5] |= 1u << (i & 31u);
         if ((e = hipExtStreamCreateWithCUMask((hipStream_t*)&dev->stream, 8, mask)) != hipSuccess) return fail("hipExtStreamCreateWithCUMask", e);
     } else
     if ((e = hipStreamCreateWithFlags((hipStream_t*)&dev->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);

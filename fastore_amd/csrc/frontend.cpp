@@ -326,6 +326,7 @@ struct BinEncoder::Impl {
     bool traceResize = false;
     std::vector<fsdev::MatchRow>* matchTrace = nullptr;   // host scan: note every read's answer here (same indexing as mRows)
     bool wantDevEmit = false;            // BinEncoder::setDeviceEmit
+    AsyncMateFn asyncMates;              // BinEncoder::setAsyncMates
     MatchFn matcher;
     uint64_t matchSeqBase = 0, matchSeqBytes = 0;
 
@@ -1221,7 +1222,7 @@ struct BinEncoder::Impl {
 
     void encodeLz(const Batch& batch, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, BinStreams& o)
     {
-        const bool stageTrace = getenv("FS_BIN_TRACE") && bin.recCount >= 40000;      // stage clock of the heaviest bins (design studies)
+        const bool stageTrace = getenv("FS_BIN_TRACE") && bin.recCount >= (atoi(getenv("FS_BIN_TRACE")) > 1 ? (uint32_t)atoi(getenv("FS_BIN_TRACE")) : 40000u);      // stage clock of the heaviest bins (design studies; FS_BIN_TRACE=1: 40 000 records and more, n: n and more)
         auto clk = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; };
         const double t0 = stageTrace ? clk() : 0; double t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         setArchive(arch);
@@ -1281,8 +1282,9 @@ struct BinEncoder::Impl {
             encodeTree(root, false);
         }
         matchRle.end(); consMatchRle.end(); lzRle0.end();
-        if (pe) { finishPairs(); matchRlePE.end(); }
-        if (stageTrace) { t4 = clk(); fprintf(stderr, "[bin] %u records: nodes + sort %.1f ms, match table + device search %.1f ms (pre %d), top-level tree %.1f ms, contigs + sub-trees + emission %.1f ms\n", bin.recCount, t1 - t0, t2 - t1, (int)havePre, t3 - t2, t4 - t3); }
+        const double tp = stageTrace ? clk() : 0;
+        if (pe) { finishPairs(); if (!o.pairsPending) matchRlePE.end(); }
+        if (stageTrace) { t4 = clk(); fprintf(stderr, "[bin] %u records: nodes + sort %.1f ms, match table + device search %.1f ms (pre %d), top-level tree %.1f ms, contigs + sub-trees + emission %.1f ms, mate searches + their streams %.1f ms\n", bin.recCount, t1 - t0, t2 - t1, (int)havePre, t3 - t2, tp - t3, t4 - tp); }
     }
 };
 
@@ -1295,6 +1297,7 @@ namespace fs {
 BinEncoder::BinEncoder(const PackParams& par) : impl_(new Impl(par)) {}
 void BinEncoder::setMatcher(MatchFn fn) { impl_->matcher = std::move(fn); }
 void BinEncoder::setDeviceEmit(bool on) { impl_->wantDevEmit = on; }
+void BinEncoder::setAsyncMates(AsyncMateFn fn) { impl_->asyncMates = std::move(fn); }
 void BinEncoder::setMateMatcher(MateFn fn) { impl_->mateMatcher = std::move(fn); }
 void BinEncoder::checkMateMatcher(const Batch& data, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, const MateFn& fn, uint64_t& pairs, uint64_t& differing)
 {

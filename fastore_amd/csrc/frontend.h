@@ -10,6 +10,7 @@
 #include <deque>
 #include <vector>
 #include <functional>
+#include <memory>
 #include "format.h"
 #include "qvz.h"
 #include "device_types.h"
@@ -65,11 +66,12 @@ struct BinStreams {
     // CLetters, their paired-end counterparts -- and LzId stay empty; the device writes them from the ops the walk left, the bin's
     // bases [emitSeqLo, emitSeqHi) of the batch's base array, its contigs' bytes and its LZ ids
     bool deviceEmit = false;
+    bool pairsPending = false;             // the bin's pairs went to the device's batched mate search: its mate streams are still to come
     std::vector<fsdev::EmitOp> emitOps; std::vector<uint32_t> lzIds; std::vector<uint8_t> contigBytes;
     uint64_t emitSeqLo = 0, emitSeqHi = 0; const uint8_t* emitSeq = nullptr;      // (emitSeq: the first of those bases; owned by the batch)
     uint64_t emitBound[fsdev::ECH_COUNT + 1] = {0};          // per channel: an upper bound of its units (bytes, pairs, bits); [ECH_COUNT]: LzId bytes
     void reset(uint32_t n) { nStreams = n; rawIdSize = 0; for (auto& v : s) v.clear(); quaRefs.clear(); quaSymbols = 0; quaN.clear(); quaPacked = nullptr; quaPackedBytes = 0; idRefs.clear(); headPacked = nullptr; headPackedBytes = 0;
-                             deviceEmit = false; emitOps.clear(); lzIds.clear(); contigBytes.clear(); emitSeqLo = emitSeqHi = 0; emitSeq = nullptr; for (auto& b : emitBound) b = 0; }
+                             deviceEmit = false; pairsPending = false; emitOps.clear(); lzIds.clear(); contigBytes.clear(); emitSeqLo = emitSeqHi = 0; emitSeq = nullptr; for (auto& b : emitBound) b = 0; }
 };
 
 // which streams are range-coded in place (true) vs PPMd-compressed (false), and with which model
@@ -91,8 +93,30 @@ typedef std::function<bool(const uint8_t* seq, size_t seqBytes, const fsdev::Pac
 typedef std::function<bool(const uint8_t* seq, size_t seqBytes, const fsdev::MatePair* pairs, size_t nPairs, const uint32_t* validBits, size_t validWords,
                            const fsdev::MateParams& par, fsdev::MateRow* rows)> MateFn;
 
+// A paired-end bin whose mate searches are the device's AND are not waited for: the walk is over, the host thread goes on to its
+// next bin, and what is left of the bin -- every pair's search (fs_match_mates, many bins per launch) and, from the rows, the mate's
+// streams -- happens when the batch the search rides in comes back (emitPairsFromRows).  Everything that step needs stands here: the
+// front end's per-thread state is long busy with another bin.  (Only with device-side emission: the mate's streams are then ops.)
+struct PendingPairs {
+    BinStreams* out = nullptr;
+    std::vector<fsdev::MatePair> pairs;            // in the walk's order; mate_off counts from `seq`
+    std::vector<uint8_t> seType;                   // the single-end match type of each pair's first read (the PE flag's context)
+    std::vector<fsdev::MateRow> rows;              // the searches' answers (filled by the device)
+    const uint8_t* seq = nullptr; size_t seqBytes = 0;     // the mates' bases: one stretch of the batch's base array ...
+    uint64_t seqLo = 0;                            // ... beginning at this offset of it
+    fsdev::MateParams mp{};
+    std::vector<uint32_t> validBits;               // the valid-signature table of the archive's minimizer parameters
+    int32_t shiftCost = 1, mismatchCost = 2; uint32_t maxMismatchesLowCost = 0;
+    std::function<void(const char* error)> done;   // the bin is complete (or failed)
+};
+typedef std::function<bool(std::unique_ptr<PendingPairs>)> AsyncMateFn;     // true: taken (done() will be called, possibly before this returns)
+// the mate streams of a bin from its searches' rows (LzCompressorPE::CompressPair's coding half, FastqCompressor.cpp:4740-4900), as ops
+void emitPairsFromRows(PendingPairs& pp);
+
 class BinEncoder {
 public:
+    // paired-end bins with device-side emission: hand the pairs over instead of searching (empty: search now)
+    void setAsyncMates(AsyncMateFn fn);
     explicit BinEncoder(const PackParams& par);
     // mate searches of the following encodeLz calls (paired-end bins) go through `fn` (empty: the host search)
     void setMateMatcher(MateFn fn);

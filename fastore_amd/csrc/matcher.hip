@@ -496,7 +496,13 @@ int match_lane_create(Device* dev, MatchLane** out)
     {
         std::lock_guard<std::mutex> g(g_poolMx);
         StreamPool& p = g_pool[dev->deviceId & 15];
-        for (int i = 0; i < matchStreams() && e == hipSuccess; ++i) if (!p.s[i]) e = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
+        for (int i = 0; i < matchStreams() && e == hipSuccess; ++i) if (!p.s[i]) {
+            if (const uint32_t sc = search_cus()) {      // (the compute units the coder lanes leave alone: engine.hip, lane_init)
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (uint32_t b = 0; b < sc; ++b) mask[b >> 5] |= 1u << (b & 31u);
+                e = hipExtStreamCreateWithCUMask(&p.s[i], 8, mask);
+            } else e = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
+        }
         if (e == hipSuccess) { m->stream = p.s[p.next++ % (unsigned)matchStreams()]; ++p.users; }
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->evWait, hipEventBlockingSync | hipEventDisableTiming);
@@ -701,6 +707,58 @@ int match_mates(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
     HIP_TRY(hipMemcpyAsync(rows, m->dMateRows, nPairs * sizeof(MateRow), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(m->evWait, st));
     HIP_TRY(hipEventSynchronize(m->evWait));
+    if (kernelMs) { float a = 0; (void)hipEventElapsedTime(&a, m->ev0, m->ev1); *kernelMs += a; }
+    return 0;
+}
+
+// The mate searches of SEVERAL bins in one launch (a workgroup per bin; the bins of a batch share the archive's parameters): what lets
+// the device search without the host threads waiting bin by bin.  jobs[j].rows[i] answers jobs[j].pairs[i].
+int match_mates_batch(Device* dev, MatchLane* m, const MateBatchJob* jobs, size_t nJobs, const uint32_t* validBits, size_t validWords, const MateParams& par, double* kernelMs)
+{
+    if (nJobs == 0) return 0;
+    if (par.window < 1u || par.window > kMateThreads || par.sig_len < 2u || par.sig_len > 8u || validWords < ((1ull << (2u * par.sig_len)) + 31u) / 32u) {
+        snprintf(dev->err, sizeof dev->err, "device mate search: window %u / signature length %u not supported", par.window, par.sig_len); return -1;
+    }
+    HIP_TRY(hipSetDevice(m->deviceId));
+    uint64_t seqTotal = 0, pairTotal = 0;
+    std::vector<uint64_t> seqBase(nJobs);
+    for (size_t j = 0; j < nJobs; ++j) {
+        seqBase[j] = seqTotal; seqTotal += (jobs[j].seqBytes + 15u) & ~(uint64_t)15u; pairTotal += jobs[j].nPairs;
+        for (size_t i = 0; i < jobs[j].nPairs; ++i) {
+            const MatePair& p = jobs[j].pairs[i];
+            if ((uint64_t)p.mate_off + p.mate_len > jobs[j].seqBytes || p.mate_len > 255u || p.mate_len < par.sig_len) { snprintf(dev->err, sizeof dev->err, "device mate search: job %zu, pair %zu outside the bases", j, i); return -1; }
+        }
+    }
+    if (seqTotal > 0xFFFFFF00ull || pairTotal > 0xFFFFFF00ull) { snprintf(dev->err, sizeof dev->err, "device mate search: batch beyond 4 GiB"); return -1; }
+    if (pairTotal == 0) return 0;
+    if (ensureBuf(dev, m->dSeq, m->capSeq, seqTotal + 64) || ensureBuf(dev, m->dPairs, m->capPairs, pairTotal * sizeof(MatePair)) || ensureBuf(dev, m->dMateRows, m->capMateRows, pairTotal * sizeof(MateRow)) ||
+        ensureBuf(dev, m->dValid, m->capValid, 8192 + 64) || ensureBuf(dev, m->dCalls, m->capCalls, nJobs * sizeof(MateJob) + 64)) return -1;
+    hipStream_t st = m->stream;
+    std::vector<MateJob> mj(nJobs); std::vector<MatePair> all(pairTotal);
+    uint64_t at = 0;
+    for (size_t j = 0; j < nJobs; ++j) {
+        mj[j] = MateJob{(uint32_t)at, (uint32_t)jobs[j].nPairs};
+        for (size_t i = 0; i < jobs[j].nPairs; ++i) { all[at + i] = jobs[j].pairs[i]; all[at + i].mate_off += (uint32_t)seqBase[j]; }
+        at += jobs[j].nPairs;
+        if (jobs[j].seqBytes) HIP_TRY(hipMemcpyAsync(m->dSeq + seqBase[j], jobs[j].seq, jobs[j].seqBytes, hipMemcpyHostToDevice, st));
+    }
+    std::vector<uint32_t> vb(2048, 0u);
+    memcpy(vb.data(), validBits, std::min<size_t>(validWords, 2048) * 4u);
+    HIP_TRY(hipMemcpyAsync(m->dPairs, all.data(), pairTotal * sizeof(MatePair), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->dValid, vb.data(), 8192, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->dCalls, mj.data(), nJobs * sizeof(MateJob), hipMemcpyHostToDevice, st));
+    static bool attrSet[16] = {};
+    if (!attrSet[m->deviceId & 15]) { HIP_TRY(hipFuncSetAttribute((const void*)fs_match_mates, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MateShared))); attrSet[m->deviceId & 15] = true; }
+    HIP_TRY(hipEventRecord(m->ev0, st));
+    hipLaunchKernelGGL(fs_match_mates, dim3((uint32_t)nJobs), dim3(kMateThreads), sizeof(MateShared), st, (const MateJob*)m->dCalls, (const MatePair*)m->dPairs, (const uint8_t*)m->dSeq, (const uint32_t*)m->dValid, par, m->dMateRows);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(m->ev1, st));
+    std::vector<MateRow> rows(pairTotal);
+    HIP_TRY(hipMemcpyAsync(rows.data(), m->dMateRows, pairTotal * sizeof(MateRow), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(m->evWait, st));
+    HIP_TRY(hipEventSynchronize(m->evWait));
+    at = 0;
+    for (size_t j = 0; j < nJobs; ++j) { if (jobs[j].nPairs) memcpy(jobs[j].rows, rows.data() + at, jobs[j].nPairs * sizeof(MateRow)); at += jobs[j].nPairs; }
     if (kernelMs) { float a = 0; (void)hipEventElapsedTime(&a, m->ev0, m->ev1); *kernelMs += a; }
     return 0;
 }

@@ -456,6 +456,73 @@ MateFn Context::mateMatcherFor(uint32_t tid)
     };
 }
 
+// The device's mate searches without the host threads waiting for them (FS_DEVICE_MATES=2): a bin's pairs are handed over when
+// its walk is done (fs::PendingPairs), two worker threads gather what has come in, search a whole batch of bins in one launch
+// (fs_match_mates: a workgroup per bin), write the bins' mate streams from the rows and report the bins complete.
+struct Context::MateDispatcher {
+    Context& c; std::mutex mx; std::condition_variable cv; std::vector<std::unique_ptr<PendingPairs>> q; bool closing = false; uint32_t inFlight = 0;
+    std::vector<std::thread> workers; std::vector<fsengine::MatchLane*> lanes;
+    explicit MateDispatcher(Context& ctx) : c(ctx)
+    {
+        lanes.assign(2, nullptr);
+        for (uint32_t w = 0; w < 2; ++w) workers.emplace_back([this, w]() { run(w); });
+    }
+    ~MateDispatcher()
+    {
+        { std::lock_guard<std::mutex> g(mx); closing = true; }
+        cv.notify_all();
+        for (auto& t : workers) t.join();
+        for (auto* l : lanes) if (l) fsengine::match_lane_destroy(l);
+    }
+    bool push(std::unique_ptr<PendingPairs> pp)
+    {
+        { std::lock_guard<std::mutex> g(mx); if (closing) return false; q.push_back(std::move(pp)); }
+        cv.notify_one();
+        return true;
+    }
+    static bool sameParams(const fsdev::MateParams& a, const fsdev::MateParams& b) { return memcmp(&a, &b, sizeof a) == 0; }
+    void run(uint32_t w)
+    {
+        for (;;) {
+            std::vector<std::unique_ptr<PendingPairs>> batch;
+            {
+                std::unique_lock<std::mutex> lk(mx);
+                cv.wait(lk, [&]() { return !q.empty() || closing; });
+                if (q.empty()) return;                       // closing, nothing left
+                // (a moment for more bins to arrive: a launch carries what is there, up to 64 bins of one archive's parameters)
+                if (q.size() < 8 && !closing) { lk.unlock(); std::this_thread::sleep_for(std::chrono::microseconds(300)); lk.lock(); }
+                uint64_t bytes = 0;
+                for (size_t i = 0; i < q.size() && batch.size() < 64;) {
+                    if (!batch.empty() && (!sameParams(q[i]->mp, batch[0]->mp) || q[i]->validBits != batch[0]->validBits || bytes + q[i]->seqBytes > (1ull << 30))) { ++i; continue; }
+                    bytes += q[i]->seqBytes; batch.push_back(std::move(q[i])); q.erase(q.begin() + (ptrdiff_t)i);
+                }
+                if (batch.empty()) continue;                 // (the other worker took them during that moment)
+                inFlight += (uint32_t)batch.size();
+            }
+            std::string err;
+            try {
+                fsengine::Device* dev = c.device();
+                if (!lanes[w] && fsengine::match_lane_create(dev, &lanes[w]) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+                std::vector<fsengine::MateBatchJob> jobs(batch.size());
+                uint64_t nPairs = 0;
+                for (size_t j = 0; j < batch.size(); ++j) {
+                    PendingPairs& pp = *batch[j];
+                    pp.rows.resize(pp.pairs.size());
+                    jobs[j] = fsengine::MateBatchJob{pp.seq, pp.seqBytes, pp.pairs.data(), pp.pairs.size(), pp.rows.data()};
+                    nPairs += pp.pairs.size();
+                }
+                const double t0 = nowMs(); double kms = 0;
+                if (fsengine::match_mates_batch(dev, lanes[w], jobs.data(), jobs.size(), batch[0]->validBits.data(), batch[0]->validBits.size(), batch[0]->mp, &kms) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+                c.matedPairs += nPairs; c.mateUs += (uint64_t)((nowMs() - t0) * 1e3); c.mateKernelUs += (uint64_t)(kms * 1e3);
+                for (auto& pp : batch) emitPairsFromRows(*pp);
+            } catch (const std::exception& e) { err = e.what(); }
+            for (auto& pp : batch) pp->done(err.empty() ? nullptr : err.c_str());
+            { std::lock_guard<std::mutex> g(mx); inFlight -= (uint32_t)batch.size(); }
+            cv.notify_all();
+        }
+    }
+};
+
 void Context::mateMatcherCheck(const std::string& inPrefix, uint64_t& pairs, uint64_t& differing)
 {
     pairs = differing = 0;
@@ -1158,8 +1225,23 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     if (trace) fprintf(stderr, "[trace] batch set-up (slices, %u lanes, matcher lanes) %.1f ms\n", nLanes, tf - t0);
     try {
         std::mutex roundMx; std::condition_variable roundCv; uint32_t binsDone = 0;
-        const bool deviceMates = getenv("FS_DEVICE_MATES") && atoi(getenv("FS_DEVICE_MATES")) != 0;       // (read per batch: the tests switch it inside one process)
+        const int matesMode = getenv("FS_DEVICE_MATES") ? atoi(getenv("FS_DEVICE_MATES")) : 0;       // (read per batch: the tests switch it inside one process)
+        const bool deviceMates = matesMode == 1;                 // 1: the device's searches, bin by bin, waited for (round 3's form); 2: batched, not waited for
         const bool deviceEmit = !(getenv("FS_DEVICE_EMIT") && atoi(getenv("FS_DEVICE_EMIT")) == 0);
+        std::unique_ptr<MateDispatcher> mateDispatcher;
+        if (matesMode == 2 && deviceEmit && deviceMatcher) mateDispatcher.reset(new MateDispatcher(*this));
+        std::mutex asyncErrMx; std::string asyncErr;
+        // (a bin whose pairs are with the device is complete when BOTH its host task has returned -- it still fills in the bin's packed
+        // scores and read ids behind the walk -- and its rows have come back: whichever is second counts it)
+        std::unique_ptr<std::atomic<uint8_t>[]> parts(new std::atomic<uint8_t>[nBins]);
+        for (uint32_t i = 0; i < nBins; ++i) parts[i].store(2);
+        // a bin is through the front end: its slice counts it (here, or -- its pairs still with the device -- when they come back)
+        auto binComplete = [&](uint32_t k) {
+            Slice& S = slices[sliceOf[k]];
+            bool last;
+            { std::lock_guard<std::mutex> lk(S.mx); last = --S.pending == 0; }
+            if (last) S.cv.notify_all();
+        };
         parallelFor(nBins, hostThreads, [&](uint32_t k, uint32_t tid) {
             const uint32_t b = byWork[k];
             if (abort.load()) return;                                // (the device could not be made: nothing left to do for the bins)
@@ -1183,14 +1265,23 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             // the streams that hold bases (HardReads, LettersX, Match, ...: fsdev::EmitOp) and the LZ ids' run-length coding: written
             // by the device from the ops the walk leaves (FS_DEVICE_EMIT=0: by the walk itself, A/B runs)
             encs[tid]->setDeviceEmit(deviceEmit);
+            if (mateDispatcher) {
+                MateDispatcher* md = mateDispatcher.get();
+                encs[tid]->setAsyncMates([&, k, md](std::unique_ptr<PendingPairs> pp) {
+                    pp->done = [&, k](const char* error) {
+                        if (error) { { std::lock_guard<std::mutex> g(asyncErrMx); if (asyncErr.empty()) asyncErr = error; } abort.store(true); for (Slice& s : slices) { std::lock_guard<std::mutex> lk(s.mx); s.cv.notify_all(); } }
+                        if (parts[k].fetch_sub(1) == 1) binComplete(k);
+                    };
+                    return md->push(std::move(pp));
+                });
+            } else encs[tid]->setAsyncMates(AsyncMateFn());
             const double ta = trace ? nowMs() : 0.0;
             produce(b, *encs[tid], st[b], info[b], recBytes[b]);
             if (trace) busyMs[tid] += nowMs() - ta;
-            Slice& S = slices[sliceOf[k]];
-            bool last;
-            { std::lock_guard<std::mutex> lk(S.mx); last = --S.pending == 0; }
-            if (last) S.cv.notify_all();
+            if (!st[b].pairsPending || parts[k].fetch_sub(1) == 1) binComplete(k);
         });
+        mateDispatcher.reset();                                  // (waits for the searches still on their way and their bins' completion)
+        if (!asyncErr.empty()) throw std::runtime_error(asyncErr);
     } catch (...) {
         abort.store(true);
         for (Slice& s : slices) { std::lock_guard<std::mutex> lk(s.mx); s.cv.notify_all(); }

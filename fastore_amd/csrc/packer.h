@@ -139,6 +139,7 @@ struct Context {
     // parity check of the device mate search: every standard bin of a paired-end library through the host search and fs_match_mates
     void mateMatcherCheck(const std::string& inPrefix, uint64_t& pairs, uint64_t& differing);
     // parity check of the device tokeniser: every standard bin's read ids through the host tokeniser and through fs_tokenise_ids
+    struct MateDispatcher;
     void emitCheck(const std::string& inPrefix, uint64_t& ops, uint64_t& streamsCompared, uint64_t& differing);
     void tokeniserCheck(const std::string& inPrefix, uint64_t& ids, uint64_t& differingBins);
     // merged small bins + N bin (batch with ONE bin, records already in stored order): RawCompressorSE/PE

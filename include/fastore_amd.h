@@ -119,6 +119,9 @@ typedef struct fsgpu_stats {
      * descriptor per read when the device unpacks them itself (fs_unpack_planes; FastqPacker.cpp:290-411), else ASCII --
      * and the reads whose bases the device unpacked */
     uint64_t matcher_bases_h2d_bytes, matcher_unpacked_reads;
+    /* mate search of paired-end bins on the device (fs_match_mates; FS_DEVICE_MATES=1: a bin at a time, 2: many bins a launch, nobody waits):
+     * pairs searched, wall time of its calls (summed over the callers), HIP-event time of its kernels (summed over the launches) */
+    uint64_t mate_pairs; double mate_call_ms, mate_kernel_ms;
 } fsgpu_stats;
 
 void fsgpu_config_defaults(fsgpu_config* cfg);

@@ -205,6 +205,13 @@ int match_reads(Device* dev, MatchLane*, const uint8_t* seqIn, size_t seqBytes, 
 
 // what fs_match_mates computes, as a plain loop over a history kept newest first (test-only stand-in; the rules are those of
 // LzCompressorPE::CompressPair, restated from the kernel's description, not from the product's host search)
+int match_mates(Device*, MatchLane*, const uint8_t* seq, size_t, const MatePair* pairs, size_t nPairs, const uint32_t* validBits, size_t, const MateParams& par, MateRow* rows, double*);
+int match_mates_batch(Device* dev, MatchLane* m, const MateBatchJob* jobs, size_t nJobs, const uint32_t* validBits, size_t validWords, const MateParams& par, double* kms)
+{
+    for (size_t j = 0; j < nJobs; ++j)
+        if (jobs[j].nPairs && match_mates(dev, m, jobs[j].seq, jobs[j].seqBytes, jobs[j].pairs, jobs[j].nPairs, validBits, validWords, par, jobs[j].rows, kms) != 0) return -1;
+    return 0;
+}
 int match_mates(Device*, MatchLane*, const uint8_t* seq, size_t, const MatePair* pairs, size_t nPairs, const uint32_t* validBits, size_t, const MateParams& par, MateRow* rows, double*)
 {
     struct Entry { uint32_t sig[4]; uint32_t pos[4]; uint32_t off, len; int32_t pair; bool live; };

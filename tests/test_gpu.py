@@ -482,11 +482,14 @@ def test_device_mate_search_on_a_fresh_library_and_same_archive_either_way(tmp_p
     with fastore_amd.Packer(device_id=0) as p:
         pairs, differing = p.pe_matcher_check(binned)
         assert pairs > 50_000 and differing == 0, (pairs, differing)
-    # (the archive with the host's searches -- the default -- is test_gpu_pack_equals_live_reference_on_a_library_with_long_streams[pe_long])
-    monkeypatch.setenv("FS_DEVICE_MATES", "1")
-    with fastore_amd.Packer(device_id=0) as p:
-        p.pack_file(binned, os.path.join(t, "gpu1"))
-    assert_same_archive(os.path.join(t, "gpu1"), ref)
+    # (the archive with the host's searches is test_gpu_pack_equals_live_reference_on_a_library_with_long_streams[pe_long])
+    # the device's searches handed over and run in batches of bins (2), and bin by bin (1)
+    for mode in ("2", "1"):
+        monkeypatch.setenv("FS_DEVICE_MATES", mode)
+        with fastore_amd.Packer(device_id=0) as p:
+            st = p.pack_file(binned, os.path.join(t, "gpu" + mode))
+        assert_same_archive(os.path.join(t, "gpu" + mode), ref)
+        assert st["mate_pairs"] > 50_000 and st["mate_kernel_ms"] > 0, (mode, st["mate_pairs"])
 
 
 @pytest.mark.parametrize("name,paired,flags", manifest())

@@ -40,7 +40,7 @@ def test_c_abi_exports_every_declared_symbol(product_lib):
 def test_structs_match_header_layout(product_lib):
     import fastore_amd
     assert ctypes.sizeof(fastore_amd.Config) == 96
-    assert ctypes.sizeof(fastore_amd.Stats) == 312
+    assert ctypes.sizeof(fastore_amd.Stats) == 336
     cfg = fastore_amd.Config()
     product_lib.fsgpu_config_defaults(ctypes.byref(cfg))
     # reference defaults: fastore_pack/Params.h:18-147, fastore_bin/Globals.h:61-62
@@ -508,14 +508,17 @@ def test_mate_search_rows_against_the_scalar_restatement(emu_lib, name, paired, 
 
 @pytest.mark.parametrize("name,paired,flags", [m for m in manifest() if m[1]])
 def test_device_mate_search_is_taken_and_changes_no_byte(emu_lib, tmp_path, monkeypatch, name, paired, flags):
-    # the archive with the mate searches taken from the "device" (here: the emulation's stand-in) and with the host's search
+    # the archive with the mate searches taken from the "device" (here: the emulation's stand-in) -- bin by bin and waited for (1), or
+    # handed over and searched in batches of bins while the host threads go on (2: fs::PendingPairs, the mate streams written from
+    # the rows when a batch comes back; several slices and few threads, so that bins complete in every order) -- and with the host's search
     import fastore_amd
     ref = open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
-    for mode in ("1", "0"):
+    for mode, kw in (("1", {}), ("2", {}), ("2", dict(host_threads=3, pipeline_slices=5, pipeline_lanes=2)), ("0", {})):
         monkeypatch.setenv("FS_DEVICE_MATES", mode)
-        with fastore_amd.Packer(lib=emu_lib, device_id=0, **knobs_from_flags(flags)) as p:
-            p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o" + mode)))
-        assert open(str(tmp_path / ("o" + mode)) + ".cdata", "rb").read() == ref
+        with fastore_amd.Packer(lib=emu_lib, device_id=0, **kw, **knobs_from_flags(flags)) as p:
+            st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o" + mode)))
+        assert open(str(tmp_path / ("o" + mode)) + ".cdata", "rb").read() == ref, (mode, kw)
+        assert (st["mate_pairs"] > 1000) == (mode != "0"), (mode, st["mate_pairs"])      # ... and they were taken there, every pair of a standard bin
 
 
 @pytest.mark.parametrize("name,paired,flags", [m for m in manifest() if m[0] != "se_noheader"])
