@@ -67,7 +67,7 @@ int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std
 // Device-side read matcher (matcher.hip): a lane of its own (high-priority stream, own buffers) per caller; match_reads
 // answers every read of one bin's match-tree constructions and returns when the rows are in `rows`
 struct MatchLane;
-int match_lane_create(Device* dev, MatchLane** out);
+int match_lane_create(Device* dev, MatchLane** out, bool ownStream = false);      // ownStream: a stream of its own instead of one of the searches' shared ones (the batched mate searches: their kernels run for a tenth of a second)
 void match_lane_destroy(MatchLane* m);
 int match_lane_reserve(Device* dev, MatchLane* m, size_t maxReads, size_t maxSeqBytes, size_t maxCalls, size_t maxWarm);
 // packed != nullptr: the bases come as the bin file stores them and are unpacked on the device (fs_unpack_planes); `seq` then

@@ -29,6 +29,7 @@
 
 #include "device_types.h"
 #include "engine.h"
+#include "mates_core.h"
 
 using namespace fsdev;
 
@@ -247,194 +248,17 @@ template <int FW, bool MULTI> __global__ __launch_bounds__(MULTI ? 1024 : 64) vo
 // At or below the threshold the mate is coded against that entry.  The mate then enters the history at the front -- or, if
 // it matched with cost 0 and no mismatch, at the back, from where the next pair drops it unseen.
 //
-// MI355X mapping: one 1024-thread workgroup per bin, the pairs one after the other (each depends on where the ones before
-// went).  Per pair: the mate's bases into LDS; a thread per position builds the signature and sets its bit in the sets'
-// bitmaps (one bit per signature: 8 KB each; distinct members are counted by who set a bit first); two wavefronts pick the
-// sets' four smallest members (DPP minimum, then strike the winner's signature, four times); a thread per history entry tests
-// its listed signatures against the bitmaps and puts its alignments on a list; the sixteen wavefronts price the list -- a
-// lane per base, the entry's bases from HBM (L2-resident: the bin's own bases), the mate's from LDS, ballot + popcount -- and
-// the cheapest goes to an LDS atomic minimum over (cost, order, list index).  The entry the pair replaces is rewritten by
-// its thread.  Rows come back as the host's serial search computes them (checked pair by pair: fsgpu_pe_matcher_check).
-// (the list holds (entry, listed signature) pairs -- at most four per entry, so kMateCand = 4 x kMateThreads can never overflow; the
-// up to four alignments of a pair are made by the wavefront that prices it)
-enum : uint32_t { kMateThreads = 1024, kMateCand = 4096, kMateNone = 0xFFFFFFFFu };
-struct MateShared {
-    uint32_t mate[64];                      // the current mate's bases (bytes)
-    uint32_t sigAt[256];                    // per position: its signature if it is a member of set 1 / set 2, else kMateNone
-    uint32_t bmA[2048], bmB[2048], valid[2048];
-    uint32_t entSig[4][kMateThreads];       // per history entry: signature | position << 16 of its four slots (0 = unused: position 0 still counts)
-    uint32_t entOff[kMateThreads], entLen[kMateThreads], entPair[kMateThreads], entStamp[kMateThreads], entLive[kMateThreads];
-    uint32_t candE[kMateCand], candKey[kMateCand]; uint32_t candPos[kMateCand];      // entry, (signature, age) key, the signature's first position in the mate
-    uint32_t small1[4], small2[4];          // the sets' smallest members: signature << 8 | first position
-    uint32_t posTab[1024];                  // open-addressing table of the mate's member signatures: (signature << 8 | position) + 1, 0 = empty (at most 256 members)
-    uint32_t nCand, size1, size2, overflow;
-    unsigned long long best;
-    uint8_t idx[128];                       // base -> 0..3 (4: 'N', 255: anything else)
-};
+// MI355X mapping: one 1024-thread workgroup per bin, the pairs one after the other; mates_core.h says what a pair costs it and what was
+// measured on the way there.  Rows come back as the host's serial search computes them (checked pair by pair: fsgpu_pe_matcher_check).
+enum : uint32_t { kMateWindowMax = fsmate::kWindowMax };
 
-__global__ __launch_bounds__(kMateThreads) void fs_match_mates(const MateJob* __restrict__ jobs, const MatePair* __restrict__ pairs, const uint8_t* __restrict__ seq,
-                                                               const uint32_t* __restrict__ validBits, MateParams par, MateRow* __restrict__ rows)
+__global__ __launch_bounds__(fsmate::kThreads) void fs_match_mates(const MateJob* __restrict__ jobs, const MatePair* __restrict__ pairs, const uint8_t* __restrict__ seq,
+                                                                   const uint32_t* __restrict__ validBits, MateParams par, MateRow* __restrict__ rows, uint32_t* __restrict__ hist)
 {
-    extern __shared__ uint8_t mateLds[];
-    MateShared& sh = *(MateShared*)mateLds;
-    const MateJob job = jobs[blockIdx.x];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t W = par.window, sigLen = par.sig_len, sigMask = (1u << (2u * sigLen)) - 1u;
-    for (uint32_t i = tid; i < 2048u; i += kMateThreads) { sh.bmA[i] = 0u; sh.bmB[i] = 0u; sh.valid[i] = (i << 5) <= sigMask ? validBits[i] : 0u; }
-    if (tid < 128u) { uint32_t v = 255u; for (uint32_t k = 0; k < 5u; ++k) if (par.symbol_order[k] == tid) v = k; sh.idx[tid] = (uint8_t)v; }
-    sh.entLive[tid] = 0u; sh.entStamp[tid] = 0u; sh.entPair[tid] = 0u; sh.entOff[tid] = 0u; sh.entLen[tid] = 0u;
-    for (int j = 0; j < 4; ++j) sh.entSig[j][tid] = 0u;
-    if (tid == 0u) { sh.nCand = 0u; sh.size1 = 0u; sh.size2 = 0u; sh.overflow = 0u; sh.best = ~0ull; }
-    sh.posTab[tid] = 0u;
-    __syncthreads();
-    // the history as a ring: slots leave in the order W-1, W-2, .., 0, W-1, .. -- except that a mate that went to the BACK leaves first
-    uint32_t ring = W - 1u, frontPushes = 0u, backSlot = kMateNone;
-    for (uint32_t p = 0; p < job.count; ++p) {
-        const MatePair pr = pairs[job.first + p];
-        const uint32_t plen = pr.mate_len;
-        const uint32_t slot = backSlot != kMateNone ? backSlot : ring;            // the entry that leaves (and will hold this mate)
-        if (tid == slot) sh.entLive[slot] = 0u;
-        if (tid < (plen + 3u) / 4u) { uint32_t w = 0; for (uint32_t b = 0; b < 4u; ++b) { const uint32_t q = 4u * tid + b; w |= (q < plen ? (uint32_t)seq[pr.mate_off + q] : (uint32_t)'N') << (8u * b); } sh.mate[tid] = w; }
-        __syncthreads();
-        // ---- the mate's signatures (FindMinimizers over the two halves)
-        const int32_t half = (int32_t)plen / 2;
-        const int32_t end1 = (int32_t)plen - (int32_t)sigLen - ((int32_t)par.skip_zone + half - ((int32_t)sigLen - 1));
-        const int32_t end2 = (int32_t)plen - (int32_t)sigLen - (int32_t)par.skip_zone;
-        uint32_t m = 0; bool ok = false, in1 = false, in2 = false;
-        if (tid < 256u && (int32_t)tid + (int32_t)sigLen <= (int32_t)plen) {
-            in1 = (int32_t)tid < end1; in2 = (int32_t)tid >= half && (int32_t)tid < end2;
-            if (in1 || in2) {
-                ok = true;
-                const uint8_t* mb = (const uint8_t*)sh.mate;
-                for (uint32_t k = 0; k < sigLen; ++k) { const uint32_t c = sh.idx[mb[tid + k] & 127u]; if (c > 3u) ok = false; m = (m << 2) | (c & 3u); }
-                ok = ok && ((sh.valid[m >> 5] >> (m & 31u)) & 1u) != 0u;
-            }
-        }
-        bool member = false;
-        if (ok && in1) { const uint32_t old = atomicOr(&sh.bmA[m >> 5], 1u << (m & 31u)); member = true; if (!((old >> (m & 31u)) & 1u)) atomicAdd(&sh.size1, 1u); }
-        __syncthreads();
-        if (ok && in2 && !in1) {
-            if (!((sh.bmA[m >> 5] >> (m & 31u)) & 1u)) { const uint32_t old = atomicOr(&sh.bmB[m >> 5], 1u << (m & 31u)); member = true; if (!((old >> (m & 31u)) & 1u)) atomicAdd(&sh.size2, 1u); }
-        }
-        if (tid < 256u) sh.sigAt[tid] = member ? m : kMateNone;
-        if (member) {      // where a member signature stands: looked up by the entries that list it
-            uint32_t h = (m * 0x9E3779B1u) >> 22;
-            while (atomicCAS(&sh.posTab[h], 0u, ((m << 8) | tid) + 1u) != 0u) h = (h + 1u) & 1023u;
-        }
-        __syncthreads();
-        // ---- the four smallest members of each set, with their first positions (wave 0: set 1, wave 1: set 2)
-        if (wave < 2u) {
-            uint32_t key[4];
-            for (uint32_t q = 0; q < 4u; ++q) {
-                const uint32_t t = lane + 64u * q; const uint32_t sg = sh.sigAt[t];
-                const bool mine = sg != kMateNone && (wave == 0u ? (int32_t)t < end1 : (int32_t)t >= half);
-                key[q] = mine ? (sg << 8) | t : kMateNone;
-            }
-            for (uint32_t r = 0; r < 4u; ++r) {
-                uint32_t loc = key[0] < key[1] ? key[0] : key[1]; const uint32_t l2 = key[2] < key[3] ? key[2] : key[3]; loc = loc < l2 ? loc : l2;
-                const uint32_t best = wave_min_u32(loc);
-                if (lane == 0u) (wave == 0u ? sh.small1 : sh.small2)[r] = best;
-                for (uint32_t q = 0; q < 4u; ++q) if (best != kMateNone && (key[q] >> 8) == (best >> 8)) key[q] = kMateNone;
-            }
-        }
-        // ---- every live entry: its listed signatures against the sets; its alignments onto the list
-        if (tid < W && sh.entLive[tid]) {
-            const uint32_t pos = frontPushes - sh.entStamp[tid] - 1u;             // place in the history, newest = 0
-            const uint32_t rank = (W - 1u) - pos;                                  // oldest first
-            for (uint32_t j = 0; j < 4u; ++j) {
-                const uint32_t sj = sh.entSig[j][tid] & 0xFFFFu;
-                if (sj == 0u) break;
-                if (!(((sh.bmA[sj >> 5] | sh.bmB[sj >> 5]) >> (sj & 31u)) & 1u)) continue;
-                uint32_t posH = 256u;
-                for (uint32_t h = (sj * 0x9E3779B1u) >> 22;; h = (h + 1u) & 1023u) {
-                    const uint32_t e = sh.posTab[h];
-                    if (e == 0u) break;
-                    if (((e - 1u) >> 8) == sj) { posH = (e - 1u) & 255u; break; }
-                }
-                if (posH >= 256u) continue;
-                const uint32_t at = atomicAdd(&sh.nCand, 1u);
-                if (at < kMateCand) { sh.candE[at] = tid; sh.candPos[at] = posH; sh.candKey[at] = (sj << 12) | (rank << 2); }
-                else sh.overflow = 1u;                                                           // (cannot happen: four per entry at most)
-            }
-        }
-        __syncthreads();
-        // ---- price the list: a wavefront per alignment, a lane per base
-        {
-            const uint32_t nCand = sh.nCand < kMateCand ? sh.nCand : (uint32_t)kMateCand;
-            const uint8_t* mb = (const uint8_t*)sh.mate;
-            for (uint32_t c = wave; c < nCand; c += kMateThreads / 64u) {
-              const uint32_t e = sh.candE[c]; const int32_t posH = (int32_t)sh.candPos[c];
-              // the entry's FOUR stored positions against the signature's position in the mate (unused zeros included, as the
-              // reference does); the same alignment again: the earlier one decides
-              int32_t seen[4]; uint32_t nSeen = 0;
-              for (uint32_t k = 0; k < 4u; ++k) {
-                const int32_t shift = (int32_t)(sh.entSig[k][e] >> 16) - posH;
-                if (shift > 127 || shift < -127) continue;
-                bool dup = false;
-                for (uint32_t q = 0; q < nSeen; ++q) dup = dup || seen[q] == shift;
-                if (dup) continue;
-                seen[nSeen++] = shift;
-                const uint32_t recOff = shift < 0 ? (uint32_t)-shift : 0u, lzOff = shift > 0 ? (uint32_t)shift : 0u;
-                const uint32_t lzLen = sh.entLen[e], a = plen - recOff, b = lzLen - lzOff, minLen = a < b ? a : b;
-                const uint8_t* lz = seq + sh.entOff[e] + lzOff;
-                const uint32_t ashift = (uint32_t)(shift < 0 ? -shift : shift);
-                // an alignment that already costs MORE than the cheapest one found so far cannot win (equal cost still can: the order
-                // among equals decides); the bound only ever falls, so a stale look at it prunes less, never wrongly
-                const uint32_t bound = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((volatile uint32_t*)&sh.best)[1] >> 12));      // (cost: bits 44.. of the word; one look for the whole wavefront)
-                uint32_t mism = 0, cost = ashift * (uint32_t)par.shift_cost;
-                if (cost > bound) continue;
-                for (uint32_t i = lane; i < ((minLen + 63u) & ~63u); i += 64u) {
-                    const bool diff = i < minLen && mb[recOff + i] != lz[i];
-                    mism += (uint32_t)__popcll(__ballot(diff));
-                    if (ashift * (uint32_t)par.shift_cost + mism * (uint32_t)par.mismatch_cost > bound) break;
-                }
-                cost = ashift * (uint32_t)par.shift_cost + mism * (uint32_t)par.mismatch_cost;
-                if (cost > bound) continue;
-                if (lane == 0u && cost < 255u) atomicMin(&sh.best, ((unsigned long long)cost << 44) | ((unsigned long long)(sh.candKey[c] | k) << 12) | c);
-              }
-            }
-        }
-        __syncthreads();
-        // ---- the answer, and the mate's own entry
-        const unsigned long long best = sh.best;
-        uint32_t cost = 255u, prevId = 0, matchPair = 0; int32_t shift = 0; bool noMism = false;
-        if (best != ~0ull) {
-            cost = (uint32_t)(best >> 44);
-            const uint32_t cc = (uint32_t)(best & 0xFFFull);
-            const uint32_t e = sh.candE[cc], kk = (uint32_t)(best >> 12) & 3u;
-            shift = (int32_t)(sh.entSig[kk][e] >> 16) - (int32_t)sh.candPos[cc];
-            prevId = frontPushes - sh.entStamp[e] - 1u; matchPair = sh.entPair[e];
-            const uint32_t ashift = (uint32_t)(shift < 0 ? -shift : shift);
-            noMism = cost == ashift * (uint32_t)par.shift_cost;
-        }
-        const bool matched = (int32_t)cost <= (int32_t)pr.threshold;
-        const bool identical = matched && noMism && cost == 0u;
-        if (tid == 0u) {
-            MateRow row; row.match = matched ? (int32_t)matchPair : -1; row.cost = (int16_t)cost; row.shift = (int16_t)shift; row.prev_id = (uint16_t)prevId;
-            row.no_mismatches = noMism ? 1 : 0; row.overflow = (uint8_t)sh.overflow;
-            rows[job.first + p] = row;
-        }
-        // the sets' bits and the table's entries are taken back by the lanes that set them
-        sh.posTab[tid] = 0u;
-        if (member) { atomicAnd(&sh.bmA[m >> 5], ~(1u << (m & 31u))); atomicAnd(&sh.bmB[m >> 5], ~(1u << (m & 31u))); }
-        __syncthreads();
-        if (tid == slot) {
-            // two signatures from the smaller set, then from the other one up to four in all (their smallest members)
-            const uint32_t s1 = sh.size1, s2 = sh.size2;
-            const uint32_t* first = s1 > s2 ? sh.small2 : sh.small1; const uint32_t* second = s1 > s2 ? sh.small1 : sh.small2;
-            const uint32_t firstSize = s1 > s2 ? s2 : s1, total = s1 + s2;
-            uint32_t n = 0;
-            for (uint32_t q = 0; n < (firstSize < 2u ? firstSize : 2u); ++n, ++q) sh.entSig[n][slot] = (first[q] >> 8) | ((first[q] & 0xFFu) << 16);
-            for (uint32_t q = 0; n < (total < 4u ? total : 4u); ++n, ++q) sh.entSig[n][slot] = (second[q] >> 8) | ((second[q] & 0xFFu) << 16);
-            for (; n < 4u; ++n) sh.entSig[n][slot] = 0u;
-            sh.entOff[slot] = pr.mate_off; sh.entLen[slot] = plen; sh.entPair[slot] = p; sh.entStamp[slot] = frontPushes;
-            sh.entLive[slot] = identical ? 0u : 1u;                               // (at the back it is dropped before anyone looks)
-        }
-        if (tid == 0u) { sh.nCand = 0u; sh.size1 = 0u; sh.size2 = 0u; sh.best = ~0ull; }
-        if (identical) backSlot = slot;
-        else { ring = ring == 0u ? W - 1u : ring - 1u; backSlot = kMateNone; ++frontPushes; }      // (a slot that came back from the back IS the ring's current one)
-        __syncthreads();
-    }
+#if defined(__HIP_DEVICE_COMPILE__)      // (the compiler's host pass only needs the kernel's name)
+    __shared__ fsmate::Shared sh;
+    fsmate::search_bin(sh, jobs[blockIdx.x], pairs, seq, validBits, par, rows, hist + (size_t)blockIdx.x * fsmate::hist_words(par.window));
+#endif
 }
 
 template <class T> int ensureBuf(fsengine::Device* dev, T*& p, size_t& cap, size_t need)
@@ -482,10 +306,12 @@ struct MatchLane {
     uint32_t* dPlanes = nullptr; size_t capPlanes = 0;
     MatchRow* dRows = nullptr; size_t capRows = 0;
     MatePair* dPairs = nullptr; size_t capPairs = 0; MateRow* dMateRows = nullptr; size_t capMateRows = 0; uint32_t* dValid = nullptr; size_t capValid = 0;
+    uint32_t* dHist = nullptr; size_t capHist = 0;             // the mate searches' histories (mates_core.h: hist_words per bin of a launch)
     uint8_t* hStage = nullptr; size_t capStage = 0; bool stagePageable = false;
+    bool ownStream = false;
 };
 
-int match_lane_create(Device* dev, MatchLane** out)
+int match_lane_create(Device* dev, MatchLane** out, bool ownStream)
 {
     *out = nullptr;
     HIP_TRY(hipSetDevice(dev->deviceId));
@@ -493,7 +319,14 @@ int match_lane_create(Device* dev, MatchLane** out)
     // (streams of normal priority: a high-priority queue makes the scheduler save and restore the resident coder waves
     // around every search -- measured: the coder kernels ran twice as long)
     hipError_t e = hipSuccess;
-    {
+    if (ownStream) {
+        if (const uint32_t sc = search_cus()) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t b = 0; b < sc; ++b) mask[b >> 5] |= 1u << (b & 31u);
+            e = hipExtStreamCreateWithCUMask(&m->stream, 8, mask);
+        } else e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+        m->ownStream = e == hipSuccess;
+    } else {
         std::lock_guard<std::mutex> g(g_poolMx);
         StreamPool& p = g_pool[dev->deviceId & 15];
         for (int i = 0; i < matchStreams() && e == hipSuccess; ++i) if (!p.s[i]) {
@@ -517,6 +350,7 @@ void match_lane_destroy(MatchLane* m)
 {
     if (!m) return;
     (void)hipSetDevice(m->deviceId);
+    if (m->stream && m->ownStream) { (void)hipStreamSynchronize(m->stream); (void)hipStreamDestroy(m->stream); m->stream = nullptr; }
     if (m->stream) {
         (void)hipStreamSynchronize(m->stream);
         std::lock_guard<std::mutex> g(g_poolMx);
@@ -524,7 +358,7 @@ void match_lane_destroy(MatchLane* m)
         if (--p.users == 0) { for (int i = 0; i < kMatchStreamsMax; ++i) if (p.s[i]) { (void)hipStreamDestroy(p.s[i]); p.s[i] = nullptr; } }
         m->stream = nullptr;
     }
-    void* ptrs[] = {m->dSeq, m->dReads, m->dPacked, m->dCalls, m->dIds, m->dWarm, m->dPlanes, m->dRows, m->dPairs, m->dMateRows, m->dValid};
+    void* ptrs[] = {m->dSeq, m->dReads, m->dPacked, m->dCalls, m->dIds, m->dWarm, m->dPlanes, m->dRows, m->dPairs, m->dMateRows, m->dValid, m->dHist};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (m->hStage) pinned_free(m->hStage, m->capStage, !m->stagePageable);
     if (m->evWait) (void)hipEventDestroy(m->evWait);
@@ -682,14 +516,15 @@ int match_mates(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
                 const MateParams& par, MateRow* rows, double* kernelMs)
 {
     if (nPairs == 0) return 0;
-    if (par.window < 1u || par.window > kMateThreads || par.sig_len < 2u || par.sig_len > 8u || validWords < ((1ull << (2u * par.sig_len)) + 31u) / 32u) {
+    if (par.window < 1u || par.window > kMateWindowMax || par.sig_len < 2u || par.sig_len > 8u || validWords < ((1ull << (2u * par.sig_len)) + 31u) / 32u) {
         snprintf(dev->err, sizeof dev->err, "device mate search: window %u / signature length %u not supported", par.window, par.sig_len); return -1;
     }
     HIP_TRY(hipSetDevice(m->deviceId));
     for (size_t i = 0; i < nPairs; ++i)
         if ((uint64_t)pairs[i].mate_off + pairs[i].mate_len > seqBytes || pairs[i].mate_len > 255u || pairs[i].mate_len < par.sig_len) { snprintf(dev->err, sizeof dev->err, "device mate search: pair %zu outside the bases", i); return -1; }
     if (ensureBuf(dev, m->dSeq, m->capSeq, seqBytes + 64) || ensureBuf(dev, m->dPairs, m->capPairs, nPairs * sizeof(MatePair)) || ensureBuf(dev, m->dMateRows, m->capMateRows, nPairs * sizeof(MateRow)) ||
-        ensureBuf(dev, m->dValid, m->capValid, 8192 + 64) || ensureBuf(dev, m->dCalls, m->capCalls, sizeof(MateJob) + 64)) return -1;
+        ensureBuf(dev, m->dValid, m->capValid, 8192 + 64) || ensureBuf(dev, m->dCalls, m->capCalls, sizeof(MateJob) + 64) ||
+        ensureBuf(dev, m->dHist, m->capHist, (size_t)fsmate::hist_words(par.window) * 4u)) return -1;
     hipStream_t st = m->stream;
     const MateJob job{0u, (uint32_t)nPairs};
     std::vector<uint32_t> vb(2048, 0u);
@@ -698,10 +533,8 @@ int match_mates(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
     HIP_TRY(hipMemcpyAsync(m->dPairs, pairs, nPairs * sizeof(MatePair), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->dValid, vb.data(), 8192, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->dCalls, &job, sizeof job, hipMemcpyHostToDevice, st));
-    static bool attrSet[16] = {};
-    if (!attrSet[m->deviceId & 15]) { HIP_TRY(hipFuncSetAttribute((const void*)fs_match_mates, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MateShared))); attrSet[m->deviceId & 15] = true; }
     HIP_TRY(hipEventRecord(m->ev0, st));
-    hipLaunchKernelGGL(fs_match_mates, dim3(1), dim3(kMateThreads), sizeof(MateShared), st, (const MateJob*)m->dCalls, (const MatePair*)m->dPairs, (const uint8_t*)m->dSeq, (const uint32_t*)m->dValid, par, m->dMateRows);
+    hipLaunchKernelGGL(fs_match_mates, dim3(1), dim3(fsmate::kThreads), 0, st, (const MateJob*)m->dCalls, (const MatePair*)m->dPairs, (const uint8_t*)m->dSeq, (const uint32_t*)m->dValid, par, m->dMateRows, m->dHist);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev1, st));
     HIP_TRY(hipMemcpyAsync(rows, m->dMateRows, nPairs * sizeof(MateRow), hipMemcpyDeviceToHost, st));
@@ -716,7 +549,7 @@ int match_mates(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
 int match_mates_batch(Device* dev, MatchLane* m, const MateBatchJob* jobs, size_t nJobs, const uint32_t* validBits, size_t validWords, const MateParams& par, double* kernelMs)
 {
     if (nJobs == 0) return 0;
-    if (par.window < 1u || par.window > kMateThreads || par.sig_len < 2u || par.sig_len > 8u || validWords < ((1ull << (2u * par.sig_len)) + 31u) / 32u) {
+    if (par.window < 1u || par.window > kMateWindowMax || par.sig_len < 2u || par.sig_len > 8u || validWords < ((1ull << (2u * par.sig_len)) + 31u) / 32u) {
         snprintf(dev->err, sizeof dev->err, "device mate search: window %u / signature length %u not supported", par.window, par.sig_len); return -1;
     }
     HIP_TRY(hipSetDevice(m->deviceId));
@@ -732,7 +565,8 @@ int match_mates_batch(Device* dev, MatchLane* m, const MateBatchJob* jobs, size_
     if (seqTotal > 0xFFFFFF00ull || pairTotal > 0xFFFFFF00ull) { snprintf(dev->err, sizeof dev->err, "device mate search: batch beyond 4 GiB"); return -1; }
     if (pairTotal == 0) return 0;
     if (ensureBuf(dev, m->dSeq, m->capSeq, seqTotal + 64) || ensureBuf(dev, m->dPairs, m->capPairs, pairTotal * sizeof(MatePair)) || ensureBuf(dev, m->dMateRows, m->capMateRows, pairTotal * sizeof(MateRow)) ||
-        ensureBuf(dev, m->dValid, m->capValid, 8192 + 64) || ensureBuf(dev, m->dCalls, m->capCalls, nJobs * sizeof(MateJob) + 64)) return -1;
+        ensureBuf(dev, m->dValid, m->capValid, 8192 + 64) || ensureBuf(dev, m->dCalls, m->capCalls, nJobs * sizeof(MateJob) + 64) ||
+        ensureBuf(dev, m->dHist, m->capHist, nJobs * (size_t)fsmate::hist_words(par.window) * 4u)) return -1;
     hipStream_t st = m->stream;
     std::vector<MateJob> mj(nJobs); std::vector<MatePair> all(pairTotal);
     uint64_t at = 0;
@@ -747,10 +581,8 @@ int match_mates_batch(Device* dev, MatchLane* m, const MateBatchJob* jobs, size_
     HIP_TRY(hipMemcpyAsync(m->dPairs, all.data(), pairTotal * sizeof(MatePair), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->dValid, vb.data(), 8192, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(m->dCalls, mj.data(), nJobs * sizeof(MateJob), hipMemcpyHostToDevice, st));
-    static bool attrSet[16] = {};
-    if (!attrSet[m->deviceId & 15]) { HIP_TRY(hipFuncSetAttribute((const void*)fs_match_mates, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MateShared))); attrSet[m->deviceId & 15] = true; }
     HIP_TRY(hipEventRecord(m->ev0, st));
-    hipLaunchKernelGGL(fs_match_mates, dim3((uint32_t)nJobs), dim3(kMateThreads), sizeof(MateShared), st, (const MateJob*)m->dCalls, (const MatePair*)m->dPairs, (const uint8_t*)m->dSeq, (const uint32_t*)m->dValid, par, m->dMateRows);
+    hipLaunchKernelGGL(fs_match_mates, dim3((uint32_t)nJobs), dim3(fsmate::kThreads), 0, st, (const MateJob*)m->dCalls, (const MatePair*)m->dPairs, (const uint8_t*)m->dSeq, (const uint32_t*)m->dValid, par, m->dMateRows, m->dHist);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev1, st));
     std::vector<MateRow> rows(pairTotal);

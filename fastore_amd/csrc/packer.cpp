@@ -462,6 +462,7 @@ MateFn Context::mateMatcherFor(uint32_t tid)
 struct Context::MateDispatcher {
     Context& c; std::mutex mx; std::condition_variable cv; std::vector<std::unique_ptr<PendingPairs>> q; bool closing = false; uint32_t inFlight = 0;
     std::vector<std::thread> workers; std::vector<fsengine::MatchLane*> lanes;
+    std::atomic<uint32_t> launches{0}, binsSent{0}, maxBins{0}; std::atomic<uint64_t> pairsSent{0}, kernelUs{0}, maxLaunchUs{0};       // (FS_TRACE)
     explicit MateDispatcher(Context& ctx) : c(ctx)
     {
         lanes.assign(2, nullptr);
@@ -473,6 +474,7 @@ struct Context::MateDispatcher {
         cv.notify_all();
         for (auto& t : workers) t.join();
         for (auto* l : lanes) if (l) fsengine::match_lane_destroy(l);
+        if (getenv("FS_TRACE")) fprintf(stderr, "[trace] mate searches: %u launches, %u bins, %llu pairs, %.1f ms of kernels, longest launch %.1f ms, most bins in a launch %u\n", launches.load(), binsSent.load(), (unsigned long long)pairsSent.load(), kernelUs.load() / 1e3, maxLaunchUs.load() / 1e3, maxBins.load());
     }
     bool push(std::unique_ptr<PendingPairs> pp)
     {
@@ -502,7 +504,7 @@ struct Context::MateDispatcher {
             std::string err;
             try {
                 fsengine::Device* dev = c.device();
-                if (!lanes[w] && fsengine::match_lane_create(dev, &lanes[w]) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
+                if (!lanes[w] && fsengine::match_lane_create(dev, &lanes[w], true) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
                 std::vector<fsengine::MateBatchJob> jobs(batch.size());
                 uint64_t nPairs = 0;
                 for (size_t j = 0; j < batch.size(); ++j) {
@@ -514,6 +516,9 @@ struct Context::MateDispatcher {
                 const double t0 = nowMs(); double kms = 0;
                 if (fsengine::match_mates_batch(dev, lanes[w], jobs.data(), jobs.size(), batch[0]->validBits.data(), batch[0]->validBits.size(), batch[0]->mp, &kms) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
                 c.matedPairs += nPairs; c.mateUs += (uint64_t)((nowMs() - t0) * 1e3); c.mateKernelUs += (uint64_t)(kms * 1e3);
+                ++launches; binsSent += (uint32_t)batch.size(); pairsSent += nPairs; kernelUs += (uint64_t)(kms * 1e3);
+                { uint64_t m = maxLaunchUs.load(); while ((uint64_t)(kms * 1e3) > m && !maxLaunchUs.compare_exchange_weak(m, (uint64_t)(kms * 1e3))) {} }
+                { uint32_t m = maxBins.load(); while ((uint32_t)batch.size() > m && !maxBins.compare_exchange_weak(m, (uint32_t)batch.size())) {} }
                 for (auto& pp : batch) emitPairsFromRows(*pp);
             } catch (const std::exception& e) { err = e.what(); }
             for (auto& pp : batch) pp->done(err.empty() ? nullptr : err.c_str());

@@ -10,6 +10,8 @@
 #include <map>
 #include <vector>
 #include <atomic>
+#include <mutex>
+#include <dlfcn.h>
 #include "../../fastore_amd/csrc/engine.h"
 #include "../../fastore_amd/csrc/ppmd_core.h"
 #include "../../fastore_amd/csrc/rc_core.h"
@@ -128,7 +130,7 @@ static void gatherQuality(uint8_t* buf, size_t inputBytes, const GatherPlan& g)
 
 // what matcher.hip computes, as a plain scalar loop over a window kept newest first (test-only stand-in)
 struct MatchLane { int unused; };
-int match_lane_create(Device*, MatchLane** out) { *out = new MatchLane(); return 0; }
+int match_lane_create(Device*, MatchLane** out, bool) { *out = new MatchLane(); return 0; }
 void match_lane_destroy(MatchLane* m) { delete m; }
 int match_lane_reserve(Device*, MatchLane*, size_t, size_t, size_t, size_t) { return 0; }
 static std::atomic<uint64_t> g_unpackWords{0}, g_unpackDiff{0};
@@ -214,6 +216,12 @@ int match_mates_batch(Device* dev, MatchLane* m, const MateBatchJob* jobs, size_
 }
 int match_mates(Device*, MatchLane*, const uint8_t* seq, size_t, const MatePair* pairs, size_t nPairs, const uint32_t* validBits, size_t, const MateParams& par, MateRow* rows, double*)
 {
+    if (const char* lib = getenv("FS_EMU_SIMT_MATES")) {              // the kernel's own body on the lock-step wave emulation (tests/emu/mates_simt.cpp) instead of the plain loop below
+        typedef int (*Fn)(const uint8_t*, const MatePair*, uint32_t, const uint32_t*, const MateParams*, MateRow*);
+        static const Fn fn = [lib]() { void* h = dlopen(lib, RTLD_NOW | RTLD_LOCAL); return h ? (Fn)dlsym(h, "simt_match_mates") : (Fn) nullptr; }();      // (the emulation keeps a set of fibers per calling thread)
+        if (!fn) return -1;
+        return fn(seq, pairs, (uint32_t)nPairs, validBits, &par, rows);
+    }
     struct Entry { uint32_t sig[4]; uint32_t pos[4]; uint32_t off, len; int32_t pair; bool live; };
     std::vector<Entry> hist;                                           // newest first; only entries that went to the front
     uint8_t idx[128]; memset(idx, 255, sizeof idx);

@@ -17,7 +17,7 @@ def simt():
     os.makedirs(os.path.dirname(out), exist_ok=True)
     # FS_EMU_DEFS: extra -D flags (kernel experiments, e.g. -DFS_WIN_PREFETCH=1) for the same tests
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU"] + os.environ.get("FS_EMU_DEFS", "").split() + ["-shared", "-fPIC", "-o", out,
-                           os.path.join(ROOT, "tests", "emu", "ppmd_simt.cpp"), os.path.join(ROOT, "tests", "emu", "simt.cpp"), os.path.join(ROOT, "tests", "emu", "qvz_host_ref.cpp")])
+                           os.path.join(ROOT, "tests", "emu", "ppmd_simt.cpp"), os.path.join(ROOT, "tests", "emu", "mates_simt.cpp"), os.path.join(ROOT, "tests", "emu", "simt.cpp"), os.path.join(ROOT, "tests", "emu", "qvz_host_ref.cpp")])
     lib = ctypes.CDLL(out)
     lib.simt_ppmd_encode.restype = ctypes.c_size_t
     lib.simt_ppmd_encode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
@@ -226,3 +226,25 @@ def test_range_coded_streams_through_the_coder_wave(simt, oracle):
     for i, (m, d) in enumerate(streams):
         want = oracle_ppmd(oracle, d) if m is None else oracle_rc(oracle, m, d)
         assert bufs[i].raw[:sizes[i]] == want, (i, m, len(d))
+
+
+@pytest.mark.parametrize("window", [None, 2, 5, 64, 100])
+def test_mate_search_kernel_body_gives_the_host_searchs_rows(simt, monkeypatch, window):
+    # fs_match_mates' body (mates_core.h: a wavefront per paired-end bin -- planes from ballots, the sets in an LDS table, candidates
+    # priced a lane each) on the emulated wave, through the product's own parity check: every pair of every standard bin of the golden
+    # paired-end library, rows against the host's search (LzCompressorPE::CompressPair, FastqCompressor.cpp:4460-4740); small histories
+    # make the ring wrap and turn over many times
+    import fastore_amd
+    from conftest import manifest, knobs_from_flags, GOLDEN
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "fastore_amd", "csrc"), "-j", "8", "emu"], stdout=subprocess.DEVNULL)
+    emu = fastore_amd.load_library(os.path.join(ROOT, "build", "libfastore_emu.so"))
+    monkeypatch.setenv("FS_EMU_SIMT_MATES", os.path.join(ROOT, "build", "libsimt_emu.so"))
+    for name, paired, flags in manifest():
+        if not paired:
+            continue
+        kn = knobs_from_flags(flags)
+        if window:
+            kn["max_pair_lz_window"] = window
+        with fastore_amd.Packer(lib=emu, device_id=0, **kn) as p:
+            pairs, differing = p.pe_matcher_check(os.path.join(GOLDEN, name + ".in"))
+        assert pairs > 1000 and differing == 0, (name, window, pairs, differing)
