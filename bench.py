@@ -278,7 +278,12 @@ def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome,
         runs, rc = [], 0
         say("leg %s: the fastore_pack e process, %d runs" % (name, cli_runs))
         for _ in range(cli_runs):
-            t = time.perf_counter(); rc = subprocess.call(cli, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); tc = time.perf_counter() - t
+            t = time.perf_counter()
+            try:
+                rc = subprocess.call(cli, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            except subprocess.TimeoutExpired:      # (a process that does not end is reported as such, not waited for)
+                rc = -9
+            tc = time.perf_counter() - t
             runs.append(round(tc, 2))
             if rc != 0:
                 break

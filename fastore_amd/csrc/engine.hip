@@ -13,6 +13,7 @@
 //   (/root/reference/fastore/fastore_pack/FastqCompressor.cpp:1055-1126, 684-699, 1199-1210) and
 //   the TEncoder<...>/PpmdEncoder calls behind them.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <sys/mman.h>
 #include <unistd.h>
 #include <stdio.h>
@@ -118,6 +119,18 @@ __device__ __noinline__ bool rc_encode_queued_out_of_line(uint32_t model, fs_gpt
     return false;                 // (the host pass of the compiler only parses this)
 #endif
 }
+// (qvz_core.h: a QVZ stream's symbols coded by the coder wave of the two-wave form with the windowed coders)
+__device__ __noinline__ void qvz_encode_queued_out_of_line(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32_t n, fs_gptr out, uint32_t cap,
+                                                           FS_LDS fsppmd::Shared* sh, FS_GLOBAL uint32_t* sizeOut, uint32_t* qTail)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    fsqvz::QvzQueue qq; qq.m.sh = sh; qq.m.qTail = *qTail; qq.m.qHeadSeen = *qTail - fsppmd::CQ_SIZE; qq.sizeOut = sizeOut;
+    (void)fsqvz::encode_stream_windowed(arena, model, in, n, out, cap, &qq);
+    *qTail = qq.m.qTail;
+#else
+    (void)arena; (void)model; (void)in; (void)n; (void)out; (void)cap; (void)sh; (void)sizeOut; (void)qTail;      // (the host pass of the compiler only parses this)
+#endif
+}
 __device__ __noinline__ uint32_t rc_serial_out_of_line(uint32_t model, fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap)
 { return fsrc::encode_model_serial(model, table, pairs, n, out, cap); }
 
@@ -131,7 +144,8 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
         if (threadIdx.x == 0) { sh.qTail = 0u; sh.qHead = 0u; sh.qStarts = 0u; sh.qOpened = 0u; }
         __syncthreads();                               // the workgroup's only barrier: from here on the waves go separate ways
         const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        if (wv == 1u) { fsppmd::coder_wave<RCWIN>((FS_LDS fsppmd::Shared*)&sh); return; }
+        // (the kernels with the windowed coders: the coder wave also owns the range coder and the QVZ arithmetic coder for the streams whose steps come through the ring)
+        if (wv == 1u) { fsppmd::coder_wave<RCWIN, typename std::conditional<RCWIN, fsqvz::WaveCoder, fsppmd::NoQvz>::type>((FS_LDS fsppmd::Shared*)&sh); return; }
     }
     // maps == nullptr: exclusive launch (no other kernel in flight), one arena per workgroup index
     uint32_t slot = blockIdx.x, xcc = 0, word = 0, bit = 0;
@@ -197,6 +211,11 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
                 else size = fsppmd::encode_member(ar, (FS_LDS fsppmd::Shared*)&sh, src, n, dst, cap, &rs);
             }
         } else if (kind == KIND_QVZ) {
+            if (TWO && RCWIN && FS_QVZ_WINDOWS) {
+                KernArgs k3 = kernargs();
+                qvz_encode_queued_out_of_line(ar, (fs_cgptr)(k->in + item.aux_off), src, n, dst, cap, (FS_LDS fsppmd::Shared*)&sh, (FS_GLOBAL uint32_t*)(k3->outSizes + it), &qTail);
+                rcQueued = true;
+            } else
             size = qvz_encode_out_of_line(ar, (fs_cgptr)(k->in + item.aux_off), src, n, dst, cap);
         } else {
             // (rc_core.h: the small alphabets' triples coded by the coder wave of the two-wave form)
@@ -1248,15 +1267,16 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         // -- the quality scores of a --reduced or --max library -- take the kernels with the windowed coders.  A lossless
         // launch (flags and letters: a few per cent of its PPMd symbols) keeps the kernels it had: with a plain length
         // threshold every launch of the BASELINE library qualified, and its step was 1-2 % longer for it.
+        // (a --lossy library's QVZ streams likewise: the same kernels put their fractions and the interval's pass on the coder wave)
         uint64_t sumRc = 0, sumPpmd = 0;
         for (const auto& it : items) {
             if (it.kind == KIND_PPMD) sumPpmd += it.in_len;
-            else if (it.kind != KIND_QVZ && it.kind - KIND_RC_BASE <= fsrc::M_A8O6) sumRc += it.in_len;
+            else if (it.kind == KIND_QVZ || it.kind - KIND_RC_BASE <= fsrc::M_A8O6) sumRc += it.in_len;
         }
         bool rcWin = sumRc >= 4096u && 4u * sumRc >= sumPpmd;
         {   // the coder wave takes the range coder's pass: worth a second wave per stream where a long range-coded stream ends the launch
             uint32_t maxRc = 0;
-            for (const auto& it : items) if (it.kind != KIND_PPMD && it.kind != KIND_QVZ && it.kind - KIND_RC_BASE <= fsrc::M_A8O6) maxRc = std::max(maxRc, it.in_len);
+            for (const auto& it : items) if (it.kind != KIND_PPMD && (it.kind == KIND_QVZ || it.kind - KIND_RC_BASE <= fsrc::M_A8O6)) maxRc = std::max(maxRc, it.in_len);
             if (rcWin && maxRc >= (256u << 10) && !getenv("FS_WAVES") && !getenv("FS_TWO_WAVE")) waves = 2u;
         }
         if (const char* rw = getenv("FS_RC_WINDOWS")) rcWin = atoi(rw) != 0;

@@ -329,7 +329,19 @@ FS_DEV void FreeUnits(Coder& m, uint32_t ptr, uint32_t NU)
 enum : uint32_t { CQ_SIZE = 256u, CQ_SERIAL = 0x80000000u, CQ_CMD = 0xFFFFFFFFu, CQ_START = 1u, CQ_END = 2u, CQ_EXIT = 3u,
                   // a range-coded stream's triples through the same ring (coder_wave<true>: the kernel with the windowed range coders).  Entry:
                   // A = cumulative frequency | (frequency & 0x3FFF) << 16 | CQ_RC ; M = total | (frequency >> 14) << 16
-                  CQ_START_RC = 4u, CQ_END_RC = 5u, CQ_END_RC_BAD = 6u, CQ_RC = 1u << 30 };
+                  CQ_START_RC = 4u, CQ_END_RC = 5u, CQ_END_RC_BAD = 6u, CQ_RC = 1u << 30,
+                  // a QVZ stream's symbols through the same ring (coder_wave<true, fsqvz::WaveCoder>, qvz_core.h).  Entry:
+                  // A = counts below the symbol (20 bits) | (its count & 0x3FF) << 20 ; M = the context's total (20 bits) | (count >> 10) << 20 | CQ_QVZ
+                  CQ_START_QVZ = 7u, CQ_END_QVZ = 8u, CQ_END_QVZ_BAD = 9u, CQ_QVZ = 1u << 31 };
+// what coder_wave does with a QVZ stream's entries: nothing, in the kernels that carry no QVZ coder on their coder wave
+struct NoQvz {
+    static constexpr bool on = false;
+    struct State {};
+    FS_DEV_M static void start(State&, fs_gptr, uint32_t) {}
+    FS_DEV_M static void prepare(uint32_t, uint32_t, uint32_t&, uint32_t&, uint32_t&, uint32_t&) {}
+    FS_DEV_M static void code(State&, uint32_t, uint32_t, uint32_t, uint32_t) {}
+    FS_DEV_M static uint32_t finish(State&) { return 0u; }
+};
 
 FS_DEV void put_byte(Coder& m, uint32_t c) { if (m.outPos < m.outCap) fs_st8(m.out + m.outPos, c); m.outPos += (m.outPos < m.outCap); }
 // (a range-coded stream's byte: its size counts on past the capacity, as rc_core.h's put does)
@@ -383,9 +395,9 @@ FS_DEV void cq_send_exit(FS_LDS Shared* sh, uint32_t qTail)
 FS_DEV void cq_push(Coder&, uint32_t, uint32_t) {}
 FS_DEV void cq_send_exit(FS_LDS Shared*, uint32_t) {}
 #if defined(__HIPCC__)      // (the compiler's host pass over a kernel that names the template: it must find a callable declaration)
-template <bool RC> __host__ __device__ inline void coder_wave(FS_LDS Shared*) {}
+template <bool RC, class QV = NoQvz> __host__ __device__ inline void coder_wave(FS_LDS Shared*) {}
 #else
-template <bool RC> FS_DEV void coder_wave(FS_LDS Shared*) {}
+template <bool RC, class QV = NoQvz> FS_DEV void coder_wave(FS_LDS Shared*) {}
 #endif
 #endif
 
@@ -1153,7 +1165,8 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
 // until the exit command; every wait is for the model wave, which never waits for anything but ring space.
 // RC: the wave also owns the range coder of rc_core.h (64-bit low) for the range-coded streams whose triples come through the ring
 // (fs_encode_streams2_w); the kernel every lossless launch takes instantiates coder_wave<false> and carries none of it.
-template <bool RC> FS_DEV void coder_wave(FS_LDS Shared* sh)
+// QV: what the wave does with a QVZ stream's entries (fsqvz::WaveCoder: the arithmetic coder of arith.cpp over them; NoQvz: no such streams)
+template <bool RC, class QV = NoQvz> FS_DEV void coder_wave(FS_LDS Shared* sh)
 {
     Coder m;                                                   // only the coder's own fields are used here
     m.sh = sh; m.queued = 0; m.low = 0; m.range = 0xFFFFFFFFu; m.out = nullptr; m.outCap = 0; m.outPos = 0;
@@ -1161,6 +1174,7 @@ template <bool RC> FS_DEV void coder_wave(FS_LDS Shared* sh)
     const uint32_t lane = (uint32_t)FS_LANE();
     uint32_t head = 0, starts = 0;
     uint64_t rcLow = 0; uint32_t rcRange = 0xFFFFFFFFu; bool rcMode = false;      // (RC) the range coder of rc_core.h (64-bit low) while a range-coded stream is open
+    typename QV::State qs; bool qvMode = false;                                    // (QV) the arithmetic coder while a QVZ stream is open
     for (;;) {
         uint32_t tail;
         for (;;) { tail = FS_Q_LOAD(sh->qTail); if (tail != head) break; FS_Q_IDLE(); }
@@ -1170,8 +1184,12 @@ template <bool RC> FS_DEV void coder_wave(FS_LDS Shared* sh)
         head += n;
         FS_Q_STORE(sh->qHead, head);                            // the batch is in registers: its slots are free again
         const bool special = lane < n && (eA >> 31) != 0u;
-        uint32_t eL = 1u;
-        if (RC && lane < n && !special && (eA & CQ_RC) != 0u) {       // a range-coded stream's triple: frequency | cumulative frequency, reciprocal of the total
+        uint32_t eL = 1u, eX = 0u, eY = 0u;
+        if (QV::on && lane < n && !special && (eM & CQ_QVZ) != 0u) {          // a QVZ symbol: its two fractions of the interval, all the batch's at once
+            uint32_t a0, a1, a2, a3;
+            QV::prepare(eA, eM, a0, a1, a2, a3);
+            eA = a0; eM = a1; eX = a2; eY = a3;
+        } else if (RC && lane < n && !special && (eA & CQ_RC) != 0u) {       // a range-coded stream's triple: frequency | cumulative frequency, reciprocal of the total
             const uint32_t F = ((eA >> 16) & 0x3FFFu) | (((eM >> 16) & 3u) << 14), LO = eA & 0xFFFFu;
             const Recip rc = recip_make(eM & 0xFFFFu);
             eA = LO | (F << 16); eM = rc.mul; eL = rc.l;
@@ -1184,6 +1202,9 @@ template <bool RC> FS_DEV void coder_wave(FS_LDS Shared* sh)
         for (uint32_t i = 0; i < n;) {
             const uint64_t ahead = todo >> i;
             const uint32_t stop = ahead ? i + fs_ctz64(ahead) : n;
+            if (QV::on && qvMode) {      // arithmetic_encoder_step (arith.cpp:33-103) over the symbols [i, stop)
+                for (; i < stop; ++i) QV::code(qs, FS_UNI(fs_readlane(eA, i)), FS_UNI(fs_readlane(eM, i)), FS_UNI(fs_readlane(eX, i)), FS_UNI(fs_readlane(eY, i)));
+            }
             if (RC && rcMode) {      // RangeEncoder::EncodeFrequency (rc/RangeCoder.h:40-84) over the triples [i, stop)
                 for (; i < stop; ++i) {
                     const uint32_t FL = FS_UNI(fs_readlane(eA, i)), M0 = FS_UNI(fs_readlane(eM, i)), L0 = FS_UNI(fs_readlane(eL, i));
@@ -1237,6 +1258,17 @@ template <bool RC> FS_DEV void coder_wave(FS_LDS Shared* sh)
                 for (int k = 0; k < 8; k++) { rc_put(m, (uint32_t)(rcLow >> 56)); rcLow <<= 8; }      // TEncoder::End: eight flush bytes
                 if (sizeOut) *sizeOut = M == CQ_END_RC ? m.outPos : 0xFFFFFFFFu;
                 rcMode = false;
+            } else if (QV::on && M == CQ_START_QVZ) {
+                FS_LDS uint32_t* box = sh->qBox[starts & 1u];
+                const uint64_t o = (uint64_t)FS_LDS_RD(box[0]) | ((uint64_t)FS_LDS_RD(box[1]) << 32), z = (uint64_t)FS_LDS_RD(box[3]) | ((uint64_t)FS_LDS_RD(box[4]) << 32);
+                sizeOut = (FS_GLOBAL uint32_t*)(uintptr_t)z;
+                QV::start(qs, (fs_gptr)(uintptr_t)o, FS_LDS_RD(box[2]));
+                ++starts; FS_Q_STORE(sh->qStarts, starts);
+                qvMode = true;
+            } else if (QV::on && (M == CQ_END_QVZ || M == CQ_END_QVZ_BAD)) {
+                const uint32_t size = QV::finish(qs);
+                if (sizeOut) *sizeOut = M == CQ_END_QVZ ? size : 0xFFFFFFFFu;
+                qvMode = false;
             } else return;                                      // CQ_EXIT
         }
     }

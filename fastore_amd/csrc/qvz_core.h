@@ -16,6 +16,7 @@
 // program order is all the ordering the updates need.
 #pragma once
 #include "wave.h"
+#include "ppmd_core.h"      // (the two-wave kernels: a stream's symbols through the PPMd walk's ring to the coder wave)
 
 namespace fsqvz {
 
@@ -231,7 +232,39 @@ FS_DEV void q_code(BitOut& o, uint32_t& l, uint32_t& u, uint32_t& scale3, QFrac 
     }
 }
 
-FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32_t n, fs_gptr out, uint32_t cap)
+// The coder wave's side of a QVZ stream in the two-wave kernels (fsppmd::coder_wave<true, WaveCoder>): a batch's entries become fractions --
+// all lanes at once --, then the interval passes over them in stream order.
+struct WaveCoder {
+    static constexpr bool on = true;
+    struct State { BitOut o; uint32_t l, u, scale3; };
+    FS_DEV_M static void start(State& s, fs_gptr out, uint32_t cap) { s.o.out = out; s.o.pos = 0; s.o.cap = cap; s.o.acc = 0; s.o.nb = 0; s.o.overflow = 0; s.l = 0; s.u = (1u << M_BITS) - 1u; s.scale3 = 0; }
+    FS_DEV_M static void prepare(uint32_t A, uint32_t M, uint32_t& bLo, uint32_t& bHi, uint32_t& uLo, uint32_t& uHi)
+    {
+        const uint32_t cumLo = A & 0xFFFFFu, cnt = ((A >> 20) & 0x3FFu) | (((M >> 20) & 0x3FFu) << 10), total = M & 0xFFFFFu;
+        const QFrac fB = q_frac(cumLo, total ? total : 1u), fU = q_frac(cumLo + cnt, total ? total : 1u);
+        bLo = fB.lo; bHi = fB.hi; uLo = fU.lo; uHi = fU.hi;
+    }
+    FS_DEV_M static void code(State& s, uint32_t bLo, uint32_t bHi, uint32_t uLo, uint32_t uHi)
+    {
+        QFrac b, u; b.lo = bLo; b.hi = bHi; u.lo = uLo; u.hi = uHi;
+        s.l = FS_UNI(s.l); s.u = FS_UNI(s.u); s.scale3 = FS_UNI(s.scale3);
+        q_code(s.o, s.l, s.u, s.scale3, b, u);
+    }
+    FS_DEV_M static uint32_t finish(State& s)      // encoder_last_step: the msb of the tag, the pending bits, the other m-1 tag bits, zero padding
+    {
+        const uint32_t msbShift = M_BITS - 1, clearMask = (1u << msbShift) - 1u;
+        put_decided(s.o, s.l >> msbShift, s.scale3);
+        put_bits(s.o, s.l & clearMask, M_BITS - 1);
+        if (s.o.nb) put_bits(s.o, 0u, 8u - s.o.nb);
+        FS_WAVE_SYNC();
+        return s.o.overflow ? 0xFFFFFFFFu : s.o.pos;
+    }
+};
+// q (the two-wave kernel fs_encode_streams2_w): the symbols' counts go to the coder wave through the PPMd walk's ring instead of being coded
+// here -- fetching and updating the contexts of window k + 1 then runs beside the fractions and the interval's pass over window k; the
+// stream's size is written by the coder wave, the return value is 0
+struct QvzQueue { fsppmd::Coder m; FS_GLOBAL uint32_t* sizeOut; };
+FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32_t n, fs_gptr out, uint32_t cap, QvzQueue* q = nullptr)
 {
     const FS_GLOBAL ModelHeader* hdr = (const FS_GLOBAL ModelHeader*)model;
     const uint32_t nCtx = FS_UNI(hdr->n_ctx), words = FS_UNI(hdr->image_words);
@@ -245,6 +278,19 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr i
     uint32_t l = 0, u = (1u << M_BITS) - 1u, scale3 = 0, bad = 0;
     const uint32_t msbShift = M_BITS - 1, clearMask = (1u << msbShift) - 1u;
     const FS_GLOBAL uint32_t* sym = (const FS_GLOBAL uint32_t*)in;
+    if (q) {      // hand the coder wave this stream's output buffer (the mailbox protocol of fsppmd::encode_member)
+        fsppmd::Coder& m = q->m;
+        const uint32_t s = FS_UNI(FS_LDS_RD(m.sh->qOpened));
+        if (s >= 2u) fsppmd::cq_wait_starts(m, s - 1u);
+        if (FS_LANE() == 0) {
+            const uint64_t o64 = (uint64_t)(uintptr_t)out, z = (uint64_t)(uintptr_t)q->sizeOut;
+            FS_LDS uint32_t* box = m.sh->qBox[s & 1u];
+            box[0] = (uint32_t)o64; box[1] = (uint32_t)(o64 >> 32); box[2] = cap; box[3] = (uint32_t)z; box[4] = (uint32_t)(z >> 32);
+            m.sh->qOpened = s + 1u;
+        }
+        FS_WAVE_SYNC();
+        fsppmd::cq_push(m, fsppmd::CQ_CMD, fsppmd::CQ_START_QVZ);
+    }
     for (uint32_t k = 0; k < n && !bad;) {
         const uint32_t left = FS_UNI(n - k), W = left < 64u ? left : 64u;
         const bool valid = lane < W;
@@ -295,14 +341,18 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr i
         // the window's updates: every context is there once
         if (lane < take) { blk[0] = total + STEP; blk[1u + x] = cnt + STEP; }
         FS_EMU_MEET();
-        // every position's two fractions, all lanes at once
-        const uint32_t tsafe = total ? total : 1u;
-        const QFrac fB = q_frac(cumLo, tsafe), fU = q_frac(cumLo + cnt, tsafe);
-        l = FS_UNI(l); u = FS_UNI(u); scale3 = FS_UNI(scale3);
-        for (uint32_t i = 0; i < take; ++i) {
-            QFrac b1, u1;
-            b1.lo = FS_UNI(fs_readlane(fB.lo, i)); b1.hi = FS_UNI(fs_readlane(fB.hi, i)); u1.lo = FS_UNI(fs_readlane(fU.lo, i)); u1.hi = FS_UNI(fs_readlane(fU.hi, i));
-            q_code(o, l, u, scale3, b1, u1);
+        if (q) {
+            if (take) fsppmd::cq_push_lanes(q->m, cumLo | ((cnt & 0x3FFu) << 20), total | ((cnt >> 10) << 20) | fsppmd::CQ_QVZ, take);
+        } else {
+            // every position's two fractions, all lanes at once
+            const uint32_t tsafe = total ? total : 1u;
+            const QFrac fB = q_frac(cumLo, tsafe), fU = q_frac(cumLo + cnt, tsafe);
+            l = FS_UNI(l); u = FS_UNI(u); scale3 = FS_UNI(scale3);
+            for (uint32_t i = 0; i < take; ++i) {
+                QFrac b1, u1;
+                b1.lo = FS_UNI(fs_readlane(fB.lo, i)); b1.hi = FS_UNI(fs_readlane(fB.hi, i)); u1.lo = FS_UNI(fs_readlane(fU.lo, i)); u1.hi = FS_UNI(fs_readlane(fU.hi, i));
+                q_code(o, l, u, scale3, b1, u1);
+            }
         }
         k += take;
         if (take < W) {          // symbol k: shares its context, is due for a rescale, or is malformed -- the one-symbol step
@@ -313,10 +363,12 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr i
             if (x1 >= card1 || card1 > MAX_CARD) { bad = 1; break; }
             uint32_t c1, n1, t1;
             model_step(stat + off1, card1, x1, c1, n1, t1);
-            q_code(o, l, u, scale3, q_frac(c1, t1), q_frac(c1 + n1, t1));
+            if (q) fsppmd::cq_push(q->m, c1 | ((n1 & 0x3FFu) << 20), t1 | ((n1 >> 10) << 20) | fsppmd::CQ_QVZ);
+            else q_code(o, l, u, scale3, q_frac(c1, t1), q_frac(c1 + n1, t1));
             ++k;
         }
     }
+    if (q) { fsppmd::cq_push(q->m, fsppmd::CQ_CMD, bad ? fsppmd::CQ_END_QVZ_BAD : fsppmd::CQ_END_QVZ); return 0u; }
     const uint32_t msbL = l >> msbShift;
     put_decided(o, msbL, scale3);
     put_bits(o, l & clearMask, M_BITS - 1);
@@ -324,6 +376,8 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr i
     FS_WAVE_SYNC();
     return (o.overflow || bad) ? 0xFFFFFFFFu : o.pos;
 }
+#else
+struct WaveCoder : fsppmd::NoQvz {};      // (the compiler's host pass over the kernels names it)
 #endif
 
 }  // namespace fsqvz

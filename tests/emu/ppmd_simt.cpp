@@ -72,6 +72,19 @@ extern "C" long simt_qvz_encode(int form, const uint8_t* blob, const uint8_t* sy
 {
     uint8_t* arena = (uint8_t*)aligned_alloc(64, (arenaBytes + 4096 + 63) & ~63ull);
     uint32_t size = 0;
+    if (form == 2) {      // the two-wave kernel's form: the symbols' counts through the ring, fractions and the interval's pass on the coder wave
+        fsppmd::Shared* sh = new fsppmd::Shared;
+        sh->qTail = sh->qHead = 0; sh->qStarts = sh->qOpened = 0;
+        size = 0xFFFFFFFEu;
+        simt::run_waves(2, [&](int wave, int) {
+            if (wave == 1) { fsppmd::coder_wave<true, fsqvz::WaveCoder>(sh); return; }
+            fsqvz::QvzQueue qq; qq.m.sh = sh; qq.m.qTail = 0; qq.m.qHeadSeen = 0u - fsppmd::CQ_SIZE; qq.sizeOut = &size;
+            (void)fsqvz::encode_stream_windowed(arena, blob, syms, (uint32_t)n, out, (uint32_t)cap, &qq);
+            fsppmd::cq_send_exit(sh, qq.m.qTail);
+        });
+        delete sh; free(arena);
+        return size == 0xFFFFFFFFu ? -1 : (long)size;
+    }
     simt::run_waves(1, [&](int, int) {
         const uint32_t s = form ? fsqvz::encode_stream_windowed(arena, blob, syms, (uint32_t)n, out, (uint32_t)cap) : fsqvz::encode_stream(arena, blob, syms, (uint32_t)n, out, (uint32_t)cap);
         if (simt::lane() == 0) size = s;

@@ -168,8 +168,9 @@ def qvz_case(rng, n_ctx, n, max_card, same_ctx_runs):
 
 
 def test_qvz_forms_on_the_emulated_wave_reproduce_the_one_lane_coder(simt):
-    # the QVZ coder's 64-lane forms -- the one the kernels run (a symbol per trip, lanes over the context's counts) and the windowed
-    # form (64 symbols per step; not in the kernels yet) -- against the same header compiled for one lane
+    # the QVZ coder's 64-lane forms -- a symbol per trip with the lanes over the context's counts (0), 64 symbols per step (1: the one-wave
+    # kernels), and that with the fractions and the interval's pass on the coder wave of the two-wave kernels (2: the symbols' counts through
+    # the PPMd walk's ring, two emulated wavefronts) -- against the same header compiled for one lane
     for f in (simt.simt_qvz_encode, simt.host_qvz_encode):
         f.restype = ctypes.c_long
     simt.simt_qvz_encode.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
@@ -181,7 +182,7 @@ def test_qvz_forms_on_the_emulated_wave_reproduce_the_one_lane_coder(simt):
         cap = 4 * n + 64
         want = ctypes.create_string_buffer(cap); nw = simt.host_qvz_encode(blob, syms + b"\0" * 256, n, arena, want, cap)
         assert nw >= 0
-        for form in (0, 1):
+        for form in (0, 1, 2):
             got = ctypes.create_string_buffer(cap); ng = simt.simt_qvz_encode(form, blob, syms + b"\0" * 256, n, arena, got, cap)
             assert ng == nw and got.raw[:ng] == want.raw[:nw], (form, n_ctx, n)
     # a symbol outside its context's alphabet gives the stream up in every form
@@ -189,7 +190,7 @@ def test_qvz_forms_on_the_emulated_wave_reproduce_the_one_lane_coder(simt):
     bad = bytearray(syms); bad[4 * 300 + 3] = 200
     out = ctypes.create_string_buffer(4096)
     assert simt.host_qvz_encode(blob, bytes(bad) + b"\0" * 256, 500, arena, out, 4096) == -1
-    for form in (0, 1):
+    for form in (0, 1, 2):
         assert simt.simt_qvz_encode(form, blob, bytes(bad) + b"\0" * 256, 500, arena, out, 4096) == -1
 
 
