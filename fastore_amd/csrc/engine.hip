@@ -61,14 +61,25 @@ struct SlotMap { unsigned long long w[kBitmapWords]; };
 
 __device__ __forceinline__ uint32_t xcc_id()
 { uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & (kXcc - 1u); }
+// the compute unit a wavefront runs on, inside its XCD: cu_id (bits 8-11), sh_id (12), se_id (13-15) of HW_ID
+__device__ __forceinline__ uint32_t cu_in_xcc()
+{ uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v)); return (v >> 8) & 0xFFu; }
+// A compute unit to itself for the streams that end a launch.  A long stream beside twelve others a compute unit runs a third slower than
+// alone (0.175 against 0.134 us per symbol; profiles/r02_cc_long_stream_beside_short_ones.txt: it is the company on the compute unit, not the
+// device's load), and the step IS its longest stream.  So the workgroup that takes a stream of isolateLen symbols or more marks its compute
+// unit as held (a table in device memory beside the slot maps: a tag per compute unit, the count of holds, their limit); every workgroup
+// of every launch looks at its compute unit's tag before it takes its next stream and sleeps while another holds it; the holder lets go
+// when its stream ends.  Nobody gives a stream back and nobody waits while working, so every wait ends; holds are limited to a quarter of
+// the compute units, the other streams keep the rest.
+enum : uint32_t { kHoldCount = kXcc * 256u, kHoldLimit = kHoldCount + 1u, kHoldWords = kHoldCount + 2u };
 
 // The launch parameters stay in the kernarg segment and are re-read (scalar loads, a few per stream) where they are
 // needed: held in SGPRs for the whole kernel they were ~20 registers of pressure on the coder loops, which already
 // spill scalars to vector lanes.  `kernargs()` hides the pointer from the optimiser so that the loads are not hoisted.
 struct EncodeArgs {
     const StreamItem* items; const uint32_t* order; const uint8_t* in; uint8_t* out; uint32_t* outSizes; uint32_t* restarts;
-    uint8_t* arenas; uint64_t arenaStride; uint32_t* queueHead; SlotMap* maps; unsigned long long* unused0;
-    uint32_t nItems, longLen, slotsPerXcc, pad;
+    uint8_t* arenas; uint64_t arenaStride; uint32_t* queueHead; SlotMap* maps; uint32_t* cuHold;
+    uint32_t nItems, longLen, slotsPerXcc, isolateLen;
 };
 typedef const __attribute__((address_space(4))) EncodeArgs* KernArgs;
 __device__ __forceinline__ KernArgs kernargs()
@@ -107,28 +118,28 @@ __device__ __noinline__ uint32_t qvz_encode_out_of_line(fs_gptr arena, fs_cgptr 
 // (and the one-symbol loop of the range coders: with every coder but PPMd out of line no kernel spills a vector register any more --
 // the one-wave kernel had 19-37 spilled and 64-136 bytes of scratch per lane all round; 3 072 equal PPMd streams 6.60 -> 6.86 G symbols/s)
 __device__ __noinline__ bool rc_encode_queued_out_of_line(uint32_t model, fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap,
-                                                          FS_LDS fsppmd::Shared* sh, FS_GLOBAL uint32_t* sizeOut, uint32_t* qTail)
+                                                          FS_LDS fsppmd::Shared* sh, FS_GLOBAL uint32_t* sizeOut, uint32_t* qTail, uint32_t prio)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    fsrc::RcQueue rq; rq.m.sh = sh; rq.m.qTail = *qTail; rq.m.qHeadSeen = *qTail - fsppmd::CQ_SIZE; rq.sizeOut = sizeOut;
+    fsrc::RcQueue rq; rq.m.sh = sh; rq.m.qTail = *qTail; rq.m.qHeadSeen = *qTail - fsppmd::CQ_SIZE; rq.sizeOut = sizeOut; rq.prio = prio;
     const bool done = fsrc::encode_model_queued(model, table, pairs, n, out, cap, &rq);
     *qTail = rq.m.qTail;
     return done;
 #else
-    (void)model; (void)table; (void)pairs; (void)n; (void)out; (void)cap; (void)sh; (void)sizeOut; (void)qTail;
+    (void)model; (void)table; (void)pairs; (void)n; (void)out; (void)cap; (void)sh; (void)sizeOut; (void)qTail; (void)prio;
     return false;                 // (the host pass of the compiler only parses this)
 #endif
 }
 // (qvz_core.h: a QVZ stream's symbols coded by the coder wave of the two-wave form with the windowed coders)
 __device__ __noinline__ void qvz_encode_queued_out_of_line(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32_t n, fs_gptr out, uint32_t cap,
-                                                           FS_LDS fsppmd::Shared* sh, FS_GLOBAL uint32_t* sizeOut, uint32_t* qTail)
+                                                           FS_LDS fsppmd::Shared* sh, FS_GLOBAL uint32_t* sizeOut, uint32_t* qTail, uint32_t prio)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    fsqvz::QvzQueue qq; qq.m.sh = sh; qq.m.qTail = *qTail; qq.m.qHeadSeen = *qTail - fsppmd::CQ_SIZE; qq.sizeOut = sizeOut;
+    fsqvz::QvzQueue qq; qq.m.sh = sh; qq.m.qTail = *qTail; qq.m.qHeadSeen = *qTail - fsppmd::CQ_SIZE; qq.sizeOut = sizeOut; qq.prio = prio;
     (void)fsqvz::encode_stream_windowed(arena, model, in, n, out, cap, &qq);
     *qTail = qq.m.qTail;
 #else
-    (void)arena; (void)model; (void)in; (void)n; (void)out; (void)cap; (void)sh; (void)sizeOut; (void)qTail;      // (the host pass of the compiler only parses this)
+    (void)arena; (void)model; (void)in; (void)n; (void)out; (void)cap; (void)sh; (void)sizeOut; (void)qTail; (void)prio;      // (the host pass of the compiler only parses this)
 #endif
 }
 __device__ __noinline__ uint32_t rc_serial_out_of_line(uint32_t model, fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap)
@@ -182,8 +193,20 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
     }
     uint8_t* arena;
     { KernArgs k = kernargs(); arena = k->arenas + (uint64_t)slot * k->arenaStride; }
+    const bool isolating = useMaps && kernargs()->isolateLen != 0u;
+    const uint32_t cuIx = isolating ? xcc_id() * 256u + cu_in_xcc() : 0u, holdTag = slot + 1u;
     for (;;) {
         KernArgs k = kernargs();
+        if (isolating) {                              // another workgroup has this compute unit to itself: not a stream more until it lets go
+            uint32_t* hold = k->cuHold + cuIx;
+            for (;;) {
+                uint32_t h = 0;
+                if (threadIdx.x == 0) h = __hip_atomic_load(hold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+                if (h == 0u || h == holdTag) break;
+                __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
+            }
+        }
         uint32_t q = 0;
         if (threadIdx.x == 0) q = atomicAdd(k->queueHead, 1u);
         q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
@@ -196,9 +219,22 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
         // The launch ends when its longest stream ends, so the long PPMd streams get issue priority over the thousands
         // of short ones that share their SIMD (priority only reorders issue among resident waves).
         const uint32_t longLen = k->longLen;
-        if (kind == KIND_PPMD && n >= longLen) __builtin_amdgcn_s_setprio(3);
-        else if (kind == KIND_PPMD && 2u * n >= longLen) __builtin_amdgcn_s_setprio(2);
+        // (a --reduced or --lossy launch: its long streams are range-coded or QVZ ones, and their pass runs on the coder wave, which takes the priority over)
+        const bool weighs = kind == KIND_PPMD || kind == KIND_QVZ || kind - KIND_RC_BASE <= fsrc::M_A8O6;
+        const uint32_t prio = weighs && n >= longLen ? 3u : (weighs && 2u * n >= longLen ? 2u : 0u);
+        if (prio == 3u) __builtin_amdgcn_s_setprio(3);
+        else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(0);
+        bool holding = false;
+        if (isolating && weighs && n >= k->isolateLen) {      // a stream that ends the launch: the compute unit to itself, if it is free and holds are to be had
+            uint32_t got = 0;
+            if (threadIdx.x == 0) {
+                uint32_t* tab = k->cuHold;
+                if (atomicAdd(tab + kHoldCount, 1u) < __hip_atomic_load(tab + kHoldLimit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && atomicCAS(tab + cuIx, 0u, holdTag) == 0u) got = 1u;
+                else atomicSub(tab + kHoldCount, 1u);
+            }
+            holding = __builtin_amdgcn_readfirstlane((int)got) != 0;
+        }
         fs_cgptr src = (fs_cgptr)(k->in + item.in_off);
         fs_gptr dst = (fs_gptr)(k->out + item.out_off);
         fs_gptr ar = (fs_gptr)arena;
@@ -213,7 +249,7 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
         } else if (kind == KIND_QVZ) {
             if (TWO && RCWIN && FS_QVZ_WINDOWS) {
                 KernArgs k3 = kernargs();
-                qvz_encode_queued_out_of_line(ar, (fs_cgptr)(k->in + item.aux_off), src, n, dst, cap, (FS_LDS fsppmd::Shared*)&sh, (FS_GLOBAL uint32_t*)(k3->outSizes + it), &qTail);
+                qvz_encode_queued_out_of_line(ar, (fs_cgptr)(k->in + item.aux_off), src, n, dst, cap, (FS_LDS fsppmd::Shared*)&sh, (FS_GLOBAL uint32_t*)(k3->outSizes + it), &qTail, prio);
                 rcQueued = true;
             } else
             size = qvz_encode_out_of_line(ar, (fs_cgptr)(k->in + item.aux_off), src, n, dst, cap);
@@ -221,7 +257,7 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
             // (rc_core.h: the small alphabets' triples coded by the coder wave of the two-wave form)
             if (TWO && RCWIN && kind - KIND_RC_BASE <= fsrc::M_A8O6) {
                 KernArgs k3 = kernargs();
-                rcQueued = rc_encode_queued_out_of_line(kind - KIND_RC_BASE, ar, src, n, dst, cap, (FS_LDS fsppmd::Shared*)&sh, (FS_GLOBAL uint32_t*)(k3->outSizes + it), &qTail);
+                rcQueued = rc_encode_queued_out_of_line(kind - KIND_RC_BASE, ar, src, n, dst, cap, (FS_LDS fsppmd::Shared*)&sh, (FS_GLOBAL uint32_t*)(k3->outSizes + it), &qTail, prio);
             } else
             size = RCWIN ? rc_encode_out_of_line(kind - KIND_RC_BASE, ar, src, n, dst, cap) : rc_serial_out_of_line(kind - KIND_RC_BASE, ar, src, n, dst, cap);
         }
@@ -251,6 +287,7 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
             if (t == 0u) v = rs;
             k2->restarts[16u * it + t] = v;
         }
+        if (holding && threadIdx.x == 0) { KernArgs k4 = kernargs(); __hip_atomic_store(k4->cuHold + cuIx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicSub(k4->cuHold + kHoldCount, 1u); }
         FS_WAVE_SYNC();
     }
     if (TWO) fsppmd::cq_send_exit((FS_LDS fsppmd::Shared*)&sh, qTail);
@@ -797,6 +834,7 @@ struct Pool {
     uint8_t* arenas = nullptr; uint64_t bytes = 0, slotStride = 0;
     uint32_t slotsPerXcc = 0;
     SlotMap* maps = nullptr;
+    uint32_t* cuHold = nullptr;       // kHoldWords words behind the maps: a tag per compute unit, the holds' count, their limit
     std::shared_mutex gate;
     std::mutex m; int lanes = 0;
 };
@@ -911,8 +949,13 @@ int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size
     lap("properties, memory info");
     if ((e = hipMalloc((void**)&pool->arenas, pool->bytes)) != hipSuccess) return fail("hipMalloc(arenas)", e);
     lap("hipMalloc of the arena pool");
-    if ((e = hipMalloc((void**)&pool->maps, sizeof(SlotMap) * kXcc)) != hipSuccess) return fail("hipMalloc(slot maps)", e);
-    if ((e = hipMemset(pool->maps, 0, sizeof(SlotMap) * kXcc)) != hipSuccess) return fail("hipMemset(slot maps)", e);
+    if ((e = hipMalloc((void**)&pool->maps, sizeof(SlotMap) * kXcc + kHoldWords * 4u)) != hipSuccess) return fail("hipMalloc(slot maps)", e);
+    if ((e = hipMemset(pool->maps, 0, sizeof(SlotMap) * kXcc + kHoldWords * 4u)) != hipSuccess) return fail("hipMemset(slot maps)", e);
+    {   // the compute units' hold table lives behind the slot maps; FS_ISOLATE_MAX: how many compute units may be held at a time (default: a quarter)
+        pool->cuHold = (uint32_t*)(pool->maps + kXcc);
+        const uint32_t limit = getenv("FS_ISOLATE_MAX") ? (uint32_t)std::max(0, atoi(getenv("FS_ISOLATE_MAX"))) : 64u;
+        if ((e = hipMemcpy(pool->cuHold + kHoldLimit, &limit, 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(hold limit)", e);
+    }
     lap("slot maps (first memset: code objects)");
     if (lane_init(dev, err, errLen) != 0) { (void)hipFree(pool->arenas); (void)hipFree(pool->maps); delete pool; delete dev; return -1; }
     pool->lanes = 1;
@@ -1165,7 +1208,12 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     const uint64_t stride = exclusive ? ((need + kGuard) + 4095ull) & ~4095ull : pool->slotStride;
     uint32_t maxLen = 0;
     for (const auto& it : items) if (it.kind == KIND_PPMD) maxLen = std::max(maxLen, it.in_len);
-    const uint32_t longLen = std::max(1u, maxLen / 2);                     // "long" = at least half of the longest PPMd stream
+    uint32_t maxAny = maxLen;                                                 // (... or QVZ stream, or stream of a range coder with a windowed form: what a --lossy / --reduced launch ends with)
+    for (const auto& it : items) if (it.kind == KIND_QVZ || (it.kind != KIND_PPMD && it.kind - KIND_RC_BASE <= fsrc::M_A8O6)) maxAny = std::max(maxAny, it.in_len);
+    const uint32_t longLen = std::max(1u, maxAny / 2);                     // "long" = at least half of the longest such stream
+    // ... and a long stream of a million symbols or more gets a compute unit to itself (FS_ISOLATE=0: nobody does; FS_ISOLATE_MIN: the million)
+    static const uint32_t isolateMin = getenv("FS_ISOLATE") && atoi(getenv("FS_ISOLATE")) == 0 ? 0u : (getenv("FS_ISOLATE_MIN") ? (uint32_t)std::max(1, atoi(getenv("FS_ISOLATE_MIN"))) : (1u << 20));
+    const uint32_t isolateLen = isolateMin ? std::max(isolateMin, longLen) : 0u;
 
     const uint32_t nRest = nItems;
     HIP_TRY(hipMemcpyAsync(dev->dIn, input, inputBytes, hipMemcpyHostToDevice, st));
@@ -1253,8 +1301,8 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         EncodeArgs ka;
         ka.items = (const StreamItem*)dev->dItems; ka.order = (const uint32_t*)dev->dOrder; ka.in = (const uint8_t*)dev->dIn; ka.out = (uint8_t*)dev->dScratch;
         ka.outSizes = (uint32_t*)dev->dSizes; ka.restarts = (uint32_t*)dev->dRestarts; ka.arenas = pool->arenas; ka.arenaStride = stride;
-        ka.queueHead = (uint32_t*)dev->queueHead; ka.maps = exclusive ? (SlotMap*)nullptr : pool->maps; ka.unused0 = nullptr;
-        ka.nItems = nRest; ka.longLen = longLen; ka.slotsPerXcc = pool->slotsPerXcc; ka.pad = 0;
+        ka.queueHead = (uint32_t*)dev->queueHead; ka.maps = exclusive ? (SlotMap*)nullptr : pool->maps; ka.cuHold = pool->cuHold;
+        ka.nItems = nRest; ka.longLen = longLen; ka.slotsPerXcc = pool->slotsPerXcc; ka.isolateLen = isolateLen;
         // two-wave form where the step is bound by its longest PPMd stream (the coder runs beside the model walk: ~1.4x per
         // stream, but a stream takes two wave slots); FS_TWO_WAVE=0/1 forces either form
         // (FS_WAVES=1/2 forces a form; FS_TWO_WAVE=0/1 is the older switch.  Round 3's three-wave form -- windows prepared by a

@@ -1656,12 +1656,16 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             }
             // what a bin brings into a lane's staging buffer, roughly: its quality scores (packed, or a byte / a pair each), its
             // read ids, the descriptors and the small streams -- a fresh context sizes its lanes' pinned buffers by it up front
-            stageEstimate.assign(nb, 0);
+            stageEstimate.assign(nb, 0); std::vector<uint64_t> archEstimate(nb, 0);
             for (uint32_t k = 0; k < nb; ++k) {
                 const BinInfo& bi = libs[work[first + k].lib]->bf.bins().at(work[first + k].sig);
                 const uint32_t qmk = archives[work[first + k].lib].cfg.quaParams.method;
                 const uint64_t q = packedQ ? bi.totalQuaSize + (qmk == MET_QVZ ? bi.totalRawDnaSize / 4u * 4u + (2ull << 20) : 0ull) : (qmk == MET_NONE ? bi.totalRawDnaSize : (qmk == MET_QVZ ? 4ull : 2ull) * bi.totalRawDnaSize);
                 stageEstimate[k] = q + (packedH ? bi.totalHeadSize : 2ull * bi.totalRawHeadSize) + 80ull * bi.totalRecordsCount;
+                // (what the bin's block will roughly weigh: a quarter of what is staged -- PPMd on quality scores --, but QVZ's scores go up as a
+                // word each and come back as a fraction of a bit: the estimate made a --lossy pack reserve 1.5 GB for a 0.4 GB archive and
+                // pay 140 ms a step for making and dropping the pages)
+                archEstimate[k] = (qmk == MET_QVZ ? bi.totalRawDnaSize / 16u : q / 4u) + ((packedH ? bi.totalHeadSize : 2ull * bi.totalRawHeadSize) + 80ull * bi.totalRecordsCount) / 4u;
             }
             if (seqBase[nb] > 0xFFFFFFF0ull || headBase[nb] > 0xFFFFFFF0ull || recBase[nb] > 0xFFFFFFF0ull) throw std::runtime_error("batch exceeds 4 GiB");
             batch.seq.resize(seqBase[nb]); batch.recs.resize(recBase[nb]);
@@ -1686,7 +1690,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             // batch's staged bytes (PPMd on quality scores) -- their page-cache pages are made while the device works
             std::vector<uint64_t> aheadBytes(nLibs, 0);
             if (lastBatchNow) {
-                for (uint32_t k = 0; k < nb; ++k) aheadBytes[work[first + k].lib] += stageEstimate[k] / 4;
+                for (uint32_t k = 0; k < nb; ++k) aheadBytes[work[first + k].lib] += archEstimate[k];
                 for (size_t l = 0; l < nLibs; ++l) {
                     Lib& L = *libs[l];
                     std::lock_guard<std::mutex> lk(L.awMx);                      // (block 0's thread may be putting its block at the archive's head right now)

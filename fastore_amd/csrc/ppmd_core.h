@@ -76,7 +76,7 @@ struct Shared {
     // of them, used alternately: the model wave may only rewrite box (s & 1) for its stream number s once the coder wave has
     // READ that box for stream s - 2, which qStarts (streams the coder wave has opened) tells it -- qHead alone does not:
     // the coder wave frees a batch's ring slots when the batch is in its registers, before it has worked the batch off.
-    uint32_t qBox[2][5];          // qOutLo, qOutHi, qOutCap, qSizeLo, qSizeHi
+    uint32_t qBox[2][6];          // qOutLo, qOutHi, qOutCap, qSizeLo, qSizeHi, the stream's issue priority (range-coded and QVZ streams: their pass is the coder wave's)
     uint32_t qStarts;             // written by the coder wave
     uint32_t qOpened;             // model wave only: streams it has started in this workgroup
     // (LDS per workgroup stays below 12 800 bytes: above it a compute unit holds eleven one-wave workgroups instead of twelve --
@@ -388,6 +388,15 @@ FS_DEV void cq_push_lanes(Coder& m, uint32_t A, uint32_t M, uint32_t L)
 }
 // the coder wave has opened every stream up to number `upTo` - 1 (their mailboxes are read)
 FS_DEV void cq_wait_starts(Coder& m, uint32_t upTo) { while ((int32_t)(FS_Q_LOAD(m.sh->qStarts) - upTo) < 0) FS_Q_IDLE(); }
+// the coder wave takes over the issue priority of the stream whose pass it runs (the launch ends with its longest stream)
+FS_DEV void cq_take_priority(uint32_t p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (p >= 3u) __builtin_amdgcn_s_setprio(3); else if (p == 2u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#else
+    (void)p;
+#endif
+}
 // the model wave's last word: the coder wave returns
 FS_DEV void cq_send_exit(FS_LDS Shared* sh, uint32_t qTail)
 { Coder m; m.sh = sh; m.qTail = qTail; m.qHeadSeen = qTail - CQ_SIZE; cq_push(m, CQ_CMD, CQ_EXIT); }
@@ -1252,23 +1261,25 @@ template <bool RC, class QV = NoQvz> FS_DEV void coder_wave(FS_LDS Shared* sh)
                 FS_LDS uint32_t* box = sh->qBox[starts & 1u];
                 const uint64_t o = (uint64_t)FS_LDS_RD(box[0]) | ((uint64_t)FS_LDS_RD(box[1]) << 32), z = (uint64_t)FS_LDS_RD(box[3]) | ((uint64_t)FS_LDS_RD(box[4]) << 32);
                 m.out = (fs_gptr)(uintptr_t)o; sizeOut = (FS_GLOBAL uint32_t*)(uintptr_t)z; m.outCap = FS_LDS_RD(box[2]); m.outPos = 0;
+                cq_take_priority(FS_LDS_RD(box[5]));
                 ++starts; FS_Q_STORE(sh->qStarts, starts);
                 rcLow = 0; rcRange = 0xFFFFFFFFu; rcMode = true;
             } else if (RC && (M == CQ_END_RC || M == CQ_END_RC_BAD)) {
                 for (int k = 0; k < 8; k++) { rc_put(m, (uint32_t)(rcLow >> 56)); rcLow <<= 8; }      // TEncoder::End: eight flush bytes
                 if (sizeOut) *sizeOut = M == CQ_END_RC ? m.outPos : 0xFFFFFFFFu;
-                rcMode = false;
+                rcMode = false; cq_take_priority(0u);
             } else if (QV::on && M == CQ_START_QVZ) {
                 FS_LDS uint32_t* box = sh->qBox[starts & 1u];
                 const uint64_t o = (uint64_t)FS_LDS_RD(box[0]) | ((uint64_t)FS_LDS_RD(box[1]) << 32), z = (uint64_t)FS_LDS_RD(box[3]) | ((uint64_t)FS_LDS_RD(box[4]) << 32);
                 sizeOut = (FS_GLOBAL uint32_t*)(uintptr_t)z;
                 QV::start(qs, (fs_gptr)(uintptr_t)o, FS_LDS_RD(box[2]));
+                cq_take_priority(FS_LDS_RD(box[5]));
                 ++starts; FS_Q_STORE(sh->qStarts, starts);
                 qvMode = true;
             } else if (QV::on && (M == CQ_END_QVZ || M == CQ_END_QVZ_BAD)) {
                 const uint32_t size = QV::finish(qs);
                 if (sizeOut) *sizeOut = M == CQ_END_QVZ ? size : 0xFFFFFFFFu;
-                qvMode = false;
+                qvMode = false; cq_take_priority(0u);
             } else return;                                      // CQ_EXIT
         }
     }

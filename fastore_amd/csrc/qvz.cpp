@@ -1,5 +1,7 @@
 // QVZ codebook parsing and quality symbolisation (see qvz.h for the reference map).
 #include "qvz.h"
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <stdexcept>
 #include "qvz_core.h"
@@ -121,6 +123,7 @@ void QvzModel::parse(BitReader& r)
     std::vector<fsqvz::Desc> desc(nCtx);
     uint32_t words = 0;
     for (uint32_t i = 0; i < nCtx; ++i) { desc[i].off = words; desc[i].card = card[i]; words += 1u + card[i]; }
+    if (getenv("FS_TRACE")) { uint32_t mx = 0; for (uint32_t i = 0; i < nCtx; ++i) mx = std::max<uint32_t>(mx, card[i]); fprintf(stderr, "[trace] QVZ codebook: %u columns, %u contexts, %u words of counts, %.1f symbols a context, at most %u\n", columns, nCtx, words, nCtx ? (double)(words - nCtx) / nCtx : 0.0, mx); }
     fsqvz::ModelHeader h{nCtx, words, columns, 0};
     blob.assign(fsqvz::blob_bytes(nCtx, words), 0);
     memcpy(blob.data(), &h, sizeof h);

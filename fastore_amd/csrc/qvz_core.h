@@ -263,7 +263,7 @@ struct WaveCoder {
 // q (the two-wave kernel fs_encode_streams2_w): the symbols' counts go to the coder wave through the PPMd walk's ring instead of being coded
 // here -- fetching and updating the contexts of window k + 1 then runs beside the fractions and the interval's pass over window k; the
 // stream's size is written by the coder wave, the return value is 0
-struct QvzQueue { fsppmd::Coder m; FS_GLOBAL uint32_t* sizeOut; };
+struct QvzQueue { fsppmd::Coder m; FS_GLOBAL uint32_t* sizeOut; uint32_t prio = 0; };
 FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr in, uint32_t n, fs_gptr out, uint32_t cap, QvzQueue* q = nullptr)
 {
     const FS_GLOBAL ModelHeader* hdr = (const FS_GLOBAL ModelHeader*)model;
@@ -285,7 +285,7 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr arena, fs_cgptr model, fs_cgptr i
         if (FS_LANE() == 0) {
             const uint64_t o64 = (uint64_t)(uintptr_t)out, z = (uint64_t)(uintptr_t)q->sizeOut;
             FS_LDS uint32_t* box = m.sh->qBox[s & 1u];
-            box[0] = (uint32_t)o64; box[1] = (uint32_t)(o64 >> 32); box[2] = cap; box[3] = (uint32_t)z; box[4] = (uint32_t)(z >> 32);
+            box[0] = (uint32_t)o64; box[1] = (uint32_t)(o64 >> 32); box[2] = cap; box[3] = (uint32_t)z; box[4] = (uint32_t)(z >> 32); box[5] = q->prio;
             m.sh->qOpened = s + 1u;
         }
         FS_WAVE_SYNC();

@@ -161,7 +161,7 @@ FS_DEV uint32_t encode_stream(fs_gptr table /*16-byte aligned, table_bytes()*/, 
 // through the PPMd walk's ring (ppmd_core.h: coder_wave<true>) instead of being coded here -- the model side of window k + 1
 // then runs beside the range coder's pass over window k; the stream's size is written by the coder wave, the return value
 // is 0.  Measured on a lone 7 M-symbol <8,6> stream: 0.110 -> 0.084 us per symbol (profiles/r04_rc_on_coder_wave.txt).
-struct RcQueue { fsppmd::Coder m; FS_GLOBAL uint32_t* sizeOut; };
+struct RcQueue { fsppmd::Coder m; FS_GLOBAL uint32_t* sizeOut; uint32_t prio = 0; };
 template <int BITS, int ORDER, bool ADV, int CTXBITS>
 FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n, fs_gptr out, uint32_t cap, RcQueue* q = nullptr)
 {
@@ -191,7 +191,7 @@ FS_DEV uint32_t encode_stream_windowed(fs_gptr table, fs_cgptr pairs, uint32_t n
         if (FS_LANE() == 0) {
             const uint64_t o = (uint64_t)(uintptr_t)out, z = (uint64_t)(uintptr_t)q->sizeOut;
             FS_LDS uint32_t* box = m.sh->qBox[s & 1u];
-            box[0] = (uint32_t)o; box[1] = (uint32_t)(o >> 32); box[2] = cap; box[3] = (uint32_t)z; box[4] = (uint32_t)(z >> 32);
+            box[0] = (uint32_t)o; box[1] = (uint32_t)(o >> 32); box[2] = cap; box[3] = (uint32_t)z; box[4] = (uint32_t)(z >> 32); box[5] = q->prio;
             m.sh->qOpened = s + 1u;
         }
         FS_WAVE_SYNC();
