@@ -62,7 +62,7 @@ def sh(cmd, **kw):
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, **kw)
 
 
-_T0 = time.time()
+_T0 = float(os.environ.get("FS_BENCH_T0", "0")) or time.time()       # (a leg's child process counts on from the parent's start)
 
 
 def say(msg):
@@ -182,7 +182,41 @@ def reference_pack(binned, refp, cores, pe, sweep=False):
     return nt, tn, others
 
 
-def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome, steps, warmup, cores, lib, cli_runs, traffic_file=None, sweep=False, quality=None):
+def cli_phase(fastore_amd, args, work, name, reads, paired, genome, cores, cli_runs, quality=None):
+    """wall time of the `fastore_pack e` PROCESS (start -> exit: HIP init, arena allocation, reading .b*, writing .c*), page
+    cache warm.  Run for every leg BEFORE this process touches the device: a user's fastore_pack does not share the GPU with a second
+    process that holds sixteen hardware queues of its own -- with one, the child's sixteen are more than the device maps at once, launches
+    of the child wait for queues that never come free and the process stands still (found in round 4: profiles/r04_cli_two_processes.txt).
+    The archive of the last run is kept for the comparison with the in-process one."""
+    quality = quality or QUALITY
+    binned, fastq_bytes = prepare_library(work, name, reads, 150, genome, 8, min(cores, 32), paired, quality)
+    pe = ["-z"] if paired else []
+    cli_out = os.path.join(work, "cli_" + name)
+    cli = [fastore_amd.PACK_CLI, "e", "-i" + binned, "-o" + cli_out] + PACK_FLAGS + pe
+    runs, rc = [], 0
+    say("leg %s: the fastore_pack e process, %d runs" % (name, cli_runs))
+    for _ in range(cli_runs):
+        t = time.perf_counter()
+        try:
+            # (FS_BENCH_CLI_LOG=<file>: the process's stderr -- its FS_TRACE timeline, a watchdog's report -- is kept)
+            with open(os.environ["FS_BENCH_CLI_LOG"], "ab") if os.environ.get("FS_BENCH_CLI_LOG") else open(os.devnull, "wb") as errf:
+                rc = subprocess.call(cli, stdout=subprocess.DEVNULL, stderr=errf, timeout=int(os.environ.get("FS_BENCH_CLI_TIMEOUT", "240")))
+        except subprocess.TimeoutExpired:      # (a process that does not end is reported as such, not waited for)
+            rc = -9
+        tc = time.perf_counter() - t
+        runs.append(round(tc, 2))
+        if rc != 0:
+            break
+    med = sorted(runs)[len(runs) // 2]
+    # (the first processes on a fresh box wait 1-4 s in their first large device allocation while the driver clears
+    # memory it has not handed out before -- profiles/r02_mm_alloc_sizes.txt: not the program's time --, hence
+    # several runs; the MEDIAN is quoted, all runs are listed)
+    return {"value": round(fastq_bytes / med / 1e6, 2) if rc == 0 else None, "unit": "MB/s", "seconds": med, "runs_seconds": runs,
+            "what": "SURVEY 8(d)'s metric: the fastore_pack e PROCESS, start -> exit (HIP init, arena allocation, .b* in, .c* out), page cache warm; run before this process opened the device",
+            "best_seconds": min(runs), "quoted": "median of the runs", "exit": rc, "command": "fastore_pack e " + " ".join(PACK_FLAGS + pe), "_archive": cli_out}
+
+
+def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome, steps, warmup, cores, lib, cli, traffic_file=None, sweep=False, quality=None):
     """ONE library on ONE GPU: K timed pack steps (file to file), then the CLI process, the reference on the same library,
     and the block-for-block comparison.  Returns the leg's result dict."""
     L = 150
@@ -269,33 +303,11 @@ def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome,
     }
     device_name = packer.device_name
     pe = ["-z"] if paired else []
-    packer.close()                 # the CLI process is measured on a device that is otherwise idle, as a user would run it
-    if cli_runs > 0:
-        # wall time of the `fastore_pack e` PROCESS (start -> exit: HIP init, arena allocation, reading .b*,
-        # writing .c*), page cache warm -- beside the warm in-process number above
-        cli_out = os.path.join(work, "cli_" + name)
-        cli = [fastore_amd.PACK_CLI, "e", "-i" + binned, "-o" + cli_out] + PACK_FLAGS + pe
-        runs, rc = [], 0
-        say("leg %s: the fastore_pack e process, %d runs" % (name, cli_runs))
-        for _ in range(cli_runs):
-            t = time.perf_counter()
-            try:
-                rc = subprocess.call(cli, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
-            except subprocess.TimeoutExpired:      # (a process that does not end is reported as such, not waited for)
-                rc = -9
-            tc = time.perf_counter() - t
-            runs.append(round(tc, 2))
-            if rc != 0:
-                break
-        med = sorted(runs)[len(runs) // 2]
-        # (the first processes on a fresh box wait 1-4 s in their first large device allocation while the driver clears
-        # memory it has not handed out before -- profiles/r02_mm_alloc_sizes.txt: not the program's time --, hence
-        # several runs; the MEDIAN is quoted, all runs are listed)
-        res["process"] = {"value": round(fastq_bytes / med / 1e6, 2) if rc == 0 else None, "unit": "MB/s", "seconds": med, "runs_seconds": runs,
-                          "what": "SURVEY 8(d)'s metric: the fastore_pack e PROCESS, start -> exit (HIP init, arena allocation, .b* in, .c* out), page cache warm",
-                          "best_seconds": min(runs), "quoted": "median of the runs", "exit": rc,
-                          "archive_identical_to_the_in_process_one": bool(rc == 0 and all(open(cli_out + e, "rb").read() == open(out + e, "rb").read() for e in (".cdata", ".cmeta"))),
-                          "command": "fastore_pack e " + " ".join(PACK_FLAGS + pe)}
+    packer.close()
+    if cli:       # (cli_phase's result: the process was timed before this one opened the device; its archive against the in-process one)
+        cli_out = cli.pop("_archive")
+        cli["archive_identical_to_the_in_process_one"] = bool(cli["exit"] == 0 and all(open(cli_out + e, "rb").read() == open(out + e, "rb").read() for e in (".cdata", ".cmeta")))
+        res["process"] = cli
         drop(cli_out)
     if not args.no_cpu_baseline:
         refp = os.path.join(work, "ref_" + name)
@@ -347,6 +359,8 @@ def main():
     ap.add_argument("--replicas", "--weak", dest="replicas", action="store_true", help="--gpus N: every rank packs the whole library into its own archive")
     ap.add_argument("--quality", choices=sorted(QUALITY_MODES), default="lossless",
                     help="mode of the library as scripts/fastore_compress.sh names it: lossless (-q0, the BASELINE metric's), reduced (8-bin scores, -q2 -C: configs[3]'s), lossy (QVZ, -q3 -C)")
+    ap.add_argument("--in-process", action="store_true", help="N = 1: measure the legs in THIS process instead of in a process each (profiler runs: a process that has opened the device must not start another)")
+    ap.add_argument("--one-leg", default=None, help=argparse.SUPPRESS)      # (internal: this process measures ONE leg, described by the JSON file named, and prints its result)
     args = ap.parse_args()
     global QUALITY
     QUALITY = args.quality
@@ -380,6 +394,13 @@ def main():
     alt = os.environ.get("FASTORE_AMD_LIB")
     lib = fastore_amd.load_library(alt) if alt else None
 
+    if args.one_leg:
+        spec = json.load(open(args.one_leg))
+        leg, dev = one_library_leg(fastore_amd, torch, args, args.work, spec["name"], spec["reads"], spec["paired"], spec["genome"], spec["steps"], spec["warmup"], cores, lib,
+                                   spec.get("cli"), spec.get("traffic_file"), spec.get("sweep", False), quality=spec["quality"])
+        print(json.dumps({"leg": leg, "device": dev}), flush=True)
+        return
+
     if world == 1:
         # ---- the N = 1 line: the headline leg (configs[1], or --paired) and, beside it, the paired-end, --reduced and --lossy legs ----
         if args.gpus != 1:
@@ -412,8 +433,38 @@ def main():
         if "main" in errs:
             raise SystemExit("could not prepare the headline library: " + errs["main"])
         traffic_file = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json") if (args.reads == 10_000_000 and not args.paired and QUALITY == "lossless") else None
-        leg, dev = one_library_leg(fastore_amd, torch, args, args.work, name, args.reads, args.paired, genome, args.steps, args.warmup, cores, lib,
-                                   0 if args.no_cli else 3, traffic_file, args.cpu_sweep)
+        # every leg's fastore_pack e PROCESS first, while this process has not opened the device (cli_phase says why)
+        clis = {}
+        if not args.no_cli:
+            for key, lname, lreads, lpaired, lgenome, lq in legs:
+                if key not in errs:
+                    try:
+                        clis[key] = cli_phase(fastore_amd, args, args.work, lname, lreads, lpaired, lgenome, cores, 3, quality=lq)
+                    except Exception as e:      # noqa: BLE001
+                        say("leg %s: the process could not be timed: %s" % (lname, e))
+        # Every leg is measured by a process of its own, one after the other; this process never opens the device.  (Two reasons: a leg that
+        # stands still is ended at its time limit and reported in its place instead of taking the line with it; and a process that HAS
+        # packed keeps its hardware queues, which a second process on the same device must not meet -- cli_phase.)
+        def leg_process(key, lname, lreads, lpaired, lgenome, lq, steps, warmup, limit_s, traffic=None, sweep=False):
+            if args.in_process:
+                return one_library_leg(fastore_amd, torch, args, args.work, lname, lreads, lpaired, lgenome, steps, warmup, cores, lib, clis.get(key), traffic, sweep, quality=lq)
+            spec = {"name": lname, "reads": lreads, "paired": lpaired, "genome": lgenome, "quality": lq, "steps": steps, "warmup": warmup, "cli": clis.get(key),
+                    "traffic_file": traffic, "sweep": sweep}
+            sf = os.path.join(args.work, "leg_%s.json" % key)
+            json.dump(spec, open(sf, "w"))
+            env = dict(os.environ, FS_BENCH_T0=repr(_T0))
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--one-leg", sf], stdout=subprocess.PIPE, env=env, timeout=limit_s)
+            except subprocess.TimeoutExpired:
+                raise RuntimeError("the leg's process did not end within %d s and was stopped" % limit_s)
+            if r.returncode != 0:
+                raise RuntimeError("the leg's process ended with code %d" % r.returncode)
+            out = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            return out["leg"], out["device"]
+        ref_s = 0 if args.no_cpu_baseline else 120 + (240 if args.cpu_t1 else 0) + (200 if args.cpu_sweep else 0)
+        leg, dev = leg_process("main", name, args.reads, args.paired, genome, QUALITY, args.steps, args.warmup, 240 + 12 * (args.steps + args.warmup) * max(1, args.reads // 10_000_000 * (3 if args.paired else 1)) + ref_s,
+                               traffic_file, args.cpu_sweep)
+
         res = {"metric": "fastore_pack compressed MB/s (input FASTQ)", "value": leg["value"], "unit": "MB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                "value_is": "the K timed warm steps (file to file, context made); `process` holds SURVEY 8(d)'s process start -> exit, `speedup` both ratios"}
@@ -429,7 +480,7 @@ def main():
                 continue
             ls, lw = (max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))) if key == "pe" else (max(1, min(args.steps, 3)), 1)
             try:
-                lleg, _ = one_library_leg(fastore_amd, torch, args, args.work, lname, lreads, lpaired, lgenome, ls, lw, cores, lib, 0 if args.no_cli else 3, quality=lq)
+                lleg, _ = leg_process(key, lname, lreads, lpaired, lgenome, lq, ls, lw, (420 if key == "pe" else 240) + ref_s)
             except Exception as e:          # noqa: BLE001
                 lleg = {"error": "%s: %s" % (type(e).__name__, e)}
             res[key] = lleg

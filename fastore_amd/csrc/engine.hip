@@ -71,7 +71,8 @@ __device__ __forceinline__ uint32_t cu_in_xcc()
 // of every launch looks at its compute unit's tag before it takes its next stream and sleeps while another holds it; the holder lets go
 // when its stream ends.  Nobody gives a stream back and nobody waits while working, so every wait ends; holds are limited to a quarter of
 // the compute units, the other streams keep the rest.
-enum : uint32_t { kHoldCount = kXcc * 256u, kHoldLimit = kHoldCount + 1u, kHoldWords = kHoldCount + 2u };
+enum : uint32_t { kHoldCount = kXcc * 256u, kHoldLimit = kHoldCount + 1u, kSlotState = kHoldCount + 2u, kHoldWords = kSlotState + kXcc * kBitmapWords * 64u };
+// (behind the holds: a word per arena slot saying where its workgroup stands -- phase | stream's place in the queue << 4 | launch << 24 --, read by lane_debug when a batch stands still)
 
 // The launch parameters stay in the kernarg segment and are re-read (scalar loads, a few per stream) where they are
 // needed: held in SGPRs for the whole kernel they were ~20 registers of pressure on the coder loops, which already
@@ -193,11 +194,16 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
     }
     uint8_t* arena;
     { KernArgs k = kernargs(); arena = k->arenas + (uint64_t)slot * k->arenaStride; }
+    uint32_t* slotState = useMaps ? kernargs()->cuHold + kSlotState + (xcc * kBitmapWords * 64u + word * 64u + bit) : nullptr;
+    const uint32_t launchTag = (uint32_t)(((uintptr_t)kernargs()->queueHead >> 6) & 0xFFu) << 24;
+    #define FS_SLOT_AT(phase, q_) do { if (slotState && threadIdx.x == 0) __hip_atomic_store(slotState, (uint32_t)(phase) | ((uint32_t)(q_) << 4) | launchTag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+    FS_SLOT_AT(1, 0);
     const bool isolating = useMaps && kernargs()->isolateLen != 0u;
     const uint32_t cuIx = isolating ? xcc_id() * 256u + cu_in_xcc() : 0u, holdTag = slot + 1u;
     for (;;) {
         KernArgs k = kernargs();
         if (isolating) {                              // another workgroup has this compute unit to itself: not a stream more until it lets go
+            FS_SLOT_AT(2, 0);
             uint32_t* hold = k->cuHold + cuIx;
             for (;;) {
                 uint32_t h = 0;
@@ -211,6 +217,7 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
         if (threadIdx.x == 0) q = atomicAdd(k->queueHead, 1u);
         q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
         if (q >= k->nItems) break;                    // every wave reaches this exit: the queue is finite
+        FS_SLOT_AT(3, q & 0xFFFFFu);
         const uint32_t it = k->order[q];
         const StreamItem item = k->items[it];
         const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.kind);
@@ -287,10 +294,14 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
             if (t == 0u) v = rs;
             k2->restarts[16u * it + t] = v;
         }
+        FS_SLOT_AT(4, q & 0xFFFFFu);
         if (holding && threadIdx.x == 0) { KernArgs k4 = kernargs(); __hip_atomic_store(k4->cuHold + cuIx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicSub(k4->cuHold + kHoldCount, 1u); }
         FS_WAVE_SYNC();
     }
+    FS_SLOT_AT(5, 0);
     if (TWO) fsppmd::cq_send_exit((FS_LDS fsppmd::Shared*)&sh, qTail);
+    FS_SLOT_AT(6, 0);
+    #undef FS_SLOT_AT
     if (useMaps && threadIdx.x == 0) {
         KernArgs k = kernargs();
         // the wave's stores have left for the XCD's L2 before the slot shows as free; its next owner runs on this XCD
@@ -1017,6 +1028,32 @@ int lane_debug(Device* dev, char* out, size_t outLen)
     if (!ok) { snprintf(out, outLen, "device read failed"); return -1; }
     int n = snprintf(out, outLen, "queue head %u, stream %s; arena slots taken per XCD:", head, hipStreamQuery((hipStream_t)dev->stream) == hipSuccess ? "idle" : "busy");
     for (uint32_t x = 0; x < kXcc && n > 0 && (size_t)n < outLen; ++x) { int c = 0; for (uint32_t w = 0; w < kBitmapWords; ++w) c += __builtin_popcountll(maps[x].w[w]); n += snprintf(out + n, outLen - n, " %d", c); }
+    {   // where the workgroups that hold the slots stand (all launches of the pool; printed once per call)
+        std::vector<uint32_t> st(kXcc * kBitmapWords * 64u, 0u), holds(kHoldWords - (kXcc * kBitmapWords * 64u), 0u);
+        hipStream_t s2 = nullptr;
+        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess) {
+            bool ok2 = hipMemcpyAsync(st.data(), dev->pool->cuHold + kSlotState, st.size() * 4u, hipMemcpyDeviceToHost, s2) == hipSuccess;
+            ok2 = ok2 && hipMemcpyAsync(holds.data(), dev->pool->cuHold, holds.size() * 4u, hipMemcpyDeviceToHost, s2) == hipSuccess;
+            ok2 = ok2 && hipStreamSynchronize(s2) == hipSuccess;
+            (void)hipStreamDestroy(s2);
+            if (ok2) {
+                uint32_t phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t held = 0;
+                for (uint32_t x = 0; x < kXcc; ++x) for (uint32_t w = 0; w < kBitmapWords; ++w) for (uint32_t b = 0; b < 64u; ++b)
+                    if ((maps[x].w[w] >> b) & 1ull) ++phase[st[x * kBitmapWords * 64u + w * 64u + b] & 7u];
+                for (uint32_t c = 0; c < kHoldCount; ++c) held += holds[c] != 0u;
+                if (n > 0 && (size_t)n < outLen) n += snprintf(out + n, outLen - n, "; slot holders by phase (1 start, 2 waiting for a held compute unit, 3 in a stream, 4 stream done, 5 leaving, 6 left):");
+                for (uint32_t ph = 0; ph < 8u && n > 0 && (size_t)n < outLen; ++ph) n += snprintf(out + n, outLen - n, " %u", phase[ph]);
+                if (n > 0 && (size_t)n < outLen) n += snprintf(out + n, outLen - n, "; compute units held %u (count word %u)", held, holds[kHoldCount]);
+                // the streams the slot holders of THIS launch are in
+                const uint32_t tag = (uint32_t)(((uintptr_t)dev->queueHead >> 6) & 0xFFu);
+                uint32_t shown = 0;
+                for (uint32_t x = 0; x < kXcc; ++x) for (uint32_t w = 0; w < kBitmapWords; ++w) for (uint32_t b = 0; b < 64u; ++b) {
+                    const uint32_t v = st[x * kBitmapWords * 64u + w * 64u + b];
+                    if (((maps[x].w[w] >> b) & 1ull) && (v >> 24) == tag && (v & 7u) == 3u && shown < 12u && n > 0 && (size_t)n < outLen) { n += snprintf(out + n, outLen - n, "%s%u", shown ? "," : "; this launch's workgroups are in streams (queue places) ", (v >> 4) & 0xFFFFFu); ++shown; }
+                }
+            }
+        }
+    }
     return 0;
 }
 

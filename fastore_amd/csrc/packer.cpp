@@ -1199,7 +1199,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 bool dn; { std::lock_guard<std::mutex> g(S.mx); dn = S.done; }
                 if (dn || S.tSubmit <= 0 || S.lane < 0) continue;
                 fprintf(stderr, "[watchdog] slice %u device state: ", si); fflush(stderr);
-                char buf[512] = {0};
+                char buf[1536] = {0};
                 fsengine::lane_debug(lanes[(uint32_t)S.lane], buf, sizeof buf);
                 fprintf(stderr, "%s\n", buf); fflush(stderr);
             }
@@ -1261,11 +1261,11 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             // Later the coder kernels hold every register of the chip (3 waves x 168 VGPRs per SIMD): a search would wait
             // for coder waves to leave, longer than the host scan takes, so the lighter bins keep the host scan.
             encs[tid]->setMatcher(k < matcherBins ? matcherFor(tid) : MatchFn());
-            // (paired-end bins: fs_match_mates gives the host search's rows pair for pair -- 61 404 of 61 404 on a fresh library, every
-            // golden bin at five history sizes -- but it is NOT the product's default: one 1024-thread workgroup per bin on the two
-            // streams the searches share, every alignment priced in full (the host's search gives up on an alignment at the
-            // first base past the best cost so far): the 6 M-pair step took 45 s with it against 2.6 s without,
-            // profiles/r03_device_mate_search.txt.  FS_DEVICE_MATES=1 switches it on.)
+            // (paired-end bins: fs_match_mates gives the host search's rows pair for pair -- every golden bin at five history sizes, the
+            // 195 266 pairs of a fresh library -- but it is NOT the product's default: its 1024-thread workgroups need a compute unit to
+            // themselves and the coder kernels hold every one for most of the step, so the 6 M-pair step takes 3.06 s with the device's
+            // searches (batched, FS_DEVICE_MATES=2) against 2.53 s with the host's: profiles/r04_mate_search_forms.txt.  FS_DEVICE_MATES=1: bin by
+            // bin, the host thread waiting -- round 3's hand-over.)
             encs[tid]->setMateMatcher(k < matcherBins && deviceMates ? mateMatcherFor(tid) : MateFn());
             // the streams that hold bases (HardReads, LettersX, Match, ...: fsdev::EmitOp) and the LZ ids' run-length coding: written
             // by the device from the ops the walk leaves (FS_DEVICE_EMIT=0: by the walk itself, A/B runs)

@@ -178,6 +178,31 @@ def test_qvz_device_matches_oracle_many_ragged_blocks(packer, oracle):
             assert g == oracle_qvz(oracle, footer, lens, quals)
 
 
+def test_qvz_long_block_through_the_coder_wave_and_through_one_wave(monkeypatch, oracle):
+    # a block long enough for the launch to take the two-wave kernel: the symbols' counts go through the ring, fractions and the interval's pass run on
+    # the coder wave (fsppmd::coder_wave<true, fsqvz::WaveCoder>); beside it short blocks (other streams of the same launch share the coder wave one
+    # after the other) and the same launch forced onto the one-wave kernel: all equal to the oracle's coder (arith.cpp / qv_compressor.cpp restated)
+    import fastore_amd
+    rng = np.random.default_rng(909)
+    footer = qvz_inputs.qvz_footer()
+    reads = 5200                                             # x 60 scores = 312 000 symbols >= 256 Ki
+    lens = np.full(reads, 60, dtype=np.uint32)
+    walk = np.clip(38 + np.cumsum(rng.integers(-1, 2, reads * 60)) % 30, 2, 41).astype(np.uint8)
+    blocks = [(lens, walk)]
+    for i in range(20):
+        l2 = rng.integers(1, 61, int(rng.integers(1, 300))).astype(np.uint32)
+        blocks.append((l2, rng.integers(2, 42, int(l2.sum())).astype(np.uint8)))
+    want = [oracle_qvz(oracle, footer, l, q) for l, q in blocks]
+    for waves in (None, "1", "2"):
+        if waves is None:
+            monkeypatch.delenv("FS_WAVES", raising=False)
+        else:
+            monkeypatch.setenv("FS_WAVES", waves)
+        with fastore_amd.Packer(device_id=0) as p:
+            got = p.qvz_encode(footer, blocks)
+        assert got == want, waves
+
+
 def test_qvz_device_rejects_bad_input(packer):
     import fastore_amd
     f = qvz_inputs.qvz_footer()
