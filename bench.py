@@ -254,8 +254,9 @@ def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome,
     packer.reset_stats()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    each = []
     for _ in range(steps):
-        step()
+        t1 = time.perf_counter(); step(); each.append(round((time.perf_counter() - t1) * 1e3, 1))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     say("leg %s: %.1f ms per step" % (name, dt / steps * 1e3))
@@ -274,7 +275,7 @@ def one_library_leg(fastore_amd, torch, args, work, name, reads, paired, genome,
         rf["traffic_source"] = os.path.relpath(traffic_file, ROOT)
     rf["ppmd_symbols_per_s_whole_job"] = round(st["ppmd_symbols"] / dt, 1)
     res = {
-        "value": round(fastq_bytes * steps / dt / 1e6, 2), "unit": "MB/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2),
+        "value": round(fastq_bytes * steps / dt / 1e6, 2), "unit": "MB/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2), "each_step_ms": each,
         "config": {"workload": "ONE library of %.1f M x %d bp %s synthetic FASTQ (gen_fastq genome %d bp, seed 8), --%s, C1 profile%s"
                                % (reads / 1e6, L, "PE pairs" if paired else "SE reads", genome, quality, "" if not paired else " (configs[2] scaled by %g)" % (reads / 100e6)),
                    "fastq_bytes": fastq_bytes, "pack_flags": " ".join(PACK_FLAGS + (["-z"] if paired else [])), "parallelism": "1 GPU"},

@@ -207,7 +207,15 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
             uint32_t* hold = k->cuHold + cuIx;
             for (;;) {
                 uint32_t h = 0;
-                if (threadIdx.x == 0) h = __hip_atomic_load(hold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (threadIdx.x == 0) {
+                    h = __hip_atomic_load(hold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // (... unless the launch's next stream is itself a long one: a long stream that waits for a worker costs the launch its
+                    // whole length -- seen as steps of 2.0 instead of 1.35 s when most of a launch's workgroups slept --, company costs a tenth)
+                    if (h != 0u && h != holdTag) {
+                        const uint32_t qh = __hip_atomic_load(k->queueHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (qh < k->nItems && k->items[k->order[qh]].in_len >= k->isolateLen) h = 0u;
+                    }
+                }
                 h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
                 if (h == 0u || h == holdTag) break;
                 __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
@@ -1248,8 +1256,9 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     uint32_t maxAny = maxLen;                                                 // (... or QVZ stream, or stream of a range coder with a windowed form: what a --lossy / --reduced launch ends with)
     for (const auto& it : items) if (it.kind == KIND_QVZ || (it.kind != KIND_PPMD && it.kind - KIND_RC_BASE <= fsrc::M_A8O6)) maxAny = std::max(maxAny, it.in_len);
     const uint32_t longLen = std::max(1u, maxAny / 2);                     // "long" = at least half of the longest such stream
-    // ... and a long stream of a million symbols or more gets a compute unit to itself (FS_ISOLATE=0: nobody does; FS_ISOLATE_MIN: the million)
-    static const uint32_t isolateMin = getenv("FS_ISOLATE") && atoi(getenv("FS_ISOLATE")) == 0 ? 0u : (getenv("FS_ISOLATE_MIN") ? (uint32_t)std::max(1, atoi(getenv("FS_ISOLATE_MIN"))) : (1u << 20));
+    // ... and, with FS_ISOLATE=1, a long stream of a million symbols or more (FS_ISOLATE_MIN) gets a compute unit to itself.  Not the default: over
+    // twenty steps the typical step gained 1-5 %, but one step in seven took 2.0 instead of 1.4 s (profiles/r04_compute_unit_isolation.txt)
+    static const uint32_t isolateMin = !(getenv("FS_ISOLATE") && atoi(getenv("FS_ISOLATE")) != 0) ? 0u : (getenv("FS_ISOLATE_MIN") ? (uint32_t)std::max(1, atoi(getenv("FS_ISOLATE_MIN"))) : (1u << 20));
     const uint32_t isolateLen = isolateMin ? std::max(isolateMin, longLen) : 0u;
 
     const uint32_t nRest = nItems;
@@ -1353,15 +1362,23 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         // launch (flags and letters: a few per cent of its PPMd symbols) keeps the kernels it had: with a plain length
         // threshold every launch of the BASELINE library qualified, and its step was 1-2 % longer for it.
         // (a --lossy library's QVZ streams likewise: the same kernels put their fractions and the interval's pass on the coder wave)
+        // (The streams the emission kernels write -- match bits, letters -- do not count: what the host knows of them is the ROOM they were
+        // given, a multiple of their size, and with it every lossless launch took these kernels: found in the round's kernel statistics.)
+        std::vector<uint8_t> roomOnly(items.size(), 0);
+        if (emit && emit->n_jobs) {
+            const EmitJob* ej = (const EmitJob*)(input + emit->jobs_off);
+            for (uint32_t j = 0; j < emit->n_jobs; ++j) for (uint32_t ch = 0; ch <= ECH_COUNT; ++ch) if (ej[j].item[ch] < items.size()) roomOnly[ej[j].item[ch]] = 1;
+        }
         uint64_t sumRc = 0, sumPpmd = 0;
-        for (const auto& it : items) {
+        for (size_t i = 0; i < items.size(); ++i) {
+            const auto& it = items[i];
             if (it.kind == KIND_PPMD) sumPpmd += it.in_len;
-            else if (it.kind == KIND_QVZ || it.kind - KIND_RC_BASE <= fsrc::M_A8O6) sumRc += it.in_len;
+            else if (!roomOnly[i] && (it.kind == KIND_QVZ || it.kind - KIND_RC_BASE <= fsrc::M_A8O6)) sumRc += it.in_len;
         }
         bool rcWin = sumRc >= 4096u && 4u * sumRc >= sumPpmd;
         {   // the coder wave takes the range coder's pass: worth a second wave per stream where a long range-coded stream ends the launch
             uint32_t maxRc = 0;
-            for (const auto& it : items) if (it.kind != KIND_PPMD && (it.kind == KIND_QVZ || it.kind - KIND_RC_BASE <= fsrc::M_A8O6)) maxRc = std::max(maxRc, it.in_len);
+            for (size_t i = 0; i < items.size(); ++i) { const auto& it = items[i]; if (!roomOnly[i] && it.kind != KIND_PPMD && (it.kind == KIND_QVZ || it.kind - KIND_RC_BASE <= fsrc::M_A8O6)) maxRc = std::max(maxRc, it.in_len); }
             if (rcWin && maxRc >= (256u << 10) && !getenv("FS_WAVES") && !getenv("FS_TWO_WAVE")) waves = 2u;
         }
         if (const char* rw = getenv("FS_RC_WINDOWS")) rcWin = atoi(rw) != 0;
