@@ -52,81 +52,112 @@ FS_EMIT_FN uint32_t channel_b(const fsdev::EmitOp& op)
 FS_EMIT_FN uint32_t unit_l(uint32_t ch) { return (ch == fsdev::ECH_HARD || ch == fsdev::ECH_HARD_PE) ? 1u : 2u; }
 FS_EMIT_FN bool is_bit_channel(uint32_t ch) { return ch == fsdev::ECH_MATCH_BITS || ch == fsdev::ECH_CMATCH_BITS || ch == fsdev::ECH_MATCH_BITS_PE; }
 
+// How an op reads the bin's bytes.  Direct: a load per byte (the host emulation).  Win16: sixteen bytes a load, kept in registers while the walk
+// stays inside them (the kernels: a thread that walks its record byte by byte touches every cache line sixty-four times, and between its
+// visits the lines of the other 63 threads of its wavefront push it out -- fs_emit_write moved 36 GB a step for 3 GB of bases,
+// profiles/r04_hbm_traffic.json).  `base` must be 16-byte aligned for Win16 (the bins' bases and contigs are placed so).
+struct Direct {
+    const uint8_t* base;
+    FS_EMIT_FN explicit Direct(const uint8_t* b) : base(b) {}
+    FS_EMIT_FN uint32_t get(uint32_t off) const { return base[off]; }
+};
+struct Win16 {
+    const uint8_t* base; uint32_t blk; uint32_t w0, w1, w2, w3;
+    FS_EMIT_FN explicit Win16(const uint8_t* b) : base(b), blk(0xFFFFFFFFu), w0(0), w1(0), w2(0), w3(0) {}
+    FS_EMIT_FN uint32_t get(uint32_t off)
+    {
+        const uint32_t b = off >> 4;
+        if (b != blk) {
+            struct alignas(16) Q { uint32_t x, y, z, w; };
+            const Q q = *(const Q*)(base + 16u * (size_t)b);
+            w0 = q.x; w1 = q.y; w2 = q.z; w3 = q.w; blk = b;
+        }
+        const uint32_t k = (off >> 2) & 3u, w = k == 0u ? w0 : (k == 1u ? w1 : (k == 2u ? w2 : w3));
+        return (w >> (8u * (off & 3u))) & 0xFFu;
+    }
+};
+
 // seq: the bin's bases; contig: the bin's contig bytes (per contig: sequence[2 L] then variant[2 L], L = the contig's read length)
-FS_EMIT_FN void emit_op(const fsdev::EmitOp& op, const fsdev::EmitJob& job, const uint8_t* seq, const uint8_t* contig, Sink& s)
+template <class R>
+FS_EMIT_FN void emit_op_with(const fsdev::EmitOp& op, const fsdev::EmitJob& job, const uint8_t* seq, const uint8_t* contig, Sink& s)
 {
     const uint8_t* d2i = job.dna_to_idx;
     const uint32_t sigLen = job.sig_len;
     const uint32_t idxN = d2i['N'];
     switch (op.kind) {
     case fsdev::EMIT_HARD: {
-        const uint8_t* a = seq + op.seq_a;
+        R a(seq);
         const int32_t L = (int32_t)op.len_a, m = (int32_t)op.pos_a;
         for (int32_t i = 0; i < L; ++i) {
-            if (i < m || i >= m + (int32_t)sigLen) put_byte(s, a[i]);
+            if (i < m || i >= m + (int32_t)sigLen) put_byte(s, a.get(op.seq_a + (uint32_t)i));
             else if (i == m) put_byte(s, '.');
         }
         break;
     }
     case fsdev::EMIT_PE_HARD: {
-        const uint8_t* a = seq + op.seq_a;
-        for (uint32_t i = 0; i < op.len_a; ++i) put_byte(s, a[i]);
+        R a(seq);
+        for (uint32_t i = 0; i < op.len_a; ++i) put_byte(s, a.get(op.seq_a + i));
         break;
     }
     case fsdev::EMIT_MATCH: case fsdev::EMIT_PE_MATCH: {
         const bool pe = op.kind == fsdev::EMIT_PE_MATCH;
-        const uint8_t* newSeq = seq + op.seq_a; const uint8_t* bestSeq = seq + op.seq_b;
+        R rn(seq), rb(seq);
+        uint32_t newOff = op.seq_a, bestOff = op.seq_b;
         uint32_t newLen = op.len_a, bestLen = op.len_b, bestPos = op.pos_b;
         const int32_t shift = op.shift;
-        if (shift >= 0) { bestSeq += shift; bestLen -= (uint32_t)shift; bestPos -= (uint32_t)shift; }
+        if (shift >= 0) { bestOff += (uint32_t)shift; bestLen -= (uint32_t)shift; bestPos -= (uint32_t)shift; }
         else {
-            for (int32_t i = 0; i < -shift; ++i) put_letter(s, d2i[newSeq[i] & 127u], idxN);
-            newSeq += -shift; newLen -= (uint32_t)(-shift);
+            for (int32_t i = 0; i < -shift; ++i) put_letter(s, d2i[rn.get(newOff + (uint32_t)i) & 127u], idxN);
+            newOff += (uint32_t)(-shift); newLen -= (uint32_t)(-shift);
         }
         const uint32_t minLen = bestLen < newLen ? bestLen : newLen;
         if (op.mode == fsdev::EMIT_FULL || op.mode == fsdev::EMIT_EXPENSIVE) {
             for (uint32_t i = 0; i < minLen; ++i) {
                 if (!pe && i == bestPos) { i += sigLen - 1u; continue; }      // (the signature is not coded; the mate has none)
-                const bool eq = bestSeq[i] == newSeq[i];
+                const uint32_t cb = rb.get(bestOff + i), cn = rn.get(newOff + i);
+                const bool eq = cb == cn;
                 if (op.mode == fsdev::EMIT_FULL) put_bit(s, eq); else put_match_symbol(s, eq);
-                if (!eq) put_letter(s, d2i[newSeq[i] & 127u], d2i[bestSeq[i] & 127u]);
+                if (!eq) put_letter(s, d2i[cn & 127u], d2i[cb & 127u]);
             }
         }
-        for (uint32_t i = minLen; i < newLen; ++i) put_letter(s, d2i[newSeq[i] & 127u], idxN);
+        for (uint32_t i = minLen; i < newLen; ++i) put_letter(s, d2i[rn.get(newOff + i) & 127u], idxN);
         break;
     }
     case fsdev::EMIT_CREAD: {
-        const uint8_t* a = seq + op.seq_a;
+        R a(seq), cs(contig), var(contig);
         const uint32_t readLen = op.len_a, m = op.pos_a;
-        const uint8_t* cs = contig + op.seq_b; const uint8_t* var = cs + 2u * op.pos_b;      // (pos_b: the contig's read length)
+        const uint32_t csOff = op.seq_b, varOff = op.seq_b + 2u * op.pos_b;      // (pos_b: the contig's read length)
         const uint32_t consStart = readLen - m;
         uint32_t it = 0;
         while (it < job.begin_cut) {
             if (it == m) { it += sigLen; continue; }
-            put_letter(s, d2i[a[it] & 127u], d2i[cs[consStart + it] & 127u]); it++;
+            put_letter(s, d2i[a.get(op.seq_a + it) & 127u], d2i[cs.get(csOff + consStart + it) & 127u]); it++;
         }
         while (it < readLen - job.end_cut) {
             if (it == m) { it += sigLen; continue; }
-            if (var[consStart + it]) put_letter(s, d2i[a[it] & 127u], d2i[cs[consStart + it] & 127u]);
+            if (var.get(varOff + consStart + it)) put_letter(s, d2i[a.get(op.seq_a + it) & 127u], d2i[cs.get(csOff + consStart + it) & 127u]);
             it++;
         }
-        while (it < readLen) { put_letter(s, d2i[a[it] & 127u], d2i[cs[consStart + it] & 127u]); it++; }
+        while (it < readLen) { put_letter(s, d2i[a.get(op.seq_a + it) & 127u], d2i[cs.get(csOff + consStart + it) & 127u]); it++; }
         break;
     }
     case fsdev::EMIT_CDEF: {
+        R cs(contig), var(contig);
         const uint32_t readLen = op.pos_b, mainSigPos = op.pos_a;
-        const uint8_t* cs = contig + op.seq_b; const uint8_t* var = cs + 2u * readLen;
+        const uint32_t csOff = op.seq_b, varOff = op.seq_b + 2u * readLen;
         const uint32_t lzFirst = readLen - mainSigPos, lzSecond = lzFirst + readLen;
         for (uint32_t i = op.len_a; i < op.len_b; ++i) {
             if (i == readLen) { i += sigLen - 1u; continue; }
-            put_bit(s, var[i] == 0);
-            if (i < lzFirst + 2u || i >= lzSecond - 2u || var[i] != 0) put_letter(s, d2i[cs[i] & 127u], idxN);
+            const uint32_t v = var.get(varOff + i);
+            put_bit(s, v == 0u);
+            if (i < lzFirst + 2u || i >= lzSecond - 2u || v != 0u) put_letter(s, d2i[cs.get(csOff + i) & 127u], idxN);
         }
         break;
     }
     default: break;
     }
 }
+FS_EMIT_FN void emit_op(const fsdev::EmitOp& op, const fsdev::EmitJob& job, const uint8_t* seq, const uint8_t* contig, Sink& s) { emit_op_with<Direct>(op, job, seq, contig, s); }
 
 // ---- the run-length coders, one symbol at a time (the emulation's form, and the tail of the kernels' chunks) ----
 // BinaryRleEncoder (rle/RleEncoder.h:21-79): a byte per zero -- the ones in front of it + 2 when there are any, else 0 --, a byte 255
@@ -177,6 +208,9 @@ inline const char* plan_error(const uint8_t* input, size_t inputBytes, const fsd
         const EmitJob& jb = jobs[j];
         if (!((uint64_t)jb.first_op + jb.n_ops <= plan.n_ops && (uint64_t)jb.first_id + jb.n_ids <= plan.n_ids && jb.seq_off + jb.seq_bytes <= inputBytes &&
               jb.contig_off + jb.contig_bytes <= inputBytes && jb.sig_len >= 1u && jb.sig_len <= 32u)) return "ops, ids, bases or contig bytes outside the batch input";
+        // (the kernels read sixteen bytes a load: Win16)
+        if ((jb.seq_off & 15u) != 0u || (jb.contig_off & 15u) != 0u || ((jb.seq_off + jb.seq_bytes + 15u) & ~15ull) > ((inputBytes + 15u) & ~15ull) || ((jb.contig_off + jb.contig_bytes + 15u) & ~15ull) > ((inputBytes + 15u) & ~15ull))
+            return "bases or contig bytes not placed on sixteen-byte boundaries";
         uint64_t need[ECH_COUNT + 1] = {0};
         need[ECH_COUNT] = 6ull * jb.n_ids + 2u;
         for (uint32_t k = 0; k < jb.n_ops; ++k) {

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void fs_emit_count(const EmitJob* __restrict__
     const EmitOp op = ops[g];
     const EmitJob& job = jobs[op.pad2[0]];
     fsemit::Sink s;
-    fsemit::emit_op(op, job, in + job.seq_off, in + job.contig_off, s);
+    fsemit::emit_op_with<fsemit::Win16>(op, job, in + job.seq_off, in + job.contig_off, s);
     counts[2u * g] = s.nL; counts[2u * g + 1u] = s.nB;
 }
 
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void fs_emit_write(const EmitJob* __restrict__
     uint8_t dummy[2];
     s.outL = chL < ECH_COUNT ? out + job.out_off[chL] + (uint64_t)fsemit::unit_l(chL) * offs[2u * g] : dummy;
     s.outB = chB < ECH_COUNT ? (fsemit::is_bit_channel(chB) ? out + job.raw_off[chB] + offs[2u * g + 1u] : out + job.out_off[chB] + 2ull * offs[2u * g + 1u]) : dummy;
-    fsemit::emit_op(op, job, in + job.seq_off, in + job.contig_off, s);
+    fsemit::emit_op_with<fsemit::Win16>(op, job, in + job.seq_off, in + job.contig_off, s);
 }
 
 // BinaryRleEncoder over one bit channel of one bin (blockIdx.x = 3 * bin + which).  A thread takes 16 bits; a chunk is 4 096 bits.

@@ -360,7 +360,10 @@ static void emitStreams(uint8_t* buf, const EmitPlan& plan, uint64_t emitBase, s
             fsemit::Sink s; uint8_t dummy[4];
             s.outL = chL < ECH_COUNT ? out + job.out_off[chL] + (uint64_t)fsemit::unit_l(chL) * at[chL] : dummy;
             s.outB = chB < ECH_COUNT ? (fsemit::is_bit_channel(chB) ? out + job.raw_off[chB] + at[chB] : out + job.out_off[chB] + 2ull * at[chB]) : dummy;
-            fsemit::emit_op(op, job, buf + job.seq_off, buf + job.contig_off, s);
+            // (FS_EMU_WIN16=1: through the kernels' reader -- sixteen bytes a load -- instead of a load per byte; the batch buffer is malloc'ed, its regions sixteen-byte placed)
+            static const bool win16 = getenv("FS_EMU_WIN16") && atoi(getenv("FS_EMU_WIN16")) != 0;
+            if (win16 && ((uintptr_t)buf & 15u) == 0u) fsemit::emit_op_with<fsemit::Win16>(op, job, buf + job.seq_off, buf + job.contig_off, s);
+            else fsemit::emit_op(op, job, buf + job.seq_off, buf + job.contig_off, s);
             if (chL < ECH_COUNT) at[chL] += s.nL;
             if (chB < ECH_COUNT) at[chB] += s.nB;
         }
