@@ -367,6 +367,9 @@ def main():
     QUALITY = args.quality
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse:
+        # several ranks on ONE device: together they must not ask for more hardware queues than the device maps (profiles/r04_cli_two_processes.txt)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(2, 16 // max(1, world))))
     import torch
     dist = None
     if world > 1:

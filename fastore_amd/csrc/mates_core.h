@@ -36,7 +36,12 @@
 namespace fsmate {
 using namespace fsdev;
 
-enum : uint32_t { kThreads = 1024, kWaves = kThreads / 64u, kWindowMax = 1024, kHash = 1024, kHashShift = 22, kItems = 4096, kNone = 0xFFFFFFFFu, kPlaneWords = 9,
+// (FSM_ITEMS: a shorter list for the tests, so that the passes over a part of the history at a time are met on small bins too)
+#if !defined(FSM_ITEMS)
+  #define FSM_ITEMS 4096
+#endif
+enum : uint32_t { kThreads = 1024, kWaves = kThreads / 64u, kWindowMax = 1024, kHash = 1024, kHashShift = 22, kItems = FSM_ITEMS, kPartEntries = kItems / 16u /* sixteen alignments an entry at most: a part's never overflow the list */,
+                  kParts = (kWindowMax + kPartEntries - 1u) / kPartEntries, kNone = 0xFFFFFFFFu, kPlaneWords = 9,
                   kEntryWords = 4u + 4u * kPlaneWords };
 
 struct alignas(16) Shared {
@@ -333,13 +338,13 @@ FS_DEV void search_bin(Shared& sh, const MateJob job, const MatePair* pairs, con
         bool over = sh.overflow != 0u;
         if (over || (lim1 < 254u && (sh.best == ~0ull || (uint32_t)(sh.best >> 48) > lim1))) {
             uint32_t low = over ? 0u : lim1 + 1u;
-            for (uint32_t part = 0; part < 5u; ++part) {                // part 0: everything; parts 1..4: the quarters, when part 0 did not fit
+            for (uint32_t part = 0; part <= kParts; ++part) {             // part 0: everything; parts 1..: kPartEntries entries at a time (quarters in the product), when part 0 did not fit
                 if (part == 1u && !over) break;
                 const uint32_t bound = sh.best == ~0ull ? 254u : (uint32_t)(sh.best >> 48);
                 FSM_SYNC(sh, gen);                                      // (everyone has read the list's state of the pass before)
                 if (tid == 0u) { sh.nItems = 0u; sh.overflow = 0u; }
                 FSM_SYNC(sh, gen);
-                if (bound >= low) list(low, bound, part == 0u ? 0u : (part - 1u) * (kWindowMax / 4u), part == 0u ? (uint32_t)kWindowMax : part * (kWindowMax / 4u));
+                if (bound >= low) list(low, bound, part == 0u ? 0u : (part - 1u) * kPartEntries, part == 0u ? (uint32_t)kWindowMax : part * kPartEntries);
                 FSM_SYNC(sh, gen);
                 if (part == 0u) { over = sh.overflow != 0u; if (over) continue; }      // (did not fit: nothing of it is priced, the quarters do it all)
                 price(bound);

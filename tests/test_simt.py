@@ -4,6 +4,7 @@ the same source is compiled with -DFS_SIMT_EMU and runs as 64 cooperative fibers
 import ctypes
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -227,6 +228,27 @@ def test_range_coded_streams_through_the_coder_wave(simt, oracle):
     for i, (m, d) in enumerate(streams):
         want = oracle_ppmd(oracle, d) if m is None else oracle_rc(oracle, m, d)
         assert bufs[i].raw[:sizes[i]] == want, (i, m, len(d))
+
+
+def test_mate_search_kernel_body_with_a_short_alignment_list(monkeypatch):
+    # the same with a list of 256 alignments instead of 4 096 (-DFSM_ITEMS=256): the first pass overflows, the pair before is "dense", the guess
+    # is too low -- every pass over a part of the history at a time that a deep library needs (pe_long on the device) is met on the golden bins
+    import fastore_amd
+    from conftest import manifest, knobs_from_flags, GOLDEN
+    out = os.path.join(ROOT, "build", "libsimt_emu_short_list.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU", "-DFSM_ITEMS=256", "-shared", "-fPIC", "-o", out,
+                           os.path.join(ROOT, "tests", "emu", "mates_simt.cpp"), os.path.join(ROOT, "tests", "emu", "simt.cpp")])
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "fastore_amd", "csrc"), "-j", "8", "emu"], stdout=subprocess.DEVNULL)
+    code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import fastore_amd; from conftest import knobs_from_flags, manifest, GOLDEN\n"
+            "lib = fastore_amd.load_library(%r)\n"
+            "for name, paired, flags in manifest():\n"
+            "    if paired:\n"
+            "        with fastore_amd.Packer(lib=lib, device_id=0, **knobs_from_flags(flags)) as p: print(p.pe_matcher_check(os.path.join(GOLDEN, name + '.in')))" %
+            (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "build", "libfastore_emu.so")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, env=dict(os.environ, FS_EMU_SIMT_MATES=out))      # (the emulation library reads the switch once: a process of its own)
+    assert r.returncode == 0, r.stderr
+    rows = [eval(l) for l in r.stdout.decode().strip().splitlines()]
+    assert rows and all(pairs > 1000 and differing == 0 for pairs, differing in rows), rows
 
 
 @pytest.mark.parametrize("window", [None, 2, 5, 64, 100])
