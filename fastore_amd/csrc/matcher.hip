@@ -252,7 +252,7 @@ template <int FW, bool MULTI> __global__ __launch_bounds__(MULTI ? 1024 : 64) vo
 // measured on the way there.  Rows come back as the host's serial search computes them (checked pair by pair: fsgpu_pe_matcher_check).
 enum : uint32_t { kMateWindowMax = fsmate::kWindowMax };
 
-__global__ __launch_bounds__(fsmate::kThreads) void fs_match_mates(const MateJob* __restrict__ jobs, const MatePair* __restrict__ pairs, const uint8_t* __restrict__ seq,
+__global__ __launch_bounds__(1024) void fs_match_mates(const MateJob* __restrict__ jobs, const MatePair* __restrict__ pairs, const uint8_t* __restrict__ seq,
                                                                    const uint32_t* __restrict__ validBits, MateParams par, MateRow* __restrict__ rows, uint32_t* __restrict__ hist)
 {
 #if defined(__HIP_DEVICE_COMPILE__)      // (the compiler's host pass only needs the kernel's name)

@@ -40,7 +40,11 @@ using namespace fsdev;
 #if !defined(FSM_ITEMS)
   #define FSM_ITEMS 4096
 #endif
-enum : uint32_t { kThreads = 1024, kWaves = kThreads / 64u, kWindowMax = 1024, kHash = 1024, kHashShift = 22, kItems = FSM_ITEMS, kPartEntries = kItems / 16u /* sixteen alignments an entry at most: a part's never overflow the list */,
+// (FSM_THREADS: the workgroup's size, 256 .. 1024: a thread takes kWindowMax / kThreads history entries)
+#if !defined(FSM_THREADS)
+  #define FSM_THREADS 1024
+#endif
+enum : uint32_t { kThreads = FSM_THREADS, kWaves = kThreads / 64u, kEPT = 1024u / kThreads, kWindowMax = 1024, kHash = 1024, kHashShift = 22, kItems = FSM_ITEMS, kPartEntries = kItems / 16u /* sixteen alignments an entry at most: a part's never overflow the list */,
                   kParts = (kWindowMax + kPartEntries - 1u) / kPartEntries, kNone = 0xFFFFFFFFu, kPlaneWords = 9,
                   kEntryWords = 4u + 4u * kPlaneWords };
 
@@ -161,7 +165,7 @@ FS_DEV void search_bin(Shared& sh, const MateJob job, const MatePair* pairs, con
         const uint32_t plen = pr.mate_len, base = baseNext;
         if (p + 1u < job.count) { prNext = pairs[job.first + p + 1u]; baseNext = wave < 4u && tid < prNext.mate_len ? (uint32_t)seq[prNext.mate_off + tid] : 0u; }
         // ---- the mate's planes (wavefronts 0..3: 64 positions each); the table and the pair's counters start empty
-        sh.hash[tid] = 0u;
+        for (uint32_t i = tid; i < kHash; i += kThreads) sh.hash[i] = 0u;
         if (tid == 0u) { sh.nItems = 0u; sh.size1 = 0u; sh.size2 = 0u; sh.overflow = 0u; sh.nAll = 0u; sh.best = ~0ull; }
         if (wave < 4u) {
             uint32_t code = 4u;
@@ -222,14 +226,18 @@ FS_DEV void search_bin(Shared& sh, const MateJob job, const MatePair* pairs, con
         // ---- ... and the history, a thread per entry: its listed signatures against the table; the alignments whose bound |shift| x s lies in
         // [low, lim] go on the list (entries [eLo, eHi))
         const uint32_t lowValid = pushes >= W ? 0u : W - pushes;
-        const bool live = tid < W && tid >= lowValid && !(pushes >= W && tid == ring);
-        Quad e4; e4.x = e4.y = e4.z = e4.w = 0u;
-        if (live) e4 = ldq(sh.ring4[tid]);
-        auto list = [&](uint32_t low, uint32_t lim, uint32_t eLo, uint32_t eHi) {
+        Quad e4s[kEPT]; bool lives[kEPT];
+        FSM_UNROLL for (uint32_t u = 0; u < kEPT; ++u) {
+            const uint32_t e = tid + kThreads * u;
+            lives[u] = e < W && e >= lowValid && !(pushes >= W && e == ring);
+            e4s[u].x = e4s[u].y = e4s[u].z = e4s[u].w = 0u;
+            if (lives[u]) e4s[u] = ldq(sh.ring4[e]);
+        }
+        auto list_one = [&](uint32_t ent, const Quad& e4, bool live, uint32_t low, uint32_t lim, uint32_t eLo, uint32_t eHi) {
             const uint32_t minShift = sc != 0u ? ((low + sc - 1u) * inv20) >> 20 : (low != 0u ? 128u : 0u);         // |shift| x s >= low
             const uint32_t maxShift = sc != 0u ? (lim * inv20) >> 20 : 127u;                                          // |shift| x s <= lim
             uint32_t want = 0u, posOf = 0u, all = 0u;      // bit 4 j + k: alignment (j, k) goes on the list; byte j: the signature's first position in the mate; all: alignments there are
-            if (live && tid >= eLo && tid < eHi) {
+            if (live && ent >= eLo && ent < eHi) {
                 uint32_t first[4];
                 FSM_UNROLL for (uint32_t j = 0; j < 4u; ++j) { const uint32_t sj = sel4(e4, j) & 0xFFFFu; first[j] = sj != 0u ? sh.hash[(sj * 0x9E3779B1u) >> kHashShift] : 0u; }
                 FSM_UNROLL for (uint32_t j = 0; j < 4u; ++j) {
@@ -268,8 +276,11 @@ FS_DEV void search_bin(Shared& sh, const MateJob job, const MatePair* pairs, con
             uint32_t at = at0 + (run >> 16) - mine;
             for (uint32_t m = want; m != 0u; m &= m - 1u, ++at) {
                 const uint32_t bit = (uint32_t)__builtin_ctz(m), j = bit >> 2, k = bit & 3u;
-                if (at < kItems) sh.items[at] = (tid << 12) | (j << 10) | (k << 8) | ((posOf >> (8u * j)) & 0xFFu); else sh.overflow = 1u;
+                if (at < kItems) sh.items[at] = (ent << 12) | (j << 10) | (k << 8) | ((posOf >> (8u * j)) & 0xFFu); else sh.overflow = 1u;
             }
+        };
+        auto list = [&](uint32_t low, uint32_t lim, uint32_t eLo, uint32_t eHi) {
+            FSM_UNROLL for (uint32_t u = 0; u < kEPT; ++u) list_one(tid + kThreads * u, e4s[u], lives[u], low, lim, eLo, eHi);
         };
         // what is on the list, a thread per alignment; the cheapest goes to the workgroup's minimum
         auto price = [&](uint32_t bound) {
