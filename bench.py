@@ -484,7 +484,12 @@ def main():
                 continue
             ls, lw = (max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))) if key == "pe" else (max(1, min(args.steps, 3)), 1)
             try:
-                lleg, _ = leg_process(key, lname, lreads, lpaired, lgenome, lq, ls, lw, (420 if key == "pe" else 240) + ref_s)
+                # (the whole run keeps inside FS_BENCH_BUDGET_S, 560 s by default -- the driver gives the command ten minutes --: a leg gets what is
+                # left of it at most, and one that could not even start says so; the line itself is printed in any case)
+                left = _T0 + float(os.environ.get("FS_BENCH_BUDGET_S", "560")) - time.time() - 5.0
+                if left < 45.0:
+                    raise RuntimeError("not started: the run's time budget was used up")
+                lleg, _ = leg_process(key, lname, lreads, lpaired, lgenome, lq, ls, lw, int(min((420 if key == "pe" else 240) + ref_s, left)))
             except Exception as e:          # noqa: BLE001
                 lleg = {"error": "%s: %s" % (type(e).__name__, e)}
             res[key] = lleg
