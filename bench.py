@@ -200,7 +200,7 @@ def cli_phase(fastore_amd, args, work, name, reads, paired, genome, cores, cli_r
         try:
             # (FS_BENCH_CLI_LOG=<file>: the process's stderr -- its FS_TRACE timeline, a watchdog's report -- is kept)
             with open(os.environ["FS_BENCH_CLI_LOG"], "ab") if os.environ.get("FS_BENCH_CLI_LOG") else open(os.devnull, "wb") as errf:
-                rc = subprocess.call(cli, stdout=subprocess.DEVNULL, stderr=errf, timeout=int(os.environ.get("FS_BENCH_CLI_TIMEOUT", "240")))
+                rc = subprocess.call(cli, stdout=subprocess.DEVNULL, stderr=errf, timeout=int(os.environ.get("FS_BENCH_CLI_TIMEOUT", "90")))
         except subprocess.TimeoutExpired:      # (a process that does not end is reported as such, not waited for)
             rc = -9
         tc = time.perf_counter() - t
