@@ -637,6 +637,7 @@ static bool packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& 
         a.timing.ppmd_symbols += b.timing.ppmd_symbols; a.timing.rc_symbols += b.timing.rc_symbols; a.timing.restarts += b.timing.restarts; a.timing.max_restarts = std::max(a.timing.max_restarts, b.timing.max_restarts);
         a.timing.h2d_bytes += b.timing.h2d_bytes; a.timing.gather_ms += b.timing.gather_ms; a.timing.gather_symbols += b.timing.gather_symbols; a.timing.gather_bytes += b.timing.gather_bytes; a.timing.id_strings += b.timing.id_strings;
         for (int w = 0; w < 16; ++w) a.timing.win[w] += b.timing.win[w];
+        a.timing.tail_launches += b.timing.tail_launches;
         a.matchedReads += b.matchedReads.load(); a.matchUs += b.matchUs.load(); a.matchKernelUs += b.matchKernelUs.load(); a.matchBasesUp += b.matchBasesUp.load(); a.matchUnpackedReads += b.matchUnpackedReads.load();
         a.matedPairs += b.matedPairs.load(); a.mateUs += b.mateUs.load(); a.mateKernelUs += b.mateKernelUs.load(); b.matedPairs = 0; b.mateUs = 0; b.mateKernelUs = 0;
         b.matchedReads = 0; b.matchUs = 0; b.matchKernelUs = 0; b.matchBasesUp = 0; b.matchUnpackedReads = 0;
@@ -745,6 +746,7 @@ int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out)
     out->gather_kernel_ms = ctx->c.timing.gather_ms; out->gather_symbols = ctx->c.timing.gather_symbols; out->gather_bytes = ctx->c.timing.gather_bytes;
     out->rc_symbols = ctx->c.timing.rc_symbols; out->ppmd_restarts = ctx->c.timing.restarts; out->ppmd_max_restarts = ctx->c.timing.max_restarts;
     out->h2d_bytes = ctx->c.timing.h2d_bytes; out->d2h_bytes = ctx->c.timing.d2h_bytes;
+    out->struct_bytes = sizeof(fsgpu_stats); out->coder_tail_launches = ctx->c.timing.tail_launches;
     return FSGPU_OK;
 }
 

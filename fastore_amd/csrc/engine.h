@@ -13,6 +13,7 @@ struct BatchTiming {
     uint64_t id_strings = 0;                                                 // fs_tokenise_ids: read ids tokenised on the device
     uint64_t launches = 0, items = 0, ppmd_symbols = 0, rc_symbols = 0, restarts = 0, max_restarts = 0;
     uint64_t h2d_bytes = 0, d2h_bytes = 0;
+    uint64_t tail_launches = 0;                 // coder launches made again because no workgroup of the launch found a free arena slot (engine.hip: run_encode)
     uint64_t win[16] = {0};                     // windowed PPMd hit path, summed over the streams: [1] attempts [2] windows [3] symbols [4] rounds [5] redone; [8..15] phase clocks / 64
 };
 
@@ -42,10 +43,10 @@ struct Device {
     // hipFree does), so they are kept until the lane is between batches (lanes_equalize) or goes
     void* oldStage[4]; size_t oldStageCap[4]; uint32_t nOldStage;
     uint32_t stagePageable;                                // the staging buffers of this lane are not registered with the runtime
+    uint32_t trace;                                        // FS_TRACE was set when the lane was made: every launch is waited for where it is made
 };
 
 int device_count();
-uint32_t search_cus();      // FS_SEARCH_CUS: compute units kept for the search kernels (the coder lanes launch on the others); 0 = no partition
 int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size_t errLen);
 int lane_create(Device* first, Device** out, char* err, size_t errLen);      // another lane on the GPU (and pool) of `first`
 void device_destroy(Device* dev);                                            // a lane; the pool goes with its last lane

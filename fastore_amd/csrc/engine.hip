@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <time.h>
 #include <algorithm>
 #include <atomic>
@@ -46,41 +47,32 @@ constexpr uint64_t kGuard = 64ull << 10;
 #endif
 constexpr uint32_t kWavesPerSimd = FS_WAVES_PER_SIMD;
 
-// Arena slots.  The pool is cut into kXcc partitions of `slotsPerXcc` arenas; a wave claims a slot of the XCD it runs
+// Arena slots.  The pool is cut into kXcc partitions of `slotsPerXcc` arenas; a workgroup claims a slot of the XCD it runs
 // on and gives it back when its queue is empty.  Slots never migrate between XCDs: the per-XCD L2s are not coherent
 // with each other, so an arena reused from another XCD inside one cache epoch could be clobbered by a late write-back
 // of the previous owner's dead lines.  A partition is a bitmap (bit set = taken): claim = find a clear bit, atomicOr,
-// keep it if the bit was clear before; release = atomicAnd.  There is no queue and no ticket, so nothing can be lost or
-// overwritten (round 1's ticket ring could drop a ticket when a slot was returned before the waiter's next poll, which
-// left that wave spinning for ever: the "stall with more than four launches in flight").  A claim only has to retry
-// while more waves are resident on the XCD than it has slots (a small --max-waves): the holders do not depend on the
-// waiters, so every wave reaches its exit.
+// keep it if the bit was clear before; release = atomicAnd.
+// NO workgroup ever waits for another one.  A workgroup that finds its partition full (more workgroups resident on the
+// XCD than it has slots: a small pool, e.g. --max-waves or the one-shot pool, under one-wave launches) LEAVES at once, without
+// having taken a stream; the streams are taken by the launch's other workgroups, and should none of them have found a slot
+// either the host sees the queue's head short of its end and launches again (run_encode: the tail launch).  Rounds 1-4 had
+// the workgroup spin for a slot inside the kernel -- a wait for a workgroup of ANOTHER launch, which stands still when that
+// launch's hardware queue is not mapped while the spinners hold the compute units (two packs on one device:
+// profiles/r04_cli_two_processes.txt).
 constexpr uint32_t kXcc = 8;
 constexpr uint32_t kBitmapWords = 16;            // 64-bit words per XCD: up to 1024 slots
 struct SlotMap { unsigned long long w[kBitmapWords]; };
 
 __device__ __forceinline__ uint32_t xcc_id()
 { uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & (kXcc - 1u); }
-// the compute unit a wavefront runs on, inside its XCD: cu_id (bits 8-11), sh_id (12), se_id (13-15) of HW_ID
-__device__ __forceinline__ uint32_t cu_in_xcc()
-{ uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v)); return (v >> 8) & 0xFFu; }
-// A compute unit to itself for the streams that end a launch.  A long stream beside twelve others a compute unit runs a third slower than
-// alone (0.175 against 0.134 us per symbol; profiles/r02_cc_long_stream_beside_short_ones.txt: it is the company on the compute unit, not the
-// device's load), and the step IS its longest stream.  So the workgroup that takes a stream of isolateLen symbols or more marks its compute
-// unit as held (a table in device memory beside the slot maps: a tag per compute unit, the count of holds, their limit); every workgroup
-// of every launch looks at its compute unit's tag before it takes its next stream and sleeps while another holds it; the holder lets go
-// when its stream ends.  Nobody gives a stream back and nobody waits while working, so every wait ends; holds are limited to a quarter of
-// the compute units, the other streams keep the rest.
-enum : uint32_t { kHoldCount = kXcc * 256u, kHoldLimit = kHoldCount + 1u, kSlotState = kHoldCount + 2u, kHoldWords = kSlotState + kXcc * kBitmapWords * 64u };
-// (behind the holds: a word per arena slot saying where its workgroup stands -- phase | stream's place in the queue << 4 | launch << 24 --, read by lane_debug when a batch stands still)
 
 // The launch parameters stay in the kernarg segment and are re-read (scalar loads, a few per stream) where they are
 // needed: held in SGPRs for the whole kernel they were ~20 registers of pressure on the coder loops, which already
 // spill scalars to vector lanes.  `kernargs()` hides the pointer from the optimiser so that the loads are not hoisted.
 struct EncodeArgs {
     const StreamItem* items; const uint32_t* order; const uint8_t* in; uint8_t* out; uint32_t* outSizes; uint32_t* restarts;
-    uint8_t* arenas; uint64_t arenaStride; uint32_t* queueHead; SlotMap* maps; uint32_t* cuHold;
-    uint32_t nItems, longLen, slotsPerXcc, isolateLen;
+    uint8_t* arenas; uint64_t arenaStride; uint32_t* queueHead; SlotMap* maps;
+    uint32_t nItems, longLen, slotsPerXcc;
 };
 typedef const __attribute__((address_space(4))) EncodeArgs* KernArgs;
 __device__ __forceinline__ KernArgs kernargs()
@@ -170,62 +162,36 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
             SlotMap* mp = k->maps + xcc;
             const uint32_t per = k->slotsPerXcc, words = (per + 63u) >> 6;
             uint32_t w0 = blockIdx.x % words;                       // spread the first probes over the words
-            for (;;) {
-                bool got = false;
-                for (uint32_t i = 0; i < words && !got; ++i) {
-                    const uint32_t wi = (w0 + i) % words;
-                    // bits past the partition's last slot are never offered
-                    const unsigned long long valid = (wi + 1u) * 64u <= per ? ~0ull : ((1ull << (per - wi * 64u)) - 1ull);
-                    unsigned long long cur = __hip_atomic_load(&mp->w[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    while ((~cur & valid) != 0ull) {
-                        const uint32_t b = (uint32_t)__builtin_ctzll(~cur & valid);
-                        const unsigned long long old = __hip_atomic_fetch_or(&mp->w[wi], 1ull << b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (!(old & (1ull << b))) { s = 1u + wi * 64u + b; got = true; break; }
-                        cur = old | (1ull << b);
-                    }
+            for (uint32_t i = 0; i < words && s == 0u; ++i) {
+                const uint32_t wi = (w0 + i) % words;
+                // bits past the partition's last slot are never offered
+                const unsigned long long valid = (wi + 1u) * 64u <= per ? ~0ull : ((1ull << (per - wi * 64u)) - 1ull);
+                unsigned long long cur = __hip_atomic_load(&mp->w[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while ((~cur & valid) != 0ull) {
+                    const uint32_t b = (uint32_t)__builtin_ctzll(~cur & valid);
+                    const unsigned long long old = __hip_atomic_fetch_or(&mp->w[wi], 1ull << b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (!(old & (1ull << b))) { s = 1u + wi * 64u + b; break; }
+                    cur = old | (1ull << b);
                 }
-                if (got) break;
-                __builtin_amdgcn_s_sleep(64);
             }
         }
-        s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s) - 1u;
+        s = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
+        if (s == 0u) {                                  // the partition is full: leave, never wait (the streams stay in the queue for the others, or for the tail launch)
+            if (TWO) fsppmd::cq_send_exit((FS_LDS fsppmd::Shared*)&sh, qTail);
+            return;
+        }
+        s -= 1u;
         word = s >> 6; bit = s & 63u;
         slot = xcc * kernargs()->slotsPerXcc + s;
     }
     uint8_t* arena;
     { KernArgs k = kernargs(); arena = k->arenas + (uint64_t)slot * k->arenaStride; }
-    uint32_t* slotState = useMaps ? kernargs()->cuHold + kSlotState + (xcc * kBitmapWords * 64u + word * 64u + bit) : nullptr;
-    const uint32_t launchTag = (uint32_t)(((uintptr_t)kernargs()->queueHead >> 6) & 0xFFu) << 24;
-    #define FS_SLOT_AT(phase, q_) do { if (slotState && threadIdx.x == 0) __hip_atomic_store(slotState, (uint32_t)(phase) | ((uint32_t)(q_) << 4) | launchTag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
-    FS_SLOT_AT(1, 0);
-    const bool isolating = useMaps && kernargs()->isolateLen != 0u;
-    const uint32_t cuIx = isolating ? xcc_id() * 256u + cu_in_xcc() : 0u, holdTag = slot + 1u;
     for (;;) {
         KernArgs k = kernargs();
-        if (isolating) {                              // another workgroup has this compute unit to itself: not a stream more until it lets go
-            FS_SLOT_AT(2, 0);
-            uint32_t* hold = k->cuHold + cuIx;
-            for (;;) {
-                uint32_t h = 0;
-                if (threadIdx.x == 0) {
-                    h = __hip_atomic_load(hold, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // (... unless the launch's next stream is itself a long one: a long stream that waits for a worker costs the launch its
-                    // whole length -- seen as steps of 2.0 instead of 1.35 s when most of a launch's workgroups slept --, company costs a tenth)
-                    if (h != 0u && h != holdTag) {
-                        const uint32_t qh = __hip_atomic_load(k->queueHead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (qh < k->nItems && k->items[k->order[qh]].in_len >= k->isolateLen) h = 0u;
-                    }
-                }
-                h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
-                if (h == 0u || h == holdTag) break;
-                __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127);
-            }
-        }
         uint32_t q = 0;
         if (threadIdx.x == 0) q = atomicAdd(k->queueHead, 1u);
         q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
         if (q >= k->nItems) break;                    // every wave reaches this exit: the queue is finite
-        FS_SLOT_AT(3, q & 0xFFFFFu);
         const uint32_t it = k->order[q];
         const StreamItem item = k->items[it];
         const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.kind);
@@ -240,16 +206,6 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
         if (prio == 3u) __builtin_amdgcn_s_setprio(3);
         else if (prio == 2u) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(0);
-        bool holding = false;
-        if (isolating && weighs && n >= k->isolateLen) {      // a stream that ends the launch: the compute unit to itself, if it is free and holds are to be had
-            uint32_t got = 0;
-            if (threadIdx.x == 0) {
-                uint32_t* tab = k->cuHold;
-                if (atomicAdd(tab + kHoldCount, 1u) < __hip_atomic_load(tab + kHoldLimit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && atomicCAS(tab + cuIx, 0u, holdTag) == 0u) got = 1u;
-                else atomicSub(tab + kHoldCount, 1u);
-            }
-            holding = __builtin_amdgcn_readfirstlane((int)got) != 0;
-        }
         fs_cgptr src = (fs_cgptr)(k->in + item.in_off);
         fs_gptr dst = (fs_gptr)(k->out + item.out_off);
         fs_gptr ar = (fs_gptr)arena;
@@ -302,14 +258,9 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
             if (t == 0u) v = rs;
             k2->restarts[16u * it + t] = v;
         }
-        FS_SLOT_AT(4, q & 0xFFFFFu);
-        if (holding && threadIdx.x == 0) { KernArgs k4 = kernargs(); __hip_atomic_store(k4->cuHold + cuIx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); atomicSub(k4->cuHold + kHoldCount, 1u); }
         FS_WAVE_SYNC();
     }
-    FS_SLOT_AT(5, 0);
     if (TWO) fsppmd::cq_send_exit((FS_LDS fsppmd::Shared*)&sh, qTail);
-    FS_SLOT_AT(6, 0);
-    #undef FS_SLOT_AT
     if (useMaps && threadIdx.x == 0) {
         KernArgs k = kernargs();
         // the wave's stores have left for the XCD's L2 before the slot shows as free; its next owner runs on this XCD
@@ -853,7 +804,6 @@ struct Pool {
     uint8_t* arenas = nullptr; uint64_t bytes = 0, slotStride = 0;
     uint32_t slotsPerXcc = 0;
     SlotMap* maps = nullptr;
-    uint32_t* cuHold = nullptr;       // kHoldWords words behind the maps: a tag per compute unit, the holds' count, their limit
     std::shared_mutex gate;
     std::mutex m; int lanes = 0;
 };
@@ -888,38 +838,13 @@ static void pool_grow(Device* dev, Pool* pool, uint64_t need)
     if (getenv("FS_TRACE")) fprintf(stderr, "[trace] arena pool grown to %u slots of %.1f MB (%.1f GB) for a %.1f MB coder table\n", pool->slotsPerXcc * kXcc, big / 1e6, want / 1e6 / 1e3, need / 1e6);
 }
 
-// (engine.h) compute units kept for the search kernels: FS_SEARCH_CUS, 0 = none
-uint32_t search_cus()
-{
-    static const uint32_t n = []() { const char* e = getenv("FS_SEARCH_CUS"); const int v = e ? atoi(e) : 0; return (uint32_t)(v < 8 ? 0 : (v > 128 ? 128 : v & ~7)); }();
-    return n;
-}
-
 static int lane_init(Device* dev, char* err, size_t errLen)
 {
     hipError_t e;
     auto fail = [&](const char* what, hipError_t c) { snprintf(err, errLen, "%s: %s", what, hipGetErrorString(c)); return -1; };
     if ((e = hipSetDevice(dev->deviceId)) != hipSuccess) return fail("hipSetDevice", e);
     dev->stagePageable = g_pageableStaging ? 1u : 0u;
-    // Experiment (FS_XCD_SPLIT=<m|b>:<xcds>:<lanes>): the first <lanes> coder lanes of the process -- the ones the slices with the longest
-    // streams take -- launch on <xcds> of the eight XCDs only, all later lanes on the others: an L2 (4 MB per XCD) and TLB of their own
-    // for the long streams.  m: CU-mask bit i belongs to XCD i % 8 (the runtime deals the mask round robin); b: to XCD i / 32.
-    static std::atomic<uint32_t> laneNo{0};
-    const uint32_t myLane = laneNo++;
-    const char* xs = getenv("FS_XCD_SPLIT");
-    uint32_t xk = 0, xl = 0; char xm = 0;
-    if (xs && sscanf(xs, "%c:%u:%u", &xm, &xk, &xl) == 3 && xk >= 1 && xk <= 7 && (xm == 'm' || xm == 'b')) {
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t i = 0; i < 256u; ++i) { const uint32_t xcd = xm == 'm' ? i % 8u : i / 32u; if ((xcd < xk) == (myLane < xl)) mask[i >> 5] |= 1u << (i & 31u); }
-        if ((e = hipExtStreamCreateWithCUMask((hipStream_t*)&dev->stream, 8, mask)) != hipSuccess) return fail("hipExtStreamCreateWithCUMask", e);
-    } else if (const uint32_t sc = search_cus()) {
-        // FS_SEARCH_CUS=<n> (a multiple of 8): n compute units -- n / 8 on every XCD: CU-mask bit i belongs to XCD i % 8 -- are kept for the
-        // search kernels (fs_match_reads, fs_match_mates, whose workgroups need sixteen free wave slots and up to 110 KB of LDS on ONE
-        // compute unit: behind the coder kernels' resident waves they wait for a launch to drain); the coder lanes launch on the others
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (uint32_t i = sc; i < 256u; ++i) mask[i >> 5] |= 1u << (i & 31u);
-        if ((e = hipExtStreamCreateWithCUMask((hipStream_t*)&dev->stream, 8, mask)) != hipSuccess) return fail("hipExtStreamCreateWithCUMask", e);
-    } else
+    dev->trace = getenv("FS_TRACE") ? 1u : 0u;
     if ((e = hipStreamCreateWithFlags((hipStream_t*)&dev->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipMalloc((void**)&dev->queueHead, 64)) != hipSuccess) return fail("hipMalloc(queue)", e);
     for (int i = 0; i < 6; ++i) if ((e = hipEventCreate((hipEvent_t*)&dev->ev[i])) != hipSuccess) return fail("hipEventCreate", e);
@@ -968,13 +893,8 @@ int device_create(Device** out, int deviceId, uint32_t maxWaves, char* err, size
     lap("properties, memory info");
     if ((e = hipMalloc((void**)&pool->arenas, pool->bytes)) != hipSuccess) return fail("hipMalloc(arenas)", e);
     lap("hipMalloc of the arena pool");
-    if ((e = hipMalloc((void**)&pool->maps, sizeof(SlotMap) * kXcc + kHoldWords * 4u)) != hipSuccess) return fail("hipMalloc(slot maps)", e);
-    if ((e = hipMemset(pool->maps, 0, sizeof(SlotMap) * kXcc + kHoldWords * 4u)) != hipSuccess) return fail("hipMemset(slot maps)", e);
-    {   // the compute units' hold table lives behind the slot maps; FS_ISOLATE_MAX: how many compute units may be held at a time (default: a quarter)
-        pool->cuHold = (uint32_t*)(pool->maps + kXcc);
-        const uint32_t limit = getenv("FS_ISOLATE_MAX") ? (uint32_t)std::max(0, atoi(getenv("FS_ISOLATE_MAX"))) : 64u;
-        if ((e = hipMemcpy(pool->cuHold + kHoldLimit, &limit, 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy(hold limit)", e);
-    }
+    if ((e = hipMalloc((void**)&pool->maps, sizeof(SlotMap) * kXcc)) != hipSuccess) return fail("hipMalloc(slot maps)", e);
+    if ((e = hipMemset(pool->maps, 0, sizeof(SlotMap) * kXcc)) != hipSuccess) return fail("hipMemset(slot maps)", e);
     lap("slot maps (first memset: code objects)");
     if (lane_init(dev, err, errLen) != 0) { (void)hipFree(pool->arenas); (void)hipFree(pool->maps); delete pool; delete dev; return -1; }
     pool->lanes = 1;
@@ -1036,32 +956,6 @@ int lane_debug(Device* dev, char* out, size_t outLen)
     if (!ok) { snprintf(out, outLen, "device read failed"); return -1; }
     int n = snprintf(out, outLen, "queue head %u, stream %s; arena slots taken per XCD:", head, hipStreamQuery((hipStream_t)dev->stream) == hipSuccess ? "idle" : "busy");
     for (uint32_t x = 0; x < kXcc && n > 0 && (size_t)n < outLen; ++x) { int c = 0; for (uint32_t w = 0; w < kBitmapWords; ++w) c += __builtin_popcountll(maps[x].w[w]); n += snprintf(out + n, outLen - n, " %d", c); }
-    {   // where the workgroups that hold the slots stand (all launches of the pool; printed once per call)
-        std::vector<uint32_t> st(kXcc * kBitmapWords * 64u, 0u), holds(kHoldWords - (kXcc * kBitmapWords * 64u), 0u);
-        hipStream_t s2 = nullptr;
-        if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess) {
-            bool ok2 = hipMemcpyAsync(st.data(), dev->pool->cuHold + kSlotState, st.size() * 4u, hipMemcpyDeviceToHost, s2) == hipSuccess;
-            ok2 = ok2 && hipMemcpyAsync(holds.data(), dev->pool->cuHold, holds.size() * 4u, hipMemcpyDeviceToHost, s2) == hipSuccess;
-            ok2 = ok2 && hipStreamSynchronize(s2) == hipSuccess;
-            (void)hipStreamDestroy(s2);
-            if (ok2) {
-                uint32_t phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t held = 0;
-                for (uint32_t x = 0; x < kXcc; ++x) for (uint32_t w = 0; w < kBitmapWords; ++w) for (uint32_t b = 0; b < 64u; ++b)
-                    if ((maps[x].w[w] >> b) & 1ull) ++phase[st[x * kBitmapWords * 64u + w * 64u + b] & 7u];
-                for (uint32_t c = 0; c < kHoldCount; ++c) held += holds[c] != 0u;
-                if (n > 0 && (size_t)n < outLen) n += snprintf(out + n, outLen - n, "; slot holders by phase (1 start, 2 waiting for a held compute unit, 3 in a stream, 4 stream done, 5 leaving, 6 left):");
-                for (uint32_t ph = 0; ph < 8u && n > 0 && (size_t)n < outLen; ++ph) n += snprintf(out + n, outLen - n, " %u", phase[ph]);
-                if (n > 0 && (size_t)n < outLen) n += snprintf(out + n, outLen - n, "; compute units held %u (count word %u)", held, holds[kHoldCount]);
-                // the streams the slot holders of THIS launch are in
-                const uint32_t tag = (uint32_t)(((uintptr_t)dev->queueHead >> 6) & 0xFFu);
-                uint32_t shown = 0;
-                for (uint32_t x = 0; x < kXcc; ++x) for (uint32_t w = 0; w < kBitmapWords; ++w) for (uint32_t b = 0; b < 64u; ++b) {
-                    const uint32_t v = st[x * kBitmapWords * 64u + w * 64u + b];
-                    if (((maps[x].w[w] >> b) & 1ull) && (v >> 24) == tag && (v & 7u) == 3u && shown < 12u && n > 0 && (size_t)n < outLen) { n += snprintf(out + n, outLen - n, "%s%u", shown ? "," : "; this launch's workgroups are in streams (queue places) ", (v >> 4) & 0xFFFFFu); ++shown; }
-                }
-            }
-        }
-    }
     return 0;
 }
 
@@ -1256,11 +1150,6 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     uint32_t maxAny = maxLen;                                                 // (... or QVZ stream, or stream of a range coder with a windowed form: what a --lossy / --reduced launch ends with)
     for (const auto& it : items) if (it.kind == KIND_QVZ || (it.kind != KIND_PPMD && it.kind - KIND_RC_BASE <= fsrc::M_A8O6)) maxAny = std::max(maxAny, it.in_len);
     const uint32_t longLen = std::max(1u, maxAny / 2);                     // "long" = at least half of the longest such stream
-    // ... and, with FS_ISOLATE=1, a long stream of a million symbols or more (FS_ISOLATE_MIN) gets a compute unit to itself.  Not the default: over
-    // twenty steps the typical step gained 1-5 %, but one step in seven took 2.0 instead of 1.4 s (profiles/r04_compute_unit_isolation.txt)
-    static const uint32_t isolateMin = !(getenv("FS_ISOLATE") && atoi(getenv("FS_ISOLATE")) != 0) ? 0u : (getenv("FS_ISOLATE_MIN") ? (uint32_t)std::max(1, atoi(getenv("FS_ISOLATE_MIN"))) : (1u << 20));
-    const uint32_t isolateLen = isolateMin ? std::max(isolateMin, longLen) : 0u;
-
     const uint32_t nRest = nItems;
     HIP_TRY(hipMemcpyAsync(dev->dIn, input, inputBytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dev->dItems, items.data(), sizeof(StreamItem) * nItems, hipMemcpyHostToDevice, st));
@@ -1343,12 +1232,14 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     }
     if (emit && emit->n_jobs && emit_launch(dev, st, *emit, emitBase, eml)) return -1;
     HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[0], st));
+    std::vector<uint32_t> restarts, writtenLen;
+    uint32_t qHead = 0, tailLaunches = 0;
     {
         EncodeArgs ka;
         ka.items = (const StreamItem*)dev->dItems; ka.order = (const uint32_t*)dev->dOrder; ka.in = (const uint8_t*)dev->dIn; ka.out = (uint8_t*)dev->dScratch;
         ka.outSizes = (uint32_t*)dev->dSizes; ka.restarts = (uint32_t*)dev->dRestarts; ka.arenas = pool->arenas; ka.arenaStride = stride;
-        ka.queueHead = (uint32_t*)dev->queueHead; ka.maps = exclusive ? (SlotMap*)nullptr : pool->maps; ka.cuHold = pool->cuHold;
-        ka.nItems = nRest; ka.longLen = longLen; ka.slotsPerXcc = pool->slotsPerXcc; ka.isolateLen = isolateLen;
+        ka.queueHead = (uint32_t*)dev->queueHead; ka.maps = exclusive ? (SlotMap*)nullptr : pool->maps;
+        ka.nItems = nRest; ka.longLen = longLen; ka.slotsPerXcc = pool->slotsPerXcc;
         // two-wave form where the step is bound by its longest PPMd stream (the coder runs beside the model walk: ~1.4x per
         // stream, but a stream takes two wave slots); FS_TWO_WAVE=0/1 forces either form
         // (FS_WAVES=1/2 forces a form; FS_TWO_WAVE=0/1 is the older switch.  Round 3's three-wave form -- windows prepared by a
@@ -1382,18 +1273,40 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
             if (rcWin && maxRc >= (256u << 10) && !getenv("FS_WAVES") && !getenv("FS_TWO_WAVE")) waves = 2u;
         }
         if (const char* rw = getenv("FS_RC_WINDOWS")) rcWin = atoi(rw) != 0;
-        if (waves == 2u) { const uint32_t g2 = std::max(1u, std::min(grid, dev->nWaves / 2u)); if (rcWin) hipLaunchKernelGGL(fs_encode_streams2_w, dim3(g2), dim3(128), 0, st, ka); else hipLaunchKernelGGL(fs_encode_streams2, dim3(g2), dim3(128), 0, st, ka); }
-        else if (rcWin) hipLaunchKernelGGL(fs_encode_streams_w, dim3(grid), dim3(64), 0, st, ka);
-        else hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, ka);
-        HIP_TRY(hipGetLastError());
+        auto launch = [&]() -> hipError_t {
+            if (waves == 2u) { const uint32_t g2 = std::max(1u, std::min(grid, dev->nWaves / 2u)); if (rcWin) hipLaunchKernelGGL(fs_encode_streams2_w, dim3(g2), dim3(128), 0, st, ka); else hipLaunchKernelGGL(fs_encode_streams2, dim3(g2), dim3(128), 0, st, ka); }
+            else if (rcWin) hipLaunchKernelGGL(fs_encode_streams_w, dim3(grid), dim3(64), 0, st, ka);
+            else hipLaunchKernelGGL(fs_encode_streams, dim3(grid), dim3(64), 0, st, ka);
+            return hipGetLastError();
+        };
+        HIP_TRY(launch());
+        HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));
+        if (dev->trace) { HIP_TRY(wait_stream(dev, st)); }
+        sizes.resize(nItems);
+        restarts.resize(16ull * nItems);
+        HIP_TRY(hipMemcpyAsync(&qHead, dev->queueHead, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(sizes.data(), dev->dSizes, 4ull * nItems, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(restarts.data(), dev->dRestarts, 64ull * nItems, hipMemcpyDeviceToHost, st));
+        // (the streams the device's own kernels wrote: their lengths, for the statistics -- the host knows only the room it gave them)
+        if (emit && emit->n_jobs) { writtenLen.resize(nItems); HIP_TRY(hipMemcpy2DAsync(writtenLen.data(), 4, (const uint8_t*)dev->dItems + offsetof(StreamItem, in_len), sizeof(StreamItem), 4, nItems, hipMemcpyDeviceToHost, st)); }
+        HIP_TRY(wait_stream(dev, st));
+        // The tail launch.  A workgroup that finds no free arena slot on its XCD leaves at once (no workgroup ever waits for another:
+        // encode_streams_body), and the launch's other workgroups take its streams; only when NONE of a launch's workgroups found a slot
+        // -- or those that did left before the queue was... they never do: they leave when it is empty -- is the queue's head short of
+        // its end here.  Then the launch is made again (same queue, same arguments) until every stream has been taken; whoever takes a
+        // stream codes it to its end.  The slots are held by this pool's other launches, which drain on their own, so every pass ends.
+        for (uint32_t pass = 0; qHead < nRest; ++pass) {
+            if (pass > 100000u) { snprintf(dev->err, sizeof dev->err, "coder launch: no arena slot in %u passes (queue at %u of %u)", pass, qHead, nRest); return -1; }
+            if (pass) { struct timespec ts = {0, pass < 64u ? 200000L : 2000000L}; nanosleep(&ts, nullptr); }
+            ++tailLaunches;
+            HIP_TRY(launch());
+            HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));
+            HIP_TRY(hipMemcpyAsync(&qHead, dev->queueHead, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sizes.data(), dev->dSizes, 4ull * nItems, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(restarts.data(), dev->dRestarts, 64ull * nItems, hipMemcpyDeviceToHost, st));
+            HIP_TRY(wait_stream(dev, st));
+        }
     }
-    HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));
-    if (getenv("FS_TRACE")) { HIP_TRY(wait_stream(dev, st)); }
-    sizes.resize(nItems);
-    std::vector<uint32_t> restarts(16ull * nItems);
-    HIP_TRY(hipMemcpyAsync(sizes.data(), dev->dSizes, 4ull * nItems, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(restarts.data(), dev->dRestarts, 64ull * nItems, hipMemcpyDeviceToHost, st));
-    HIP_TRY(wait_stream(dev, st));
     if (timing) {
         float a = 0;
         (void)hipEventElapsedTime(&a, (hipEvent_t)dev->ev[0], (hipEvent_t)dev->ev[1]);
@@ -1405,7 +1318,14 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
             timing->gather_bytes += gather->qvz ? 4u * gather->symbols + (gather->symbols * 3u + 3u) / 4u + gather->symbols / 4u
                                                 : (gather->bits == 6u ? gather->symbols + (gather->symbols * 3u + 3u) / 4u : 2u * gather->symbols + (gather->symbols * gather->bits + 7u) / 8u);
         }
-        for (uint32_t i = 0; i < nItems; ++i) { timing->restarts += restarts[16ull * i]; if (items[i].kind == KIND_PPMD) timing->max_restarts = std::max<uint64_t>(timing->max_restarts, restarts[16ull * i]); for (int k = 1; k < 16; ++k) timing->win[k] += restarts[16ull * i + k]; if (items[i].kind == KIND_PPMD) timing->ppmd_symbols += items[i].in_len; else timing->rc_symbols += items[i].in_len; }
+        timing->tail_launches += tailLaunches;
+        for (uint32_t i = 0; i < nItems; ++i) {
+            timing->restarts += restarts[16ull * i];
+            if (items[i].kind == KIND_PPMD) timing->max_restarts = std::max<uint64_t>(timing->max_restarts, restarts[16ull * i]);
+            for (int k = 1; k < 16; ++k) timing->win[k] += restarts[16ull * i + k];
+            const uint32_t len = writtenLen.empty() ? items[i].in_len : writtenLen[i];      // (what was coded, not the room a device-written stream was given)
+            if (items[i].kind == KIND_PPMD) timing->ppmd_symbols += len; else timing->rc_symbols += len;
+        }
     }
     return 0;
 }

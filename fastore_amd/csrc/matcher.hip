@@ -320,21 +320,13 @@ int match_lane_create(Device* dev, MatchLane** out, bool ownStream)
     // around every search -- measured: the coder kernels ran twice as long)
     hipError_t e = hipSuccess;
     if (ownStream) {
-        if (const uint32_t sc = search_cus()) {
-            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (uint32_t b = 0; b < sc; ++b) mask[b >> 5] |= 1u << (b & 31u);
-            e = hipExtStreamCreateWithCUMask(&m->stream, 8, mask);
-        } else e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+        e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
         m->ownStream = e == hipSuccess;
     } else {
         std::lock_guard<std::mutex> g(g_poolMx);
         StreamPool& p = g_pool[dev->deviceId & 15];
         for (int i = 0; i < matchStreams() && e == hipSuccess; ++i) if (!p.s[i]) {
-            if (const uint32_t sc = search_cus()) {      // (the compute units the coder lanes leave alone: engine.hip, lane_init)
-                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (uint32_t b = 0; b < sc; ++b) mask[b >> 5] |= 1u << (b & 31u);
-                e = hipExtStreamCreateWithCUMask(&p.s[i], 8, mask);
-            } else e = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
+            e = hipStreamCreateWithFlags(&p.s[i], hipStreamNonBlocking);
         }
         if (e == hipSuccess) { m->stream = p.s[p.next++ % (unsigned)matchStreams()]; ++p.users; }
     }

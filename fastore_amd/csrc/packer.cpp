@@ -1318,7 +1318,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         timing.encode_ms += S.timing.encode_ms; timing.assemble_ms += S.timing.assemble_ms; timing.launches += S.timing.launches; timing.items += S.timing.items;
         timing.ppmd_symbols += S.timing.ppmd_symbols; timing.rc_symbols += S.timing.rc_symbols; timing.restarts += S.timing.restarts; timing.max_restarts = std::max(timing.max_restarts, S.timing.max_restarts); for (int w = 0; w < 16; ++w) timing.win[w] += S.timing.win[w];
         timing.h2d_bytes += S.timing.h2d_bytes; timing.d2h_bytes += S.timing.d2h_bytes;
-        timing.gather_ms += S.timing.gather_ms; timing.gather_symbols += S.timing.gather_symbols; timing.gather_bytes += S.timing.gather_bytes; timing.id_strings += S.timing.id_strings;
+        timing.gather_ms += S.timing.gather_ms; timing.gather_symbols += S.timing.gather_symbols; timing.gather_bytes += S.timing.gather_bytes; timing.id_strings += S.timing.id_strings; timing.tail_launches += S.timing.tail_launches;
         if (trace) fprintf(stderr, "[trace] slice %u/%u: %u bins, front end done at %.1f ms, staged+submitted at %.1f ms (%.0f MB; staging buffer %.1f ms), device done at %.1f ms (kernel %.1f ms)\n",
                            si + 1, nSlices, cut[si + 1] - cut[si], S.tReady - t0, S.tSubmit - t0, S.inBytes / 1e6, S.bufMs, S.tDone - t0, S.timing.encode_ms);
     }

@@ -122,6 +122,10 @@ typedef struct fsgpu_stats {
     /* mate search of paired-end bins on the device (fs_match_mates; FS_DEVICE_MATES=1: a bin at a time, 2: many bins a launch, nobody waits):
      * pairs searched, wall time of its calls (summed over the callers), HIP-event time of its kernels (summed over the launches) */
     uint64_t mate_pairs; double mate_call_ms, mate_kernel_ms;
+    /* From here on the layout is APPEND-ONLY: new counters go behind the last one, none is taken out (struct_bytes says how much
+     * of the struct the library filled, so a caller built against an older header reads what it knows and nothing shifted). */
+    uint64_t struct_bytes;               /* sizeof(fsgpu_stats) of the library that filled it */
+    uint64_t coder_tail_launches;        /* coder launches made again because none of a launch's workgroups found a free arena slot (no workgroup waits inside a kernel) */
 } fsgpu_stats;
 
 void fsgpu_config_defaults(fsgpu_config* cfg);

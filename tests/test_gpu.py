@@ -4,6 +4,7 @@ made by the real reference, (c) the real reference itself (oracle/_ref) on fresh
 libraries when its binaries travelled with the checkout."""
 import os
 import subprocess
+import time
 
 import numpy as np
 import pytest
@@ -260,10 +261,16 @@ def test_gpu_pack_is_deterministic_and_sizes_add_up(tmp_path):
     import fastore_amd
     name, paired, flags = manifest()[1]
     outs = []
-    for i, (waves, slices) in enumerate(((0, 1), (37, 1), (0, 6), (300, 3))):       # wave counts and pipeline slicing change scheduling, never the bytes
+    tails = []
+    # wave counts and pipeline slicing change scheduling, never the bytes.  (16, 6) and (300, 3): pools of 2 and 38 arena slots per XCD
+    # under several launches at once -- workgroups that find their XCD's slots taken leave without waiting, and a launch none of whose
+    # workgroups found one is made again (coder_tail_launches)
+    for i, (waves, slices) in enumerate(((0, 1), (37, 1), (0, 6), (300, 3), (16, 6))):
         with fastore_amd.Packer(device_id=0, max_waves=waves, pipeline_slices=slices, **knobs_from_flags(flags)) as p:
-            p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o%d" % i)))
+            st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o%d" % i)))
+            tails.append(p.stats()["coder_tail_launches"])
         outs.append(open(str(tmp_path / ("o%d.cdata" % i)), "rb").read())
+    print("coder tail launches per configuration:", tails)
     assert all(o == outs[0] for o in outs[1:])
     assert outs[0] == open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
 
@@ -663,3 +670,33 @@ def test_bench_two_ranks_rehearsed_on_one_device_against_the_live_reference(tmp_
     assert res["n_gpus"] == 2 and res["ranks"] == 2 and res["scaling"] == "weak" and res["collective_backend"].startswith("gloo")
     assert res["parity"]["every_library_every_block_bit_identical_to_reference"] and res["parity"]["per_library"] == [True, True], res["parity"]
     assert res["parity"]["strong_line_archive_identical_to_reference"] and res["strong"]["value"] > 0
+
+
+@pytest.mark.timeout(400, method="thread")
+def test_two_cli_processes_share_the_device_with_long_streams_and_both_end(tmp_path, ref_libs):
+    # Two `fastore_pack e` processes at once on the one device, DEFAULT environment, twenty rounds.  Rounds 1-4 had a workgroup without an
+    # arena slot spin inside its kernel for a workgroup of ANOTHER launch to free one; with two processes' hardware queues competing that
+    # was a standstill (profiles/r04_cli_two_processes.txt).  No workgroup waits for another any more (engine.hip: a full partition is left
+    # at once, the host launches again if nobody took the streams).  Each child has 120 s; a child that hangs is killed and fails the test.
+    import fastore_amd
+    binned, pe, _ = ref_libs.library("se_long")
+    ref, _ = ref_libs.packed("se_long")
+    t = str(tmp_path)
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES",)}
+    want = {e: open(ref + e, "rb").read() for e in (".cdata",)}
+    times = []
+    for rnd in range(20):
+        t0 = time.monotonic()
+        kids = [subprocess.Popen([fastore_amd.PACK_CLI, "e", "-i" + binned, "-o" + os.path.join(t, "o%d" % k)] + C1_FLAGS + pe, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE) for k in range(2)]
+        for k, kid in enumerate(kids):
+            try:
+                _, err = kid.communicate(timeout=120)
+            except subprocess.TimeoutExpired:
+                for x in kids:
+                    x.kill()
+                pytest.fail("round %d: process %d still running after 120 s beside another pack on the same device" % (rnd, k))
+            assert kid.returncode == 0, (rnd, k, err[-400:])
+        times.append(time.monotonic() - t0)
+        for k in range(2):
+            assert open(os.path.join(t, "o%d.cdata" % k), "rb").read() == want[".cdata"], (rnd, k)
+    print("two processes per round, seconds per round:", " ".join("%.1f" % x for x in times))
