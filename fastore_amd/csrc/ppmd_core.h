@@ -1012,6 +1012,9 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
 #if FS_WIDE
 #include "ppmd_window.h"
 #endif
+#if !defined(FS_WIN_SKIP1)
+  #define FS_WIN_SKIP1 1      // serial symbols coded without a window attempt after an attempt that coded nothing (the first three in a row)
+#endif
 
 // Encode one member.  `arena` = ARENA_BYTES of 16-byte aligned scratch (content irrelevant),
 // returns the member size (clipped at outCap like the reference's ByteStream::Put).
@@ -1076,7 +1079,7 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
 #if defined(FS_SER_PROFILE)
                 uint64_t tW = FS_PROF_NOW();
 #endif
-                const uint32_t penaltyIfNone = winPenalty + 1u, skipIfNone = penaltyIfNone <= 3u ? 1u : (penaltyIfNone >= 9u ? 64u : 1u << (penaltyIfNone - 3u));
+                const uint32_t penaltyIfNone = winPenalty + 1u, skipIfNone = penaltyIfNone <= 3u ? (uint32_t)FS_WIN_SKIP1 : (penaltyIfNone >= 9u ? 64u : 1u << (penaltyIfNone - 3u));
                 const uint32_t done = window_step(m, in, n, FS_UNI(pos), FS_UNI(MinContext), hist);
 #if defined(FS_SER_PROFILE)
                 if (done == 0u) FS_PROF_ACC(m.sh->serStats[4], tW);
