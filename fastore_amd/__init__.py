@@ -43,7 +43,7 @@ class Stats(C.Structure):
                 ("stolen_bins", C.c_uint64),
                 ("matcher_bases_h2d_bytes", C.c_uint64), ("matcher_unpacked_reads", C.c_uint64),
                 ("mate_pairs", C.c_uint64), ("mate_call_ms", C.c_double), ("mate_kernel_ms", C.c_double),
-                ("struct_bytes", C.c_uint64), ("coder_tail_launches", C.c_uint64)]
+                ("struct_bytes", C.c_uint64), ("ppmd_window_drops", C.c_uint64), ("coder_tail_launches", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

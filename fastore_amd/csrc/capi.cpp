@@ -746,7 +746,7 @@ int fsgpu_get_stats(const fsgpu_ctx* ctx, fsgpu_stats* out)
     out->gather_kernel_ms = ctx->c.timing.gather_ms; out->gather_symbols = ctx->c.timing.gather_symbols; out->gather_bytes = ctx->c.timing.gather_bytes;
     out->rc_symbols = ctx->c.timing.rc_symbols; out->ppmd_restarts = ctx->c.timing.restarts; out->ppmd_max_restarts = ctx->c.timing.max_restarts;
     out->h2d_bytes = ctx->c.timing.h2d_bytes; out->d2h_bytes = ctx->c.timing.d2h_bytes;
-    out->struct_bytes = sizeof(fsgpu_stats); out->coder_tail_launches = ctx->c.timing.tail_launches;
+    out->struct_bytes = sizeof(fsgpu_stats); out->ppmd_window_drops = ctx->c.timing.win[7]; out->coder_tail_launches = ctx->c.timing.tail_launches;
     return FSGPU_OK;
 }
 

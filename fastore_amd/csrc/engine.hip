@@ -251,6 +251,7 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
                 else if (t == 6u || t == 7u) v = sh.winStats[t];          // serial-path clocks: escapes, UpdateModel
 #else
                 if (t >= 1u && t <= 6u) v = sh.winStats[t - 1u];
+                else if (t == 7u) v = sh.winStats[7];                    // rescales that let states drop out inside windows
 #endif
                 else if (t >= 8u && t < 15u) v = sh.winStats[t];
                 else if (t == 15u) v = (uint32_t)((FS_PROF_NOW() - tStream) >> 6);

@@ -97,15 +97,16 @@ template <int N> FS_DEV uint32_t packed_find(const PackedT<N>& c, uint32_t ns, u
 
 // The reference's rescale for OrderFall == 0 (Model.cpp:246-280) on a packed list: found state (place kf) to the front,
 // frequencies halved, stable insertion sort by the halved frequencies -- a 19-step min/max network on one word per
-// state --, SummFreq rebuilt, the found state's bonus.  Returns false and changes nothing when a state would drop out
-// (frequency 1 -> 0): that path frees units (ShrinkUnits / FreeUnits) and stays with the serial code.
+// state --, SummFreq rebuilt, the found state's bonus.  States whose frequency was 1 drop out (nsOut = the NumStats field behind
+// the rescale; the caller shrinks the units when the window is committed: win_write_back).  Returns false and changes nothing
+// when only the found state would be left: that context turns binary (FreeUnits), which stays with the serial code.
 // K = 4: every context that rescales has at most four states (the caller checks, wave-wide): a five-step network and half
 // the packing
-template <int K, int N> FS_DEV bool packed_rescale(PackedT<N>& c, uint32_t ns, uint32_t kf, uint32_t& summ, uint32_t& flags)
+template <int K, int N> FS_DEV bool packed_rescale(PackedT<N>& c, uint32_t ns, uint32_t kf, uint32_t& summ, uint32_t& flags, uint32_t& nsOut)
 {
     typedef typename PackedT<N>::W W;
     uint32_t key[K];
-    uint32_t sumOld = 0, sumNew = 0, f0 = 0; bool zeros = false, hiAny = false;
+    uint32_t sumOld = 0, sumNew = 0, f0 = 0, zeros = 0; bool hiAny = false;
     #pragma unroll
     for (uint32_t j = 0; j < (uint32_t)K; ++j) {
         const uint32_t f = (uint32_t)(c.F >> (8u * j)) & 0xFFu, sy = (uint32_t)(c.S >> (8u * j)) & 0xFFu, pj = (c.P >> (4u * j)) & 0xFu, nf = f >> 1;
@@ -113,12 +114,14 @@ template <int K, int N> FS_DEV bool packed_rescale(PackedT<N>& c, uint32_t ns, u
         const uint32_t r = isF ? 0u : (j < kf ? j + 1u : j);                 // place after the move-to-front
         if (valid) { sumOld += f; sumNew += nf; }
         if (valid && isF) f0 = f;
-        if (valid && !isF && nf == 0u) zeros = true;
+        if (valid && !isF && nf == 0u) ++zeros;
         if (valid && !isF && nf != 0u && sy >= 0x40u) hiAny = true;
-        // descending order of the keys = the reference's order: halved frequency, then the earlier place; found state on top
+        // descending order of the keys = the reference's order: halved frequency, then the earlier place; found state on top.  A state
+        // that drops out (frequency 1 -> 0; Model.cpp:264-275) keeps a key below every state that stays and above the unused places
         key[j] = !valid ? 0u : (((isF ? 0xFFu : nf) << 24) | ((15u - r) << 20) | (nf << 12) | (sy << 4) | pj);
     }
-    if (zeros) return false;
+    nsOut = ns - zeros;
+    if (nsOut == 0u && zeros != 0u) return false;                           // one state left: the context turns binary (units freed) -- the serial path's business
     #define FS_CE(a, b) do { const uint32_t hi_ = fs_umax(key[a], key[b]), lo_ = fs_umin(key[a], key[b]); key[a] = hi_; key[b] = lo_; } while (0)
     if (K == 8) {
         FS_CE(0, 1); FS_CE(2, 3); FS_CE(4 % K, 5 % K); FS_CE(6 % K, 7 % K);
@@ -132,7 +135,7 @@ template <int K, int N> FS_DEV bool packed_rescale(PackedT<N>& c, uint32_t ns, u
         FS_CE(0, 1); FS_CE(2, 3); FS_CE(0, 2); FS_CE(1, 3); FS_CE(1, 2);
     }
     #undef FS_CE
-    const uint32_t escFreq = summ - sumOld, nf0 = f0 >> 1;
+    const uint32_t escFreq = summ - sumOld + zeros, nf0 = f0 >> 1;          // (EscFreq += the states that dropped out: Model.cpp:268)
     uint32_t s = sumNew + ((escFreq + 1u) >> 1), a;
     if ((flags & 0x04u) == 0u) {
         const uint32_t sfm = summ - escFreq;
@@ -144,8 +147,9 @@ template <int K, int N> FS_DEV bool packed_rescale(PackedT<N>& c, uint32_t ns, u
     W S = 0, F = 0; uint32_t P = 0;
     #pragma unroll
     for (uint32_t j = 0; j < (uint32_t)K; ++j) {
-        S |= (W)((key[j] >> 4) & 0xFFu) << (8u * j);
-        F |= (W)(j == 0u ? nf0 + a : ((key[j] >> 12) & 0xFFu)) << (8u * j);
+        const bool stays = j <= nsOut;                                    // the places behind the last state that stays hold nothing
+        S |= (W)(stays ? (key[j] >> 4) & 0xFFu : 0u) << (8u * j);
+        F |= (W)(!stays ? 0u : (j == 0u ? nf0 + a : ((key[j] >> 12) & 0xFFu))) << (8u * j);
         P |= (key[j] & 0xFu) << (4u * j);
     }
     c.S = S; c.F = F; c.P = P;
@@ -166,7 +170,10 @@ template <int N> FS_DEV bool packed_rescale_quick_ok(const PackedT<N>& c, uint32
     const W nf = (W)(c.F >> 1) & fs_rep8<W>(0x7Fu) & vm;
     const W ge = (W)((nf | fs_rep8<W>(0x80u)) - (W)(nf >> 8)) & fs_rep8<W>(0x80u);          // byte j: nf[j] >= nf[j+1] (both below 128: no borrow crosses a byte)
     const W need = (W)(vm >> 8) & (W)~(W)0xFFu & fs_rep8<W>(0x80u);                         // places 1 .. ns-1
-    return kf == 0u && (ge & need) == need;
+    // ... and no state but the found one drops to zero (those lists are compacted by the network form)
+    const W zx = nf | (W)0xFFu | (W)~vm;
+    const bool zeros = ((W)(zx - fs_rep8<W>(1u)) & (W)~zx & fs_rep8<W>(0x80u)) != (W)0;
+    return kf == 0u && !zeros && (ge & need) == need;
 }
 
 template <int N> FS_DEV bool packed_rescale_quick(PackedT<N>& c, uint32_t ns, uint32_t& summ, uint32_t& flags, bool live)
@@ -223,6 +230,7 @@ template <int N> struct WinFetch : WinHead {   // ... and its state list, as fet
 template <int N> struct WinSolved {            // per lane, after the rounds
     uint32_t ownerLane; bool owner;
     PackedT<N> c; uint32_t summ, flags;        // an owner's context after all its positions
+    uint32_t ns; bool dropped; uint32_t dropPos;   // ... its NumStats field then; a rescale of the window let states drop out (one per context and window at most), at this position
     uint32_t tA, tM;                // the position's price: cumulative frequency | frequency << 16 | PrevSuccess << 23 ; the total
 };
 
@@ -301,7 +309,7 @@ template <int N> FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, ui
         E = bad ? fs_ctz64(bad) : 64u;
         if (s >= 64u) E = s;
     }
-    o.ownerLane = lane; o.owner = false; o.c = f.c; o.summ = f.r0 >> 16; o.flags = (f.r0 >> 8) & 0xFFu; o.tA = 0; o.tM = 0;
+    o.ownerLane = lane; o.owner = false; o.c = f.c; o.summ = f.r0 >> 16; o.flags = (f.r0 >> 8) & 0xFFu; o.tA = 0; o.tM = 0; o.ns = f.ns; o.dropped = false; o.dropPos = 0;
     FS_PROF_ACC_W(m.sh->winStats[9], tp);                            // state lists, find, chain
     if (E <= s) return E;
 
@@ -387,9 +395,11 @@ template <int N> FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, ui
     // lists, the chain, the context sets and the closed-form prices of the positions that stay do not depend on
     // the positions that go.
     PackedT<N> c; uint32_t summ, flags;
+    uint32_t nsCur, dropPos; bool dropped;       // an owner's NumStats field as the rounds go (a rescale may let states drop out: once per context and window)
     for (;;) {
         inWin = lane >= s && lane < E; owner = inWin && ownerLane == lane;
         c = f.c; summ = summ0; flags = flags0; rlo = rhi = 0u; rounds = 0;
+        nsCur = ns; dropped = false; dropPos = 0u;
         {   // the owner: what its context's finished positions added, and what is left for the rounds
             const uint64_t lim = (E >= 64u ? ~0ull : (1ull << E) - 1ull) & (~0ull << s);
             const uint64_t doneSet = (cfFirstBad < 64u ? cfSm & ((1ull << cfFirstBad) - 1ull) : cfSm) & lim;
@@ -419,8 +429,8 @@ template <int N> FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, ui
             { const uint32_t nlo = rlo & (rlo - 1u), nhi = rhi & (rhi - 1u); rhi = rlo == 0u ? nhi : rhi; rlo = nlo; }
             const uint32_t sy = fs_bperm(sym, p);
             // encodeSymbol1 + update1 on the owner's copy (Model.cpp:447-481)
-            const uint32_t kk = packed_find<N>(c, ns, sy);
-            const bool lost = act && kk >= 8u;                        // cannot happen while nothing drops out; never trust it
+            const uint32_t kk = packed_find<N>(c, nsCur, sy);
+            const bool lost = act && kk >= 8u;                        // the symbol's state dropped out in a rescale of this window: an escape, the serial path's
             const bool go = act && !lost;
             const uint32_t k8 = 8u * (kk & 7u);
             const uint32_t fr = (uint32_t)(c.F >> k8) & 0xFFu, fPrev = (kk & 7u) ? (uint32_t)(c.F >> ((k8 - 8u) & (8u * N - 1u))) & 0xFFu : 0u;
@@ -451,22 +461,32 @@ template <int N> FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, ui
             if (fs_ballot(resc) != 0ull) {
                 PackedT<N> c2 = c; uint32_t summ2 = summ, flags2 = flags;
                 const uint32_t kf = doSwap ? kk - 1u : kk;
-                bool done;
-                if (fs_ballot(resc && !packed_rescale_quick_ok<N>(c, ns, kf)) == 0ull) {
-                    done = packed_rescale_quick<N>(c2, ns, summ2, flags2, resc);
+                bool done; uint32_t nsOut = nsCur;
+                if (fs_ballot(resc && !packed_rescale_quick_ok<N>(c, nsCur, kf)) == 0ull) {
+                    done = packed_rescale_quick<N>(c2, nsCur, summ2, flags2, resc);
 #if defined(FS_SIMT_EMU)
                     {   // the lock-step emulation holds the short form against the network, lane by lane
-                        PackedT<N> c3 = c; uint32_t summ3 = summ, flags3 = flags;
-                        const bool done3 = packed_rescale<N, N>(c3, ns, kf, summ3, flags3);
-                        if (resc && (done3 != done || (done && (c3.S != c2.S || c3.F != c2.F || c3.P != c2.P || summ3 != summ2 || flags3 != flags2)))) {
-                            fprintf(stderr, "packed_rescale_quick differs from the network (ns %u)\n", ns); abort();
+                        PackedT<N> c3 = c; uint32_t summ3 = summ, flags3 = flags, ns3 = nsCur;
+                        const bool done3 = packed_rescale<N, N>(c3, nsCur, kf, summ3, flags3, ns3);
+                        if (resc && (done3 != done || ns3 != nsCur || (done && (c3.S != c2.S || c3.F != c2.F || c3.P != c2.P || summ3 != summ2 || flags3 != flags2)))) {
+                            fprintf(stderr, "packed_rescale_quick differs from the network (ns %u)\n", nsCur); abort();
                         }
                         if (resc) simt_count_quick_rescale();
                     }
 #endif
-                } else done = fs_ballot(resc && ns > 3u) == 0ull ? packed_rescale<4, N>(c2, ns, kf, summ2, flags2) : packed_rescale<(N == 8 ? 8 : 4), N>(c2, ns, kf, summ2, flags2);
-                if (resc && done) { c = c2; summ = summ2; flags = flags2; }
-                if (resc && !done) cut = true;                     // a state drops out: the serial path takes this symbol
+                } else done = fs_ballot(resc && nsCur > 3u) == 0ull ? packed_rescale<4, N>(c2, nsCur, kf, summ2, flags2, nsOut) : packed_rescale<(N == 8 ? 8 : 4), N>(c2, nsCur, kf, summ2, flags2, nsOut);
+                // States dropped out (frequency 1 -> 0: Model.cpp:264-275).  The list is compact in the registers already; its units are
+                // shrunk when the window is committed, in stream order with the other contexts' (win_write_back).  A second such rescale
+                // of one context inside one window is left to the serial path: the reference would shrink its units twice, with other
+                // contexts' blocks moving through the free lists in between.
+                const bool drops = resc && done && nsOut != nsCur;
+                if (resc && done && !(drops && dropped)) { c = c2; summ = summ2; flags = flags2; nsCur = nsOut; }
+                if (drops && dropped) cut = true;
+#if !defined(FS_WIN_PROFILE)
+                { const uint32_t nDrops = fs_popc64(fs_ballot(drops && !dropped)); FS_STAT_ADD(m.sh->winStats[7], nDrops); }      // rescales that let states drop out inside a window (profile builds keep a clock in this word)
+#endif
+                if (drops && !dropped) { dropped = true; dropPos = p; }
+                if (resc && !done) cut = true;                     // the context turns binary: the serial path takes this symbol
             }
             myCut = cut && p < myCut ? p : myCut;
             rlo = cut ? 0u : rlo; rhi = cut ? 0u : rhi;
@@ -488,7 +508,7 @@ template <int N> FS_DEV uint32_t win_solve(Coder& m, fs_cgptr in, uint32_t n, ui
     inWin = lane >= s && lane < E;
     // every position's price: its own (closed form), or what its owner left in its slot
     o.tA = inWin ? (cfDone ? cfA : m.sh->winA[lane]) : 0u; o.tM = inWin ? (cfDone ? cfM : m.sh->winM[lane]) : 0u;
-    o.ownerLane = ownerLane; o.owner = owner; o.c = c; o.summ = summ; o.flags = flags;
+    o.ownerLane = ownerLane; o.owner = owner; o.c = c; o.summ = summ; o.flags = flags; o.ns = nsCur; o.dropped = owner && dropped; o.dropPos = dropPos;
     FS_WAVE_SYNC();
     return E;
 }
@@ -501,9 +521,22 @@ template <int N> FS_DEV void win_write_back(Coder& m, const WinFetch<N>& f, cons
     #pragma unroll
     for (int j = 0; j < N; ++j) m.sh->winTab[8u * lane + (uint32_t)j] = f.sc[j];
     FS_WAVE_SYNC();
+    // Contexts whose lists lost states in a rescale of this window: their units shrink now (ShrinkUnits, SubAlloc.hpp:170-184 -- a
+    // block of the right size from the free list if there is one, else the tail split off), one context after the other in the
+    // order of the positions that rescaled them: the free lists are stacks, the order of the calls is part of the model's state.
+    // (Nothing else of the window touches the allocator, and the episode behind the window comes behind all of them.)
+    uint32_t stats = f.stats;
+    for (uint64_t dr = fs_ballot(o.owner && o.dropped); dr != 0ull;) {
+        uint32_t j = fs_ctz64(dr), best = FS_UNI(fs_readlane(o.dropPos, j));
+        for (uint64_t t = dr & (dr - 1ull); t != 0ull; t &= t - 1ull) { const uint32_t b = fs_ctz64(t), pb = FS_UNI(fs_readlane(o.dropPos, b)); if (pb < best) { best = pb; j = b; } }
+        const uint32_t st0 = FS_UNI(fs_readlane(f.stats, j)), ns0 = FS_UNI(fs_readlane(f.ns, j)), ns1 = FS_UNI(fs_readlane(o.ns, j));
+        const uint32_t st1 = ShrinkUnits(m, st0, (ns0 + 2u) >> 1, (ns1 + 2u) >> 1);
+        if (lane == j) stats = st1;
+        dr &= ~(1ull << j);
+    }
     if (o.owner) {
-        fs_gptr32 p = (fs_gptr32)HP(f.stats);
-        const uint32_t nst = f.ns + 1u;
+        fs_gptr32 p = (fs_gptr32)HP(stats);
+        const uint32_t nst = o.ns + 1u;
         uint32_t w[3 * N / 2], sf[N], so[N];
         #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -520,7 +553,8 @@ template <int N> FS_DEV void win_write_back(Coder& m, const WinFetch<N>& f, cons
         const uint32_t units = (nst + 1u) >> 1;
         #pragma unroll
         for (int u = 0; u < N / 2; ++u) if ((uint32_t)u < units) { p[3 * u] = w[3 * u]; p[3 * u + 1] = w[3 * u + 1]; p[3 * u + 2] = w[3 * u + 2]; }
-        *(fs_gptr32)HP(f.addr) = f.ns | (o.flags << 8) | (o.summ << 16);
+        *(fs_gptr32)HP(f.addr) = o.ns | (o.flags << 8) | (o.summ << 16);
+        if (stats != f.stats) *(fs_gptr32)(HP(f.addr) + 4u) = stats;
     }
     FS_WAVE_SYNC();
 }

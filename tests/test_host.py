@@ -41,7 +41,7 @@ def test_c_abi_exports_every_declared_symbol(product_lib):
 def test_structs_match_header_layout(product_lib):
     import fastore_amd
     assert ctypes.sizeof(fastore_amd.Config) == 96
-    assert ctypes.sizeof(fastore_amd.Stats) == 352
+    assert ctypes.sizeof(fastore_amd.Stats) == 360
     cfg = fastore_amd.Config()
     product_lib.fsgpu_config_defaults(ctypes.byref(cfg))
     # reference defaults: fastore_pack/Params.h:18-147, fastore_bin/Globals.h:61-62

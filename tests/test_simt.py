@@ -32,7 +32,7 @@ def encode(lib, data):
     st = (ctypes.c_uint64 * 8)()
     # the device batch pads every stream to 16 bytes: the window reads whole aligned words around the last symbols
     n = lib.simt_ppmd_encode(data + b"\0" * 32, len(data), buf, len(buf), None, st)
-    return buf.raw[:n], {"attempts": st[0], "windows": st[1], "covered": st[2], "rounds": st[3], "redone": st[4]}
+    return buf.raw[:n], {"attempts": st[0], "windows": st[1], "covered": st[2], "rounds": st[3], "redone": st[4], "drops": st[7]}
 
 
 def quality(n, seed, read_len=150):
@@ -52,6 +52,8 @@ def test_windowed_hit_path_reproduces_the_serial_walk_on_quality_streams(simt, o
     assert got == oracle_ppmd(oracle, data)
     # the path under test really ran: most of the stream went through windows, with shared contexts and redone windows
     assert st["covered"] > 0.7 * len(data) and st["rounds"] > st["windows"] and st["redone"] > 0, st
+    # rescales that let states drop out of their context were taken inside windows (their units shrunk at the window's commit)
+    assert st["drops"] > 100, st
     # most rescales inside the rounds take the short form (no sorting network); the emulation build holds every one of them
     # against the network and aborts on a difference
     assert simt.simt_quick_rescales() > 1000
