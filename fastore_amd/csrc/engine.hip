@@ -236,24 +236,23 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
             KernArgs k2 = kernargs();
             if (threadIdx.x == 0 && !(TWO && kind == KIND_PPMD && n > 0) && !rcQueued) k2->outSizes[it] = size;       // (two-wave form: a PPMd member's size comes from the coder wave)
             // per-stream telemetry: [0] model restarts, [1..6] windowed hit path (attempts, windows, symbols, rounds, redone
-            // windows, light rounds), [8..14] phase clocks / 64 and [15] the stream's whole time / 64 (FS_WIN_PROFILE builds, else 0)
+            // windows, light rounds), [7] rescales inside windows that let states drop out; FS_WIN_PROFILE builds:
+            // [6..7] the serial path's clocks, [8..14] phase clocks / 64 and [15] the stream's whole time / 64
             const uint32_t t = threadIdx.x;
             uint32_t v = 0;
             if (kind == KIND_PPMD && n > 0) {
 #if defined(FS_SER_PROFILE)
                 if (t >= 1u && t <= 5u) v = sh.serStats[t - 1u];       // (design study: the serial path's clocks in place of the window counters)
                 else if (t == 6u || t == 7u) v = sh.winStats[t];
-                if (t == 3u) v = sh.serStats[5];                        // rescales inside rounds
-                if (t == 1u) v = sh.serStats[6];                        // swaps inside rounds
-                if (t == 2u) v = sh.serStats[7];                        // positions walked in rounds
+                else if (t >= 8u && t < 15u) v = sh.winStats[t];
 #elif defined(FS_WIN_PROFILE)
                 if (t >= 1u && t <= 5u) v = sh.winStats[t - 1u];
                 else if (t == 6u || t == 7u) v = sh.winStats[t];          // serial-path clocks: escapes, UpdateModel
+                else if (t >= 8u && t < 15u) v = sh.winStats[t];
 #else
                 if (t >= 1u && t <= 6u) v = sh.winStats[t - 1u];
                 else if (t == 7u) v = sh.winStats[7];                    // rescales that let states drop out inside windows
 #endif
-                else if (t >= 8u && t < 15u) v = sh.winStats[t];
                 else if (t == 15u) v = (uint32_t)((FS_PROF_NOW() - tStream) >> 6);
             }
             if (t == 0u) v = rs;

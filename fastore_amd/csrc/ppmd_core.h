@@ -1012,9 +1012,7 @@ FS_DEV void encodeSymbol2(Coder& m, uint32_t c, Ctx& mc, int symbol, Ctx& sufRec
 #if FS_WIDE
 #include "ppmd_window.h"
 #endif
-#if !defined(FS_WIN_SKIP1)
-  #define FS_WIN_SKIP1 1      // serial symbols coded without a window attempt after an attempt that coded nothing (the first three in a row)
-#endif
+
 
 // Encode one member.  `arena` = ARENA_BYTES of 16-byte aligned scratch (content irrelevant),
 // returns the member size (clipped at outCap like the reference's ByteStream::Put).
@@ -1079,7 +1077,7 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
 #if defined(FS_SER_PROFILE)
                 uint64_t tW = FS_PROF_NOW();
 #endif
-                const uint32_t penaltyIfNone = winPenalty + 1u, skipIfNone = penaltyIfNone <= 3u ? (uint32_t)FS_WIN_SKIP1 : (penaltyIfNone >= 9u ? 64u : 1u << (penaltyIfNone - 3u));
+                const uint32_t penaltyIfNone = winPenalty + 1u, skipIfNone = penaltyIfNone <= 3u ? 0u : (penaltyIfNone >= 9u ? 64u : 1u << (penaltyIfNone - 3u));
                 const uint32_t done = window_step(m, in, n, FS_UNI(pos), FS_UNI(MinContext), hist);
 #if defined(FS_SER_PROFILE)
                 if (done == 0u) FS_PROF_ACC(m.sh->serStats[4], tW);
@@ -1087,7 +1085,8 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
                 // a window that stopped short did so in front of a symbol for the serial path: skip one attempt.  An attempt
                 // that codes nothing doubles the pause (learning phase of a model, unpredictable streams).
                 // (a failed attempt costs less than half a serial symbol, and the symbols behind a read boundary are plain hits
-                // again after two or three: the pause only starts to grow with the fourth failure in a row)
+                // again after two or three: the first three failures in a row cost no pause at all -- round 5: 454 -> 449 ms on a
+                // lone 3 M-symbol stream against a pause of one symbol --, then it grows)
                 if (done != 0u) { winPenalty = 0; winSkip = done < 64u ? 1u : 0u; }
                 else { ++winPenalty; winSkip = skipIfNone; }
                 if (done != 0u) {
