@@ -104,6 +104,7 @@ struct Coder {
     uint32_t pfCtx; CtxRaw pf;     // record of the next symbol's first context, requested ahead of this symbol's stores (0 = none)
     uint32_t inAhead;              // windowed path: the input has been pulled into the cache up to here
     uint32_t ldsHeads;             // the sub-allocator's list heads live in LDS (else behind the heap)
+    uint32_t newCtx;               // the context the walk stands in was made by the last symbol's CreateSuccessors: a binary context, no window starts there
 };
 
 #if defined(FS_HEAP_STATS)      // design study (tools/heap_locality.cpp, host emulation only): which heap addresses the walk touches
@@ -574,6 +575,7 @@ FS_DEV uint32_t CreateSuccessors(Coder& m, bool Skip, uint32_t p, uint32_t pSucc
         fs_st32(HP(pc1), w0); fs_st32(HP(pc1) + 4, iUpBranch + 1u); fs_st32(HP(pc1) + 8, pc);
         S_SUCC_SET(ps[--pps], pc = pc1);
     } while (pps != 0);
+    m.newCtx = pc;
     return pc;
 }
 
@@ -1028,7 +1030,7 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
     // -- "the ring is empty" -- held in practice, the model's start-up outlasts any backlog, but was a promise nobody made:
     // found on the lock-step emulation at the end of round 3, where a range-coded stream's last windows were still in the ring)
     m.queued = queued ? 1u : 0u; m.qTail = qTail; m.qHeadSeen = qTail - CQ_SIZE;
-    m.inAhead = 0;
+    m.inAhead = 0; m.newCtx = 0;
     m.NumMasked = 0; m.FoundState = 0; m.BSumm = 0; m.rLow = m.rHigh = m.rScale = 0; m.fsSym = m.fsFreq = m.fsSucc = 0;
     for (uint32_t i = (uint32_t)FS_LANE(); i < 16u; i += FS_WAVE) sh->winStats[i] = 0u;
 #if defined(FS_SER_PROFILE)
@@ -1072,8 +1074,12 @@ FS_DEV uint32_t encode_member(fs_gptr arena, FS_LDS Shared* sh, fs_cgptr in, uin
 #if FS_WIDE
         if (windows && FS_UNI((uint32_t)m.OrderFall) == 0u && FS_UNI(pos) >= 4u && FS_UNI(pos) < n) {
             hint_learn(m, FS_UNI(hist), FS_UNI(MinContext));
+            // (a context CreateSuccessors has just made holds one symbol: no window starts in a binary context, and the attempt that
+            // finds that out costs a fetch of 64 positions -- 9 000 of 73 000 attempts on a 3 M-symbol quality stream)
+            const bool fresh = FS_UNI(m.newCtx) == FS_UNI(MinContext);
+            m.newCtx = 0;
             if (FS_UNI(winSkip) != 0u) --winSkip;
-            else {
+            else if (!fresh) {
 #if defined(FS_SER_PROFILE)
                 uint64_t tW = FS_PROF_NOW();
 #endif

@@ -26,7 +26,7 @@ with fastore_amd.Packer(lib=_lib, device_id=0, max_waves=int(sys.argv[2]) if len
         print("   windows: %.1f %% of the symbols in %d windows (%.1f symbols, %.2f rounds per window, %.2f of the windows without a round; %d attempts, %d redone)" % (
             100.0 * st["ppmd_window_symbols"] / max(1, st["ppmd_symbols"]), st["ppmd_windows"], st["ppmd_window_symbols"] / w, st["ppmd_window_rounds"] / w, st["ppmd_window_light_rounds"] / w,
             st["ppmd_window_attempts"], st["ppmd_windows_redone"]), flush=True)
-        print("   %d rescales inside windows let states drop out" % st["ppmd_window_drops"], flush=True)
+        print("   %d rescales inside windows let states drop out; coder tail launches %d" % (st.get("ppmd_window_drops", 0), st.get("coder_tail_launches", 0)), flush=True)
         if "serprof" in os.environ.get("FS_LIB", ""):      # -DFS_SER_PROFILE builds: the serial path's clocks ride in the window counters' places
             ns = max(1, st["ppmd_window_rounds"])
             print("   serial path (FS_SER_PROFILE): %d serial symbols; clocks per serial symbol: start -> first context ready %.0f, first-context coding + hand-off %.0f, tail of the loop %.0f; failed window attempts %.0f" % (
