@@ -12,12 +12,13 @@ Workload (BASELINE.json configs[1]): ONE library of 10 M x 150 b
 47 660 reads, so its quality streams run up to 7.15 M PPMd symbols: the shape that decides the device step.
 `--paired` packs ONE library of --reads pairs instead (configs[2] scaled by the stated factor).
 
---gpus N > 1 (default, "scaling": "weak" -- per-GPU work fixed): the job is a SET of N such libraries (seeds 8 .. 8+N-1,
-prepared side by side, one per rank); every rank codes its LPT share (over the .bmeta per-signature totals) of EVERY
-library's bins in one device pipeline, the only collective is ONE all-reduce of the concatenated block-size tables (one
-u64 per block) over RCCL, every rank writes its blocks at their offsets in the N archives.  `--strong` shards the ONE
-library of the N = 1 run instead (its step is bound by single streams, which more GPUs do not shorten: expect a flat
-curve); `--replicas` makes every rank pack the whole library into its own archive.
+--gpus N > 1 (default, `value`, "scaling": "strong" -- total work fixed): the ONE library of the N = 1 run, bin-sharded over the N
+ranks as BASELINE.json's configs[3] / configs[4] ask (every rank codes its LPT share, over the .bmeta per-signature totals, of the
+library's bins; the only collective is ONE all-reduce of the block-size table, one u64 per block, over RCCL; every rank writes its
+blocks at their offsets in the one archive).  Its step is bound by single streams, which more GPUs do not shorten: reported as
+measured.  Beside it, key `weak_set` ("scaling": "weak" -- per-GPU work fixed): a SET of N such libraries (seeds 8 .. 8+N-1,
+prepared side by side, one per rank), every rank its share of EVERY library's bins in one device pipeline.  `--strong`: the
+headline alone; `--weak-set`: the set as the headline (rounds 3-4's line); `--replicas`: every rank packs the whole library.
 
 cpu_baseline = the real reference fastore_pack (oracle/_ref) on the same library at -t min(32, cores) (and at
 -t1 with --cpu-t1, ~4 min); parity = every block of the product's archive against the reference's block of the same
@@ -351,7 +352,8 @@ def main():
     ap.add_argument("--cpu-sweep", action="store_true", help="also time the reference at -t16 and -t48 once")
     ap.add_argument("--no-cli", action="store_true", help="skip the end-to-end run of the fastore_pack CLI (process start -> exit)")
     ap.add_argument("--paired", action="store_true", help="the headline leg packs ONE paired-end library of --reads pairs (configs[2] scaled)")
-    ap.add_argument("--pe-reads", type=int, default=15_000_000, help="pairs of the paired-end leg of the N = 1 line (configs[2] scaled to what the run's window holds)")
+    ap.add_argument("--pe-reads", type=int, default=25_000_000, help="pairs of the paired-end leg of the N = 1 line (configs[2] scaled to what the run's window holds)")
+    ap.add_argument("--weak-set", action="store_true", help="--gpus N: the SET of N libraries is the headline (`value`), the ONE-library line the side key")
     ap.add_argument("--no-pe", action="store_true", help="N = 1: the headline leg only (skips the paired-end leg and the --reduced leg)")
     ap.add_argument("--no-reduced", action="store_true", help="N = 1: skip the --reduced leg (the same reads with 8-bin quality scores)")
     ap.add_argument("--no-lossy", action="store_true", help="N = 1: skip the --lossy leg (the same reads with QVZ-coded quality scores)")
@@ -419,16 +421,19 @@ def main():
                 legs.append(("lossy", name + "_lossy", args.reads, False, genome, "lossy"))
         # every leg's library is generated and binned by the reference's tools BEFORE the first timed step, side by side (the
         # stages are untimed, but one after the other they were half of the run's wall time)
-        per = max(4, min(32, cores // max(1, len(legs))))
         errs = {}
 
-        def prep(leg):
+        def prep(leg, workers):
             try:
-                prepare_library(args.work, leg[1], leg[2], L, leg[4], 8, per, leg[3], leg[5])
+                prepare_library(args.work, leg[1], leg[2], L, leg[4], 8, workers, leg[3], leg[5])
             except Exception as e:      # noqa: BLE001
                 errs[leg[0]] = "%s: %s" % (type(e).__name__, e)
         t0 = time.time()
-        th = [threading.Thread(target=prep, args=(leg,)) for leg in legs]
+        # the paired-end library is the long pole (25 M pairs: 16 GB of FASTQ through four stages of the reference's tools): it starts
+        # first and keeps 32 workers (the tools' limit is 64, their best here 32); the single-end libraries share the other cores
+        big = [leg for leg in legs if leg[3]]; small = [leg for leg in legs if not leg[3]]
+        per_small = max(4, min(32, (cores - (32 if big else 0)) // max(1, len(small)))) if cores >= 64 else max(4, min(32, cores // max(1, len(legs))))
+        th = [threading.Thread(target=prep, args=(leg, min(32, cores))) for leg in big] + [threading.Thread(target=prep, args=(leg, per_small)) for leg in small]
         for t in th:
             t.start()
         for t in th:
@@ -436,14 +441,24 @@ def main():
         prep_all_s = time.time() - t0
         if "main" in errs:
             raise SystemExit("could not prepare the headline library: " + errs["main"])
-        traffic_file = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json") if (args.reads == 10_000_000 and not args.paired and QUALITY == "lossless") else None
+        # HBM bytes per step of every leg: from the committed counter passes of this very command (tools/pmc_passes.sh -> tools/hbm_traffic.py),
+        # newest round first; a leg whose passes were not taken says null
+        def traffic_of(key):
+            if not (args.reads == 10_000_000 and not args.paired and QUALITY == "lossless"):
+                return None
+            for rnd in ("r05", "r04"):
+                f = os.path.join(ROOT, "profiles", "%s_hbm_traffic%s.json" % (rnd, "" if key == "main" else "_" + key))
+                if os.path.exists(f) and (key == "main" or args.pe_reads == json.load(open(f)).get("pe_reads", args.pe_reads)):
+                    return f
+            return None
+        traffic_file = traffic_of("main")
         # every leg's fastore_pack e PROCESS first, while this process has not opened the device (cli_phase says why)
         clis = {}
         if not args.no_cli:
             for key, lname, lreads, lpaired, lgenome, lq in legs:
                 if key not in errs:
                     try:
-                        clis[key] = cli_phase(fastore_amd, args, args.work, lname, lreads, lpaired, lgenome, cores, 3, quality=lq)
+                        clis[key] = cli_phase(fastore_amd, args, args.work, lname, lreads, lpaired, lgenome, cores, 3 if key == "main" else 2, quality=lq)
                     except Exception as e:      # noqa: BLE001
                         say("leg %s: the process could not be timed: %s" % (lname, e))
         # Every leg is measured by a process of its own, one after the other; this process never opens the device.  (Two reasons: a leg that
@@ -457,39 +472,57 @@ def main():
             sf = os.path.join(args.work, "leg_%s.json" % key)
             json.dump(spec, open(sf, "w"))
             env = dict(os.environ, FS_BENCH_T0=repr(_T0))
+            # (a session of its own: at its time limit the leg goes with everything it started -- the reference's pack is its grandchild)
+            proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--one-leg", sf], stdout=subprocess.PIPE, env=env, start_new_session=True)
             try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--one-leg", sf], stdout=subprocess.PIPE, env=env, timeout=limit_s)
+                stdout, _ = proc.communicate(timeout=limit_s)
             except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
                 raise RuntimeError("the leg's process did not end within %d s and was stopped" % limit_s)
-            if r.returncode != 0:
-                raise RuntimeError("the leg's process ended with code %d" % r.returncode)
-            out = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            if proc.returncode != 0:
+                raise RuntimeError("the leg's process ended with code %d" % proc.returncode)
+            out = json.loads(stdout.decode().strip().splitlines()[-1])
             return out["leg"], out["device"]
         ref_s = 0 if args.no_cpu_baseline else 120 + (240 if args.cpu_t1 else 0) + (200 if args.cpu_sweep else 0)
-        leg, dev = leg_process("main", name, args.reads, args.paired, genome, QUALITY, args.steps, args.warmup, 240 + 12 * (args.steps + args.warmup) * max(1, args.reads // 10_000_000 * (3 if args.paired else 1)) + ref_s,
-                               traffic_file, args.cpu_sweep)
+        budget_end = _T0 + float(os.environ.get("FS_BENCH_BUDGET_S", "560"))
+        main_limit = 240 + 12 * (args.steps + args.warmup) * max(1, args.reads // 10_000_000 * (3 if args.paired else 1)) + ref_s
+        try:
+            leg, dev = leg_process("main", name, args.reads, args.paired, genome, QUALITY, args.steps, args.warmup, int(max(60.0, min(main_limit, budget_end - time.time() - 5.0))),
+                                   traffic_file, args.cpu_sweep)
+        except Exception as e:          # noqa: BLE001  (the line is printed in any case: what was measured before stays in it)
+            leg, dev = {"value": None, "ms_per_step": None, "error": "%s: %s" % (type(e).__name__, e), "process": {k: v for k, v in clis.get("main", {}).items() if k != "_archive"} or None}, None
 
         res = {"metric": "fastore_pack compressed MB/s (input FASTQ)", "value": leg["value"], "unit": "MB/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                "value_is": "the K timed warm steps (file to file, context made); `process` holds SURVEY 8(d)'s process start -> exit, `speedup` both ratios"}
+        # (the keys the line is read for first: the process, both ratios, the roofline, the reference, parity -- then the rest)
+        for k in ("config", "process", "speedup", "speedup_vs_cpu_baseline", "speedup_vs_cpu_baseline_regime", "roofline", "cpu_baseline", "parity"):
+            if k in leg:
+                res[k] = leg[k]
         for k, v in leg.items():
             if k not in res:
                 res[k] = v
-        res["stages_ms_per_step_rank0"] = res.pop("stages_ms_per_step")
+        if "stages_ms_per_step" in res:
+            res["stages_ms_per_step_rank0"] = res.pop("stages_ms_per_step")
         res["device"] = dev; res["host_cores"] = cores; res["prep_all_legs_s"] = round(prep_all_s, 1)
         for key, lname, lreads, lpaired, lgenome, lq in legs[1:]:
             # (a leg beside the headline must never cost the line itself: what goes wrong in it is reported in its place)
             if key in errs:
                 res[key] = {"error": errs[key]}
                 continue
-            ls, lw = (max(1, min(args.steps, 5)), max(1, min(args.warmup, 2))) if key == "pe" else (max(1, min(args.steps, 3)), 1)
+            ls, lw = max(1, min(args.steps, 3)), 1
             try:
                 # (the whole run keeps inside FS_BENCH_BUDGET_S, 560 s by default -- the driver gives the command ten minutes --: a leg gets what is
                 # left of it at most, and one that could not even start says so; the line itself is printed in any case)
-                left = _T0 + float(os.environ.get("FS_BENCH_BUDGET_S", "560")) - time.time() - 5.0
+                left = budget_end - time.time() - 5.0
                 if left < 45.0:
                     raise RuntimeError("not started: the run's time budget was used up")
-                lleg, _ = leg_process(key, lname, lreads, lpaired, lgenome, lq, ls, lw, int(min((420 if key == "pe" else 240) + ref_s, left)))
+                lleg, _ = leg_process(key, lname, lreads, lpaired, lgenome, lq, ls, lw, int(min((420 if key == "pe" else 240) + ref_s, left)), traffic_of(key))
             except Exception as e:          # noqa: BLE001
                 lleg = {"error": "%s: %s" % (type(e).__name__, e)}
             res[key] = lleg
@@ -577,17 +610,25 @@ def main():
         dist.barrier()
         return dt, dict(zip(keys, v.tolist())), st, outs(made[-1])
 
-    main_kind = "set" if lib_set else ("one" if sharded else "replica")
+    # The headline of an N > 1 run is the ONE library of the N = 1 run bin-sharded over the ranks (BASELINE.json's configs[3] / [4]: strong
+    # scaling; its step is bound by single streams, which more GPUs do not shorten -- reported as measured); the SET of N libraries
+    # (weak scaling: per-GPU work fixed) is measured beside it and printed under `weak_set`.  --weak-set swaps the two.
+    set_first = lib_set and args.weak_set
+    main_kind = ("set" if set_first else "one") if sharded else "replica"
     dt, tot, st, last = timed(main_kind, args.steps, args.warmup)
-    strong = None
+    side = None; slast = None
     if lib_set:
-        # the strong line beside the weak one: ONE library (library 0 of the set) sharded over the same ranks -- its step is
-        # bound by single streams, which more GPUs do not shorten; reported as measured
         ks, kw = max(1, min(args.steps, 3)), 1
-        sdt, stot, _, slast = timed("one", ks, kw)
-        strong = {"scaling": "strong", "value": round(fastq_one * ks / sdt / 1e6, 2), "unit": "MB/s", "steps": ks, "warmup": kw, "ms_per_step": round(sdt / ks * 1e3, 2),
-                  "workload": "ONE library (library 0 of the set, %.1f MB FASTQ) bin-sharded over the %d ranks" % (fastq_one / 1e6, world),
-                  "roofline": roofline_of(stot, ks)}
+        side_kind = "one" if set_first else "set"
+        sdt, stot, _, slast = timed(side_kind, ks, kw)
+        sbytes = fastq_one if side_kind == "one" else fastq_set
+        side = {"scaling": "strong" if side_kind == "one" else "weak", "value": round(sbytes * ks / sdt / 1e6, 2), "unit": "MB/s", "steps": ks, "warmup": kw, "ms_per_step": round(sdt / ks * 1e3, 2),
+                "workload": ("ONE library (library 0 of the set, %.1f MB FASTQ) bin-sharded over the %d ranks" % (fastq_one / 1e6, world)) if side_kind == "one" else
+                            ("a SET of %d libraries (%.1f MB FASTQ), every rank its share of every library's bins in one device pipeline" % (world, fastq_set / 1e6)),
+                "roofline": roofline_of(stot, ks)}
+    # (the archives of the two lines: `set_last` = the N archives of the set, `one_last` = the one library's)
+    set_last = (last if set_first else slast) if lib_set else None
+    one_last = (slast if set_first else last) if sharded else None
 
     # parity of the SET line: rank r runs the reference on library r (the ranks side by side, each with its share of the host's
     # cores) and compares the archive the N ranks wrote for it block for block; rank 0 collects the verdicts
@@ -596,8 +637,8 @@ def main():
         pe_flag = ["-z"] if args.paired else []
         refp_r = os.path.join(args.work, "ref_" + names[rank])
         nt_r, tn_r, _ = reference_pack(binned_set[rank], refp_r, max(4, cores // world), pe_flag)
-        ok_r = bool(nt_r is not None and same_blocks(last[rank], refp_r))
-        strong_ok = bool(nt_r is not None and same_blocks(slast[0], refp_r)) if (rank == 0 and strong is not None) else None
+        ok_r = bool(nt_r is not None and same_blocks(set_last[rank], refp_r))
+        strong_ok = bool(nt_r is not None and same_blocks(one_last[0], refp_r)) if rank == 0 else None
         for e in (".cdata", ".cmeta"):
             try:
                 os.remove(refp_r + e)
@@ -608,21 +649,22 @@ def main():
         set_parity = gathered
     if rank == 0:
         jobs = world if args.replicas else 1
-        fastq_bytes = fastq_set if lib_set else fastq_one
+        fastq_bytes = fastq_set if main_kind == "set" else fastq_one
         value = fastq_bytes * jobs * args.steps / dt / 1e6
         rf = roofline_of(tot, args.steps); rf["ppmd_symbols_per_s_whole_job"] = round(tot["ppmd_symbols"] / dt, 1)
         sym = max(1.0, float(tot["ppmd_symbols"]))
         res = {
             "metric": "fastore_pack compressed MB/s (input FASTQ)", "value": round(value, 2), "unit": "MB/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s of %.1f M x %d bp %s synthetic FASTQ (gen_fastq genome %d bp, seed%s), --%s, C1 profile%s"
-                                   % ("ONE library" if not lib_set else "a SET of %d libraries, each" % world, args.reads / 1e6, L, "PE pairs" if args.paired else "SE reads", genome,
-                                      " 8" if not lib_set else "s 8..%d" % (7 + world), QUALITY,
-                                      "" if not args.paired else " (configs[2] scaled by %g)" % (args.reads / 100e6)),
+            "scaling": "weak" if (main_kind == "set" or args.replicas) else "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s of %.1f M x %d bp %s synthetic FASTQ (gen_fastq genome %d bp, seed%s), --%s, C1 profile%s%s"
+                                   % ("ONE library" if main_kind != "set" else "a SET of %d libraries, each" % world, args.reads / 1e6, L, "PE pairs" if args.paired else "SE reads", genome,
+                                      " 8" if main_kind != "set" else "s 8..%d" % (7 + world), QUALITY,
+                                      "" if not args.paired else " (configs[2] scaled by %g)" % (args.reads / 100e6),
+                                      "" if main_kind != "one" else ": the library of the N = 1 line, bin-sharded over %d GPUs as configs[3] / configs[4] shard theirs" % world),
                        "fastq_bytes": fastq_bytes, "pack_flags": " ".join(PACK_FLAGS),
                        "parallelism": ("%d ranks, each the whole library (replicas)" % world if args.replicas else
-                                       ("%d ranks pack disjoint LPT shards of the library's bins; one all-reduce of the block-size table over RCCL; no block bytes cross ranks" % world if args.strong else
+                                       ("%d ranks pack disjoint LPT shards of the library's bins; one all-reduce of the block-size table over RCCL; no block bytes cross ranks" % world if main_kind == "one" else
                                         "%d ranks, each its LPT share of the bins of all %d libraries in one device pipeline; one all-reduce of the concatenated block-size tables over RCCL; no block bytes cross ranks" % (world, world)))},
             "roofline": rf,
             "host_coded_symbol_fraction": round(float(tot.get("host_coded_symbols", 0)) / sym, 4),
@@ -631,19 +673,20 @@ def main():
             "device": packer.device_name, "host_cores": cores, "prep_s": round(prep_s, 1),
             "ranks": world, "collective_backend": "%s (%s)" % (backend, "RCCL over xGMI" if backend == "nccl" else "CPU rehearsal on one device"),
         }
-        if strong is not None:
-            res["strong"] = strong
+        if side is not None:
+            res["strong" if side["scaling"] == "strong" else "weak_set"] = side
         if set_parity is not None:
             ok0, nt0, tn0, strong_ok = set_parity[0]
             if nt0 is not None:
                 res["cpu_baseline"] = {"value": round(fastq_one / tn0 / 1e6, 2), "unit": "MB/s", "cores": min(nt0, max(4, cores // world)), "kind": "reference",
                                        "sample": "reference fastore_pack e -t%d on library 0 (%.1f MB FASTQ) while the other ranks run it on their libraries, %d host cores" % (nt0, fastq_one / 1e6, cores),
                                        "threads": nt0, "seconds": round(tn0, 2)}
-            res["parity"] = {"every_library_every_block_bit_identical_to_reference": bool(all(g[0] for g in set_parity)),
-                             "per_library": [bool(g[0]) for g in set_parity],
-                             "on": "all %d archives of the SET as the %d ranks wrote them, each against the reference's pack of that library" % (world, world)}
-            if strong_ok is not None:
-                res["parity"]["strong_line_archive_identical_to_reference"] = bool(strong_ok)
+            set_ok = {"every_library_every_block_bit_identical_to_reference": bool(all(g[0] for g in set_parity)), "per_library": [bool(g[0]) for g in set_parity],
+                      "on": "all %d archives of the SET as the %d ranks wrote them, each against the reference's pack of that library" % (world, world)}
+            one_ok = {"every_block_bit_identical_to_reference": bool(strong_ok), "block_order": "-t1 (block 0, ascending signature)",
+                      "on": "the ONE library's archive as the %d ranks wrote it (%d blocks) against the reference's pack of it" % (world, len(read_archive(one_last[0])[0]))}
+            # (the headline's parity on top, the other line's under its key)
+            res["parity"] = dict(set_ok, one_library=one_ok) if main_kind == "set" else dict(one_ok, weak_set=set_ok)
         elif not args.no_cpu_baseline and sharded:
             # parity of the N > 1 job (--strong): the ONE library's archive against the reference's pack of it; the reference is
             # timed on rank 0's host cores while the other ranks wait
@@ -653,10 +696,8 @@ def main():
             if nt is not None:
                 res["cpu_baseline"] = {"value": round(fastq_one / tn / 1e6, 2), "unit": "MB/s", "cores": min(nt, cores), "kind": "reference",
                                        "sample": "reference fastore_pack e -t%d on library 0 (%.1f MB FASTQ), %d host cores" % (nt, fastq_one / 1e6, cores), "threads": nt, "seconds": round(tn, 2)}
-                res["parity"] = {"library_0_every_block_bit_identical_to_reference": bool(same_blocks(last[0], refp)),
-                                 "on": "library 0 of the job as the %d ranks wrote it (%d blocks)" % (world, len(read_archive(last[0])[0]))}
-                if strong is not None:
-                    res["parity"]["strong_line_archive_identical_to_reference"] = bool(same_blocks(slast[0], refp))
+                res["parity"] = {"library_0_every_block_bit_identical_to_reference": bool(same_blocks(one_last[0], refp)),
+                                 "on": "library 0 of the job as the %d ranks wrote it (%d blocks)" % (world, len(read_archive(one_last[0])[0]))}
             drop([refp])
         print(json.dumps(res), flush=True)
     packer.close()

@@ -667,14 +667,19 @@ def test_bench_two_ranks_rehearsed_on_one_device_against_the_live_reference(tmp_
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
-    assert res["n_gpus"] == 2 and res["ranks"] == 2 and res["scaling"] == "weak" and res["collective_backend"].startswith("gloo")
-    assert res["parity"]["every_library_every_block_bit_identical_to_reference"] and res["parity"]["per_library"] == [True, True], res["parity"]
-    assert res["parity"]["strong_line_archive_identical_to_reference"] and res["strong"]["value"] > 0
+    # the headline: the ONE library bin-sharded over the ranks (strong scaling, BASELINE.json's configs[3] / [4]); beside it the SET of two
+    assert res["n_gpus"] == 2 and res["ranks"] == 2 and res["scaling"] == "strong" and res["collective_backend"].startswith("gloo")
+    assert res["value"] > 0 and "ONE library" in res["config"]["workload"]
+    assert res["parity"]["every_block_bit_identical_to_reference"], res["parity"]
+    ws = res["parity"]["weak_set"]
+    assert ws["every_library_every_block_bit_identical_to_reference"] and ws["per_library"] == [True, True], res["parity"]
+    assert res["weak_set"]["scaling"] == "weak" and res["weak_set"]["value"] > 0
 
 
 @pytest.mark.timeout(400, method="thread")
 def test_two_cli_processes_share_the_device_with_long_streams_and_both_end(tmp_path, ref_libs):
-    # Two `fastore_pack e` processes at once on the one device, DEFAULT environment, twenty rounds.  Rounds 1-4 had a workgroup without an
+    # Two `fastore_pack e` processes at once on the one device, DEFAULT environment; FS_TWO_PROC_ROUNDS rounds (8 in the suite, which must end
+    # inside the driver's window -- a round beside another process takes up to 13 s; the twenty-round run is profiles/r05_cli_two_processes.txt).  Rounds 1-4 had a workgroup without an
     # arena slot spin inside its kernel for a workgroup of ANOTHER launch to free one; with two processes' hardware queues competing that
     # was a standstill (profiles/r04_cli_two_processes.txt).  No workgroup waits for another any more (engine.hip: a full partition is left
     # at once, the host launches again if nobody took the streams).  Each child has 120 s; a child that hangs is killed and fails the test.
@@ -685,7 +690,7 @@ def test_two_cli_processes_share_the_device_with_long_streams_and_both_end(tmp_p
     env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES",)}
     want = {e: open(ref + e, "rb").read() for e in (".cdata",)}
     times = []
-    for rnd in range(20):
+    for rnd in range(int(os.environ.get("FS_TWO_PROC_ROUNDS", "8"))):
         t0 = time.monotonic()
         kids = [subprocess.Popen([fastore_amd.PACK_CLI, "e", "-i" + binned, "-o" + os.path.join(t, "o%d" % k)] + C1_FLAGS + pe, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE) for k in range(2)]
         for k, kid in enumerate(kids):
