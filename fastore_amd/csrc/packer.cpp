@@ -1230,8 +1230,12 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     if (trace) fprintf(stderr, "[trace] batch set-up (slices, %u lanes, matcher lanes) %.1f ms\n", nLanes, tf - t0);
     try {
         std::mutex roundMx; std::condition_variable roundCv; uint32_t binsDone = 0;
+        // The mate searches of paired-end bins on the device (fs_match_mates), batched and not waited for: FS_DEVICE_MATES=2.  NOT the default: a bin's
+        // pairs are a chain -- 11 us a pair in a 1024-thread workgroup that wants a compute unit to itself, against ~1.6 us a pair and thread on the
+        // host -- and the coder kernels hold the compute units for most of a step: round 5, 6 M pairs: 2.19 s a step with the host's search, 2.92 s
+        // with the device's for every bin, 3.4 s with the device's for all but the heaviest bins (profiles/r05_mate_search_modes.txt).  The kernel
+        // stays under test row for row and archive for archive.
         const int matesMode = getenv("FS_DEVICE_MATES") ? atoi(getenv("FS_DEVICE_MATES")) : 0;       // (read per batch: the tests switch it inside one process)
-        const bool deviceMates = matesMode == 1;                 // 1: the device's searches, bin by bin, waited for (round 3's form); 2: batched, not waited for
         const bool deviceEmit = !(getenv("FS_DEVICE_EMIT") && atoi(getenv("FS_DEVICE_EMIT")) == 0);
         std::unique_ptr<MateDispatcher> mateDispatcher;
         if (matesMode == 2 && deviceEmit && deviceMatcher) mateDispatcher.reset(new MateDispatcher(*this));
@@ -1261,12 +1265,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             // Later the coder kernels hold every register of the chip (3 waves x 168 VGPRs per SIMD): a search would wait
             // for coder waves to leave, longer than the host scan takes, so the lighter bins keep the host scan.
             encs[tid]->setMatcher(k < matcherBins ? matcherFor(tid) : MatchFn());
-            // (paired-end bins: fs_match_mates gives the host search's rows pair for pair -- every golden bin at five history sizes, the
-            // 195 266 pairs of a fresh library -- but it is NOT the product's default: its 1024-thread workgroups need a compute unit to
-            // themselves and the coder kernels hold every one for most of the step, so the 6 M-pair step takes 3.06 s with the device's
-            // searches (batched, FS_DEVICE_MATES=2) against 2.53 s with the host's: profiles/r04_mate_search_forms.txt.  FS_DEVICE_MATES=1: bin by
-            // bin, the host thread waiting -- round 3's hand-over.)
-            encs[tid]->setMateMatcher(k < matcherBins && deviceMates ? mateMatcherFor(tid) : MateFn());
+            encs[tid]->setMateMatcher(MateFn());
             // the streams that hold bases (HardReads, LettersX, Match, ...: fsdev::EmitOp) and the LZ ids' run-length coding: written
             // by the device from the ops the walk leaves (FS_DEVICE_EMIT=0: by the walk itself, A/B runs)
             encs[tid]->setDeviceEmit(deviceEmit);

@@ -515,8 +515,8 @@ def test_device_mate_search_on_a_fresh_library_and_same_archive_either_way(tmp_p
         pairs, differing = p.pe_matcher_check(binned)
         assert pairs > 50_000 and differing == 0, (pairs, differing)
     # (the archive with the host's searches is test_gpu_pack_equals_live_reference_on_a_library_with_long_streams[pe_long])
-    # the device's searches handed over and run in batches of bins (2), and bin by bin (1)
-    for mode in ("2", "1"):
+    # the device's searches handed over and run in batches of bins
+    for mode in ("2",):
         monkeypatch.setenv("FS_DEVICE_MATES", mode)
         with fastore_amd.Packer(device_id=0) as p:
             st = p.pack_file(binned, os.path.join(t, "gpu" + mode))

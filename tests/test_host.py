@@ -509,12 +509,12 @@ def test_mate_search_rows_against_the_scalar_restatement(emu_lib, name, paired, 
 
 @pytest.mark.parametrize("name,paired,flags", [m for m in manifest() if m[1]])
 def test_device_mate_search_is_taken_and_changes_no_byte(emu_lib, tmp_path, monkeypatch, name, paired, flags):
-    # the archive with the mate searches taken from the "device" (here: the emulation's stand-in) -- bin by bin and waited for (1), or
-    # handed over and searched in batches of bins while the host threads go on (2: fs::PendingPairs, the mate streams written from
-    # the rows when a batch comes back; several slices and few threads, so that bins complete in every order) -- and with the host's search
+    # the archive with the mate searches taken from the "device" (here: the emulation's stand-in) -- handed over and searched in batches of
+    # bins while the host threads go on (2: fs::PendingPairs, the mate streams written from the rows when a batch comes back; several
+    # slices and few threads, so that bins complete in every order) -- and with the host's search
     import fastore_amd
     ref = open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
-    for mode, kw in (("1", {}), ("2", {}), ("2", dict(host_threads=3, pipeline_slices=5, pipeline_lanes=2)), ("0", {})):
+    for mode, kw in (("2", {}), ("2", dict(host_threads=3, pipeline_slices=5, pipeline_lanes=2)), ("0", {})):
         monkeypatch.setenv("FS_DEVICE_MATES", mode)
         with fastore_amd.Packer(lib=emu_lib, device_id=0, **kw, **knobs_from_flags(flags)) as p:
             st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o" + mode)))
