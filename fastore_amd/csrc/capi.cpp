@@ -77,21 +77,16 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
     const unsigned share = usableCores() * 3u / 2u / localRanks;
     c.hostCores = std::max(1u, usableCores() / localRanks);
     c.hostThreads = cfg->host_threads ? cfg->host_threads : std::max(localRanks > 1 ? 4u : 1u, std::min(24u, share));
-    if (getenv("FS_HOST_THREADS")) c.hostThreads = std::max(1, atoi(getenv("FS_HOST_THREADS")));     // experiments
     if (getenv("FS_BATCH_BASES") && atoll(getenv("FS_BATCH_BASES")) > 0) c.cfg.batch_bases = (uint64_t)atoll(getenv("FS_BATCH_BASES"));      // (tests: small device batches)
     if (getenv("FS_PIPELINE_SLICES") && atoi(getenv("FS_PIPELINE_SLICES")) > 0) c.cfg.pipeline_slices = (uint32_t)atoi(getenv("FS_PIPELINE_SLICES"));
     if (getenv("FS_PIPELINE_LANES") && atoi(getenv("FS_PIPELINE_LANES")) > 0) c.cfg.pipeline_lanes = (uint32_t)atoi(getenv("FS_PIPELINE_LANES"));
     if (getenv("FS_DEVICE_MATCHER") && atoi(getenv("FS_DEVICE_MATCHER")) == 0) c.deviceMatcher = false;       // A/B runs: the host window scan
     if (getenv("FS_MAX_WAVES") && atoi(getenv("FS_MAX_WAVES")) > 0) c.cfg.max_waves = (uint32_t)atoi(getenv("FS_MAX_WAVES"));
     if (c.par.mismatchCost <= 0 || c.par.shiftCost < 0 || c.par.maxLzWindowSize == 0 || c.par.maxPairLzWindowSize == 0) { g_createError = "invalid matcher parameters"; delete ctx; return nullptr; }
-    {   // one-shot contexts stage through pageable memory (FS_PAGEABLE_STAGING=0/1 forces either way: A/B runs)
-        bool pageable = cfg->one_shot != 0;
-        if (const char* ps = getenv("FS_PAGEABLE_STAGING")) pageable = atoi(ps) != 0;
-        fsengine::set_pageable_staging(pageable);
-    }
+    fsengine::set_pageable_staging(cfg->one_shot != 0);       // one-shot contexts stage through pageable memory
     // the device: at once -- or, for a context that packs once, on a thread of its own while the caller goes on to the
     // pack call and the front end of the first bins (fs::Context::device() waits for it; a failure is reported there, as
-    // loudly: "no HIP device available ..." becomes the pack call's error).  FS_SYNC_DEVICE=1 keeps the order of old.
+    // loudly: "no HIP device available ..." becomes the pack call's error).
     fs::Context* cp = &c;
     const int deviceId = cfg->device_id; const uint32_t maxWaves = c.cfg.max_waves;
     auto make = [cp, deviceId, maxWaves]() -> std::string {
@@ -100,7 +95,7 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
         if (fsengine::device_create(&cp->dev, deviceId, maxWaves, err, sizeof err) != 0) return err[0] ? std::string(err) : std::string("device creation failed");
         return std::string();
     };
-    if (cfg->one_shot && !getenv("FS_SYNC_DEVICE")) {
+    if (cfg->one_shot) {
         c.devPending = std::async(std::launch::async, make).share();
         c.devAsync.store(true);
         return ctx;
@@ -119,7 +114,6 @@ void fsgpu_destroy(fsgpu_ctx* ctx)
     const double t0 = clk();
     for (fsgpu_ctx* h : ctx->helpers) fsgpu_destroy(h);
     ctx->helpers.clear();
-    for (const std::string& n : ctx->c.stealNames) (void)unlink(n.c_str());      // (the node's work counters of the last sharded packs)
     for (fsengine::MatchLane* m : ctx->c.matchLanes) fsengine::match_lane_destroy(m);
     const double t1 = clk();
     for (size_t i = 1; i < ctx->c.lanes.size(); ++i) fsengine::device_destroy(ctx->c.lanes[i]);      // lanes[0] == dev

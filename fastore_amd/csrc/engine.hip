@@ -815,11 +815,9 @@ static bool g_pageableStaging = false;
 // --reduced library's step was 7.1 s that way against 1.15 s with its fourteen slices side by side (profiles/r03_reduced_mode.txt).
 // So the first such launch makes the pool's slots big enough, once, with nothing in flight (the gate taken alone): same number of
 // slots, 3 072 x 32 MiB = 103 GB of the 288.  Only then: lossless packs -- and the helper pipelines of libraries of several
-// batches, each with a pool of its own -- keep the 53 GB pool.  No room for it (or FS_BIG_SLOTS=0): the exclusive launches stay.
+// batches, each with a pool of its own -- keep the 53 GB pool.  No room for it: the exclusive launches stay.
 static void pool_grow(Device* dev, Pool* pool, uint64_t need)
 {
-    const char* bs = getenv("FS_BIG_SLOTS");
-    if (bs && atoi(bs) == 0) return;
     const uint64_t big = ((need + kGuard) + 4095ull) & ~4095ull;
     std::unique_lock<std::shared_mutex> alone(pool->gate);                    // every launch in flight has drained
     if (big <= pool->slotStride) return;                                    // another lane was first
@@ -1241,12 +1239,11 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         ka.queueHead = (uint32_t*)dev->queueHead; ka.maps = exclusive ? (SlotMap*)nullptr : pool->maps;
         ka.nItems = nRest; ka.longLen = longLen; ka.slotsPerXcc = pool->slotsPerXcc;
         // two-wave form where the step is bound by its longest PPMd stream (the coder runs beside the model walk: ~1.4x per
-        // stream, but a stream takes two wave slots); FS_TWO_WAVE=0/1 forces either form
-        // (FS_WAVES=1/2 forces a form; FS_TWO_WAVE=0/1 is the older switch.  Round 3's three-wave form -- windows prepared by a
+        // stream, but a stream takes two wave slots)
+        // (FS_WAVES=1/2 forces a form: the tests run every stream through both.  Round 3's three-wave form -- windows prepared by a
         // wave of their own ahead of the serial walk -- was bit-exact and slower, 1.10 s against 0.97 s on a lone 7 M-symbol
         // stream, and left the tree in round 4; its measurements stay in profiles/r03_three_wave_*.txt.)
         uint32_t waves = maxLen >= (256u << 10) ? 2u : 1u;
-        if (const char* tw = getenv("FS_TWO_WAVE")) waves = atoi(tw) != 0 ? 2u : 1u;
         if (const char* tw = getenv("FS_WAVES")) waves = (uint32_t)std::max(1, std::min(2, atoi(tw)));
         // Launches whose range-coded symbols (small alphabets: the models with a windowed form) weigh beside their PPMd symbols
         // -- the quality scores of a --reduced or --max library -- take the kernels with the windowed coders.  A lossless
@@ -1270,7 +1267,7 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         {   // the coder wave takes the range coder's pass: worth a second wave per stream where a long range-coded stream ends the launch
             uint32_t maxRc = 0;
             for (size_t i = 0; i < items.size(); ++i) { const auto& it = items[i]; if (!roomOnly[i] && it.kind != KIND_PPMD && (it.kind == KIND_QVZ || it.kind - KIND_RC_BASE <= fsrc::M_A8O6)) maxRc = std::max(maxRc, it.in_len); }
-            if (rcWin && maxRc >= (256u << 10) && !getenv("FS_WAVES") && !getenv("FS_TWO_WAVE")) waves = 2u;
+            if (rcWin && maxRc >= (256u << 10) && !getenv("FS_WAVES")) waves = 2u;
         }
         if (const char* rw = getenv("FS_RC_WINDOWS")) rcWin = atoi(rw) != 0;
         auto launch = [&]() -> hipError_t {

@@ -740,7 +740,6 @@ struct BinEncoder::Impl {
                 // branch expands to (-last - cur), i.e. never exceeds maxShift (fastore_bin/Globals.h:70, ContigBuilder.cpp:219)
                 int32_t d = lastM - (int32_t)m; if (d < 0) d = -lastM - (int32_t)m;
 #ifdef FS_DEBUG_DUMP
-                if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == curSig) { uint32_t nvc = 0; for (uint16_t p : w.newVariantPositions) nvc += bi.recordsPerPos[p];
                   printf("D ham %u newvars %zu nvc %u d %d maxShift %u normal %f shift %d cost %d exceeds %d\n", ham, w.newVariantPositions.size(), nvc, d, maxShift, normalEncodeCost(node), node.shift, node.cost, (int)consCostExceeds(bi, w, ham, node)); }
 #endif
                 if (!(w.newVariantPositions.empty() || (ham <= par.maxHammingDistance && w.newVariantPositions.size() <= par.maxNewVariantsPerRead))
@@ -887,7 +886,6 @@ struct BinEncoder::Impl {
             int32_t node = nextQueue.front(); nextQueue.pop_front();
             bi.reset(L);
 #ifdef FS_DEBUG_DUMP
-            if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == curSig) { const Rec& r = R(nodes[node].vrec); printf("T start %s\n", std::string((const char*)B->head.data() + r.headOff, r.headLen).c_str()); }
 #endif
             if (!addRecord(bi, node, false)) { if (!nodes[node].children.empty()) addChildrenToQueue(nextQueue, node); continue; }
             std::deque<int32_t> curQueue = std::move(nextQueue); nextQueue.clear();
@@ -896,7 +894,6 @@ struct BinEncoder::Impl {
                 node = curQueue.front(); curQueue.pop_front();
                 { bool r1 = addRecord(bi, node, true);
 #ifdef FS_DEBUG_DUMP
-                if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == curSig) { const Rec& r = R(nodes[node].vrec); printf("A1 %s %d\n", std::string((const char*)B->head.data() + r.headOff, r.headLen).c_str(), (int)r1); }
 #endif
                 if (!r1) { nextQueue.push_back(node); continue; } }
                 if (false) {}
@@ -907,19 +904,16 @@ struct BinEncoder::Impl {
                 node = curQueue.front(); curQueue.pop_front();
                 { bool r2 = addRecord(bi, node, false);
 #ifdef FS_DEBUG_DUMP
-                if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == curSig) { const Rec& r = R(nodes[node].vrec); printf("A2 %s %d\n", std::string((const char*)B->head.data() + r.headOff, r.headLen).c_str(), (int)r2); }
 #endif
                 if (!r2) { nextQueue.push_back(node); continue; } }
                 if (false) {}
                 else if (!nodes[node].children.empty()) addChildrenToQueue(curQueue, node);
             }
 #ifdef FS_DEBUG_DUMP
-            if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == curSig) printf("T size %zu\n", bi.nodes.size());
 #endif
             if (bi.nodes.size() < par.minConsensusSize) continue;
             optimizeContig(bi);
 #ifdef FS_DEBUG_DUMP
-            if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == curSig) printf("T opt size %zu\n", bi.nodes.size());
 #endif
             if (bi.nodes.size() < par.minConsensusSize) continue;
             updateContigLinkage(bi);
@@ -1267,15 +1261,6 @@ struct BinEncoder::Impl {
         constructMatchTree(order, roots, -1, wantTable ? 0 : -1);
         if (stageTrace) t3 = clk();
 #ifdef FS_DEBUG_DUMP
-        if (getenv("FS_DUMP_SIG") && (uint32_t)atoi(getenv("FS_DUMP_SIG")) == bin.signature) {
-            auto H = [&](int32_t n) { if (n < 0) return std::string("-"); const Rec& r = R(nodes[n].vrec); return std::string((const char*)B->head.data() + r.headOff, r.headLen); };
-            for (int32_t n : order) printf("N %s type %d parent %s shift %d cost %d nomism %d em %d trees %d\n", H(n).c_str(), nodes[n].type, H(nodes[n].parent).c_str(), nodes[n].shift, nodes[n].cost, (int)nodes[n].noMismatches, (int)nodes[n].em.size(), (int)nodes[n].trees.size());
-            for (int32_t root : roots) if (!nodes[root].children.empty()) buildContigs(root);
-            for (auto& c : contigs) { printf("C range %u %u vars %u members", c.rangeFirst, c.rangeSecond, c.variantsCount); for (int32_t mm : c.nodes) printf(" %s", H(mm).c_str()); printf("\n"); }
-            for (int32_t n : order) if (nodes[n].contig >= 0) printf("M %s\n", H(n).c_str());
-            for (int32_t n : order) { printf("K %s :", H(n).c_str()); for (int32_t c : nodes[n].children) printf(" %s", H(c).c_str()); printf("\n"); }
-            fflush(stdout); exit(0);
-        }
 #endif
         for (int32_t root : roots) {
             if (!nodes[root].children.empty()) buildContigs(root);

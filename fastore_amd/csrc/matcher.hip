@@ -284,8 +284,8 @@ namespace fsengine {
 // kernels that run for a second: a stream that had to share one of THOSE queues would wait behind such a kernel.
 enum { kMatchStreamsMax = 6 };
 struct StreamPool { hipStream_t s[kMatchStreamsMax] = {}; int users = 0; unsigned next = 0; };
-// streams the matcher lanes of a device share (FS_MATCHER_STREAMS: A/B runs; the coder lanes need a hardware queue each)
-static int matchStreams() { static const int n = []() { const char* e = getenv("FS_MATCHER_STREAMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > kMatchStreamsMax ? (int)kMatchStreamsMax : v); }(); return n; }
+// streams the matcher lanes of a device share: two (the coder lanes need a hardware queue each)
+static int matchStreams() { return 2; }
 static std::mutex g_poolMx; static StreamPool g_pool[16];
 
 // parity check of the device-side unpack (fsgpu_unpack_check, or FS_UNPACK_CHECK=1 for a whole run): plane words compared / differing

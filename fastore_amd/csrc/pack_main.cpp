@@ -94,9 +94,6 @@ int main(int argc, char** argv)
     cfg.host_threads = hostThreads >= 0 ? (uint32_t)hostThreads : (uint32_t)threads;   // -j overrides -t (which keeps the reference's 1..64 range)
     if (gpus < 1 || gpus > 64) { fprintf(stderr, "Error: invalid number of devices specified\n"); return 255; }
     if (gpus > 1) {
-        // (the contexts share the node's work counter: the lightest bins go to whichever device runs out of work first)
-        // (the key names the counter's file: process id AND start time, so that a file a dead run of the same id left behind is never found)
-        if (!getenv("FS_STEAL_KEY")) { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); char k[64]; snprintf(k, sizeof k, "pid%ld.%lld%09ld", (long)getpid(), (long long)ts.tv_sec, ts.tv_nsec); setenv("FS_STEAL_KEY", k, 1); }
         // one context (and one set of host threads) per device; every device takes its LPT share of the bins (longest first over
         // the .bmeta record totals, packer.cpp: shardOwners), no block bytes cross devices
         std::vector<fsgpu_ctx*> ctxs(gpus, nullptr);

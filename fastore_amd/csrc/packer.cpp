@@ -706,6 +706,8 @@ void Context::compressBatch(const Batch& batch, const std::vector<uint32_t>& bin
     const uint32_t nBins = (uint32_t)batch.bins.size();
     std::vector<uint64_t> weight(nBins);
     for (uint32_t b = 0; b < nBins; ++b) weight[b] = batch.bins[b].recCount;
+    binBases.assign(nBins, 0);
+    for (uint32_t b = 0; b < nBins; ++b) binBases[b] = batch.bins[b].rawDnaSize;
     compressBins(nBins, weight, binArch, [&](uint32_t b, BinEncoder& enc, BinStreams& out, BinIn& info, uint64_t& recBytes) {
         info = batch.bins[b];
         enc.encodeLz(batch, info, archives[binArch[b]], out);
@@ -747,17 +749,11 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     const bool autoSlices = cfg.pipeline_slices == 0;
     // (one bin per CORE in the first round -- the threads beyond the cores joining as bins finish -- was tried: the first slice
     // goes up 25 ms earlier, the second one, whose streams are nearly as long, later: no gain, profiles/r02_yy_first_round.txt)
-    uint32_t firstRound = hostThreads;
-    if (const char* fr = getenv("FS_FIRST_ROUND")) firstRound = std::max(1u, std::min<uint32_t>(hostThreads, (uint32_t)atoi(fr)));     // A/B runs
+    const uint32_t firstRound = hostThreads;
     const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? 14u : 1u);
     if (wantSlices > 1) {
-        // FS_SLICE_WEIGHTS="1,2,2,3" (experiment): relative weights of ALL slices instead of the rule below
         std::vector<double> share;
-        const char* sw = getenv("FS_SLICE_WEIGHTS");
-        if (sw) {
-            for (const char* q = sw; *q && share.size() < wantSlices; ) { const double v = atof(q); share.push_back(v > 0 ? v : 1.0); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
-            share.resize(wantSlices, 1.0);
-        } else if (!autoSlices) {
+        if (!autoSlices) {
             uint64_t firstW = 0; const uint32_t firstBins = std::min<uint32_t>(std::max(1u, hostThreads), nBins / wantSlices);
             for (uint32_t i = 0; i < firstBins; ++i) firstW += weight[byWork[i]];
             const double f = std::min(0.5, (double)firstW / (double)std::max<uint64_t>(1, totalW));
@@ -1242,6 +1238,16 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         std::mutex asyncErrMx; std::string asyncErr;
         // (a bin whose pairs are with the device is complete when BOTH its host task has returned -- it still fills in the bin's packed
         // scores and read ids behind the walk -- and its rows have come back: whichever is second counts it)
+        // A slice lives in ONE 32-bit address space on the device: its bins' streams, and -- for the bins whose base-holding streams the device
+        // writes itself -- their bases, ops and the room of everything those ops may write: ~7 bytes a base against ~2.75 for a bin whose walk
+        // writes its own streams.  Slices are cut by weight, so with few slices (pipeline_slices <= 4, or fewer than 64 bins: one slice) a batch
+        // of more than ~0.6 GB of bases would pass 4 GiB ("emitted streams larger than 4 GiB").  Every bin claims its footprint from its
+        // slice's budget before its walk starts; a bin that finds the budget used up keeps the walk's own streams (same bytes in the archive).
+        std::unique_ptr<std::atomic<uint64_t>[]> sliceDevBytes(new std::atomic<uint64_t>[nSlices]);
+        for (uint32_t si = 0; si < nSlices; ++si) sliceDevBytes[si].store(0);
+        const std::vector<uint64_t> basesOf = binBases.size() == nBins ? binBases : std::vector<uint64_t>();
+        binBases.clear();
+        static const uint64_t sliceDevCap = getenv("FS_SLICE_DEV_CAP") ? (uint64_t)atoll(getenv("FS_SLICE_DEV_CAP")) : (3600ull << 20);      // (the variable: tests of the fall-back)
         std::unique_ptr<std::atomic<uint8_t>[]> parts(new std::atomic<uint8_t>[nBins]);
         for (uint32_t i = 0; i < nBins; ++i) parts[i].store(2);
         // a bin is through the front end: its slice counts it (here, or -- its pairs still with the device -- when they come back)
@@ -1259,7 +1265,10 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 roundCv.wait(lk, [&]() { return binsDone > k - firstRound || abort.load(); });
             }
             struct Done { std::mutex& m; std::condition_variable& cv; uint32_t& n; ~Done() { { std::lock_guard<std::mutex> g(m); ++n; } cv.notify_all(); } } done{roundMx, roundCv, binsDone};     // (also when the bin throws)
+            static const bool binTrace = getenv("FS_BIN_TRACE") != nullptr;
+            if (binTrace && k < 32) fprintf(stderr, "[bin] rank %u (bin %u, thread %u) claimed at %.1f ms of the batch\n", k, b, tid, nowMs() - t0);
             if (!encs[tid]) encs[tid].reset(new BinEncoder(par));
+            if (binTrace && k < 32) fprintf(stderr, "[bin] rank %u: encoder ready at %.1f ms of the batch\n", k, nowMs() - t0);
             // The heaviest bins -- the first few rounds of the host threads -- have their window searches done by the device:
             // they sit on the critical path (their quality streams are the longest) and the device is still nearly empty.
             // Later the coder kernels hold every register of the chip (3 waves x 168 VGPRs per SIMD): a search would wait
@@ -1268,7 +1277,14 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             encs[tid]->setMateMatcher(MateFn());
             // the streams that hold bases (HardReads, LettersX, Match, ...: fsdev::EmitOp) and the LZ ids' run-length coding: written
             // by the device from the ops the walk leaves (FS_DEVICE_EMIT=0: by the walk itself, A/B runs)
-            encs[tid]->setDeviceEmit(deviceEmit);
+            bool emitHere = deviceEmit;
+            {
+                const uint64_t bases = basesOf.empty() ? weight[b] * 320u : basesOf[b];
+                std::atomic<uint64_t>& used = sliceDevBytes[sliceOf[k]];
+                if (emitHere && used.fetch_add(7u * bases) + 7u * bases > sliceDevCap) { used.fetch_sub(4u * bases); emitHere = false; }
+                else if (!emitHere) used.fetch_add(3u * bases);
+            }
+            encs[tid]->setDeviceEmit(emitHere);
             if (mateDispatcher) {
                 MateDispatcher* md = mateDispatcher.get();
                 encs[tid]->setAsyncMates([&, k, md](std::unique_ptr<PendingPairs> pp) {
@@ -1394,59 +1410,6 @@ void Context::compressRawBlock(Batch& batch, const ArchiveParams& arch, std::vec
 }
 
 // ------------------------------------------------------------------------------------------------
-// The work-stealing tail of a bin-sharded pack ("LPT-greedy over G GPUs with a work-stealing tail (atomic next-bin
-// counter per node)").  The heaviest bins -- all but the lightest `kTailPercent` of the records -- are dealt up front by
-// shardOwners; the rest is cut into chunks that the ranks claim from ONE counter as they run out of work.  The counter is a
-// 64-byte file in /dev/shm that every rank of the job maps: named by what the ranks of one job share and another job does not --
-// the launcher's process id (the ranks of torch.distributed.run are its children; contexts inside one process: that
-// process), the libraries' names, and how many sharded packs the context has made.  Which rank packs a block never shows in
-// the archive; that EVERY block was packed by exactly one rank is checked when the size tables come together (shardWrite).
-namespace {
-enum : uint32_t { kTailPercent = 15, kChunksPerRank = 4 };
-struct StealCounter {
-    std::atomic<uint32_t>* p = nullptr; int fd = -1; std::string name;
-    // what the ranks of one job share and another job does not: FS_STEAL_KEY (fastore_amd/shard.py broadcasts a random number once
-    // per job; fastore_pack -G, whose contexts live in one process, sets its process id), else torch.distributed's rendezvous
-    // (MASTER_ADDR : MASTER_PORT).  Neither: no tail -- every bin is dealt up front, as before.
-    static std::string fileName(const std::vector<std::string>& prefixes, uint32_t seq)
-    {
-        uint64_t h = 1469598103934665603ull;
-        auto mix = [&](const char* s) { for (; s && *s; ++s) { h ^= (unsigned char)*s; h *= 1099511628211ull; } h ^= 0xFFu; h *= 1099511628211ull; };
-        for (const std::string& s : prefixes) mix(s.c_str());
-        if (const char* k = getenv("FS_STEAL_KEY")) { mix("key"); mix(k); }
-        else if (getenv("MASTER_PORT")) { mix("rdzv"); mix(getenv("MASTER_ADDR")); mix(getenv("MASTER_PORT")); }
-        char buf[96]; snprintf(buf, sizeof buf, "/dev/shm/fastore_steal.%016llx.%u", (unsigned long long)h, seq);
-        return buf;
-    }
-    // The rank that CREATES the file (O_EXCL: exactly one does) sizes it, which zeroes the count; the others open what is there
-    // and wait until it has its 64 bytes.  A file left behind by a job that died cannot be told from a live one by a rank that
-    // merely finds it, so a key must not be used twice: shard.py draws a fresh one per job, `fastore_pack -G` removes its own
-    // (process id + prefixes) before its contexts start, a launcher that sets FS_STEAL_KEY owns its uniqueness -- and every
-    // context removes its counters when it goes, error paths included (capi.cpp: fsgpu_destroy; packFiles' catch).
-    bool open(const std::vector<std::string>& prefixes, uint32_t seq)
-    {
-        name = fileName(prefixes, seq);
-        fd = ::open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd >= 0) { if (ftruncate(fd, 64) != 0) { ::close(fd); fd = -1; (void)unlink(name.c_str()); return false; } }
-        else {
-            if (errno != EEXIST) return false;
-            fd = ::open(name.c_str(), O_RDWR);
-            if (fd < 0) return false;
-            struct stat sb; int tries = 0;
-            while (fstat(fd, &sb) == 0 && sb.st_size < 64 && tries++ < 2000) usleep(1000);      // (the creator is between open and ftruncate)
-            if (sb.st_size < 64) { ::close(fd); fd = -1; return false; }
-        }
-        void* m = mmap(nullptr, 64, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        if (m == MAP_FAILED) { ::close(fd); fd = -1; return false; }
-        p = (std::atomic<uint32_t>*)m;
-        return true;
-    }
-    uint32_t claim() { return p->fetch_add(1u, std::memory_order_relaxed); }
-    ~StealCounter() { if (p) munmap((void*)p, 64); if (fd >= 0) ::close(fd); }
-};
-}  // namespace
-
-// ------------------------------------------------------------------------------------------------
 void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::vector<std::string>& outPrefixes, int verbose, bool hold)
 {
     const double tStart = nowMs();
@@ -1475,30 +1438,12 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         if (hold) L.aw.startInMemory(archives[l].cfg);
         else L.aw.start(world > 1 ? outPrefixes[l] + ".part" + std::to_string(rank) : outPrefixes[l], archives[l].cfg);
     });
-    // the tail's chunks of all libraries: [library l's chunks at l * nChunks ...); claimed in this order by every rank
-    StealCounter steal;
-    // (FS_STEAL=1 switches the tail ON.  It is off by default since the end of round 3: every chunk a rank claims after its
-    // first batch is a device batch of its own -- slices, launches, a drain: 150 ms and more for a few hundred light bins -- and
-    // with one chunk claimed per pass a rank ran four of them behind its share: two ranks on one device, 2 M-read libraries,
-    // 1 677 ms per step without the tail and 2 335 with it (profiles/r03_rehearse_2ranks*.json).  The shares dealt by
-    // shardOwners (longest stream first) are within a few per cent of each other; a tail costs more than it can level.)
-    // The counter is a file of THIS node, so the tail is only dealt when every rank of the job runs on it: contexts of one process
-    // (fastore_pack -G, the tests), or a launcher that says so (torch.distributed.run exports LOCAL_WORLD_SIZE; equal to the job's
-    // world size = one node).  A job over several nodes deals every bin up front: with a counter per node every node would claim
-    // the whole tail, and the summed size table would count those blocks twice.
-    bool oneNode = true;
-    if (const char* lw = getenv("LOCAL_WORLD_SIZE")) oneNode = (uint32_t)atoi(lw) == world;
-    else if (getenv("MASTER_PORT") && !getenv("FS_STEAL_ONE_NODE")) oneNode = false;         // a rendezvous, and nobody vouches for the node
-    const bool wantSteal = world > 1 && oneNode && splitRole == 0 && (getenv("FS_STEAL") && atoi(getenv("FS_STEAL")) != 0) && (getenv("FS_STEAL_KEY") || getenv("MASTER_PORT"));
-    if (wantSteal) {
-        if (!steal.open(inPrefixes, stealSeq)) throw std::runtime_error("Cannot open the node's work counter in /dev/shm");
-        stealNames.push_back(steal.name);
-        while (stealNames.size() > 2) { (void)unlink(stealNames.front().c_str()); stealNames.erase(stealNames.begin()); }      // (every rank has long opened a counter two packs old)
-        ++stealSeq;
-    }
-    std::vector<std::vector<Work>> tail(steal.p ? nLibs * world * kChunksPerRank : 0);
+    // Every bin is dealt up front (shardOwners: longest stream first, then the sums).  Round 3 had a work-stealing tail behind it -- the lightest
+    // 15 % of the records in chunks that the ranks of a node claimed from one counter in /dev/shm as they ran out of work --, built, tested
+    // and never the default: every chunk claimed behind a rank's first batch is a device batch of its own (150 ms and more for a few hundred
+    // light bins), the shares dealt up front are within a few per cent of each other, and the two-rank rehearsal was no faster with it
+    // (1 659 against 1 648 ms a step, profiles/r03_rehearse_2ranks_last_tail_*.json).  It left the tree in round 5.
     for (size_t l = 0; l < nLibs; ++l) {
-        const size_t chunkBase = l * world * kChunksPerRank;
         const auto& stdSigs = libs[l]->bf.stdSignatures();
         std::vector<uint64_t> w(stdSigs.size());
         for (uint32_t i = 0; i < stdSigs.size(); ++i) w[i] = libs[l]->bf.bins().at(stdSigs[i]).totalRecordsCount;
@@ -1519,20 +1464,6 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                 if (bases != 0 && bases + add > cap) { ++cls; bases = 0; if (cls + 1u >= world) break; }
                 owner[i] = cls; bases += add;
             }
-        } else if (steal.p) {
-            // head: all but the lightest kTailPercent of the records, dealt by shardOwners; tail: chunks, dealt round robin by weight
-            std::vector<uint32_t> idx(stdSigs.size());
-            for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = i;
-            std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
-            uint64_t total = 0, acc = 0; for (uint64_t v : w) total += v;
-            size_t headN = idx.size();
-            for (size_t k = idx.size(); k-- > 0;) { acc += w[idx[k]]; if (acc * 100u > total * kTailPercent) break; headN = k; }
-            std::vector<uint64_t> hw(headN); for (size_t k = 0; k < headN; ++k) hw[k] = w[idx[k]];
-            const std::vector<uint32_t> ho = shardOwners(hw, world);
-            owner.assign(stdSigs.size(), ~0u);
-            for (size_t k = 0; k < headN; ++k) owner[idx[k]] = ho[k];
-            const uint32_t nChunks = world * kChunksPerRank;
-            for (size_t k = headN; k < idx.size(); ++k) tail[(chunkBase + (k - headN) % nChunks)].push_back(Work{(uint32_t)l, stdSigs[idx[k]]});
         } else owner = shardOwners(w, world);
         for (uint32_t i = 0; i < stdSigs.size(); ++i) if (owner[i] == rank) work.push_back(Work{(uint32_t)l, stdSigs[i]});
         if (getenv("FS_TRACE")) fprintf(stderr, "[trace] library %zu: rank %u of %u (split role %u) packs %zu of %zu standard bins\n", l, rank, world, splitRole, work.size(), stdSigs.size());
@@ -1549,9 +1480,8 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
     for (const Work& w : work) stdBases += libs[w.lib]->bf.bins().at(w.sig).totalRawDnaSize;
     // (Round 3: with eight cores or more the block-0 threads start at once all the same -- a paired-end library's block 0 is
     // 0.8 s of one serial PPMd stream per 6 M pairs; behind a 1.3 s front end it WAS the end of the step (2.57 s), beside it
-    // it costs the front end a sixteenth of its cores for that time.  FS_BLOCK0_EARLY=0/1 forces either order.)
-    bool block0Early = hostCores >= 8;
-    if (const char* be = getenv("FS_BLOCK0_EARLY")) block0Early = atoi(be) != 0;
+    // it costs the front end a sixteenth of its cores for that time.)
+    const bool block0Early = hostCores >= 8;
     std::mutex gateMx; std::condition_variable gateCv; bool hostTasksDone = work.empty() || stdBases > budget || block0Early; size_t block0Unpacked = 0, block0Threads = 0;
     std::thread closer;
     if (rank == 0) {
@@ -1598,28 +1528,8 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         L.pending.clear();
     };
     Batch& batch = workBatch; std::vector<uint32_t> binArch; size_t next = 0, done = 0;
-    // the tail: one more chunk whenever what is left of this rank's work fits one batch (ranks that are behind do not ask)
-    // (the first claim, in front of the rank's first batch, takes all but one of the chunks a rank would get if all claimed
-    // alike -- they ride in that batch; every later claim is one chunk, a batch of its own: only a rank that is ahead pays it)
-    bool tailOpen = steal.p != nullptr; uint64_t stolenBins = 0; bool firstClaim = true;
-    auto claimChunk = [&]() {
-        if (!tailOpen) return;
-        uint64_t left = 0;
-        for (size_t k = next; k < work.size() && left <= budget; ++k) left += libs[work[k].lib]->bf.bins().at(work[k].sig).totalRawDnaSize;
-        if (left > budget) return;
-        uint32_t want = firstClaim ? (uint32_t)std::max<size_t>(1, tail.size() / std::max(1u, world) - 1u) : 1u;      // (tail.size() / world = a rank's share of the chunks)
-        firstClaim = false;
-        while (want) {                                              // (empty chunks -- tiny libraries -- are stepped over)
-            const uint32_t c = steal.claim();
-            if (c >= tail.size()) { tailOpen = false; return; }
-            if (tail[c].empty()) continue;
-            for (const Work& w : tail[c]) work.push_back(w);
-            stolenBins += tail[c].size(); stats.stolen_bins += tail[c].size();
-            --want;
-        }
-    };
     try {
-        for (claimChunk(); next < work.size(); claimChunk()) {
+        while (next < work.size()) {
             batch.clear(); binArch.clear();
             double tio = nowMs();
             // choose the bins of this batch by their (known) unpacked size, unpack them in parallel, then concatenate
@@ -1655,6 +1565,8 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             }
             // what a bin brings into a lane's staging buffer, roughly: its quality scores (packed, or a byte / a pair each), its
             // read ids, the descriptors and the small streams -- a fresh context sizes its lanes' pinned buffers by it up front
+            binBases.assign(nb, 0);
+            for (uint32_t k = 0; k < nb; ++k) binBases[k] = libs[work[first + k].lib]->bf.bins().at(work[first + k].sig).totalRawDnaSize;
             stageEstimate.assign(nb, 0); std::vector<uint64_t> archEstimate(nb, 0);
             for (uint32_t k = 0; k < nb; ++k) {
                 const BinInfo& bi = libs[work[first + k].lib]->bf.bins().at(work[first + k].sig);
@@ -1681,10 +1593,11 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             else { batch.qua.resize(seqBase[nb]); batch.quaPacked.clear(); batch.quaBit.clear(); }
             if (packedD) { batch.dnaPacked.resize(dpBase[nb]); batch.dnaBit.resize(recBase[nb]); batch.dnaInfo.resize(recBase[nb]); }
             else { batch.dnaPacked.clear(); batch.dnaBit.clear(); batch.dnaInfo.clear(); }
+            if (getenv("FS_TRACE")) fprintf(stderr, "[trace] batch of %u bins: record arrays placed at %.1f ms of the pack\n", nb, nowMs() - tStart);
             std::vector<Batch> graph(nb);                              // per bin: its stored graph (node indices local to it)
             for (size_t k = first; k < next; ++k) binArch.push_back(work[k].lib);
             stats.io_ms += nowMs() - tio;
-            const bool lastBatchNow = next >= work.size() && !tailOpen;
+            const bool lastBatchNow = next >= work.size();
             // what the archives will hold at the end, roughly: what they hold, what is pending, block 0 and a quarter of this
             // batch's staged bytes (PPMd on quality scores) -- their page-cache pages are made while the device works
             std::vector<uint64_t> aheadBytes(nLibs, 0);
@@ -1711,6 +1624,7 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
             compressBins(nb, weight, binArch, [&](uint32_t k, BinEncoder& enc, BinStreams& out, BinIn& info, uint64_t& recBytes) {
                 const Work& w = work[first + k];
                 const double tu = getenv("FS_BIN_TRACE") ? nowMs() : 0;
+                if (tu > 0 && k < 3) fprintf(stderr, "[bin] task %u starts at %.1f ms of the pack\n", k, tu - tStart);
                 libs[w.lib]->bf.unpackPlaced(w.sig, batch, seqBase[k], headBase[k], (uint32_t)recBase[k], graph[k], packedQ ? (int64_t)quaBase[k] : -1, packedH ? (int64_t)hpBase[k] : -1, packedD ? (int64_t)dpBase[k] : -1);
                 if (tu > 0 && recBase[k + 1] - recBase[k] >= 40000) fprintf(stderr, "[bin] %llu records: unpack %.1f ms\n", (unsigned long long)(recBase[k + 1] - recBase[k]), nowMs() - tu);
                 info = graph[k].bins.at(0);

@@ -114,6 +114,7 @@ struct Context {
     // (after unpacking it, for the file path) on one of the host threads
     typedef std::function<void(uint32_t, BinEncoder&, BinStreams&, BinIn&, uint64_t&)> BinProducer;
     void compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, const std::vector<uint32_t>& binArch, const BinProducer& produce);
+    std::vector<uint64_t> binBases;               // optional, per bin of the coming compressBins call: its bases (unpacked), for the slices' address budget
     std::vector<uint64_t> stageEstimate;          // optional, per bin of the coming compressBins call: bytes it will bring into a lane's staging buffer
     std::vector<BinIn> binInfo;                   // per bin of the last compressBins call
     std::function<void()> onHostTasksDone;        // called by compressBins when its host tasks are done (the device may still run)
@@ -124,10 +125,6 @@ struct Context {
     // two pipelines on one device for libraries of several batches (capi.cpp: packSplit): 0 = none, 1 = this context packs the
     // heaviest bins (one batch's worth: their streams are the longest of the job), 2 = all the others
     uint32_t splitRole = 0;
-    // bin-sharded packs (world_size > 1): the lightest bins are not dealt up front but claimed, a chunk at a time, by whichever rank
-    // runs out of work first -- a counter the ranks of the node share (packer.cpp: StealCounter).  Calls so far: names the counter.
-    uint32_t stealSeq = 0;
-    std::vector<std::string> stealNames;          // the counters of the last packs (files in /dev/shm: taken away two packs later, and with the context)
     struct { size_t reads = 0, seqBytes = 0, calls = 0, warm = 0; } matchReserve;     // bounds of the largest bin of the coming batch (0: grow on demand)
     std::atomic<uint64_t> matchedReads{0}, matchUs{0}, matchKernelUs{0}, matchBasesUp{0}, matchUnpackedReads{0};
     // the device unpacks the bases of the window search itself from the bin's .bdna bytes (FS_DEVICE_UNPACK=0: ASCII bases go up)

@@ -114,7 +114,7 @@ typedef struct fsgpu_stats {
     uint64_t tokenised_ids;              /* read ids split into the IdToken / IdValue streams by fs_tokenise_ids (device) */
     uint64_t device_batches;             /* device batches the standard bins were cut into (fsgpu_config.batch_bases each at most) */
     uint64_t ppmd_max_restarts;          /* most model restarts (sub-allocator exhausted, Model.cpp:109-140 again) inside ONE PPMd stream */
-    uint64_t stolen_bins;                /* bin-sharded packs with FS_STEAL=1: bins of the job's work-stealing tail that this rank claimed (the lightest 15 % of the records are then not dealt up front); 0 otherwise */
+    uint64_t stolen_bins;                /* always 0 since round 5 (the work-stealing tail of bin-sharded packs left the tree; the field stays for the layout's sake) */
     /* window search (fs_match_reads): bytes of bases that went up for it -- packed as the bin file stores them (.bdna) plus a
      * descriptor per read when the device unpacks them itself (fs_unpack_planes; FastqPacker.cpp:290-411), else ASCII --
      * and the reads whose bases the device unpacked */

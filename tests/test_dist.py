@@ -21,32 +21,26 @@ lib = fastore_amd.load_library(os.path.join(sys.argv[1], "build", "libfastore_em
 knobs = eval(sys.argv[7])
 with fastore_amd.Packer(lib=lib, host_threads=2, rank=dist.get_rank(), world_size=dist.get_world_size(), **knobs) as p:
     shard.pack_sharded(p, sys.argv[5], sys.argv[6], dist)
-    open(sys.argv[6] + ".stolen%d" % dist.get_rank(), "w").write("%d %d" % (p.stats()["stolen_bins"], p.stats()["bins"]))
+    open(sys.argv[6] + ".bins%d" % dist.get_rank(), "w").write("%d" % p.stats()["bins"])
 dist.destroy_process_group()
 '''
 
 
 @pytest.mark.parametrize("name", ["se_lossless", "pe_lossless"])
-@pytest.mark.parametrize("world,steal", [(2, "1"), (3, "1"), (2, None)])
-def test_sharded_pack_equals_single_writer(emu_lib, tmp_path, name, world, steal):
-    # steal: the work-stealing tail switched on (FS_STEAL=1) / the product's default (every bin dealt up front)
-    env = dict(os.environ); env.pop("FS_STEAL", None)
-    if steal:
-        env["FS_STEAL"] = steal
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pack_equals_single_writer(emu_lib, tmp_path, name, world):
     flags = [m for m in manifest() if m[0] == name][0][2]
     script = tmp_path / "w.py"; script.write_text(WORKER)
     port = str(29500 + (os.getpid() + world) % 400)
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r), str(world), os.path.join(GOLDEN, name + ".in"),
-                               str(tmp_path / "o"), repr(knobs_from_flags(flags))], env=env) for r in range(world)]
+                               str(tmp_path / "o"), repr(knobs_from_flags(flags))]) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
     assert_same_archive(str(tmp_path / "o"), os.path.join(GOLDEN, name + ".ref"))
     assert not [f for f in os.listdir(tmp_path) if ".part" in f]
-    # the work-stealing tail: the lightest bins were claimed from the node's counter (by whichever ranks asked first), every
-    # bin was packed exactly once (the archive above), and the counter's file is gone with the contexts
-    got = [tuple(int(x) for x in open(str(tmp_path / "o") + ".stolen%d" % r).read().split()) for r in range(world)]
-    assert (sum(s for s, _ in got) > 10 if steal else sum(s for s, _ in got) == 0) and all(b > 0 for _, b in got), got
-    assert not [f for f in os.listdir("/dev/shm") if f.startswith("fastore_steal.")]
+    # every rank packed a share of the bins (dealt up front: longest stream first), every bin exactly once (the archive above)
+    got = [int(open(str(tmp_path / "o") + ".bins%d" % r).read()) for r in range(world)]
+    assert all(b > 0 for b in got), got
 
 
 WORKER_SET = r'''

@@ -607,3 +607,18 @@ def test_device_emission_ops_and_the_host_walk_write_the_same_streams(emu_lib, t
         with fastore_amd.Packer(lib=emu_lib, device_id=0, **knobs_from_flags(flags)) as p:
             p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o" + mode)))
         assert open(str(tmp_path / ("o" + mode)) + ".cdata", "rb").read() == ref, mode
+
+
+@pytest.mark.parametrize("name,paired,flags", manifest()[:2])
+def test_a_slice_that_would_outgrow_its_address_space_falls_back_to_the_walks_own_streams(emu_lib, tmp_path, name, paired, flags):
+    # A slice lives in one 32-bit address space on the device; a bin whose base-holding streams the device writes costs ~7 bytes a base
+    # there.  Every bin claims its footprint from its slice's budget before its walk starts, and a bin that finds the budget used up keeps
+    # the walk's own streams instead of failing the pack ("emitted streams larger than 4 GiB" with few slices and > 0.6 GB of bases).
+    # Here with a budget of a few bins' worth and ONE slice: some bins go one way, some the other, the archive is the reference's.
+    code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import fastore_amd; from conftest import knobs_from_flags\n"
+            "lib = fastore_amd.load_library(%r)\n"
+            "with fastore_amd.Packer(lib=lib, device_id=0, pipeline_slices=1, **knobs_from_flags(%r)) as p: p.pack_file(%r, %r)" %
+            (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "build", "libfastore_emu.so"), list(flags), os.path.join(GOLDEN, name + ".in"), str(tmp_path / "o")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, env=dict(os.environ, FS_SLICE_DEV_CAP=str(2 << 20)))
+    assert r.returncode == 0, r.stderr
+    assert open(str(tmp_path / "o.cdata"), "rb").read() == open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
