@@ -1,6 +1,5 @@
-// Stream emission of one record: what the ops of fsdev::EmitOp write.  One source for the device kernels
-// (fs_emit_count / fs_emit_write: a thread per op, the same walk twice -- first counting, then writing behind the counts of the
-// ops in front) and for the test-only host emulation.
+// Stream emission of one record: what the ops of fsdev::EmitOp write -- the serial form: the definition the kernels'
+// wavefront-per-op form (emit_wave.h) is held against, and the test-only host emulation's own.
 //
 // Reference (fastore_pack/FastqCompressor.cpp): CompressHardRead :1388-1410, CompressNormalMatch :1460-1560, CompressContigRead
 // :1690-1760, StoreContigDefinition :1620-1680, LzCompressorPE::CompressPair's letter and match loops :4790-4900.
@@ -52,29 +51,11 @@ FS_EMIT_FN uint32_t channel_b(const fsdev::EmitOp& op)
 FS_EMIT_FN uint32_t unit_l(uint32_t ch) { return (ch == fsdev::ECH_HARD || ch == fsdev::ECH_HARD_PE) ? 1u : 2u; }
 FS_EMIT_FN bool is_bit_channel(uint32_t ch) { return ch == fsdev::ECH_MATCH_BITS || ch == fsdev::ECH_CMATCH_BITS || ch == fsdev::ECH_MATCH_BITS_PE; }
 
-// How an op reads the bin's bytes.  Direct: a load per byte (the host emulation).  Win16: sixteen bytes a load, kept in registers while the walk
-// stays inside them (the kernels: a thread that walks its record byte by byte touches every cache line sixty-four times, and between its
-// visits the lines of the other 63 threads of its wavefront push it out -- fs_emit_write moved 36 GB a step for 3 GB of bases,
-// profiles/r04_hbm_traffic.json).  `base` must be 16-byte aligned for Win16 (the bins' bases and contigs are placed so).
+// How the serial form reads the bin's bytes: a load per byte.  (The kernels take a wavefront per op: emit_wave.h.)
 struct Direct {
     const uint8_t* base;
     FS_EMIT_FN explicit Direct(const uint8_t* b) : base(b) {}
     FS_EMIT_FN uint32_t get(uint32_t off) const { return base[off]; }
-};
-struct Win16 {
-    const uint8_t* base; uint32_t blk; uint32_t w0, w1, w2, w3;
-    FS_EMIT_FN explicit Win16(const uint8_t* b) : base(b), blk(0xFFFFFFFFu), w0(0), w1(0), w2(0), w3(0) {}
-    FS_EMIT_FN uint32_t get(uint32_t off)
-    {
-        const uint32_t b = off >> 4;
-        if (b != blk) {
-            struct alignas(16) Q { uint32_t x, y, z, w; };
-            const Q q = *(const Q*)(base + 16u * (size_t)b);
-            w0 = q.x; w1 = q.y; w2 = q.z; w3 = q.w; blk = b;
-        }
-        const uint32_t k = (off >> 2) & 3u, w = k == 0u ? w0 : (k == 1u ? w1 : (k == 2u ? w2 : w3));
-        return (w >> (8u * (off & 3u))) & 0xFFu;
-    }
 };
 
 // seq: the bin's bases; contig: the bin's contig bytes (per contig: sequence[2 L] then variant[2 L], L = the contig's read length)
@@ -208,7 +189,7 @@ inline const char* plan_error(const uint8_t* input, size_t inputBytes, const fsd
         const EmitJob& jb = jobs[j];
         if (!((uint64_t)jb.first_op + jb.n_ops <= plan.n_ops && (uint64_t)jb.first_id + jb.n_ids <= plan.n_ids && jb.seq_off + jb.seq_bytes <= inputBytes &&
               jb.contig_off + jb.contig_bytes <= inputBytes && jb.sig_len >= 1u && jb.sig_len <= 32u)) return "ops, ids, bases or contig bytes outside the batch input";
-        // (the kernels read sixteen bytes a load: Win16)
+        // (the bins' bases and contig bytes are placed on sixteen-byte boundaries)
         if ((jb.seq_off & 15u) != 0u || (jb.contig_off & 15u) != 0u || ((jb.seq_off + jb.seq_bytes + 15u) & ~15ull) > ((inputBytes + 15u) & ~15ull) || ((jb.contig_off + jb.contig_bytes + 15u) & ~15ull) > ((inputBytes + 15u) & ~15ull))
             return "bases or contig bytes not placed on sixteen-byte boundaries";
         uint64_t need[ECH_COUNT + 1] = {0};

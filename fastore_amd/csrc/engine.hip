@@ -33,6 +33,7 @@
 #include "rc_core.h"
 #include "qvz_core.h"
 #include "emit_core.h"
+#include "emit_wave.h"
 
 using namespace fsdev;
 
@@ -537,67 +538,77 @@ __global__ __launch_bounds__(256) void fs_id_write(const IdChunk* __restrict__ c
 
 
 // ---- device-side stream emission (SURVEY 8 a6 + a11): fsdev::EmitOp, emit_core.h ----
-// The streams of a bin that hold bases are written here from the ops the host's walk left.  A thread per op, the op's walk twice
-// (fs_emit_count, then fs_emit_write behind the counts of the ops in front of it in ITS channels: fs_emit_scan, a workgroup per
-// bin); the match bits of the run-length coded channels land as a byte each and go through fs_rle_binary, the bin's LZ ids through
-// fs_rle0 -- BinaryRleEncoder and Rle0Encoder (rle/RleEncoder.h:21-79, 140-212) as block scans: what a position emits depends on
-// the symbols in front of it only through the length of the run it stands in (mod 253: a byte 255 is due every 253 ones; mod 2:
-// zeros go in pairs), and "the run so far" is a scan of maps that either restart the count (a zero / a value) or add to it.
+// The streams of a bin that hold bases are written here from the ops the host's walk left.  A WAVEFRONT per op (emit_wave.h: 64 lanes
+// take 64 consecutive positions of the record, a letter's place is a population count of a ballot, the match bits ARE a ballot and land
+// in a packed word array), the op's walk twice (fs_emit_count, then fs_emit_write behind the counts of the ops in front of it in ITS
+// channels: fs_emit_scan, a workgroup per bin); the packed match bits of the run-length coded channels go through fs_rle_binary, the
+// bin's LZ ids through fs_rle0 -- BinaryRleEncoder and Rle0Encoder (rle/RleEncoder.h:21-79, 140-212) as block scans: what a position
+// emits depends on the symbols in front of it only through the length of the run it stands in (mod 253: a byte 255 is due every 253
+// ones; mod 2: zeros go in pairs), and "the run so far" is a scan of maps that either restart the count (a zero / a value) or add to it.
+// The block scans: inside a wavefront by lane shuffles (six steps, no LDS, no barrier), across the workgroup's waves through one
+// LDS word a wave and two barriers (round 4: Hillis-Steele over 256 LDS words, sixteen barriers a scan).
 template <int T> __device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* sm, uint32_t& total)
 {
-    const uint32_t tid = threadIdx.x;
-    sm[tid] = v;
+    static_assert(T % 64 == 0 && T <= 1024, "whole wavefronts");
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t x = v;
+    #pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, (int)d, 64); if (lane >= d) x += y; }
+    if (lane == 63u) sm[wave] = x;
     __syncthreads();
-    for (uint32_t d = 1; d < (uint32_t)T; d <<= 1) {
-        const uint32_t a = tid >= d ? sm[tid - d] : 0u;
-        __syncthreads();
-        sm[tid] += a;
-        __syncthreads();
-    }
-    const uint32_t incl = sm[tid]; total = sm[T - 1];
+    uint32_t before = 0, all = 0;
+    #pragma unroll
+    for (uint32_t w = 0; w < (uint32_t)T / 64u; ++w) { const uint32_t t = sm[w]; if (w < wave) before += t; all += t; }
+    total = all;
     __syncthreads();
-    return incl - v;
+    return before + x - v;
 }
 // Every thread holds a map of a counter: `restart` -> the counter becomes v, else -> (counter + v) mod M.  Returns the counter as
 // it stands IN FRONT of this thread when `carry` stands in front of the block; carryOut: behind the block's last thread.
+// (maps compose: (k2, v2) after (k1, v1) = k2 ? (1, v2) : (k1, (v1 + v2) mod M))
 template <int T> __device__ __forceinline__ uint32_t block_counter_scan(bool restart, uint32_t v, uint32_t M, uint32_t carry, uint32_t* sk, uint32_t* sv, uint32_t& carryOut)
 {
-    const uint32_t tid = threadIdx.x;
-    sk[tid] = restart ? 1u : 0u; sv[tid] = v;
-    __syncthreads();
-    for (uint32_t d = 1; d < (uint32_t)T; d <<= 1) {
-        // the map of [tid - d - ..., tid - d] applied first, then mine
-        const uint32_t ok = tid >= d ? sk[tid - d] : 0u, ov = tid >= d ? sv[tid - d] : 0u;
-        const uint32_t mk = sk[tid], mv = sv[tid];
-        __syncthreads();
-        if (tid >= d && !mk) { sk[tid] = ok; sv[tid] = (ov + mv) % M; }
-        __syncthreads();
+    static_assert(T % 64 == 0 && T <= 1024, "whole wavefronts");
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t k = restart ? 1u : 0u, x = v % M;
+    #pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t pk = (uint32_t)__shfl_up((int)k, (int)d, 64), px = (uint32_t)__shfl_up((int)x, (int)d, 64);
+        if (lane >= d && !k) { k = pk; x = (px + x) % M; }
     }
-    const uint32_t lk = sk[T - 1], lv = sv[T - 1];
-    carryOut = lk ? lv : (carry + lv) % M;
-    uint32_t before = carry;
-    if (tid > 0u) { const uint32_t pk = sk[tid - 1], pv = sv[tid - 1]; before = pk ? pv : (carry + pv) % M; }
+    // the map of the lanes in front of me inside my wave (lane 0: none)
+    const uint32_t ek = (uint32_t)__shfl_up((int)k, 1, 64), ex = (uint32_t)__shfl_up((int)x, 1, 64);
+    if (lane == 63u) { sk[wave] = k; sv[wave] = x; }
     __syncthreads();
-    return before;
+    // the counter in front of my wave: the carry through the maps of the waves in front; and behind the block: through all of them
+    uint32_t cur = carry, mine = carry;
+    #pragma unroll
+    for (uint32_t w = 0; w < (uint32_t)T / 64u; ++w) { if (w == wave) mine = cur; cur = sk[w] ? sv[w] : (cur + sv[w]) % M; }
+    carryOut = cur;
+    __syncthreads();
+    return lane == 0u ? mine : (ek ? ex : (mine + ex) % M);
 }
 
-__global__ __launch_bounds__(256) void fs_emit_count(const EmitJob* __restrict__ jobs, const EmitOp* __restrict__ ops, uint32_t nOps, const uint8_t* __restrict__ in, uint32_t* __restrict__ counts)
+// one wavefront per op: what it writes into its (at most two) channels
+__device__ __forceinline__ void emit_count_body(const EmitJob* jobs, const EmitOp* ops, uint32_t nOps, const uint8_t* in, uint32_t* counts)
 {
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    if (g >= nOps) return;
+    const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (g >= nOps) return;                                              // (the whole wavefront)
     const EmitOp op = ops[g];
     const EmitJob& job = jobs[op.pad2[0]];
-    fsemit::Sink s;
-    fsemit::emit_op_with<fsemit::Win16>(op, job, in + job.seq_off, in + job.contig_off, s);
-    counts[2u * g] = s.nL; counts[2u * g + 1u] = s.nB;
+    const fsemit::WaveCount c = fsemit::emit_op_wave<false>(op, job, in + job.seq_off, in + job.contig_off, nullptr, nullptr, nullptr, 0u);
+    if ((threadIdx.x & 63u) == 0u) { counts[2u * g] = c.nL; counts[2u * g + 1u] = c.nB; }
 }
+__global__ __launch_bounds__(256) void fs_emit_count(const EmitJob* __restrict__ jobs, const EmitOp* __restrict__ ops, uint32_t nOps, const uint8_t* __restrict__ in, uint32_t* __restrict__ counts)
+{ emit_count_body(jobs, ops, nOps, in, counts); }
 
 // one workgroup per bin: every op's place in its channels; the channels' totals; the lengths of the streams that are complete with
-// fs_emit_write (all but the run-length coded ones) into their stream items
+// fs_emit_write (all but the run-length coded ones) into their stream items; the packed words of the bit channels cleared (fs_emit_write
+// ORs the match bits into them)
 __global__ __launch_bounds__(256) void fs_emit_scan(const EmitJob* __restrict__ jobs, const EmitOp* __restrict__ ops, const uint32_t* __restrict__ counts, uint32_t* __restrict__ offs,
-                                                    uint32_t* __restrict__ totals, StreamItem* items)
+                                                    uint32_t* __restrict__ totals, StreamItem* items, uint8_t* __restrict__ out)
 {
-    __shared__ uint32_t sm[256];
+    __shared__ uint32_t sm[4];
     __shared__ uint32_t run[ECH_COUNT];
     const EmitJob& job = jobs[blockIdx.x];
     const uint32_t tid = threadIdx.x;
@@ -629,39 +640,48 @@ __global__ __launch_bounds__(256) void fs_emit_scan(const EmitJob* __restrict__ 
         totals[(ECH_COUNT + 1u) * blockIdx.x + tid] = run[tid];
         if (!fsemit::is_bit_channel(tid) && job.item[tid] != 0xFFFFFFFFu) items[job.item[tid]].in_len = run[tid];
     }
+    for (uint32_t c = 0; c < ECH_COUNT; ++c) {
+        if (!fsemit::is_bit_channel(c) || job.item[c] == 0xFFFFFFFFu) continue;
+        uint32_t* words = (uint32_t*)(out + job.raw_off[c]);
+        const uint32_t n = (run[c] + 31u) / 32u + 2u;                      // (+ 2: append_bits may touch two words behind the last bit's; the room is the channel's cap in BYTES: >= n * 4)
+        for (uint32_t i = tid; i < n; i += 256u) words[i] = 0u;
+    }
 }
 
-__global__ __launch_bounds__(256) void fs_emit_write(const EmitJob* __restrict__ jobs, const EmitOp* __restrict__ ops, uint32_t nOps, const uint8_t* __restrict__ in, const uint32_t* __restrict__ offs,
-                                                     uint8_t* __restrict__ out)
+__device__ __forceinline__ void emit_write_body(const EmitJob* jobs, const EmitOp* ops, uint32_t nOps, const uint8_t* in, const uint32_t* offs, uint8_t* out)
 {
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t g = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (g >= nOps) return;
     const EmitOp op = ops[g];
     const EmitJob& job = jobs[op.pad2[0]];
     const uint32_t chL = fsemit::channel_l(op), chB = fsemit::channel_b(op);
-    fsemit::Sink s;
-    uint8_t dummy[2];
-    s.outL = chL < ECH_COUNT ? out + job.out_off[chL] + (uint64_t)fsemit::unit_l(chL) * offs[2u * g] : dummy;
-    s.outB = chB < ECH_COUNT ? (fsemit::is_bit_channel(chB) ? out + job.raw_off[chB] + offs[2u * g + 1u] : out + job.out_off[chB] + 2ull * offs[2u * g + 1u]) : dummy;
-    fsemit::emit_op_with<fsemit::Win16>(op, job, in + job.seq_off, in + job.contig_off, s);
+    const uint32_t offL = offs[2u * g], offB = offs[2u * g + 1u];
+    uint8_t* outL = chL < ECH_COUNT ? out + job.out_off[chL] + (uint64_t)fsemit::unit_l(chL) * offL : nullptr;
+    const bool bitCh = chB < ECH_COUNT && fsemit::is_bit_channel(chB);
+    uint8_t* outSym = (chB < ECH_COUNT && !bitCh) ? out + job.out_off[chB] + 2ull * offB : nullptr;
+    uint32_t* outBits = bitCh ? (uint32_t*)(out + job.raw_off[chB]) : nullptr;
+    (void)fsemit::emit_op_wave<true>(op, job, in + job.seq_off, in + job.contig_off, outL, outSym, outBits, offB);
 }
+__global__ __launch_bounds__(256) void fs_emit_write(const EmitJob* __restrict__ jobs, const EmitOp* __restrict__ ops, uint32_t nOps, const uint8_t* __restrict__ in, const uint32_t* __restrict__ offs,
+                                                     uint8_t* __restrict__ out)
+{ emit_write_body(jobs, ops, nOps, in, offs, out); }
 
-// BinaryRleEncoder over one bit channel of one bin (blockIdx.x = 3 * bin + which).  A thread takes 16 bits; a chunk is 4 096 bits.
+// BinaryRleEncoder over one bit channel of one bin (blockIdx.x = 3 * bin + which).  The bits come packed (LSB first: fs_emit_write);
+// a thread takes 16 of them with one shift; a chunk is 4 096 bits.
 __global__ __launch_bounds__(256) void fs_rle_binary(const EmitJob* __restrict__ jobs, const uint32_t* __restrict__ totals, uint8_t* out, StreamItem* items)
 {
-    __shared__ uint32_t sk[256], sv[256];
+    __shared__ uint32_t sk[4], sv[4];
     const uint32_t chOf[3] = {ECH_MATCH_BITS, ECH_CMATCH_BITS, ECH_MATCH_BITS_PE};
     const uint32_t j = blockIdx.x / 3u, ch = chOf[blockIdx.x % 3u];
     const EmitJob& job = jobs[j];
     if (job.item[ch] == 0xFFFFFFFFu) return;                              // (uniform: the whole workgroup)
     const uint32_t n = totals[(ECH_COUNT + 1u) * j + ch], tid = threadIdx.x;
-    const uint8_t* bits = out + job.raw_off[ch];
+    const uint32_t* words = (const uint32_t*)(out + job.raw_off[ch]);
     uint8_t* dst = out + job.out_off[ch];
     uint32_t carry = 0, written = 0;
     for (uint32_t base = 0; base < n; base += 4096u) {
         const uint32_t i0 = base + 16u * tid, cnt = i0 >= n ? 0u : (n - i0 < 16u ? n - i0 : 16u);
-        uint32_t m = 0;                                                    // bit k: position i0 + k holds a one
-        for (uint32_t k = 0; k < cnt; ++k) m |= (bits[i0 + k] ? 1u : 0u) << k;
+        const uint32_t m = cnt ? (words[i0 >> 5] >> (i0 & 31u)) & ((1u << cnt) - 1u) : 0u;      // bit k: position i0 + k holds a one
         const uint32_t zeros = cnt ? ~m & ((1u << cnt) - 1u) : 0u;
         const uint32_t lead = zeros ? (uint32_t)__builtin_ctz(zeros) : cnt;              // ones in front of my first zero
         const uint32_t tail = zeros ? cnt - 1u - (31u - (uint32_t)__builtin_clz(zeros)) : 0u;      // ones behind my last zero
@@ -687,7 +707,7 @@ __global__ __launch_bounds__(256) void fs_rle_binary(const EmitJob* __restrict__
 // Rle0Encoder over the LZ ids of one bin.  A thread takes one id; the counter is the parity of the zeros in front of it.
 __global__ __launch_bounds__(256) void fs_rle0(const EmitJob* __restrict__ jobs, const uint32_t* __restrict__ ids, uint8_t* out, StreamItem* items)
 {
-    __shared__ uint32_t sk[256], sv[256];
+    __shared__ uint32_t sk[4], sv[4];
     const EmitJob& job = jobs[blockIdx.x];
     if (job.item[ECH_COUNT] == 0xFFFFFFFFu) return;
     const uint32_t n = job.n_ids, tid = threadIdx.x;
@@ -1054,13 +1074,13 @@ static int emit_launch(Device* dev, hipStream_t st, const EmitPlan& plan, uint64
     uint32_t* counts = (uint32_t*)(dev->dIn + L.countsOff); uint32_t* offs = (uint32_t*)(dev->dIn + L.offsOff); uint32_t* totals = (uint32_t*)(dev->dIn + L.totalsOff);
     uint8_t* out = (uint8_t*)(dev->dIn + emitBase);
     if (plan.n_ops) {
-        hipLaunchKernelGGL(fs_emit_count, dim3((plan.n_ops + 255u) / 256u), dim3(256), 0, st, jobs, ops, plan.n_ops, (const uint8_t*)dev->dIn, counts);
+        hipLaunchKernelGGL(fs_emit_count, dim3((plan.n_ops + 3u) / 4u), dim3(256), 0, st, jobs, ops, plan.n_ops, (const uint8_t*)dev->dIn, counts);
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(fs_emit_scan, dim3(plan.n_jobs), dim3(256), 0, st, jobs, ops, (const uint32_t*)counts, offs, totals, (StreamItem*)dev->dItems);
+    hipLaunchKernelGGL(fs_emit_scan, dim3(plan.n_jobs), dim3(256), 0, st, jobs, ops, (const uint32_t*)counts, offs, totals, (StreamItem*)dev->dItems, out);
     HIP_TRY(hipGetLastError());
     if (plan.n_ops) {
-        hipLaunchKernelGGL(fs_emit_write, dim3((plan.n_ops + 255u) / 256u), dim3(256), 0, st, jobs, ops, plan.n_ops, (const uint8_t*)dev->dIn, (const uint32_t*)offs, out);
+        hipLaunchKernelGGL(fs_emit_write, dim3((plan.n_ops + 3u) / 4u), dim3(256), 0, st, jobs, ops, plan.n_ops, (const uint8_t*)dev->dIn, (const uint32_t*)offs, out);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(fs_rle_binary, dim3(3u * plan.n_jobs), dim3(256), 0, st, jobs, (const uint32_t*)totals, out, (StreamItem*)dev->dItems);

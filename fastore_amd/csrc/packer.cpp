@@ -1233,8 +1233,6 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         // stays under test row for row and archive for archive.
         const int matesMode = getenv("FS_DEVICE_MATES") ? atoi(getenv("FS_DEVICE_MATES")) : 0;       // (read per batch: the tests switch it inside one process)
         const bool deviceEmit = !(getenv("FS_DEVICE_EMIT") && atoi(getenv("FS_DEVICE_EMIT")) == 0);
-        std::unique_ptr<MateDispatcher> mateDispatcher;
-        if (matesMode == 2 && deviceEmit && deviceMatcher) mateDispatcher.reset(new MateDispatcher(*this));
         std::mutex asyncErrMx; std::string asyncErr;
         // (a bin whose pairs are with the device is complete when BOTH its host task has returned -- it still fills in the bin's packed
         // scores and read ids behind the walk -- and its rows have come back: whichever is second counts it)
@@ -1257,6 +1255,10 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             { std::lock_guard<std::mutex> lk(S.mx); last = --S.pending == 0; }
             if (last) S.cv.notify_all();
         };
+        // (declared behind everything its workers' callbacks touch -- parts, the error string and its mutex, binComplete --: should a host
+        // task throw, the unwinding joins the workers FIRST, while all of that is still there)
+        std::unique_ptr<MateDispatcher> mateDispatcher;
+        if (matesMode == 2 && deviceEmit && deviceMatcher) mateDispatcher.reset(new MateDispatcher(*this));
         parallelFor(nBins, hostThreads, [&](uint32_t k, uint32_t tid) {
             const uint32_t b = byWork[k];
             if (abort.load()) return;                                // (the device could not be made: nothing left to do for the bins)

@@ -354,16 +354,20 @@ static void emitStreams(uint8_t* buf, const EmitPlan& plan, uint64_t emitBase, s
     for (uint32_t j = 0; j < plan.n_jobs; ++j) {
         const EmitJob& job = jobs[j];
         uint32_t at[ECH_COUNT] = {0};
+        // FS_EMU_SIMT_EMIT=<build/libsimt_emu.so>: the kernels' own body -- a wavefront per op, the match bits as packed ballots (emit_wave.h) -- on the
+        // lock-step wave emulation (tests/emu/emit_simt.cpp) instead of the serial form below
+        typedef int (*SimtEmit)(const uint8_t*, const EmitJob*, const EmitOp*, uint8_t*, uint32_t*);
+        static const SimtEmit simtEmit = []() -> SimtEmit { const char* lib = getenv("FS_EMU_SIMT_EMIT"); if (!lib) return nullptr; void* h = dlopen(lib, RTLD_NOW | RTLD_LOCAL); return h ? (SimtEmit)dlsym(h, "simt_emit_job") : (SimtEmit) nullptr; }();
+        if (getenv("FS_EMU_SIMT_EMIT")) {
+            if (!simtEmit || simtEmit(buf, &job, ops, out, at) != 0) { fprintf(stderr, "FS_EMU_SIMT_EMIT: the emulated emission kernels could not run\n"); abort(); }
+        } else
         for (uint32_t k = 0; k < job.n_ops; ++k) {
             const EmitOp& op = ops[job.first_op + k];
             const uint32_t chL = fsemit::channel_l(op), chB = fsemit::channel_b(op);
             fsemit::Sink s; uint8_t dummy[4];
             s.outL = chL < ECH_COUNT ? out + job.out_off[chL] + (uint64_t)fsemit::unit_l(chL) * at[chL] : dummy;
             s.outB = chB < ECH_COUNT ? (fsemit::is_bit_channel(chB) ? out + job.raw_off[chB] + at[chB] : out + job.out_off[chB] + 2ull * at[chB]) : dummy;
-            // (FS_EMU_WIN16=1: through the kernels' reader -- sixteen bytes a load -- instead of a load per byte; the batch buffer is malloc'ed, its regions sixteen-byte placed)
-            static const bool win16 = getenv("FS_EMU_WIN16") && atoi(getenv("FS_EMU_WIN16")) != 0;
-            if (win16 && ((uintptr_t)buf & 15u) == 0u) fsemit::emit_op_with<fsemit::Win16>(op, job, buf + job.seq_off, buf + job.contig_off, s);
-            else fsemit::emit_op(op, job, buf + job.seq_off, buf + job.contig_off, s);
+            fsemit::emit_op(op, job, buf + job.seq_off, buf + job.contig_off, s);
             if (chL < ECH_COUNT) at[chL] += s.nL;
             if (chB < ECH_COUNT) at[chB] += s.nB;
         }

@@ -592,15 +592,7 @@ def test_device_emission_ops_and_the_host_walk_write_the_same_streams(emu_lib, t
     with fastore_amd.Packer(lib=emu_lib, device_id=0, **knobs_from_flags(flags)) as p:
         ops, streams, differing = p.emit_check(os.path.join(GOLDEN, name + ".in"))
     assert ops > 1000 and streams >= 7 * 20 and differing == 0, (ops, streams, differing)
-    # ... and through the kernels' reader (fsemit::Win16: sixteen bytes a load, kept while the walk stays inside them) in a process of its own
-    # (the emulation reads the switch once)
-    code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import fastore_amd; from conftest import knobs_from_flags\n"
-            "lib = fastore_amd.load_library(%r)\n"
-            "with fastore_amd.Packer(lib=lib, device_id=0, **knobs_from_flags(%r)) as p: print(p.emit_check(%r))" %
-            (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "build", "libfastore_emu.so"), list(flags), os.path.join(GOLDEN, name + ".in")))
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, env=dict(os.environ, FS_EMU_WIN16="1"))
-    assert r.returncode == 0, r.stderr
-    assert eval(r.stdout.decode().strip().splitlines()[-1]) == (ops, streams, 0)
+    # (the kernels' own form -- a wavefront per op, emit_wave.h -- runs on the lock-step emulation: tests/test_simt.py)
     ref = open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
     for mode in ("1", "0"):
         monkeypatch.setenv("FS_DEVICE_EMIT", mode)

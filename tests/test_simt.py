@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, VECTORS, oracle_ppmd
+from conftest import GOLDEN, ROOT, VECTORS, manifest, oracle_ppmd
 
 
 @pytest.fixture(scope="module")
@@ -18,7 +18,7 @@ def simt():
     os.makedirs(os.path.dirname(out), exist_ok=True)
     # FS_EMU_DEFS: extra -D flags (kernel experiments, e.g. -DFS_WIN_PREFETCH=1) for the same tests
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-DFS_SIMT_EMU"] + os.environ.get("FS_EMU_DEFS", "").split() + ["-shared", "-fPIC", "-o", out,
-                           os.path.join(ROOT, "tests", "emu", "ppmd_simt.cpp"), os.path.join(ROOT, "tests", "emu", "mates_simt.cpp"), os.path.join(ROOT, "tests", "emu", "simt.cpp"), os.path.join(ROOT, "tests", "emu", "qvz_host_ref.cpp")])
+                           os.path.join(ROOT, "tests", "emu", "ppmd_simt.cpp"), os.path.join(ROOT, "tests", "emu", "mates_simt.cpp"), os.path.join(ROOT, "tests", "emu", "emit_simt.cpp"), os.path.join(ROOT, "tests", "emu", "simt.cpp"), os.path.join(ROOT, "tests", "emu", "qvz_host_ref.cpp")])
     lib = ctypes.CDLL(out)
     lib.simt_ppmd_encode.restype = ctypes.c_size_t
     lib.simt_ppmd_encode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
@@ -273,3 +273,23 @@ def test_mate_search_kernel_body_gives_the_host_searchs_rows(simt, monkeypatch, 
         with fastore_amd.Packer(lib=emu, device_id=0, **kn) as p:
             pairs, differing = p.pe_matcher_check(os.path.join(GOLDEN, name + ".in"))
         assert pairs > 1000 and differing == 0, (name, window, pairs, differing)
+
+
+@pytest.mark.parametrize("name,paired,flags", manifest())
+def test_emission_kernel_body_writes_the_host_walks_streams(simt, name, paired, flags):
+    # fs_emit_count / fs_emit_write's body (emit_wave.h: a wavefront per op -- a letter's place is the population count of a ballot, the match
+    # bits are a ballot and land in a packed word array) on the lock-step wave emulation: the PRE-ENTROPY bytes of every base-holding stream
+    # of every standard bin of every golden library against the host walk writing them itself (the product's own check, fsgpu_emit_check),
+    # and the archive.  In a process of its own: the emulation library reads the switch once.
+    code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import fastore_amd; from conftest import knobs_from_flags\n"
+            "lib = fastore_amd.load_library(%r)\n"
+            "with fastore_amd.Packer(lib=lib, device_id=0, **knobs_from_flags(%r)) as p:\n"
+            "    print(p.emit_check(%r)); p.pack_file(%r, sys.argv[1])" %
+            (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "build", "libfastore_emu.so"), list(flags), os.path.join(GOLDEN, name + ".in"), os.path.join(GOLDEN, name + ".in")))
+    import tempfile
+    with tempfile.TemporaryDirectory() as t:
+        r = subprocess.run([sys.executable, "-c", code, os.path.join(t, "o")], capture_output=True, env=dict(os.environ, FS_EMU_SIMT_EMIT=os.path.join(ROOT, "build", "libsimt_emu.so")), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ops, streams, differing = eval(r.stdout.decode().strip().splitlines()[-1])
+        assert ops > 1000 and streams >= 7 * 20 and differing == 0, (ops, streams, differing)
+        assert open(os.path.join(t, "o.cdata"), "rb").read() == open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
