@@ -62,6 +62,7 @@ void pinned_free(void* p, size_t bytes, bool pinned = true);
 void set_pageable_staging(bool on);
 bool pageable_staging();
 uint8_t* staging_buffer(Device* dev, size_t bytes);     // grow-only pinned host buffer for the batch input
+void staging_release(Device* dev);                      // the lane's staging buffers go (a context that packs once: behind its last slice, beside the device's tail)
 int lanes_equalize(Device* const* lanes, size_t n);     // between batches: every lane gets the device buffers of the best-equipped one
 int encode_streams_raw(Device* dev, const uint8_t* input, size_t inputBytes, std::vector<fsdev::StreamItem>& items,
                        std::vector<uint8_t>& raw, std::vector<uint32_t>& sizes, BatchTiming* timing);

@@ -940,13 +940,17 @@ void device_destroy(Device* dev)
     if (!dev) return;
     (void)hipSetDevice(dev->deviceId);
     if (dev->stream) (void)hipStreamSynchronize((hipStream_t)dev->stream);
+    const double td0 = wallMs();
     void* ptrs[] = {dev->queueHead, dev->dIn, dev->dScratch, dev->dItems, dev->dOrder, dev->dSizes, dev->dRestarts, dev->dPlans, dev->dBlocks};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    const double td1 = wallMs();
     if (dev->evWait) (void)hipEventDestroy((hipEvent_t)dev->evWait);
     if (dev->hStage) pinned_free(dev->hStage, dev->capStage, !dev->stagePageable);
     for (uint32_t i = 0; i < dev->nOldStage; ++i) pinned_free(dev->oldStage[i], dev->oldStageCap[i], !dev->stagePageable);
+    const double td2 = wallMs();
     for (int i = 0; i < 6; ++i) if (dev->ev[i]) (void)hipEventDestroy((hipEvent_t)dev->ev[i]);
     if (dev->stream) (void)hipStreamDestroy((hipStream_t)dev->stream);
+    if (dev->trace) fprintf(stderr, "[trace] lane teardown: device buffers %.1f ms, staging buffer %.1f ms, events + stream %.1f ms\n", td1 - td0, td2 - td1, wallMs() - td2);
     if (Pool* pool = dev->pool) {
         bool last;
         { std::lock_guard<std::mutex> g(pool->m); last = --pool->lanes == 0; }
@@ -1014,6 +1018,14 @@ uint8_t* staging_buffer(Device* dev, size_t bytes)
     if (!dev->hStage) { snprintf(dev->err, sizeof dev->err, "pinned staging buffer of %zu bytes failed", want); return nullptr; }
     dev->capStage = want;
     return dev->hStage;
+}
+
+void staging_release(Device* dev)
+{
+    if (dev->hStage) pinned_free(dev->hStage, dev->capStage, !dev->stagePageable);
+    dev->hStage = nullptr; dev->capStage = 0;
+    for (uint32_t i = 0; i < dev->nOldStage; ++i) pinned_free(dev->oldStage[i], dev->oldStageCap[i], !dev->stagePageable);
+    dev->nOldStage = 0;
 }
 
 // H2D + fs_encode_streams + D2H of the per-stream sizes.  Leaves the coded streams in dev->dScratch.

@@ -144,6 +144,8 @@ struct Batch {
     std::vector<BinIn> bins;
     // append `o` (whole bins) behind this batch, re-basing every index
     void append(const Batch& o);
+    // give the memory back (clear() keeps the capacity for the next batch)
+    void release() { Batch empty; std::swap(*this, empty); }
     void clear() { seq.clear(); qua.clear(); head.clear(); recs.clear(); quaPacked.clear(); quaBit.clear(); headPacked.clear(); headBit.clear(); dnaPacked.clear(); dnaBit.clear(); dnaInfo.clear(); nodes.clear(); topNodes.clear(); emRecs.clear(); trees.clear(); bins.clear(); }
 };
 

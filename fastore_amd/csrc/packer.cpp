@@ -857,6 +857,8 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         }
     });
 
+    std::atomic<uint32_t> slicesWithLane(0), slicesStaged(0);
+    std::thread stagedReleaser; std::mutex releaserMx;
     auto runSlice = [&](uint32_t si) {
         Slice& S = slices[si];
         {   // the slice's bins have all been through the front end
@@ -880,6 +882,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 }
             }
             S.lane = (int)freeLanes[pick]; freeLanes.erase(freeLanes.begin() + (ptrdiff_t)pick);
+            ++slicesWithLane;
         }
         S.tReady = nowMs();
         try {
@@ -1167,9 +1170,13 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 }
             });
             S.tSubmit = nowMs(); S.inBytes = inBytes;
+            // (everything the slice needs of the batch's arrays is in its staging buffer now)
+            if (++slicesStaged == nSlices && releaseEarly && onAllStaged) { std::lock_guard<std::mutex> g(releaserMx); stagedReleaser = std::thread(onAllStaged); }
             if (fsengine::encode_batch(L, input, inBytes, S.items, S.plans, sliceBlocks[si], S.sizes, &S.timing, nStrings ? &gp : nullptr, idJobs.empty() ? nullptr : &ip, emitJobs.empty() ? nullptr : &ep) != 0) S.err = std::string("device: ") + L->err;
         } catch (const std::exception& e) { S.err = e.what(); }
         S.tDone = nowMs();
+        // (a context that packs once: no further slice will ask for a lane -- this one's staging buffer goes now, beside the device's tail)
+        if (releaseEarly && slicesWithLane.load() == nSlices && S.lane >= 0) fsengine::staging_release(lanes[(uint32_t)S.lane]);
         { std::lock_guard<std::mutex> lk(laneMx); freeLanes.push_back((uint32_t)S.lane); }
         laneCv.notify_one();
         { std::lock_guard<std::mutex> lk(S.mx); S.done = true; }
@@ -1205,6 +1212,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     auto joinAll = [&]() {
         if (laneMaker.joinable()) laneMaker.join();
         for (Slice& s : slices) if (s.th.joinable()) s.th.join();
+        { std::lock_guard<std::mutex> g(releaserMx); if (stagedReleaser.joinable()) stagedReleaser.join(); }
         nLanes = madeLanes.load();
         if (watchdog.joinable()) { { std::lock_guard<std::mutex> g(wdMx); wdStop = true; } wdCv.notify_all(); watchdog.join(); }
     };
@@ -1623,6 +1631,9 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
                     parallelFor((uint32_t)nLibs, std::min<uint32_t>((uint32_t)nLibs, 8u), [&](uint32_t l, uint32_t) { libs[l]->bf.close(); });
                 });
             };
+            releaseEarly = cfg.one_shot != 0 && lastBatchNow;
+            // (... and what only the host tasks and the staging used: the bins' streams, the encoders' work buffers)
+            onAllStaged = [&]() { const double tr = nowMs(); batch.release(); std::vector<Batch>().swap(graph); std::vector<BinStreams>().swap(streamPool); encoders.clear(); if (getenv("FS_TRACE")) fprintf(stderr, "[trace] the batch's record arrays given back in %.1f ms, at %.1f ms of the pack\n", nowMs() - tr, nowMs() - tStart); };
             compressBins(nb, weight, binArch, [&](uint32_t k, BinEncoder& enc, BinStreams& out, BinIn& info, uint64_t& recBytes) {
                 const Work& w = work[first + k];
                 const double tu = getenv("FS_BIN_TRACE") ? nowMs() : 0;
@@ -1692,14 +1703,14 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         if (verbose == 1) for (size_t l = 0; l < nLibs; ++l) libs[l]->aw.printStreamSizes(stdout);
         stats.io_ms += nowMs() - tio;
     } catch (...) {
-        onHostTasksDone = nullptr;
+        onHostTasksDone = nullptr; onAllStaged = nullptr; releaseEarly = false;
         { std::lock_guard<std::mutex> lk(gateMx); hostTasksDone = true; }
         gateCv.notify_all();
         for (auto& L : libs) if (L->t0.joinable()) L->t0.join();
         if (closer.joinable()) closer.join();
         throw;
     }
-    onHostTasksDone = nullptr;
+    onHostTasksDone = nullptr; onAllStaged = nullptr; releaseEarly = false;
     { std::lock_guard<std::mutex> lk(gateMx); hostTasksDone = true; }          // no standard bins at all: block 0 starts here
     gateCv.notify_all();
     if (closer.joinable()) closer.join();

@@ -118,6 +118,12 @@ struct Context {
     std::vector<uint64_t> stageEstimate;          // optional, per bin of the coming compressBins call: bytes it will bring into a lane's staging buffer
     std::vector<BinIn> binInfo;                   // per bin of the last compressBins call
     std::function<void()> onHostTasksDone;        // called by compressBins when its host tasks are done (the device may still run)
+    // A context that packs ONCE (the CLI): what the last batch does not need any more is given back while the device still walks the long
+    // streams -- the batch's record arrays when its last slice has been staged (onAllStaged, on a thread of its own), a lane's staging
+    // buffer when its slice is done -- instead of at the process's end, where freeing 8 GB of pages was 0.5 s of its 2.4 s
+    // (profiles/r05_cli_trace.txt).  Set by packFiles for the last batch.
+    bool releaseEarly = false;
+    std::function<void()> onAllStaged;
     std::vector<std::unique_ptr<BinEncoder>> encoders;   // one per host thread
     // device-side window search (matcher.hip): a matcher lane per host thread, made on first use; deviceMatcher off = host scan
     std::vector<fsengine::MatchLane*> matchLanes;

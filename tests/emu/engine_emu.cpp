@@ -31,6 +31,7 @@ void set_pageable_staging(bool) {}
 bool pageable_staging() { return false; }
 int lane_debug(Device*, char* out, size_t outLen) { if (out && outLen) snprintf(out, outLen, "host emulation"); return 0; }
 
+void staging_release(Device* d) { free(d->hStage); d->hStage = nullptr; d->capStage = 0; }
 uint8_t* staging_buffer(Device* d, size_t bytes)
 { if (bytes > d->capStage) { free(d->hStage); d->hStage = (uint8_t*)malloc(bytes + bytes / 4 + 4096); d->capStage = bytes + bytes / 4 + 4096; } return d->hStage; }
 

@@ -28,6 +28,15 @@ s=$(date +%s.%N); FS_TRACE=1 fastore_amd/fastore_pack e -i$lib -o$W/cli_o -r -f2
 echo "traced run: $(python3 -c "print('%.2f' % ($e - $s))") s" >> $out
 echo "---- FS_TRACE=1 FS_BIN_TRACE=40000 (stage clocks of the heaviest bins) ----" >> $out
 FS_TRACE=1 FS_BIN_TRACE=40000 fastore_amd/fastore_pack e -i$lib -o$W/cli_o -r -f256 -c10 -d8 -w1024 -W1024 2>&1 | grep -E "^\[bin\]|slice 1/|main:|device_create: up|record arrays|library 0" | head -150 >> $out
+echo "---- a warm context with the host's window scan (FS_DEVICE_MATCHER=0): stage clocks of the heaviest bins ----" >> $out
+FS_DEVICE_MATCHER=0 FS_BIN_TRACE=40000 python3 - 2>&1 <<PY3 | grep -E "nodes \+ sort|pack" | head -14 >> $out
+import sys, os, time
+sys.path.insert(0, os.getcwd())
+import fastore_amd
+with fastore_amd.Packer(device_id=0) as p:
+    for i in range(2):
+        t = time.time(); p.pack_file("$lib", "$W/py_o"); print("pack %d: %.2f s" % (i, time.time() - t), flush=True)
+PY3
 echo "---- the same in a warm context (python: one Packer, three packs; FS_BIN_TRACE on the last) ----" >> $out
 FS_BIN_TRACE=40000 python3 - >> $out 2>&1 <<PY2
 import sys, os, time
