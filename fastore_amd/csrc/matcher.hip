@@ -261,10 +261,14 @@ __global__ __launch_bounds__(1024) void fs_match_mates(const MateJob* __restrict
 #endif
 }
 
+// (a lane's search buffers may be carved out of ONE allocation: match_lane_reserve; a buffer that outgrows its part gets an allocation of its own,
+// and only what is not inside the block is ever freed by itself)
+static thread_local const uint8_t* t_blockLo = nullptr; static thread_local const uint8_t* t_blockHi = nullptr;
+static bool insideBlock(const void* p) { return p && (const uint8_t*)p >= t_blockLo && (const uint8_t*)p < t_blockHi; }
 template <class T> int ensureBuf(fsengine::Device* dev, T*& p, size_t& cap, size_t need)
 {
     if (need <= cap && p) return 0;
-    if (p) (void)hipFree(p);
+    if (p && !insideBlock(p)) (void)hipFree(p);
     p = nullptr; cap = 0;
     const size_t want = need + need / 4 + 4096;
     hipError_t e = hipMalloc((void**)&p, want);
@@ -309,7 +313,10 @@ struct MatchLane {
     uint32_t* dHist = nullptr; size_t capHist = 0;             // the mate searches' histories (mates_core.h: hist_words per bin of a launch)
     uint8_t* hStage = nullptr; size_t capStage = 0; bool stagePageable = false;
     bool ownStream = false;
+    uint8_t* block = nullptr; size_t blockBytes = 0;      // the eight search buffers as made by match_lane_reserve: one allocation
 };
+// (ensureBuf's view of the lane whose buffers it is asked to grow)
+struct BlockScope { explicit BlockScope(const MatchLane* m) { t_blockLo = m->block; t_blockHi = m->block ? m->block + m->blockBytes : nullptr; } ~BlockScope() { t_blockLo = t_blockHi = nullptr; } };
 
 int match_lane_create(Device* dev, MatchLane** out, bool ownStream)
 {
@@ -351,7 +358,8 @@ void match_lane_destroy(MatchLane* m)
         m->stream = nullptr;
     }
     void* ptrs[] = {m->dSeq, m->dReads, m->dPacked, m->dCalls, m->dIds, m->dWarm, m->dPlanes, m->dRows, m->dPairs, m->dMateRows, m->dValid, m->dHist};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
+    { BlockScope bs(m); for (void* p : ptrs) if (p && !insideBlock(p)) (void)hipFree(p); }
+    if (m->block) (void)hipFree(m->block);
     if (m->hStage) pinned_free(m->hStage, m->capStage, !m->stagePageable);
     if (m->evWait) (void)hipEventDestroy(m->evWait);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -365,6 +373,29 @@ int match_lane_reserve(Device* dev, MatchLane* m, size_t maxReads, size_t maxSeq
 {
     HIP_TRY(hipSetDevice(m->deviceId));
     const size_t planeBytes = maxReads * (size_t)(4 * 16) * 4u;
+    BlockScope scope(m);
+    {   // The eight buffers of a search as ONE allocation (a lane that has none yet: a fresh context -- the CLI -- makes its 24 matcher lanes at
+        // once, side by side, and the runtime serialises their allocations: eight each were part of the 0.3 s the first slice of a cold
+        // process is ready later than a warm one's).  A lane that has buffers grows them one by one, as before.
+        const size_t need[8] = {maxSeqBytes + 64, maxReads * sizeof(MatchRead), maxReads * sizeof(PackedRead), maxCalls * sizeof(MatchCall), maxCalls * 4u, maxWarm * 4u + 16, planeBytes, maxReads * sizeof(MatchRow)};
+        const bool fresh = !m->block && !m->dSeq && !m->dReads && !m->dPacked && !m->dCalls && !m->dIds && !m->dWarm && !m->dPlanes && !m->dRows;
+        if (fresh) {
+            size_t off[9]; off[0] = 0;
+            for (int i = 0; i < 8; ++i) off[i + 1] = off[i] + ((need[i] + need[i] / 8 + 4096 + 255) & ~(size_t)255);
+            uint8_t* blk = nullptr;
+            if (hipMalloc((void**)&blk, off[8]) == hipSuccess) {
+                m->block = blk; m->blockBytes = off[8];
+                m->dSeq = blk + off[0]; m->capSeq = off[1] - off[0];
+                m->dReads = (MatchRead*)(blk + off[1]); m->capReads = off[2] - off[1];
+                m->dPacked = (PackedRead*)(blk + off[2]); m->capPacked = off[3] - off[2];
+                m->dCalls = (MatchCall*)(blk + off[3]); m->capCalls = off[4] - off[3];
+                m->dIds = (uint32_t*)(blk + off[4]); m->capIds = off[5] - off[4];
+                m->dWarm = (uint32_t*)(blk + off[5]); m->capWarm = off[6] - off[5];
+                m->dPlanes = (uint32_t*)(blk + off[6]); m->capPlanes = off[7] - off[6];
+                m->dRows = (MatchRow*)(blk + off[7]); m->capRows = off[8] - off[7];
+            } else (void)hipGetLastError();       // (no room for the whole: one by one below)
+        }
+    }
     if (ensureBuf(dev, m->dSeq, m->capSeq, maxSeqBytes + 64) || ensureBuf(dev, m->dReads, m->capReads, maxReads * sizeof(MatchRead)) || ensureBuf(dev, m->dPacked, m->capPacked, maxReads * sizeof(PackedRead)) ||
         ensureBuf(dev, m->dCalls, m->capCalls, maxCalls * sizeof(MatchCall)) || ensureBuf(dev, m->dIds, m->capIds, maxCalls * 4u) || ensureBuf(dev, m->dWarm, m->capWarm, maxWarm * 4u + 16) ||
         ensureBuf(dev, m->dPlanes, m->capPlanes, planeBytes) || ensureBuf(dev, m->dRows, m->capRows, maxReads * sizeof(MatchRow))) return -1;
@@ -420,6 +451,7 @@ int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
         else large[slots <= 128u ? 0 : (slots <= 256u ? 1 : (slots <= 512u ? 2 : 3))].push_back((uint32_t)c);
     }
     const size_t planeBytes = nReads * (size_t)(4 * FW) * 4u;
+    BlockScope scope(m);
     if (ensureBuf(dev, m->dSeq, m->capSeq, srcBytes + 64) || ensureBuf(dev, m->dReads, m->capReads, nReads * sizeof(MatchRead)) || (packed && ensureBuf(dev, m->dPacked, m->capPacked, nReads * sizeof(PackedRead))) ||
         ensureBuf(dev, m->dCalls, m->capCalls, nCalls * sizeof(MatchCall)) || ensureBuf(dev, m->dIds, m->capIds, nCalls * 4u) || ensureBuf(dev, m->dWarm, m->capWarm, nWarm * 4u + 16) ||
         ensureBuf(dev, m->dPlanes, m->capPlanes, planeBytes) || ensureBuf(dev, m->dRows, m->capRows, nReads * sizeof(MatchRow))) return -1;
@@ -514,6 +546,7 @@ int match_mates(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
     HIP_TRY(hipSetDevice(m->deviceId));
     for (size_t i = 0; i < nPairs; ++i)
         if ((uint64_t)pairs[i].mate_off + pairs[i].mate_len > seqBytes || pairs[i].mate_len > 255u || pairs[i].mate_len < par.sig_len) { snprintf(dev->err, sizeof dev->err, "device mate search: pair %zu outside the bases", i); return -1; }
+    BlockScope scope(m);
     if (ensureBuf(dev, m->dSeq, m->capSeq, seqBytes + 64) || ensureBuf(dev, m->dPairs, m->capPairs, nPairs * sizeof(MatePair)) || ensureBuf(dev, m->dMateRows, m->capMateRows, nPairs * sizeof(MateRow)) ||
         ensureBuf(dev, m->dValid, m->capValid, 8192 + 64) || ensureBuf(dev, m->dCalls, m->capCalls, sizeof(MateJob) + 64) ||
         ensureBuf(dev, m->dHist, m->capHist, (size_t)fsmate::hist_words(par.window) * 4u)) return -1;
@@ -556,6 +589,7 @@ int match_mates_batch(Device* dev, MatchLane* m, const MateBatchJob* jobs, size_
     }
     if (seqTotal > 0xFFFFFF00ull || pairTotal > 0xFFFFFF00ull) { snprintf(dev->err, sizeof dev->err, "device mate search: batch beyond 4 GiB"); return -1; }
     if (pairTotal == 0) return 0;
+    BlockScope scope(m);
     if (ensureBuf(dev, m->dSeq, m->capSeq, seqTotal + 64) || ensureBuf(dev, m->dPairs, m->capPairs, pairTotal * sizeof(MatePair)) || ensureBuf(dev, m->dMateRows, m->capMateRows, pairTotal * sizeof(MateRow)) ||
         ensureBuf(dev, m->dValid, m->capValid, 8192 + 64) || ensureBuf(dev, m->dCalls, m->capCalls, nJobs * sizeof(MateJob) + 64) ||
         ensureBuf(dev, m->dHist, m->capHist, nJobs * (size_t)fsmate::hist_words(par.window) * 4u)) return -1;

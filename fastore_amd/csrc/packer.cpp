@@ -1244,16 +1244,18 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
         std::mutex asyncErrMx; std::string asyncErr;
         // (a bin whose pairs are with the device is complete when BOTH its host task has returned -- it still fills in the bin's packed
         // scores and read ids behind the walk -- and its rows have come back: whichever is second counts it)
-        // A slice lives in ONE 32-bit address space on the device: its bins' streams, and -- for the bins whose base-holding streams the device
-        // writes itself -- their bases, ops and the room of everything those ops may write: ~7 bytes a base against ~2.75 for a bin whose walk
-        // writes its own streams.  Slices are cut by weight, so with few slices (pipeline_slices <= 4, or fewer than 64 bins: one slice) a batch
-        // of more than ~0.6 GB of bases would pass 4 GiB ("emitted streams larger than 4 GiB").  Every bin claims its footprint from its
-        // slice's budget before its walk starts; a bin that finds the budget used up keeps the walk's own streams (same bytes in the archive).
+        // A slice lives in ONE 32-bit address space on the device: what goes up (packed scores and read ids, descriptors, the small streams) and
+        // what the device writes behind it (the gathered quality stream, a byte a score; the read-id pairs) -- ~3.5 bytes a base --, and for the
+        // bins whose base-holding streams the device writes itself their bases, ops and the ROOM of everything those ops may write: ~10 bytes
+        // a base in all.  Slices are cut by weight, so with few slices (pipeline_slices <= 4, or fewer than 64 bins: one slice), or with the
+        // bins of a 25 M-pair library (the twelve heaviest hold 0.6 GB of bases: found by the round's first 25 M-pair run, "quality gather plan
+        // outside the batch input"), a slice would pass 4 GiB.  Every bin claims its footprint from its slice's budget before its walk starts;
+        // a bin that finds the budget used up keeps the walk's own streams (same bytes in the archive).
         std::unique_ptr<std::atomic<uint64_t>[]> sliceDevBytes(new std::atomic<uint64_t>[nSlices]);
         for (uint32_t si = 0; si < nSlices; ++si) sliceDevBytes[si].store(0);
         const std::vector<uint64_t> basesOf = binBases.size() == nBins ? binBases : std::vector<uint64_t>();
         binBases.clear();
-        static const uint64_t sliceDevCap = getenv("FS_SLICE_DEV_CAP") ? (uint64_t)atoll(getenv("FS_SLICE_DEV_CAP")) : (3600ull << 20);      // (the variable: tests of the fall-back)
+        static const uint64_t sliceDevCap = getenv("FS_SLICE_DEV_CAP") ? (uint64_t)atoll(getenv("FS_SLICE_DEV_CAP")) : (3700ull << 20);      // (the variable: tests of the fall-back)
         std::unique_ptr<std::atomic<uint8_t>[]> parts(new std::atomic<uint8_t>[nBins]);
         for (uint32_t i = 0; i < nBins; ++i) parts[i].store(2);
         // a bin is through the front end: its slice counts it (here, or -- its pairs still with the device -- when they come back)
@@ -1291,8 +1293,8 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             {
                 const uint64_t bases = basesOf.empty() ? weight[b] * 320u : basesOf[b];
                 std::atomic<uint64_t>& used = sliceDevBytes[sliceOf[k]];
-                if (emitHere && used.fetch_add(7u * bases) + 7u * bases > sliceDevCap) { used.fetch_sub(4u * bases); emitHere = false; }
-                else if (!emitHere) used.fetch_add(3u * bases);
+                if (emitHere && used.fetch_add(10u * bases) + 10u * bases > sliceDevCap) { used.fetch_sub(10u * bases - 7u * bases / 2u); emitHere = false; }
+                else if (!emitHere) used.fetch_add(7u * bases / 2u);
             }
             encs[tid]->setDeviceEmit(emitHere);
             if (mateDispatcher) {

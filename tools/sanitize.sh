@@ -1,7 +1,6 @@
 #!/bin/bash
 # Host pipeline under the sanitizers (CPU only: the test-only emulation stands in for the kernels): every golden fixture through
-# fastore_pack built with -fsanitize=address,undefined and with -fsanitize=thread, one context and two (-G2: the bin-sharded path with
-# its work-stealing tail) and with small device batches (two pipelines in one process); the archives must equal the reference's and the sanitizers must stay silent.
+# fastore_pack built with -fsanitize=address,undefined and with -fsanitize=thread, one context and two (-G2: the bin-sharded path) and with small device batches (two pipelines in one process); the archives must equal the reference's and the sanitizers must stay silent.
 #   tools/sanitize.sh [asan|tsan]        (default: both)
 set -u
 cd "$(dirname "$0")/.."
