@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <time.h>
 #include <algorithm>
 #include <atomic>
 #include <mutex>
@@ -298,6 +299,8 @@ std::atomic<uint64_t> g_unpackChecked{0}, g_unpackDiffering{0};
 void unpack_check(bool on) { g_unpackCheck = on; if (on) { g_unpackChecked = 0; g_unpackDiffering = 0; } }
 void unpack_check_counts(uint64_t* words, uint64_t* differing) { *words = g_unpackChecked.load(); *differing = g_unpackDiffering.load(); }
 
+static double laneClockMs() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; }
+
 struct MatchLane {
     int deviceId = 0;
     hipStream_t stream = nullptr; hipEvent_t evWait = nullptr, ev0 = nullptr, ev1 = nullptr;
@@ -314,6 +317,7 @@ struct MatchLane {
     uint8_t* hStage = nullptr; size_t capStage = 0; bool stagePageable = false;
     bool ownStream = false;
     uint8_t* block = nullptr; size_t blockBytes = 0;      // the eight search buffers as made by match_lane_reserve: one allocation
+    uint32_t calls = 0;                                   // searches so far (FS_TRACE times a lane's first)
 };
 // (ensureBuf's view of the lane whose buffers it is asked to grow)
 struct BlockScope { explicit BlockScope(const MatchLane* m) { t_blockLo = m->block; t_blockHi = m->block ? m->block + m->blockBytes : nullptr; } ~BlockScope() { t_blockLo = t_blockHi = nullptr; } };
@@ -372,6 +376,7 @@ void match_lane_destroy(MatchLane* m)
 int match_lane_reserve(Device* dev, MatchLane* m, size_t maxReads, size_t maxSeqBytes, size_t maxCalls, size_t maxWarm)
 {
     HIP_TRY(hipSetDevice(m->deviceId));
+    const double tr0 = dev->trace ? laneClockMs() : 0;
     const size_t planeBytes = maxReads * (size_t)(4 * 16) * 4u;
     BlockScope scope(m);
     {   // The eight buffers of a search as ONE allocation (a lane that has none yet: a fresh context -- the CLI -- makes its 24 matcher lanes at
@@ -399,15 +404,17 @@ int match_lane_reserve(Device* dev, MatchLane* m, size_t maxReads, size_t maxSeq
     if (ensureBuf(dev, m->dSeq, m->capSeq, maxSeqBytes + 64) || ensureBuf(dev, m->dReads, m->capReads, maxReads * sizeof(MatchRead)) || ensureBuf(dev, m->dPacked, m->capPacked, maxReads * sizeof(PackedRead)) ||
         ensureBuf(dev, m->dCalls, m->capCalls, maxCalls * sizeof(MatchCall)) || ensureBuf(dev, m->dIds, m->capIds, maxCalls * 4u) || ensureBuf(dev, m->dWarm, m->capWarm, maxWarm * 4u + 16) ||
         ensureBuf(dev, m->dPlanes, m->capPlanes, planeBytes) || ensureBuf(dev, m->dRows, m->capRows, maxReads * sizeof(MatchRow))) return -1;
+    const double tr1 = dev->trace ? laneClockMs() : 0;
     const size_t upBytes = ((maxSeqBytes + 64 + 15) & ~(size_t)15) + ((maxReads * sizeof(PackedRead) + 15) & ~(size_t)15) + ((maxReads * sizeof(MatchRead) + 15) & ~(size_t)15) + ((maxCalls * sizeof(MatchCall) + 15) & ~(size_t)15) + ((maxCalls * 4u + 15) & ~(size_t)15) + maxWarm * 4u + 64;
     if (upBytes > m->capStage) {
         if (m->hStage) pinned_free(m->hStage, m->capStage, !m->stagePageable);
         m->hStage = nullptr; m->capStage = 0;
         size_t want = upBytes + 65536;
-        m->stagePageable = pageable_staging(); m->hStage = (uint8_t*)pinned_alloc(&want, !m->stagePageable);
+        m->stagePageable = false;      /* (a few megabytes: pinned in a one-shot context too -- a copy from pageable memory is the runtime's, synchronous, one thread at a time: 10-85 ms a call with 24 callers) */ m->hStage = (uint8_t*)pinned_alloc(&want, !m->stagePageable);
         if (!m->hStage) { snprintf(dev->err, sizeof dev->err, "device matcher: pinned staging buffer of %zu bytes failed", want); return -1; }
         m->capStage = want;
     }
+    if (dev->trace && m->calls == 0) fprintf(stderr, "[trace] matcher lane reserve: device buffers %.1f ms, staging buffer %.1f ms\n", tr1 - tr0, laneClockMs() - tr1);
     return 0;
 }
 
@@ -417,6 +424,8 @@ int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
                 const MatchCall* calls, size_t nCalls, const uint32_t* warm, size_t nWarm, const MatchParams& par, MatchRow* rows, double* kernelMs)
 {
     if (nReads == 0 || nCalls == 0) return 0;
+    const bool timed = dev->trace && m->calls < 2u; ++m->calls;
+    const double tc0 = timed ? laneClockMs() : 0;
     if (par.window < 2u || par.window > 1025u) { snprintf(dev->err, sizeof dev->err, "device matcher: window of %u slots not supported (2..1025)", par.window); return -1; }
     HIP_TRY(hipSetDevice(m->deviceId));
     uint32_t maxLen = 0;
@@ -461,10 +470,11 @@ int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
         if (m->hStage) pinned_free(m->hStage, m->capStage, !m->stagePageable);
         m->hStage = nullptr; m->capStage = 0;
         size_t want = upBytes + upBytes / 4 + 65536;
-        m->stagePageable = pageable_staging(); m->hStage = (uint8_t*)pinned_alloc(&want, !m->stagePageable);
+        m->stagePageable = false;      /* (a few megabytes: pinned in a one-shot context too -- a copy from pageable memory is the runtime's, synchronous, one thread at a time: 10-85 ms a call with 24 callers) */ m->hStage = (uint8_t*)pinned_alloc(&want, !m->stagePageable);
         if (!m->hStage) { snprintf(dev->err, sizeof dev->err, "device matcher: pinned staging buffer of %zu bytes failed", want); return -1; }
         m->capStage = want;
     }
+    const double tc1 = timed ? laneClockMs() : 0;
     uint8_t* h = m->hStage; size_t o = 0;
     memcpy(h + o, packed ? packed->dna : seq, srcBytes); memset(h + o + srcBytes, 0, 64); const size_t oSeq = o; o += (srcBytes + 64 + 15) & ~(size_t)15;      // (spare bytes: the unpack kernel reads two bytes per base)
     size_t oPacked = 0;
@@ -477,6 +487,7 @@ int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
     o += (nCalls * 4u + 15) & ~(size_t)15;
     const size_t oWarm = o;
     if (nWarm) memcpy(h + o, warm, nWarm * 4u);
+    const double tc2 = timed ? laneClockMs() : 0;
     hipStream_t st = m->stream;
     HIP_TRY(hipMemcpyAsync(m->dSeq, h + oSeq, srcBytes + (packed ? 64 : 0), hipMemcpyHostToDevice, st));
     if (packed) HIP_TRY(hipMemcpyAsync(m->dPacked, h + oPacked, nReads * sizeof(PackedRead), hipMemcpyHostToDevice, st));
@@ -527,9 +538,14 @@ int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
     launch(smallAt, small.size(), 64u);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(m->ev1, st));
+    const double tc3 = timed ? laneClockMs() : 0;
     HIP_TRY(hipMemcpyAsync(rows, m->dRows, nReads * sizeof(MatchRow), hipMemcpyDeviceToHost, st));
+    const double tc4 = timed ? laneClockMs() : 0;
     HIP_TRY(hipEventRecord(m->evWait, st));
     HIP_TRY(hipEventSynchronize(m->evWait));
+    if (timed) { float a = 0; (void)hipEventElapsedTime(&a, m->ev0, m->ev1);
+                 fprintf(stderr, "[trace] matcher lane call %u (%zu reads): checks + buffers %.1f ms, staging copy %.1f ms, uploads + launches enqueued %.1f ms, rows' copy enqueued %.1f ms, waited %.1f ms (kernels %.1f ms)\n",
+                         m->calls, nReads, tc1 - tc0, tc2 - tc1, tc3 - tc2, tc4 - tc3, laneClockMs() - tc4, a); }
     if (kernelMs) { float a = 0; (void)hipEventElapsedTime(&a, m->ev0, m->ev1); *kernelMs += a; }
     return 0;
 }
