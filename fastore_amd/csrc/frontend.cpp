@@ -328,6 +328,7 @@ struct BinEncoder::Impl {
     bool wantDevEmit = false;            // BinEncoder::setDeviceEmit
     AsyncMateFn asyncMates;              // BinEncoder::setAsyncMates
     MatchFn matcher;
+    std::function<bool()> matcherGate;   // BinEncoder::setMatcherGate: asked once a bin, before its table is made
     uint64_t matchSeqBase = 0, matchSeqBytes = 0;
 
     void buildMatchTable(const std::vector<int32_t>& topOrder)
@@ -1247,10 +1248,11 @@ struct BinEncoder::Impl {
         // (reads of mostly 'N', manual thresholds) sends the whole bin through the host scan, which keeps the
         // reference's handling of that corner
         havePre = false;
-        const bool wantTable = (bool)matcher || matchTrace != nullptr;
+        const bool deviceSearch = (bool)matcher && !matchTrace && (!matcherGate || matcherGate());
+        const bool wantTable = deviceSearch || matchTrace != nullptr;
         if (wantTable) buildMatchTable(order);
         if (matchTrace && traceResize) { matchTrace->assign(mReads.size(), fsdev::MatchRow{-1, 0, 0, 0, 0, 0, 0}); }
-        if (matcher && !matchTrace && par.maxLzWindowSize >= 2 && par.maxLzWindowSize <= 1025 && bin.maxLen <= 256) {
+        if (deviceSearch && par.maxLzWindowSize >= 2 && par.maxLzWindowSize <= 1025 && bin.maxLen <= 256) {
             mRows.resize(mReads.size());
             if (matcher(B->seq.data() + matchSeqBase, matchSeqBytes, packedDna(), mReads.data(), mReads.size(), mCalls.data(), mCalls.size(), mWarm.data(), mWarm.size(), matchParams(), mRows.data())) {
                 havePre = true;
@@ -1281,6 +1283,7 @@ namespace fs {
 
 BinEncoder::BinEncoder(const PackParams& par) : impl_(new Impl(par)) {}
 void BinEncoder::setMatcher(MatchFn fn) { impl_->matcher = std::move(fn); }
+void BinEncoder::setMatcherGate(std::function<bool()> fn) { impl_->matcherGate = std::move(fn); }
 void BinEncoder::setDeviceEmit(bool on) { impl_->wantDevEmit = on; }
 void BinEncoder::setAsyncMates(AsyncMateFn fn) { impl_->asyncMates = std::move(fn); }
 void BinEncoder::setMateMatcher(MateFn fn) { impl_->mateMatcher = std::move(fn); }

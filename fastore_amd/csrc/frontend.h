@@ -124,6 +124,9 @@ public:
     void checkMateMatcher(const Batch& data, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, const MateFn& fn, uint64_t& pairs, uint64_t& differing);
     // window searches of the following encodeLz calls go through `fn` (empty: the host scan)
     void setMatcher(MatchFn fn);
+    // asked once per bin before anything is made for the device search: false = this bin's searches are the host's scan (the packer's
+    // answer for the bins behind the heaviest ones: "only while fewer searches are waiting for the device than threads may wait for free")
+    void setMatcherGate(std::function<bool()> fn);
     // the streams that hold bases are written by the device from ops (fsdev::EmitOp) instead of by the walk itself
     void setDeviceEmit(bool on);
     // parity check of the device matcher: runs the bin through the host scan and through `fn`, returns the number of reads

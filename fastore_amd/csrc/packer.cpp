@@ -433,6 +433,7 @@ MatchFn Context::matcherFor(uint32_t tid)
                 throw std::runtime_error(std::string("device: ") + dev->err);
         }
         const double t0 = nowMs(); double kms = 0;
+        struct InFlight { std::atomic<int>& n; explicit InFlight(std::atomic<int>& x) : n(x) { ++n; } ~InFlight() { --n; } } inFlight(searchesInFlight);
         if (fsengine::match_reads(dev, matchLanes[tid], seq, seqBytes, packed, reads, nReads, calls, nCalls, warm, nWarm, mp, rows, &kms) != 0) throw std::runtime_error(std::string("device: ") + dev->err);
         matchBasesUp += packed ? packed->bytes + nReads * sizeof(fsdev::PackedRead) : seqBytes; if (packed) matchUnpackedReads += nReads;
         matchedReads += nReads; matchUs += (uint64_t)((nowMs() - t0) * 1e3); matchKernelUs += (uint64_t)(kms * 1e3);
@@ -1223,6 +1224,13 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     if (matchLanes.size() < hostThreads) matchLanes.resize(hostThreads, nullptr);
     uint32_t matcherBins = deviceMatcher ? 6u * hostThreads : 0u;      // measured on the BASELINE library: 72 bins 1841, 144 bins 1923, 250+ bins below 1750 MB/s (the searches start to wait for registers)
     if (const char* mb = getenv("FS_MATCHER_BINS")) matcherBins = (uint32_t)std::max(0, atoi(mb));
+    // (the lighter bins' searches: how many threads may wait for the device at once -- the threads the process has beyond its cores, in
+    // a paired-end batch, whose step is the host's; a single-end step is its longest stream on the device, and searches that run
+    // beside it cost it 4 %: profiles/r05_search_surplus.txt)
+    bool pairedBatch = false;
+    for (uint32_t b = 0; b < nBins && !pairedBatch; ++b) pairedBatch = archives[binArch[b]].cfg.archiveType.readType == READ_PE;
+    uint32_t searchSurplus = pairedBatch && hostCores && hostThreads > hostCores ? hostThreads - hostCores : 0u;
+    if (const char* ss = getenv("FS_SEARCH_SURPLUS")) searchSurplus = (uint32_t)std::max(0, atoi(ss));
     if (deviceMatcher && matchReserve.reads && matcherBins) {
         // the matcher lanes of an earlier batch get room for this batch's largest bin now, while no coder kernel is in
         // flight (growing frees, and a free waits for every running kernel); lanes that do not exist yet are made by
@@ -1283,9 +1291,15 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             if (binTrace && k < 32) fprintf(stderr, "[bin] rank %u: encoder ready at %.1f ms of the batch\n", k, nowMs() - t0);
             // The heaviest bins -- the first few rounds of the host threads -- have their window searches done by the device:
             // they sit on the critical path (their quality streams are the longest) and the device is still nearly empty.
-            // Later the coder kernels hold every register of the chip (3 waves x 168 VGPRs per SIMD): a search would wait
-            // for coder waves to leave, longer than the host scan takes, so the lighter bins keep the host scan.
-            encs[tid]->setMatcher(k < matcherBins ? matcherFor(tid) : MatchFn());
+            // Later the coder kernels hold the chip's registers (two waves of 180 VGPRs a SIMD leave 144: a 1024-thread search wants four
+            // waves of ~70 there) and a search WAITS for coder workgroups to leave.  A waiting thread costs nothing while more threads
+            // are runnable than the process has cores, so the lighter bins' searches go to the device as long as fewer threads are
+            // inside a search than that surplus, and are the host's scan otherwise -- in paired-end batches (round 5, profiles/
+            // r05_matcher_cap_*.txt, r05_search_surplus.txt: every bin on the device whatever the queue: +6 % on the single-end step, nothing
+            // on a paired-end one; with the surplus rule +4 % and -4 %).
+            encs[tid]->setMatcher(deviceMatcher ? matcherFor(tid) : MatchFn());
+            if (k < matcherBins) encs[tid]->setMatcherGate(nullptr);
+            else encs[tid]->setMatcherGate([this, searchSurplus]() { return searchesInFlight.load(std::memory_order_relaxed) < (int)searchSurplus; });
             encs[tid]->setMateMatcher(MateFn());
             // the streams that hold bases (HardReads, LettersX, Match, ...: fsdev::EmitOp) and the LZ ids' run-length coding: written
             // by the device from the ops the walk leaves (FS_DEVICE_EMIT=0: by the walk itself, A/B runs)

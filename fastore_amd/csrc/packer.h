@@ -133,6 +133,7 @@ struct Context {
     uint32_t splitRole = 0;
     struct { size_t reads = 0, seqBytes = 0, calls = 0, warm = 0; } matchReserve;     // bounds of the largest bin of the coming batch (0: grow on demand)
     std::atomic<uint64_t> matchedReads{0}, matchUs{0}, matchKernelUs{0}, matchBasesUp{0}, matchUnpackedReads{0};
+    std::atomic<int> searchesInFlight{0};      // host threads inside a device window search right now (the gate of the lighter bins' searches)
     // the device unpacks the bases of the window search itself from the bin's .bdna bytes (FS_DEVICE_UNPACK=0: ASCII bases go up)
     static bool deviceUnpack() { const char* e = getenv("FS_DEVICE_UNPACK"); return !(e && atoi(e) == 0); }      // (read per batch)
     MatchFn matcherFor(uint32_t tid);

@@ -578,6 +578,14 @@ def test_device_matcher_on_fresh_libraries_and_same_archive_either_way(tmp_path,
         ops, streams, wrong = p.emit_check(binned)             # ... and through the emission kernels: bins of tens of thousands of ops, contigs, sub-trees, long runs
         assert ops > reads // 4 and wrong == 0, (ops, streams, wrong)
         p.pack_file(binned, os.path.join(t, "dev"))
+    # the lighter bins' rule -- on the device while fewer than n threads are inside a search, else the host's scan -- for EVERY bin: which
+    # bins go where changes from run to run, the archive does not
+    monkeypatch.setenv("FS_MATCHER_BINS", "0"); monkeypatch.setenv("FS_SEARCH_SURPLUS", "2")
+    with fastore_amd.Packer(device_id=0, **kn) as p:
+        st = p.pack_file(binned, os.path.join(t, "gate"))
+    assert 0 < st["matcher_reads"], st["matcher_reads"]
+    assert open(os.path.join(t, "dev.cdata"), "rb").read() == open(os.path.join(t, "gate.cdata"), "rb").read()
+    monkeypatch.delenv("FS_MATCHER_BINS"); monkeypatch.delenv("FS_SEARCH_SURPLUS")
     monkeypatch.setenv("FS_DEVICE_MATCHER", "0"); monkeypatch.setenv("FS_DEVICE_IDS", "0"); monkeypatch.setenv("FS_DEVICE_QUALITY", "0")
     with fastore_amd.Packer(device_id=0, **kn) as p:
         p.pack_file(binned, os.path.join(t, "host"))
