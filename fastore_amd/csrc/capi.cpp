@@ -112,8 +112,12 @@ void fsgpu_destroy(fsgpu_ctx* ctx)
     const bool trace = getenv("FS_TRACE") != nullptr;
     auto clk = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; };
     const double t0 = clk();
-    for (fsgpu_ctx* h : ctx->helpers) fsgpu_destroy(h);
+    // (the pipelines a large library was split over hold tens of gigabytes of host pages each: they are given back side by side, and beside
+    // this context's own -- one after the other it was 1.2-1.5 s behind a 25 M-pair pack, profiles/r05_cli_trace_pe_25m.txt)
+    std::vector<std::thread> helperEnds;
+    for (fsgpu_ctx* h : ctx->helpers) helperEnds.emplace_back([h]() { fsgpu_destroy(h); });
     ctx->helpers.clear();
+    struct JoinAll { std::vector<std::thread>& t; ~JoinAll() { for (auto& x : t) if (x.joinable()) x.join(); } } joinHelpers{helperEnds};
     for (fsengine::MatchLane* m : ctx->c.matchLanes) fsengine::match_lane_destroy(m);
     const double t1 = clk();
     for (size_t i = 1; i < ctx->c.lanes.size(); ++i) fsengine::device_destroy(ctx->c.lanes[i]);      // lanes[0] == dev

@@ -1436,6 +1436,23 @@ void Context::compressRawBlock(Batch& batch, const ArchiveParams& arch, std::vec
 }
 
 // ------------------------------------------------------------------------------------------------
+std::vector<uint32_t> splitClasses(const std::vector<uint64_t>& records, const std::vector<uint64_t>& bases, uint32_t classes, uint64_t cap, std::vector<uint64_t>* classBases)
+{
+    std::vector<uint32_t> idx(records.size());
+    for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return records[a] > records[b]; });
+    std::vector<uint32_t> owner(records.size(), classes - 1u);
+    uint64_t sum = 0; uint32_t cls = 0;
+    for (uint32_t i : idx) {
+        if (cls + 1u >= classes) break;
+        const uint64_t add = bases[i];
+        if (sum != 0 && sum + add > cap) { ++cls; sum = 0; if (cls + 1u >= classes) break; }
+        owner[i] = cls; sum += add;
+    }
+    if (classBases) { classBases->assign(classes, 0); for (size_t i = 0; i < owner.size(); ++i) (*classBases)[owner[i]] += bases[i]; }
+    return owner;
+}
+
 void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::vector<std::string>& outPrefixes, int verbose, bool hold)
 {
     const double tStart = nowMs();
@@ -1475,21 +1492,10 @@ void Context::packFiles(const std::vector<std::string>& inPrefixes, const std::v
         for (uint32_t i = 0; i < stdSigs.size(); ++i) w[i] = libs[l]->bf.bins().at(stdSigs[i]).totalRecordsCount;
         std::vector<uint32_t> owner;
         if (splitRole != 0) {
-            // weight classes: the heaviest bins, as many as one batch holds, are rank 0's; (three pipelines) the next batch's worth
-            // rank 1's; all the others the last rank's -- the longest streams of the job start at once and run beside everything
-            // else, instead of in front of it
-            const uint64_t cap = cfg.batch_bases ? cfg.batch_bases : (3072ull << 20);
-            std::vector<uint32_t> idx(stdSigs.size());
-            for (uint32_t i = 0; i < idx.size(); ++i) idx[i] = i;
-            std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
-            owner.assign(stdSigs.size(), world - 1u);
-            uint64_t bases = 0; uint32_t cls = 0;
-            for (uint32_t i : idx) {
-                if (cls + 1u >= world) break;
-                const uint64_t add = libs[l]->bf.bins().at(stdSigs[i]).totalRawDnaSize;
-                if (bases != 0 && bases + add > cap) { ++cls; bases = 0; if (cls + 1u >= world) break; }
-                owner[i] = cls; bases += add;
-            }
+            // weight classes (splitClasses): the longest streams of the job start at once and run beside everything else, instead of in front of it
+            std::vector<uint64_t> bs(stdSigs.size());
+            for (uint32_t i = 0; i < stdSigs.size(); ++i) bs[i] = libs[l]->bf.bins().at(stdSigs[i]).totalRawDnaSize;
+            owner = splitClasses(w, bs, world, cfg.batch_bases ? cfg.batch_bases : (3072ull << 20));
         } else owner = shardOwners(w, world);
         for (uint32_t i = 0; i < stdSigs.size(); ++i) if (owner[i] == rank) work.push_back(Work{(uint32_t)l, stdSigs[i]});
         if (getenv("FS_TRACE")) fprintf(stderr, "[trace] library %zu: rank %u of %u (split role %u) packs %zu of %zu standard bins\n", l, rank, world, splitRole, work.size(), stdSigs.size());

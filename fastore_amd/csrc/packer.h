@@ -38,6 +38,10 @@ private:
 // record totals of the .bmeta footer (fastore_bin/BinFile.h:57-79) -- heaviest bin to the least loaded rank, ties to
 // the lower index / rank.  A pure function of the footer: every rank computes the same table, nothing is exchanged.
 std::vector<uint32_t> shardOwners(const std::vector<uint64_t>& weights, uint32_t world);
+// The weight classes of a library packed by several pipelines on ONE device (capi.cpp: packSplit): the heaviest bins, as many as one device
+// batch holds (cap bases), are class 0, the next batch's worth class 1 (three classes), all the others the last class.  records / bases: per
+// standard bin, in the order of the library's signature list; classBases (optional): the bases every class ends up with.
+std::vector<uint32_t> splitClasses(const std::vector<uint64_t>& records, const std::vector<uint64_t>& bases, uint32_t classes, uint64_t cap, std::vector<uint64_t>* classBases = nullptr);
 
 class ArchiveWriter {
 public:
