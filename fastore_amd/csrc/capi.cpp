@@ -583,7 +583,9 @@ static bool packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& 
     const uint32_t want = pipelines - 1;
     while (ctx->helpers.size() < want) {
         fsgpu_config hc = a.cfg;
-        hc.one_shot = 0; hc.world_size = 1; hc.rank = 0; hc.host_threads = 1;      // (set for each pack below)
+        // (a context that packs once has helpers that pack once: they too give their batch's host memory back while the device walks the
+        // long streams -- 52 GB resident at the end of a 25 M-pair pack was 1.4 s of teardown, one munmap at a time whatever the threads)
+        hc.world_size = 1; hc.rank = 0; hc.host_threads = 1;      // (set for each pack below)
         fsgpu_ctx* h = fsgpu_create(&hc);
         if (!h) {
             if (verbose > 1 || getenv("FS_TRACE")) fprintf(stderr, "[split] pipeline %zu could not be made (%s): one pipeline\n", ctx->helpers.size() + 2, fsgpu_create_error());
