@@ -42,6 +42,9 @@ struct Device {
     // staging buffers outgrown in the middle of a batch: un-registering pinned memory waits for every running kernel (as a
     // hipFree does), so they are kept until the lane is between batches (lanes_equalize) or goes
     void* oldStage[4]; size_t oldStageCap[4]; uint32_t nOldStage;
+    // ... and device buffers outgrown in the middle of a batch (a lane that takes a second, larger slice): a hipFree waits for every running kernel
+    // of the DEVICE -- of the other pipelines of a split pack too, whose streams run for seconds --, so they are kept as well
+    void* oldDev[32]; uint32_t nOldDev;
     uint32_t stagePageable;                                // the staging buffers of this lane are not registered with the runtime
     uint32_t trace;                                        // FS_TRACE was set when the lane was made: every launch is waited for where it is made
 };

@@ -789,7 +789,7 @@ static hipError_t wait_stream(fsengine::Device* dev, hipStream_t st)
 template <class T> int ensure(fsengine::Device* dev, T*& p, size_t& capBytes, size_t needBytes)
 {
     if (needBytes <= capBytes && p) return 0;
-    if (p) (void)hipFree(p);
+    if (p) { if (dev->nOldDev < 32u) dev->oldDev[dev->nOldDev++] = (void*)p; else (void)hipFree(p); }      // (kept until nothing is in flight: engine.h)
     p = nullptr; capBytes = 0;
     size_t want = needBytes + needBytes / 4 + 4096;
     HIP_TRY(hipMalloc((void**)&p, want));
@@ -943,6 +943,7 @@ void device_destroy(Device* dev)
     const double td0 = wallMs();
     void* ptrs[] = {dev->queueHead, dev->dIn, dev->dScratch, dev->dItems, dev->dOrder, dev->dSizes, dev->dRestarts, dev->dPlans, dev->dBlocks};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (uint32_t i = 0; i < dev->nOldDev; ++i) (void)hipFree(dev->oldDev[i]);
     const double td1 = wallMs();
     if (dev->evWait) (void)hipEventDestroy((hipEvent_t)dev->evWait);
     if (dev->hStage) pinned_free(dev->hStage, dev->capStage, !dev->stagePageable);
@@ -1376,6 +1377,8 @@ int lanes_equalize(Device* const* lanes, size_t n)
         HIP_TRY(hipSetDevice(dev->deviceId));
         for (uint32_t k = 0; k < dev->nOldStage; ++k) pinned_free(dev->oldStage[k], dev->oldStageCap[k], !dev->stagePageable);      // nothing is in flight here
         dev->nOldStage = 0;
+        for (uint32_t k = 0; k < dev->nOldDev; ++k) (void)hipFree(dev->oldDev[k]);
+        dev->nOldDev = 0;
         auto grow = [&](auto*& p, size_t& cap, size_t want) -> int {
             if (cap >= want && p) return 0;
             if (p) (void)hipFree(p);

@@ -751,11 +751,12 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
     // (one bin per CORE in the first round -- the threads beyond the cores joining as bins finish -- was tried: the first slice
     // goes up 25 ms earlier, the second one, whose streams are nearly as long, later: no gain, profiles/r02_yy_first_round.txt)
     const uint32_t firstRound = hostThreads;
+    const uint32_t sliceRound = sliceThreads ? std::min(sliceThreads, hostThreads) : hostThreads;      // (the bins of a first slice)
     const uint32_t wantSlices = cfg.pipeline_slices ? std::min(cfg.pipeline_slices, nBins) : ((nBins >= 64 && totalW >= 200000) ? 14u : 1u);
     if (wantSlices > 1) {
         std::vector<double> share;
         if (!autoSlices) {
-            uint64_t firstW = 0; const uint32_t firstBins = std::min<uint32_t>(std::max(1u, hostThreads), nBins / wantSlices);
+            uint64_t firstW = 0; const uint32_t firstBins = std::min<uint32_t>(std::max(1u, sliceRound), nBins / wantSlices);
             for (uint32_t i = 0; i < firstBins; ++i) firstW += weight[byWork[i]];
             const double f = std::min(0.5, (double)firstW / (double)std::max<uint64_t>(1, totalW));
             share.assign(wantSlices, (1.0 - f) / (wantSlices - 1)); share[0] = f;
@@ -773,7 +774,7 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
             // first slice is exactly the bins the host threads take in their first round (one each: ready when the
             // heaviest bin is), the middle slices grow, and the last ones -- small bins only, short streams -- shrink
             // again, so that little device work is left when the host is done.
-            const uint32_t firstBins = std::min<uint32_t>(std::max(1u, firstRound), std::max(1u, nBins / wantSlices));
+            const uint32_t firstBins = std::min<uint32_t>(std::max(1u, sliceRound), std::max(1u, nBins / wantSlices));
             uint64_t firstW = 0;
             for (uint32_t i = 0; i < firstBins; ++i) firstW += weight[byWork[i]];
             // (measured on the BASELINE library, profiles/r02_ae_slice_weights.txt: the first round goes up as TWO slices -- the
@@ -1284,6 +1285,8 @@ void Context::compressBins(uint32_t nBins, const std::vector<uint64_t>& weight, 
                 std::unique_lock<std::mutex> lk(roundMx);
                 roundCv.wait(lk, [&]() { return binsDone > k - firstRound || abort.load(); });
             }
+            // (a split pack: the pipelines share the worker slots, the heaviest class first)
+            struct Slot { HostGate* g; uint32_t c; Slot(HostGate* x, uint32_t cls) : g(x), c(cls) { if (g) g->acquire(c); } ~Slot() { if (g) g->release(c); } } slot(hostGate, gateClass);
             struct Done { std::mutex& m; std::condition_variable& cv; uint32_t& n; ~Done() { { std::lock_guard<std::mutex> g(m); ++n; } cv.notify_all(); } } done{roundMx, roundCv, binsDone};     // (also when the bin throws)
             static const bool binTrace = getenv("FS_BIN_TRACE") != nullptr;
             if (binTrace && k < 32) fprintf(stderr, "[bin] rank %u (bin %u, thread %u) claimed at %.1f ms of the batch\n", k, b, tid, nowMs() - t0);

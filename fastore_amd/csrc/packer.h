@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <functional>
 #include <memory>
 #include <string>
@@ -42,6 +44,30 @@ std::vector<uint32_t> shardOwners(const std::vector<uint64_t>& weights, uint32_t
 // batch holds (cap bases), are class 0, the next batch's worth class 1 (three classes), all the others the last class.  records / bases: per
 // standard bin, in the order of the library's signature list; classBases (optional): the bases every class ends up with.
 std::vector<uint32_t> splitClasses(const std::vector<uint64_t>& records, const std::vector<uint64_t>& bases, uint32_t classes, uint64_t cap, std::vector<uint64_t>* classBases = nullptr);
+// Worker slots shared by the pipelines of ONE split pack (capi.cpp: packSplit): a bin's front end holds a slot; pipelines that wait are served
+// in the order packSplit gives their classes, a class holding no more slots at once than its cap.  (Round 5: with a fixed share of the threads
+// each, the heaviest class's 183 bins kept six threads busy for 9 s of a 25 M-pair pack while the lightest class's twelve were done after 2.7 s.)
+struct HostGate {
+    std::mutex mx; std::condition_variable cv; uint32_t free;
+    uint32_t waiting[4] = {0, 0, 0, 0}, held[4] = {0, 0, 0, 0};
+    uint32_t rank[4] = {0, 1, 2, 3};      // a class's place in the order the waiting pipelines are served (0 first)
+    uint32_t cap[4] = {0, 0, 0, 0};       // the slots a class may hold at once (0: any number)
+    explicit HostGate(uint32_t slots) : free(slots) {}
+    bool eligible(uint32_t c) const { return cap[c] == 0 || held[c] < cap[c]; }
+    void acquire(uint32_t cls)
+    {
+        std::unique_lock<std::mutex> lk(mx);
+        ++waiting[cls];
+        cv.wait(lk, [&]() {
+            if (!free || !eligible(cls)) return false;
+            for (uint32_t c = 0; c < 4; ++c) if (rank[c] < rank[cls] && waiting[c] && eligible(c)) return false;
+            return true;
+        });
+        --waiting[cls]; --free; ++held[cls];
+        if (free) cv.notify_all();
+    }
+    void release(uint32_t cls) { { std::lock_guard<std::mutex> g(mx); ++free; --held[cls]; } cv.notify_all(); }
+};
 
 class ArchiveWriter {
 public:
@@ -137,6 +163,8 @@ struct Context {
     uint32_t splitRole = 0;
     struct { size_t reads = 0, seqBytes = 0, calls = 0, warm = 0; } matchReserve;     // bounds of the largest bin of the coming batch (0: grow on demand)
     std::atomic<uint64_t> matchedReads{0}, matchUs{0}, matchKernelUs{0}, matchBasesUp{0}, matchUnpackedReads{0};
+    HostGate* hostGate = nullptr; uint32_t gateClass = 0;      // a split pack: the pipelines' shared worker slots, this pipeline's class (0 = heaviest)
+    uint32_t sliceThreads = 0;                                 // ... and the number of bins a first slice is made of (0: hostThreads)
     std::atomic<int> searchesInFlight{0};      // host threads inside a device window search right now (the gate of the lighter bins' searches)
     // the device unpacks the bases of the window search itself from the bin's .bdna bytes (FS_DEVICE_UNPACK=0: ASCII bases go up)
     static bool deviceUnpack() { const char* e = getenv("FS_DEVICE_UNPACK"); return !(e && atoi(e) == 0); }      // (read per batch)
