@@ -601,10 +601,10 @@ static bool packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& 
                   ~Keep() { for (size_t i = 0; i < cs.size(); ++i) { cs[i]->cfg = cfg[i]; cs[i]->hostThreads = threads[i]; cs[i]->splitRole = 0; if (!done) { cs[i]->shards.clear(); cs[i]->shards.shrink_to_fit(); } } } } keep;
     for (fs::Context* c : cs) { keep.cs.push_back(c); keep.cfg.push_back(c->cfg); keep.threads.push_back(c->hostThreads); }
     // Host threads: every pipeline has all of them, and a bin's front end holds one of T worker slots they share.  Who is served first:
-    // (three pipelines) the LIGHTEST class, up to a cap -- a third of the slots, more if it holds more than that share of the bases --: its many
-    // short streams go through the device while it is still empty (behind the heavy classes' resident waves the same streams took 4.3 s instead
-    // of 1); then the heaviest class, whose front end is the step's critical path (its last slice's streams start when its last bin is
-    // through); the middle class fills what is left.  (Rounds 3-4 and the start of round 5: a quarter of the threads each for the heavy
+    // (three pipelines) the heaviest class, whose front end is the step's critical path (its last slice's streams start when its last bin is
+    // through) -- with at most two thirds of the slots; the other third is the LIGHTEST class's from the first millisecond: its many short
+    // streams go through the device while it is still empty (behind the heavy classes' resident waves the same streams took 4.3 s instead
+    // of 1); the middle class fills what is left.  (Rounds 3-4 and the start of round 5: a quarter of the threads each for the heavy
     // classes of three, a third of two -- the heaviest class's 183 bins of a 25 M-pair library then took six threads 9.0 s while the lightest
     // class's twelve were done after 2.7 s, profiles/r05_cli_trace_pe_25m.txt.  FS_SPLIT_GATE=0: those fixed shares.)
     const bool gated = !(getenv("FS_SPLIT_GATE") && atoi(getenv("FS_SPLIT_GATE")) == 0);
@@ -615,11 +615,12 @@ static bool packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& 
         std::vector<uint64_t> rec(sigs.size()), bas(sigs.size()), classBases;
         for (size_t i = 0; i < sigs.size(); ++i) { const auto& d = bf.bins().at(sigs[i]); rec[i] = d.totalRecordsCount; bas[i] = d.totalRawDnaSize; }
         (void)fs::splitClasses(rec, bas, pipelines, a.cfg.batch_bases ? a.cfg.batch_bases : (3072ull << 20), &classBases);
-        const double all = (double)std::max<uint64_t>(1, classBases[0] + classBases[1] + classBases[2]);
-        gate.rank[2] = 0; gate.rank[0] = 1; gate.rank[1] = 2;
-        gate.cap[2] = std::max(1u, std::min(T * 2u / 3u, std::max(T / 3u, (uint32_t)(1.5 * T * (double)classBases[2] / all))));
-        gate.cap[0] = std::max(1u, T - gate.cap[2]);      // (... which are KEPT for it: the heaviest class's threads are there first and would hold every slot for its first round, seconds)
-        if (getenv("FS_TRACE")) fprintf(stderr, "[trace] split pack: classes of %.2f / %.2f / %.2f G bases, %u worker slots, the lightest class first with up to %u\n", classBases[0] / 1e9, classBases[1] / 1e9, classBases[2] / 1e9, T, gate.cap[2]);
+        // the heaviest class first, but never with more than two thirds of the slots: the rest is the lightest class's from the start (it
+        // takes what the heaviest leaves as well), the middle class comes last.  (With the lightest class first and a cap by its share of
+        // the bases a 40 M-pair library, whose last class holds half the bases, gave the heaviest class 8 slots: 18.1 -> 19.7 s a step.)
+        gate.rank[0] = 0; gate.rank[2] = 1; gate.rank[1] = 2;
+        gate.cap[0] = std::max(1u, T - std::max(1u, T / 3u));
+        if (getenv("FS_TRACE")) fprintf(stderr, "[trace] split pack: classes of %.2f / %.2f / %.2f G bases, %u worker slots, the heaviest class first with up to %u\n", classBases[0] / 1e9, classBases[1] / 1e9, classBases[2] / 1e9, T, gate.cap[0]);
     }
     struct Ungate { std::vector<fs::Context*>& cs; ~Ungate() { for (fs::Context* c : cs) { c->hostGate = nullptr; c->gateClass = 0; c->sliceThreads = 0; } } } ungate{cs};
     for (uint32_t k = 0; k < pipelines; ++k) {
