@@ -609,18 +609,13 @@ static bool packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& 
     // class's twelve were done after 2.7 s, profiles/r05_cli_trace_pe_25m.txt.  FS_SPLIT_GATE=0: those fixed shares.)
     const bool gated = !(getenv("FS_SPLIT_GATE") && atoi(getenv("FS_SPLIT_GATE")) == 0);
     fs::HostGate gate(T);
-    if (pipelines == 3) {
-        fs::BinFile bf; bf.open(in, a.par.minBinSize);
-        const auto& sigs = bf.stdSignatures();
-        std::vector<uint64_t> rec(sigs.size()), bas(sigs.size()), classBases;
-        for (size_t i = 0; i < sigs.size(); ++i) { const auto& d = bf.bins().at(sigs[i]); rec[i] = d.totalRecordsCount; bas[i] = d.totalRawDnaSize; }
-        (void)fs::splitClasses(rec, bas, pipelines, a.cfg.batch_bases ? a.cfg.batch_bases : (3072ull << 20), &classBases);
+    {
         // the heaviest class first, but never with more than two thirds of the slots: the rest is the lightest class's from the start (it
-        // takes what the heaviest leaves as well), the middle class comes last.  (With the lightest class first and a cap by its share of
-        // the bases a 40 M-pair library, whose last class holds half the bases, gave the heaviest class 8 slots: 18.1 -> 19.7 s a step.)
-        gate.rank[0] = 0; gate.rank[2] = 1; gate.rank[1] = 2;
+        // takes what the heaviest leaves as well), the middle class of three comes last.  (With the lightest class first and a cap by its share
+        // of the bases a 40 M-pair library, whose last class holds half the bases, gave the heaviest class 8 slots: 18.1 -> 19.7 s a step.)
+        gate.rank[0] = 0; gate.rank[pipelines - 1u] = 1; if (pipelines == 3) gate.rank[1] = 2;
         gate.cap[0] = std::max(1u, T - std::max(1u, T / 3u));
-        if (getenv("FS_TRACE")) fprintf(stderr, "[trace] split pack: classes of %.2f / %.2f / %.2f G bases, %u worker slots, the heaviest class first with up to %u\n", classBases[0] / 1e9, classBases[1] / 1e9, classBases[2] / 1e9, T, gate.cap[0]);
+        if (getenv("FS_TRACE")) fprintf(stderr, "[trace] split pack: %u pipelines, %u worker slots, the heaviest class first with up to %u\n", pipelines, T, gate.cap[0]);
     }
     struct Ungate { std::vector<fs::Context*>& cs; ~Ungate() { for (fs::Context* c : cs) { c->hostGate = nullptr; c->gateClass = 0; c->sliceThreads = 0; } } } ungate{cs};
     for (uint32_t k = 0; k < pipelines; ++k) {
