@@ -327,6 +327,11 @@ struct BinEncoder::Impl {
     std::vector<fsdev::MatchRow>* matchTrace = nullptr;   // host scan: note every read's answer here (same indexing as mRows)
     bool wantDevEmit = false;            // BinEncoder::setDeviceEmit
     AsyncMateFn asyncMates;              // BinEncoder::setAsyncMates
+    // what a prefix-buffer neighbour is priced with, ONE load away from its node id (through the node, its record and the record's place in the
+    // batch it is three, each a cache miss in a bin of tens of thousands of reads: a search prices up to 1 026 neighbours -- round 5: 70-145 k
+    // clocks a search -> 30-65 k with this table and the bases of the neighbour six ahead asked for early)
+    struct NodeSeq { const uint8_t* seq; uint16_t len, minPos; };
+    std::vector<NodeSeq> nodeSeq;
     MatchFn matcher;
     std::function<bool()> matcherGate;   // BinEncoder::setMatcherGate: asked once a bin, before its table is made
     uint64_t matchSeqBase = 0, matchSeqBytes = 0;
@@ -584,15 +589,21 @@ struct BinEncoder::Impl {
                         const size_t lb = std::lower_bound(rpb->begin(), rpb->end(), cur, prefixLess) - rpb->begin();
                         lbPos = lb;
                         const uint32_t maxCnt = W / 2 + 1;
-                        for (size_t p = lb, cnt = 0; p < rpb->size() && cnt < maxCnt; ++p, ++cnt) {
-                            const int32_t lv = nodes[(*rpb)[p]].vrec;
-                            if (!updateLzMatch(fwd, rs, rl, rm, seq(lv), seqLen(lv), (int32_t)minimPos(lv))) continue;
-                            fwdNode = (*rpb)[p];
+                        const int32_t* const ids = rpb->data(); const size_t nIds = rpb->size();
+                        const NodeSeq* const nsq = nodeSeq.data();
+                        for (size_t p = lb, cnt = 0; p < nIds && cnt < maxCnt; ++p, ++cnt) {
+                            if (p + 6 < nIds) _mm_prefetch((const char*)(nsq[ids[p + 6]].seq + rm), _MM_HINT_T0);
+                            if (p + 12 < nIds) _mm_prefetch((const char*)&nsq[ids[p + 12]], _MM_HINT_T0);
+                            const NodeSeq& c = nsq[ids[p]];
+                            if (!updateLzMatch(fwd, rs, rl, rm, c.seq, c.len, (int32_t)c.minPos)) continue;
+                            fwdNode = ids[p];
                         }
                         for (size_t q = lb, cnt = 0; q > 0 && cnt < maxCnt; --q, ++cnt) {
-                            const int32_t lv = nodes[(*rpb)[q - 1]].vrec;
-                            if (!updateLzMatch(rev, rs, rl, rm, seq(lv), seqLen(lv), (int32_t)minimPos(lv))) continue;
-                            revNode = (*rpb)[q - 1];
+                            if (q > 6) _mm_prefetch((const char*)(nsq[ids[q - 7]].seq + rm), _MM_HINT_T0);
+                            if (q > 12) _mm_prefetch((const char*)&nsq[ids[q - 13]], _MM_HINT_T0);
+                            const NodeSeq& c = nsq[ids[q - 1]];
+                            if (!updateLzMatch(rev, rs, rl, rm, c.seq, c.len, (int32_t)c.minPos)) continue;
+                            revNode = ids[q - 1];
                         }
                         const int32_t minCost = fwd.cost < rev.cost ? fwd.cost : rev.cost;
                         if (minCost < encodeThreshold && minCost < mr.cost) {
@@ -1213,6 +1224,8 @@ struct BinEncoder::Impl {
             if (ni.treeCount) { n.trees.resize(ni.treeCount); for (uint32_t k = 0; k < ni.treeCount; ++k) n.trees[k] = ni.treeBegin + k; }
         }
         contigs.clear();
+        nodeSeq.resize(nodes.size());
+        for (size_t i = 0; i < nodes.size(); ++i) { const int32_t v = nodes[i].vrec; nodeSeq[i] = NodeSeq{seq(v), (uint16_t)seqLen(v), (uint16_t)minimPos(v)}; }
     }
 
     void encodeLz(const Batch& batch, const Batch& graph, const BinIn& bin, const ArchiveParams& arch, BinStreams& o)
