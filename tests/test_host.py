@@ -79,6 +79,14 @@ def test_introsort_equals_libstdcxx_sort(tmp_path):
     assert subprocess.run([exe], capture_output=True).stdout.strip() == b"OK"
 
 
+def test_split_pack_worker_slots_keep_caps_and_serve_by_rank(tmp_path):
+    # packer.h: HostGate -- the worker slots the pipelines of a split pack share (capi.cpp: packSplit)
+    exe = str(tmp_path / "t_hostgate")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "emu", "test_hostgate.cpp")])
+    r = subprocess.run([exe], capture_output=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == b"ok", r.stderr
+
+
 def read_cmeta(path):
     m = open(path, "rb").read()
     foff, fsize = struct.unpack_from("<QQ", m, 0)
