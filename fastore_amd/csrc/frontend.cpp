@@ -287,6 +287,60 @@ struct BinEncoder::Impl {
         return false;
     }
 
+    // One of the 25 prefix buffers (the reference's std::set<MatchNode*, prefixFun>, ReadsClassifier.cpp:115-145): node ids in prefix order, in CHUNKS of at
+    // most 1 024 -- an insert moves half a chunk at most.  (As one sorted vector a bin of n reads paid n^2 / 50 moves: 0.4 s of the 1.1 s its top-level tree
+    // took in a 197 k-pair bin, and four times that at twice the size.)  A search looks at up to W/2+1 neighbours either way: they are copied out, in order.
+    struct PrefixSet {
+        enum : size_t { kMax = 1024 };
+        std::vector<std::vector<int32_t>> chunks;
+        struct Pos { size_t c, i; };                         // (chunks.size(), 0) = end
+        bool atEnd(Pos p) const { return p.c >= chunks.size(); }
+        int32_t at(Pos p) const { return chunks[p.c][p.i]; }
+        template <class Less> Pos lowerBound(int32_t x, Less less) const
+        {
+            if (chunks.empty()) return Pos{0, 0};
+            // the last chunk whose first element is less than x may hold the bound; if none is, the bound is the very first element
+            size_t lo = 0, hi = chunks.size();
+            while (lo < hi) { const size_t mid = (lo + hi) / 2; if (less(chunks[mid].front(), x)) lo = mid + 1; else hi = mid; }
+            if (lo == 0) return Pos{0, 0};
+            const std::vector<int32_t>& ch = chunks[lo - 1];
+            const size_t i = (size_t)(std::lower_bound(ch.begin(), ch.end(), x, less) - ch.begin());
+            if (i < ch.size()) return Pos{lo - 1, i};
+            return lo < chunks.size() ? Pos{lo, 0} : Pos{chunks.size(), 0};
+        }
+        void forward(Pos p, size_t maxCnt, std::vector<int32_t>& out) const      // the elements from p on
+        {
+            out.clear();
+            for (size_t c = p.c, i = p.i; c < chunks.size() && out.size() < maxCnt; ++c, i = 0) {
+                const size_t take = std::min(maxCnt - out.size(), chunks[c].size() - i);
+                out.insert(out.end(), chunks[c].begin() + (ptrdiff_t)i, chunks[c].begin() + (ptrdiff_t)(i + take));
+            }
+        }
+        void backward(Pos p, size_t maxCnt, std::vector<int32_t>& out) const     // the elements in front of p, nearest first
+        {
+            out.clear();
+            size_t c = p.c, i = p.i;
+            while (out.size() < maxCnt) {
+                if (i == 0) { if (c == 0) break; --c; i = chunks[c].size(); continue; }
+                out.push_back(chunks[c][--i]);
+            }
+        }
+        void insert(Pos p, int32_t x)
+        {
+            if (chunks.empty()) { chunks.emplace_back(); chunks[0].reserve(64); chunks[0].push_back(x); return; }
+            if (atEnd(p)) { p.c = chunks.size() - 1; p.i = chunks[p.c].size(); }
+            else if (p.i == 0 && p.c > 0 && chunks[p.c - 1].size() < chunks[p.c].size()) { --p.c; p.i = chunks[p.c].size(); }      // (in front of a chunk = behind the one before it)
+            std::vector<int32_t>& ch = chunks[p.c];
+            ch.insert(ch.begin() + (ptrdiff_t)p.i, x);
+            if (ch.size() > kMax) {
+                std::vector<int32_t> upper(ch.begin() + (ptrdiff_t)(kMax / 2), ch.end());
+                ch.resize(kMax / 2);
+                chunks.insert(chunks.begin() + (ptrdiff_t)p.c + 1, std::move(upper));
+            }
+        }
+    };
+    std::vector<int32_t> prefFwd, prefRev;                   // a search's neighbours, copied out of the set
+
     struct WinEntry { const uint8_t* seq; int32_t node; uint16_t seqLen, minPos; };
     // the LZ window, newest entry first: a power-of-two ring (the scan over it is the hottest loop of the front end; a
     // std::deque pays a block lookup per index)
@@ -441,7 +495,7 @@ struct BinEncoder::Impl {
         win.reset(W);
         uint32_t numDummies = W; bool dupAtBack = false;
         const bool usePrefix = par.extraReduceHardReads || par.extraReduceExpensiveLzMatches;
-        std::vector<int32_t> rp[25];              // the 25 std::set<MatchNode*, prefixFun> as sorted vectors
+        PrefixSet rp[25];                         // the 25 std::set<MatchNode*, prefixFun>
 
         // every node that enters a prefix buffer has minimPos >= 8, so the first six bases before the signature (in
         // comparison order) are inside the compared range of any pair: packed into one word they decide most comparisons
@@ -572,7 +626,7 @@ struct BinEncoder::Impl {
                 dupAtBack = true;                 // lzBuffer.push_back(newLz): recycled by the next read
             } else {
                 int32_t parentNode = -1;
-                std::vector<int32_t>* rpb = nullptr; size_t lbPos = ~(size_t)0;      // lower bound of `cur` in *rpb once known
+                PrefixSet* rpb = nullptr; PrefixSet::Pos lbPos{0, 0}; bool haveLb = false;      // lower bound of `cur` in *rpb once known
                 if (usePrefix) {
                     const uint32_t expensiveLzThreshold = (uint32_t)encodeThreshold / 2;
                     const bool searchRev = isHard || (par.extraReduceExpensiveLzMatches && mr.cost > (int32_t)expensiveLzThreshold);
@@ -586,24 +640,29 @@ struct BinEncoder::Impl {
                     if (searchRev && rm >= 8) {
                         MatchResult fwd, rev; int32_t fwdNode = -1, revNode = -1;
                         fwd.cost = encodeThreshold + 1; rev.cost = encodeThreshold + 1;
-                        const size_t lb = std::lower_bound(rpb->begin(), rpb->end(), cur, prefixLess) - rpb->begin();
-                        lbPos = lb;
+                        lbPos = rpb->lowerBound(cur, prefixLess); haveLb = true;
                         const uint32_t maxCnt = W / 2 + 1;
-                        const int32_t* const ids = rpb->data(); const size_t nIds = rpb->size();
+                        rpb->forward(lbPos, maxCnt, prefFwd); rpb->backward(lbPos, maxCnt, prefRev);
                         const NodeSeq* const nsq = nodeSeq.data();
-                        for (size_t p = lb, cnt = 0; p < nIds && cnt < maxCnt; ++p, ++cnt) {
-                            if (p + 6 < nIds) _mm_prefetch((const char*)(nsq[ids[p + 6]].seq + rm), _MM_HINT_T0);
-                            if (p + 12 < nIds) _mm_prefetch((const char*)&nsq[ids[p + 12]], _MM_HINT_T0);
-                            const NodeSeq& c = nsq[ids[p]];
-                            if (!updateLzMatch(fwd, rs, rl, rm, c.seq, c.len, (int32_t)c.minPos)) continue;
-                            fwdNode = ids[p];
+                        {
+                            const int32_t* const ids = prefFwd.data(); const size_t nIds = prefFwd.size();
+                            for (size_t p = 0; p < nIds; ++p) {
+                                if (p + 6 < nIds) _mm_prefetch((const char*)(nsq[ids[p + 6]].seq + rm), _MM_HINT_T0);
+                                if (p + 12 < nIds) _mm_prefetch((const char*)&nsq[ids[p + 12]], _MM_HINT_T0);
+                                const NodeSeq& c = nsq[ids[p]];
+                                if (!updateLzMatch(fwd, rs, rl, rm, c.seq, c.len, (int32_t)c.minPos)) continue;
+                                fwdNode = ids[p];
+                            }
                         }
-                        for (size_t q = lb, cnt = 0; q > 0 && cnt < maxCnt; --q, ++cnt) {
-                            if (q > 6) _mm_prefetch((const char*)(nsq[ids[q - 7]].seq + rm), _MM_HINT_T0);
-                            if (q > 12) _mm_prefetch((const char*)&nsq[ids[q - 13]], _MM_HINT_T0);
-                            const NodeSeq& c = nsq[ids[q - 1]];
-                            if (!updateLzMatch(rev, rs, rl, rm, c.seq, c.len, (int32_t)c.minPos)) continue;
-                            revNode = ids[q - 1];
+                        {
+                            const int32_t* const ids = prefRev.data(); const size_t nIds = prefRev.size();
+                            for (size_t p = 0; p < nIds; ++p) {
+                                if (p + 6 < nIds) _mm_prefetch((const char*)(nsq[ids[p + 6]].seq + rm), _MM_HINT_T0);
+                                if (p + 12 < nIds) _mm_prefetch((const char*)&nsq[ids[p + 12]], _MM_HINT_T0);
+                                const NodeSeq& c = nsq[ids[p]];
+                                if (!updateLzMatch(rev, rs, rl, rm, c.seq, c.len, (int32_t)c.minPos)) continue;
+                                revNode = ids[p];
+                            }
                         }
                         const int32_t minCost = fwd.cost < rev.cost ? fwd.cost : rev.cost;
                         if (minCost < encodeThreshold && minCost < mr.cost) {
@@ -623,8 +682,8 @@ struct BinEncoder::Impl {
                 }
                 if (!pre) win.push_front(newLz);
                 if (rpb) {                        // std::set::insert: skipped when an equivalent node is present
-                    const auto it = lbPos != ~(size_t)0 ? rpb->begin() + (ptrdiff_t)lbPos : std::lower_bound(rpb->begin(), rpb->end(), cur, prefixLess);
-                    if (it == rpb->end() || prefixLess(cur, *it)) rpb->insert(it, cur);
+                    const PrefixSet::Pos it = haveLb ? lbPos : rpb->lowerBound(cur, prefixLess);
+                    if (rpb->atEnd(it) || prefixLess(cur, rpb->at(it))) rpb->insert(it, cur);
                 }
             }
         }
