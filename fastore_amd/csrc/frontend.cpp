@@ -418,9 +418,12 @@ struct BinEncoder::Impl {
                 uint32_t tsz = 64; while (tsz < 2u * n) tsz <<= 1;
                 dupTable.assign(tsz, Slot3{0, 0, 0});
                 uint32_t pushed = 0;
+                const NodeSeq* const nsq = nodeSeq.data();               // (bases, length, signature position a load away from the node id; the reads eight ahead asked for early)
                 for (uint32_t i = 0; i < n; ++i) {
-                    const int32_t a = nodes[topOrder[i]].vrec;
-                    const uint8_t* sa = seq(a); const uint32_t la = seqLen(a), ma = minimPos(a);
+                    if (i + 16 < n) _mm_prefetch((const char*)&nsq[topOrder[i + 16]], _MM_HINT_T0);
+                    if (i + 8 < n) { const uint8_t* pf = nsq[topOrder[i + 8]].seq; _mm_prefetch((const char*)pf, _MM_HINT_T0); _mm_prefetch((const char*)pf + 64, _MM_HINT_T0); _mm_prefetch((const char*)pf + 128, _MM_HINT_T0); }
+                    const NodeSeq& na = nsq[topOrder[i]];
+                    const uint8_t* sa = na.seq; const uint32_t la = na.len, ma = na.minPos;
                     uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t)la << 32 | ma);
                     uint32_t k = 0;
                     for (; k + 8 <= la; k += 8) { uint64_t w; memcpy(&w, sa + k, 8); h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 32; }
@@ -430,8 +433,8 @@ struct BinEncoder::Impl {
                         Slot3& s = dupTable[at];
                         if (s.read == 0) { s.hash = h; s.read = i + 1u; s.push = pushed++; break; }        // a new class
                         if (s.hash != h) continue;
-                        const int32_t b = nodes[topOrder[s.read - 1u]].vrec;
-                        if (seqLen(b) != la || minimPos(b) != ma || memcmp(seq(b), sa, la) != 0) continue;
+                        const NodeSeq& nb = nsq[topOrder[s.read - 1u]];
+                        if (nb.len != la || nb.minPos != ma || memcmp(nb.seq, sa, la) != 0) continue;
                         if (pushed - 1u - s.push < cap) dup[i] = 1;                                         // its class's non-duplicate is still in the window
                         else { s.read = i + 1u; s.push = pushed++; }                                        // it has left: this read takes its place
                         break;
