@@ -74,6 +74,7 @@ struct EncodeArgs {
     const StreamItem* items; const uint32_t* order; const uint8_t* in; uint8_t* out; uint32_t* outSizes; uint32_t* restarts;
     uint8_t* arenas; uint64_t arenaStride; uint32_t* queueHead; SlotMap* maps;
     uint32_t nItems, longLen, slotsPerXcc;
+    uint32_t budget;      // symbols a workgroup codes in ONE launch before it gives its arena slot back and leaves (0: until the queue is empty)
 };
 typedef const __attribute__((address_space(4))) EncodeArgs* KernArgs;
 __device__ __forceinline__ KernArgs kernargs()
@@ -187,6 +188,7 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
     }
     uint8_t* arena;
     { KernArgs k = kernargs(); arena = k->arenas + (uint64_t)slot * k->arenaStride; }
+    uint32_t coded = 0;                                   // symbols this workgroup has coded in this launch (+ a fixed charge per stream)
     for (;;) {
         KernArgs k = kernargs();
         uint32_t q = 0;
@@ -260,6 +262,16 @@ template <int WAVES, bool RCWIN = false> __device__ __forceinline__ void encode_
             k2->restarts[16u * it + t] = v;
         }
         FS_WAVE_SYNC();
+        // A workgroup's share of one launch is bounded: past it the slot goes back and the workgroup leaves; the streams still in the queue
+        // are the next launch's (run_encode launches again while the queue is not empty), whose workgroups take the slots that are free THEN.
+        // Without this a launch keeps the workgroups that found a slot in its first microseconds -- a launch made while the pool's other
+        // launches held nearly every slot coded its 2 610 streams with a handful of workgroups, 4.7 s instead of 0.25, long after the slots
+        // were free again (round 5, tools/cli_stall_hunt.sh).
+        if (useMaps) {
+            const uint32_t b = kernargs()->budget;
+            coded += n > 4096u ? n : 4096u;
+            if (b != 0u && coded >= b) break;
+        }
     }
     if (TWO) fsppmd::cq_send_exit((FS_LDS fsppmd::Shared*)&sh, qTail);
     if (useMaps && threadIdx.x == 0) {
@@ -775,13 +787,27 @@ __global__ __launch_bounds__(256) void fs_assemble_blocks(const BlockPlan* __res
     }
 }
 
-// Waiting for a lane's stream: a blocking event, not hipStreamSynchronize.  The runtime's default wait spins on a core
-// for the whole device call; with eight lanes that is eight cores taken from the host front end.
+// Waiting for a lane's stream: an event that is POLLED between sleeps, neither hipStreamSynchronize nor a blocking wait.  The runtime's
+// default wait spins on a core for the whole device call (with fourteen lanes that is fourteen cores taken from the host front end), and a
+// hipEventSynchronize on a blocking-sync event has been seen to sleep THROUGH the end of the work it waits for: one fastore_pack e process in ten
+// to twenty, behind processes that had just given 18 GB back, sat 8-25 s in front of an idle stream -- queue drained, no arena slot taken -- until
+// something else woke it (round 4's "one stall that is not explained", round 5's tools/cli_stall_hunt.sh with FS_WATCHDOG).  Sleeps of 20 us
+// doubling to 1 ms: a long kernel costs a lane thread a thousand wake-ups a second, the end of the work is seen within a millisecond.
+static hipError_t wait_event_polled(hipEvent_t ev)
+{
+    long ns = 20000;
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        struct timespec ts = {0, ns}; nanosleep(&ts, nullptr);
+        if (ns < 1000000L) ns *= 2;
+    }
+}
 static hipError_t wait_stream(fsengine::Device* dev, hipStream_t st)
 {
     hipError_t e = hipEventRecord((hipEvent_t)dev->evWait, st);
     if (e != hipSuccess) return e;
-    return hipEventSynchronize((hipEvent_t)dev->evWait);
+    return wait_event_polled((hipEvent_t)dev->evWait);
 }
 
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(dev->err, sizeof dev->err, "%s failed: %s", #x, hipGetErrorString(e_)); return -1; } } while (0)
@@ -1271,6 +1297,7 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         ka.outSizes = (uint32_t*)dev->dSizes; ka.restarts = (uint32_t*)dev->dRestarts; ka.arenas = pool->arenas; ka.arenaStride = stride;
         ka.queueHead = (uint32_t*)dev->queueHead; ka.maps = exclusive ? (SlotMap*)nullptr : pool->maps;
         ka.nItems = nRest; ka.longLen = longLen; ka.slotsPerXcc = pool->slotsPerXcc;
+        { static const uint32_t budget = getenv("FS_WG_BUDGET") ? (uint32_t)atoll(getenv("FS_WG_BUDGET")) : (1u << 20); ka.budget = exclusive ? 0u : budget; }      // (the variable: A/B runs; 0 = no bound)
         // two-wave form where the step is bound by its longest PPMd stream (the coder runs beside the model walk: ~1.4x per
         // stream, but a stream takes two wave slots)
         // (FS_WAVES=1/2 forces a form: the tests run every stream through both.  Round 3's three-wave form -- windows prepared by a
@@ -1325,9 +1352,11 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         // -- or those that did left before the queue was... they never do: they leave when it is empty -- is the queue's head short of
         // its end here.  Then the launch is made again (same queue, same arguments) until every stream has been taken; whoever takes a
         // stream codes it to its end.  The slots are held by this pool's other launches, which drain on their own, so every pass ends.
-        for (uint32_t pass = 0; qHead < nRest; ++pass) {
-            if (pass > 100000u) { snprintf(dev->err, sizeof dev->err, "coder launch: no arena slot in %u passes (queue at %u of %u)", pass, qHead, nRest); return -1; }
-            if (pass) { struct timespec ts = {0, pass < 64u ? 200000L : 2000000L}; nanosleep(&ts, nullptr); }
+        uint32_t idle = 0;                                          // passes in a row that took no stream
+        for (uint32_t pass = 0, headBefore = qHead; qHead < nRest; ++pass) {
+            if (idle > 100000u) { snprintf(dev->err, sizeof dev->err, "coder launch: no arena slot in %u passes (queue at %u of %u)", idle, qHead, nRest); return -1; }
+            if (idle) { struct timespec ts = {0, idle < 64u ? 200000L : 2000000L}; nanosleep(&ts, nullptr); }      // (a pass that took streams is followed at once)
+            headBefore = qHead;
             ++tailLaunches;
             HIP_TRY(launch());
             HIP_TRY(hipEventRecord((hipEvent_t)dev->ev[1], st));
@@ -1335,6 +1364,7 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
             HIP_TRY(hipMemcpyAsync(sizes.data(), dev->dSizes, 4ull * nItems, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(restarts.data(), dev->dRestarts, 64ull * nItems, hipMemcpyDeviceToHost, st));
             HIP_TRY(wait_stream(dev, st));
+            idle = qHead > headBefore ? 0u : idle + 1u;
         }
     }
     if (timing) {

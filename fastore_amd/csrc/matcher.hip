@@ -299,6 +299,18 @@ std::atomic<uint64_t> g_unpackChecked{0}, g_unpackDiffering{0};
 void unpack_check(bool on) { g_unpackCheck = on; if (on) { g_unpackChecked = 0; g_unpackDiffering = 0; } }
 void unpack_check_counts(uint64_t* words, uint64_t* differing) { *words = g_unpackChecked.load(); *differing = g_unpackDiffering.load(); }
 
+// (polled between sleeps, not a blocking wait: engine.hip, wait_stream, says what a blocking wait has been seen to do)
+static hipError_t wait_event_polled(hipEvent_t ev)
+{
+    long ns = 20000;
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        struct timespec ts = {0, ns}; nanosleep(&ts, nullptr);
+        if (ns < 1000000L) ns *= 2;
+    }
+}
+
 static double laneClockMs() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6; }
 
 struct MatchLane {
@@ -542,7 +554,7 @@ int match_reads(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
     HIP_TRY(hipMemcpyAsync(rows, m->dRows, nReads * sizeof(MatchRow), hipMemcpyDeviceToHost, st));
     const double tc4 = timed ? laneClockMs() : 0;
     HIP_TRY(hipEventRecord(m->evWait, st));
-    HIP_TRY(hipEventSynchronize(m->evWait));
+    HIP_TRY(wait_event_polled(m->evWait));
     if (timed) { float a = 0; (void)hipEventElapsedTime(&a, m->ev0, m->ev1);
                  fprintf(stderr, "[trace] matcher lane call %u (%zu reads): checks + buffers %.1f ms, staging copy %.1f ms, uploads + launches enqueued %.1f ms, rows' copy enqueued %.1f ms, waited %.1f ms (kernels %.1f ms)\n",
                          m->calls, nReads, tc1 - tc0, tc2 - tc1, tc3 - tc2, tc4 - tc3, laneClockMs() - tc4, a); }
@@ -580,7 +592,7 @@ int match_mates(Device* dev, MatchLane* m, const uint8_t* seq, size_t seqBytes, 
     HIP_TRY(hipEventRecord(m->ev1, st));
     HIP_TRY(hipMemcpyAsync(rows, m->dMateRows, nPairs * sizeof(MateRow), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(m->evWait, st));
-    HIP_TRY(hipEventSynchronize(m->evWait));
+    HIP_TRY(wait_event_polled(m->evWait));
     if (kernelMs) { float a = 0; (void)hipEventElapsedTime(&a, m->ev0, m->ev1); *kernelMs += a; }
     return 0;
 }
@@ -630,7 +642,7 @@ int match_mates_batch(Device* dev, MatchLane* m, const MateBatchJob* jobs, size_
     std::vector<MateRow> rows(pairTotal);
     HIP_TRY(hipMemcpyAsync(rows.data(), m->dMateRows, pairTotal * sizeof(MateRow), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(m->evWait, st));
-    HIP_TRY(hipEventSynchronize(m->evWait));
+    HIP_TRY(wait_event_polled(m->evWait));
     at = 0;
     for (size_t j = 0; j < nJobs; ++j) { if (jobs[j].nPairs) memcpy(jobs[j].rows, rows.data() + at, jobs[j].nPairs * sizeof(MateRow)); at += jobs[j].nPairs; }
     if (kernelMs) { float a = 0; (void)hipEventElapsedTime(&a, m->ev0, m->ev1); *kernelMs += a; }

@@ -126,7 +126,7 @@ typedef struct fsgpu_stats {
      * of the struct the library filled, so a caller built against an older header reads what it knows and nothing shifted). */
     uint64_t struct_bytes;               /* sizeof(fsgpu_stats) of the library that filled it */
     uint64_t ppmd_window_drops;          /* rescales inside windows that let states drop out of their context (units shrunk at the window's commit; rounds 2-4 ended the window there) */
-    uint64_t coder_tail_launches;        /* coder launches made again because none of a launch's workgroups found a free arena slot (no workgroup waits inside a kernel) */
+    uint64_t coder_tail_launches;        /* coder launches made again for the streams a launch left in its queue: its workgroups found no free arena slot (none waits inside a kernel) or had coded their share of one launch */
 } fsgpu_stats;
 
 void fsgpu_config_defaults(fsgpu_config* cfg);
