@@ -687,7 +687,7 @@ def test_bench_two_ranks_rehearsed_on_one_device_against_the_live_reference(tmp_
 @pytest.mark.timeout(400, method="thread")
 def test_two_cli_processes_share_the_device_with_long_streams_and_both_end(tmp_path, ref_libs):
     # Two `fastore_pack e` processes at once on the one device, DEFAULT environment; FS_TWO_PROC_ROUNDS rounds (8 in the suite, which must end
-    # inside the driver's window -- a round beside another process takes up to 13 s; the twenty-round run is profiles/r05_cli_two_processes.txt).  Rounds 1-4 had a workgroup without an
+    # inside the driver's window -- a round beside another process takes 1.4-5.5 s; the twenty-round runs are profiles/r05_cli_two_processes.txt).  Rounds 1-4 had a workgroup without an
     # arena slot spin inside its kernel for a workgroup of ANOTHER launch to free one; with two processes' hardware queues competing that
     # was a standstill (profiles/r04_cli_two_processes.txt).  No workgroup waits for another any more (engine.hip: a full partition is left
     # at once, the host launches again if nobody took the streams).  Each child has 120 s; a child that hangs is killed and fails the test.
