@@ -1370,7 +1370,7 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
     if (timing) {
         float a = 0;
         (void)hipEventElapsedTime(&a, (hipEvent_t)dev->ev[0], (hipEvent_t)dev->ev[1]);
-        timing->encode_ms += a; timing->launches += 1; timing->items += nItems; timing->h2d_bytes += inputBytes;
+        timing->encode_ms += a; timing->launches += 1 + tailLaunches; timing->items += nItems; timing->h2d_bytes += inputBytes;      // (every pass is a kernel of its own in a profiler's table: the launches counted here are what its average is over)
         if (ids) timing->id_strings += ids->n_strings;
         if (gather && gather->n_strings) {
             float g = 0; (void)hipEventElapsedTime(&g, (hipEvent_t)dev->ev[4], (hipEvent_t)dev->ev[5]);
