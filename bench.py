@@ -458,7 +458,7 @@ def main():
             for key, lname, lreads, lpaired, lgenome, lq in legs:
                 if key not in errs:
                     try:
-                        clis[key] = cli_phase(fastore_amd, args, args.work, lname, lreads, lpaired, lgenome, cores, 3 if key == "main" else 2, quality=lq)
+                        clis[key] = cli_phase(fastore_amd, args, args.work, lname, lreads, lpaired, lgenome, cores, 3, quality=lq)      # (three runs a leg: one process in ten waits 1-3 s in its arena allocation while the driver takes back what the process before it held -- the median holds)
                     except Exception as e:      # noqa: BLE001
                         say("leg %s: the process could not be timed: %s" % (lname, e))
         # Every leg is measured by a process of its own, one after the other; this process never opens the device.  (Two reasons: a leg that

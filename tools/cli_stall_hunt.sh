@@ -6,7 +6,7 @@ tag=$1; runs=${2:-20}; wd=${3:-8}
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 W=${FASTORE_BENCH_DIR:-/tmp/fastore_bench}
-lib=$W/se10000k.b8
+lib=$W/${FS_HUNT_LIB:-se10000k}.b8
 out=gpurun_out/${tag}_stall_hunt.txt
 : > $out
 for r in $(seq 1 $runs); do
