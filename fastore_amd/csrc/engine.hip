@@ -1297,7 +1297,7 @@ static int run_encode(Device* dev, const uint8_t* input, size_t inputBytes, std:
         ka.outSizes = (uint32_t*)dev->dSizes; ka.restarts = (uint32_t*)dev->dRestarts; ka.arenas = pool->arenas; ka.arenaStride = stride;
         ka.queueHead = (uint32_t*)dev->queueHead; ka.maps = exclusive ? (SlotMap*)nullptr : pool->maps;
         ka.nItems = nRest; ka.longLen = longLen; ka.slotsPerXcc = pool->slotsPerXcc;
-        { static const uint32_t budget = getenv("FS_WG_BUDGET") ? (uint32_t)atoll(getenv("FS_WG_BUDGET")) : (1u << 20); ka.budget = exclusive ? 0u : budget; }      // (the variable: A/B runs; 0 = no bound)
+        { const char* wb = getenv("FS_WG_BUDGET"); ka.budget = exclusive ? 0u : (wb ? (uint32_t)atoll(wb) : (1u << 20)); }      // (the variable, read per launch: A/B runs and the tests; 0 = no bound)
         // two-wave form where the step is bound by its longest PPMd stream (the coder runs beside the model walk: ~1.4x per
         // stream, but a stream takes two wave slots)
         // (FS_WAVES=1/2 forces a form: the tests run every stream through both.  Round 3's three-wave form -- windows prepared by a

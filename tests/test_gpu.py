@@ -257,7 +257,7 @@ def test_gpu_pack_equals_live_reference_on_fresh_library(tmp_path, paired, q, re
             assert records(outs[1]) == records(os.path.join(t, "lib_2.fastq"))
 
 
-def test_gpu_pack_is_deterministic_and_sizes_add_up(tmp_path):
+def test_gpu_pack_is_deterministic_and_sizes_add_up(tmp_path, monkeypatch):
     import fastore_amd
     name, paired, flags = manifest()[1]
     outs = []
@@ -270,6 +270,15 @@ def test_gpu_pack_is_deterministic_and_sizes_add_up(tmp_path):
             st = p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / ("o%d" % i)))
             tails.append(p.stats()["coder_tail_launches"])
         outs.append(open(str(tmp_path / ("o%d.cdata" % i)), "rb").read())
+    # ... and a workgroup's share of one launch cut to a stream or two (FS_WG_BUDGET): every launch is made again and again for what its
+    # workgroups left in the queue -- the same bytes
+    monkeypatch.setenv("FS_WG_BUDGET", "6000")
+    with fastore_amd.Packer(device_id=0, max_waves=37, pipeline_slices=1, **knobs_from_flags(flags)) as p:      # (37 workgroups for all the streams: alone they need no second launch)
+        p.pack_file(os.path.join(GOLDEN, name + ".in"), str(tmp_path / "ob"))
+        tails.append(p.stats()["coder_tail_launches"])
+    monkeypatch.delenv("FS_WG_BUDGET")
+    outs.append(open(str(tmp_path / "ob.cdata"), "rb").read())
+    assert tails[-1] > 0, tails
     print("coder tail launches per configuration:", tails)
     assert all(o == outs[0] for o in outs[1:])
     assert outs[0] == open(os.path.join(GOLDEN, name + ".ref.cdata"), "rb").read()
