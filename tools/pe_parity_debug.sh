@@ -27,7 +27,8 @@ def diff(ours):
                 k = next((i for i in range(min(len(a), len(b))) if a[i] != b[i]), min(len(a), len(b)))
                 bad.append((g, s, rs, k))
     return bad
-for env in ({}, {"FS_SEARCH_SURPLUS": "0"}, {"FS_DEVICE_MATCHER": "0"}, {"FS_DEVICE_EMIT": "0"}, {"FS_SPLIT_PIPELINES": "0"}, {"FS_WG_BUDGET": "0"}):
+variants = ({}, {"FS_SEARCH_SURPLUS": "0"}, {"FS_DEVICE_MATCHER": "0"}, {"FS_DEVICE_EMIT": "0"}, {"FS_SPLIT_PIPELINES": "0"}, {"FS_WG_BUDGET": "0"})
+for env in variants[:int(os.environ.get("PARITY_VARIANTS", "6"))]:
     for k in ("FS_SEARCH_SURPLUS", "FS_DEVICE_MATCHER", "FS_DEVICE_EMIT", "FS_SPLIT_PIPELINES", "FS_WG_BUDGET"): os.environ.pop(k, None)
     os.environ.update(env)
     o = os.path.join(W, "dbg_out")
