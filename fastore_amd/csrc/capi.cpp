@@ -36,6 +36,10 @@ void fsgpu_config_defaults(fsgpu_config* cfg)
 int fsgpu_device_count(void) { return fsengine::device_count(); }
 const char* fsgpu_create_error(void) { return g_createError.c_str(); }
 
+// packSplit -> fsgpu_create: the device whose arena pool the context being made shares (one pool a device for the pipelines of a split pack: three
+// pools were 53 GB that the next process's allocations waited for the driver to take back -- 2.9 s of a 25 M-pair pack behind another)
+static thread_local fsengine::Device* t_poolDonor = nullptr;
+
 static unsigned usableCores()
 {
     unsigned n = std::max(1u, std::thread::hardware_concurrency());
@@ -89,9 +93,11 @@ fsgpu_ctx* fsgpu_create(const fsgpu_config* cfg)
     // loudly: "no HIP device available ..." becomes the pack call's error).
     fs::Context* cp = &c;
     const int deviceId = cfg->device_id; const uint32_t maxWaves = c.cfg.max_waves;
-    auto make = [cp, deviceId, maxWaves]() -> std::string {
+    fsengine::Device* const donor = t_poolDonor;      // (a helper pipeline of a split pack: its lanes are made on the parent's arena pool)
+    auto make = [cp, deviceId, maxWaves, donor]() -> std::string {
         if (fsengine::device_count() <= 0) return "no HIP device available: the fastore_pack hot path has no CPU fallback";
         char err[256] = {0};
+        if (donor) { if (fsengine::lane_create(donor, &cp->dev, err, sizeof err) != 0) return err[0] ? std::string(err) : std::string("lane creation failed"); return std::string(); }
         if (fsengine::device_create(&cp->dev, deviceId, maxWaves, err, sizeof err) != 0) return err[0] ? std::string(err) : std::string("device creation failed");
         return std::string();
     };
@@ -586,7 +592,11 @@ static bool packSplit(fsgpu_ctx* ctx, const std::string& in, const std::string& 
         // (a context that packs once has helpers that pack once: they too give their batch's host memory back while the device walks the
         // long streams -- 52 GB resident at the end of a 25 M-pair pack was 1.4 s of teardown, one munmap at a time whatever the threads)
         hc.world_size = 1; hc.rank = 0; hc.host_threads = 1;      // (set for each pack below)
+        fsengine::Device* parentDev = nullptr;
+        if (!(getenv("FS_SPLIT_POOLS") && atoi(getenv("FS_SPLIT_POOLS")) != 0)) { try { parentDev = a.device(); } catch (...) { parentDev = nullptr; } }      // (FS_SPLIT_POOLS=1: a pool of its own per pipeline, A/B runs)
+        t_poolDonor = parentDev;
         fsgpu_ctx* h = fsgpu_create(&hc);
+        t_poolDonor = nullptr;
         if (!h) {
             if (verbose > 1 || getenv("FS_TRACE")) fprintf(stderr, "[split] pipeline %zu could not be made (%s): one pipeline\n", ctx->helpers.size() + 2, fsgpu_create_error());
             return false;
